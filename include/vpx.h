@@ -1,0 +1,126 @@
+/*
+ * vpx.h — C ABI of libvpx_hip.so: the MI355X (gfx950) implementation of vp-suite's spatiotemporal recurrent hot path.
+ *
+ * The reference (AIS-Bonn/vp-suite) has NO native/FFI layer: its hot path is a sequence of ATen calls issued from
+ * Python. Each entry point below therefore replaces one Python-level callable of the reference; the
+ * binding a maintainer adds is a ctypes stub. All pointers are DEVICE pointers (hipMalloc'd / torch
+ * CUDA tensors), fp32 unless stated. The library never allocates, never synchronises and enqueues everything on the
+ * `stream` argument (a hipStream_t passed as void*; NULL = default stream). The caller owns every buffer including
+ * workspace and reserve. Return value: 0 = OK, negative = error (message via vpx_last_error(), thread-local).
+ *
+ * Entry point                      replaces (reference file:line)
+ * -------------------------------  -----------------------------------------------------------------------------
+ * vpx_convlstm_seq_fwd / _bwd      model_blocks.ConvLSTM.forward            vp_suite/model_blocks/conv_lstm_hzzone.py:38-70
+ *                                  ConvLSTMCell.forward (T=1, IFOG)         vp_suite/model_blocks/conv_lstm_ndrplz.py:28-43
+ *                                  ConvLSTM(ndrplz) per-layer time loop     vp_suite/model_blocks/conv_lstm_ndrplz.py:112-121
+ * vpx_stlstm_step_fwd / _bwd       SpatioTemporalLSTMCell.forward           vp_suite/model_blocks/predrnn.py:57-83
+ * vpx_decouple_fwd / _bwd          adapter + normalize + |cos| + mean       vp_suite/models/predrnn_v2.py:197-198,209-211
+ * vpx_conv2d_nhwc_fwd              F.conv2d 1x1 / kxk "same", stride 1      vp_suite/models/predrnn_v2.py:223 (conv_last)
+ * vpx_nchw_to_nhwc / nhwc_to_nchw  (layout adaptors at the boundary; the reference is NCHW throughout)
+ *
+ * Layouts. VPX_LAYOUT_NHWC ("channels last", the library's native layout):
+ *      x [B,T,H,W,Cin]   h/c states [B,H,W,Ch]   out [B,T,H,W,Ch]   peepholes [H,W,Ch]
+ *    VPX_LAYOUT_NCHW (the reference's layout; the library transposes through the workspace):
+ *      x [B,T,Cin,H,W]   h/c states [B,Ch,H,W]   out [B,T,Ch,H,W]   peepholes [1,Ch,H,W]
+ *    Convolution weights / biases and their gradients are ALWAYS in the reference's parameter layout
+ *    (OIHW, e.g. _conv.weight [4Ch, Cin+Ch, kh, kw]) so reference checkpoints are used unchanged.
+ */
+#ifndef VPX_H_
+#define VPX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VPX_VERSION 100
+
+enum { VPX_OK = 0, VPX_ERR_ARG = -1, VPX_ERR_WORKSPACE = -2, VPX_ERR_LAUNCH = -3, VPX_ERR_UNSUPPORTED = -4 };
+
+enum { VPX_GATE_IFGO = 0 /* chunk order (i,f,g,o): conv_lstm_hzzone.py:62 */,
+       VPX_GATE_IFOG = 1 /* split order (i,f,o,g): conv_lstm_ndrplz.py:34 */ };
+enum { VPX_LAYOUT_NHWC = 0, VPX_LAYOUT_NCHW = 1 };
+enum { VPX_PREC_F32 = 0    /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 operands + fp32 accumulate */,
+       VPX_PREC_BF16X3 = 1 /* split bf16 (hi/lo) operands, 3 bf16 MFMAs per product, fp32 accumulate (~fp32 accuracy) */,
+       VPX_PREC_BF16 = 2   /* bf16 operands, fp32 accumulate, fp32 state and I/O */ };
+enum { VPX_FLAG_SAVE_FOR_BWD = 1 /* forward fills `reserve` (gate activations + cell states per step) */ };
+
+typedef struct vpx_convlstm_desc {
+    int32_t B, T, Cin, Ch, H, W, kh, kw; /* padding is kh/2, kw/2 ("same"), stride 1 — the only form the cells use */
+    int32_t gate_order;                   /* VPX_GATE_* */
+    int32_t layout;                       /* VPX_LAYOUT_* */
+    int32_t precision;                    /* VPX_PREC_* */
+    int32_t flags;                        /* VPX_FLAG_* */
+} vpx_convlstm_desc;
+
+typedef struct vpx_stlstm_desc {
+    int32_t B, Cin, Ch, H, W, k; /* filter_size k (odd), stride 1, padding k/2: predrnn.py:22 */
+    int32_t layer_norm;          /* 0/1: LayerNorm([C,H,W]) after conv_x/h/m/o (predrnn.py:24-40) */
+    int32_t layout, precision, flags;
+} vpx_stlstm_desc;
+
+int vpx_version(void);
+const char* vpx_last_error(void);
+
+/* ---- ConvLSTM over a sequence ------------------------------------------------------------------------------ */
+size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d); /* scratch, contents undefined between calls */
+size_t vpx_convlstm_reserve_bytes(const vpx_convlstm_desc* d);   /* saved-for-backward, 0 without SAVE_FOR_BWD */
+
+/* x may be NULL (all-zero input: conv_lstm_hzzone.py:54-56), h0/c0 may be NULL (zero state: :40-45), bias may be NULL,
+ * Wci/Wcf/Wco may be NULL together (no peephole = the ndrplz cell). hT/cT may be NULL. */
+int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float* h0, const float* c0,
+                         const float* W, const float* bias, const float* Wci, const float* Wcf, const float* Wco,
+                         float* out, float* hT, float* cT, void* reserve, size_t reserve_bytes, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* BPTT. `out`/`reserve` are the forward's. dout/dhT/dcT may be NULL (zero). Every gradient output may be NULL
+ * (skipped). dW/db/dWc* are OVERWRITTEN (not accumulated). */
+int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, const float* h0, const float* c0,
+                         const float* W, const float* Wci, const float* Wcf, const float* Wco, const float* out,
+                         const void* reserve, size_t reserve_bytes, const float* dout, const float* dhT,
+                         const float* dcT, float* dx, float* dh0, float* dc0, float* dW, float* db, float* dWci,
+                         float* dWcf, float* dWco, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- ST-LSTM cell step (PredRNN-V2) -------------------------------------------------------------------------- */
+size_t vpx_stlstm_workspace_bytes(const vpx_stlstm_desc* d);
+size_t vpx_stlstm_reserve_bytes(const vpx_stlstm_desc* d);
+
+/* Weights in reference layout: Wx [7Ch,Cin,k,k] Wh [4Ch,Ch,k,k] Wm [3Ch,Ch,k,k] Wo [Ch,2Ch,k,k] Wlast [Ch,2Ch,1,1].
+ * ln: NULL or 8 pointers {x_gamma,x_beta,h_gamma,h_beta,m_gamma,m_beta,o_gamma,o_beta}, each in reference [C,H,W]. */
+int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c, const float* m,
+                        const float* Wx, const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
+                        const float* const* ln, float* h_new, float* c_new, float* m_new, float* delta_c,
+                        float* delta_m, void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c, const float* m,
+                        const float* Wx, const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
+                        const void* reserve, size_t reserve_bytes, const float* dh_new, const float* dc_new,
+                        const float* dm_new, const float* ddelta_c, const float* ddelta_m, float* dx, float* dh,
+                        float* dc, float* dm, float* dWx, float* dWh, float* dWm, float* dWo, float* dWlast,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- decoupling-loss term: mean_{b,ch} |cos(normalize(A*dc), normalize(A*dm))| over H*W ---------------------- */
+/* delta_c/delta_m [B,H,W,Ch] (NHWC) ; adapter [Ch,Ch] ; value: 1 float on device ; workspace >= 2*B*H*W*Ch*4 + 4*B*Ch*4 */
+size_t vpx_decouple_workspace_bytes(int B, int Ch, int H, int W);
+int vpx_decouple_fwd(const float* delta_c, const float* delta_m, const float* adapter, float* value, int B, int Ch,
+                     int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* adapter, const float* dvalue,
+                     float* d_delta_c, float* d_delta_m, float* d_adapter, int B, int Ch, int H, int W,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- plain stride-1 "same" convolution, NHWC, optional bias; y [N,H,W,Co] = conv(x [N,H,W,Ci], w [Co,Ci,kh,kw]) --- */
+size_t vpx_conv2d_workspace_bytes(int Ci, int Co, int kh, int kw);
+int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Ci,
+                        int Co, int kh, int kw, int precision, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- layout adaptors: src [N,C,H,W] <-> dst [N,H,W,C] -------------------------------------------------------- */
+int vpx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, void* stream);
+int vpx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VPX_H_ */

@@ -1,0 +1,126 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu): the HIP ConvLSTM path, called through the C ABI
+(include/vpx.h), against the reference-generated golden vectors and against the pinned oracle on seeded inputs.
+
+Tolerance: north_star demands 1e-4 relative (fp32); the reference's own tests use atol=1e-4 (_convlstm_hzzone.py:91).
+The exact-fp32 MFMA path is held to 1e-5 of the tensor's max magnitude."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from golden_util import load_golden, name_seed, seeded_rand, seeded_randn
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def _relmax(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("tag", list(gc.HZZONE_CASES))
+@pytest.mark.parametrize("mode", ["full", "states", "noinput"])
+def test_hzzone_block_vs_golden(vpx, dev, tag, mode):
+    Cin, Ch, H, W, k, B, T, _ = gc.HZZONE_CASES[tag]
+    inp = {n: v.to(dev) for n, v in gc.hzzone_inputs(tag, Cin, Ch, H, W, k, B, T).items()}
+    g = load_golden(f"hzzone_{tag}_{mode}")
+    x = None if mode == "noinput" else inp["x"]
+    h0 = None if mode == "full" else inp["h0"]
+    c0 = None if mode == "full" else inp["c0"]
+    out, hT, cT = vpx.ops.convlstm_seq(x, h0, c0, inp["W"], inp["b"], inp["Wci"], inp["Wcf"], inp["Wco"], seq_len=T,
+                                       in_channels=Cin)
+    assert out.shape == (B, T, Ch, H, W)
+    assert _relmax(out, g["out"]) < RTOL and _relmax(hT, g["hT"]) < RTOL and _relmax(cT, g["cT"]) < RTOL
+
+
+@pytest.mark.parametrize("tag", list(gc.NDRPLZ_CELL_CASES))
+def test_ndrplz_cell_vs_golden(vpx, dev, tag):
+    Cin, Ch, H, W, kh, kw, bias, B = gc.NDRPLZ_CELL_CASES[tag]
+    inp = {n: v.to(dev) for n, v in gc.ndrplz_cell_inputs(tag, Cin, Ch, H, W, kh, kw, bias, B).items()}
+    g = load_golden(f"ndrplz_cell_{tag}")
+    out, hT, cT = vpx.ops.convlstm_seq(inp["x"][:, None], inp["h"], inp["c"], inp["W"], inp["b"] if bias else None,
+                                       seq_len=1, in_channels=Cin, gate_order=vpx._lib.GATE_IFOG)
+    assert _relmax(hT, g["h_next"]) < RTOL and _relmax(cT, g["c_next"]) < RTOL
+    assert _relmax(out[:, 0], g["h_next"]) < RTOL
+
+
+def test_c_abi_nchw_layout(vpx, dev):
+    """Calls the C ABI directly on reference-layout (NCHW) buffers: the drop-in form of the boundary."""
+    L = vpx._lib.lib()
+    Cin, Ch, H, W, k, B, T, _ = gc.HZZONE_CASES["tiny"]
+    inp = {n: v.to(dev).contiguous() for n, v in gc.hzzone_inputs("tiny", Cin, Ch, H, W, k, B, T).items()}
+    g = load_golden("hzzone_tiny_states")
+    d = vpx._lib.ConvLSTMDesc(B, T, Cin, Ch, H, W, k, k, vpx._lib.GATE_IFGO, vpx._lib.LAYOUT_NCHW, vpx._lib.PREC_F32, 0)
+    ws_bytes = L.vpx_convlstm_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    out = torch.empty(B, T, Ch, H, W, device=dev)
+    hT = torch.empty(B, Ch, H, W, device=dev)
+    cT = torch.empty(B, Ch, H, W, device=dev)
+    p = vpx._lib.ptr
+    rc = L.vpx_convlstm_seq_fwd(ctypes.byref(d), p(inp["x"]), p(inp["h0"]), p(inp["c0"]), p(inp["W"]), p(inp["b"]),
+                                p(inp["Wci"]), p(inp["Wcf"]), p(inp["Wco"]), p(out), p(hT), p(cT), None, 0, p(ws),
+                                ws_bytes, None)
+    assert rc == 0, L.vpx_last_error()
+    torch.cuda.synchronize()
+    assert _relmax(out, g["out"]) < RTOL and _relmax(hT, g["hT"]) < RTOL and _relmax(cT, g["cT"]) < RTOL
+
+
+def test_c_abi_error_paths(vpx, dev):
+    L = vpx._lib.lib()
+    d = vpx._lib.ConvLSTMDesc(1, 1, 4, 4, 8, 8, 4, 4, 0, 0, 0, 0)  # even kernel size
+    assert L.vpx_convlstm_workspace_bytes(ctypes.byref(d)) == 0
+    d = vpx._lib.ConvLSTMDesc(1, 1, 4, 4, 8, 8, 3, 3, 0, 0, 0, 0)
+    rc = L.vpx_convlstm_seq_fwd(ctypes.byref(d), *([None] * 11), None, 0, None, 0, None)
+    assert rc == -1 and b"NULL" in L.vpx_last_error()
+    with pytest.raises(ValueError):
+        vpx.ops.convlstm_seq(None, None, None, torch.zeros(16, 8, 3, 3, device=dev), None, seq_len=1, in_channels=4)
+
+
+# the six ConvLSTM block shapes of convlstm-shi at 64x64 (ef_conv_lstm.py:31-33) + the "64x64x64ch" headline cell
+REAL_SHAPES = [(16, 64, 64, 64), (64, 96, 32, 32), (96, 96, 16, 16), (96, 96, 32, 32), (96, 64, 64, 64),
+               (64, 64, 64, 64)]
+
+
+@pytest.mark.parametrize("Cin,Ch,H,W", REAL_SHAPES)
+def test_real_block_shapes_vs_oracle(vpx, dev, Cin, Ch, H, W):
+    from oracle import torch_ref as tr
+    B, T, k = 2, 3, 3
+    tag = f"real.{Cin}.{Ch}.{H}"
+    Wt = seeded_randn((4 * Ch, Cin + Ch, k, k), name_seed(tag + "W"), 1.0 / np.sqrt((Cin + Ch) * 9))
+    b = seeded_randn((4 * Ch,), name_seed(tag + "b"), 0.1)
+    pw = [seeded_randn((1, Ch, H, W), name_seed(tag + n), 0.1) for n in ("ci", "cf", "co")]
+    x = seeded_rand((B, T, Cin, H, W), name_seed(tag + "x"))
+    h0 = seeded_randn((B, Ch, H, W), name_seed(tag + "h0"), 0.5)
+    c0 = seeded_randn((B, Ch, H, W), name_seed(tag + "c0"), 0.5)
+    with torch.no_grad():
+        ro, (rh, rc) = tr.convlstm_hzzone_seq(x, (h0, c0), T, Wt, b, *pw, padding=1)
+    out, hT, cT = vpx.ops.convlstm_seq(x.to(dev), h0.to(dev), c0.to(dev), Wt.to(dev), b.to(dev),
+                                       *[p.to(dev) for p in pw], seq_len=T, in_channels=Cin)
+    assert _relmax(out, ro) < RTOL and _relmax(cT, rc) < RTOL and _relmax(hT, rh) < RTOL
+    # zero-input form used by forecaster.rnn3 (ef_blocks.py:109-110)
+    with torch.no_grad():
+        ro2, _ = tr.convlstm_hzzone_seq(None, (h0, c0), T, Wt, b, *pw, padding=1)
+    out2, _, _ = vpx.ops.convlstm_seq(None, h0.to(dev), c0.to(dev), Wt.to(dev), b.to(dev), *[p.to(dev) for p in pw],
+                                      seq_len=T, in_channels=Cin)
+    assert _relmax(out2, ro2) < RTOL
+
+
+def test_conv2d_same_vs_torch(vpx, dev):
+    for (Ci, Co, k, H, W) in [(128, 16, 1, 16, 16), (24, 40, 3, 9, 21), (7, 130, 5, 12, 10)]:
+        x = seeded_randn((3, Ci, H, W), name_seed(f"c2d.x{Ci}{k}"))
+        w = seeded_randn((Co, Ci, k, k), name_seed(f"c2d.w{Ci}{k}"), 1.0 / np.sqrt(Ci * k * k))
+        b = seeded_randn((Co,), name_seed(f"c2d.b{Ci}{k}"), 0.1)
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=k // 2).float()
+        y = vpx.ops.conv2d_same(x.to(dev), w.to(dev), b.to(dev))
+        assert _relmax(y, ref) < RTOL

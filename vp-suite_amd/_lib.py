@@ -1,0 +1,112 @@
+"""ctypes binding of libvpx_hip.so (C ABI: include/vpx.h). No torch types cross the boundary: only raw device
+pointers (tensor.data_ptr()), sizes and the current HIP stream handle.
+
+There is NO CPU fallback: if the shared library is missing or fails to load, every op raises."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvpx_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+GATE_IFGO, GATE_IFOG = 0, 1
+LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+FLAG_SAVE_FOR_BWD = 1
+
+EXPORTED_SYMBOLS = [
+    "vpx_version", "vpx_last_error",
+    "vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes", "vpx_convlstm_seq_fwd", "vpx_convlstm_seq_bwd",
+    "vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes", "vpx_stlstm_step_fwd", "vpx_stlstm_step_bwd",
+    "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
+    "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
+]
+
+
+class ConvLSTMDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "T", "Cin", "Ch", "H", "W", "kh", "kw", "gate_order", "layout",
+                                              "precision", "flags")]
+
+
+class STLSTMDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "Cin", "Ch", "H", "W", "k", "layer_norm", "layout", "precision",
+                                              "flags")]
+
+
+class VpxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force: bool = False, jobs: int = 4) -> str:
+    """Compiles every HIP source under csrc/ for gfx950 into vp-suite_amd/libvpx_hip.so (hipcc cross-compiles
+    without a GPU). No-op when the library is newer than all sources."""
+    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "vpx.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", CSRC_DIR, "-s", f"-j{jobs}"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VpxError(f"HIP extension not built: {LIB_PATH} is missing (run `python -c 'import __graft_entry__ as g; "
+                           f"g.build()'` or `make -C {CSRC_DIR}`). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp = ctypes.c_void_p
+        sz = ctypes.c_size_t
+        L.vpx_version.restype = ctypes.c_int
+        L.vpx_last_error.restype = ctypes.c_char_p
+        for name in ("vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes"):
+            getattr(L, name).restype = sz
+            getattr(L, name).argtypes = [ctypes.POINTER(ConvLSTMDesc)]
+        for name in ("vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes"):
+            getattr(L, name).restype = sz
+            getattr(L, name).argtypes = [ctypes.POINTER(STLSTMDesc)]
+        L.vpx_convlstm_seq_fwd.restype = ctypes.c_int
+        L.vpx_convlstm_seq_fwd.argtypes = [ctypes.POINTER(ConvLSTMDesc)] + [vp] * 11 + [vp, sz, vp, sz, vp]
+        L.vpx_convlstm_seq_bwd.restype = ctypes.c_int
+        L.vpx_convlstm_seq_bwd.argtypes = [ctypes.POINTER(ConvLSTMDesc)] + [vp] * 8 + [vp, sz] + [vp] * 11 + [vp, sz, vp]
+        L.vpx_stlstm_step_fwd.restype = ctypes.c_int
+        L.vpx_stlstm_step_fwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 9 + [vp] + [vp] * 5 + [vp, sz, vp, sz, vp]
+        L.vpx_stlstm_step_bwd.restype = ctypes.c_int
+        L.vpx_stlstm_step_bwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 9 + [vp, sz] + [vp] * 5 + [vp] * 9 + [vp, sz, vp]
+        L.vpx_decouple_workspace_bytes.restype = sz
+        L.vpx_decouple_workspace_bytes.argtypes = [ctypes.c_int] * 4
+        L.vpx_decouple_fwd.restype = ctypes.c_int
+        L.vpx_decouple_fwd.argtypes = [vp] * 4 + [ctypes.c_int] * 4 + [vp, sz, vp]
+        L.vpx_decouple_bwd.restype = ctypes.c_int
+        L.vpx_decouple_bwd.argtypes = [vp] * 7 + [ctypes.c_int] * 4 + [vp, sz, vp]
+        L.vpx_conv2d_workspace_bytes.restype = sz
+        L.vpx_conv2d_workspace_bytes.argtypes = [ctypes.c_int] * 4
+        L.vpx_conv2d_nhwc_fwd.restype = ctypes.c_int
+        L.vpx_conv2d_nhwc_fwd.argtypes = [vp] * 4 + [ctypes.c_int] * 8 + [vp, sz, vp]
+        for name in ("vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw"):
+            getattr(L, name).restype = ctypes.c_int
+            getattr(L, name).argtypes = [vp, vp] + [ctypes.c_int] * 4 + [vp]
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    """Maps library error codes to the exception types the reference raises for the same misuse
+    (ValueError for shape/argument problems, e.g. predrnn_v2.py:136-137; NotImplementedError conv_lstm_ndrplz.py:100)."""
+    if rc == 0:
+        return
+    msg = lib().vpx_last_error().decode(errors="replace")
+    if rc == -1:
+        raise ValueError(f"{what}: {msg}")
+    if rc == -4:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise VpxError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor or None."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,319 @@
+// vpx_api.hip — the extern "C" boundary of libvpx_hip.so (declared in include/vpx.h).
+// Host-side orchestration only: plan building, workspace carving, per-timestep launches on the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "vpx_internal.h"
+
+namespace vpx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Carver {  // bump allocator over the caller's workspace
+    char* base;
+    size_t off, cap;
+    float* take(size_t nfloat) {
+        float* p = reinterpret_cast<float*>(base + off);
+        off += align256(nfloat * sizeof(float));
+        return p;
+    }
+};
+
+#define VPX_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return VPX_ERR_LAUNCH;                                                            \
+        }                                                                                     \
+    } while (0)
+
+static void gate_positions(int gate_order, int gp[4]) {
+    gp[0] = 0;
+    gp[1] = 1;
+    if (gate_order == VPX_GATE_IFGO) { gp[2] = 2; gp[3] = 3; }  // logical g at chunk 2, o at chunk 3
+    else { gp[2] = 3; gp[3] = 2; }                             // ndrplz: o at chunk 2, g at chunk 3
+}
+
+static int check_convlstm_desc(const vpx_convlstm_desc* d) {
+    if (!d) { set_error("desc is NULL"); return VPX_ERR_ARG; }
+    if (d->B < 1 || d->T < 1 || d->Cin < 1 || d->Ch < 1 || d->H < 1 || d->W < 1) {
+        set_error("convlstm desc: non-positive dimension (B=%d T=%d Cin=%d Ch=%d H=%d W=%d)", d->B, d->T, d->Cin,
+                  d->Ch, d->H, d->W);
+        return VPX_ERR_ARG;
+    }
+    if (d->kh < 1 || d->kw < 1 || !(d->kh & 1) || !(d->kw & 1) || d->kh > 7 || d->kw > 7) {
+        set_error("convlstm desc: kernel size must be odd and <= 7 (got %dx%d)", d->kh, d->kw);
+        return VPX_ERR_ARG;
+    }
+    if (d->gate_order != VPX_GATE_IFGO && d->gate_order != VPX_GATE_IFOG) {
+        set_error("convlstm desc: unknown gate_order %d", d->gate_order);
+        return VPX_ERR_ARG;
+    }
+    if (d->layout != VPX_LAYOUT_NHWC && d->layout != VPX_LAYOUT_NCHW) {
+        set_error("convlstm desc: unknown layout %d", d->layout);
+        return VPX_ERR_ARG;
+    }
+    if (d->precision != VPX_PREC_F32) {
+        set_error("convlstm desc: precision %d not implemented yet (only VPX_PREC_F32)", d->precision);
+        return VPX_ERR_UNSUPPORTED;
+    }
+    return VPX_OK;
+}
+
+struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
+    int taps, n_tiles, nstage, chunks_total;
+    ConvStage stage[MAX_STAGE];
+    size_t n_state, n_x, n_out, n_peep;
+};
+
+static int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L) {
+    L.taps = d->kh * d->kw;
+    L.n_tiles = (d->Ch + 31) / 32;
+    const int segC[2] = {d->Cin, d->Ch};
+    L.nstage = build_stages(L.stage, &L.chunks_total, segC, 2, L.taps, CS_F32, KC_F32);
+    if (L.nstage < 0) { set_error("convlstm: too many channel stages (Cin=%d Ch=%d)", d->Cin, d->Ch); return VPX_ERR_UNSUPPORTED; }
+    L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
+    L.n_x = (size_t)d->B * d->T * d->H * d->W * d->Cin;
+    L.n_out = (size_t)d->B * d->T * d->H * d->W * d->Ch;
+    L.n_peep = (size_t)d->H * d->W * d->Ch;
+    return VPX_OK;
+}
+
+}  // namespace vpx
+
+using namespace vpx;
+
+extern "C" {
+
+int vpx_version(void) { return VPX_VERSION; }
+const char* vpx_last_error(void) { return g_err; }
+
+int vpx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, void* stream) {
+    if (!src || !dst || N < 1 || C < 1 || H < 1 || W < 1) { set_error("vpx_nchw_to_nhwc: bad argument"); return VPX_ERR_ARG; }
+    VPX_CHECK_HIP(launch_nchw_to_nhwc(src, dst, N, C, H, W, (hipStream_t)stream));
+    return VPX_OK;
+}
+int vpx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, void* stream) {
+    if (!src || !dst || N < 1 || C < 1 || H < 1 || W < 1) { set_error("vpx_nhwc_to_nchw: bad argument"); return VPX_ERR_ARG; }
+    VPX_CHECK_HIP(launch_nhwc_to_nchw(src, dst, N, C, H, W, (hipStream_t)stream));
+    return VPX_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------------------- */
+size_t vpx_convlstm_reserve_bytes(const vpx_convlstm_desc* d) {
+    ConvLSTMLayout L;
+    if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
+    if (!(d->flags & VPX_FLAG_SAVE_FOR_BWD)) return 0;
+    // gates [T][B,H,W,4Ch] + cell states [T][B,H,W,Ch]
+    return align256((size_t)d->T * L.n_state * 4 * sizeof(float)) + align256((size_t)d->T * L.n_state * sizeof(float));
+}
+
+size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
+    ConvLSTMLayout L;
+    if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
+    // forward: packed weights + cell scratch. backward needs more (see convlstm_bwd.hip); report the max of both.
+    size_t fwd = align256(packed_weight_bytes(L.n_tiles, L.chunks_total)) + align256(L.n_state * sizeof(float));
+    if (d->layout == VPX_LAYOUT_NCHW)
+        fwd += align256(L.n_x * 4) + align256(L.n_out * 4) + 4 * align256(L.n_state * 4) + 3 * align256(L.n_peep * 4);
+    return fwd + 256;
+}
+
+int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float* h0, const float* c0,
+                         const float* W, const float* bias, const float* Wci, const float* Wcf, const float* Wco,
+                         float* out, float* hT, float* cT, void* reserve, size_t reserve_bytes, void* workspace,
+                         size_t workspace_bytes, void* stream_) {
+    int rc = check_convlstm_desc(d);
+    if (rc != VPX_OK) return rc;
+    ConvLSTMLayout L;
+    if ((rc = convlstm_layout(d, L)) != VPX_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!W || !out) { set_error("vpx_convlstm_seq_fwd: W and out must not be NULL"); return VPX_ERR_ARG; }
+    const bool peep = Wci || Wcf || Wco;
+    if (peep && !(Wci && Wcf && Wco)) { set_error("vpx_convlstm_seq_fwd: peephole tensors must be given together"); return VPX_ERR_ARG; }
+    const bool save = (d->flags & VPX_FLAG_SAVE_FOR_BWD) != 0;
+    if (save && (!reserve || reserve_bytes < vpx_convlstm_reserve_bytes(d))) {
+        set_error("vpx_convlstm_seq_fwd: reserve too small (%zu < %zu)", reserve_bytes, vpx_convlstm_reserve_bytes(d));
+        return VPX_ERR_WORKSPACE;
+    }
+    if (!workspace || workspace_bytes < vpx_convlstm_workspace_bytes(d)) {
+        set_error("vpx_convlstm_seq_fwd: workspace too small (%zu < %zu)", workspace_bytes, vpx_convlstm_workspace_bytes(d));
+        return VPX_ERR_WORKSPACE;
+    }
+    const int B = d->B, T = d->T, Cin = d->Cin, Ch = d->Ch, H = d->H, Wd = d->W;
+    const size_t HW = (size_t)H * Wd;
+    Carver ws{(char*)workspace, 0, workspace_bytes};
+    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    float* wpk = ws.take(packed_weight_bytes(L.n_tiles, L.chunks_total) / sizeof(float));
+    float* c_scratch = ws.take(L.n_state);
+
+    // ---- layout adaptation (reference NCHW -> native NHWC) ----
+    const float *xn = x, *h0n = h0, *c0n = c0, *wci = Wci, *wcf = Wcf, *wco = Wco;
+    float *outn = out, *hTn = hT, *cTn = cT;
+    if (d->layout == VPX_LAYOUT_NCHW) {
+        float* bx = ws.take(L.n_x);
+        outn = ws.take(L.n_out);
+        float* bh0 = ws.take(L.n_state);
+        float* bc0 = ws.take(L.n_state);
+        float* bhT = ws.take(L.n_state);
+        float* bcT = ws.take(L.n_state);
+        float* p0 = ws.take(L.n_peep);
+        float* p1 = ws.take(L.n_peep);
+        float* p2 = ws.take(L.n_peep);
+        if (x) { VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B * T, Cin, H, Wd, stream)); xn = bx; }
+        if (h0) { VPX_CHECK_HIP(launch_nchw_to_nhwc(h0, bh0, B, Ch, H, Wd, stream)); h0n = bh0; }
+        if (c0) { VPX_CHECK_HIP(launch_nchw_to_nhwc(c0, bc0, B, Ch, H, Wd, stream)); c0n = bc0; }
+        if (peep) {
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(Wci, p0, 1, Ch, H, Wd, stream));
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(Wcf, p1, 1, Ch, H, Wd, stream));
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(Wco, p2, 1, Ch, H, Wd, stream));
+            wci = p0; wcf = p1; wco = p2;
+        }
+        hTn = hT ? bhT : nullptr;
+        cTn = cT ? bcT : nullptr;
+    }
+
+    // ---- weight repack: OIHW [4Ch, Cin+Ch, kh, kw] -> per-tile K-chunk stream ----
+    int gp[4];
+    gate_positions(d->gate_order, gp);
+    PackDesc pd{};
+    const long long ld_o = (long long)(Cin + Ch) * L.taps;
+    pd.seg[0] = PackSeg{W, ld_o, L.taps, 0, Cin};
+    pd.seg[1] = PackSeg{W, ld_o, L.taps, Cin, Ch};
+    memcpy(pd.stage, L.stage, sizeof(ConvStage) * L.nstage);
+    pd.nstage = L.nstage;
+    pd.chunks_total = L.chunks_total;
+    pd.n_tiles = L.n_tiles;
+    pd.taps = L.taps;
+    pd.NG = 4;
+    for (int g = 0; g < 4; ++g) { pd.rowbase[g] = gp[g] * Ch; pd.goff[g] = 0; }
+    pd.tile_stride = 32;
+    pd.nch = Ch;
+    pd.transposed = 0;
+    pd.flip = 0;
+    VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+
+    float* gates_all = nullptr;
+    float* cs_all = nullptr;
+    if (save) {
+        gates_all = (float*)reserve;
+        cs_all = (float*)((char*)reserve + align256((size_t)T * L.n_state * 4 * sizeof(float)));
+    }
+
+    // ---- time loop: one fused conv + gate + state-update launch per step ----
+    for (int t = 0; t < T; ++t) {
+        ConvPlan P{};
+        P.B = B; P.H = H; P.W = Wd; P.kh = d->kh; P.kw = d->kw;
+        P.tiles_x = (Wd + TILE_W - 1) / TILE_W;
+        P.tiles_y = (H + TILE_H - 1) / TILE_H;
+        P.nseg = 2;
+        P.seg[0] = ConvSeg{xn ? xn + (size_t)t * HW * Cin : nullptr, (long long)((size_t)T * HW * Cin), Cin, 0};
+        const float* hprev = (t == 0) ? h0n : outn + (size_t)(t - 1) * HW * Ch;
+        const long long hprev_bs = (long long)((t == 0) ? HW * Ch : (size_t)T * HW * Ch);
+        P.seg[1] = ConvSeg{hprev, hprev_bs, Ch, 0};
+        P.nstage = 0;
+        for (int s = 0; s < L.nstage; ++s) {
+            const float* src = P.seg[L.stage[s].seg].ptr;
+            if (src) P.stage[P.nstage++] = L.stage[s];  // absent source == all-zero operand: its K range is skipped
+        }
+        P.chunks_total = L.chunks_total;
+        P.a_bytes = conv_a_bytes(L.stage, L.nstage, d->kh, d->kw);
+        P.wpk = wpk;
+
+        ConvLSTMStepArgs ea{};
+        ea.bias = bias;
+        memcpy(ea.gate_pos, gp, sizeof(gp));
+        ea.Ch = Ch;
+        if (save) {
+            ea.c_in = (t == 0) ? c0n : cs_all + (size_t)(t - 1) * L.n_state;
+            ea.c_out = cs_all + (size_t)t * L.n_state;
+            ea.gates = gates_all + (size_t)t * L.n_state * 4;
+        } else {
+            ea.c_in = (t == 0) ? c0n : c_scratch;
+            ea.c_out = c_scratch;
+            ea.gates = nullptr;
+        }
+        ea.wci = wci; ea.wcf = wcf; ea.wco = wco;
+        ea.h_out = outn + (size_t)t * HW * Ch;
+        ea.h_bstride = (long long)((size_t)T * HW * Ch);
+        VPX_CHECK_HIP(launch_convlstm_step_f32(P, ea, L.n_tiles, stream));
+    }
+
+    // ---- final states ----
+    const float* c_last = save ? cs_all + (size_t)(T - 1) * L.n_state : c_scratch;
+    if (cTn) VPX_CHECK_HIP(hipMemcpyAsync(cTn, c_last, L.n_state * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (hTn)
+        VPX_CHECK_HIP(hipMemcpy2DAsync(hTn, HW * Ch * sizeof(float), outn + (size_t)(T - 1) * HW * Ch,
+                                       (size_t)T * HW * Ch * sizeof(float), HW * Ch * sizeof(float), B,
+                                       hipMemcpyDeviceToDevice, stream));
+    if (d->layout == VPX_LAYOUT_NCHW) {
+        VPX_CHECK_HIP(launch_nhwc_to_nchw(outn, out, B * T, Ch, H, Wd, stream));
+        if (hT) VPX_CHECK_HIP(launch_nhwc_to_nchw(hTn, hT, B, Ch, H, Wd, stream));
+        if (cT) VPX_CHECK_HIP(launch_nhwc_to_nchw(cTn, cT, B, Ch, H, Wd, stream));
+    }
+    return VPX_OK;
+}
+
+/* ---- plain conv ------------------------------------------------------------------------------------------------ */
+size_t vpx_conv2d_workspace_bytes(int Ci, int Co, int kh, int kw) {
+    if (Ci < 1 || Co < 1 || kh < 1 || kw < 1) return 0;
+    ConvStage st[MAX_STAGE];
+    int chunks = 0;
+    const int segC[1] = {Ci};
+    if (build_stages(st, &chunks, segC, 1, kh * kw, CS_F32, KC_F32) < 0) return 0;
+    return align256(packed_weight_bytes((Co + NT - 1) / NT, chunks)) + 256;
+}
+
+int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Ci,
+                        int Co, int kh, int kw, int precision, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!x || !w || !y || N < 1 || H < 1 || W < 1 || Ci < 1 || Co < 1 || !(kh & 1) || !(kw & 1) || kh > 7 || kw > 7) {
+        set_error("vpx_conv2d_nhwc_fwd: bad argument");
+        return VPX_ERR_ARG;
+    }
+    if (precision != VPX_PREC_F32) { set_error("vpx_conv2d_nhwc_fwd: only VPX_PREC_F32 implemented"); return VPX_ERR_UNSUPPORTED; }
+    hipStream_t stream = (hipStream_t)stream_;
+    ConvPlan P{};
+    int chunks = 0;
+    const int segC[1] = {Ci};
+    P.nstage = build_stages(P.stage, &chunks, segC, 1, kh * kw, CS_F32, KC_F32);
+    if (P.nstage < 0) { set_error("vpx_conv2d_nhwc_fwd: too many channel stages"); return VPX_ERR_UNSUPPORTED; }
+    const int n_tiles = (Co + NT - 1) / NT;
+    if (!workspace || workspace_bytes < vpx_conv2d_workspace_bytes(Ci, Co, kh, kw)) {
+        set_error("vpx_conv2d_nhwc_fwd: workspace too small");
+        return VPX_ERR_WORKSPACE;
+    }
+    Carver ws{(char*)workspace, 0, workspace_bytes};
+    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    float* wpk = ws.take(packed_weight_bytes(n_tiles, chunks) / sizeof(float));
+    PackDesc pd{};
+    pd.seg[0] = PackSeg{w, (long long)Ci * kh * kw, kh * kw, 0, Ci};
+    memcpy(pd.stage, P.stage, sizeof(ConvStage) * P.nstage);
+    pd.nstage = P.nstage; pd.chunks_total = chunks; pd.n_tiles = n_tiles; pd.taps = kh * kw; pd.NG = 4;
+    for (int g = 0; g < 4; ++g) { pd.rowbase[g] = g * 32; pd.goff[g] = g * 32; }
+    pd.tile_stride = NT; pd.nch = Co;
+    VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+    P.B = N; P.H = H; P.W = W; P.kh = kh; P.kw = kw;
+    P.tiles_x = (W + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_H - 1) / TILE_H;
+    P.nseg = 1;
+    P.seg[0] = ConvSeg{x, (long long)H * W * Ci, Ci, 0};
+    P.chunks_total = chunks;
+    P.a_bytes = conv_a_bytes(P.stage, P.nstage, kh, kw);
+    P.wpk = wpk;
+    PlainEpiArgs ea{};
+    ea.bias = bias; ea.Co = Co; ea.split = Co;
+    ea.out0 = y; ea.bstride0 = (long long)H * W * Co; ea.ld0 = Co;
+    VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, n_tiles, stream));
+    return VPX_OK;
+}
+
+}  // extern "C"

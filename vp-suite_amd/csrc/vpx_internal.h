@@ -1,0 +1,111 @@
+// vpx_internal.h — shared declarations of libvpx_hip.so (gfx950 only; no CUDA / multi-backend paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/vpx.h"
+
+namespace vpx {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution geometry.
+//   M = output pixels: one workgroup owns a TILE_H x TILE_W patch of one image (128 pixels, 4 waves x 32 pixels)
+//   N = NG "gate groups" x 32 channels: every wave holds, for its 32 pixels, the NG accumulators of the SAME 32
+//       channels (i,f,g,o of one channel sit in one lane -> the LSTM epilogue is lane-local, no shuffles)
+//   K = (source segment, channel stage, tap, channel): activations are staged ONCE per channel stage as a halo tile in
+//       LDS (NHWC rows, channel-contiguous) and re-used by all kh*kw taps; weights stream through LDS in KC-deep chunks.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TILE_H = 8;
+constexpr int TILE_W = 16;
+constexpr int NTHREADS = 256;
+constexpr int NT = 128;      // GEMM-N per workgroup (4 groups x 32)
+constexpr int MAX_NG = 4;
+constexpr int KC_F32 = 32;   // k-depth of one weight chunk, fp32 operands (16 KiB per chunk)
+constexpr int CS_F32 = 64;   // channels per activation stage, fp32 operands
+constexpr int MAX_SEG = 3;
+constexpr int MAX_STAGE = 16;
+
+struct ConvSeg {          // one activation source, NHWC [B][H][W][C] with arbitrary batch stride (selects a time slice)
+    const float* ptr;
+    long long bstride;    // elements between consecutive batch items
+    int C;                // real channels (row length in memory)
+    int _pad;
+};
+
+struct ConvStage {        // one K-stage: channels [c0, c0+cn) of segment `seg`, all taps
+    int seg, c0, cn;      // cn is a multiple of 8 (zero-padded beyond the segment's real C)
+    int chunk0;           // first weight chunk of this stage inside the packed per-tile weight stream
+    int nq;               // number of 8-deep k-steps = taps * cn / 8
+    int _p0, _p1, _p2;
+};
+
+struct ConvPlan {
+    int B, H, W, kh, kw, tiles_x, tiles_y;
+    int nseg, nstage;
+    int chunks_total;     // weight chunks per N-tile
+    int a_bytes;          // LDS bytes reserved for the activation stage
+    int _pad;
+    ConvSeg seg[MAX_SEG];
+    ConvStage stage[MAX_STAGE];
+    const float* wpk;     // packed weights [n_tiles][chunks_total][NT][KC]
+};
+
+// Source description for the weight repack kernel: where does packed element (n_tile, g, j, stage, tap, c) come from?
+struct PackSeg {
+    const float* w;       // OIHW tensor holding this segment's weights
+    long long ld_o;       // elements per "O" index
+    long long ld_i;       // elements per "I" index (= kh*kw for OIHW)
+    int coff;             // offset of this segment's channel 0 along the contraction ("I", or "O" if transposed) axis
+    int C;                // real channels of the segment
+};
+struct PackDesc {
+    PackSeg seg[MAX_SEG];
+    ConvStage stage[MAX_STAGE];
+    int nstage, chunks_total, n_tiles, taps;
+    int NG;               // groups per tile actually used (rows of unused groups are zero)
+    int rowbase[MAX_NG];  // source output-row of (channel 0, tile 0) for group g; -1 = group unused
+    int goff[MAX_NG];     // channel-index offset of group g used only for the validity test
+    int tile_stride;      // channels advanced per n_tile
+    int nch;              // number of valid output channels
+    int transposed;       // 1: contraction runs over the weight's O axis, outputs over its I axis (data-gradient conv)
+    int flip;             // 1: spatially flipped taps (data-gradient conv)
+};
+
+void set_error(const char* fmt, ...);
+int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int kc);
+int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw);
+size_t packed_weight_bytes(int n_tiles, int chunks_total);
+
+hipError_t launch_pack_weights(const PackDesc& pd, float* dst, hipStream_t s);
+
+// ConvLSTM fused step (epilogue = gates + state update). Pointers NHWC.
+struct ConvLSTMStepArgs {
+    const float* bias;        // reference layout [4Ch] or null
+    int gate_pos[4];          // position of logical gates (i,f,g,o) in the reference's 4Ch axis
+    int Ch;
+    const float* c_in;        // [B,H,W,Ch] or null (zeros)
+    float* c_out;             // [B,H,W,Ch] (may alias c_in)
+    const float* wci;         // [H,W,Ch] or null
+    const float* wcf;
+    const float* wco;
+    float* h_out;             // h_t slab
+    long long h_bstride;      // elements between batch items of h_out
+    float* gates;             // [B,H,W,4Ch] post-activation (i,f,g,o) or null
+};
+hipError_t launch_convlstm_step_f32(const ConvPlan& plan, const ConvLSTMStepArgs& ea, int n_tiles, hipStream_t s);
+
+// Plain epilogue: y = conv (+bias), channels [0,split) -> out0, [split, Co) -> out1 (either may be null = dropped).
+struct PlainEpiArgs {
+    const float* bias;        // [Co] or null
+    int Co, split;
+    float* out0; long long bstride0; int ld0;   // NHWC, ld = channels per pixel of the destination tensor
+    float* out1; long long bstride1; int ld1;
+    int accumulate;           // 1: += into destination
+};
+hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, int n_tiles, hipStream_t s);
+
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
+
+}  // namespace vpx

@@ -1,0 +1,156 @@
+"""torch-level operators over the C ABI (include/vpx.h). Tensors keep the reference's LOGICAL shapes
+([B,T,C,H,W], [B,C,H,W]) but live channels-last in memory (NHWC) so that kernels get coalesced channel rows and the
+glue convolutions of the models (MIOpen, channels_last) exchange activations with them without a copy."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvLSTMDesc, check, ptr
+
+PRECISIONS = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _lib.VpxError(f"{what}: tensors must live on the GPU (got device '{t.device}'). The hot path runs only as "
+                            f"HIP kernels on MI355X; there is no CPU fallback.")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{what}: expected float32 tensors, got {t.dtype}")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_channels_last(t: torch.Tensor) -> torch.Tensor:
+    """Same logical tensor ([..., C, H, W]) with NHWC memory. No copy if it already is."""
+    nd = t.dim()
+    perm = list(range(nd - 3)) + [nd - 2, nd - 1, nd - 3]
+    inv = list(range(nd - 3)) + [nd - 1, nd - 3, nd - 2]
+    return t.permute(perm).contiguous().permute(inv)
+
+
+def is_channels_last(t: torch.Tensor) -> bool:
+    nd = t.dim()
+    perm = list(range(nd - 3)) + [nd - 2, nd - 1, nd - 3]
+    return t.permute(perm).is_contiguous()
+
+
+def new_channels_last(shape, device, dtype=torch.float32) -> torch.Tensor:
+    """Uninitialised tensor of logical shape [..., C, H, W] with NHWC memory."""
+    *lead, C, H, W = shape
+    nd = len(shape)
+    inv = list(range(nd - 3)) + [nd - 1, nd - 3, nd - 2]
+    return torch.empty(*lead, H, W, C, device=device, dtype=dtype).permute(inv)
+
+
+class _ConvLSTMSeqFn(torch.autograd.Function):
+    """out, hT, cT = ConvLSTM over T steps. Replaces the python time loop of conv_lstm_hzzone.py:52-70 /
+    conv_lstm_ndrplz.py:112-121 by ONE library call (T fused conv+gate launches on the current stream)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, c0, W, b, Wci, Wcf, Wco, seq_len, gate_order, precision, in_channels):
+        need_grad = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (x, h0, c0, W, b, Wci, Wcf, Wco))
+        ref = x if x is not None else h0
+        _require_gpu(ref, "convlstm_seq")
+        dev = ref.device
+        Ch = W.shape[0] // 4
+        kh, kw = int(W.shape[2]), int(W.shape[3])
+        Cin = int(in_channels)
+        if W.shape[1] != Cin + Ch:
+            raise ValueError(f"convlstm_seq: weight has {W.shape[1]} input channels, expected {Cin}+{Ch}")
+        if x is not None:
+            B, T, cx, H, Wd = x.shape
+            if cx != Cin or T < seq_len:
+                raise ValueError(f"convlstm_seq: input shape {tuple(x.shape)} does not match Cin={Cin}, T>={seq_len}")
+            x = to_channels_last(x[:, :seq_len]) if T != seq_len else to_channels_last(x)
+        else:
+            B, _, H, Wd = h0.shape
+        T = int(seq_len)
+        h0c = None if h0 is None else to_channels_last(h0)
+        c0c = None if c0 is None else to_channels_last(c0)
+        peep = Wci is not None
+        wci = to_channels_last(Wci) if peep else None
+        wcf = to_channels_last(Wcf) if peep else None
+        wco = to_channels_last(Wco) if peep else None
+        Wc = W.contiguous()
+        bc = None if b is None else b.contiguous()
+        d = ConvLSTMDesc(B, T, Cin, Ch, H, Wd, kh, kw, gate_order, _lib.LAYOUT_NHWC, precision,
+                         _lib.FLAG_SAVE_FOR_BWD if need_grad else 0)
+        L = _lib.lib()
+        ws_bytes = L.vpx_convlstm_workspace_bytes(ctypes.byref(d))
+        rs_bytes = L.vpx_convlstm_reserve_bytes(ctypes.byref(d))
+        if ws_bytes == 0:
+            check(-1 if "not implemented" not in L.vpx_last_error().decode() else -4, "vpx_convlstm_workspace_bytes")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        reserve = torch.empty(max(rs_bytes, 1), dtype=torch.uint8, device=dev)
+        out = new_channels_last((B, T, Ch, H, Wd), dev)
+        hT = new_channels_last((B, Ch, H, Wd), dev)
+        cT = new_channels_last((B, Ch, H, Wd), dev)
+        rc = L.vpx_convlstm_seq_fwd(ctypes.byref(d), ptr(x), ptr(h0c), ptr(c0c), ptr(Wc), ptr(bc), ptr(wci), ptr(wcf),
+                                    ptr(wco), ptr(out), ptr(hT), ptr(cT), ptr(reserve), rs_bytes, ptr(ws), ws_bytes,
+                                    _stream())
+        check(rc, "vpx_convlstm_seq_fwd")
+        if need_grad:
+            ctx.save_for_backward(x, h0c, c0c, Wc, wci, wcf, wco, out, reserve)
+            ctx.desc = d
+            ctx.has_bias = b is not None
+            ctx.rs_bytes = rs_bytes
+        return out, hT, cT
+
+    @staticmethod
+    def backward(ctx, dout, dhT, dcT):
+        x, h0c, c0c, Wc, wci, wcf, wco, out, reserve = ctx.saved_tensors
+        d = ctx.desc
+        dev = out.device
+        L = _lib.lib()
+        B, T, Cin, Ch, H, Wd = d.B, d.T, d.Cin, d.Ch, d.H, d.W
+        needs = ctx.needs_input_grad
+        dout = None if dout is None else to_channels_last(dout)
+        dhT = None if dhT is None else to_channels_last(dhT)
+        dcT = None if dcT is None else to_channels_last(dcT)
+        dx = new_channels_last((B, T, Cin, H, Wd), dev) if (x is not None and needs[0]) else None
+        dh0 = new_channels_last((B, Ch, H, Wd), dev) if (h0c is not None and needs[1]) else None
+        dc0 = new_channels_last((B, Ch, H, Wd), dev) if (c0c is not None and needs[2]) else None
+        dW = torch.empty_like(Wc) if needs[3] else None
+        db = torch.empty(4 * Ch, device=dev) if (ctx.has_bias and needs[4]) else None
+        peep = wci is not None
+        dwci = new_channels_last((1, Ch, H, Wd), dev) if (peep and needs[5]) else None
+        dwcf = new_channels_last((1, Ch, H, Wd), dev) if (peep and needs[6]) else None
+        dwco = new_channels_last((1, Ch, H, Wd), dev) if (peep and needs[7]) else None
+        ws_bytes = L.vpx_convlstm_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = L.vpx_convlstm_seq_bwd(ctypes.byref(d), ptr(x), ptr(h0c), ptr(c0c), ptr(Wc), ptr(wci), ptr(wcf), ptr(wco),
+                                    ptr(out), ptr(reserve), ctx.rs_bytes, ptr(dout), ptr(dhT), ptr(dcT), ptr(dx),
+                                    ptr(dh0), ptr(dc0), ptr(dW), ptr(db), ptr(dwci), ptr(dwcf), ptr(dwco), ptr(ws),
+                                    ws_bytes, _stream())
+        check(rc, "vpx_convlstm_seq_bwd")
+        return dx, dh0, dc0, dW, db, dwci, dwcf, dwco, None, None, None, None
+
+
+def convlstm_seq(x, h0, c0, W, b, Wci=None, Wcf=None, Wco=None, *, seq_len, in_channels, gate_order=_lib.GATE_IFGO,
+                 precision="f32"):
+    """x: [B,T,Cin,H,W] or None; h0/c0: [B,Ch,H,W] or None (not both x and h0 None). Returns (out [B,T,Ch,H,W], hT, cT)."""
+    if x is None and h0 is None:
+        raise ValueError("convlstm_seq: inputs and states must not both be None")
+    return _ConvLSTMSeqFn.apply(x, h0, c0, W, b, Wci, Wcf, Wco, int(seq_len), int(gate_order), PRECISIONS[precision],
+                                int(in_channels))
+
+
+def conv2d_same(x, w, bias=None, precision="f32"):
+    """Stride-1 'same' convolution on a channels-last [N,C,H,W] tensor through the library's implicit-GEMM kernel
+    (inference only; used for PredRNN's 1x1 frame head, predrnn_v2.py:223)."""
+    _require_gpu(x, "conv2d_same")
+    x = to_channels_last(x)
+    N, Ci, H, Wd = x.shape
+    Co, _, kh, kw = w.shape
+    L = _lib.lib()
+    ws_bytes = L.vpx_conv2d_workspace_bytes(Ci, Co, kh, kw)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    y = new_channels_last((N, Co, H, Wd), x.device)
+    rc = L.vpx_conv2d_nhwc_fwd(ptr(x), ptr(w.contiguous()), ptr(None if bias is None else bias.contiguous()), ptr(y),
+                               N, H, Wd, Ci, Co, kh, kw, PRECISIONS[precision], ptr(ws), ws_bytes, _stream())
+    check(rc, "vpx_conv2d_nhwc_fwd")
+    return y
