@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — predicted frames/s of the convlstm-shi hot path (BASELINE.json metric) on N MI355X GPUs of one node.
+
+Workload (config.workload): the default `convlstm-shi` model (EF-ConvLSTM, vp_suite/models/precipitation_nowcasting/
+ef_conv_lstm.py:31-65) on MovingMNIST-shaped synthetic frames [B, 10+10, 1, 64, 64], 10 context -> 10 predicted frames
+(BASELINE.json configs[1]). One "step" = one pass of the hot path over one batch: mode=infer is VPModel.forward under
+no_grad; mode=train is forward + MSE + backward + gradient all-reduce (RCCL) + Adam. Batch-sharded data parallel,
+per-GPU batch fixed (weak scaling), no data-path collective in infer mode.
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     — live HIP-event timing of the dominant kernel (fused ConvLSTM cell), algorithmic FLOPs / duration
+  cpu_baseline — the oracle's PyTorch-CPU restatement of the same forward, timed on the host cores (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}  # MI355X_MICROARCH.md: f32 matrix 157.3 TF, bf16 dense ~2.5 PF
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (reference default run config batch_size=32)")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="f32")
+    ap.add_argument("--img", type=int, default=64)
+    ap.add_argument("--channels", type=int, default=1)
+    ap.add_argument("--context", type=int, default=10)
+    ap.add_argument("--pred", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(model, args):
+    """Times the oracle's plain-PyTorch CPU restatement (oracle/torch_ref.py) of the same forward on the host cores.
+    Bounded sample: batch 4 (BASELINE configs[0]) of the same 10->10 workload, repeated for ~cpu_seconds."""
+    from oracle import torch_ref
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cores = torch.get_num_threads()
+    b = 4
+    x = torch.rand(b, args.context, args.channels, args.img, args.img)
+    with torch.no_grad():
+        torch_ref.ef_convlstm_forward(sd, x, args.pred)  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            torch_ref.ef_convlstm_forward(sd, x, args.pred)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > args.cpu_seconds or n >= 50:
+                break
+    return {"value": round(n * b * args.pred / el, 2), "unit": "predicted frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/torch_ref.ef_convlstm_forward (PyTorch-CPU restatement of the reference path), "
+                      f"batch {b}, {args.context}->{args.pred}, {args.channels}x{args.img}x{args.img}, "
+                      f"{n} iterations in {el:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import vp_suite_amd
+    from vp_suite_amd import ops
+    from vp_suite_amd.models import MODEL_CLASSES
+
+    torch.manual_seed(0)  # identical random-init weights on every rank
+    model = MODEL_CLASSES["convlstm-shi"](str(dev), img_shape=(args.channels, args.img, args.img), action_size=0,
+                                          tensor_value_range=[0.0, 1.0], cell_precision=args.precision).to(dev)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.split(".")[-1] in ("Wci", "Wcf", "Wco"):
+                p.normal_(0.0, 0.1)  # exercise the peephole path (reference init is zeros)
+    torch.manual_seed(42 + rank)
+    frames = torch.rand(args.batch, args.context + args.pred, args.channels, args.img, args.img, device=dev)
+    x, target = frames[:, :args.context], frames[:, args.context:]
+
+    if args.mode == "train":
+        from vp_suite_amd.train import DataParallelTrainer
+        trainer = DataParallelTrainer(model, lr=1e-4, world_size=world)
+
+        def step():
+            trainer.step(x, target, args.pred)
+    else:
+        def step():
+            with torch.no_grad():
+                model(x, pred_frames=args.pred)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = ops.KernelProfile()
+    ops.PROFILE = prof
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILE = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ps = prof.summary()
+        ach_tflops = ps["flops"] / (ps["ms"] * 1e-3) / 1e12 if ps["ms"] > 0 else 0.0
+        ach_gbs = ps["bytes"] / (ps["ms"] * 1e-3) / 1e9 if ps["ms"] > 0 else 0.0
+        peak = PEAK_TFLOPS[args.precision]
+        frames_total = world * args.batch * args.pred * args.steps
+        out = {
+            "metric": "predicted frames/sec (whole node), MovingMNIST 64x64 10->10",
+            "value": round(frames_total / elapsed, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": f"convlstm-shi (EF-ConvLSTM default) on MovingMNIST-shaped synthetic frames "
+                                   f"{args.channels}x{args.img}x{args.img}, {args.context}->{args.pred}, "
+                                   f"random-init weights",
+                       "mode": args.mode, "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}"},
+            "roofline": {
+                "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach_tflops / peak, 4), "traffic": None,
+                "kernel": "conv_gemm_f32_kernel<EpiConvLSTM> (fused ConvLSTM cell step)",
+                "launches": ps["launches"], "avg_launch_us": round(ps["ms"] * 1e3 / max(ps["launches"], 1), 2),
+                "algorithmic_gflop_per_launch": round(ps["flops"] / max(ps["launches"], 1) / 1e9, 3),
+                "hbm_view": {"achieved_GBps": round(ach_gbs, 1), "peak_GBps": HBM_PEAK_GBS,
+                             "frac": round(ach_gbs / HBM_PEAK_GBS, 4)},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

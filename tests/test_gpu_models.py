@@ -1,0 +1,66 @@
+"""GPU parity of the full models (drop-in VPModel surface) against reference-generated golden vectors."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from golden_util import checksum, fill_state_dict_, load_golden, name_seed, seeded_rand
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4  # north_star: within 1e-4 relative (fp32)
+
+
+def _relmax(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _ef(vpx, tag, kw):
+    from vp_suite_amd.models import MODEL_CLASSES
+    m = MODEL_CLASSES["convlstm-shi"]("cuda", **kw)
+    fill_state_dict_(m, name_seed("ef." + tag))
+    return m.to("cuda")
+
+
+@pytest.mark.parametrize("tag,kw,B,T,P", [("tiny", gc.EF_TINY_KW, 2, 3, 2), ("tiny3", gc.EF_TINY3_KW, 2, 2, 3)])
+def test_ef_convlstm_forward_vs_golden(vpx, tag, kw, B, T, P):
+    g = load_golden(f"ef_{tag}")
+    m = _ef(vpx, tag, kw)
+    c, h, w = kw["img_shape"]
+    frames = seeded_rand((B, T + P, c, h, w), name_seed(f"ef.{tag}.frames")).cuda()
+    with torch.no_grad():
+        pred, ml = m(frames[:, :T], pred_frames=P)
+        pred1 = m.pred_1(frames[:, :T])
+    assert ml is None and pred.shape == (B, P, c, h, w) and pred1.shape == (B, c, h, w)
+    assert _relmax(pred, g["pred"]) < RTOL and _relmax(pred1, g["pred1"]) < RTOL
+
+
+@pytest.mark.parametrize("tag,c", [("full_c1", 1), ("full_c3", 3)])
+def test_ef_convlstm_full_size_vs_golden(vpx, tag, c):
+    """BASELINE configs C1/C2 shape: default convlstm-shi, 64x64, 10 -> 10."""
+    g = load_golden(f"ef_{tag}")
+    m = _ef(vpx, tag, dict(img_shape=(c, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0]))
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"])
+    x = seeded_rand((1, 10, c, 64, 64), name_seed(f"ef.{tag}.x"))
+    assert abs(checksum(x) - float(g["chk_x"])) < 1e-9
+    with torch.no_grad():
+        pred, _ = m(x.cuda(), pred_frames=10)
+    assert _relmax(pred[:, :, :, ::4, ::4], g["pred_slice"]) < RTOL
+    assert abs(checksum(pred) - float(g["pred_chk"])) < 1e-3 * max(1.0, abs(float(g["pred_chk"])))
+
+
+def test_reference_shape_contract(vpx):
+    """The reference's own model test (tests/test_models.py:19-35): shapes of pred_1 and forward(pred_frames=5)."""
+    from vp_suite_amd.models import MODEL_CLASSES
+    b, p, (c, h, w) = 2, 5, (3, 64, 64)
+    for key, cls in MODEL_CLASSES.items():
+        model = cls("cuda", action_size=3, img_shape=(c, h, w), temporal_dim=3, action_conditional=False,
+                    tensor_value_range=[0.0, 1.0]).to("cuda")
+        t = p + 3 if cls.NEEDS_COMPLETE_INPUT else 3
+        x = torch.randn(b, t, c, h, w, device="cuda")
+        with torch.no_grad():
+            assert model.pred_1(x).shape == (b, c, h, w)
+            assert model(x, pred_frames=p)[0].shape == (b, p, c, h, w)

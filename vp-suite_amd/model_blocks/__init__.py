@@ -1,0 +1,4 @@
+"""Model blocks with the reference's registry names (vp_suite/model_blocks/__init__.py)."""
+from .conv_lstm_hzzone import ConvLSTM  # noqa: F401
+from .conv_lstm_ndrplz import ConvLSTM as ConvLSTM_ndrplz  # noqa: F401
+from .conv_lstm_ndrplz import ConvLSTMCell  # noqa: F401

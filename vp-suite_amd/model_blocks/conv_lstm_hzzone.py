@@ -1,0 +1,51 @@
+"""ConvLSTM (Shi et al.) with peephole connections — drop-in for vp_suite/model_blocks/conv_lstm_hzzone.py:7-70.
+
+Same constructor signature, parameter names/shapes/init (`_conv.weight [4Ch,Cin+Ch,k,k]`, `_conv.bias`, `Wci/Wcf/Wco
+[1,Ch,H,W]` zeros) and return convention `(stack(h_t) [B,T,Ch,H,W], (h_T, c_T))`. The python time loop with its
+cat/conv2d/chunk/sigmoid/tanh op sequence (:52-70) is replaced by one call into libvpx_hip.so.
+
+Divergence (documented): on non-CPU devices the reference silently de-registers the peephole tensors
+(`nn.Parameter(...).to(device)` yields a plain tensor, :30-32); here they are always real parameters, as on the
+reference's CPU path (the oracle)."""
+import torch
+from torch import nn
+
+from .. import _lib, ops
+from ..base import VPModelBlock
+
+
+class ConvLSTM(VPModelBlock):
+    NAME = "ConvLSTM (Shi et al.)"
+    PAPER_REFERENCE = "https://arxiv.org/abs/1506.04214"
+    CODE_REFERENCE = "https://github.com/Hzzone/Precipitation-Nowcasting"
+    MATCHES_REFERENCE = "Yes"
+
+    precision = "f32"  #: arithmetic of the fused cell kernel: "f32" (exact), "bf16x3", "bf16"
+
+    def __init__(self, device, in_channels, enc_channels, state_h, state_w, kernel_size, stride=1, padding=1):
+        super().__init__()
+        if stride != 1 or 2 * padding != kernel_size - 1:
+            # the recurrence feeds h (state size) back through the same conv: only stride-1 "same" convs are consistent
+            raise NotImplementedError("ConvLSTM block needs stride=1 and padding=kernel_size//2 (state-preserving conv)")
+        self.device = device
+        self._conv = nn.Conv2d(in_channels + enc_channels, 4 * enc_channels, kernel_size, stride, padding)
+        self.state_h, self.state_w = state_h, state_w
+        shape = (1, enc_channels, state_h, state_w)
+        self.Wci = nn.Parameter(torch.zeros(shape))
+        self.Wcf = nn.Parameter(torch.zeros(shape))
+        self.Wco = nn.Parameter(torch.zeros(shape))
+        self.in_c, self.enc_c = in_channels, enc_channels
+
+    def forward(self, inputs, states, seq_len):
+        """inputs [B,T,Cin,H,W] or None (zero input every step); states (h, c) or None (zero states)."""
+        if inputs is None and states is None:
+            raise ValueError("inputs and states should not be all none")
+        if states is None:
+            # zero states contribute nothing: the library skips the h-segment at t=0 instead of reading zeros
+            h0 = c0 = None
+        else:
+            h0, c0 = states
+        out, hT, cT = ops.convlstm_seq(inputs, h0, c0, self._conv.weight, self._conv.bias, self.Wci, self.Wcf, self.Wco,
+                                       seq_len=seq_len, in_channels=self.in_c, gate_order=_lib.GATE_IFGO,
+                                       precision=self.precision)
+        return out, (hT, cT)

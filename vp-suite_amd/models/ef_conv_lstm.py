@@ -1,0 +1,188 @@
+"""Encoder-Forecaster ConvLSTM ("convlstm-shi") — drop-in for
+vp_suite/models/precipitation_nowcasting/ef_blocks.py:15-187 and ef_conv_lstm.py:8-108.
+
+Identical hyper-parameter names/defaults, module tree and state_dict keys
+(`encoder.stage{n}.conv{n}_leaky_1.*`, `encoder.rnn{n}.{_conv.weight,_conv.bias,Wci,Wcf,Wco}`,
+`forecaster.rnn{n}.*`, `forecaster.stage{n}.deconv*_leaky_1.*`, `forecaster.stage1.conv3_3.*`), so reference
+checkpoints load unchanged. The six recurrent blocks run as fused HIP kernels; activations stay channels-last (NHWC)
+between the glue convolutions (MIOpen) and the recurrent kernels, so no layout round trips happen inside the model."""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..base import VPModel
+from ..model_blocks import ConvLSTM
+from ..utils import conv_output_shape, convtransp_output_shape
+
+
+def _stage(spec: "OrderedDict[str, list]") -> nn.Sequential:
+    """Layer-name driven stage builder with the reference's naming rules (ef_blocks.py:15-49): 'identity', 'pool',
+    'deconv*' (ConvTranspose2d), 'conv*' (Conv2d); a 'relu' / 'leaky' tag in the name appends the activation
+    (LeakyReLU slope 0.2) under the key '<tag>_<name>'. Values: [c_in, c_out, kernel, stride, pad]."""
+    layers = []
+    for name, v in spec.items():
+        if "identity" in name:
+            layers.append((name, nn.Identity()))
+            continue
+        if "pool" in name:
+            layers.append((name, nn.MaxPool2d(kernel_size=v[0], stride=v[1], padding=v[2])))
+            continue
+        if "deconv" in name:
+            op = nn.ConvTranspose2d(v[0], v[1], v[2], v[3], v[4])
+        elif "conv" in name:
+            op = nn.Conv2d(v[0], v[1], v[2], v[3], v[4])
+        else:
+            raise NotImplementedError
+        layers.append((name, op))
+        if "relu" in name:
+            layers.append(("relu_" + name, nn.ReLU(inplace=True)))
+        elif "leaky" in name:
+            layers.append(("leaky_" + name, nn.LeakyReLU(negative_slope=0.2, inplace=True)))
+    return nn.Sequential(OrderedDict(layers))
+
+
+def _apply_framewise(subnet: nn.Module, seq: torch.Tensor) -> torch.Tensor:
+    """Runs a 2-D stage on every frame of [B,T,C,H,W], channels-last in and out (B*T is folded into the batch)."""
+    b, t = seq.shape[:2]
+    flat = ops.to_channels_last(seq).reshape(b * t, *seq.shape[2:])  # a view: NHWC memory folds B,T for free
+    y = subnet(flat.contiguous(memory_format=torch.channels_last))
+    y = y.contiguous(memory_format=torch.channels_last)
+    return y.view(b, t, *y.shape[1:])
+
+
+class Encoder(nn.Module):
+    def __init__(self, subnets, rnns):
+        super().__init__()
+        assert len(subnets) == len(rnns)
+        self.blocks = len(subnets)
+        for index, (params, rnn) in enumerate(zip(subnets, rnns), 1):
+            setattr(self, f"stage{index}", _stage(params))
+            setattr(self, f"rnn{index}", rnn)
+
+    def forward_by_stage(self, input, subnet, rnn):
+        input = _apply_framewise(subnet, input)
+        return rnn(input, None, seq_len=input.shape[1])
+
+    def forward(self, input):
+        hidden_states = []
+        for i in range(1, self.blocks + 1):
+            input, state = self.forward_by_stage(input, getattr(self, f"stage{i}"), getattr(self, f"rnn{i}"))
+            hidden_states.append(state)
+        return tuple(hidden_states)
+
+
+class Forecaster(nn.Module):
+    def __init__(self, subnets, rnns):
+        super().__init__()
+        assert len(subnets) == len(rnns)
+        self.blocks = len(subnets)
+        for index, (params, rnn) in enumerate(zip(subnets, rnns)):
+            setattr(self, f"rnn{self.blocks - index}", rnn)
+            setattr(self, f"stage{self.blocks - index}", _stage(params))
+
+    def forward_by_stage(self, input, state, pred_frames, subnet, rnn):
+        input, _ = rnn(input, state, pred_frames)
+        return _apply_framewise(subnet, input)
+
+    def forward(self, hidden_states, pred_frames):
+        # like the reference (ef_blocks.py:109-110) the top block is addressed as stage3/rnn3 and gets no input
+        input = self.forward_by_stage(None, hidden_states[-1], pred_frames, self.stage3, self.rnn3)
+        for i in range(self.blocks - 1, 0, -1):
+            input = self.forward_by_stage(input, hidden_states[i - 1], pred_frames, getattr(self, f"stage{i}"),
+                                          getattr(self, f"rnn{i}"))
+        return input
+
+
+class Encoder_Forecaster(VPModel):
+    NAME = "Encoder-Forecaster Structure (Shi et al.)"
+
+    def __init__(self, device, **model_kwargs):
+        super().__init__(device, **model_kwargs)
+        for name, val in [(k, v) for k, v in vars(self).items() if k.startswith(("enc_", "dec_"))]:
+            want = 2 * self.num_layers if name in ("enc_c", "dec_c") else self.num_layers
+            if len(val) != want:
+                raise AttributeError(f"Speficied {self.num_layers} layers, but len of attribute '{name}' "
+                                     f"doesn't match that ({val}).")
+        hw = (self.img_h, self.img_w)
+        enc_h, enc_w = [], []
+        for n in range(self.num_layers):
+            hw = conv_output_shape(hw, self.enc_conv_k[n], self.enc_conv_s[n], self.enc_conv_p[n])
+            enc_h.append(hw[0]); enc_w.append(hw[1])
+        dec_h, dec_w = [hw[0]], [hw[1]]
+        for n in range(self.num_layers - 1):
+            hw = convtransp_output_shape(hw, self.dec_conv_k[n], self.dec_conv_s[n], self.dec_conv_p[n])
+            dec_h.append(hw[0]); dec_w.append(hw[1])
+        final = convtransp_output_shape(hw, self.dec_conv_k[-1], self.dec_conv_s[-1], self.dec_conv_p[-1])
+        if (self.img_h, self.img_w) != tuple(final):
+            sizes = list(zip(enc_h, enc_w)) + list(zip(dec_h, dec_w))
+            raise AttributeError(f"Model layer hyperparameters yield wrong output size: {tuple(final)} "
+                                 f"(expected: {(self.img_h, self.img_w)}). All hidden sizes: {sizes}")
+        self.enc_rnn_state_h, self.enc_rnn_state_w = enc_h, enc_w
+        self.dec_rnn_state_h, self.dec_rnn_state_w = dec_h, dec_w
+        enc_convs, enc_rnns, dec_convs, dec_rnns = self._build_encoder_decoder()
+        self.encoder = Encoder(enc_convs, enc_rnns).to(self.device)
+        self.forecaster = Forecaster(dec_convs, dec_rnns).to(self.device)
+        self.NON_CONFIG_VARS.extend(["encoder", "forecaster"])
+
+    def _build_encoder_decoder(self):
+        raise NotImplementedError
+
+    def pred_1(self, x, **kwargs):
+        return self(x, pred_frames=1, **kwargs)[0].squeeze(dim=1)
+
+    def forward(self, x, pred_frames: int = 1, **kwargs):
+        return self.forecaster(self.encoder(x), pred_frames), None
+
+
+class EF_ConvLSTM(Encoder_Forecaster):
+    NAME = "EF-ConvLSTM (Shi et al.)"
+    PAPER_REFERENCE = "https://arxiv.org/abs/1506.04214"
+    CODE_REFERENCE = "https://github.com/Hzzone/Precipitation-Nowcasting"
+    MATCHES_REFERENCE = "Yes"
+
+    # hyper-parameters: names and defaults of ef_conv_lstm.py:31-65 (c=channels, k=kernel, s=stride, p=padding)
+    num_layers = 3
+    enc_c = [16, 64, 64, 96, 96, 96]
+    dec_c = [96, 96, 96, 96, 64, 16]
+    enc_conv_names = ["conv1_leaky_1", "conv2_leaky_1", "conv3_leaky_1"]
+    enc_conv_k, enc_conv_s, enc_conv_p = [3, 3, 3], [1, 2, 2], [1, 1, 1]
+    dec_conv_names = ["deconv1_leaky_1", "deconv2_leaky_1", "deconv3_leaky_1"]
+    dec_conv_k, dec_conv_s, dec_conv_p = [4, 4, 3], [2, 2, 1], [1, 1, 1]
+    enc_rnn_k, enc_rnn_s, enc_rnn_p = [3, 3, 3], [1, 1, 1], [1, 1, 1]
+    dec_rnn_k, dec_rnn_s, dec_rnn_p = [3, 3, 3], [1, 1, 1], [1, 1, 1]
+    final_conv_1_name, final_conv_1_c, final_conv_1_k, final_conv_1_s, final_conv_1_p = "identity", 16, 3, 1, 1
+    final_conv_2_name, final_conv_2_k, final_conv_2_s, final_conv_2_p = "conv3_3", 1, 1, 0
+    cell_precision = "f32"  #: arithmetic of the fused ConvLSTM kernels ("f32" | "bf16x3" | "bf16")
+
+    def _build_encoder_decoder(self):
+        enc_convs, enc_rnns, dec_convs, dec_rnns = [], [], [], []
+        c_prev = self.img_c
+        for n in range(self.num_layers):
+            c_mid, c_out = self.enc_c[2 * n], self.enc_c[2 * n + 1]
+            enc_convs.append(OrderedDict({self.enc_conv_names[n]: [c_prev, c_mid, self.enc_conv_k[n],
+                                                                   self.enc_conv_s[n], self.enc_conv_p[n]]}))
+            enc_rnns.append(self._rnn(c_mid, c_out, self.enc_rnn_state_h[n], self.enc_rnn_state_w[n],
+                                      self.enc_rnn_k[n], self.enc_rnn_s[n], self.enc_rnn_p[n]))
+            c_prev = c_out
+        for n in range(self.num_layers):
+            c_mid, c_out = self.dec_c[2 * n], self.dec_c[2 * n + 1]
+            dec_rnns.append(self._rnn(c_prev, c_mid, self.dec_rnn_state_h[n], self.dec_rnn_state_w[n],
+                                      self.dec_rnn_k[n], self.dec_rnn_s[n], self.dec_rnn_p[n]))
+            spec = OrderedDict({self.dec_conv_names[n]: [c_mid, c_out, self.dec_conv_k[n], self.dec_conv_s[n],
+                                                         self.dec_conv_p[n]]})
+            if n == self.num_layers - 1:
+                spec[self.final_conv_1_name] = [c_out, self.final_conv_1_c, self.final_conv_1_k, self.final_conv_1_s,
+                                                self.final_conv_1_p]
+                spec[self.final_conv_2_name] = [self.final_conv_1_c, self.img_c, self.final_conv_2_k,
+                                                self.final_conv_2_s, self.final_conv_2_p]
+            dec_convs.append(spec)
+            c_prev = c_out
+        return enc_convs, enc_rnns, dec_convs, dec_rnns
+
+    def _rnn(self, c_in, c_state, h, w, k, s, p):
+        blk = ConvLSTM(device=self.device, in_channels=c_in, enc_channels=c_state, state_h=h, state_w=w,
+                       kernel_size=k, stride=s, padding=p)
+        blk.precision = self.cell_precision
+        return blk

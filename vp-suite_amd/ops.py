@@ -11,6 +11,22 @@ from ._lib import ConvLSTMDesc, check, ptr
 PRECISIONS = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}
 
 
+class KernelProfile:
+    """Opt-in HIP-event bracket around every fused-cell library call (used by bench.py for the live roofline numbers).
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []  # (start_event, end_event, algorithmic_flops, algorithmic_bytes, cell_launches, tag)
+
+    def summary(self):
+        ms = sum(s.elapsed_time(e) for s, e, *_ in self.records)
+        return dict(ms=ms, flops=sum(r[2] for r in self.records), bytes=sum(r[3] for r in self.records),
+                    launches=sum(r[4] for r in self.records))
+
+
+PROFILE = None  # set to a KernelProfile() to collect
+
+
 def _require_gpu(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise _lib.VpxError(f"{what}: tensors must live on the GPU (got device '{t.device}'). The hot path runs only as "
@@ -89,10 +105,18 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
         out = new_channels_last((B, T, Ch, H, Wd), dev)
         hT = new_channels_last((B, Ch, H, Wd), dev)
         cT = new_channels_last((B, Ch, H, Wd), dev)
+        if PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         rc = L.vpx_convlstm_seq_fwd(ctypes.byref(d), ptr(x), ptr(h0c), ptr(c0c), ptr(Wc), ptr(bc), ptr(wci), ptr(wcf),
                                     ptr(wco), ptr(out), ptr(hT), ptr(cT), ptr(reserve), rs_bytes, ptr(ws), ws_bytes,
                                     _stream())
         check(rc, "vpx_convlstm_seq_fwd")
+        if PROFILE is not None:
+            ev1.record()
+            fl, by = convlstm_algorithmic_work(B, T, Cin if x is not None else 0, Ch, H, Wd, kh, kw,
+                                               h0 is not None, peep)
+            PROFILE.records.append((ev0, ev1, fl, by, T, "convlstm_fwd"))
         if need_grad:
             ctx.save_for_backward(x, h0c, c0c, Wc, wci, wcf, wco, out, reserve)
             ctx.desc = d
@@ -128,6 +152,20 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
                                     ws_bytes, _stream())
         check(rc, "vpx_convlstm_seq_bwd")
         return dx, dh0, dc0, dW, db, dwci, dwcf, dwco, None, None, None, None
+
+
+def convlstm_algorithmic_work(B, T, Cin, Ch, H, W, kh, kw, has_h0=True, peephole=True, dt=4):
+    """Algorithmic FLOPs and bytes of a ConvLSTM sequence call: per cell-step and sample
+    flops = 2*4Ch*(Cin+Ch)*k^2*H*W over the operand ranges that are not identically zero;
+    bytes = dt*H*W*(Cin + 2Ch + 2Ch) (read x,h,c; write h,c) + per-step shared weights/bias/peepholes."""
+    flops = 0.0
+    nbytes = 0.0
+    for t in range(T):
+        kc = Cin + (Ch if (t > 0 or has_h0) else 0)
+        flops += 2.0 * 4 * Ch * kc * kh * kw * H * W * B
+        nbytes += dt * H * W * (Cin + 4 * Ch) * B
+        nbytes += dt * (4 * Ch * (Cin + Ch) * kh * kw + 4 * Ch + (3 * Ch * H * W if peephole else 0))
+    return flops, nbytes
 
 
 def convlstm_seq(x, h0, c0, W, b, Wci=None, Wcf=None, Wco=None, *, seq_len, in_channels, gate_order=_lib.GATE_IFGO,
