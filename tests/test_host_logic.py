@@ -1,0 +1,136 @@
+"""CPU-side tests: host logic of the product package, the C-ABI library's exports, and loud failure without a GPU.
+No compute calls into the HIP library here (there is no GPU in the build container)."""
+import ctypes
+import json
+import os
+import pickle
+import re
+
+import pytest
+import torch
+
+import golden_cases as gc
+from golden_util import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(vpx):
+    """Every function declared in include/vpx.h is exported by libvpx_hip.so (and bound in _lib.py)."""
+    hdr = open(os.path.join(ROOT, "include", "vpx.h")).read()
+    declared = sorted(set(re.findall(r"\b(vpx_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    L = vpx._lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/vpx.h but not exported"
+    assert sorted(vpx._lib.EXPORTED_SYMBOLS) == declared
+    assert L.vpx_version() == 100
+
+
+def test_workspace_queries_run_without_gpu(vpx):
+    L = vpx._lib.lib()
+    d = vpx._lib.ConvLSTMDesc(4, 10, 64, 64, 64, 64, 3, 3, 0, 0, 0, 1)
+    assert L.vpx_convlstm_workspace_bytes(ctypes.byref(d)) > 0
+    # reserve = gates (4Ch) + cell states (Ch) per step, fp32
+    assert L.vpx_convlstm_reserve_bytes(ctypes.byref(d)) >= 4 * 10 * 64 * 64 * 64 * 5 * 4
+    bad = vpx._lib.ConvLSTMDesc(4, 10, 64, 64, 64, 64, 2, 2, 0, 0, 0, 0)
+    assert L.vpx_convlstm_workspace_bytes(ctypes.byref(bad)) == 0
+    assert b"odd" in L.vpx_last_error()
+
+
+def test_no_cpu_fallback(vpx):
+    """The product path must fail loudly on CPU tensors instead of silently computing on the host."""
+    from vp_suite_amd.model_blocks import ConvLSTM
+    blk = ConvLSTM("cpu", 3, 8, 12, 10, 3, 1, 1)
+    with pytest.raises(vpx.VpxError, match="no CPU fallback"):
+        blk(torch.rand(2, 4, 3, 12, 10), None, 4)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "vp-suite_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M)
+                assert "/root/reference" not in src
+
+
+@pytest.mark.parametrize("tag,kw", [("tiny", gc.EF_TINY_KW), ("tiny3", gc.EF_TINY3_KW),
+                                    ("full_c1", dict(img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0]))])
+def test_ef_state_dict_contract(vpx, tag, kw):
+    """Parameter names, shapes and ORDER equal the reference's (fixture stores its state_dict table)."""
+    from vp_suite_amd.models import MODEL_CLASSES
+    g = load_golden(f"ef_{tag}")
+    shapes = json.loads(str(g["sd_shapes"]))
+    m = MODEL_CLASSES["convlstm-shi"]("cpu", **kw)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(list(sd[k].shape) == shapes[k] for k in shapes)
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"])
+    # peepholes are real parameters (CPU behaviour of the reference), zero-initialised
+    assert "encoder.rnn1.Wci" in dict(m.named_parameters()) and float(m.encoder.rnn1.Wci.abs().sum()) == 0.0
+
+
+def test_ef_config_and_kwarg_rules(vpx):
+    from vp_suite_amd.models import MODEL_CLASSES
+    EF = MODEL_CLASSES["convlstm-shi"]
+    m = EF("cpu", img_shape=(3, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0])
+    cfg = m.config
+    assert cfg["img_c"] == 3 and cfg["NAME"] == "EF-ConvLSTM (Shi et al.)" and cfg["enc_rnn_state_h"] == [64, 32, 16]
+    assert cfg["dec_rnn_state_h"] == [16, 32, 64]
+    assert not any(isinstance(v, (torch.Tensor, torch.nn.Module)) for v in cfg.values())
+    with pytest.raises(ValueError, match="missing required parameter"):
+        EF("cpu", img_shape=(3, 64, 64), action_size=0)
+    with pytest.raises(ValueError, match="mismatching types"):
+        EF("cpu", img_shape=(3, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0], num_layers="3")
+    with pytest.raises(AttributeError, match="doesn't match"):
+        EF("cpu", img_shape=(3, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0], enc_c=[1, 2, 3])
+    with pytest.raises(AttributeError, match="wrong output size"):
+        EF("cpu", img_shape=(3, 50, 50), action_size=0, tensor_value_range=[0.0, 1.0])
+    # 128x128 (BASELINE config C4) is accepted by the shape calculus
+    m128 = EF("cpu", img_shape=(3, 128, 128), action_size=0, tensor_value_range=[0.0, 1.0])
+    assert m128.enc_rnn_state_h == [128, 64, 32]
+    assert sum(p.numel() for p in m128.parameters()) == 12764003
+
+
+def test_model_is_picklable_whole(vpx):
+    """The reference checkpoints by pickling the whole module (vpsuite.py:394)."""
+    from vp_suite_amd.models import MODEL_CLASSES
+    m = MODEL_CLASSES["convlstm-shi"]("cpu", **gc.EF_TINY_KW)
+    m2 = pickle.loads(pickle.dumps(m))
+    assert list(m2.state_dict().keys()) == list(m.state_dict().keys())
+
+
+def test_unpack_data_and_mse(vpx):
+    from vp_suite_amd.measure import PredictionLossProvider, mse_measure
+    from vp_suite_amd.models import MODEL_CLASSES
+    m = MODEL_CLASSES["convlstm-shi"]("cpu", **gc.EF_TINY_KW)
+    frames = torch.rand(2, 6, 1, 16, 16)
+    data = {"frames": frames, "actions": torch.zeros(2, 5, 0)}
+    cfg = {"device": "cpu", "context_frames": 3, "pred_frames": 2}
+    x, y, _ = m.unpack_data(data, cfg)
+    assert x.shape == (2, 3, 1, 16, 16) and torch.equal(y, frames[:, 3:5])
+    xr, yr, _ = m.unpack_data(data, cfg, reverse=True)
+    assert torch.equal(xr, torch.flip(frames, dims=[1])[:, :3])
+    xc, yc, _ = m.unpack_data(data, cfg, complete=True)
+    assert xc.shape[1] == 5 and torch.equal(yc, frames[:, 3:5])
+    a, b = torch.rand(2, 3, 1, 4, 4), torch.rand(2, 3, 1, 4, 4)
+    want = ((a - b) ** 2).sum(dim=(2, 3, 4)).mean()
+    assert torch.allclose(mse_measure(a, b), want)
+    disp, total = PredictionLossProvider({"device": "cpu", "losses_and_scales": {"mse": 2.0}}).get_losses(a, b)
+    assert torch.allclose(total, 2 * want) and torch.allclose(disp["mse"], want)
+    with pytest.raises(ValueError):
+        mse_measure(a[0], b[0])
+
+
+def test_channels_last_helpers(vpx):
+    t = torch.rand(2, 3, 5, 4, 6)
+    cl = vpx.ops.to_channels_last(t)
+    assert cl.shape == t.shape and torch.equal(cl, t) and vpx.ops.is_channels_last(cl)
+    assert cl.permute(0, 1, 3, 4, 2).is_contiguous()
+    n = vpx.ops.new_channels_last((2, 3, 5, 4, 6), "cpu")
+    assert n.shape == t.shape and vpx.ops.is_channels_last(n)
+    fl, by = vpx.ops.convlstm_algorithmic_work(1, 1, 64, 64, 64, 64, 3, 3)
+    assert abs(fl - 2.416e9) < 1e7  # BASELINE.md §4 headline cell: 2.416 GFLOP per sample-step
+    assert abs(by - (5.243e6 + 4.326e6)) < 2e4
