@@ -124,3 +124,106 @@ def test_conv2d_same_vs_torch(vpx, dev):
         ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=k // 2).float()
         y = vpx.ops.conv2d_same(x.to(dev), w.to(dev), b.to(dev))
         assert _relmax(y, ref) < RTOL
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BPTT
+# ------------------------------------------------------------------------------------------------------------------
+GRTOL = 2e-5  # gradients: relative to the tensor's max magnitude
+
+
+@pytest.mark.parametrize("tag", ["tiny", "k5"])
+@pytest.mark.parametrize("mode", ["full", "states", "noinput"])
+def test_hzzone_block_bwd_vs_golden(vpx, dev, tag, mode):
+    Cin, Ch, H, W, k, B, T, _ = gc.HZZONE_CASES[tag]
+    inp = {n: v.to(dev) for n, v in gc.hzzone_inputs(tag, Cin, Ch, H, W, k, B, T).items()}
+    g = load_golden(f"hzzone_{tag}_{mode}")
+    leaves = {n: inp[n].clone().requires_grad_(True) for n in ("x", "h0", "c0", "W", "b", "Wci", "Wcf", "Wco")}
+    x = None if mode == "noinput" else leaves["x"]
+    h0 = None if mode == "full" else leaves["h0"]
+    c0 = None if mode == "full" else leaves["c0"]
+    out, hT, cT = vpx.ops.convlstm_seq(x, h0, c0, leaves["W"], leaves["b"], leaves["Wci"], leaves["Wcf"], leaves["Wco"],
+                                       seq_len=T, in_channels=Cin)
+    assert _relmax(out, g["out"]) < RTOL
+    loss = (out * inp["g_out"]).sum() + (hT * inp["g_hT"]).sum() + (cT * inp["g_cT"]).sum()
+    loss.backward()
+    names = {"dW": "W", "db": "b", "dWci": "Wci", "dWcf": "Wcf", "dWco": "Wco", "dx": "x", "dh0": "h0", "dc0": "c0"}
+    for gname, lname in names.items():
+        if gname in g:
+            assert leaves[lname].grad is not None, gname
+            assert _relmax(leaves[lname].grad, g[gname]) < GRTOL, gname
+
+
+@pytest.mark.parametrize("tag", list(gc.NDRPLZ_CELL_CASES))
+def test_ndrplz_cell_bwd_vs_golden(vpx, dev, tag):
+    Cin, Ch, H, W, kh, kw, bias, B = gc.NDRPLZ_CELL_CASES[tag]
+    inp = {n: v.to(dev) for n, v in gc.ndrplz_cell_inputs(tag, Cin, Ch, H, W, kh, kw, bias, B).items()}
+    g = load_golden(f"ndrplz_cell_{tag}")
+    lv = {n: inp[n].clone().requires_grad_(True) for n in ("x", "h", "c", "W", "b")}
+    _, hT, cT = vpx.ops.convlstm_seq(lv["x"][:, None], lv["h"], lv["c"], lv["W"], lv["b"] if bias else None,
+                                     seq_len=1, in_channels=Cin, gate_order=vpx._lib.GATE_IFOG)
+    ((hT * inp["g_h"]).sum() + (cT * inp["g_c"]).sum()).backward()
+    assert _relmax(lv["x"].grad, g["dx"]) < GRTOL and _relmax(lv["h"].grad, g["dh"]) < GRTOL
+    assert _relmax(lv["c"].grad, g["dc"]) < GRTOL and _relmax(lv["W"].grad, g["dW"]) < GRTOL
+    if bias:
+        assert _relmax(lv["b"].grad, g["db"]) < GRTOL
+
+
+@pytest.mark.parametrize("Cin,Ch,H,W", [(16, 64, 64, 64), (96, 96, 16, 16), (96, 64, 32, 32)])
+def test_real_block_shapes_bwd_vs_oracle(vpx, dev, Cin, Ch, H, W):
+    """Real block shapes: gradients against autograd through the pinned torch restatement (fp32 CPU)."""
+    from oracle import torch_ref as tr
+    B, T, k = 2, 3, 3
+    tag = f"realbwd.{Cin}.{Ch}.{H}"
+    P = {"W": seeded_randn((4 * Ch, Cin + Ch, k, k), name_seed(tag + "W"), 1.0 / np.sqrt((Cin + Ch) * 9)),
+         "b": seeded_randn((4 * Ch,), name_seed(tag + "b"), 0.1),
+         "Wci": seeded_randn((1, Ch, H, W), name_seed(tag + "ci"), 0.1),
+         "Wcf": seeded_randn((1, Ch, H, W), name_seed(tag + "cf"), 0.1),
+         "Wco": seeded_randn((1, Ch, H, W), name_seed(tag + "co"), 0.1),
+         "x": seeded_rand((B, T, Cin, H, W), name_seed(tag + "x")),
+         "h0": seeded_randn((B, Ch, H, W), name_seed(tag + "h0"), 0.5),
+         "c0": seeded_randn((B, Ch, H, W), name_seed(tag + "c0"), 0.5)}
+    g_out = seeded_randn((B, T, Ch, H, W), name_seed(tag + "go"))
+    g_c = seeded_randn((B, Ch, H, W), name_seed(tag + "gc"))
+    ref = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+    ro, (rh, rc) = tr.convlstm_hzzone_seq(ref["x"], (ref["h0"], ref["c0"]), T, ref["W"], ref["b"], ref["Wci"],
+                                          ref["Wcf"], ref["Wco"], padding=1)
+    ((ro * g_out).sum() + (rc * g_c).sum()).backward()
+    lv = {n: v.to(dev).requires_grad_(True) for n, v in P.items()}
+    out, hT, cT = vpx.ops.convlstm_seq(lv["x"], lv["h0"], lv["c0"], lv["W"], lv["b"], lv["Wci"], lv["Wcf"], lv["Wco"],
+                                       seq_len=T, in_channels=Cin)
+    ((out * g_out.to(dev)).sum() + (cT * g_c.to(dev)).sum()).backward()
+    for n in P:
+        assert _relmax(lv[n].grad, ref[n].grad) < 5e-5, n
+
+
+def test_c_abi_nchw_bwd(vpx, dev):
+    """Forward + backward through the raw C ABI on reference-layout (NCHW) buffers."""
+    L = vpx._lib.lib()
+    Cin, Ch, H, W, k, B, T, _ = gc.HZZONE_CASES["tiny"]
+    inp = {n: v.to(dev).contiguous() for n, v in gc.hzzone_inputs("tiny", Cin, Ch, H, W, k, B, T).items()}
+    g = load_golden("hzzone_tiny_states")
+    d = vpx._lib.ConvLSTMDesc(B, T, Cin, Ch, H, W, k, k, vpx._lib.GATE_IFGO, vpx._lib.LAYOUT_NCHW, vpx._lib.PREC_F32,
+                              vpx._lib.FLAG_SAVE_FOR_BWD)
+    ws_bytes = L.vpx_convlstm_workspace_bytes(ctypes.byref(d))
+    rs_bytes = L.vpx_convlstm_reserve_bytes(ctypes.byref(d))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    rs = torch.empty(rs_bytes, dtype=torch.uint8, device=dev)
+    out = torch.empty(B, T, Ch, H, W, device=dev)
+    hT, cT = torch.empty(B, Ch, H, W, device=dev), torch.empty(B, Ch, H, W, device=dev)
+    p = vpx._lib.ptr
+    rc = L.vpx_convlstm_seq_fwd(ctypes.byref(d), p(inp["x"]), p(inp["h0"]), p(inp["c0"]), p(inp["W"]), p(inp["b"]),
+                                p(inp["Wci"]), p(inp["Wcf"]), p(inp["Wco"]), p(out), p(hT), p(cT), p(rs), rs_bytes,
+                                p(ws), ws_bytes, None)
+    assert rc == 0, L.vpx_last_error()
+    G = {n: torch.empty_like(inp[m]) for n, m in (("dx", "x"), ("dh0", "h0"), ("dc0", "c0"), ("dW", "W"), ("db", "b"),
+                                                   ("dWci", "Wci"), ("dWcf", "Wcf"), ("dWco", "Wco"))}
+    rc = L.vpx_convlstm_seq_bwd(ctypes.byref(d), p(inp["x"]), p(inp["h0"]), p(inp["c0"]), p(inp["W"]), p(inp["Wci"]),
+                                p(inp["Wcf"]), p(inp["Wco"]), p(out), p(rs), rs_bytes, p(inp["g_out"]), p(inp["g_hT"]),
+                                p(inp["g_cT"]), p(G["dx"]), p(G["dh0"]), p(G["dc0"]), p(G["dW"]), p(G["db"]),
+                                p(G["dWci"]), p(G["dWcf"]), p(G["dWco"]), p(ws), ws_bytes, None)
+    assert rc == 0, L.vpx_last_error()
+    torch.cuda.synchronize()
+    assert _relmax(out, g["out"]) < RTOL
+    for n in G:
+        assert _relmax(G[n], g[n]) < GRTOL, n

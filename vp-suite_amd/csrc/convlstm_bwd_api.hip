@@ -1,0 +1,174 @@
+// convlstm_bwd_api.hip — vpx_convlstm_seq_bwd: BPTT through the fused ConvLSTM sequence (include/vpx.h).
+// Per step (reverse time): gate-backward (pointwise) -> data-gradient conv (same implicit-GEMM kernel as the forward,
+// weights packed transposed + tap-flipped); after the loop one weight-gradient launch over all (t, b) images, a
+// K-slice reduction into the reference's OIHW layout, and a column sum for the bias gradient.
+#include "vpx_host.h"
+
+using namespace vpx;
+
+extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, const float* h0, const float* c0,
+                                    const float* W, const float* Wci, const float* Wcf, const float* Wco,
+                                    const float* out, const void* reserve, size_t reserve_bytes, const float* dout,
+                                    const float* dhT, const float* dcT, float* dx, float* dh0, float* dc0, float* dW,
+                                    float* db, float* dWci, float* dWcf, float* dWco, void* workspace,
+                                    size_t workspace_bytes, void* stream_) {
+    int rc = check_convlstm_desc(d);
+    if (rc != VPX_OK) return rc;
+    ConvLSTMLayout L;
+    if ((rc = convlstm_layout(d, L)) != VPX_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!(d->flags & VPX_FLAG_SAVE_FOR_BWD)) { set_error("vpx_convlstm_seq_bwd: desc lacks VPX_FLAG_SAVE_FOR_BWD"); return VPX_ERR_ARG; }
+    if (!W || !out || !reserve) { set_error("vpx_convlstm_seq_bwd: W, out and reserve must not be NULL"); return VPX_ERR_ARG; }
+    if (reserve_bytes < vpx_convlstm_reserve_bytes(d)) { set_error("vpx_convlstm_seq_bwd: reserve too small"); return VPX_ERR_WORKSPACE; }
+    if (!workspace || workspace_bytes < vpx_convlstm_workspace_bytes(d)) {
+        set_error("vpx_convlstm_seq_bwd: workspace too small (%zu < %zu)", workspace_bytes, vpx_convlstm_workspace_bytes(d));
+        return VPX_ERR_WORKSPACE;
+    }
+    const bool peep = Wci || Wcf || Wco;
+    if (peep && !(Wci && Wcf && Wco)) { set_error("vpx_convlstm_seq_bwd: peephole tensors must be given together"); return VPX_ERR_ARG; }
+    const bool dpeep = dWci || dWcf || dWco;
+    if (dpeep && !(dWci && dWcf && dWco && peep)) { set_error("vpx_convlstm_seq_bwd: peephole gradients must be requested together"); return VPX_ERR_ARG; }
+
+    const int B = d->B, T = d->T, Cin = d->Cin, Ch = d->Ch, H = d->H, Wd = d->W;
+    const int N4 = 4 * Ch, Ct = Cin + Ch;
+    const size_t HW = (size_t)H * Wd;
+    Carver ws{(char*)workspace, 0, workspace_bytes};
+    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    float* wpk = ws.take(packed_weight_bytes(L.d_tiles_full, L.d_chunks) / sizeof(float));
+    float* dG_all = ws.take((size_t)T * L.n_state * 4);
+    float* dh_buf = ws.take(L.n_state);
+    float* dc_buf = ws.take(L.n_state);
+    float* slabs = ws.take(L.slab_floats);
+
+    // ---- layout adaptation ----
+    const float *xn = x, *h0n = h0, *c0n = c0, *outn = out, *doutn = dout, *dhTn = dhT, *dcTn = dcT;
+    const float *wci = Wci, *wcf = Wcf, *wco = Wco;
+    float *dxn = dx, *dh0n = dh0, *dc0n = dc0, *dwci = dWci, *dwcf = dWcf, *dwco = dWco;
+    if (d->layout == VPX_LAYOUT_NCHW) {
+        float* bx = ws.take(L.n_x);
+        float* bdx = ws.take(L.n_x);
+        float* bout = ws.take(L.n_out);
+        float* bdout = ws.take(L.n_out);
+        float* st[6];
+        for (auto& p : st) p = ws.take(L.n_state);
+        float* pp[6];
+        for (auto& p : pp) p = ws.take(L.n_peep);
+        if (x) { VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B * T, Cin, H, Wd, stream)); xn = bx; }
+        VPX_CHECK_HIP(launch_nchw_to_nhwc(out, bout, B * T, Ch, H, Wd, stream)); outn = bout;
+        if (dout) { VPX_CHECK_HIP(launch_nchw_to_nhwc(dout, bdout, B * T, Ch, H, Wd, stream)); doutn = bdout; }
+        if (h0) { VPX_CHECK_HIP(launch_nchw_to_nhwc(h0, st[0], B, Ch, H, Wd, stream)); h0n = st[0]; }
+        if (c0) { VPX_CHECK_HIP(launch_nchw_to_nhwc(c0, st[1], B, Ch, H, Wd, stream)); c0n = st[1]; }
+        if (dhT) { VPX_CHECK_HIP(launch_nchw_to_nhwc(dhT, st[2], B, Ch, H, Wd, stream)); dhTn = st[2]; }
+        if (dcT) { VPX_CHECK_HIP(launch_nchw_to_nhwc(dcT, st[3], B, Ch, H, Wd, stream)); dcTn = st[3]; }
+        if (dh0) dh0n = st[4];
+        if (dc0) dc0n = st[5];
+        if (dx) dxn = bdx;
+        if (peep) {
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(Wci, pp[0], 1, Ch, H, Wd, stream));
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(Wcf, pp[1], 1, Ch, H, Wd, stream));
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(Wco, pp[2], 1, Ch, H, Wd, stream));
+            wci = pp[0]; wcf = pp[1]; wco = pp[2];
+        }
+        if (dpeep) { dwci = pp[3]; dwcf = pp[4]; dwco = pp[5]; }
+    }
+
+    const float* gates_all = (const float*)reserve;
+    const float* cs_all = (const float*)((const char*)reserve + align256((size_t)T * L.n_state * 4 * sizeof(float)));
+    int gp[4];
+    gate_positions(d->gate_order, gp);
+
+    if (dpeep) {
+        VPX_CHECK_HIP(hipMemsetAsync(dwci, 0, L.n_peep * sizeof(float), stream));
+        VPX_CHECK_HIP(hipMemsetAsync(dwcf, 0, L.n_peep * sizeof(float), stream));
+        VPX_CHECK_HIP(hipMemsetAsync(dwco, 0, L.n_peep * sizeof(float), stream));
+    }
+
+    // ---- data-gradient weights: contraction over the 4Ch gate rows, outputs over [x | h] (or only h) columns ----
+    const bool need_dx = dxn && xn;
+    const int col_start = need_dx ? 0 : Cin;
+    const int n_out = need_dx ? Ct : Ch;
+    const int d_tiles = (n_out + NT - 1) / NT;
+    {
+        PackDesc pd{};
+        pd.seg[0] = PackSeg{W, (long long)Ct * L.taps, L.taps, 0, N4};
+        memcpy(pd.stage, L.d_stage, sizeof(ConvStage) * L.d_nstage);
+        pd.nstage = L.d_nstage; pd.chunks_total = L.d_chunks; pd.n_tiles = d_tiles; pd.taps = L.taps; pd.NG = 4;
+        for (int g = 0; g < 4; ++g) { pd.rowbase[g] = col_start + g * 32; pd.goff[g] = g * 32; }
+        pd.tile_stride = NT; pd.nch = n_out; pd.transposed = 1; pd.flip = 1;
+        VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+    }
+
+    for (int t = T - 1; t >= 0; --t) {
+        GateBwdArgs ga{};
+        ga.B = B; ga.HW = (int)HW; ga.Ch = Ch;
+        memcpy(ga.gate_pos, gp, sizeof(gp));
+        ga.gates = gates_all + (size_t)t * L.n_state * 4;
+        ga.c_t = cs_all + (size_t)t * L.n_state;
+        ga.c_prev = (t > 0) ? cs_all + (size_t)(t - 1) * L.n_state : c0n;
+        ga.dh_in = (t == T - 1) ? dhTn : dh_buf;
+        ga.dout = doutn ? doutn + (size_t)t * HW * Ch : nullptr;
+        ga.dout_bstride = (long long)((size_t)T * HW * Ch);
+        ga.dc_in = (t == T - 1) ? dcTn : dc_buf;
+        ga.dc_out = (t == 0 && dc0n) ? dc0n : dc_buf;
+        ga.wci = wci; ga.wcf = wcf; ga.wco = wco;
+        ga.dwci = dpeep ? dwci : nullptr; ga.dwcf = dpeep ? dwcf : nullptr; ga.dwco = dpeep ? dwco : nullptr;
+        ga.dG = dG_all + (size_t)t * L.n_state * 4;
+        VPX_CHECK_HIP(launch_gate_bwd(ga, stream));
+
+        float* dh_target = (t > 0) ? dh_buf : dh0n;  // at t = 0 the recurrent gradient is dL/dh0 (if requested)
+        if (need_dx || dh_target) {
+            ConvPlan P{};
+            P.B = B; P.H = H; P.W = Wd; P.kh = d->kh; P.kw = d->kw;
+            P.tiles_x = (Wd + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_H - 1) / TILE_H;
+            P.nseg = 1;
+            P.seg[0] = ConvSeg{ga.dG, (long long)(HW * N4), N4, 0};
+            P.nstage = L.d_nstage;
+            memcpy(P.stage, L.d_stage, sizeof(ConvStage) * L.d_nstage);
+            P.chunks_total = L.d_chunks;
+            P.a_bytes = conv_a_bytes(L.d_stage, L.d_nstage, d->kh, d->kw);
+            P.wpk = wpk;
+            PlainEpiArgs ea{};
+            ea.Co = n_out;
+            ea.split = need_dx ? Cin : 0;
+            ea.out0 = need_dx ? dxn + (size_t)t * HW * Cin : nullptr;
+            ea.bstride0 = (long long)((size_t)T * HW * Cin); ea.ld0 = Cin;
+            ea.out1 = dh_target; ea.bstride1 = (long long)(HW * Ch); ea.ld1 = Ch;
+            VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, d_tiles, stream));
+        }
+    }
+    if (dxn && !xn) { set_error("vpx_convlstm_seq_bwd: dx requested but x is NULL"); return VPX_ERR_ARG; }
+
+    // ---- weight gradient over all (t, b) images ----
+    if (dW) {
+        VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, L.slab_floats * sizeof(float), stream));
+        WgradArgs wa{};
+        wa.T = T; wa.B = B; wa.H = H; wa.W = Wd; wa.HW = (int)HW; wa.kh = d->kh; wa.kw = d->kw;
+        wa.tiles_x = (Wd + TILE_W - 1) / TILE_W; wa.tiles_y = (H + TILE_H - 1) / TILE_H;
+        wa.N4 = N4; wa.Cin = Cin; wa.Ch = Ch; wa.Ct = Ct;
+        wa.dG = dG_all;
+        wa.x = xn; wa.x_bstride = (long long)((size_t)T * HW * Cin); wa.x_tstride = (long long)(HW * Cin);
+        wa.hseq = outn; wa.h_bstride = (long long)((size_t)T * HW * Ch); wa.h_tstride = (long long)(HW * Ch);
+        wa.h0 = h0n;
+        wa.n_ctiles = 0;
+        for (int i = 0; i < L.n_ctiles; ++i)
+            if (L.ct[i].seg == 1 || xn) wa.ct[wa.n_ctiles++] = L.ct[i];  // no input tensor: its columns stay zero
+        wa.slabs = slabs;
+        VPX_CHECK_HIP(launch_wgrad(wa, L.n_slices, stream));
+        VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dW, L.n_slices, L.taps, N4, Ct, stream));
+    }
+    if (db) {
+        VPX_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)N4 * sizeof(float), stream));
+        VPX_CHECK_HIP(launch_colsum(dG_all, db, (long long)T * B * HW, N4, stream));
+    }
+    if (d->layout == VPX_LAYOUT_NCHW) {
+        if (dx) VPX_CHECK_HIP(launch_nhwc_to_nchw(dxn, dx, B * T, Cin, H, Wd, stream));
+        if (dh0) VPX_CHECK_HIP(launch_nhwc_to_nchw(dh0n, dh0, B, Ch, H, Wd, stream));
+        if (dc0) VPX_CHECK_HIP(launch_nhwc_to_nchw(dc0n, dc0, B, Ch, H, Wd, stream));
+        if (dpeep) {
+            VPX_CHECK_HIP(launch_nhwc_to_nchw(dwci, dWci, 1, Ch, H, Wd, stream));
+            VPX_CHECK_HIP(launch_nhwc_to_nchw(dwcf, dWcf, 1, Ch, H, Wd, stream));
+            VPX_CHECK_HIP(launch_nhwc_to_nchw(dwco, dWco, 1, Ch, H, Wd, stream));
+        }
+    }
+    return VPX_OK;
+}

@@ -1,0 +1,269 @@
+// lstm_bwd.hip — BPTT kernels of the ConvLSTM block (the reference gets these from autograd over the unrolled python
+// loop, conv_lstm_hzzone.py:52-70; here they are explicit):
+//   convlstm_gate_bwd_kernel  HBM-bound: d(pre-activations) from (dh, dc), carries dc, reduces peephole grads over b
+//   wgrad_kernel              dW partials: M = 64 gate rows, N = 64 input channels, all taps of a tap group at once,
+//                             K = pixels of the (t, b, tile) work items of one K-slice; fp32 MFMA 32x32x2
+//   wgrad_reduce_kernel       sums the K-slices and writes the reference's OIHW layout
+//   colsum_kernel             bias gradient
+#include "vpx_internal.h"
+
+namespace vpx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void convlstm_gate_bwd_kernel(const GateBwdArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int HW = a.HW, Ch = a.Ch;
+    if (idx >= HW * Ch) return;
+    const int pix = idx / Ch, ch = idx - pix * Ch;
+    const size_t pc = (size_t)pix * Ch + ch;
+    float wci = 0.f, wcf = 0.f, wco = 0.f;
+    const bool peep = a.wci != nullptr;
+    if (peep) { wci = a.wci[pc]; wcf = a.wcf[pc]; wco = a.wco[pc]; }
+    float dpi = 0.f, dpf = 0.f, dpo = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        const size_t s = ((size_t)b * HW + pix) * Ch + ch;
+        const float* gs = a.gates + ((size_t)b * HW + pix) * 4 * Ch + ch;
+        const float i_ = gs[0], f_ = gs[Ch], g_ = gs[2 * Ch], o_ = gs[3 * Ch];
+        const float cn = a.c_t[s];
+        const float cp = a.c_prev ? a.c_prev[s] : 0.0f;
+        float dht = a.dh_in ? a.dh_in[s] : 0.0f;
+        if (a.dout) dht += a.dout[(size_t)b * a.dout_bstride + pc];
+        const float tc = tanhf(cn);
+        const float dao = dht * tc * o_ * (1.0f - o_);
+        float dcn = (a.dc_in ? a.dc_in[s] : 0.0f) + dht * o_ * (1.0f - tc * tc);
+        if (peep) { dcn += dao * wco; dpo += dao * cn; }
+        const float dai = dcn * g_ * i_ * (1.0f - i_);
+        const float daf = dcn * cp * f_ * (1.0f - f_);
+        const float dag = dcn * i_ * (1.0f - g_ * g_);
+        float dcp = dcn * f_;
+        if (peep) { dcp += dai * wci + daf * wcf; dpi += dai * cp; dpf += daf * cp; }
+        a.dc_out[s] = dcp;
+        float* dg = a.dG + ((size_t)b * HW + pix) * 4 * Ch + ch;
+        dg[a.gate_pos[0] * Ch] = dai;
+        dg[a.gate_pos[1] * Ch] = daf;
+        dg[a.gate_pos[2] * Ch] = dag;
+        dg[a.gate_pos[3] * Ch] = dao;
+    }
+    if (peep && a.dwci) {  // single owner per (pix, ch): plain accumulate over the time steps
+        a.dwci[pc] += dpi;
+        a.dwcf[pc] += dpf;
+        a.dwco[pc] += dpo;
+    }
+}
+
+hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s) {
+    const int n = a.HW * a.Ch;
+    hipLaunchKernelGGL(convlstm_gate_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// column sums of a [rows][cols] matrix, atomically added to out[cols] (bias gradient)
+__global__ void colsum_kernel(const float* __restrict__ m, float* __restrict__ out, long long rows, int cols,
+                              long long rows_per_block) {
+    const long long r0 = blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float acc = 0.f;
+        for (long long r = r0; r < r1; ++r) acc += m[r * cols + c];
+        atomicAdd(out + c, acc);
+    }
+}
+
+hipError_t launch_colsum(const float* m, float* out, long long rows, int cols, hipStream_t s) {
+    int blocks = 512;
+    if (rows < blocks) blocks = (int)rows;
+    const long long rpb = (rows + blocks - 1) / blocks;
+    blocks = (int)((rows + rpb - 1) / rpb);
+    int threads = cols < 256 ? ((cols + 63) / 64 * 64) : 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(threads), 0, s, m, out, rows, cols, rpb);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient. Work item = (t, b, spatial tile); slice `blockIdx.y` owns items slice, slice + n_slices, ...
+// LDS: dG tile [128 px][64 rows] (32 KiB) + activation halo tile [halo positions][64 ch].
+// Each wave owns a 32 (rows) x 32 (channels) output block for up to WG_MAXT taps: acc[tap] += dG^T (px-contracted) A_tap.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MAXT>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int n_ct = a.n_ctiles;
+    const int ct_id = blockIdx.x % n_ct;
+    const int nt_id = blockIdx.x / n_ct;
+    const WgradCTile ct = a.ct[ct_id];
+    const int tap0 = blockIdx.z * MAXT;
+    int ntaps = a.kh * a.kw - tap0;
+    if (ntaps > MAXT) ntaps = MAXT;
+    const int halo_w = TILE_W + a.kw - 1, halo_h = TILE_H + a.kh - 1, npos = halo_w * halo_h;
+    const int ph = a.kh / 2, pw = a.kw / 2;
+    float* G_lds = reinterpret_cast<float*>(smem);                 // [128][64]
+    float* A_lds = reinterpret_cast<float*>(smem + 128 * 64 * 4);  // [npos][64]
+
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // per-tap LDS offsets (in floats) of the shifted activation pixel, relative to (py*halo_w + px)
+    int tapoff[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int tp = tap0 + t;
+        const int dy = tp / a.kw, dx = tp - dy * a.kw;
+        tapoff[t] = (dy * halo_w + dx) * 64;
+    }
+
+    const int tiles = a.tiles_x * a.tiles_y;
+    const long long n_items = (long long)a.T * a.B * tiles;
+    const int n0 = nt_id * 64;  // first gate row of this workgroup
+    for (long long w = blockIdx.y; w < n_items; w += gridDim.y) {
+        const int tile = (int)(w % tiles);
+        const long long tb = w / tiles;
+        const int b = (int)(tb % a.B);
+        const int t = (int)(tb / a.B);
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+        // activation source of this item
+        const float* src;
+        int C;
+        if (ct.seg == 0) {
+            src = a.x + (size_t)b * a.x_bstride + (size_t)t * a.x_tstride;
+            C = a.Cin;
+        } else {
+            C = a.Ch;
+            if (t > 0) src = a.hseq + (size_t)b * a.h_bstride + (size_t)(t - 1) * a.h_tstride;
+            else if (a.h0) src = a.h0 + (size_t)b * a.HW * a.Ch;
+            else continue;  // zero hidden state at t = 0 contributes nothing (uniform branch)
+        }
+        const float* dg = a.dG + ((size_t)t * a.B + b) * a.HW * a.N4;
+        __syncthreads();
+        // ---- stage dG tile: 128 pixels x 64 rows ----
+        if ((a.N4 & 3) == 0) {
+            for (int v = tid; v < 128 * 16; v += NTHREADS) {
+                const int p = v >> 4, q4 = v & 15;
+                const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
+                const int n = n0 + q4 * 4;
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if (gy < a.H && gx < a.W && n < a.N4)
+                    val = *reinterpret_cast<const f32x4*>(dg + ((size_t)gy * a.W + gx) * a.N4 + n);
+                *reinterpret_cast<f32x4*>(G_lds + p * 64 + q4 * 4) = val;
+            }
+        } else {
+            for (int e = tid; e < 128 * 64; e += NTHREADS) {
+                const int p = e >> 6, q = e & 63;
+                const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
+                const int n = n0 + q;
+                float val = 0.f;
+                if (gy < a.H && gx < a.W && n < a.N4) val = dg[((size_t)gy * a.W + gx) * a.N4 + n];
+                G_lds[p * 64 + q] = val;
+            }
+        }
+        // ---- stage activation halo tile: npos x 64 channels [ct.c0, ct.c0 + 64) ----
+        if ((C & 3) == 0) {
+            for (int v = tid; v < npos * 16; v += NTHREADS) {
+                const int pos = v >> 4, q4 = v & 15;
+                const int hy = pos / halo_w, hx = pos - hy * halo_w;
+                const int gy = y0 - ph + hy, gx = x0 - pw + hx;
+                const int c = ct.c0 + q4 * 4;
+                f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < C)
+                    val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * a.W + gx) * C + c);
+                *reinterpret_cast<f32x4*>(A_lds + pos * 64 + q4 * 4) = val;
+            }
+        } else {
+            for (int e = tid; e < npos * 64; e += NTHREADS) {
+                const int pos = e >> 6, q = e & 63;
+                const int hy = pos / halo_w, hx = pos - hy * halo_w;
+                const int gy = y0 - ph + hy, gx = x0 - pw + hx;
+                const int c = ct.c0 + q;
+                float val = 0.f;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < C) val = src[((size_t)gy * a.W + gx) * C + c];
+                A_lds[pos * 64 + q] = val;
+            }
+        }
+        __syncthreads();
+        // ---- contraction over the tile's 128 pixels, 2 per MFMA (lane half hh takes pixel 2*kk + hh) ----
+        const float* gp = G_lds + wn * 32 + i;
+        const float* ap = A_lds + wc * 32 + i;
+#pragma unroll 4
+        for (int kk = 0; kk < 64; ++kk) {
+            const int p = 2 * kk + hh;
+            const float av = gp[p * 64];
+            const int abase = ((p >> 4) * halo_w + (p & 15)) * 64;
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                if (t < ntaps) {
+                    const float bv = ap[abase + tapoff[t]];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- slab[slice][tap][row][Ct] = acc (each element written exactly once per launch) ----
+    const int col = ct.cglobal + wc * 32 + i;  // channel inside the concatenated [x | h] axis
+    const bool col_ok = (wc * 32 + i) < ct.cn;
+    float* slab = a.slabs + (size_t)blockIdx.y * a.kh * a.kw * a.N4 * a.Ct;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t >= ntaps) continue;
+        float* st = slab + (size_t)(tap0 + t) * a.N4 * a.Ct;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (n < a.N4 && col_ok) st[(size_t)n * a.Ct + col] = acc[t][r];
+        }
+    }
+}
+
+hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s) {
+    constexpr int MAXT = 9;
+    const int taps = a.kh * a.kw;
+    const int groups = (taps + MAXT - 1) / MAXT;
+    const int npos = (TILE_H + a.kh - 1) * (TILE_W + a.kw - 1);
+    const size_t lds = 128 * 64 * 4 + (size_t)npos * 64 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<MAXT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(((a.N4 + 63) / 64) * a.n_ctiles, n_slices, groups);
+    hipLaunchKernelGGL(wgrad_kernel<MAXT>, grid, dim3(NTHREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+// dW[n][c][tap] (OIHW, ld = Ct*taps) = sum_s slab[s][tap][n][c]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dW, int n_slices, int taps,
+                                    int N4, int Ct) {
+    const long long total = (long long)N4 * Ct * taps;
+    const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    // thread order follows the slab layout (coalesced reads); the OIHW write is strided but tiny
+    const int c = (int)(e % Ct);
+    long long r = e / Ct;
+    const int n = (int)(r % N4);
+    const int tap = (int)(r / N4);
+    float acc = 0.f;
+    const size_t slab_sz = (size_t)taps * N4 * Ct;
+    for (int s = 0; s < n_slices; ++s) acc += slabs[(size_t)s * slab_sz + e];
+    dW[((size_t)n * Ct + c) * taps + tap] = acc;
+}
+
+hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s) {
+    const long long total = (long long)N4 * Ct * taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
+                       taps, N4, Ct);
+    return hipGetLastError();
+}
+
+}  // namespace vpx

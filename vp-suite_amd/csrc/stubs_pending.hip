@@ -2,10 +2,6 @@
 #include "vpx_internal.h"
 using namespace vpx;
 extern "C" {
-int vpx_convlstm_seq_bwd(const vpx_convlstm_desc*, const float*, const float*, const float*, const float*, const float*,
-                         const float*, const float*, const float*, const void*, size_t, const float*, const float*,
-                         const float*, float*, float*, float*, float*, float*, float*, float*, float*, void*, size_t,
-                         void*) { set_error("vpx_convlstm_seq_bwd: not implemented yet"); return VPX_ERR_UNSUPPORTED; }
 size_t vpx_stlstm_workspace_bytes(const vpx_stlstm_desc*) { return 0; }
 size_t vpx_stlstm_reserve_bytes(const vpx_stlstm_desc*) { return 0; }
 int vpx_stlstm_step_fwd(const vpx_stlstm_desc*, const float*, const float*, const float*, const float*, const float*,

@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "vpx_internal.h"
+#include "vpx_host.h"
 
 namespace vpx {
 
@@ -15,79 +15,6 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
-}
-
-static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-
-struct Carver {  // bump allocator over the caller's workspace
-    char* base;
-    size_t off, cap;
-    float* take(size_t nfloat) {
-        float* p = reinterpret_cast<float*>(base + off);
-        off += align256(nfloat * sizeof(float));
-        return p;
-    }
-};
-
-#define VPX_CHECK_HIP(expr)                                                                   \
-    do {                                                                                      \
-        hipError_t e__ = (expr);                                                              \
-        if (e__ != hipSuccess) {                                                              \
-            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
-            return VPX_ERR_LAUNCH;                                                            \
-        }                                                                                     \
-    } while (0)
-
-static void gate_positions(int gate_order, int gp[4]) {
-    gp[0] = 0;
-    gp[1] = 1;
-    if (gate_order == VPX_GATE_IFGO) { gp[2] = 2; gp[3] = 3; }  // logical g at chunk 2, o at chunk 3
-    else { gp[2] = 3; gp[3] = 2; }                             // ndrplz: o at chunk 2, g at chunk 3
-}
-
-static int check_convlstm_desc(const vpx_convlstm_desc* d) {
-    if (!d) { set_error("desc is NULL"); return VPX_ERR_ARG; }
-    if (d->B < 1 || d->T < 1 || d->Cin < 1 || d->Ch < 1 || d->H < 1 || d->W < 1) {
-        set_error("convlstm desc: non-positive dimension (B=%d T=%d Cin=%d Ch=%d H=%d W=%d)", d->B, d->T, d->Cin,
-                  d->Ch, d->H, d->W);
-        return VPX_ERR_ARG;
-    }
-    if (d->kh < 1 || d->kw < 1 || !(d->kh & 1) || !(d->kw & 1) || d->kh > 7 || d->kw > 7) {
-        set_error("convlstm desc: kernel size must be odd and <= 7 (got %dx%d)", d->kh, d->kw);
-        return VPX_ERR_ARG;
-    }
-    if (d->gate_order != VPX_GATE_IFGO && d->gate_order != VPX_GATE_IFOG) {
-        set_error("convlstm desc: unknown gate_order %d", d->gate_order);
-        return VPX_ERR_ARG;
-    }
-    if (d->layout != VPX_LAYOUT_NHWC && d->layout != VPX_LAYOUT_NCHW) {
-        set_error("convlstm desc: unknown layout %d", d->layout);
-        return VPX_ERR_ARG;
-    }
-    if (d->precision != VPX_PREC_F32) {
-        set_error("convlstm desc: precision %d not implemented yet (only VPX_PREC_F32)", d->precision);
-        return VPX_ERR_UNSUPPORTED;
-    }
-    return VPX_OK;
-}
-
-struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
-    int taps, n_tiles, nstage, chunks_total;
-    ConvStage stage[MAX_STAGE];
-    size_t n_state, n_x, n_out, n_peep;
-};
-
-static int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L) {
-    L.taps = d->kh * d->kw;
-    L.n_tiles = (d->Ch + 31) / 32;
-    const int segC[2] = {d->Cin, d->Ch};
-    L.nstage = build_stages(L.stage, &L.chunks_total, segC, 2, L.taps, CS_F32, KC_F32);
-    if (L.nstage < 0) { set_error("convlstm: too many channel stages (Cin=%d Ch=%d)", d->Cin, d->Ch); return VPX_ERR_UNSUPPORTED; }
-    L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
-    L.n_x = (size_t)d->B * d->T * d->H * d->W * d->Cin;
-    L.n_out = (size_t)d->B * d->T * d->H * d->W * d->Ch;
-    L.n_peep = (size_t)d->H * d->W * d->Ch;
-    return VPX_OK;
 }
 
 }  // namespace vpx
@@ -122,11 +49,15 @@ size_t vpx_convlstm_reserve_bytes(const vpx_convlstm_desc* d) {
 size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
     ConvLSTMLayout L;
     if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
-    // forward: packed weights + cell scratch. backward needs more (see convlstm_bwd.hip); report the max of both.
+    // forward: packed weights + cell scratch (+ NCHW staging)
     size_t fwd = align256(packed_weight_bytes(L.n_tiles, L.chunks_total)) + align256(L.n_state * sizeof(float));
     if (d->layout == VPX_LAYOUT_NCHW)
         fwd += align256(L.n_x * 4) + align256(L.n_out * 4) + 4 * align256(L.n_state * 4) + 3 * align256(L.n_peep * 4);
-    return fwd + 256;
+    // backward (only with SAVE_FOR_BWD): packed dgrad weights + dG for all steps + dh/dc carries + wgrad K-slice slabs
+    size_t bwd = 0;
+    if (d->flags & VPX_FLAG_SAVE_FOR_BWD)
+        bwd = convlstm_bwd_workspace_bytes(d, L);
+    return (fwd > bwd ? fwd : bwd) + 256;
 }
 
 int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float* h0, const float* c0,

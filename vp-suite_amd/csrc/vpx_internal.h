@@ -105,6 +105,40 @@ struct PlainEpiArgs {
 };
 hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, int n_tiles, hipStream_t s);
 
+// ---- BPTT pieces (lstm_bwd.hip) ----
+struct GateBwdArgs {
+    int B, HW, Ch;
+    int gate_pos[4];          // where logical (i,f,g,o) live in the reference's 4Ch axis: dG is written in THAT order
+    const float* gates;       // [B,HW,4Ch] saved post-activation (i,f,g,o) of this step
+    const float* c_t;         // [B,HW,Ch] cell state after this step
+    const float* c_prev;      // cell state before this step, or null (zeros)
+    const float* dh_in;       // recurrent dh flowing in from step t+1 (or dhT), or null
+    const float* dout;        // dL/d out[:, t] slab or null
+    long long dout_bstride;
+    const float* dc_in;       // dc flowing in (or dcT), or null
+    float* dc_out;            // dc flowing out to step t-1
+    const float* wci; const float* wcf; const float* wco;  // peepholes [HW,Ch] or null
+    float* dwci; float* dwcf; float* dwco;                  // accumulated (+=) over steps, or null
+    float* dG;                // [B,HW,4Ch] d(pre-activation), reference gate order
+};
+hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s);
+hipError_t launch_colsum(const float* m, float* out, long long rows, int cols, hipStream_t s);
+
+struct WgradCTile { int seg, c0, cn, cglobal; };   // 64-channel slice [c0, c0+cn) of segment seg; cglobal = column in [x|h]
+struct WgradArgs {
+    int T, B, H, W, HW, kh, kw, tiles_x, tiles_y;
+    int N4, Cin, Ch, Ct;      // gate rows (4Ch), segment channel counts, Ct = Cin + Ch
+    const float* dG;          // [T][B,HW,N4]
+    const float* x; long long x_bstride, x_tstride;        // x[b,t] slabs (null if no input)
+    const float* hseq; long long h_bstride, h_tstride;     // forward outputs: h_{t-1} = hseq[b, t-1]
+    const float* h0;          // [B,HW,Ch] or null
+    int n_ctiles;
+    WgradCTile ct[16];
+    float* slabs;             // [n_slices][taps][N4][Ct]
+};
+hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s);
+hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s);
+
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
 

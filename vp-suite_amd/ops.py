@@ -66,9 +66,7 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
     conv_lstm_ndrplz.py:112-121 by ONE library call (T fused conv+gate launches on the current stream)."""
 
     @staticmethod
-    def forward(ctx, x, h0, c0, W, b, Wci, Wcf, Wco, seq_len, gate_order, precision, in_channels):
-        need_grad = torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (x, h0, c0, W, b, Wci, Wcf, Wco))
+    def forward(ctx, x, h0, c0, W, b, Wci, Wcf, Wco, seq_len, gate_order, precision, in_channels, need_grad):
         ref = x if x is not None else h0
         _require_gpu(ref, "convlstm_seq")
         dev = ref.device
@@ -151,7 +149,7 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
                                     ptr(dh0), ptr(dc0), ptr(dW), ptr(db), ptr(dwci), ptr(dwcf), ptr(dwco), ptr(ws),
                                     ws_bytes, _stream())
         check(rc, "vpx_convlstm_seq_bwd")
-        return dx, dh0, dc0, dW, db, dwci, dwcf, dwco, None, None, None, None
+        return dx, dh0, dc0, dW, db, dwci, dwcf, dwco, None, None, None, None, None
 
 
 def convlstm_algorithmic_work(B, T, Cin, Ch, H, W, kh, kw, has_h0=True, peephole=True, dt=4):
@@ -173,8 +171,11 @@ def convlstm_seq(x, h0, c0, W, b, Wci=None, Wcf=None, Wco=None, *, seq_len, in_c
     """x: [B,T,Cin,H,W] or None; h0/c0: [B,Ch,H,W] or None (not both x and h0 None). Returns (out [B,T,Ch,H,W], hT, cT)."""
     if x is None and h0 is None:
         raise ValueError("convlstm_seq: inputs and states must not both be None")
+    # grad mode is always off INSIDE Function.forward, so decide here whether the forward must fill the reserve
+    need_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (x, h0, c0, W, b, Wci, Wcf, Wco))
     return _ConvLSTMSeqFn.apply(x, h0, c0, W, b, Wci, Wcf, Wco, int(seq_len), int(gate_order), PRECISIONS[precision],
-                                int(in_channels))
+                                int(in_channels), need_grad)
 
 
 def conv2d_same(x, w, bias=None, precision="f32"):
