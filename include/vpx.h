@@ -45,7 +45,9 @@ enum { VPX_LAYOUT_NHWC = 0, VPX_LAYOUT_NCHW = 1 };
 enum { VPX_PREC_F32 = 0    /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 operands + fp32 accumulate */,
        VPX_PREC_BF16X3 = 1 /* split bf16 (hi/lo) operands, 3 bf16 MFMAs per product, fp32 accumulate (~fp32 accuracy) */,
        VPX_PREC_BF16 = 2   /* bf16 operands, fp32 accumulate, fp32 state and I/O */ };
-enum { VPX_FLAG_SAVE_FOR_BWD = 1 /* forward fills `reserve` (gate activations + cell states per step) */ };
+enum { VPX_FLAG_SAVE_FOR_BWD = 1 /* forward fills `reserve` (gate activations + cell states per step) */,
+       VPX_FLAG_WEIGHTS_PACKED = 2 /* ST-LSTM: `workspace` still holds the repacked weights of a previous call with the
+                                      SAME weight values and desc (caller keeps one workspace per cell per forward) */ };
 
 typedef struct vpx_convlstm_desc {
     int32_t B, T, Cin, Ch, H, W, kh, kw; /* padding is kh/2, kw/2 ("same"), stride 1 — the only form the cells use */
@@ -95,7 +97,10 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
                         float* delta_m, void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* c_new / m_new are the forward's outputs (the operands of conv_o / conv_last). Incoming gradients may be NULL (zero);
+ * every gradient output may be NULL (skipped); weight gradients are OVERWRITTEN. */
 int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c, const float* m,
+                        const float* c_new, const float* m_new,
                         const float* Wx, const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
                         const void* reserve, size_t reserve_bytes, const float* dh_new, const float* dc_new,
                         const float* dm_new, const float* ddelta_c, const float* ddelta_m, float* dx, float* dh,

@@ -1,0 +1,149 @@
+"""GPU parity of the ST-LSTM cell (C ABI: vpx_stlstm_step_fwd/_bwd) and the PredRNN-V2 model against
+reference-generated golden vectors."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from golden_util import checksum, fill_state_dict_, load_golden, name_seed, seeded_rand, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+GRTOL = 5e-5
+
+
+def _relmax(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize("tag", ["plain", "k3"])
+def test_stlstm_cell_vs_golden(vpx, tag):
+    from vp_suite_amd.model_blocks import SpatioTemporalLSTMCell
+    Cin, Ch, H, W, k, ln, B = gc.STLSTM_CASES[tag]
+    g = load_golden(f"stlstm_{tag}")
+    cell = SpatioTemporalLSTMCell(Cin, Ch, H, W, k, 1, ln)
+    fill_state_dict_(cell, name_seed("stlstm." + tag))
+    cell = cell.cuda()
+    inp = {n: v.cuda() for n, v in gc.stlstm_inputs(tag, Cin, Ch, H, W, B).items()}
+    lv = {n: inp[n].clone().requires_grad_(True) for n in ("x", "h", "c", "m")}
+    outs = cell(lv["x"], lv["h"], lv["c"], lv["m"])
+    for o, n in zip(outs, ("h_new", "c_new", "m_new", "delta_c", "delta_m")):
+        assert _relmax(o, g[n]) < RTOL, n
+    sum((o * inp[gn]).sum() for o, gn in zip(outs, ("g_h", "g_c", "g_m", "g_dc", "g_dm"))).backward()
+    for n in ("x", "h", "c", "m"):
+        assert _relmax(lv[n].grad, g["d" + n]) < GRTOL, n
+    for key, prm in cell.named_parameters():
+        assert _relmax(prm.grad, g["grad." + key]) < GRTOL, key
+    # second call re-uses the packed weights held in the cell's workspace
+    with torch.no_grad():
+        o2 = cell(inp["x"], inp["h"], inp["c"], inp["m"])
+        o3 = cell(inp["x"], inp["h"], inp["c"], inp["m"])
+    assert _relmax(o3[0], g["h_new"]) < RTOL and torch.equal(o2[0], o3[0])
+
+
+def test_stlstm_layernorm_fails_loudly(vpx):
+    from vp_suite_amd.model_blocks import SpatioTemporalLSTMCell
+    cell = SpatioTemporalLSTMCell(6, 8, 10, 9, 5, 1, True).cuda()
+    z = torch.zeros(2, 8, 10, 9, device="cuda")
+    with pytest.raises(NotImplementedError):
+        cell(torch.zeros(2, 6, 10, 9, device="cuda"), z, z, z)
+
+
+def test_stlstm_real_shape_vs_oracle(vpx):
+    """PredRNN default cell shapes (BASELINE C3): layer 0 (16 -> 128) and layer 1 (128 -> 128), 16x16, k=5."""
+    from oracle import torch_ref as tr
+    from vp_suite_amd.model_blocks import SpatioTemporalLSTMCell
+    for Cin in (16, 128):
+        Ch, H, W, k, B = 128, 16, 16, 5, 2
+        cell = SpatioTemporalLSTMCell(Cin, Ch, H, W, k, 1, False)
+        fill_state_dict_(cell, name_seed(f"stlstm.real{Cin}"))
+        sd = {kk: v.clone() for kk, v in cell.state_dict().items()}
+        inp = gc.stlstm_inputs(f"real{Cin}", Cin, Ch, H, W, B)
+        with torch.no_grad():
+            ref = tr.stlstm_cell(inp["x"], inp["h"], inp["c"], inp["m"], sd, "", False)
+            out = cell.cuda()(*(inp[n].cuda() for n in ("x", "h", "c", "m")))
+        for o, r in zip(out, ref):
+            assert _relmax(o, r) < RTOL
+
+
+def _predrnn(tag, kw, **extra):
+    from vp_suite_amd.models import MODEL_CLASSES
+    m = MODEL_CLASSES["predrnn-pp"]("cuda", **kw, **extra)
+    fill_state_dict_(m, name_seed("predrnn." + tag))
+    return m.to("cuda")
+
+
+def test_predrnn_tiny_vs_golden(vpx):
+    from vp_suite_amd.measure import PredictionLossProvider
+    tag, kw, B, Ttot, P = "tiny", gc.PRED_TINY_KW, 2, 5, 2
+    g = load_golden(f"predrnn_{tag}")
+    c, h, w = kw["img_shape"]
+    frames = seeded_rand((B, Ttot, c, h, w), name_seed(f"predrnn.{tag}.frames")).cuda()
+    m = _predrnn(tag, kw).eval()
+    pred, ml = m(frames, pred_frames=P)
+    assert _relmax(pred, g["eval.pred"]) < 1e-4
+    assert abs(float(ml["ST-LSTM decouple loss"]) - float(g["eval.decouple"])) < 1e-4 * abs(float(g["eval.decouple"]))
+    with torch.no_grad():
+        assert _relmax(m.pred_1(frames[:, :Ttot - P + 1]), g["eval.pred1"]) < 1e-4
+    lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
+    _, loss = lp.get_losses(pred, frames[:, Ttot - P:])
+    loss = loss + ml["ST-LSTM decouple loss"]
+    assert abs(float(loss) - float(g["eval.loss"])) < 1e-4 * abs(float(g["eval.loss"]))
+    loss.backward()
+    named = dict(m.named_parameters())
+    flat = np.concatenate([named[k].grad.detach().cpu().numpy().reshape(-1) for k in sorted(named)])
+    assert _relmax(flat, g["eval.grads_flat"]) < 1e-4
+    # reverse scheduled sampling, eval
+    with torch.no_grad():
+        pr, _ = _predrnn(tag, kw, reverse_scheduled_sampling=True).eval()(frames, pred_frames=P)
+    assert _relmax(pr, g["rss_eval.pred"]) < 1e-4
+    # train=True with the reference's random draws injected
+    m = _predrnn(tag, kw)
+    m.sampling_eta = 0.5
+    flips = torch.from_numpy(g["train.random_flip"])
+    real_rand = torch.rand
+    try:
+        torch.rand = lambda *a, **k: flips.to(k.get("device", "cpu"))
+        with torch.no_grad():
+            pt, _ = m(frames, pred_frames=P, train=True)
+    finally:
+        torch.rand = real_rand
+    assert abs(m.sampling_eta - float(g["train.eta_after"])) < 1e-12
+    assert _relmax(pt, g["train.pred"]) < 1e-4
+
+
+def test_predrnn_train_iter_vs_golden(vpx):
+    """The model's own train_iter (forward + reversed forward averaged, predrnn_v2.py:319-365) for 2 Adam steps."""
+    from vp_suite_amd.measure import PredictionLossProvider
+    tag, kw, B, Ttot, P = "tiny", gc.PRED_TINY_KW, 2, 5, 2
+    g = load_golden(f"predrnn_{tag}")
+    c, h, w = kw["img_shape"]
+    frames = seeded_rand((B, Ttot, c, h, w), name_seed(f"predrnn.{tag}.frames")).cuda()
+    m = _predrnn(tag, kw, sampling_changing_rate=2.0)
+    cfg = {"device": "cuda", "context_frames": Ttot - P, "pred_frames": P, "val_rec_criterion": "mse"}
+    data = {"frames": frames, "actions": torch.zeros(B, Ttot - 1, 0)}
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
+    for step in (1, 2):
+        m.train_iter(cfg, [data], opt, lp, epoch=0)
+        named = dict(m.named_parameters())
+        pflat = np.concatenate([named[k].detach().cpu().numpy().reshape(-1) for k in sorted(named)])
+        assert np.abs(pflat[::5] - g[f"params_after{step}_s5"]).max() < 5e-5, step
+    assert m.training_iteration == int(g["training_iteration_after2"])
+    assert abs(m.sampling_eta - float(g["sampling_eta_after2"])) < 1e-9
+
+
+def test_predrnn_full_size_vs_golden(vpx):
+    """BASELINE config C3: default predrnn-pp, 64x64, 10 -> 10."""
+    g = load_golden("predrnn_full_c1")
+    m = _predrnn("full_c1", dict(img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0])).eval()
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"])
+    frames = seeded_rand((1, 20, 1, 64, 64), name_seed("predrnn.full_c1.frames"))
+    with torch.no_grad():
+        pred, ml = m(frames.cuda(), pred_frames=10)
+    assert _relmax(pred[:, :, :, ::4, ::4], g["pred_slice"]) < 1e-4
+    assert abs(float(ml["ST-LSTM decouple loss"]) - float(g["decouple"])) < 1e-3 * abs(float(g["decouple"]))

@@ -14,6 +14,7 @@ GATE_IFGO, GATE_IFOG = 0, 1
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 FLAG_SAVE_FOR_BWD = 1
+FLAG_WEIGHTS_PACKED = 2
 
 EXPORTED_SYMBOLS = [
     "vpx_version", "vpx_last_error",
@@ -76,7 +77,7 @@ def lib():
         L.vpx_stlstm_step_fwd.restype = ctypes.c_int
         L.vpx_stlstm_step_fwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 9 + [vp] + [vp] * 5 + [vp, sz, vp, sz, vp]
         L.vpx_stlstm_step_bwd.restype = ctypes.c_int
-        L.vpx_stlstm_step_bwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 9 + [vp, sz] + [vp] * 5 + [vp] * 9 + [vp, sz, vp]
+        L.vpx_stlstm_step_bwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 11 + [vp, sz] + [vp] * 5 + [vp] * 9 + [vp, sz, vp]
         L.vpx_decouple_workspace_bytes.restype = sz
         L.vpx_decouple_workspace_bytes.argtypes = [ctypes.c_int] * 4
         L.vpx_decouple_fwd.restype = ctypes.c_int

@@ -21,16 +21,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // ---------------------------------------------------------------------------------------------------------------
-// weight repack: reference OIHW -> [n_tile][chunk][n = g*32+j][kk]  (kk = position inside the KC-deep chunk)
+// weight repack: reference OIHW -> [n_tile][chunk][n = g*32+j, g < NG][kk]  (kk = position inside the KC-deep chunk)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const PackDesc pd, float* __restrict__ dst) {
-    const long long total = (long long)pd.n_tiles * pd.chunks_total * NT * KC_F32;
+    const int ntr = pd.NG * 32;  // rows per chunk
+    const long long total = (long long)pd.n_tiles * pd.chunks_total * ntr * KC_F32;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
          e += (long long)gridDim.x * blockDim.x) {
         const int kk = (int)(e % KC_F32);
         long long r = e / KC_F32;
-        const int n = (int)(r % NT);
-        r /= NT;
+        const int n = (int)(r % ntr);
+        r /= ntr;
         const int chunk = (int)(r % pd.chunks_total);
         const int n_tile = (int)(r / pd.chunks_total);
         // which stage does this chunk belong to?
@@ -41,13 +42,13 @@ __global__ void pack_weights_kernel(const PackDesc pd, float* __restrict__ dst) 
         const int kin = (chunk - st.chunk0) * KC_F32 + kk;  // k index inside the stage = tap*cn + (c - c0)
         float v = 0.0f;
         const int g = n >> 5, j = n & 31;
-        if (kin < st.nq * 8 && g < pd.NG && pd.rowbase[g] >= 0) {
+        if (kin < st.nq * 8 && g < pd.NG && pd.rowbase[st.seg][g] >= 0) {
             const int tap = kin / st.cn;
             const int c = st.c0 + kin % st.cn;
             const PackSeg sg = pd.seg[st.seg];
             const int chan = n_tile * pd.tile_stride + pd.goff[g] + j;
             if (c < sg.C && chan < pd.nch) {
-                const int row = pd.rowbase[g] + n_tile * pd.tile_stride + j;
+                const int row = pd.rowbase[st.seg][g] + n_tile * pd.tile_stride + j;
                 const int tp = pd.flip ? (pd.taps - 1 - tap) : tap;
                 if (!pd.transposed)
                     v = sg.w[(long long)row * sg.ld_o + (long long)(sg.coff + c) * sg.ld_i + tp];
@@ -60,7 +61,7 @@ __global__ void pack_weights_kernel(const PackDesc pd, float* __restrict__ dst) 
 }
 
 hipError_t launch_pack_weights(const PackDesc& pd, float* dst, hipStream_t s) {
-    const long long total = (long long)pd.n_tiles * pd.chunks_total * NT * KC_F32;
+    const long long total = (long long)pd.n_tiles * pd.chunks_total * pd.NG * 32 * KC_F32;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
@@ -128,6 +129,59 @@ struct EpiConvLSTM {
     }
 };
 
+// ST-LSTM gate groups (predrnn.py:61-77). NGROUPS = 4: (i, f, g, o_pre) -> c ; NGROUPS = 3: (i', f', g') -> m.
+template <int NGROUPS>
+struct EpiSTGate {
+    static constexpr int NG = NGROUPS;
+    STGateArgs a;
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[NGROUPS], const TileCtx& t) const {
+        const int ch = t.n_tile * 32 + t.j;
+        if (ch >= a.Ch) return;
+        const int Ch = a.Ch;
+        const size_t img = (size_t)t.b * t.H * t.W;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int y, x;
+            if (!tile_pixel(t, r, y, x)) continue;
+            const size_t pidx = img + (size_t)y * t.W + x;
+            const size_t sidx = pidx * Ch + ch;
+            const float i_ = sigmoid_f(acc[0][r]);
+            const float f_ = sigmoid_f(acc[1][r] + a.forget_bias);
+            const float g_ = tanhf(acc[2][r]);
+            const float dlt = i_ * g_;
+            a.s_new[sidx] = f_ * a.s_in[sidx] + dlt;
+            a.delta[sidx] = dlt;
+            if constexpr (NGROUPS == 4) a.o_pre[sidx] = acc[3][r];
+            if (a.gates) {
+                float* gs = a.gates + pidx * 3 * Ch + ch;
+                gs[0] = i_;
+                gs[Ch] = f_;
+                gs[2 * Ch] = g_;
+            }
+        }
+    }
+};
+
+struct EpiSTOut {
+    static constexpr int NG = 1;
+    STOutArgs a;
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[1], const TileCtx& t) const {
+        const int ch = t.n_tile * 32 + t.j;
+        if (ch >= a.Ch) return;
+        const size_t img = (size_t)t.b * t.H * t.W;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int y, x;
+            if (!tile_pixel(t, r, y, x)) continue;
+            const size_t sidx = (img + (size_t)y * t.W + x) * a.Ch + ch;
+            const float o_ = sigmoid_f(a.o_pre[sidx] + acc[0][r]);  // predrnn.py:80
+            const float tl = tanhf(a.lc[sidx]);                     // predrnn.py:81
+            a.h_new[sidx] = o_ * tl;
+            if (a.o_save) { a.o_save[sidx] = o_; a.tl_save[sidx] = tl; }
+        }
+    }
+};
+
 struct EpiPlain {
     static constexpr int NG = 4;
     PlainEpiArgs a;
@@ -159,12 +213,13 @@ struct EpiPlain {
 // main kernel, fp32 operands
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int WROW_F32 = KC_F32 * 4 + 16;  // padded LDS row of one output channel's chunk slice (144 B: 9 x 16 B, odd)
-constexpr int WBUF_F32 = NT * WROW_F32;
 
 template <class Epi>
 __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan P, const Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NG = Epi::NG;
+    constexpr int NTR = NG * 32;                 // weight rows (output channels x gate groups) per workgroup
+    constexpr int WBUF_F32 = NTR * WROW_F32;     // one LDS weight buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
 
@@ -190,7 +245,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan 
 
     // this lane's pixel inside the tile (MFMA row = lane & 31)
     const int py = 2 * wave + (j >> 4), px = j & 15;
-    const float* wtile = P.wpk + (size_t)n_tile * P.chunks_total * (NT * KC_F32);
+    const float* wtile = P.wpk + (size_t)n_tile * P.chunks_total * (NTR * KC_F32);
 
     for (int s = 0; s < P.nstage; ++s) {
         const ConvStage st = P.stage[s];
@@ -200,7 +255,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan 
         // ---- stage the activation halo tile: positions x [c0, c0+cn) ----
         {
             const float* src = sg.ptr + (size_t)b * sg.bstride;
-            if ((sg.C & 3) == 0) {
+            const int ld = sg.ld ? sg.ld : sg.C;
+            if (((sg.C | ld) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
                 const int v4n = st.cn >> 2;
                 const int total = npos * v4n;
                 for (int v = tid; v < total; v += NTHREADS) {
@@ -210,7 +266,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan 
                     const int c = st.c0 + c4 * 4;
                     f32x4 val = {0.f, 0.f, 0.f, 0.f};
                     if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < sg.C)
-                        val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * P.W + gx) * sg.C + c);
+                        val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * P.W + gx) * ld + c);
                     *reinterpret_cast<f32x4*>(A_lds + pos * arow + c4 * 16) = val;
                 }
             } else {
@@ -222,19 +278,19 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan 
                     const int c = st.c0 + cc;
                     float val = 0.f;
                     if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < sg.C)
-                        val = src[((size_t)gy * P.W + gx) * sg.C + c];
+                        val = src[((size_t)gy * P.W + gx) * ld + c];
                     *reinterpret_cast<float*>(A_lds + pos * arow + cc * 4) = val;
                 }
             }
         }
         // ---- weight chunk 0 of this stage ----
         const int nchunks = (st.nq * 8 + KC_F32 - 1) / KC_F32;
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(wtile + (size_t)st.chunk0 * (NT * KC_F32));
-        f32x4 wr[4];
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(wtile + (size_t)st.chunk0 * (NTR * KC_F32));
+        f32x4 wr[NG];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) wr[it] = wsrc[tid + it * NTHREADS];
+        for (int it = 0; it < NG; ++it) wr[it] = wsrc[tid + it * NTHREADS];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < NG; ++it) {
             const int v = tid + it * NTHREADS;
             *reinterpret_cast<f32x4*>(W_lds + (v >> 3) * WROW_F32 + (v & 7) * 16) = wr[it];
         }
@@ -247,9 +303,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan 
         for (int ck = 0; ck < nchunks; ++ck) {
             const bool more = ck + 1 < nchunks;
             if (more) {
-                const f32x4* wn = wsrc + (size_t)(ck + 1) * (NT * KC_F32 / 4);
+                const f32x4* wn = wsrc + (size_t)(ck + 1) * (NTR * KC_F32 / 4);
 #pragma unroll
-                for (int it = 0; it < 4; ++it) wr[it] = wn[tid + it * NTHREADS];
+                for (int it = 0; it < NG; ++it) wr[it] = wn[tid + it * NTHREADS];
             }
             const char* wb = W_lds + (ck & 1) * WBUF_F32 + j * WROW_F32 + hh * 16;
 #pragma unroll
@@ -275,7 +331,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan 
             if (more) {
                 char* wdst = W_lds + ((ck + 1) & 1) * WBUF_F32;
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
+                for (int it = 0; it < NG; ++it) {
                     const int v = tid + it * NTHREADS;
                     *reinterpret_cast<f32x4*>(wdst + (v >> 3) * WROW_F32 + (v & 7) * 16) = wr[it];
                 }
@@ -290,7 +346,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan 
 
 template <class Epi>
 static hipError_t launch_conv(const ConvPlan& plan, const Epi& epi, int n_tiles, hipStream_t s) {
-    const size_t lds = (size_t)plan.a_bytes + 2 * WBUF_F32;
+    const size_t lds = (size_t)plan.a_bytes + 2 * (Epi::NG * 32 * WROW_F32);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_f32_kernel<Epi>),
@@ -311,6 +367,19 @@ hipError_t launch_convlstm_step_f32(const ConvPlan& plan, const ConvLSTMStepArgs
 
 hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, int n_tiles, hipStream_t s) {
     EpiPlain e{ea};
+    return launch_conv(plan, e, n_tiles, s);
+}
+
+hipError_t launch_st_cgroup_f32(const ConvPlan& plan, const STGateArgs& ea, int n_tiles, hipStream_t s) {
+    EpiSTGate<4> e{ea};
+    return launch_conv(plan, e, n_tiles, s);
+}
+hipError_t launch_st_mgroup_f32(const ConvPlan& plan, const STGateArgs& ea, int n_tiles, hipStream_t s) {
+    EpiSTGate<3> e{ea};
+    return launch_conv(plan, e, n_tiles, s);
+}
+hipError_t launch_st_out_f32(const ConvPlan& plan, const STOutArgs& ea, int n_tiles, hipStream_t s) {
+    EpiSTOut e{ea};
     return launch_conv(plan, e, n_tiles, s);
 }
 
@@ -348,8 +417,8 @@ int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw) {
     return (m + 15) / 16 * 16;
 }
 
-size_t packed_weight_bytes(int n_tiles, int chunks_total) {
-    return (size_t)n_tiles * chunks_total * NT * KC_F32 * sizeof(float);
+size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng) {
+    return (size_t)n_tiles * chunks_total * ng * 32 * KC_F32 * sizeof(float);
 }
 
 }  // namespace vpx

@@ -93,7 +93,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         pd.seg[0] = PackSeg{W, (long long)Ct * L.taps, L.taps, 0, N4};
         memcpy(pd.stage, L.d_stage, sizeof(ConvStage) * L.d_nstage);
         pd.nstage = L.d_nstage; pd.chunks_total = L.d_chunks; pd.n_tiles = d_tiles; pd.taps = L.taps; pd.NG = 4;
-        for (int g = 0; g < 4; ++g) { pd.rowbase[g] = col_start + g * 32; pd.goff[g] = g * 32; }
+        for (int g = 0; g < 4; ++g) { pd.rowbase[0][g] = col_start + g * 32; pd.goff[g] = g * 32; }
         pd.tile_stride = NT; pd.nch = n_out; pd.transposed = 1; pd.flip = 1;
         VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
     }

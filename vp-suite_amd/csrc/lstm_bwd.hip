@@ -144,17 +144,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
             else if (a.h0) src = a.h0 + (size_t)b * a.HW * a.Ch;
             else continue;  // zero hidden state at t = 0 contributes nothing (uniform branch)
         }
-        const float* dg = a.dG + ((size_t)t * a.B + b) * a.HW * a.N4;
+        const int ldG = a.ldG ? a.ldG : a.N4;
+        const float* dg = a.dG + ((size_t)t * a.B + b) * a.HW * ldG;
         __syncthreads();
         // ---- stage dG tile: 128 pixels x 64 rows ----
-        if ((a.N4 & 3) == 0) {
+        if (((a.N4 | ldG) & 3) == 0 && (reinterpret_cast<uintptr_t>(dg) & 15) == 0) {
             for (int v = tid; v < 128 * 16; v += NTHREADS) {
                 const int p = v >> 4, q4 = v & 15;
                 const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
                 const int n = n0 + q4 * 4;
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 if (gy < a.H && gx < a.W && n < a.N4)
-                    val = *reinterpret_cast<const f32x4*>(dg + ((size_t)gy * a.W + gx) * a.N4 + n);
+                    val = *reinterpret_cast<const f32x4*>(dg + ((size_t)gy * a.W + gx) * ldG + n);
                 *reinterpret_cast<f32x4*>(G_lds + p * 64 + q4 * 4) = val;
             }
         } else {
@@ -163,12 +164,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
                 const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
                 const int n = n0 + q;
                 float val = 0.f;
-                if (gy < a.H && gx < a.W && n < a.N4) val = dg[((size_t)gy * a.W + gx) * a.N4 + n];
+                if (gy < a.H && gx < a.W && n < a.N4) val = dg[((size_t)gy * a.W + gx) * ldG + n];
                 G_lds[p * 64 + q] = val;
             }
         }
         // ---- stage activation halo tile: npos x 64 channels [ct.c0, ct.c0 + 64) ----
-        if ((C & 3) == 0) {
+        if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
             for (int v = tid; v < npos * 16; v += NTHREADS) {
                 const int pos = v >> 4, q4 = v & 15;
                 const int hy = pos / halo_w, hx = pos - hy * halo_w;
@@ -211,15 +212,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
     // ---- slab[slice][tap][row][Ct] = acc (each element written exactly once per launch) ----
     const int col = ct.cglobal + wc * 32 + i;  // channel inside the concatenated [x | h] axis
     const bool col_ok = (wc * 32 + i) < ct.cn;
-    float* slab = a.slabs + (size_t)blockIdx.y * a.kh * a.kw * a.N4 * a.Ct;
+    const int n_out = a.n_out ? a.n_out : a.N4;
+    float* slab = a.slabs + (size_t)blockIdx.y * a.kh * a.kw * n_out * a.Ct;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         if (t >= ntaps) continue;
-        float* st = slab + (size_t)(tap0 + t) * a.N4 * a.Ct;
+        float* st = slab + (size_t)(tap0 + t) * n_out * a.Ct;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (n < a.N4 && col_ok) st[(size_t)n * a.Ct + col] = acc[t][r];
+            if (n < a.N4 && col_ok) {
+                const int row = a.blk ? (a.rowblk[n / a.blk] * a.blk + n % a.blk) : n;
+                st[(size_t)row * a.Ct + col] = acc[t][r];
+            }
         }
     }
 }
@@ -263,6 +268,59 @@ hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int 
     const long long total = (long long)N4 * Ct * taps;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
                        taps, N4, Ct);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ST-LSTM backward, pointwise stages (predrnn.py:65-81 differentiated)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void st_bwd_out_kernel(const STBwdOutArgs a) {
+    const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (e >= a.n) return;
+    const long long pix = e / a.Ch;
+    const int ch = (int)(e - pix * a.Ch);
+    const float dh = a.dh_new ? a.dh_new[e] : 0.0f;
+    const float o = a.o[e], tl = a.tl[e];
+    a.dG7[pix * a.ldG + a.o_off + ch] = dh * tl * o * (1.0f - o);  // d(o_x + o_h + conv_o(mem))
+    a.dlc[e] = dh * o * (1.0f - tl * tl);                          // d conv_last(mem)
+}
+
+__global__ void st_bwd_gates_kernel(const STBwdGateArgs a) {
+    const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const int Ch = a.Ch;
+    if (e >= a.npix * Ch) return;
+    const long long pix = e / Ch;
+    const int ch = (int)(e - pix * Ch);
+    float* dg = a.dG7 + pix * a.ldG + ch;
+    {   // c group: c_new = f*c + i*g ; delta_c = i*g
+        const float* gs = a.gates_c + pix * 3 * Ch + ch;
+        const float i_ = gs[0], f_ = gs[Ch], g_ = gs[2 * Ch];
+        const float dcn = (a.dcn_ext ? a.dcn_ext[e] : 0.0f) + a.dcn_conv[e];
+        const float ddl = dcn + (a.ddc_ext ? a.ddc_ext[e] : 0.0f);
+        dg[0] = ddl * g_ * i_ * (1.0f - i_);
+        dg[Ch] = dcn * a.c[e] * f_ * (1.0f - f_);
+        dg[2 * Ch] = ddl * i_ * (1.0f - g_ * g_);
+        if (a.dc) a.dc[e] = dcn * f_;
+    }
+    {   // m group
+        const float* gs = a.gates_m + pix * 3 * Ch + ch;
+        const float i_ = gs[0], f_ = gs[Ch], g_ = gs[2 * Ch];
+        const float dmn = (a.dmn_ext ? a.dmn_ext[e] : 0.0f) + a.dmn_conv[e];
+        const float ddl = dmn + (a.ddm_ext ? a.ddm_ext[e] : 0.0f);
+        dg[4 * Ch] = ddl * g_ * i_ * (1.0f - i_);
+        dg[5 * Ch] = dmn * a.m[e] * f_ * (1.0f - f_);
+        dg[6 * Ch] = ddl * i_ * (1.0f - g_ * g_);
+        a.dm[e] = dmn * f_;
+    }
+}
+
+hipError_t launch_st_bwd_out(const STBwdOutArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(st_bwd_out_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_st_bwd_gates(const STBwdGateArgs& a, hipStream_t s) {
+    const long long n = a.npix * a.Ch;
+    hipLaunchKernelGGL(st_bwd_gates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

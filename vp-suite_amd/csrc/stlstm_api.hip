@@ -1,0 +1,228 @@
+// stlstm_api.hip — vpx_stlstm_step_fwd / _bwd: one Spatio-Temporal LSTM cell step (predrnn.py:57-83) as four launches of
+// the implicit-GEMM kernel:
+//   c group   conv([x|h]; Wx rows i,f,g,o + Wh rows i,f,g,o)  -> c_new, delta_c, o_pre           (fused gates)
+//   m group   conv([x|m]; Wx rows i',f',g' + Wm rows i,f,g)   -> m_new, delta_m                  (fused gates)
+//   conv_last 1x1 over mem = [c_new|m_new]                    -> lc
+//   conv_o    kxk over mem, epilogue h_new = sigmoid(o_pre + conv_o) * tanh(lc)
+// The LayerNorm variant (predrnn.py:24-40) is not implemented in this round: it fails loudly.
+#include "vpx_host.h"
+
+using namespace vpx;
+
+namespace {
+
+struct STLayout {
+    int taps, tiles32, tiles128;
+    int nstage_g, chunks_g;            // gate groups: segments (x: Cin, recurrent: Ch), k x k
+    ConvStage stage_g[MAX_STAGE];
+    int nstage_o, chunks_o;            // conv_o: segments (c_new: Ch, m_new: Ch), k x k
+    ConvStage stage_o[MAX_STAGE];
+    int nstage_l, chunks_l;            // conv_last: same segments, 1 x 1
+    ConvStage stage_l[MAX_STAGE];
+    size_t n_state, n_x;
+    size_t wpk_c, wpk_m, wpk_o, wpk_l;  // float counts
+};
+
+int check_st_desc(const vpx_stlstm_desc* d) {
+    if (!d) { set_error("stlstm desc is NULL"); return VPX_ERR_ARG; }
+    if (d->B < 1 || d->Cin < 1 || d->Ch < 1 || d->H < 1 || d->W < 1) { set_error("stlstm desc: non-positive dimension"); return VPX_ERR_ARG; }
+    if (d->k < 1 || !(d->k & 1) || d->k > 7) { set_error("stlstm desc: filter size must be odd and <= 7 (got %d)", d->k); return VPX_ERR_ARG; }
+    if (d->layout != VPX_LAYOUT_NHWC && d->layout != VPX_LAYOUT_NCHW) { set_error("stlstm desc: unknown layout %d", d->layout); return VPX_ERR_ARG; }
+    if (d->layer_norm) { set_error("stlstm: the LayerNorm variant (predrnn.py:24-40) is not implemented yet"); return VPX_ERR_UNSUPPORTED; }
+    if (d->precision != VPX_PREC_F32) { set_error("stlstm: precision %d not implemented yet (only VPX_PREC_F32)", d->precision); return VPX_ERR_UNSUPPORTED; }
+    return VPX_OK;
+}
+
+int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
+    L.taps = d->k * d->k;
+    L.tiles32 = (d->Ch + 31) / 32;
+    L.tiles128 = (d->Ch + NT - 1) / NT;
+    const int segG[2] = {d->Cin, d->Ch};
+    const int segO[2] = {d->Ch, d->Ch};
+    L.nstage_g = build_stages(L.stage_g, &L.chunks_g, segG, 2, L.taps, CS_F32, KC_F32);
+    L.nstage_o = build_stages(L.stage_o, &L.chunks_o, segO, 2, L.taps, CS_F32, KC_F32);
+    L.nstage_l = build_stages(L.stage_l, &L.chunks_l, segO, 2, 1, CS_F32, KC_F32);
+    if (L.nstage_g < 0 || L.nstage_o < 0 || L.nstage_l < 0) { set_error("stlstm: too many channel stages"); return VPX_ERR_UNSUPPORTED; }
+    L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
+    L.n_x = (size_t)d->B * d->H * d->W * d->Cin;
+    L.wpk_c = packed_weight_bytes(L.tiles32, L.chunks_g, 4) / 4;
+    L.wpk_m = packed_weight_bytes(L.tiles32, L.chunks_g, 3) / 4;
+    L.wpk_o = packed_weight_bytes(L.tiles32, L.chunks_o, 1) / 4;
+    L.wpk_l = packed_weight_bytes(L.tiles128, L.chunks_l, 4) / 4;
+    return VPX_OK;
+}
+
+ConvPlan base_plan(const vpx_stlstm_desc* d, int k) {
+    ConvPlan P{};
+    P.B = d->B; P.H = d->H; P.W = d->W; P.kh = k; P.kw = k;
+    P.tiles_x = (d->W + TILE_W - 1) / TILE_W;
+    P.tiles_y = (d->H + TILE_H - 1) / TILE_H;
+    return P;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vpx_stlstm_reserve_bytes(const vpx_stlstm_desc* d) {
+    STLayout L;
+    if (check_st_desc(d) != VPX_OK || st_layout(d, L) != VPX_OK) return 0;
+    if (!(d->flags & VPX_FLAG_SAVE_FOR_BWD)) return 0;
+    // gates_c (3Ch) + gates_m (3Ch) + o + tanh(conv_last): 8 state-sized planes
+    return 2 * align256(3 * L.n_state * 4) + 2 * align256(L.n_state * 4);
+}
+
+size_t vpx_stlstm_workspace_bytes(const vpx_stlstm_desc* d) {
+    STLayout L;
+    if (check_st_desc(d) != VPX_OK || st_layout(d, L) != VPX_OK) return 0;
+    size_t b = align256(L.wpk_c * 4) + align256(L.wpk_m * 4) + align256(L.wpk_o * 4) + align256(L.wpk_l * 4);
+    b += 2 * align256(L.n_state * 4);  // o_pre, lc
+    if (d->layout == VPX_LAYOUT_NCHW) b += align256(L.n_x * 4) + 8 * align256(L.n_state * 4);
+    size_t bwd = 0;
+    if (d->flags & VPX_FLAG_SAVE_FOR_BWD) bwd = stlstm_bwd_workspace_bytes(d);
+    return (b > bwd ? b : bwd) + 256;
+}
+
+int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c, const float* m,
+                        const float* Wx, const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
+                        const float* const* ln, float* h_new, float* c_new, float* m_new, float* delta_c,
+                        float* delta_m, void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                        void* stream_) {
+    int rc = check_st_desc(d);
+    if (rc != VPX_OK) return rc;
+    STLayout L;
+    if ((rc = st_layout(d, L)) != VPX_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !h || !c || !m || !Wx || !Wh || !Wm || !Wo || !Wlast || !h_new || !c_new || !m_new || !delta_c || !delta_m) {
+        set_error("vpx_stlstm_step_fwd: NULL tensor argument");
+        return VPX_ERR_ARG;
+    }
+    const bool save = (d->flags & VPX_FLAG_SAVE_FOR_BWD) != 0;
+    if (save && (!reserve || reserve_bytes < vpx_stlstm_reserve_bytes(d))) { set_error("vpx_stlstm_step_fwd: reserve too small"); return VPX_ERR_WORKSPACE; }
+    if (!workspace || workspace_bytes < vpx_stlstm_workspace_bytes(d)) {
+        set_error("vpx_stlstm_step_fwd: workspace too small (%zu < %zu)", workspace_bytes, vpx_stlstm_workspace_bytes(d));
+        return VPX_ERR_WORKSPACE;
+    }
+    const int B = d->B, Cin = d->Cin, Ch = d->Ch, H = d->H, Wd = d->W, k = d->k;
+    const size_t HW = (size_t)H * Wd;
+    Carver ws{(char*)workspace, 0, workspace_bytes};
+    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    float* wpk_c = ws.take(L.wpk_c);
+    float* wpk_m = ws.take(L.wpk_m);
+    float* wpk_o = ws.take(L.wpk_o);
+    float* wpk_l = ws.take(L.wpk_l);
+    float* o_pre = ws.take(L.n_state);
+    float* lc = ws.take(L.n_state);
+
+    const float *xn = x, *hn = h, *cn = c, *mn = m;
+    float *hO = h_new, *cO = c_new, *mO = m_new, *dcO = delta_c, *dmO = delta_m;
+    if (d->layout == VPX_LAYOUT_NCHW) {
+        float* bx = ws.take(L.n_x);
+        float* st[8];
+        for (auto& p : st) p = ws.take(L.n_state);
+        VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B, Cin, H, Wd, stream)); xn = bx;
+        VPX_CHECK_HIP(launch_nchw_to_nhwc(h, st[0], B, Ch, H, Wd, stream)); hn = st[0];
+        VPX_CHECK_HIP(launch_nchw_to_nhwc(c, st[1], B, Ch, H, Wd, stream)); cn = st[1];
+        VPX_CHECK_HIP(launch_nchw_to_nhwc(m, st[2], B, Ch, H, Wd, stream)); mn = st[2];
+        hO = st[3]; cO = st[4]; mO = st[5]; dcO = st[6]; dmO = st[7];
+    }
+
+    // ---- weight repack (skipped when the caller vouches the workspace still holds it) ----
+    if (!(d->flags & VPX_FLAG_WEIGHTS_PACKED)) {
+        PackDesc pd{};
+        // c group: x rows (i,f,g,o) = blocks 0,1,2,6 of Wx (predrnn.py:61); h rows (i,f,g,o) = blocks 0..3 of Wh (:62)
+        pd.seg[0] = PackSeg{Wx, (long long)Cin * L.taps, L.taps, 0, Cin};
+        pd.seg[1] = PackSeg{Wh, (long long)Ch * L.taps, L.taps, 0, Ch};
+        memcpy(pd.stage, L.stage_g, sizeof(ConvStage) * L.nstage_g);
+        pd.nstage = L.nstage_g; pd.chunks_total = L.chunks_g; pd.n_tiles = L.tiles32; pd.taps = L.taps; pd.NG = 4;
+        const int xr[4] = {0, 1, 2, 6};
+        for (int g = 0; g < 4; ++g) { pd.rowbase[0][g] = xr[g] * Ch; pd.rowbase[1][g] = g * Ch; pd.goff[g] = 0; }
+        pd.tile_stride = 32; pd.nch = Ch;
+        VPX_CHECK_HIP(launch_pack_weights(pd, wpk_c, stream));
+        // m group: x rows (i',f',g') = blocks 3,4,5 of Wx; m rows (i,f,g) = blocks 0..2 of Wm (:63)
+        pd.seg[1] = PackSeg{Wm, (long long)Ch * L.taps, L.taps, 0, Ch};
+        pd.NG = 3;
+        for (int g = 0; g < 3; ++g) { pd.rowbase[0][g] = (3 + g) * Ch; pd.rowbase[1][g] = g * Ch; }
+        pd.rowbase[0][3] = pd.rowbase[1][3] = -1;
+        VPX_CHECK_HIP(launch_pack_weights(pd, wpk_m, stream));
+        // conv_o over mem = [c_new | m_new]: Wo [Ch, 2Ch, k, k]
+        PackDesc po{};
+        po.seg[0] = PackSeg{Wo, (long long)2 * Ch * L.taps, L.taps, 0, Ch};
+        po.seg[1] = PackSeg{Wo, (long long)2 * Ch * L.taps, L.taps, Ch, Ch};
+        memcpy(po.stage, L.stage_o, sizeof(ConvStage) * L.nstage_o);
+        po.nstage = L.nstage_o; po.chunks_total = L.chunks_o; po.n_tiles = L.tiles32; po.taps = L.taps; po.NG = 1;
+        for (int s = 0; s < 2; ++s) { po.rowbase[s][0] = 0; for (int g = 1; g < 4; ++g) po.rowbase[s][g] = -1; }
+        po.tile_stride = 32; po.nch = Ch;
+        VPX_CHECK_HIP(launch_pack_weights(po, wpk_o, stream));
+        // conv_last 1x1: Wlast [Ch, 2Ch, 1, 1]
+        PackDesc pl{};
+        pl.seg[0] = PackSeg{Wlast, (long long)2 * Ch, 1, 0, Ch};
+        pl.seg[1] = PackSeg{Wlast, (long long)2 * Ch, 1, Ch, Ch};
+        memcpy(pl.stage, L.stage_l, sizeof(ConvStage) * L.nstage_l);
+        pl.nstage = L.nstage_l; pl.chunks_total = L.chunks_l; pl.n_tiles = L.tiles128; pl.taps = 1; pl.NG = 4;
+        for (int s = 0; s < 2; ++s) for (int g = 0; g < 4; ++g) pl.rowbase[s][g] = g * 32;
+        for (int g = 0; g < 4; ++g) pl.goff[g] = g * 32;
+        pl.tile_stride = NT; pl.nch = Ch;
+        VPX_CHECK_HIP(launch_pack_weights(pl, wpk_l, stream));
+    }
+
+    float *gates_c = nullptr, *gates_m = nullptr, *o_save = nullptr, *tl_save = nullptr;
+    if (save) {
+        char* r = (char*)reserve;
+        gates_c = (float*)r; r += align256(3 * L.n_state * 4);
+        gates_m = (float*)r; r += align256(3 * L.n_state * 4);
+        o_save = (float*)r; r += align256(L.n_state * 4);
+        tl_save = (float*)r;
+    }
+
+    // ---- launch 1: c group ----
+    {
+        ConvPlan P = base_plan(d, k);
+        P.nseg = 2;
+        P.seg[0] = ConvSeg{xn, (long long)(HW * Cin), Cin, 0};
+        P.seg[1] = ConvSeg{hn, (long long)(HW * Ch), Ch, 0};
+        P.nstage = L.nstage_g; memcpy(P.stage, L.stage_g, sizeof(ConvStage) * L.nstage_g);
+        P.chunks_total = L.chunks_g; P.a_bytes = conv_a_bytes(L.stage_g, L.nstage_g, k, k); P.wpk = wpk_c;
+        STGateArgs ea{Ch, 1.0f, cn, cO, dcO, o_pre, gates_c};
+        VPX_CHECK_HIP(launch_st_cgroup_f32(P, ea, L.tiles32, stream));
+        // ---- launch 2: m group ----
+        P.seg[1] = ConvSeg{mn, (long long)(HW * Ch), Ch, 0};
+        P.wpk = wpk_m;
+        STGateArgs em{Ch, 1.0f, mn, mO, dmO, nullptr, gates_m};
+        VPX_CHECK_HIP(launch_st_mgroup_f32(P, em, L.tiles32, stream));
+    }
+    // ---- launch 3: conv_last(mem) 1x1 -> lc ----
+    {
+        ConvPlan P = base_plan(d, 1);
+        P.nseg = 2;
+        P.seg[0] = ConvSeg{cO, (long long)(HW * Ch), Ch, 0};
+        P.seg[1] = ConvSeg{mO, (long long)(HW * Ch), Ch, 0};
+        P.nstage = L.nstage_l; memcpy(P.stage, L.stage_l, sizeof(ConvStage) * L.nstage_l);
+        P.chunks_total = L.chunks_l; P.a_bytes = conv_a_bytes(L.stage_l, L.nstage_l, 1, 1); P.wpk = wpk_l;
+        PlainEpiArgs ea{};
+        ea.Co = Ch; ea.split = Ch; ea.out0 = lc; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
+        VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.tiles128, stream));
+    }
+    // ---- launch 4: conv_o(mem) + output gate ----
+    {
+        ConvPlan P = base_plan(d, k);
+        P.nseg = 2;
+        P.seg[0] = ConvSeg{cO, (long long)(HW * Ch), Ch, 0};
+        P.seg[1] = ConvSeg{mO, (long long)(HW * Ch), Ch, 0};
+        P.nstage = L.nstage_o; memcpy(P.stage, L.stage_o, sizeof(ConvStage) * L.nstage_o);
+        P.chunks_total = L.chunks_o; P.a_bytes = conv_a_bytes(L.stage_o, L.nstage_o, k, k); P.wpk = wpk_o;
+        STOutArgs ea{Ch, o_pre, lc, hO, o_save, tl_save};
+        VPX_CHECK_HIP(launch_st_out_f32(P, ea, L.tiles32, stream));
+    }
+    if (d->layout == VPX_LAYOUT_NCHW) {
+        VPX_CHECK_HIP(launch_nhwc_to_nchw(hO, h_new, B, Ch, H, Wd, stream));
+        VPX_CHECK_HIP(launch_nhwc_to_nchw(cO, c_new, B, Ch, H, Wd, stream));
+        VPX_CHECK_HIP(launch_nhwc_to_nchw(mO, m_new, B, Ch, H, Wd, stream));
+        VPX_CHECK_HIP(launch_nhwc_to_nchw(dcO, delta_c, B, Ch, H, Wd, stream));
+        VPX_CHECK_HIP(launch_nhwc_to_nchw(dmO, delta_m, B, Ch, H, Wd, stream));
+    }
+    (void)ln;
+    return VPX_OK;
+}
+
+}  // extern "C"

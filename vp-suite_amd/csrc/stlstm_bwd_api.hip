@@ -1,0 +1,282 @@
+// stlstm_bwd_api.hip — vpx_stlstm_step_bwd: backward of one ST-LSTM cell step (predrnn.py:57-83), explicit instead of
+// autograd. d(pre-activations) of all seven gate blocks live in ONE tensor dG7 [B,HW,7Ch] ordered
+// (i,f,g | o | i',f',g') so that Wh's rows are its first 4Ch channels, Wm's rows its last 3Ch, and Wx's row blocks the
+// permutation {0,1,2,6,3,4,5}; convolution sources are channel slices of it (ConvSeg.ld).
+//   A  pointwise: dh_new -> d(o pre-act) [dG7 block 3], d conv_last
+//   B  dgrad conv_o (k x k) + dgrad conv_last (1 x 1, accumulate) -> grads of c_new / m_new through mem
+//   C  pointwise: gate groups -> dG7 blocks 0-2, 4-6; dc; direct part of dm
+//   D  dgrad: dx (3 segments over Wx), dh (Wh), dm += (Wm)
+//   E  wgrad x5 (K-slice slabs + reduce): Wo, Wlast, Wx (row-block map), Wh, Wm
+#include "vpx_host.h"
+
+using namespace vpx;
+
+namespace {
+
+struct STBwdLayout {
+    int taps, Ch, Cin;
+    size_t n_state, n_x, n_g7;
+    // dgrad plans: stage tables + chunk counts + N tiles
+    struct DG { int nstage, chunks, tiles; ConvStage stage[MAX_STAGE]; size_t wpk; } o, l, x, h, m;
+    int n_slices;
+    size_t slab_floats;
+};
+
+int mk_dg(STBwdLayout::DG& g, const int* segC, int nseg, int taps, int n_out) {
+    g.nstage = build_stages(g.stage, &g.chunks, segC, nseg, taps, CS_F32, KC_F32);
+    if (g.nstage < 0) return -1;
+    g.tiles = (n_out + NT - 1) / NT;
+    g.wpk = packed_weight_bytes(g.tiles, g.chunks, 4) / 4;
+    return 0;
+}
+
+int st_bwd_layout(const vpx_stlstm_desc* d, STBwdLayout& L) {
+    const int Ch = d->Ch, Cin = d->Cin;
+    L.taps = d->k * d->k; L.Ch = Ch; L.Cin = Cin;
+    L.n_state = (size_t)d->B * d->H * d->W * Ch;
+    L.n_x = (size_t)d->B * d->H * d->W * Cin;
+    L.n_g7 = L.n_state * 7;
+    const int s1[1] = {Ch}, s3[3] = {3 * Ch, Ch, 3 * Ch}, s4[1] = {4 * Ch}, s3m[1] = {3 * Ch};
+    if (mk_dg(L.o, s1, 1, L.taps, 2 * Ch) || mk_dg(L.l, s1, 1, 1, 2 * Ch) || mk_dg(L.x, s3, 3, L.taps, Cin) ||
+        mk_dg(L.h, s4, 1, L.taps, Ch) || mk_dg(L.m, s3m, 1, L.taps, Ch)) {
+        set_error("stlstm bwd: too many channel stages (Ch=%d)", Ch);
+        return VPX_ERR_UNSUPPORTED;
+    }
+    const int tiles = ((d->W + TILE_W - 1) / TILE_W) * ((d->H + TILE_H - 1) / TILE_H);
+    long long items = (long long)d->B * tiles;
+    L.n_slices = (int)(items < 32 ? items : 32);
+    // largest weight-gradient tensor (elements) among Wx, Wh, Wm, Wo, Wlast
+    size_t mx = (size_t)7 * Ch * Cin * L.taps;
+    if ((size_t)4 * Ch * Ch * L.taps > mx) mx = (size_t)4 * Ch * Ch * L.taps;
+    if ((size_t)2 * Ch * Ch * L.taps > mx) mx = (size_t)2 * Ch * Ch * L.taps;
+    L.slab_floats = mx * L.n_slices;
+    return VPX_OK;
+}
+
+}  // namespace
+
+namespace vpx {
+size_t stlstm_bwd_workspace_bytes(const vpx_stlstm_desc* d) {
+    STBwdLayout L;
+    if (st_bwd_layout(d, L) != VPX_OK) return 0;
+    size_t b = align256(L.n_g7 * 4) + 4 * align256(L.n_state * 4);  // dG7, dlc, dcn_conv, dmn_conv, dm scratch
+    b += align256(L.o.wpk * 4) + align256(L.l.wpk * 4) + align256(L.x.wpk * 4) + align256(L.h.wpk * 4) + align256(L.m.wpk * 4);
+    b += align256(L.slab_floats * 4);
+    if (d->layout == VPX_LAYOUT_NCHW) b += 2 * align256(L.n_x * 4) + 14 * align256(L.n_state * 4);
+    return b;
+}
+}  // namespace vpx
+
+namespace {
+
+// one weight gradient: dW[n_out, C0 + C1, kh, kw] from dG (channel slice [N] of a [.., ldG] tensor) and up to two sources
+int run_wgrad(const vpx_stlstm_desc* d, const STBwdLayout& L, const float* dG, int N, int ldG, const float* src0, int C0,
+              const float* src1, int C1, int k, const int* rowblk, int blk, int n_out, float* slabs, float* dW,
+              hipStream_t stream) {
+    WgradArgs wa{};
+    wa.T = 1; wa.B = d->B; wa.H = d->H; wa.W = d->W; wa.HW = d->H * d->W; wa.kh = k; wa.kw = k;
+    wa.tiles_x = (d->W + TILE_W - 1) / TILE_W; wa.tiles_y = (d->H + TILE_H - 1) / TILE_H;
+    wa.N4 = N; wa.Cin = C0; wa.Ch = C1 > 0 ? C1 : 1; wa.Ct = C0 + C1;
+    wa.ldG = ldG; wa.blk = blk; wa.n_out = n_out;
+    if (rowblk) for (int i = 0; i < 8; ++i) wa.rowblk[i] = rowblk[i];
+    wa.dG = dG;
+    wa.x = src0; wa.x_bstride = (long long)wa.HW * C0; wa.x_tstride = 0;
+    wa.hseq = nullptr; wa.h0 = src1;
+    wa.n_ctiles = 0;
+    for (int c0 = 0; c0 < C0; c0 += 64) {
+        if (wa.n_ctiles >= 16) { set_error("stlstm bwd: too many channels for the weight-gradient kernel"); return VPX_ERR_UNSUPPORTED; }
+        wa.ct[wa.n_ctiles++] = WgradCTile{0, c0, (C0 - c0 < 64) ? C0 - c0 : 64, c0};
+    }
+    for (int c0 = 0; c0 < C1; c0 += 64) {
+        if (wa.n_ctiles >= 16) { set_error("stlstm bwd: too many channels for the weight-gradient kernel"); return VPX_ERR_UNSUPPORTED; }
+        wa.ct[wa.n_ctiles++] = WgradCTile{1, c0, (C1 - c0 < 64) ? C1 - c0 : 64, C0 + c0};
+    }
+    wa.slabs = slabs;
+    const int taps = k * k;
+    const size_t used = (size_t)L.n_slices * taps * n_out * wa.Ct;
+    VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, used * sizeof(float), stream));
+    VPX_CHECK_HIP(launch_wgrad(wa, L.n_slices, stream));
+    VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dW, L.n_slices, taps, n_out, wa.Ct, stream));
+    return VPX_OK;
+}
+
+}  // namespace
+
+extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c,
+                                   const float* m, const float* c_new, const float* m_new, const float* Wx,
+                                   const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
+                                   const void* reserve, size_t reserve_bytes, const float* dh_new, const float* dc_new,
+                                   const float* dm_new, const float* ddelta_c, const float* ddelta_m, float* dx,
+                                   float* dh, float* dc, float* dm, float* dWx, float* dWh, float* dWm, float* dWo,
+                                   float* dWlast, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!d) { set_error("stlstm desc is NULL"); return VPX_ERR_ARG; }
+    if (d->layer_norm) { set_error("stlstm: the LayerNorm variant is not implemented yet"); return VPX_ERR_UNSUPPORTED; }
+    if (d->precision != VPX_PREC_F32) { set_error("stlstm: only VPX_PREC_F32 is implemented"); return VPX_ERR_UNSUPPORTED; }
+    if (!(d->flags & VPX_FLAG_SAVE_FOR_BWD)) { set_error("vpx_stlstm_step_bwd: desc lacks VPX_FLAG_SAVE_FOR_BWD"); return VPX_ERR_ARG; }
+    if (!x || !h || !c || !m || !c_new || !m_new || !Wx || !Wh || !Wm || !Wo || !Wlast || !reserve) {
+        set_error("vpx_stlstm_step_bwd: NULL tensor argument");
+        return VPX_ERR_ARG;
+    }
+    STBwdLayout L;
+    int rc = st_bwd_layout(d, L);
+    if (rc != VPX_OK) return rc;
+    if (reserve_bytes < vpx_stlstm_reserve_bytes(d)) { set_error("vpx_stlstm_step_bwd: reserve too small"); return VPX_ERR_WORKSPACE; }
+    if (!workspace || workspace_bytes < vpx_stlstm_workspace_bytes(d)) { set_error("vpx_stlstm_step_bwd: workspace too small"); return VPX_ERR_WORKSPACE; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int B = d->B, Cin = d->Cin, Ch = d->Ch, H = d->H, Wd = d->W, k = d->k;
+    const size_t HW = (size_t)H * Wd;
+    const int ldG = 7 * Ch;
+
+    Carver ws{(char*)workspace, 0, workspace_bytes};
+    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    float* dG7 = ws.take(L.n_g7);
+    float* dlc = ws.take(L.n_state);
+    float* dcn_conv = ws.take(L.n_state);
+    float* dmn_conv = ws.take(L.n_state);
+    float* dm_scratch = ws.take(L.n_state);
+    float* wpk_o = ws.take(L.o.wpk);
+    float* wpk_l = ws.take(L.l.wpk);
+    float* wpk_x = ws.take(L.x.wpk);
+    float* wpk_h = ws.take(L.h.wpk);
+    float* wpk_m = ws.take(L.m.wpk);
+    float* slabs = ws.take(L.slab_floats);
+
+    const float *xn = x, *hn = h, *cn = c, *mn = m, *cnn = c_new, *mnn = m_new;
+    const float *g_h = dh_new, *g_c = dc_new, *g_m = dm_new, *g_dc = ddelta_c, *g_dm = ddelta_m;
+    float *dxn = dx, *dhn = dh, *dcn = dc, *dmn = dm;
+    if (d->layout == VPX_LAYOUT_NCHW) {
+        float* bx = ws.take(L.n_x);
+        float* bdx = ws.take(L.n_x);
+        float* st[14];
+        for (auto& p : st) p = ws.take(L.n_state);
+        VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B, Cin, H, Wd, stream)); xn = bx;
+        const float* ins[10] = {h, c, m, c_new, m_new, dh_new, dc_new, dm_new, ddelta_c, ddelta_m};
+        const float** outs[10] = {&hn, &cn, &mn, &cnn, &mnn, &g_h, &g_c, &g_m, &g_dc, &g_dm};
+        for (int i = 0; i < 10; ++i)
+            if (ins[i]) { VPX_CHECK_HIP(launch_nchw_to_nhwc(ins[i], st[i], B, Ch, H, Wd, stream)); *outs[i] = st[i]; }
+        if (dx) dxn = bdx;
+        if (dh) dhn = st[10];
+        if (dc) dcn = st[11];
+        if (dm) dmn = st[12];
+    }
+    if (!dmn) dmn = dm_scratch;
+
+    const char* r = (const char*)reserve;
+    const float* gates_c = (const float*)r; r += align256(3 * L.n_state * 4);
+    const float* gates_m = (const float*)r; r += align256(3 * L.n_state * 4);
+    const float* o_save = (const float*)r; r += align256(L.n_state * 4);
+    const float* tl_save = (const float*)r;
+
+    auto plan_for = [&](const STBwdLayout::DG& g, int kk, const float* wpk) {
+        ConvPlan P{};
+        P.B = B; P.H = H; P.W = Wd; P.kh = kk; P.kw = kk;
+        P.tiles_x = (Wd + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_H - 1) / TILE_H;
+        P.nstage = g.nstage; memcpy(P.stage, g.stage, sizeof(ConvStage) * g.nstage);
+        P.chunks_total = g.chunks; P.a_bytes = conv_a_bytes(g.stage, g.nstage, kk, kk); P.wpk = wpk;
+        return P;
+    };
+    auto pack_plain_T = [&](PackDesc& pd, const STBwdLayout::DG& g, int taps, int n_out) {
+        memcpy(pd.stage, g.stage, sizeof(ConvStage) * g.nstage);
+        pd.nstage = g.nstage; pd.chunks_total = g.chunks; pd.n_tiles = g.tiles; pd.taps = taps; pd.NG = 4;
+        for (int s = 0; s < MAX_SEG; ++s) for (int gg = 0; gg < 4; ++gg) pd.rowbase[s][gg] = gg * 32;
+        for (int gg = 0; gg < 4; ++gg) pd.goff[gg] = gg * 32;
+        pd.tile_stride = NT; pd.nch = n_out; pd.transposed = 1; pd.flip = 1;
+    };
+
+    // ---- A: through h_new = o * tanh(conv_last(mem)) ----
+    {
+        STBwdOutArgs a{(long long)L.n_state, Ch, ldG, 3 * Ch, g_h, o_save, tl_save, dG7, dlc};
+        VPX_CHECK_HIP(launch_st_bwd_out(a, stream));
+    }
+    // ---- B: grads of mem = [c_new | m_new] through conv_o (k x k) and conv_last (1 x 1) ----
+    {
+        PackDesc pd{};
+        pd.seg[0] = PackSeg{Wo, (long long)2 * Ch * L.taps, L.taps, 0, Ch};
+        pack_plain_T(pd, L.o, L.taps, 2 * Ch);
+        VPX_CHECK_HIP(launch_pack_weights(pd, wpk_o, stream));
+        ConvPlan P = plan_for(L.o, k, wpk_o);
+        P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG};
+        PlainEpiArgs ea{};
+        ea.Co = 2 * Ch; ea.split = Ch;
+        ea.out0 = dcn_conv; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
+        ea.out1 = dmn_conv; ea.bstride1 = (long long)(HW * Ch); ea.ld1 = Ch;
+        VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.o.tiles, stream));
+
+        PackDesc pl{};
+        pl.seg[0] = PackSeg{Wlast, (long long)2 * Ch, 1, 0, Ch};
+        pack_plain_T(pl, L.l, 1, 2 * Ch);
+        VPX_CHECK_HIP(launch_pack_weights(pl, wpk_l, stream));
+        ConvPlan Q = plan_for(L.l, 1, wpk_l);
+        Q.nseg = 1; Q.seg[0] = ConvSeg{dlc, (long long)(HW * Ch), Ch, 0};
+        ea.accumulate = 1;
+        VPX_CHECK_HIP(launch_conv_plain_f32(Q, ea, L.l.tiles, stream));
+    }
+    // ---- C: gate groups ----
+    {
+        STBwdGateArgs a{};
+        a.npix = (long long)B * HW; a.Ch = Ch; a.ldG = ldG;
+        a.gates_c = gates_c; a.gates_m = gates_m; a.c = cn; a.m = mn;
+        a.dcn_ext = g_c; a.dmn_ext = g_m; a.ddc_ext = g_dc; a.ddm_ext = g_dm;
+        a.dcn_conv = dcn_conv; a.dmn_conv = dmn_conv;
+        a.dG7 = dG7; a.dc = dcn; a.dm = dmn;
+        VPX_CHECK_HIP(launch_st_bwd_gates(a, stream));
+    }
+    // ---- D: data gradients ----
+    if (dxn) {
+        PackDesc pd{};
+        const long long ldo = (long long)Cin * L.taps;
+        pd.seg[0] = PackSeg{Wx, ldo, L.taps, 0, 3 * Ch};        // dG7 blocks (i,f,g)     <-> Wx row blocks 0,1,2
+        pd.seg[1] = PackSeg{Wx, ldo, L.taps, 6 * Ch, Ch};       // dG7 block  o           <-> Wx row block 6
+        pd.seg[2] = PackSeg{Wx, ldo, L.taps, 3 * Ch, 3 * Ch};   // dG7 blocks (i',f',g')  <-> Wx row blocks 3,4,5
+        pack_plain_T(pd, L.x, L.taps, Cin);
+        VPX_CHECK_HIP(launch_pack_weights(pd, wpk_x, stream));
+        ConvPlan P = plan_for(L.x, k, wpk_x);
+        P.nseg = 3;
+        P.seg[0] = ConvSeg{dG7, (long long)(HW * ldG), 3 * Ch, ldG};
+        P.seg[1] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG};
+        P.seg[2] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG};
+        PlainEpiArgs ea{};
+        ea.Co = Cin; ea.split = Cin; ea.out0 = dxn; ea.bstride0 = (long long)(HW * Cin); ea.ld0 = Cin;
+        VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.x.tiles, stream));
+    }
+    if (dhn) {
+        PackDesc pd{};
+        pd.seg[0] = PackSeg{Wh, (long long)Ch * L.taps, L.taps, 0, 4 * Ch};
+        pack_plain_T(pd, L.h, L.taps, Ch);
+        VPX_CHECK_HIP(launch_pack_weights(pd, wpk_h, stream));
+        ConvPlan P = plan_for(L.h, k, wpk_h);
+        P.nseg = 1; P.seg[0] = ConvSeg{dG7, (long long)(HW * ldG), 4 * Ch, ldG};
+        PlainEpiArgs ea{};
+        ea.Co = Ch; ea.split = Ch; ea.out0 = dhn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
+        VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.h.tiles, stream));
+    }
+    if (dm) {
+        PackDesc pd{};
+        pd.seg[0] = PackSeg{Wm, (long long)Ch * L.taps, L.taps, 0, 3 * Ch};
+        pack_plain_T(pd, L.m, L.taps, Ch);
+        VPX_CHECK_HIP(launch_pack_weights(pd, wpk_m, stream));
+        ConvPlan P = plan_for(L.m, k, wpk_m);
+        P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG};
+        PlainEpiArgs ea{};
+        ea.Co = Ch; ea.split = Ch; ea.out0 = dmn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
+        ea.accumulate = 1;  // onto dm_new_total * f' written by stage C
+        VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.m.tiles, stream));
+    }
+    // ---- E: weight gradients ----
+    if (dWo && (rc = run_wgrad(d, L, dG7 + 3 * Ch, Ch, ldG, cnn, Ch, mnn, Ch, k, nullptr, 0, Ch, slabs, dWo, stream))) return rc;
+    if (dWlast && (rc = run_wgrad(d, L, dlc, Ch, Ch, cnn, Ch, mnn, Ch, 1, nullptr, 0, Ch, slabs, dWlast, stream))) return rc;
+    if (dWx) {
+        const int rowblk[8] = {0, 1, 2, 6, 3, 4, 5, 0};
+        if ((rc = run_wgrad(d, L, dG7, 7 * Ch, ldG, xn, Cin, nullptr, 0, k, rowblk, Ch, 7 * Ch, slabs, dWx, stream))) return rc;
+    }
+    if (dWh && (rc = run_wgrad(d, L, dG7, 4 * Ch, ldG, hn, Ch, nullptr, 0, k, nullptr, 0, 4 * Ch, slabs, dWh, stream))) return rc;
+    if (dWm && (rc = run_wgrad(d, L, dG7 + 4 * Ch, 3 * Ch, ldG, mn, Ch, nullptr, 0, k, nullptr, 0, 3 * Ch, slabs, dWm, stream))) return rc;
+
+    if (d->layout == VPX_LAYOUT_NCHW) {
+        if (dx) VPX_CHECK_HIP(launch_nhwc_to_nchw(dxn, dx, B, Cin, H, Wd, stream));
+        if (dh) VPX_CHECK_HIP(launch_nhwc_to_nchw(dhn, dh, B, Ch, H, Wd, stream));
+        if (dc) VPX_CHECK_HIP(launch_nhwc_to_nchw(dcn, dc, B, Ch, H, Wd, stream));
+        if (dm) VPX_CHECK_HIP(launch_nhwc_to_nchw(dmn, dm, B, Ch, H, Wd, stream));
+    }
+    return VPX_OK;
+}

@@ -127,7 +127,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     pd.n_tiles = L.n_tiles;
     pd.taps = L.taps;
     pd.NG = 4;
-    for (int g = 0; g < 4; ++g) { pd.rowbase[g] = gp[g] * Ch; pd.goff[g] = 0; }
+    for (int g = 0; g < 4; ++g) { pd.rowbase[0][g] = pd.rowbase[1][g] = gp[g] * Ch; pd.goff[g] = 0; }
     pd.tile_stride = 32;
     pd.nch = Ch;
     pd.transposed = 0;
@@ -230,7 +230,7 @@ int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
     pd.seg[0] = PackSeg{w, (long long)Ci * kh * kw, kh * kw, 0, Ci};
     memcpy(pd.stage, P.stage, sizeof(ConvStage) * P.nstage);
     pd.nstage = P.nstage; pd.chunks_total = chunks; pd.n_tiles = n_tiles; pd.taps = kh * kw; pd.NG = 4;
-    for (int g = 0; g < 4; ++g) { pd.rowbase[g] = g * 32; pd.goff[g] = g * 32; }
+    for (int g = 0; g < 4; ++g) { pd.rowbase[0][g] = g * 32; pd.goff[g] = g * 32; }
     pd.tile_stride = NT; pd.nch = Co;
     VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
     P.B = N; P.H = H; P.W = W; P.kh = kh; P.kw = kw;

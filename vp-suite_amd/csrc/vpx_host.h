@@ -127,4 +127,7 @@ static inline size_t convlstm_bwd_workspace_bytes(const vpx_convlstm_desc* d, co
     return b;
 }
 
+// backward workspace of one ST-LSTM step (stlstm_bwd_api.hip); 0 until that file provides a real figure
+size_t stlstm_bwd_workspace_bytes(const vpx_stlstm_desc* d);
+
 }  // namespace vpx

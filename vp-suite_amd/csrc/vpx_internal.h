@@ -29,8 +29,8 @@ constexpr int MAX_STAGE = 16;
 struct ConvSeg {          // one activation source, NHWC [B][H][W][C] with arbitrary batch stride (selects a time slice)
     const float* ptr;
     long long bstride;    // elements between consecutive batch items
-    int C;                // real channels (row length in memory)
-    int _pad;
+    int C;                // channels taken from each pixel row
+    int ld;               // elements between consecutive pixels (0 = C): lets a segment be a channel slice of a wider tensor
 };
 
 struct ConvStage {        // one K-stage: channels [c0, c0+cn) of segment `seg`, all taps
@@ -48,7 +48,7 @@ struct ConvPlan {
     int _pad;
     ConvSeg seg[MAX_SEG];
     ConvStage stage[MAX_STAGE];
-    const float* wpk;     // packed weights [n_tiles][chunks_total][NT][KC]
+    const float* wpk;     // packed weights [n_tiles][chunks_total][NG*32][KC]
 };
 
 // Source description for the weight repack kernel: where does packed element (n_tile, g, j, stage, tap, c) come from?
@@ -64,7 +64,7 @@ struct PackDesc {
     ConvStage stage[MAX_STAGE];
     int nstage, chunks_total, n_tiles, taps;
     int NG;               // groups per tile actually used (rows of unused groups are zero)
-    int rowbase[MAX_NG];  // source output-row of (channel 0, tile 0) for group g; -1 = group unused
+    int rowbase[MAX_SEG][MAX_NG];  // per segment: source output-row of (channel 0, tile 0) for group g; -1 = none
     int goff[MAX_NG];     // channel-index offset of group g used only for the validity test
     int tile_stride;      // channels advanced per n_tile
     int nch;              // number of valid output channels
@@ -75,7 +75,7 @@ struct PackDesc {
 void set_error(const char* fmt, ...);
 int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int kc);
 int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw);
-size_t packed_weight_bytes(int n_tiles, int chunks_total);
+size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng = 4);
 
 hipError_t launch_pack_weights(const PackDesc& pd, float* dst, hipStream_t s);
 
@@ -105,6 +105,28 @@ struct PlainEpiArgs {
 };
 hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, int n_tiles, hipStream_t s);
 
+// ---- ST-LSTM (predrnn.py:57-83) epilogues; all tensors NHWC [B,HW,Ch] ----
+struct STGateArgs {           // "c group": acc = (i, f, g, o_pre) from [x | h];  "m group": acc = (i', f', g') from [x | m]
+    int Ch;
+    float forget_bias;        // 1.0 (predrnn.py:23)
+    const float* s_in;        // c_t (c group) or m_t (m group)
+    float* s_new;             // c_new / m_new
+    float* delta;             // delta_c / delta_m
+    float* o_pre;             // c group only: o_x + o_h (pre-activation partial), else null
+    float* gates;             // [B,HW,3Ch] post-activation (i,f,g) for the backward, or null
+};
+struct STOutArgs {            // h_new = sigmoid(o_pre + conv_o(mem)) * tanh(conv_last(mem))
+    int Ch;
+    const float* o_pre;
+    const float* lc;          // conv_last(mem)
+    float* h_new;
+    float* o_save;            // sigmoid output, or null
+    float* tl_save;           // tanh(conv_last) or null
+};
+hipError_t launch_st_cgroup_f32(const ConvPlan& plan, const STGateArgs& ea, int n_tiles, hipStream_t s);
+hipError_t launch_st_mgroup_f32(const ConvPlan& plan, const STGateArgs& ea, int n_tiles, hipStream_t s);
+hipError_t launch_st_out_f32(const ConvPlan& plan, const STOutArgs& ea, int n_tiles, hipStream_t s);
+
 // ---- BPTT pieces (lstm_bwd.hip) ----
 struct GateBwdArgs {
     int B, HW, Ch;
@@ -127,8 +149,12 @@ hipError_t launch_colsum(const float* m, float* out, long long rows, int cols, h
 struct WgradCTile { int seg, c0, cn, cglobal; };   // 64-channel slice [c0, c0+cn) of segment seg; cglobal = column in [x|h]
 struct WgradArgs {
     int T, B, H, W, HW, kh, kw, tiles_x, tiles_y;
-    int N4, Cin, Ch, Ct;      // gate rows (4Ch), segment channel counts, Ct = Cin + Ch
-    const float* dG;          // [T][B,HW,N4]
+    int N4, Cin, Ch, Ct;      // contraction-side rows (e.g. 4Ch gate rows), segment channel counts, Ct = Cin + Ch
+    int ldG;                  // elements between consecutive pixels of dG (0 = N4)
+    int blk;                  // row-block size for the output-row map (0 = identity map)
+    int rowblk[8];            // output row of dG channel n = rowblk[n / blk] * blk + n % blk
+    int n_out;                // rows of the weight-gradient tensor (0 = N4)
+    const float* dG;          // [T][B,HW,ldG]
     const float* x; long long x_bstride, x_tstride;        // x[b,t] slabs (null if no input)
     const float* hseq; long long h_bstride, h_tstride;     // forward outputs: h_{t-1} = hseq[b, t-1]
     const float* h0;          // [B,HW,Ch] or null
@@ -138,6 +164,28 @@ struct WgradArgs {
 };
 hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s);
+
+// ---- ST-LSTM backward pointwise stages ----
+struct STBwdOutArgs {         // stage A: through h_new = o * tanh(lc)
+    long long n;              // B*HW*Ch
+    int Ch, ldG, o_off;       // d(o pre-activation) is written into dG7[pix*ldG + o_off + ch]
+    const float* dh_new; const float* o; const float* tl;
+    float* dG7; float* dlc;
+};
+struct STBwdGateArgs {        // stage B: through the two gate groups
+    long long npix;           // B*HW
+    int Ch, ldG;
+    const float* gates_c; const float* gates_m;    // [B,HW,3Ch] (i,f,g)
+    const float* c; const float* m;                // cell inputs
+    const float* dcn_ext; const float* dmn_ext;    // incoming grads of c_new / m_new (may be null)
+    const float* ddc_ext; const float* ddm_ext;    // incoming grads of delta_c / delta_m (may be null)
+    const float* dcn_conv; const float* dmn_conv;  // grads of c_new / m_new through conv_o / conv_last
+    float* dG7;               // blocks (i,f,g | o | i',f',g'), o block already filled by stage A
+    float* dc;                // out: dL/dc (may be null)
+    float* dm;                // out: direct part of dL/dm = dm_new_total * f' (conv part is accumulated later)
+};
+hipError_t launch_st_bwd_out(const STBwdOutArgs& a, hipStream_t s);
+hipError_t launch_st_bwd_gates(const STBwdGateArgs& a, hipStream_t s);
 
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);

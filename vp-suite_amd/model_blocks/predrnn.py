@@ -1,0 +1,53 @@
+"""Spatio-Temporal LSTM cell (PredRNN-V2) — drop-in for vp_suite/model_blocks/predrnn.py:7-83.
+
+Same constructor signature and parameter tree (`conv_x.0.weight [7Ch,Cin,k,k]`, `conv_h.0.weight [4Ch,Ch,k,k]`,
+`conv_m.0.weight [3Ch,Ch,k,k]`, `conv_o.0.weight [Ch,2Ch,k,k]`, `conv_last.weight [Ch,2Ch,1,1]`, all bias-free) and the
+same return tuple `(h_new, c_new, m_new, delta_c, delta_m)`. The five convolutions + gate math of :57-83 run as four
+fused implicit-GEMM launches (csrc/stlstm_api.hip). The action-conditional twin (:86-169) is out of scope
+(SURVEY.md §2 row 3); the LayerNorm variant is declared but not yet implemented by the library (fails loudly)."""
+from torch import nn
+
+from .. import ops
+from ..base import VPModelBlock
+
+
+class SpatioTemporalLSTMCell(VPModelBlock):
+    NAME = "Spatio-Temporal LSTM Cell"
+    PAPER_REFERENCE = "https://arxiv.org/abs/2103.09504"
+    CODE_REFERENCE = "https://github.com/thuml/predrnn-pytorch"
+    MATCHES_REFERENCE = "Yes"
+
+    precision = "f32"
+
+    def __init__(self, in_channel, num_hidden, height, width, filter_size, stride, layer_norm):
+        super().__init__()
+        if stride != 1:
+            raise NotImplementedError("ST-LSTM cell: the recurrence needs stride 1 (state-preserving convolutions)")
+        self.num_hidden = num_hidden
+        self.padding = filter_size // 2
+        self._forget_bias = 1.0
+        self.layer_norm = bool(layer_norm)
+
+        def conv(c_in, c_out):
+            mods = [nn.Conv2d(c_in, c_out, kernel_size=filter_size, stride=stride, padding=self.padding, bias=False)]
+            if layer_norm:
+                mods.append(nn.LayerNorm([c_out, height, width]))
+            return nn.Sequential(*mods)
+
+        self.conv_x = conv(in_channel, num_hidden * 7)
+        self.conv_h = conv(num_hidden, num_hidden * 4)
+        self.conv_m = conv(num_hidden, num_hidden * 3)
+        self.conv_o = conv(num_hidden * 2, num_hidden)
+        self.conv_last = nn.Conv2d(num_hidden * 2, num_hidden, kernel_size=1, stride=1, padding=0, bias=False)
+        self._ws = ops.STWorkspace()
+
+    def __getstate__(self):  # workspaces are never pickled with the model (vpsuite.py:394 pickles whole modules)
+        state = self.__dict__.copy()
+        state["_ws"] = ops.STWorkspace()
+        return state
+
+    def forward(self, x_t, h_t, c_t, m_t):
+        if self.layer_norm:
+            raise NotImplementedError("ST-LSTM with layer_norm=True is not implemented by libvpx_hip yet")
+        return ops.stlstm_step(x_t, h_t, c_t, m_t, self.conv_x[0].weight, self.conv_h[0].weight, self.conv_m[0].weight,
+                               self.conv_o[0].weight, self.conv_last.weight, precision=self.precision, wsholder=self._ws)

@@ -1,0 +1,206 @@
+"""PredRNN-V2 ("predrnn-pp") — drop-in for vp_suite/models/predrnn_v2.py:11-365 (non-action-conditional form).
+
+Hyper-parameter names/defaults, state_dict keys (`cell_list.{l}.conv_{x,h,m,o}.0.weight`,
+`cell_list.{l}.conv_last.weight`, `conv_last.weight`, `adapter.weight`), the forward contract
+`forward(x[b,T_total,c,h,w], pred_frames, train=...) -> (pred[b,p,c,h,w], {"ST-LSTM decouple loss": scalar})`,
+scheduled-sampling schedules and the custom train_iter (forward + reversed forward, averaged) follow the reference.
+Every ST-LSTM cell step runs in libvpx_hip (4 fused launches); patchify is a pure permutation, the decoupling-loss tail
+and the 1x1 frame head stay on stock GPU ops this round.
+The action-conditional variant is outside the hot-path scope (no action dataset in the BASELINE configs)."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..base import VPModel, _progress
+from ..model_blocks import SpatioTemporalLSTMCell as STCell
+
+
+class PredRNN_V2(VPModel):
+    NAME = "PredRNN++"
+    PAPER_REFERENCE = "https://arxiv.org/abs/2103.09504"
+    CODE_REFERENCE = "https://github.com/thuml/predrnn-pytorch"
+    MATCHES_REFERENCE: str = "Yes"
+    CAN_HANDLE_ACTIONS = False
+    NEEDS_COMPLETE_INPUT = True
+
+    patch_size = 4
+    num_layers = 3
+    num_hidden = [128, 128, 128, 128]
+    filter_size = 5
+    stride = 1
+    inflated_action_dim = 3
+    layer_norm: bool = False
+    conv_actions_on_input: bool = True
+    residual_on_action_conv: bool = True
+
+    reverse_input: bool = True
+    decoupling_loss_scale = 100.0
+    scheduled_sampling: bool = True
+    sampling_stop_iter: int = 50000
+    sampling_changing_rate = 2e-5
+    reverse_scheduled_sampling: bool = False
+    r_sampling_step_1: int = 25000
+    r_sampling_step_2: int = 50000
+    r_exp_alpha: int = 5000
+    training_iteration: int = None
+    sampling_eta: float = None
+    cell_precision = "f32"  #: arithmetic of the fused ST-LSTM kernels
+
+    def __init__(self, device, **model_kwargs):
+        super().__init__(device, **model_kwargs)
+        if self.action_conditional:
+            raise NotImplementedError("action-conditional PredRNN-V2 is outside the scope of this build")
+        self.patch_c = self.patch_size * self.patch_size * self.img_c
+        self.patch_a = self.action_size
+        self.patch_h = self.rnn_h = self.img_h // self.patch_size
+        self.patch_w = self.rnn_w = self.img_w // self.patch_size
+        self.conv_actions_on_input = False
+        self.residual_on_action_conv = False
+
+        cells = []
+        for i in range(self.num_layers):
+            c_in = self.patch_c if i == 0 else self.num_hidden[i - 1]
+            cell = STCell(c_in, self.num_hidden[i], self.rnn_h, self.rnn_w, self.filter_size, self.stride,
+                          self.layer_norm)
+            cell.precision = self.cell_precision
+            cells.append(cell)
+        self.cell_list = nn.ModuleList(cells)
+        self.conv_last = nn.Conv2d(self.num_hidden[self.num_layers - 1], self.patch_c, kernel_size=1, stride=1,
+                                   padding=0, bias=False)
+        self.adapter = nn.Conv2d(self.num_hidden[0], self.num_hidden[0], kernel_size=1, stride=1, padding=0, bias=False)
+        self.training_iteration = 1
+        self.sampling_eta = 1.0
+        self.NON_CONFIG_VARS.extend(["training_iteration, sampling_eta"])
+
+    def pred_1(self, x, **kwargs):
+        return self(x, pred_frames=1, **kwargs)[0].squeeze(dim=1)
+
+    def _decouple_term(self, delta_c, delta_m):
+        b, ch = delta_c.shape[:2]
+        a = F.normalize(self.adapter(delta_c).reshape(b, ch, -1), dim=2)
+        m = F.normalize(self.adapter(delta_m).reshape(b, ch, -1), dim=2)
+        return torch.mean(torch.abs(torch.cosine_similarity(a, m, dim=2)))
+
+    def forward(self, x, pred_frames: int = 1, **kwargs):
+        b, total_frames = x.shape[:2]
+        context_frames = total_frames - pred_frames
+        if context_frames < 1:
+            raise ValueError("Model {self.NAME} needs input sequences that also include the target frames!")
+        train = kwargs.get("train", False)
+        dev = x.device
+        x_patch = self._reshape_patch(x)
+
+        def zeros(i):
+            return torch.zeros(b, self.num_hidden[i], self.rnn_h, self.rnn_w, device=dev)
+        h_t = [zeros(i) for i in range(self.num_layers)]
+        c_t = [zeros(i) for i in range(self.num_layers)]
+        memory = zeros(0)
+        mask_true = self._scheduled_sampling(b, context_frames, pred_frames, train)
+        first_blend = 1 if self.reverse_scheduled_sampling else context_frames
+        x_gen, next_frames, decouple = None, [], []
+        for t in range(total_frames - 1):
+            if t < first_blend:
+                net = x_patch[:, t]
+            else:
+                mk = mask_true[:, t - first_blend]
+                net = mk * x_patch[:, t] + (1 - mk) * x_gen
+            for i in range(self.num_layers):
+                inp = net if i == 0 else h_t[i - 1]
+                h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory)
+                decouple.append(self._decouple_term(d_c, d_m))
+            x_gen = self.conv_last(h_t[self.num_layers - 1])
+            next_frames.append(x_gen)
+        pred = self._reshape_patch_back(torch.stack(next_frames[-pred_frames:], dim=1))
+        loss = torch.mean(torch.stack(decouple, dim=0))
+        return pred, {"ST-LSTM decouple loss": self.decoupling_loss_scale * loss}
+
+    # ---- patch (un)folding: channel order (p_h, p_w, c)  (predrnn_v2.py:232-250) ----
+    def _reshape_patch(self, x):
+        b, t, c, h, w = x.shape
+        if (self.img_c, self.img_h, self.img_w) != (c, h, w):
+            raise ValueError(f"shape mismatch: expected {(self.img_c, self.img_h, self.img_w)}, got {(c, h, w)}")
+        p = self.patch_size
+        x = x.reshape(b, t, c, self.patch_h, p, self.patch_w, p).permute(0, 1, 4, 6, 2, 3, 5)
+        return x.reshape(b, t, -1, self.patch_h, self.patch_w)
+
+    def _reshape_patch_back(self, x_patch):
+        b, t, cpp = x_patch.shape[:3]
+        p = self.patch_size
+        c = cpp // (p * p)
+        x = x_patch.reshape(b, t, p, p, c, self.patch_h, self.patch_w).permute(0, 1, 4, 5, 2, 6, 3)
+        return x.reshape(b, t, c, self.patch_h * p, self.patch_w * p)
+
+    # ---- sampling schedules (predrnn_v2.py:252-317) ----
+    def _flag_tensor(self, batch_size, n, device):
+        return torch.zeros(batch_size, n, self.patch_c, self.patch_h, self.patch_w, device=device)
+
+    def _reserve_schedule_sampling(self, batch_size, context_frames, pred_frames):
+        itr = self.training_iteration
+        if itr < self.r_sampling_step_1:
+            r_eta, eta = 0.5, 0.5
+        elif itr < self.r_sampling_step_2:
+            r_eta = 1.0 - 0.5 * math.exp(-float(itr - self.r_sampling_step_1) / self.r_exp_alpha)
+            eta = 0.5 - (0.5 / (self.r_sampling_step_2 - self.r_sampling_step_1)) * (itr - self.r_sampling_step_1)
+        else:
+            r_eta, eta = 1.0, 0.0
+        dev = self._rng_device()
+        r_flip = torch.rand(batch_size, context_frames - 1, device=dev)
+        flip = torch.rand(batch_size, pred_frames - 1, device=dev)
+        r_flag = self._flag_tensor(batch_size, context_frames - 1, dev)
+        r_flag[r_flip < r_eta] = 1
+        flag = self._flag_tensor(batch_size, pred_frames - 1, dev)
+        flag[flip < eta] = 1
+        return torch.cat([r_flag, flag], dim=1)
+
+    def _std_schedule_sampling(self, batch_size, context_frames, pred_frames):
+        dev = self._rng_device()
+        if not self.scheduled_sampling:
+            # the reference returns a (0.0, zeros) tuple here (predrnn_v2.py:285-287), which its own forward cannot
+            # index; the evident intent — no ground-truth frames mixed in — is the all-zero mask
+            return self._flag_tensor(batch_size, pred_frames - 1, dev)
+        if self.training_iteration < self.sampling_stop_iter:
+            self.sampling_eta -= self.sampling_changing_rate
+        else:
+            self.sampling_eta = 0.0
+        flip = torch.rand(batch_size, pred_frames - 1, device=dev)
+        flag = self._flag_tensor(batch_size, pred_frames - 1, dev)
+        flag[flip < self.sampling_eta] = 1
+        return flag
+
+    def _test_schedule_sampling(self, batch_size, context_frames, pred_frames):
+        n = context_frames + pred_frames - 2 if self.reverse_scheduled_sampling else pred_frames - 1
+        flag = self._flag_tensor(batch_size, n, self._rng_device())
+        if self.reverse_scheduled_sampling:
+            flag[:, :context_frames - 1] = 1
+        return flag
+
+    def _scheduled_sampling(self, batch_size, context_frames, pred_frames, train):
+        if not train:
+            return self._test_schedule_sampling(batch_size, context_frames, pred_frames)
+        if self.reverse_scheduled_sampling:
+            return self._reserve_schedule_sampling(batch_size, context_frames, pred_frames)
+        return self._std_schedule_sampling(batch_size, context_frames, pred_frames)
+
+    def _rng_device(self):
+        return self.conv_last.weight.device
+
+    def train_iter(self, config, loader, optimizer, loss_provider, epoch):
+        """forward on the sequence and on its time-reversal, losses averaged, one optimizer step; counts training
+        iterations for the sampling schedule (predrnn_v2.py:319-365)."""
+        loop = _progress(loader)
+        for data in loop:
+            inp, targets, actions = self.unpack_data(data, config)
+            preds, ml = self(inp, pred_frames=config["pred_frames"], actions=actions, train=True)
+            total = self._total_loss(preds, targets, ml, loss_provider)
+            if self.reverse_input:
+                inp_r, targets_r, _ = self.unpack_data(data, config, reverse=True)
+                preds_r, ml_r = self(inp_r, pred_frames=config["pred_frames"], actions=actions, train=True)
+                total = (total + self._total_loss(preds_r, targets_r, ml_r, loss_provider)) / 2
+            optimizer.zero_grad()
+            total.backward()
+            optimizer.step()
+            self.training_iteration += 1
+            if hasattr(loop, "set_postfix"):
+                loop.set_postfix(loss=total.item())

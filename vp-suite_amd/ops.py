@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvLSTMDesc, check, ptr
+from ._lib import ConvLSTMDesc, STLSTMDesc, check, ptr
 
 PRECISIONS = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}
 
@@ -193,3 +193,87 @@ def conv2d_same(x, w, bias=None, precision="f32"):
                                N, H, Wd, Ci, Co, kh, kw, PRECISIONS[precision], ptr(ws), ws_bytes, _stream())
     check(rc, "vpx_conv2d_nhwc_fwd")
     return y
+
+
+class STWorkspace:
+    """Per-cell workspace that lets consecutive steps of one forward pass skip the weight repack
+    (VPX_FLAG_WEIGHTS_PACKED): valid while the weights' version counters and the problem shape are unchanged."""
+
+    def __init__(self):
+        self.buf = None
+        self.key = None
+
+    def get(self, nbytes, device, key):
+        """Returns (buffer, packed_valid)."""
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.key = None
+        valid = self.key == key
+        self.key = key
+        return self.buf, valid
+
+
+class _STLSTMStepFn(torch.autograd.Function):
+    """(h_new, c_new, m_new, delta_c, delta_m) = ST-LSTM cell step (predrnn.py:57-83) in one library call."""
+
+    @staticmethod
+    def forward(ctx, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision, need_grad, wsholder):
+        _require_gpu(x, "stlstm_step")
+        dev = x.device
+        B, Cin, H, Wd = x.shape
+        Ch = h.shape[1]
+        k = int(Wx.shape[-1])
+        xs, hs, cs, ms = (to_channels_last(t) for t in (x, h, c, m))
+        W5 = [w.contiguous() for w in (Wx, Wh, Wm, Wo, Wlast)]
+        flags = _lib.FLAG_SAVE_FOR_BWD if need_grad else 0
+        d = STLSTMDesc(B, Cin, Ch, H, Wd, k, 0, _lib.LAYOUT_NHWC, precision, flags)
+        L = _lib.lib()
+        ws_bytes = L.vpx_stlstm_workspace_bytes(ctypes.byref(d))
+        if ws_bytes == 0:
+            check(-4 if b"not implemented" in L.vpx_last_error() else -1, "vpx_stlstm_workspace_bytes")
+        rs_bytes = L.vpx_stlstm_reserve_bytes(ctypes.byref(d))
+        key = (B, Cin, Ch, H, Wd, k, precision, flags, tuple((w.data_ptr(), w._version) for w in W5))
+        if wsholder is not None:
+            ws, packed = wsholder.get(ws_bytes, dev, key)
+        else:
+            ws, packed = torch.empty(ws_bytes, dtype=torch.uint8, device=dev), False
+        if packed:
+            d.flags |= _lib.FLAG_WEIGHTS_PACKED
+        reserve = torch.empty(max(rs_bytes, 1), dtype=torch.uint8, device=dev)
+        outs = [new_channels_last((B, Ch, H, Wd), dev) for _ in range(5)]
+        rc = L.vpx_stlstm_step_fwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), *[ptr(w) for w in W5], None,
+                                   *[ptr(o) for o in outs], ptr(reserve), rs_bytes, ptr(ws), ws_bytes, _stream())
+        check(rc, "vpx_stlstm_step_fwd")
+        if need_grad:
+            ctx.save_for_backward(xs, hs, cs, ms, outs[1], outs[2], *W5, reserve)
+            d.flags = flags
+            ctx.desc = d
+            ctx.rs_bytes = rs_bytes
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dh_new, dc_new, dm_new, ddc, ddm):
+        xs, hs, cs, ms, c_new, m_new, Wx, Wh, Wm, Wo, Wlast, reserve = ctx.saved_tensors
+        d = ctx.desc
+        dev = xs.device
+        L = _lib.lib()
+        gin = [None if g is None else to_channels_last(g) for g in (dh_new, dc_new, dm_new, ddc, ddm)]
+        needs = ctx.needs_input_grad
+        dx = new_channels_last(tuple(xs.shape), dev) if needs[0] else None
+        dh = new_channels_last(tuple(hs.shape), dev) if needs[1] else None
+        dc = new_channels_last(tuple(cs.shape), dev) if needs[2] else None
+        dm = new_channels_last(tuple(ms.shape), dev) if needs[3] else None
+        dWs = [torch.empty_like(w) if needs[4 + i] else None for i, w in enumerate((Wx, Wh, Wm, Wo, Wlast))]
+        ws_bytes = L.vpx_stlstm_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        rc = L.vpx_stlstm_step_bwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), ptr(c_new), ptr(m_new), ptr(Wx),
+                                   ptr(Wh), ptr(Wm), ptr(Wo), ptr(Wlast), ptr(reserve), ctx.rs_bytes,
+                                   *[ptr(g) for g in gin], ptr(dx), ptr(dh), ptr(dc), ptr(dm), *[ptr(g) for g in dWs],
+                                   ptr(ws), ws_bytes, _stream())
+        check(rc, "vpx_stlstm_step_bwd")
+        return (dx, dh, dc, dm, *dWs, None, None, None)
+
+
+def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=None):
+    need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (x, h, c, m, Wx, Wh, Wm, Wo, Wlast))
+    return _STLSTMStepFn.apply(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, PRECISIONS[precision], need_grad, wsholder)
