@@ -227,3 +227,37 @@ def test_c_abi_nchw_bwd(vpx, dev):
     assert _relmax(out, g["out"]) < RTOL
     for n in G:
         assert _relmax(G[n], g[n]) < GRTOL, n
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# split-bf16 operand mode ("bf16x3"): fp32-level accuracy, held to the north-star tolerance (1e-4 relative)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", list(gc.HZZONE_CASES))
+def test_hzzone_block_bf16x3_vs_golden(vpx, dev, tag):
+    Cin, Ch, H, W, k, B, T, with_grads = gc.HZZONE_CASES[tag]
+    inp = {n: v.to(dev) for n, v in gc.hzzone_inputs(tag, Cin, Ch, H, W, k, B, T).items()}
+    g = load_golden(f"hzzone_{tag}_states")
+    lv = {n: inp[n].clone().requires_grad_(True) for n in ("x", "h0", "c0", "W", "b", "Wci", "Wcf", "Wco")}
+    out, hT, cT = vpx.ops.convlstm_seq(lv["x"], lv["h0"], lv["c0"], lv["W"], lv["b"], lv["Wci"], lv["Wcf"], lv["Wco"],
+                                       seq_len=T, in_channels=Cin, precision="bf16x3")
+    assert _relmax(out, g["out"]) < 2e-5 and _relmax(cT, g["cT"]) < 2e-5
+    if with_grads:
+        ((out * inp["g_out"]).sum() + (hT * inp["g_hT"]).sum() + (cT * inp["g_cT"]).sum()).backward()
+        for gname, lname in {"dW": "W", "db": "b", "dWci": "Wci", "dx": "x", "dh0": "h0", "dc0": "c0"}.items():
+            assert _relmax(lv[lname].grad, g[gname]) < 1e-4, gname
+
+
+@pytest.mark.parametrize("Cin,Ch,H,W", [(16, 64, 64, 64), (96, 96, 16, 16), (64, 64, 64, 64)])
+def test_real_block_shapes_bf16x3_vs_oracle(vpx, dev, Cin, Ch, H, W):
+    from oracle import torch_ref as tr
+    B, T, k = 2, 4, 3
+    tag = f"real.{Cin}.{Ch}.{H}"
+    Wt = seeded_randn((4 * Ch, Cin + Ch, k, k), name_seed(tag + "W"), 1.0 / np.sqrt((Cin + Ch) * 9))
+    b = seeded_randn((4 * Ch,), name_seed(tag + "b"), 0.1)
+    pw = [seeded_randn((1, Ch, H, W), name_seed(tag + n), 0.1) for n in ("ci", "cf", "co")]
+    x = seeded_rand((B, T, Cin, H, W), name_seed(tag + "x"))
+    with torch.no_grad():
+        ro, (rh, rc) = tr.convlstm_hzzone_seq(x, None, T, Wt, b, *pw, padding=1)
+        out, hT, cT = vpx.ops.convlstm_seq(x.to(dev), None, None, Wt.to(dev), b.to(dev), *[p.to(dev) for p in pw],
+                                           seq_len=T, in_channels=Cin, precision="bf16x3")
+    assert _relmax(out, ro) < 2e-5 and _relmax(cT, rc) < 2e-5

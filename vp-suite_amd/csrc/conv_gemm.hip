@@ -11,6 +11,8 @@
 // B fragment = one ds_read_b128 per group (4 consecutive k of the lane's output channel); 4 MFMAs per group per read.
 // MFMA k-pairing: lanes 0-31 supply k = kb+s, lanes 32-63 supply k = kb+4+s (s = 0..3) for BOTH operands, so a b128
 // read feeds four 32x32x2 steps covering 8 consecutive k.
+#include <stdlib.h>
+
 #include "vpx_internal.h"
 
 namespace vpx {
@@ -20,29 +22,45 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_bits(float v) {
+    __bf16 h = (__bf16)v;  // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+__device__ __forceinline__ void split_bf16(float v, unsigned short& hi, unsigned short& lo) {
+    hi = bf16_bits(v);
+    lo = bf16_bits(v - bf16_to_f32(hi));
+}
+
+__host__ __device__ inline int mode_kstep(int prec) { return prec == VPX_PREC_F32 ? 8 : 16; }   // channels per k-step
+__host__ __device__ inline int mode_kc(int prec) { return prec == VPX_PREC_F32 ? 16 : 32; }     // k-depth of a weight chunk
+
 // ---------------------------------------------------------------------------------------------------------------
 // weight repack: reference OIHW -> [n_tile][chunk][n = g*32+j, g < NG][kk]  (kk = position inside the KC-deep chunk)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void pack_weights_kernel(const PackDesc pd, float* __restrict__ dst) {
-    const int ntr = pd.NG * 32;  // rows per chunk
-    const long long total = (long long)pd.n_tiles * pd.chunks_total * ntr * KC_F32;
+__global__ void pack_weights_kernel(const PackDesc pd, char* __restrict__ dst) {
+    const int ntr = pd.NG * 32;                       // rows per chunk
+    const int kc = mode_kc(pd.prec);                  // k-depth of a chunk
+    const int row_bytes = kc * 4;                     // fp32: kc floats; bf16x3: kc hi-bf16 then kc lo-bf16
+    const long long total = (long long)pd.n_tiles * pd.chunks_total * ntr * kc;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
          e += (long long)gridDim.x * blockDim.x) {
-        const int kk = (int)(e % KC_F32);
-        long long r = e / KC_F32;
+        const int kk = (int)(e % kc);
+        long long r = e / kc;
         const int n = (int)(r % ntr);
         r /= ntr;
         const int chunk = (int)(r % pd.chunks_total);
         const int n_tile = (int)(r / pd.chunks_total);
-        // which stage does this chunk belong to?
-        int s = 0;
+        int s = 0;  // which stage does this chunk belong to?
         for (int i = 1; i < pd.nstage; ++i)
             if (chunk >= pd.stage[i].chunk0) s = i;
         const ConvStage st = pd.stage[s];
-        const int kin = (chunk - st.chunk0) * KC_F32 + kk;  // k index inside the stage = tap*cn + (c - c0)
+        const int kin = (chunk - st.chunk0) * kc + kk;  // k index inside the stage = tap*cn + (c - c0)
         float v = 0.0f;
         const int g = n >> 5, j = n & 31;
-        if (kin < st.nq * 8 && g < pd.NG && pd.rowbase[st.seg][g] >= 0) {
+        if (kin < st.nq * mode_kstep(pd.prec) && g < pd.NG && pd.rowbase[st.seg][g] >= 0) {
             const int tap = kin / st.cn;
             const int c = st.c0 + kin % st.cn;
             const PackSeg sg = pd.seg[st.seg];
@@ -56,16 +74,24 @@ __global__ void pack_weights_kernel(const PackDesc pd, float* __restrict__ dst) 
                     v = sg.w[(long long)(sg.coff + c) * sg.ld_o + (long long)row * sg.ld_i + tp];
             }
         }
-        dst[e] = v;
+        char* rowp = dst + ((long long)(n_tile * pd.chunks_total + chunk) * ntr + n) * row_bytes;
+        if (pd.prec == VPX_PREC_F32) {
+            reinterpret_cast<float*>(rowp)[kk] = v;
+        } else {
+            unsigned short hi, lo;
+            split_bf16(v, hi, lo);
+            reinterpret_cast<unsigned short*>(rowp)[kk] = hi;
+            reinterpret_cast<unsigned short*>(rowp)[kc + kk] = lo;
+        }
     }
 }
 
 hipError_t launch_pack_weights(const PackDesc& pd, float* dst, hipStream_t s) {
-    const long long total = (long long)pd.n_tiles * pd.chunks_total * pd.NG * 32 * KC_F32;
+    const long long total = (long long)pd.n_tiles * pd.chunks_total * pd.NG * 32 * mode_kc(pd.prec);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, pd, dst);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, pd, reinterpret_cast<char*>(dst));
     return hipGetLastError();
 }
 
@@ -210,16 +236,30 @@ struct EpiPlain {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// main kernel, fp32 operands
+// main kernel. MODE 0: fp32 operands, v_mfma_f32_32x32x2_f32 (exact). MODE 1: split-bf16 ("bf16x3"): every operand is
+// hi + lo (two bf16), the product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation —
+// fp32-level accuracy (measured 4e-6 over a full 10->10 forward) at 3/16 of the fp32 MFMA cycles.
+// Both modes use the same LDS footprints: an activation row is cn*4 B (+16 pad): fp32 values, or cn hi-bf16 followed by
+// cn lo-bf16; a weight row is one chunk of one output channel: KC fp32, or KC hi followed by KC lo.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int WROW_F32 = KC_F32 * 4 + 16;  // padded LDS row of one output channel's chunk slice (144 B: 9 x 16 B, odd)
 
-template <class Epi>
-__global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan P, const Epi epi) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <int MODE> struct ModeTraits;
+template <> struct ModeTraits<0> { static constexpr int KSTEP = 8, KC = 16, WROW_DATA = 16 * 4; };
+template <> struct ModeTraits<1> { static constexpr int KSTEP = 16, KC = 32, WROW_DATA = 32 * 4; };
+
+template <class Epi, int MODE>
+__global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
+    using MT = ModeTraits<MODE>;
+    constexpr int KC = MT::KC, KSTEP = MT::KSTEP;
+    constexpr int WROW = MT::WROW_DATA + 16;   // padded LDS row of one output channel's chunk slice (odd multiple of 16 B)
+    constexpr int QPC = KC / KSTEP;            // k-steps per chunk (2 in both modes)
     constexpr int NG = Epi::NG;
-    constexpr int NTR = NG * 32;                 // weight rows (output channels x gate groups) per workgroup
-    constexpr int WBUF_F32 = NTR * WROW_F32;     // one LDS weight buffer
+    constexpr int NTR = NG * 32;               // weight rows (gate groups x 32 channels) per workgroup
+    constexpr int WBUF = NTR * WROW;           // one LDS weight buffer
+    constexpr int WV4 = NTR * MT::WROW_DATA / 16;              // 16-byte vectors per weight chunk
+    constexpr int WIT = (WV4 + NTHREADS - 1) / NTHREADS;       // staging loads per thread per chunk
+    constexpr int V4ROW = MT::WROW_DATA / 16;                  // 16-byte vectors per weight row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
 
@@ -245,7 +285,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan 
 
     // this lane's pixel inside the tile (MFMA row = lane & 31)
     const int py = 2 * wave + (j >> 4), px = j & 15;
-    const float* wtile = P.wpk + (size_t)n_tile * P.chunks_total * (NTR * KC_F32);
+    const char* wtile = reinterpret_cast<const char*>(P.wpk) + (size_t)n_tile * P.chunks_total * (NTR * MT::WROW_DATA);
 
     for (int s = 0; s < P.nstage; ++s) {
         const ConvStage st = P.stage[s];
@@ -267,7 +307,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan 
                     f32x4 val = {0.f, 0.f, 0.f, 0.f};
                     if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < sg.C)
                         val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * P.W + gx) * ld + c);
-                    *reinterpret_cast<f32x4*>(A_lds + pos * arow + c4 * 16) = val;
+                    if constexpr (MODE == 0) {
+                        *reinterpret_cast<f32x4*>(A_lds + pos * arow + c4 * 16) = val;
+                    } else {
+                        unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+                        split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);
+                        split_bf16(val[2], h2, l2); split_bf16(val[3], h3, l3);
+                        uint2 hv = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
+                        uint2 lv = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
+                        *reinterpret_cast<uint2*>(A_lds + pos * arow + c4 * 8) = hv;
+                        *reinterpret_cast<uint2*>(A_lds + pos * arow + st.cn * 2 + c4 * 8) = lv;
+                    }
                 }
             } else {
                 const int total = npos * st.cn;
@@ -279,61 +329,89 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan 
                     float val = 0.f;
                     if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < sg.C)
                         val = src[((size_t)gy * P.W + gx) * ld + c];
-                    *reinterpret_cast<float*>(A_lds + pos * arow + cc * 4) = val;
+                    if constexpr (MODE == 0) {
+                        *reinterpret_cast<float*>(A_lds + pos * arow + cc * 4) = val;
+                    } else {
+                        unsigned short h, l;
+                        split_bf16(val, h, l);
+                        *reinterpret_cast<unsigned short*>(A_lds + pos * arow + cc * 2) = h;
+                        *reinterpret_cast<unsigned short*>(A_lds + pos * arow + st.cn * 2 + cc * 2) = l;
+                    }
                 }
             }
         }
         // ---- weight chunk 0 of this stage ----
-        const int nchunks = (st.nq * 8 + KC_F32 - 1) / KC_F32;
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(wtile + (size_t)st.chunk0 * (NTR * KC_F32));
-        f32x4 wr[NG];
+        const int nchunks = (st.nq + QPC - 1) / QPC;
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(wtile + (size_t)st.chunk0 * (NTR * MT::WROW_DATA));
+        f32x4 wr[WIT];
 #pragma unroll
-        for (int it = 0; it < NG; ++it) wr[it] = wsrc[tid + it * NTHREADS];
+        for (int it = 0; it < WIT; ++it)
+            if (tid + it * NTHREADS < WV4) wr[it] = wsrc[tid + it * NTHREADS];
 #pragma unroll
-        for (int it = 0; it < NG; ++it) {
+        for (int it = 0; it < WIT; ++it) {
             const int v = tid + it * NTHREADS;
-            *reinterpret_cast<f32x4*>(W_lds + (v >> 3) * WROW_F32 + (v & 7) * 16) = wr[it];
+            if (v < WV4) *reinterpret_cast<f32x4*>(W_lds + (v / V4ROW) * WROW + (v % V4ROW) * 16) = wr[it];
         }
         __syncthreads();
 
-        const int c8n = st.cn >> 3;
-        int c8 = 0, tdx = 0, tdy = 0;
+        const int ksn = st.cn / KSTEP;  // k-steps per tap
+        int ks = 0, tdx = 0, tdy = 0;
         const char* a_lane = A_lds + (py * halo_w + px) * arow + hh * 16;
         int tapoff = 0;
         for (int ck = 0; ck < nchunks; ++ck) {
             const bool more = ck + 1 < nchunks;
             if (more) {
-                const f32x4* wn = wsrc + (size_t)(ck + 1) * (NTR * KC_F32 / 4);
+                const f32x4* wn = wsrc + (size_t)(ck + 1) * WV4;
 #pragma unroll
-                for (int it = 0; it < NG; ++it) wr[it] = wn[tid + it * NTHREADS];
+                for (int it = 0; it < WIT; ++it)
+                    if (tid + it * NTHREADS < WV4) wr[it] = wn[tid + it * NTHREADS];
             }
-            const char* wb = W_lds + (ck & 1) * WBUF_F32 + j * WROW_F32 + hh * 16;
+            const char* wb = W_lds + (ck & 1) * WBUF + j * WROW + hh * 16;
 #pragma unroll
-            for (int q = 0; q < KC_F32 / 8; ++q) {
-                if (ck * (KC_F32 / 8) + q < st.nq) {
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(a_lane + tapoff + c8 * 32);
-                    f32x4 b4[NG];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g)
-                        b4[g] = *reinterpret_cast<const f32x4*>(wb + g * 32 * WROW_F32 + q * 32);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
+            for (int q = 0; q < QPC; ++q) {
+                if (ck * QPC + q < st.nq) {
+                    if constexpr (MODE == 0) {
+                        // fp32: one b128 = 4 consecutive channels; lanes 0-31 take k = 8*ks + s, lanes 32-63 k = 8*ks + 4 + s
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(a_lane + tapoff + ks * 32);
+                        f32x4 b4[NG];
 #pragma unroll
                         for (int g = 0; g < NG; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k], b4[g][k], acc[g], 0, 0, 0);
-                    if (++c8 == c8n) {
-                        c8 = 0;
+                            b4[g] = *reinterpret_cast<const f32x4*>(wb + g * 32 * WROW + q * 32);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int g = 0; g < NG; ++g)
+                                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k], b4[g][k], acc[g], 0, 0, 0);
+                    } else {
+                        // bf16x3: one b128 = 8 consecutive channels; lanes 0-31 take k = 16*ks + 0..7, lanes 32-63 + 8..15
+                        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_lane + tapoff + ks * 32);
+                        const bf16x8 al = *reinterpret_cast<const bf16x8*>(a_lane + tapoff + st.cn * 2 + ks * 32);
+                        bf16x8 bh[NG], bl[NG];
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            bh[g] = *reinterpret_cast<const bf16x8*>(wb + g * 32 * WROW + q * 32);
+                            bl[g] = *reinterpret_cast<const bf16x8*>(wb + g * 32 * WROW + KC * 2 + q * 32);
+                        }
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[g], acc[g], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[g], acc[g], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[g], acc[g], 0, 0, 0);
+                    }
+                    if (++ks == ksn) {
+                        ks = 0;
                         if (++tdx == P.kw) { tdx = 0; ++tdy; }
                         tapoff = (tdy * halo_w + tdx) * arow;
                     }
                 }
             }
             if (more) {
-                char* wdst = W_lds + ((ck + 1) & 1) * WBUF_F32;
+                char* wdst = W_lds + ((ck + 1) & 1) * WBUF;
 #pragma unroll
-                for (int it = 0; it < NG; ++it) {
+                for (int it = 0; it < WIT; ++it) {
                     const int v = tid + it * NTHREADS;
-                    *reinterpret_cast<f32x4*>(wdst + (v >> 3) * WROW_F32 + (v & 7) * 16) = wr[it];
+                    if (v < WV4) *reinterpret_cast<f32x4*>(wdst + (v / V4ROW) * WROW + (v % V4ROW) * 16) = wr[it];
                 }
             }
             __syncthreads();
@@ -344,20 +422,27 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_f32_kernel(const ConvPlan 
     epi(acc, t);
 }
 
-template <class Epi>
-static hipError_t launch_conv(const ConvPlan& plan, const Epi& epi, int n_tiles, hipStream_t s) {
-    const size_t lds = (size_t)plan.a_bytes + 2 * (Epi::NG * 32 * WROW_F32);
+template <class Epi, int MODE>
+static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tiles, hipStream_t s) {
+    const size_t lds = (size_t)plan.a_bytes + 2 * (Epi::NG * 32 * (ModeTraits<MODE>::WROW_DATA + 16));
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_f32_kernel<Epi>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<Epi, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(plan.B * plan.tiles_x * plan.tiles_y, n_tiles);
-    hipLaunchKernelGGL(conv_gemm_f32_kernel<Epi>, grid, dim3(NTHREADS), lds, s, plan, epi);
+    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE>), grid, dim3(NTHREADS), lds, s, plan, epi);
     return hipGetLastError();
+}
+
+template <class Epi>
+static hipError_t launch_conv(const ConvPlan& plan, const Epi& epi, int n_tiles, hipStream_t s) {
+    if (plan.prec == VPX_PREC_F32) return launch_conv_m<Epi, 0>(plan, epi, n_tiles, s);
+    if (plan.prec == VPX_PREC_BF16X3) return launch_conv_m<Epi, 1>(plan, epi, n_tiles, s);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_convlstm_step_f32(const ConvPlan& plan, const ConvLSTMStepArgs& ea, int n_tiles, hipStream_t s) {
@@ -386,10 +471,12 @@ hipError_t launch_st_out_f32(const ConvPlan& plan, const STOutArgs& ea, int n_ti
 // ---------------------------------------------------------------------------------------------------------------
 // host-side plan helpers
 // ---------------------------------------------------------------------------------------------------------------
-int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int kc) {
+int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int prec) {
+    const int kstep = mode_kstep(prec), qpc = mode_kc(prec) / kstep;
+    if (cs % kstep) cs = (cs + kstep - 1) / kstep * kstep;
     int n = 0, chunk = 0;
     for (int sgi = 0; sgi < nseg; ++sgi) {
-        const int Cp = (segC[sgi] + 7) / 8 * 8;
+        const int Cp = (segC[sgi] + kstep - 1) / kstep * kstep;
         for (int c0 = 0; c0 < Cp; c0 += cs) {
             if (n >= MAX_STAGE) return -1;
             const int cn = (Cp - c0 < cs) ? (Cp - c0) : cs;
@@ -398,13 +485,39 @@ int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, in
             s.c0 = c0;
             s.cn = cn;
             s.chunk0 = chunk;
-            s.nq = taps * cn / 8;
+            s.nq = taps * cn / kstep;
             st[n++] = s;
-            chunk += (s.nq * 8 + kc - 1) / kc;
+            chunk += (s.nq + qpc - 1) / qpc;
         }
     }
     *chunks_total = chunk;
     return n;
+}
+
+// Channels per activation stage: the smallest stage that still fits the stage table buys the most workgroups per CU
+// (LDS = halo tile + double-buffered weight chunk; 144 registers cap residency at 3 waves/SIMD). Measured on MI355X,
+// fp32, B=32: 64 ch -> 95 TF (1 WG/CU), 32 -> 118 TF (2), 16 -> 120-128 TF (3).  VPX_CS overrides for experiments.
+int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("VPX_CS");
+        forced = e ? atoi(e) : 0;
+        if (forced < 8 || (forced & 7) || forced > CS_MAX) forced = 0;
+    }
+    const int kstep = mode_kstep(prec);
+    if (forced) return forced < kstep ? kstep : forced;
+    const int npos = (TILE_H + kh - 1) * (TILE_W + kw - 1);
+    const int wbytes = 2 * ng * 32 * (mode_kc(prec) * 4 + 16);
+    int best = CS_MAX, best_wg = 0;
+    for (int cs = kstep; cs <= CS_MAX; cs *= 2) {
+        int nst = 0;
+        for (int s = 0; s < nseg; ++s) nst += ((segC[s] + kstep - 1) / kstep * kstep + cs - 1) / cs;
+        if (nst > MAX_STAGE) continue;
+        int wg = (160 * 1024) / (npos * (cs * 4 + 16) + wbytes);
+        if (wg > 3) wg = 3;
+        if (wg > best_wg || (wg == best_wg && cs > best)) { best = cs; best_wg = wg; }
+    }
+    return best;
 }
 
 int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw) {
@@ -417,8 +530,8 @@ int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw) {
     return (m + 15) / 16 * 16;
 }
 
-size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng) {
-    return (size_t)n_tiles * chunks_total * ng * 32 * KC_F32 * sizeof(float);
+size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng, int prec) {
+    return (size_t)n_tiles * chunks_total * ng * 32 * mode_kc(prec) * sizeof(float);
 }
 
 }  // namespace vpx

@@ -89,8 +89,8 @@ hipError_t launch_colsum(const float* m, float* out, long long rows, int cols, h
 // LDS: dG tile [128 px][64 rows] (32 KiB) + activation halo tile [halo positions][64 ch].
 // Each wave owns a 32 (rows) x 32 (channels) output block for up to WG_MAXT taps: acc[tap] += dG^T (px-contracted) A_tap.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAXT>
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
+template <int MAXT>  // MAXT = exact number of taps this launch handles (branch-free MFMA block)
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, const int tap_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
@@ -99,9 +99,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
     const int ct_id = blockIdx.x % n_ct;
     const int nt_id = blockIdx.x / n_ct;
     const WgradCTile ct = a.ct[ct_id];
-    const int tap0 = blockIdx.z * MAXT;
-    int ntaps = a.kh * a.kw - tap0;
-    if (ntaps > MAXT) ntaps = MAXT;
+    const int tap0 = tap_base + blockIdx.z * MAXT;
     const int halo_w = TILE_W + a.kw - 1, halo_h = TILE_H + a.kh - 1, npos = halo_w * halo_h;
     const int ph = a.kh / 2, pw = a.kw / 2;
     float* G_lds = reinterpret_cast<float*>(smem);                 // [128][64]
@@ -200,13 +198,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
             const int p = 2 * kk + hh;
             const float av = gp[p * 64];
             const int abase = ((p >> 4) * halo_w + (p & 15)) * 64;
+            float bv[MAXT];
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                if (t < ntaps) {
-                    const float bv = ap[abase + tapoff[t]];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-                }
-            }
+            for (int t = 0; t < MAXT; ++t) bv[t] = ap[abase + tapoff[t]];
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
         }
     }
     // ---- slab[slice][tap][row][Ct] = acc (each element written exactly once per launch) ----
@@ -216,7 +212,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
     float* slab = a.slabs + (size_t)blockIdx.y * a.kh * a.kw * n_out * a.Ct;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-        if (t >= ntaps) continue;
         float* st = slab + (size_t)(tap0 + t) * n_out * a.Ct;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -229,22 +224,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s) {
-    constexpr int MAXT = 9;
-    const int taps = a.kh * a.kw;
-    const int groups = (taps + MAXT - 1) / MAXT;
-    const int npos = (TILE_H + a.kh - 1) * (TILE_W + a.kw - 1);
-    const size_t lds = 128 * 64 * 4 + (size_t)npos * 64 * 4;
+template <int NTAPS>
+static hipError_t launch_wgrad_group(const WgradArgs& a, int n_slices, int tap_base, int groups, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<MAXT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NTAPS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(((a.N4 + 63) / 64) * a.n_ctiles, n_slices, groups);
-    hipLaunchKernelGGL(wgrad_kernel<MAXT>, grid, dim3(NTHREADS), lds, s, a);
+    hipLaunchKernelGGL(wgrad_kernel<NTAPS>, grid, dim3(NTHREADS), lds, s, a, tap_base);
     return hipGetLastError();
+}
+
+hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s) {
+    constexpr int MAXT = 9;  // taps per workgroup: 9 accumulator tiles per wave
+    const int taps = a.kh * a.kw;
+    const int full = taps / MAXT, rem = taps % MAXT;
+    const int npos = (TILE_H + a.kh - 1) * (TILE_W + a.kw - 1);
+    const size_t lds = 128 * 64 * 4 + (size_t)npos * 64 * 4;
+    hipError_t e = hipSuccess;
+    if (full) e = launch_wgrad_group<MAXT>(a, n_slices, 0, full, lds, s);
+    if (e != hipSuccess) return e;
+    switch (rem) {  // remainder group with its exact tap count (1x1 -> 1, 5x5 -> 7, 5x3 -> 6, 7x7 -> 4, ...)
+        case 0: break;
+        case 1: e = launch_wgrad_group<1>(a, n_slices, full * MAXT, 1, lds, s); break;
+        case 2: e = launch_wgrad_group<2>(a, n_slices, full * MAXT, 1, lds, s); break;
+        case 3: e = launch_wgrad_group<3>(a, n_slices, full * MAXT, 1, lds, s); break;
+        case 4: e = launch_wgrad_group<4>(a, n_slices, full * MAXT, 1, lds, s); break;
+        case 5: e = launch_wgrad_group<5>(a, n_slices, full * MAXT, 1, lds, s); break;
+        case 6: e = launch_wgrad_group<6>(a, n_slices, full * MAXT, 1, lds, s); break;
+        case 7: e = launch_wgrad_group<7>(a, n_slices, full * MAXT, 1, lds, s); break;
+        case 8: e = launch_wgrad_group<8>(a, n_slices, full * MAXT, 1, lds, s); break;
+    }
+    return e;
 }
 
 // dW[n][c][tap] (OIHW, ld = Ct*taps) = sum_s slab[s][tap][n][c]

@@ -29,7 +29,7 @@ int check_st_desc(const vpx_stlstm_desc* d) {
     if (d->k < 1 || !(d->k & 1) || d->k > 7) { set_error("stlstm desc: filter size must be odd and <= 7 (got %d)", d->k); return VPX_ERR_ARG; }
     if (d->layout != VPX_LAYOUT_NHWC && d->layout != VPX_LAYOUT_NCHW) { set_error("stlstm desc: unknown layout %d", d->layout); return VPX_ERR_ARG; }
     if (d->layer_norm) { set_error("stlstm: the LayerNorm variant (predrnn.py:24-40) is not implemented yet"); return VPX_ERR_UNSUPPORTED; }
-    if (d->precision != VPX_PREC_F32) { set_error("stlstm: precision %d not implemented yet (only VPX_PREC_F32)", d->precision); return VPX_ERR_UNSUPPORTED; }
+    if (d->precision != VPX_PREC_F32 && d->precision != VPX_PREC_BF16X3) { set_error("stlstm: precision %d not implemented", d->precision); return VPX_ERR_UNSUPPORTED; }
     return VPX_OK;
 }
 
@@ -39,21 +39,22 @@ int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
     L.tiles128 = (d->Ch + NT - 1) / NT;
     const int segG[2] = {d->Cin, d->Ch};
     const int segO[2] = {d->Ch, d->Ch};
-    L.nstage_g = build_stages(L.stage_g, &L.chunks_g, segG, 2, L.taps, CS_F32, KC_F32);
-    L.nstage_o = build_stages(L.stage_o, &L.chunks_o, segO, 2, L.taps, CS_F32, KC_F32);
-    L.nstage_l = build_stages(L.stage_l, &L.chunks_l, segO, 2, 1, CS_F32, KC_F32);
+    L.nstage_g = build_stages(L.stage_g, &L.chunks_g, segG, 2, L.taps, pick_stage_channels(segG, 2, d->k, d->k, 4, d->precision), d->precision);
+    L.nstage_o = build_stages(L.stage_o, &L.chunks_o, segO, 2, L.taps, pick_stage_channels(segO, 2, d->k, d->k, 1, d->precision), d->precision);
+    L.nstage_l = build_stages(L.stage_l, &L.chunks_l, segO, 2, 1, pick_stage_channels(segO, 2, 1, 1, 4, d->precision), d->precision);
     if (L.nstage_g < 0 || L.nstage_o < 0 || L.nstage_l < 0) { set_error("stlstm: too many channel stages"); return VPX_ERR_UNSUPPORTED; }
     L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
     L.n_x = (size_t)d->B * d->H * d->W * d->Cin;
-    L.wpk_c = packed_weight_bytes(L.tiles32, L.chunks_g, 4) / 4;
-    L.wpk_m = packed_weight_bytes(L.tiles32, L.chunks_g, 3) / 4;
-    L.wpk_o = packed_weight_bytes(L.tiles32, L.chunks_o, 1) / 4;
-    L.wpk_l = packed_weight_bytes(L.tiles128, L.chunks_l, 4) / 4;
+    L.wpk_c = packed_weight_bytes(L.tiles32, L.chunks_g, 4, d->precision) / 4;
+    L.wpk_m = packed_weight_bytes(L.tiles32, L.chunks_g, 3, d->precision) / 4;
+    L.wpk_o = packed_weight_bytes(L.tiles32, L.chunks_o, 1, d->precision) / 4;
+    L.wpk_l = packed_weight_bytes(L.tiles128, L.chunks_l, 4, d->precision) / 4;
     return VPX_OK;
 }
 
 ConvPlan base_plan(const vpx_stlstm_desc* d, int k) {
     ConvPlan P{};
+    P.prec = d->precision;
     P.B = d->B; P.H = d->H; P.W = d->W; P.kh = k; P.kw = k;
     P.tiles_x = (d->W + TILE_W - 1) / TILE_W;
     P.tiles_y = (d->H + TILE_H - 1) / TILE_H;
@@ -134,7 +135,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         pd.seg[0] = PackSeg{Wx, (long long)Cin * L.taps, L.taps, 0, Cin};
         pd.seg[1] = PackSeg{Wh, (long long)Ch * L.taps, L.taps, 0, Ch};
         memcpy(pd.stage, L.stage_g, sizeof(ConvStage) * L.nstage_g);
-        pd.nstage = L.nstage_g; pd.chunks_total = L.chunks_g; pd.n_tiles = L.tiles32; pd.taps = L.taps; pd.NG = 4;
+        pd.nstage = L.nstage_g; pd.chunks_total = L.chunks_g; pd.prec = d->precision; pd.n_tiles = L.tiles32; pd.taps = L.taps; pd.NG = 4;
         const int xr[4] = {0, 1, 2, 6};
         for (int g = 0; g < 4; ++g) { pd.rowbase[0][g] = xr[g] * Ch; pd.rowbase[1][g] = g * Ch; pd.goff[g] = 0; }
         pd.tile_stride = 32; pd.nch = Ch;
@@ -150,7 +151,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         po.seg[0] = PackSeg{Wo, (long long)2 * Ch * L.taps, L.taps, 0, Ch};
         po.seg[1] = PackSeg{Wo, (long long)2 * Ch * L.taps, L.taps, Ch, Ch};
         memcpy(po.stage, L.stage_o, sizeof(ConvStage) * L.nstage_o);
-        po.nstage = L.nstage_o; po.chunks_total = L.chunks_o; po.n_tiles = L.tiles32; po.taps = L.taps; po.NG = 1;
+        po.nstage = L.nstage_o; po.chunks_total = L.chunks_o; po.prec = d->precision; po.n_tiles = L.tiles32; po.taps = L.taps; po.NG = 1;
         for (int s = 0; s < 2; ++s) { po.rowbase[s][0] = 0; for (int g = 1; g < 4; ++g) po.rowbase[s][g] = -1; }
         po.tile_stride = 32; po.nch = Ch;
         VPX_CHECK_HIP(launch_pack_weights(po, wpk_o, stream));
@@ -159,7 +160,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         pl.seg[0] = PackSeg{Wlast, (long long)2 * Ch, 1, 0, Ch};
         pl.seg[1] = PackSeg{Wlast, (long long)2 * Ch, 1, Ch, Ch};
         memcpy(pl.stage, L.stage_l, sizeof(ConvStage) * L.nstage_l);
-        pl.nstage = L.nstage_l; pl.chunks_total = L.chunks_l; pl.n_tiles = L.tiles128; pl.taps = 1; pl.NG = 4;
+        pl.nstage = L.nstage_l; pl.chunks_total = L.chunks_l; pl.prec = d->precision; pl.n_tiles = L.tiles128; pl.taps = 1; pl.NG = 4;
         for (int s = 0; s < 2; ++s) for (int g = 0; g < 4; ++g) pl.rowbase[s][g] = g * 32;
         for (int g = 0; g < 4; ++g) pl.goff[g] = g * 32;
         pl.tile_stride = NT; pl.nch = Ch;

@@ -22,11 +22,12 @@ struct STBwdLayout {
     size_t slab_floats;
 };
 
-int mk_dg(STBwdLayout::DG& g, const int* segC, int nseg, int taps, int n_out) {
-    g.nstage = build_stages(g.stage, &g.chunks, segC, nseg, taps, CS_F32, KC_F32);
+int mk_dg(STBwdLayout::DG& g, const int* segC, int nseg, int k, int n_out, int prec) {
+    const int taps = k * k;
+    g.nstage = build_stages(g.stage, &g.chunks, segC, nseg, taps, pick_stage_channels(segC, nseg, k, k, 4, prec), prec);
     if (g.nstage < 0) return -1;
     g.tiles = (n_out + NT - 1) / NT;
-    g.wpk = packed_weight_bytes(g.tiles, g.chunks, 4) / 4;
+    g.wpk = packed_weight_bytes(g.tiles, g.chunks, 4, prec) / 4;
     return 0;
 }
 
@@ -37,8 +38,9 @@ int st_bwd_layout(const vpx_stlstm_desc* d, STBwdLayout& L) {
     L.n_x = (size_t)d->B * d->H * d->W * Cin;
     L.n_g7 = L.n_state * 7;
     const int s1[1] = {Ch}, s3[3] = {3 * Ch, Ch, 3 * Ch}, s4[1] = {4 * Ch}, s3m[1] = {3 * Ch};
-    if (mk_dg(L.o, s1, 1, L.taps, 2 * Ch) || mk_dg(L.l, s1, 1, 1, 2 * Ch) || mk_dg(L.x, s3, 3, L.taps, Cin) ||
-        mk_dg(L.h, s4, 1, L.taps, Ch) || mk_dg(L.m, s3m, 1, L.taps, Ch)) {
+    const int pr = d->precision;
+    if (mk_dg(L.o, s1, 1, d->k, 2 * Ch, pr) || mk_dg(L.l, s1, 1, 1, 2 * Ch, pr) || mk_dg(L.x, s3, 3, d->k, Cin, pr) ||
+        mk_dg(L.h, s4, 1, d->k, Ch, pr) || mk_dg(L.m, s3m, 1, d->k, Ch, pr)) {
         set_error("stlstm bwd: too many channel stages (Ch=%d)", Ch);
         return VPX_ERR_UNSUPPORTED;
     }
@@ -111,7 +113,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
                                    float* dWlast, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!d) { set_error("stlstm desc is NULL"); return VPX_ERR_ARG; }
     if (d->layer_norm) { set_error("stlstm: the LayerNorm variant is not implemented yet"); return VPX_ERR_UNSUPPORTED; }
-    if (d->precision != VPX_PREC_F32) { set_error("stlstm: only VPX_PREC_F32 is implemented"); return VPX_ERR_UNSUPPORTED; }
+    if (d->precision != VPX_PREC_F32 && d->precision != VPX_PREC_BF16X3) { set_error("stlstm: precision %d not implemented", d->precision); return VPX_ERR_UNSUPPORTED; }
     if (!(d->flags & VPX_FLAG_SAVE_FOR_BWD)) { set_error("vpx_stlstm_step_bwd: desc lacks VPX_FLAG_SAVE_FOR_BWD"); return VPX_ERR_ARG; }
     if (!x || !h || !c || !m || !c_new || !m_new || !Wx || !Wh || !Wm || !Wo || !Wlast || !reserve) {
         set_error("vpx_stlstm_step_bwd: NULL tensor argument");
@@ -169,6 +171,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
 
     auto plan_for = [&](const STBwdLayout::DG& g, int kk, const float* wpk) {
         ConvPlan P{};
+        P.prec = d->precision;
         P.B = B; P.H = H; P.W = Wd; P.kh = kk; P.kw = kk;
         P.tiles_x = (Wd + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_H - 1) / TILE_H;
         P.nstage = g.nstage; memcpy(P.stage, g.stage, sizeof(ConvStage) * g.nstage);
@@ -177,7 +180,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     };
     auto pack_plain_T = [&](PackDesc& pd, const STBwdLayout::DG& g, int taps, int n_out) {
         memcpy(pd.stage, g.stage, sizeof(ConvStage) * g.nstage);
-        pd.nstage = g.nstage; pd.chunks_total = g.chunks; pd.n_tiles = g.tiles; pd.taps = taps; pd.NG = 4;
+        pd.nstage = g.nstage; pd.chunks_total = g.chunks; pd.prec = d->precision; pd.n_tiles = g.tiles; pd.taps = taps; pd.NG = 4;
         for (int s = 0; s < MAX_SEG; ++s) for (int gg = 0; gg < 4; ++gg) pd.rowbase[s][gg] = gg * 32;
         for (int gg = 0; gg < 4; ++gg) pd.goff[gg] = gg * 32;
         pd.tile_stride = NT; pd.nch = n_out; pd.transposed = 1; pd.flip = 1;

@@ -50,7 +50,7 @@ size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
     ConvLSTMLayout L;
     if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
     // forward: packed weights + cell scratch (+ NCHW staging)
-    size_t fwd = align256(packed_weight_bytes(L.n_tiles, L.chunks_total)) + align256(L.n_state * sizeof(float));
+    size_t fwd = align256(packed_weight_bytes(L.n_tiles, L.chunks_total, 4, d->precision)) + align256(L.n_state * sizeof(float));
     if (d->layout == VPX_LAYOUT_NCHW)
         fwd += align256(L.n_x * 4) + align256(L.n_out * 4) + 4 * align256(L.n_state * 4) + 3 * align256(L.n_peep * 4);
     // backward (only with SAVE_FOR_BWD): packed dgrad weights + dG for all steps + dh/dc carries + wgrad K-slice slabs
@@ -85,7 +85,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     const size_t HW = (size_t)H * Wd;
     Carver ws{(char*)workspace, 0, workspace_bytes};
     ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
-    float* wpk = ws.take(packed_weight_bytes(L.n_tiles, L.chunks_total) / sizeof(float));
+    float* wpk = ws.take(packed_weight_bytes(L.n_tiles, L.chunks_total, 4, d->precision) / sizeof(float));
     float* c_scratch = ws.take(L.n_state);
 
     // ---- layout adaptation (reference NCHW -> native NHWC) ----
@@ -123,7 +123,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     pd.seg[1] = PackSeg{W, ld_o, L.taps, Cin, Ch};
     memcpy(pd.stage, L.stage, sizeof(ConvStage) * L.nstage);
     pd.nstage = L.nstage;
-    pd.chunks_total = L.chunks_total;
+    pd.chunks_total = L.chunks_total; pd.prec = d->precision;
     pd.n_tiles = L.n_tiles;
     pd.taps = L.taps;
     pd.NG = 4;
@@ -157,7 +157,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             const float* src = P.seg[L.stage[s].seg].ptr;
             if (src) P.stage[P.nstage++] = L.stage[s];  // absent source == all-zero operand: its K range is skipped
         }
-        P.chunks_total = L.chunks_total;
+        P.chunks_total = L.chunks_total; P.prec = d->precision;
         P.a_bytes = conv_a_bytes(L.stage, L.nstage, d->kh, d->kw);
         P.wpk = wpk;
 
@@ -201,8 +201,14 @@ size_t vpx_conv2d_workspace_bytes(int Ci, int Co, int kh, int kw) {
     ConvStage st[MAX_STAGE];
     int chunks = 0;
     const int segC[1] = {Ci};
-    if (build_stages(st, &chunks, segC, 1, kh * kw, CS_F32, KC_F32) < 0) return 0;
-    return align256(packed_weight_bytes((Co + NT - 1) / NT, chunks)) + 256;
+    // sized for the larger of the two operand modes
+    size_t best = 0;
+    for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16X3; ++prec) {
+        if (build_stages(st, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, 4, prec), prec) < 0) return 0;
+        const size_t b = align256(packed_weight_bytes((Co + NT - 1) / NT, chunks, 4, prec));
+        if (b > best) best = b;
+    }
+    return best + 256;
 }
 
 int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Ci,
@@ -211,12 +217,12 @@ int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
         set_error("vpx_conv2d_nhwc_fwd: bad argument");
         return VPX_ERR_ARG;
     }
-    if (precision != VPX_PREC_F32) { set_error("vpx_conv2d_nhwc_fwd: only VPX_PREC_F32 implemented"); return VPX_ERR_UNSUPPORTED; }
+    if (precision != VPX_PREC_F32 && precision != VPX_PREC_BF16X3) { set_error("vpx_conv2d_nhwc_fwd: precision %d not implemented", precision); return VPX_ERR_UNSUPPORTED; }
     hipStream_t stream = (hipStream_t)stream_;
     ConvPlan P{};
     int chunks = 0;
     const int segC[1] = {Ci};
-    P.nstage = build_stages(P.stage, &chunks, segC, 1, kh * kw, CS_F32, KC_F32);
+    P.nstage = build_stages(P.stage, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, 4, precision), precision);
     if (P.nstage < 0) { set_error("vpx_conv2d_nhwc_fwd: too many channel stages"); return VPX_ERR_UNSUPPORTED; }
     const int n_tiles = (Co + NT - 1) / NT;
     if (!workspace || workspace_bytes < vpx_conv2d_workspace_bytes(Ci, Co, kh, kw)) {
@@ -225,11 +231,11 @@ int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
     }
     Carver ws{(char*)workspace, 0, workspace_bytes};
     ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
-    float* wpk = ws.take(packed_weight_bytes(n_tiles, chunks) / sizeof(float));
+    float* wpk = ws.take(packed_weight_bytes(n_tiles, chunks, 4, precision) / sizeof(float));
     PackDesc pd{};
     pd.seg[0] = PackSeg{w, (long long)Ci * kh * kw, kh * kw, 0, Ci};
     memcpy(pd.stage, P.stage, sizeof(ConvStage) * P.nstage);
-    pd.nstage = P.nstage; pd.chunks_total = chunks; pd.n_tiles = n_tiles; pd.taps = kh * kw; pd.NG = 4;
+    pd.nstage = P.nstage; pd.chunks_total = chunks; pd.prec = precision; pd.n_tiles = n_tiles; pd.taps = kh * kw; pd.NG = 4;
     for (int g = 0; g < 4; ++g) { pd.rowbase[0][g] = g * 32; pd.goff[g] = g * 32; }
     pd.tile_stride = NT; pd.nch = Co;
     VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
@@ -237,7 +243,7 @@ int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
     P.tiles_x = (W + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_H - 1) / TILE_H;
     P.nseg = 1;
     P.seg[0] = ConvSeg{x, (long long)H * W * Ci, Ci, 0};
-    P.chunks_total = chunks;
+    P.chunks_total = chunks; P.prec = precision;
     P.a_bytes = conv_a_bytes(P.stage, P.nstage, kh, kw);
     P.wpk = wpk;
     PlainEpiArgs ea{};

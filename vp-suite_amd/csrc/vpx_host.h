@@ -1,5 +1,6 @@
 // vpx_host.h — host-side helpers shared by the extern "C" translation units.
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 
 #include "vpx_internal.h"
@@ -53,8 +54,8 @@ static inline int check_convlstm_desc(const vpx_convlstm_desc* d) {
         set_error("convlstm desc: unknown layout %d", d->layout);
         return VPX_ERR_ARG;
     }
-    if (d->precision != VPX_PREC_F32) {
-        set_error("convlstm desc: precision %d not implemented yet (only VPX_PREC_F32)", d->precision);
+    if (d->precision != VPX_PREC_F32 && d->precision != VPX_PREC_BF16X3) {
+        set_error("convlstm desc: precision %d not implemented (VPX_PREC_F32 and VPX_PREC_BF16X3 are)", d->precision);
         return VPX_ERR_UNSUPPORTED;
     }
     return VPX_OK;
@@ -78,7 +79,7 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     L.taps = d->kh * d->kw;
     L.n_tiles = (d->Ch + 31) / 32;
     const int segC[2] = {d->Cin, d->Ch};
-    L.nstage = build_stages(L.stage, &L.chunks_total, segC, 2, L.taps, CS_F32, KC_F32);
+    L.nstage = build_stages(L.stage, &L.chunks_total, segC, 2, L.taps, pick_stage_channels(segC, 2, d->kh, d->kw, 4, d->precision), d->precision);
     if (L.nstage < 0) { set_error("convlstm: too many channel stages (Cin=%d Ch=%d)", d->Cin, d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
     L.n_x = (size_t)d->B * d->T * d->H * d->W * d->Cin;
@@ -87,7 +88,7 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     // ---- backward sizing ----
     const int N4 = 4 * d->Ch, Ct = d->Cin + d->Ch;
     const int segD[1] = {N4};
-    L.d_nstage = build_stages(L.d_stage, &L.d_chunks, segD, 1, L.taps, CS_F32, KC_F32);
+    L.d_nstage = build_stages(L.d_stage, &L.d_chunks, segD, 1, L.taps, pick_stage_channels(segD, 1, d->kh, d->kw, 4, d->precision), d->precision);
     if (L.d_nstage < 0) { set_error("convlstm: too many channel stages in the data-gradient conv (Ch=%d)", d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.d_tiles_full = (Ct + NT - 1) / NT;
     L.d_tiles_h = (d->Ch + NT - 1) / NT;
@@ -116,7 +117,7 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
 
 
 static inline size_t convlstm_bwd_workspace_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
-    size_t b = align256(packed_weight_bytes(L.d_tiles_full, L.d_chunks));
+    size_t b = align256(packed_weight_bytes(L.d_tiles_full, L.d_chunks, 4, d->precision));
     b += align256((size_t)d->T * L.n_state * 4 * sizeof(float));  // dG, all steps
     b += 2 * align256(L.n_state * sizeof(float));                 // dh, dc carries
     b += align256(L.slab_floats * sizeof(float));

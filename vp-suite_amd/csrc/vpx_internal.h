@@ -21,10 +21,9 @@ constexpr int TILE_W = 16;
 constexpr int NTHREADS = 256;
 constexpr int NT = 128;      // GEMM-N per workgroup (4 groups x 32)
 constexpr int MAX_NG = 4;
-constexpr int KC_F32 = 32;   // k-depth of one weight chunk, fp32 operands (16 KiB per chunk)
-constexpr int CS_F32 = 64;   // channels per activation stage, fp32 operands
+constexpr int CS_MAX = 64;   // largest activation stage (channels); pick_stage_channels() chooses per problem
 constexpr int MAX_SEG = 3;
-constexpr int MAX_STAGE = 16;
+constexpr int MAX_STAGE = 32;
 
 struct ConvSeg {          // one activation source, NHWC [B][H][W][C] with arbitrary batch stride (selects a time slice)
     const float* ptr;
@@ -34,9 +33,9 @@ struct ConvSeg {          // one activation source, NHWC [B][H][W][C] with arbit
 };
 
 struct ConvStage {        // one K-stage: channels [c0, c0+cn) of segment `seg`, all taps
-    int seg, c0, cn;      // cn is a multiple of 8 (zero-padded beyond the segment's real C)
+    int seg, c0, cn;      // cn is a multiple of the mode's kstep (zero-padded beyond the segment's real C)
     int chunk0;           // first weight chunk of this stage inside the packed per-tile weight stream
-    int nq;               // number of 8-deep k-steps = taps * cn / 8
+    int nq;               // number of k-steps = taps * cn / kstep (kstep = 8 fp32, 16 bf16x3)
     int _p0, _p1, _p2;
 };
 
@@ -45,7 +44,7 @@ struct ConvPlan {
     int nseg, nstage;
     int chunks_total;     // weight chunks per N-tile
     int a_bytes;          // LDS bytes reserved for the activation stage
-    int _pad;
+    int prec;             // VPX_PREC_F32 | VPX_PREC_BF16X3: operand mode of the contraction
     ConvSeg seg[MAX_SEG];
     ConvStage stage[MAX_STAGE];
     const float* wpk;     // packed weights [n_tiles][chunks_total][NG*32][KC]
@@ -63,6 +62,7 @@ struct PackDesc {
     PackSeg seg[MAX_SEG];
     ConvStage stage[MAX_STAGE];
     int nstage, chunks_total, n_tiles, taps;
+    int prec;             // operand mode the packing is for (must match the ConvPlan that consumes it)
     int NG;               // groups per tile actually used (rows of unused groups are zero)
     int rowbase[MAX_SEG][MAX_NG];  // per segment: source output-row of (channel 0, tile 0) for group g; -1 = none
     int goff[MAX_NG];     // channel-index offset of group g used only for the validity test
@@ -73,9 +73,10 @@ struct PackDesc {
 };
 
 void set_error(const char* fmt, ...);
-int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int kc);
+int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int prec);
+int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec);
 int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw);
-size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng = 4);
+size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng, int prec);
 
 hipError_t launch_pack_weights(const PackDesc& pd, float* dst, hipStream_t s);
 
