@@ -34,7 +34,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (reference default run config batch_size=32)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="f32")
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3",
+                    help="operand mode of the fused cell kernels: f32 = exact fp32 MFMA; bf16x3 = split-bf16 operands, "
+                         "3 bf16 MFMAs per product, fp32 accumulate (fp32-level accuracy, parity-tested at 1e-4)")
     ap.add_argument("--img", type=int, default=64)
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--context", type=int, default=10)
@@ -152,7 +154,12 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach_tflops / peak, 4), "traffic": None,
-                "kernel": "conv_gemm_f32_kernel<EpiConvLSTM> (fused ConvLSTM cell step)",
+                "kernel": f"conv_gemm_kernel<EpiConvLSTM, {args.precision}> (fused ConvLSTM cell step)",
+                "note": ("achieved = algorithmic fp32 FLOPs / kernel time. bf16x3 issues 3 bf16 MFMAs per algorithmic "
+                         "product, so the MFMA pipe is busy for 3x this figure" if args.precision == "bf16x3" else
+                         "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+                "mfma_pipe_frac": round(ach_tflops * (3 if args.precision == "bf16x3" else 1) / peak, 4),
+                "vs_fp32_matrix_peak": round(ach_tflops / PEAK_TFLOPS["f32"], 4),
                 "launches": ps["launches"], "avg_launch_us": round(ps["ms"] * 1e3 / max(ps["launches"], 1), 2),
                 "algorithmic_gflop_per_launch": round(ps["flops"] / max(ps["launches"], 1) / 1e9, 3),
                 "hbm_view": {"achieved_GBps": round(ach_gbs, 1), "peak_GBps": HBM_PEAK_GBS,

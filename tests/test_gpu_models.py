@@ -109,3 +109,16 @@ def test_dp_trainer_on_gpu_single_rank(vpx):
     for _ in range(5):
         l1 = float(tr.step(frames[:, :3], frames[:, 3:], 2))
     assert l1 < l0
+
+
+def test_ef_convlstm_full_size_bf16x3_vs_golden(vpx):
+    """The bench's default operand mode (split bf16, fp32 accumulate) on the BASELINE C1/C2 shape: still within the
+    north-star tolerance of 1e-4 relative to the reference's fp32 CPU output."""
+    g = load_golden("ef_full_c1")
+    m = _ef(vpx, "full_c1", dict(img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0],
+                                 cell_precision="bf16x3"))
+    x = seeded_rand((1, 10, 1, 64, 64), name_seed("ef.full_c1.x"))
+    with torch.no_grad():
+        pred, _ = m(x.cuda(), pred_frames=10)
+    err = _relmax(pred[:, :, :, ::4, ::4], g["pred_slice"])
+    assert err < 1e-4, err
