@@ -261,3 +261,30 @@ def test_real_block_shapes_bf16x3_vs_oracle(vpx, dev, Cin, Ch, H, W):
         out, hT, cT = vpx.ops.convlstm_seq(x.to(dev), None, None, Wt.to(dev), b.to(dev), *[p.to(dev) for p in pw],
                                            seq_len=T, in_channels=Cin, precision="bf16x3")
     assert _relmax(out, ro) < 2e-5 and _relmax(cT, rc) < 2e-5
+
+
+@pytest.mark.parametrize("Cin,Ch,H,W", [(16, 64, 32, 32), (96, 96, 16, 16)])
+def test_real_block_shapes_bwd_bf16x3_vs_oracle(vpx, dev, Cin, Ch, H, W):
+    """bf16x3 backward (dgrad through the conv kernel, wgrad through the transposing-LDS-read kernel) vs fp32 autograd."""
+    from oracle import torch_ref as tr
+    B, T, k = 2, 3, 3
+    tag = f"realbwd3.{Cin}.{Ch}.{H}"
+    P = {"W": seeded_randn((4 * Ch, Cin + Ch, k, k), name_seed(tag + "W"), 1.0 / np.sqrt((Cin + Ch) * 9)),
+         "b": seeded_randn((4 * Ch,), name_seed(tag + "b"), 0.1),
+         "Wci": seeded_randn((1, Ch, H, W), name_seed(tag + "ci"), 0.1),
+         "Wcf": seeded_randn((1, Ch, H, W), name_seed(tag + "cf"), 0.1),
+         "Wco": seeded_randn((1, Ch, H, W), name_seed(tag + "co"), 0.1),
+         "x": seeded_rand((B, T, Cin, H, W), name_seed(tag + "x")),
+         "h0": seeded_randn((B, Ch, H, W), name_seed(tag + "h0"), 0.5),
+         "c0": seeded_randn((B, Ch, H, W), name_seed(tag + "c0"), 0.5)}
+    g_out = seeded_randn((B, T, Ch, H, W), name_seed(tag + "go"))
+    ref = {n: v.clone().requires_grad_(True) for n, v in P.items()}
+    ro, _ = tr.convlstm_hzzone_seq(ref["x"], (ref["h0"], ref["c0"]), T, ref["W"], ref["b"], ref["Wci"], ref["Wcf"],
+                                   ref["Wco"], padding=1)
+    (ro * g_out).sum().backward()
+    lv = {n: v.to(dev).requires_grad_(True) for n, v in P.items()}
+    out, hT, cT = vpx.ops.convlstm_seq(lv["x"], lv["h0"], lv["c0"], lv["W"], lv["b"], lv["Wci"], lv["Wcf"], lv["Wco"],
+                                       seq_len=T, in_channels=Cin, precision="bf16x3")
+    (out * g_out.to(dev)).sum().backward()
+    for n in P:
+        assert _relmax(lv[n].grad, ref[n].grad) < 1e-4, n

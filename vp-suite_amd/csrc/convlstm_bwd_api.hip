@@ -144,7 +144,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         WgradArgs wa{};
         wa.T = T; wa.B = B; wa.H = H; wa.W = Wd; wa.HW = (int)HW; wa.kh = d->kh; wa.kw = d->kw;
         wa.tiles_x = (Wd + TILE_W - 1) / TILE_W; wa.tiles_y = (H + TILE_H - 1) / TILE_H;
-        wa.N4 = N4; wa.Cin = Cin; wa.Ch = Ch; wa.Ct = Ct;
+        wa.N4 = N4; wa.Cin = Cin; wa.Ch = Ch; wa.Ct = Ct; wa.prec = d->precision;
         wa.dG = dG_all;
         wa.x = xn; wa.x_bstride = (long long)((size_t)T * HW * Cin); wa.x_tstride = (long long)(HW * Cin);
         wa.hseq = outn; wa.h_bstride = (long long)((size_t)T * HW * Ch); wa.h_tstride = (long long)(HW * Ch);

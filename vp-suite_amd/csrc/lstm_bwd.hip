@@ -224,6 +224,175 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient, split-bf16 operands (bf16x3). Same decomposition as wgrad_kernel; both operands are contracted over
+// PIXELS, i.e. they are needed k-major while HBM and LDS hold them channel-major. gfx950's transposing LDS read
+// (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns and lane i receives column i of the 4 rows) delivers
+// the MFMA fragments straight from the row-major tiles — no software transpose, no pre-shifted copies per tap.
+// k-step = one tile row (16 pixels): lanes 0-31 take pixels 0-7, lanes 32-63 pixels 8-15 (two tr reads of 4 rows each).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short wg_bf16_bits(float v) {
+    __bf16 h = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ void wg_split4(const f32x4 v, uint2& hi, uint2& lo) {
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = wg_bf16_bits(v[e]);
+        l[e] = wg_bf16_bits(v[e] - __builtin_bit_cast(float, (unsigned)h[e] << 16));
+    }
+    hi = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+    lo = uint2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+}
+__device__ __forceinline__ bf16x8 wg_tr_frag(const char* base) {
+    // two transposing reads: rows (pixels) +0..3 and +4..7 of this lane half's 8-pixel group; 64 columns x 2 B per row
+    typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base));
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base + 4 * 128));
+    return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+template <int MAXT>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad_bf16x3_kernel(const WgradArgs a, const int tap_base) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int n_ct = a.n_ctiles;
+    const int ct_id = blockIdx.x % n_ct;
+    const int nt_id = blockIdx.x / n_ct;
+    const WgradCTile ct = a.ct[ct_id];
+    const int tap0 = tap_base + blockIdx.z * MAXT;
+    const int halo_w = TILE_W + a.kw - 1, halo_h = TILE_H + a.kh - 1, npos = halo_w * halo_h;
+    const int ph = a.kh / 2, pw = a.kw / 2;
+    // LDS planes, row = 64 channels x bf16 = 128 B: G_hi [128 px], G_lo [128 px], A_hi [npos], A_lo [npos]
+    char* G_hi = smem;
+    char* G_lo = smem + 128 * 128;
+    char* A_hi = smem + 2 * 128 * 128;
+    char* A_lo = A_hi + npos * 128;
+
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // transposing-read address pattern of this lane inside its 16-lane group: row q, columns 4p..4p+3
+    const int L = lane & 15, q = L >> 2, p = L & 3, half16 = (lane >> 4) & 1;
+    const int g_lane = ((8 * hh + q) * 64 + wn * 32 + 16 * half16 + 4 * p) * 2;  // bytes, + tile-row * 16 * 128
+    const int a_lane = ((8 * hh + q) * 64 + wc * 32 + 16 * half16 + 4 * p) * 2;  // bytes, + position offset * 128
+    int tapoff[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int tp = tap0 + t;
+        const int dy = tp / a.kw, dx = tp - dy * a.kw;
+        tapoff[t] = (dy * halo_w + dx) * 128;
+    }
+
+    const int tiles = a.tiles_x * a.tiles_y;
+    const long long n_items = (long long)a.T * a.B * tiles;
+    const int n0 = nt_id * 64;
+    for (long long w = blockIdx.y; w < n_items; w += gridDim.y) {
+        const int tile = (int)(w % tiles);
+        const long long tb = w / tiles;
+        const int b = (int)(tb % a.B);
+        const int t = (int)(tb / a.B);
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+        const float* src;
+        int C;
+        if (ct.seg == 0) {
+            src = a.x + (size_t)b * a.x_bstride + (size_t)t * a.x_tstride;
+            C = a.Cin;
+        } else {
+            C = a.Ch;
+            if (t > 0) src = a.hseq + (size_t)b * a.h_bstride + (size_t)(t - 1) * a.h_tstride;
+            else if (a.h0) src = a.h0 + (size_t)b * a.HW * a.Ch;
+            else continue;
+        }
+        const int ldG = a.ldG ? a.ldG : a.N4;
+        const float* dg = a.dG + ((size_t)t * a.B + b) * a.HW * ldG;
+        __syncthreads();
+        // ---- stage dG tile: 128 pixels x 64 rows, split to hi/lo bf16 ----
+        const bool g_vec = ((a.N4 | ldG) & 3) == 0 && (reinterpret_cast<uintptr_t>(dg) & 15) == 0;
+        for (int v = tid; v < 128 * 16; v += NTHREADS) {
+            const int pp = v >> 4, q4 = v & 15;
+            const int gy = y0 + (pp >> 4), gx = x0 + (pp & 15);
+            const int n = n0 + q4 * 4;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (gy < a.H && gx < a.W) {
+                const float* rowp = dg + ((size_t)gy * a.W + gx) * ldG;
+                if (g_vec) { if (n < a.N4) val = *reinterpret_cast<const f32x4*>(rowp + n); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < a.N4) val[e] = rowp[n + e];
+                }
+            }
+            uint2 hi, lo;
+            wg_split4(val, hi, lo);
+            *reinterpret_cast<uint2*>(G_hi + pp * 128 + q4 * 8) = hi;
+            *reinterpret_cast<uint2*>(G_lo + pp * 128 + q4 * 8) = lo;
+        }
+        // ---- stage activation halo tile: npos x 64 channels ----
+        const bool a_vec = (C & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+        for (int v = tid; v < npos * 16; v += NTHREADS) {
+            const int pos = v >> 4, q4 = v & 15;
+            const int hy = pos / halo_w, hx = pos - hy * halo_w;
+            const int gy = y0 - ph + hy, gx = x0 - pw + hx;
+            const int c = ct.c0 + q4 * 4;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const float* rowp = src + ((size_t)gy * a.W + gx) * C;
+                if (a_vec) { if (c < C) val = *reinterpret_cast<const f32x4*>(rowp + c); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (c + e < C) val[e] = rowp[c + e];
+                }
+            }
+            uint2 hi, lo;
+            wg_split4(val, hi, lo);
+            *reinterpret_cast<uint2*>(A_hi + pos * 128 + q4 * 8) = hi;
+            *reinterpret_cast<uint2*>(A_lo + pos * 128 + q4 * 8) = lo;
+        }
+        __syncthreads();
+        // ---- 8 k-steps (tile rows) of 16 pixels ----
+#pragma unroll 2
+        for (int s = 0; s < TILE_H; ++s) {
+            const bf16x8 gh = wg_tr_frag(G_hi + g_lane + s * 16 * 128);
+            const bf16x8 gl = wg_tr_frag(G_lo + g_lane + s * 16 * 128);
+            const int arow = a_lane + s * halo_w * 128;
+#pragma unroll
+            for (int t2 = 0; t2 < MAXT; ++t2) {
+                const bf16x8 ah = wg_tr_frag(A_hi + arow + tapoff[t2]);
+                const bf16x8 al = wg_tr_frag(A_lo + arow + tapoff[t2]);
+                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ah, acc[t2], 0, 0, 0);
+                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, al, acc[t2], 0, 0, 0);
+                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, ah, acc[t2], 0, 0, 0);
+            }
+        }
+    }
+    const int col = ct.cglobal + wc * 32 + i;
+    const bool col_ok = (wc * 32 + i) < ct.cn;
+    const int n_out = a.n_out ? a.n_out : a.N4;
+    float* slab = a.slabs + (size_t)blockIdx.y * a.kh * a.kw * n_out * a.Ct;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        float* st = slab + (size_t)(tap0 + t) * n_out * a.Ct;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (n < a.N4 && col_ok) {
+                const int row = a.blk ? (a.rowblk[n / a.blk] * a.blk + n % a.blk) : n;
+                st[(size_t)row * a.Ct + col] = acc[t][r];
+            }
+        }
+    }
+}
+
 template <int NTAPS>
 static hipError_t launch_wgrad_group(const WgradArgs& a, int n_slices, int tap_base, int groups, size_t lds, hipStream_t s) {
     static bool attr_set = false;
@@ -234,7 +403,18 @@ static hipError_t launch_wgrad_group(const WgradArgs& a, int n_slices, int tap_b
         attr_set = true;
     }
     dim3 grid(((a.N4 + 63) / 64) * a.n_ctiles, n_slices, groups);
-    hipLaunchKernelGGL(wgrad_kernel<NTAPS>, grid, dim3(NTHREADS), lds, s, a, tap_base);
+    if (a.prec == VPX_PREC_BF16X3) {
+        static bool attr_set_b = false;
+        if (!attr_set_b) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_kernel<NTAPS>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set_b = true;
+        }
+        hipLaunchKernelGGL(wgrad_bf16x3_kernel<NTAPS>, grid, dim3(NTHREADS), lds, s, a, tap_base);
+    } else {
+        hipLaunchKernelGGL(wgrad_kernel<NTAPS>, grid, dim3(NTHREADS), lds, s, a, tap_base);
+    }
     return hipGetLastError();
 }
 

@@ -79,7 +79,7 @@ int run_wgrad(const vpx_stlstm_desc* d, const STBwdLayout& L, const float* dG, i
     wa.T = 1; wa.B = d->B; wa.H = d->H; wa.W = d->W; wa.HW = d->H * d->W; wa.kh = k; wa.kw = k;
     wa.tiles_x = (d->W + TILE_W - 1) / TILE_W; wa.tiles_y = (d->H + TILE_H - 1) / TILE_H;
     wa.N4 = N; wa.Cin = C0; wa.Ch = C1 > 0 ? C1 : 1; wa.Ct = C0 + C1;
-    wa.ldG = ldG; wa.blk = blk; wa.n_out = n_out;
+    wa.ldG = ldG; wa.blk = blk; wa.n_out = n_out; wa.prec = d->precision;
     if (rowblk) for (int i = 0; i < 8; ++i) wa.rowblk[i] = rowblk[i];
     wa.dG = dG;
     wa.x = src0; wa.x_bstride = (long long)wa.HW * C0; wa.x_tstride = 0;

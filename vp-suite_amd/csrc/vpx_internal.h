@@ -155,6 +155,7 @@ struct WgradArgs {
     int blk;                  // row-block size for the output-row map (0 = identity map)
     int rowblk[8];            // output row of dG channel n = rowblk[n / blk] * blk + n % blk
     int n_out;                // rows of the weight-gradient tensor (0 = N4)
+    int prec;                 // VPX_PREC_F32 (exact) | VPX_PREC_BF16X3 (split-bf16 operands via transposing LDS reads)
     const float* dG;          // [T][B,HW,ldG]
     const float* x; long long x_bstride, x_tstride;        // x[b,t] slabs (null if no input)
     const float* hseq; long long h_bstride, h_tstride;     // forward outputs: h_{t-1} = hseq[b, t-1]
