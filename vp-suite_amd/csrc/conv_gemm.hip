@@ -224,13 +224,14 @@ struct EpiSTOut {
     }
 };
 
+template <int NGP>
 struct EpiPlain {
-    static constexpr int NG = 4;
+    static constexpr int NG = NGP;
     PlainEpiArgs a;
-    __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], const TileCtx& t) const {
+    __device__ __forceinline__ void operator()(const f32x16 (&acc)[NGP], const TileCtx& t) const {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = t.n_tile * NT + g * 32 + t.j;
+        for (int g = 0; g < NGP; ++g) {
+            const int co = t.n_tile * (NGP * 32) + g * 32 + t.j;
             if (co >= a.Co) continue;
             const float bv = a.bias ? a.bias[co] : 0.0f;
             float* dst;
@@ -467,8 +468,34 @@ hipError_t launch_convlstm_step_f32(const ConvPlan& plan, const ConvLSTMStepArgs
 }
 
 hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, int n_tiles, hipStream_t s) {
-    EpiPlain e{ea};
-    return launch_conv(plan, e, n_tiles, s);
+    switch (ea.ng) {
+        case 1: return launch_conv(plan, EpiPlain<1>{ea}, n_tiles, s);
+        case 2: return launch_conv(plan, EpiPlain<2>{ea}, n_tiles, s);
+        case 3: return launch_conv(plan, EpiPlain<3>{ea}, n_tiles, s);
+        case 4: return launch_conv(plan, EpiPlain<4>{ea}, n_tiles, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+int plain_groups(int Co) {
+    int best = 4, best_pad = 1 << 30;
+    for (int ng = 4; ng >= 1; --ng) {  // ties -> more groups per tile (fewer re-reads of the activation tile)
+        const int w = ng * 32;
+        const int padded = (Co + w - 1) / w * w;
+        if (padded < best_pad) { best_pad = padded; best = ng; }
+    }
+    return best;
+}
+
+void fill_plain_pack(PackDesc& pd, int Co, int first) {
+    const int ng = plain_groups(Co);
+    pd.NG = ng;
+    for (int s = 0; s < MAX_SEG; ++s)
+        for (int g = 0; g < MAX_NG; ++g) pd.rowbase[s][g] = g < ng ? first + g * 32 : -1;
+    for (int g = 0; g < MAX_NG; ++g) pd.goff[g] = g * 32;
+    pd.tile_stride = ng * 32;
+    pd.nch = Co;
+    pd.n_tiles = plain_tiles(Co);
 }
 
 hipError_t launch_st_cgroup_f32(const ConvPlan& plan, const STGateArgs& ea, int n_tiles, hipStream_t s) {

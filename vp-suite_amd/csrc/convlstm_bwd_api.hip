@@ -39,6 +39,8 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     float* dh_buf = ws.take(L.n_state);
     float* dc_buf = ws.take(L.n_state);
     float* slabs = ws.take(L.slab_floats);
+    const int gb_blocks = gate_bwd_blocks((int)HW, Ch);
+    float* db_part = ws.take((size_t)T * gb_blocks * N4);
 
     // ---- layout adaptation ----
     const float *xn = x, *h0n = h0, *c0n = c0, *outn = out, *doutn = dout, *dhTn = dhT, *dcTn = dcT;
@@ -87,14 +89,14 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     const bool need_dx = dxn && xn;
     const int col_start = need_dx ? 0 : Cin;
     const int n_out = need_dx ? Ct : Ch;
-    const int d_tiles = (n_out + NT - 1) / NT;
+    const int d_tiles = plain_tiles(n_out);
     {
         PackDesc pd{};
         pd.seg[0] = PackSeg{W, (long long)Ct * L.taps, L.taps, 0, N4};
         memcpy(pd.stage, L.d_stage, sizeof(ConvStage) * L.d_nstage);
-        pd.nstage = L.d_nstage; pd.chunks_total = L.d_chunks; pd.prec = d->precision; pd.n_tiles = d_tiles; pd.taps = L.taps; pd.NG = 4;
-        for (int g = 0; g < 4; ++g) { pd.rowbase[0][g] = col_start + g * 32; pd.goff[g] = g * 32; }
-        pd.tile_stride = NT; pd.nch = n_out; pd.transposed = 1; pd.flip = 1;
+        pd.nstage = L.d_nstage; pd.chunks_total = L.d_chunks; pd.prec = d->precision; pd.taps = L.taps;
+        fill_plain_pack(pd, n_out, col_start);
+        pd.transposed = 1; pd.flip = 1;
         VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
     }
 
@@ -113,6 +115,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         ga.wci = wci; ga.wcf = wcf; ga.wco = wco;
         ga.dwci = dpeep ? dwci : nullptr; ga.dwcf = dpeep ? dwcf : nullptr; ga.dwco = dpeep ? dwco : nullptr;
         ga.dG = dG_all + (size_t)t * L.n_state * 4;
+        ga.db_partial = db ? db_part + (size_t)t * gb_blocks * N4 : nullptr;
         VPX_CHECK_HIP(launch_gate_bwd(ga, stream));
 
         float* dh_target = (t > 0) ? dh_buf : dh0n;  // at t = 0 the recurrent gradient is dL/dh0 (if requested)
@@ -128,7 +131,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
             P.a_bytes = conv_a_bytes(L.d_stage, L.d_nstage, d->kh, d->kw);
             P.wpk = wpk;
             PlainEpiArgs ea{};
-            ea.Co = n_out;
+            ea.Co = n_out; ea.ng = plain_groups(n_out);
             ea.split = need_dx ? Cin : 0;
             ea.out0 = need_dx ? dxn + (size_t)t * HW * Cin : nullptr;
             ea.bstride0 = (long long)((size_t)T * HW * Cin); ea.ld0 = Cin;
@@ -158,7 +161,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     }
     if (db) {
         VPX_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)N4 * sizeof(float), stream));
-        VPX_CHECK_HIP(launch_colsum(dG_all, db, (long long)T * B * HW, N4, stream));
+        VPX_CHECK_HIP(launch_colsum(db_part, db, (long long)T * gb_blocks, N4, stream));  // block partials from the gate-backward kernel
     }
     if (d->layout == VPX_LAYOUT_NCHW) {
         if (dx) VPX_CHECK_HIP(launch_nhwc_to_nchw(dxn, dx, B * T, Cin, H, Wd, stream));

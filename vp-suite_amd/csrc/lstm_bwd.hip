@@ -14,10 +14,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void convlstm_gate_bwd_kernel(const GateBwdArgs a) {
+    extern __shared__ float db_lds[];  // [4Ch] block-local bias-gradient sums (only when a.db_partial)
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int HW = a.HW, Ch = a.Ch;
-    if (idx >= HW * Ch) return;
-    const int pix = idx / Ch, ch = idx - pix * Ch;
+    if (a.db_partial) {
+        for (int n = threadIdx.x; n < 4 * Ch; n += 256) db_lds[n] = 0.0f;
+        __syncthreads();
+    }
+    const bool active = idx < HW * Ch;
+    const int pix = active ? idx / Ch : 0, ch = active ? idx - pix * Ch : 0;
+    float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;
+    if (active) {
     const size_t pc = (size_t)pix * Ch + ch;
     float wci = 0.f, wcf = 0.f, wco = 0.f;
     const bool peep = a.wci != nullptr;
@@ -46,17 +53,29 @@ __global__ __launch_bounds__(256) void convlstm_gate_bwd_kernel(const GateBwdArg
         dg[a.gate_pos[1] * Ch] = daf;
         dg[a.gate_pos[2] * Ch] = dag;
         dg[a.gate_pos[3] * Ch] = dao;
+        sb0 += dai; sb1 += daf; sb2 += dag; sb3 += dao;
     }
     if (peep && a.dwci) {  // single owner per (pix, ch): plain accumulate over the time steps
         a.dwci[pc] += dpi;
         a.dwcf[pc] += dpf;
         a.dwco[pc] += dpo;
     }
+    }  // active
+    if (a.db_partial) {  // bias gradient: LDS float atomics within the block, one plain row per block to HBM
+        if (active) {
+            atomicAdd(&db_lds[a.gate_pos[0] * Ch + ch], sb0);
+            atomicAdd(&db_lds[a.gate_pos[1] * Ch + ch], sb1);
+            atomicAdd(&db_lds[a.gate_pos[2] * Ch + ch], sb2);
+            atomicAdd(&db_lds[a.gate_pos[3] * Ch + ch], sb3);
+        }
+        __syncthreads();
+        for (int n = threadIdx.x; n < 4 * Ch; n += 256) a.db_partial[(size_t)blockIdx.x * 4 * Ch + n] = db_lds[n];
+    }
 }
 
 hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s) {
-    const int n = a.HW * a.Ch;
-    hipLaunchKernelGGL(convlstm_gate_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    const size_t lds = a.db_partial ? (size_t)4 * a.Ch * sizeof(float) : 0;
+    hipLaunchKernelGGL(convlstm_gate_bwd_kernel, dim3(gate_bwd_blocks(a.HW, a.Ch)), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

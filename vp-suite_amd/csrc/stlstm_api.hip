@@ -36,7 +36,7 @@ int check_st_desc(const vpx_stlstm_desc* d) {
 int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
     L.taps = d->k * d->k;
     L.tiles32 = (d->Ch + 31) / 32;
-    L.tiles128 = (d->Ch + NT - 1) / NT;
+    L.tiles128 = plain_tiles(d->Ch);
     const int segG[2] = {d->Cin, d->Ch};
     const int segO[2] = {d->Ch, d->Ch};
     L.nstage_g = build_stages(L.stage_g, &L.chunks_g, segG, 2, L.taps, pick_stage_channels(segG, 2, d->k, d->k, 4, d->precision), d->precision);
@@ -48,7 +48,7 @@ int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
     L.wpk_c = packed_weight_bytes(L.tiles32, L.chunks_g, 4, d->precision) / 4;
     L.wpk_m = packed_weight_bytes(L.tiles32, L.chunks_g, 3, d->precision) / 4;
     L.wpk_o = packed_weight_bytes(L.tiles32, L.chunks_o, 1, d->precision) / 4;
-    L.wpk_l = packed_weight_bytes(L.tiles128, L.chunks_l, 4, d->precision) / 4;
+    L.wpk_l = packed_weight_bytes(L.tiles128, L.chunks_l, plain_groups(d->Ch), d->precision) / 4;
     return VPX_OK;
 }
 
@@ -160,10 +160,8 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         pl.seg[0] = PackSeg{Wlast, (long long)2 * Ch, 1, 0, Ch};
         pl.seg[1] = PackSeg{Wlast, (long long)2 * Ch, 1, Ch, Ch};
         memcpy(pl.stage, L.stage_l, sizeof(ConvStage) * L.nstage_l);
-        pl.nstage = L.nstage_l; pl.chunks_total = L.chunks_l; pl.prec = d->precision; pl.n_tiles = L.tiles128; pl.taps = 1; pl.NG = 4;
-        for (int s = 0; s < 2; ++s) for (int g = 0; g < 4; ++g) pl.rowbase[s][g] = g * 32;
-        for (int g = 0; g < 4; ++g) pl.goff[g] = g * 32;
-        pl.tile_stride = NT; pl.nch = Ch;
+        pl.nstage = L.nstage_l; pl.chunks_total = L.chunks_l; pl.prec = d->precision; pl.taps = 1;
+        fill_plain_pack(pl, Ch, 0);
         VPX_CHECK_HIP(launch_pack_weights(pl, wpk_l, stream));
     }
 
@@ -201,7 +199,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         P.nstage = L.nstage_l; memcpy(P.stage, L.stage_l, sizeof(ConvStage) * L.nstage_l);
         P.chunks_total = L.chunks_l; P.a_bytes = conv_a_bytes(L.stage_l, L.nstage_l, 1, 1); P.wpk = wpk_l;
         PlainEpiArgs ea{};
-        ea.Co = Ch; ea.split = Ch; ea.out0 = lc; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
+        ea.Co = Ch; ea.split = Ch; ea.out0 = lc; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch; ea.ng = plain_groups(Ch);
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.tiles128, stream));
     }
     // ---- launch 4: conv_o(mem) + output gate ----

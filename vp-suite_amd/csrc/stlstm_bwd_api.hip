@@ -26,8 +26,8 @@ int mk_dg(STBwdLayout::DG& g, const int* segC, int nseg, int k, int n_out, int p
     const int taps = k * k;
     g.nstage = build_stages(g.stage, &g.chunks, segC, nseg, taps, pick_stage_channels(segC, nseg, k, k, 4, prec), prec);
     if (g.nstage < 0) return -1;
-    g.tiles = (n_out + NT - 1) / NT;
-    g.wpk = packed_weight_bytes(g.tiles, g.chunks, 4, prec) / 4;
+    g.tiles = plain_tiles(n_out);
+    g.wpk = packed_weight_bytes(g.tiles, g.chunks, plain_groups(n_out), prec) / 4;
     return 0;
 }
 
@@ -180,10 +180,9 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     };
     auto pack_plain_T = [&](PackDesc& pd, const STBwdLayout::DG& g, int taps, int n_out) {
         memcpy(pd.stage, g.stage, sizeof(ConvStage) * g.nstage);
-        pd.nstage = g.nstage; pd.chunks_total = g.chunks; pd.prec = d->precision; pd.n_tiles = g.tiles; pd.taps = taps; pd.NG = 4;
-        for (int s = 0; s < MAX_SEG; ++s) for (int gg = 0; gg < 4; ++gg) pd.rowbase[s][gg] = gg * 32;
-        for (int gg = 0; gg < 4; ++gg) pd.goff[gg] = gg * 32;
-        pd.tile_stride = NT; pd.nch = n_out; pd.transposed = 1; pd.flip = 1;
+        pd.nstage = g.nstage; pd.chunks_total = g.chunks; pd.prec = d->precision; pd.taps = taps;
+        fill_plain_pack(pd, n_out, 0);
+        pd.transposed = 1; pd.flip = 1;
     };
 
     // ---- A: through h_new = o * tanh(conv_last(mem)) ----
@@ -200,7 +199,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         ConvPlan P = plan_for(L.o, k, wpk_o);
         P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG};
         PlainEpiArgs ea{};
-        ea.Co = 2 * Ch; ea.split = Ch;
+        ea.Co = 2 * Ch; ea.split = Ch; ea.ng = plain_groups(2 * Ch);
         ea.out0 = dcn_conv; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
         ea.out1 = dmn_conv; ea.bstride1 = (long long)(HW * Ch); ea.ld1 = Ch;
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.o.tiles, stream));
@@ -239,7 +238,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         P.seg[1] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG};
         P.seg[2] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG};
         PlainEpiArgs ea{};
-        ea.Co = Cin; ea.split = Cin; ea.out0 = dxn; ea.bstride0 = (long long)(HW * Cin); ea.ld0 = Cin;
+        ea.Co = Cin; ea.split = Cin; ea.ng = plain_groups(Cin); ea.out0 = dxn; ea.bstride0 = (long long)(HW * Cin); ea.ld0 = Cin;
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.x.tiles, stream));
     }
     if (dhn) {
@@ -250,7 +249,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         ConvPlan P = plan_for(L.h, k, wpk_h);
         P.nseg = 1; P.seg[0] = ConvSeg{dG7, (long long)(HW * ldG), 4 * Ch, ldG};
         PlainEpiArgs ea{};
-        ea.Co = Ch; ea.split = Ch; ea.out0 = dhn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
+        ea.Co = Ch; ea.split = Ch; ea.ng = plain_groups(Ch); ea.out0 = dhn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.h.tiles, stream));
     }
     if (dm) {
@@ -261,7 +260,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         ConvPlan P = plan_for(L.m, k, wpk_m);
         P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG};
         PlainEpiArgs ea{};
-        ea.Co = Ch; ea.split = Ch; ea.out0 = dmn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
+        ea.Co = Ch; ea.split = Ch; ea.ng = plain_groups(Ch); ea.out0 = dmn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
         ea.accumulate = 1;  // onto dm_new_total * f' written by stage C
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.m.tiles, stream));
     }

@@ -205,7 +205,7 @@ size_t vpx_conv2d_workspace_bytes(int Ci, int Co, int kh, int kw) {
     size_t best = 0;
     for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16X3; ++prec) {
         if (build_stages(st, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, 4, prec), prec) < 0) return 0;
-        const size_t b = align256(packed_weight_bytes((Co + NT - 1) / NT, chunks, 4, prec));
+        const size_t b = align256(packed_weight_bytes(plain_tiles(Co), chunks, plain_groups(Co), prec));
         if (b > best) best = b;
     }
     return best + 256;
@@ -224,20 +224,19 @@ int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
     const int segC[1] = {Ci};
     P.nstage = build_stages(P.stage, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, 4, precision), precision);
     if (P.nstage < 0) { set_error("vpx_conv2d_nhwc_fwd: too many channel stages"); return VPX_ERR_UNSUPPORTED; }
-    const int n_tiles = (Co + NT - 1) / NT;
+    const int n_tiles = plain_tiles(Co);
     if (!workspace || workspace_bytes < vpx_conv2d_workspace_bytes(Ci, Co, kh, kw)) {
         set_error("vpx_conv2d_nhwc_fwd: workspace too small");
         return VPX_ERR_WORKSPACE;
     }
     Carver ws{(char*)workspace, 0, workspace_bytes};
     ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
-    float* wpk = ws.take(packed_weight_bytes(n_tiles, chunks, 4, precision) / sizeof(float));
+    float* wpk = ws.take(packed_weight_bytes(n_tiles, chunks, plain_groups(Co), precision) / sizeof(float));
     PackDesc pd{};
     pd.seg[0] = PackSeg{w, (long long)Ci * kh * kw, kh * kw, 0, Ci};
     memcpy(pd.stage, P.stage, sizeof(ConvStage) * P.nstage);
-    pd.nstage = P.nstage; pd.chunks_total = chunks; pd.prec = precision; pd.n_tiles = n_tiles; pd.taps = kh * kw; pd.NG = 4;
-    for (int g = 0; g < 4; ++g) { pd.rowbase[0][g] = g * 32; pd.goff[g] = g * 32; }
-    pd.tile_stride = NT; pd.nch = Co;
+    pd.nstage = P.nstage; pd.chunks_total = chunks; pd.prec = precision; pd.taps = kh * kw;
+    fill_plain_pack(pd, Co, 0);
     VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
     P.B = N; P.H = H; P.W = W; P.kh = kh; P.kw = kw;
     P.tiles_x = (W + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_H - 1) / TILE_H;
@@ -247,7 +246,7 @@ int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
     P.a_bytes = conv_a_bytes(P.stage, P.nstage, kh, kw);
     P.wpk = wpk;
     PlainEpiArgs ea{};
-    ea.bias = bias; ea.Co = Co; ea.split = Co;
+    ea.bias = bias; ea.Co = Co; ea.split = Co; ea.ng = plain_groups(Co);
     ea.out0 = y; ea.bstride0 = (long long)H * W * Co; ea.ld0 = Co;
     VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, n_tiles, stream));
     return VPX_OK;

@@ -90,8 +90,8 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     const int segD[1] = {N4};
     L.d_nstage = build_stages(L.d_stage, &L.d_chunks, segD, 1, L.taps, pick_stage_channels(segD, 1, d->kh, d->kw, 4, d->precision), d->precision);
     if (L.d_nstage < 0) { set_error("convlstm: too many channel stages in the data-gradient conv (Ch=%d)", d->Ch); return VPX_ERR_UNSUPPORTED; }
-    L.d_tiles_full = (Ct + NT - 1) / NT;
-    L.d_tiles_h = (d->Ch + NT - 1) / NT;
+    L.d_tiles_full = plain_tiles(Ct);
+    L.d_tiles_h = plain_tiles(d->Ch);
     L.n_ctiles = 0;
     for (int c0 = 0; c0 < d->Cin; c0 += 64) {
         if (L.n_ctiles >= 16) { set_error("convlstm: too many channels for the weight-gradient kernel"); return VPX_ERR_UNSUPPORTED; }
@@ -117,10 +117,11 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
 
 
 static inline size_t convlstm_bwd_workspace_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
-    size_t b = align256(packed_weight_bytes(L.d_tiles_full, L.d_chunks, 4, d->precision));
+    size_t b = align256(packed_weight_bytes(L.d_tiles_full, L.d_chunks, 4, d->precision));  // upper bound over both tilings
     b += align256((size_t)d->T * L.n_state * 4 * sizeof(float));  // dG, all steps
     b += 2 * align256(L.n_state * sizeof(float));                 // dh, dc carries
     b += align256(L.slab_floats * sizeof(float));
+    b += align256((size_t)d->T * gate_bwd_blocks(d->H * d->W, d->Ch) * 4 * d->Ch * sizeof(float));  // bias-gradient partials
     if (d->layout == VPX_LAYOUT_NCHW) {
         // staged copies of x, out, dout, dx + states (h0,c0,dhT,dcT,dh0,dc0) + 6 peephole-sized buffers
         b += 2 * align256(L.n_x * 4) + 2 * align256(L.n_out * 4) + 6 * align256(L.n_state * 4) + 6 * align256(L.n_peep * 4);

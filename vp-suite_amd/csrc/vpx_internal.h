@@ -103,8 +103,15 @@ struct PlainEpiArgs {
     float* out0; long long bstride0; int ld0;   // NHWC, ld = channels per pixel of the destination tensor
     float* out1; long long bstride1; int ld1;
     int accumulate;           // 1: += into destination
+    int ng;                   // 32-channel groups per N tile (plain_groups(Co)); tile covers ng*32 output channels
 };
 hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, int n_tiles, hipStream_t s);
+// N tiling of a plain convolution with Co outputs: 1..4 groups of 32 channels per workgroup, chosen to minimise padding
+int plain_groups(int Co);
+inline int plain_tiles(int Co) { const int w = plain_groups(Co) * 32; return (Co + w - 1) / w; }
+// fills NG / rowbase / goff / tile_stride / nch / n_tiles of a pack descriptor for a plain conv whose outputs start at
+// row (or column, if transposed) `first` of every segment's weight tensor
+void fill_plain_pack(PackDesc& pd, int Co, int first);
 
 // ---- ST-LSTM (predrnn.py:57-83) epilogues; all tensors NHWC [B,HW,Ch] ----
 struct STGateArgs {           // "c group": acc = (i, f, g, o_pre) from [x | h];  "m group": acc = (i', f', g') from [x | m]
@@ -143,7 +150,9 @@ struct GateBwdArgs {
     const float* wci; const float* wcf; const float* wco;  // peepholes [HW,Ch] or null
     float* dwci; float* dwcf; float* dwco;                  // accumulated (+=) over steps, or null
     float* dG;                // [B,HW,4Ch] d(pre-activation), reference gate order
+    float* db_partial;        // [gridDim.x][4Ch] per-block column sums of dG (bias gradient partials), or null
 };
+inline int gate_bwd_blocks(int HW, int Ch) { return (HW * Ch + 255) / 256; }
 hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s);
 hipError_t launch_colsum(const float* m, float* out, long long rows, int cols, hipStream_t s);
 
