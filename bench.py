@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (reference default run config batch_size=32)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer")
+    ap.add_argument("--model", choices=["convlstm-shi", "predrnn-pp"], default="convlstm-shi",
+                    help="convlstm-shi = BASELINE configs[1] (the bench line); predrnn-pp = configs[2] (secondary workload)")
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3",
                     help="operand mode of the fused cell kernels: f32 = exact fp32 MFMA; bf16x3 = split-bf16 operands, "
                          "3 bf16 MFMAs per product, fp32 accumulate (fp32-level accuracy, parity-tested at 1e-4)")
@@ -85,15 +87,16 @@ def main():
     from vp_suite_amd.models import MODEL_CLASSES
 
     torch.manual_seed(0)  # identical random-init weights on every rank
-    model = MODEL_CLASSES["convlstm-shi"](str(dev), img_shape=(args.channels, args.img, args.img), action_size=0,
-                                          tensor_value_range=[0.0, 1.0], cell_precision=args.precision).to(dev)
+    model = MODEL_CLASSES[args.model](str(dev), img_shape=(args.channels, args.img, args.img), action_size=0,
+                                      tensor_value_range=[0.0, 1.0], cell_precision=args.precision).to(dev)
+    complete = model.NEEDS_COMPLETE_INPUT
     with torch.no_grad():
         for n, p in model.named_parameters():
             if n.split(".")[-1] in ("Wci", "Wcf", "Wco"):
                 p.normal_(0.0, 0.1)  # exercise the peephole path (reference init is zeros)
     torch.manual_seed(42 + rank)
     frames = torch.rand(args.batch, args.context + args.pred, args.channels, args.img, args.img, device=dev)
-    x, target = frames[:, :args.context], frames[:, args.context:]
+    x, target = (frames if complete else frames[:, :args.context]), frames[:, args.context:]
 
     if args.mode == "train":
         from vp_suite_amd.train import DataParallelTrainer
@@ -146,7 +149,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
-            "config": {"workload": f"convlstm-shi (EF-ConvLSTM default) on MovingMNIST-shaped synthetic frames "
+            "config": {"workload": f"{args.model} (default hyper-parameters) on MovingMNIST-shaped synthetic frames "
                                    f"{args.channels}x{args.img}x{args.img}, {args.context}->{args.pred}, "
                                    f"random-init weights",
                        "mode": args.mode, "per_gpu_batch": args.batch, "global_batch": args.batch * world,
@@ -154,7 +157,9 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach_tflops / peak, 4), "traffic": None,
-                "kernel": f"conv_gemm_kernel<EpiConvLSTM, {args.precision}> (fused ConvLSTM cell step)",
+                "kernel": (f"conv_gemm_kernel<EpiConvLSTM, {args.precision}> (fused ConvLSTM cell step)"
+                           if args.model == "convlstm-shi" else
+                           f"conv_gemm_kernel<EpiSTGate/EpiSTOut/EpiPlain, {args.precision}> (ST-LSTM cell step, 4 launches)"),
                 "note": ("achieved = algorithmic fp32 FLOPs / kernel time. bf16x3 issues 3 bf16 MFMAs per algorithmic "
                          "product, so the MFMA pipe is busy for 3x this figure" if args.precision == "bf16x3" else
                          "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
@@ -166,7 +171,7 @@ def main():
                              "frac": round(ach_gbs / HBM_PEAK_GBS, 4)},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "convlstm-shi":
             out["cpu_baseline"] = cpu_baseline(model, args)
         print(json.dumps(out), flush=True)
     if world > 1:

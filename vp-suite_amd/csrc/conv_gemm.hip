@@ -115,13 +115,13 @@ hipError_t launch_pack_weights(const PackDesc& pd, float* dst, hipStream_t s) {
 // epilogues
 // ---------------------------------------------------------------------------------------------------------------
 struct TileCtx {
-    int b, y0, x0, n_tile, wave, j, hh, H, W;
+    int b, y0, x0, n_tile, prow, j, hh, H, W;  // prow = first row (inside the workgroup tile) of this 32-pixel MFMA tile
 };
 
 // accumulator register r of a 32x32 MFMA tile holds row (r&3) + 8*(r>>2) + 4*hh; wave-local pixel index = that row.
 __device__ __forceinline__ bool tile_pixel(const TileCtx& t, int r, int& y, int& x) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * t.hh;
-    y = t.y0 + 2 * t.wave + (i >> 4);
+    y = t.y0 + t.prow + (i >> 4);
     x = t.x0 + (i & 15);
     return y < t.H && x < t.W;
 }
@@ -264,8 +264,8 @@ template <int MODE> struct ModeTraits;
 template <> struct ModeTraits<0> { static constexpr int KSTEP = 8, KC = 16, WROW_DATA = 16 * 4; };
 template <> struct ModeTraits<1> { static constexpr int KSTEP = 16, KC = 32, WROW_DATA = 32 * 4; };
 
-template <class Epi, int MODE>
-__global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
+template <class Epi, int MODE, int MW>
+__global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
     using MT = ModeTraits<MODE>;
     constexpr int KC = MT::KC, KSTEP = MT::KSTEP;
     constexpr int WROW = MT::WROW_DATA + 16;   // padded LDS row of one output channel's chunk slice (odd multiple of 16 B)
@@ -286,179 +286,239 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(const ConvPlan P, c
     const int ty = mt % P.tiles_y;
     const int b = mt / P.tiles_y;
     const int n_tile = blockIdx.y;
-    const int x0 = tx * TILE_W, y0 = ty * TILE_H;
-    const int halo_w = TILE_W + P.kw - 1, halo_h = TILE_H + P.kh - 1;
+    constexpr int TH = TILE_H * MW;  // workgroup tile height: every wave owns 2*MW consecutive rows of 16 pixels
+    const int x0 = tx * TILE_W, y0 = ty * TH;
+    const int halo_w = TILE_W + P.kw - 1, halo_h = TH + P.kh - 1;
     const int npos = halo_w * halo_h;
     const int ph = P.kh / 2, pw = P.kw / 2;
 
     char* A_lds = smem;
     char* W_lds = smem + P.a_bytes;
 
-    f32x16 acc[NG];
+    f32x16 acc[MW][NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][g][r] = 0.0f;
 
-    // this lane's pixel inside the tile (MFMA row = lane & 31)
-    const int py = 2 * wave + (j >> 4), px = j & 15;
+    // this lane's pixel inside the tile (MFMA row = lane & 31); MFMA tile m of the wave sits 2 rows further down
+    const int py = 2 * MW * wave + (j >> 4), px = j & 15;
     const char* wtile = reinterpret_cast<const char*>(P.wpk) + (size_t)n_tile * P.chunks_total * (NTR * MT::WROW_DATA);
 
-    for (int s = 0; s < P.nstage; ++s) {
-        const ConvStage st = P.stage[s];
-        const ConvSeg sg = P.seg[st.seg];
-        const int arow = st.cn * 4 + 16;  // bytes per halo position (odd multiple of 16 B -> conflict-free b128 reads)
-        __syncthreads();                  // previous stage fully consumed
-        // ---- stage the activation halo tile: positions x [c0, c0+cn) ----
-        {
-            const float* src = sg.ptr + (size_t)b * sg.bstride;
-            const int ld = sg.ld ? sg.ld : sg.C;
-            if (((sg.C | ld) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-                const int v4n = st.cn >> 2;
-                const int total = npos * v4n;
-                for (int v = tid; v < total; v += NTHREADS) {
-                    const int pos = v / v4n, c4 = v - pos * v4n;
-                    const int hy = pos / halo_w, hx = pos - hy * halo_w;
-                    const int gy = y0 - ph + hy, gx = x0 - pw + hx;
-                    const int c = st.c0 + c4 * 4;
-                    f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                    if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < sg.C)
-                        val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * P.W + gx) * ld + c);
-                    if constexpr (MODE == 0) {
-                        *reinterpret_cast<f32x4*>(A_lds + pos * arow + c4 * 16) = val;
-                    } else {
-                        unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-                        split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);
-                        split_bf16(val[2], h2, l2); split_bf16(val[3], h3, l3);
-                        uint2 hv = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
-                        uint2 lv = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
-                        *reinterpret_cast<uint2*>(A_lds + pos * arow + c4 * 8) = hv;
-                        *reinterpret_cast<uint2*>(A_lds + pos * arow + st.cn * 2 + c4 * 8) = lv;
-                    }
-                }
-            } else {
-                const int total = npos * st.cn;
-                for (int e = tid; e < total; e += NTHREADS) {
-                    const int pos = e / st.cn, cc = e - pos * st.cn;
-                    const int hy = pos / halo_w, hx = pos - hy * halo_w;
-                    const int gy = y0 - ph + hy, gx = x0 - pw + hx;
-                    const int c = st.c0 + cc;
-                    float val = 0.f;
-                    if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < sg.C)
-                        val = src[((size_t)gy * P.W + gx) * ld + c];
-                    if constexpr (MODE == 0) {
-                        *reinterpret_cast<float*>(A_lds + pos * arow + cc * 4) = val;
-                    } else {
-                        unsigned short h, l;
-                        split_bf16(val, h, l);
-                        *reinterpret_cast<unsigned short*>(A_lds + pos * arow + cc * 2) = h;
-                        *reinterpret_cast<unsigned short*>(A_lds + pos * arow + st.cn * 2 + cc * 2) = l;
-                    }
-                }
-            }
-        }
-        // ---- weight chunk 0 of this stage ----
-        const int nchunks = (st.nq + QPC - 1) / QPC;
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(wtile + (size_t)st.chunk0 * (NTR * MT::WROW_DATA));
-        f32x4 wr[WIT];
+    // ---- K loop ------------------------------------------------------------------------------------------------
+    // Weight chunks form ONE stream over all active stages: chunk g sits in LDS buffer g&1; chunks g+1 and g+2 are in
+    // flight in two register sets (wrA: even chunks, wrB: odd chunks), i.e. global loads are issued two chunk
+    // iterations before their LDS write, and a stage boundary costs no weight bubble.
+    const bool wload = !(P.dbg & 4);
+    auto stage_chunks = [&](int s) { return (P.stage[s].nq + QPC - 1) / QPC; };
+    auto chunk_src = [&](int s, int ck) {
+        return reinterpret_cast<const f32x4*>(wtile + (size_t)(P.stage[s].chunk0 + ck) * (NTR * MT::WROW_DATA));
+    };
+    int ps = 0, pck = 0;  // prefetch cursor: next chunk to request from global memory
+    auto issue_load = [&](f32x4 (&wr)[WIT]) {  // returns silently past the end of the stream
+        if (ps < P.nstage) {
+            const f32x4* src = chunk_src(ps, pck);
 #pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            if (tid + it * NTHREADS < WV4) wr[it] = wsrc[tid + it * NTHREADS];
+            for (int it = 0; it < WIT; ++it)
+                if (tid + it * NTHREADS < WV4 && wload) wr[it] = src[tid + it * NTHREADS];
+            if (++pck == stage_chunks(ps)) { pck = 0; ++ps; }
+        }
+    };
+    auto write_lds = [&](const f32x4 (&wr)[WIT], int buf) {
+        char* wdst = W_lds + buf * WBUF;
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
             const int v = tid + it * NTHREADS;
-            if (v < WV4) *reinterpret_cast<f32x4*>(W_lds + (v / V4ROW) * WROW + (v % V4ROW) * 16) = wr[it];
+            if (v < WV4) *reinterpret_cast<f32x4*>(wdst + (v / V4ROW) * WROW + (v % V4ROW) * 16) = wr[it];
         }
-        __syncthreads();
+    };
+    f32x4 wrA[WIT], wrB[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) { wrA[it] = f32x4{0.f, 0.f, 0.f, 0.f}; wrB[it] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    issue_load(wrA);  // chunk 0
+    issue_load(wrB);  // chunk 1
 
-        const int ksn = st.cn / KSTEP;  // k-steps per tap
-        int ks = 0, tdx = 0, tdy = 0;
-        const char* a_lane = A_lds + (py * halo_w + px) * arow + hh * 16;
-        int tapoff = 0;
-        for (int ck = 0; ck < nchunks; ++ck) {
-            const bool more = ck + 1 < nchunks;
-            if (more) {
-                const f32x4* wn = wsrc + (size_t)(ck + 1) * WV4;
-#pragma unroll
-                for (int it = 0; it < WIT; ++it)
-                    if (tid + it * NTHREADS < WV4) wr[it] = wn[tid + it * NTHREADS];
-            }
-            const char* wb = W_lds + (ck & 1) * WBUF + j * WROW + hh * 16;
-#pragma unroll
-            for (int q = 0; q < QPC; ++q) {
-                if (ck * QPC + q < st.nq) {
-                    if constexpr (MODE == 0) {
-                        // fp32: one b128 = 4 consecutive channels; lanes 0-31 take k = 8*ks + s, lanes 32-63 k = 8*ks + 4 + s
-                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(a_lane + tapoff + ks * 32);
-                        f32x4 b4[NG];
-#pragma unroll
-                        for (int g = 0; g < NG; ++g)
-                            b4[g] = *reinterpret_cast<const f32x4*>(wb + g * 32 * WROW + q * 32);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-#pragma unroll
-                            for (int g = 0; g < NG; ++g)
-                                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k], b4[g][k], acc[g], 0, 0, 0);
-                    } else {
-                        // bf16x3: one b128 = 8 consecutive channels; lanes 0-31 take k = 16*ks + 0..7, lanes 32-63 + 8..15
-                        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_lane + tapoff + ks * 32);
-                        const bf16x8 al = *reinterpret_cast<const bf16x8*>(a_lane + tapoff + st.cn * 2 + ks * 32);
-                        bf16x8 bh[NG], bl[NG];
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) {
-                            bh[g] = *reinterpret_cast<const bf16x8*>(wb + g * 32 * WROW + q * 32);
-                            bl[g] = *reinterpret_cast<const bf16x8*>(wb + g * 32 * WROW + KC * 2 + q * 32);
+    int s = 0, ck = 0;        // compute cursor
+    long long gidx = 0;       // chunks consumed so far (parity selects LDS buffer / register set)
+    int ks = 0, tdx = 0, tdy = 0, tapoff = 0, arow = 16, ksn = 1;
+    const char* a_lane = A_lds;
+    ConvStage st{};
+    bool new_stage = true;
+    bool first = true;
+    while (s < P.nstage) {
+        if (new_stage) {
+            st = P.stage[s];
+            const ConvSeg sg = P.seg[st.seg];
+            arow = st.cn * 4 + 16;  // bytes per halo position (odd multiple of 16 B -> conflict-free b128 reads)
+            // (the barrier that ended the previous chunk guarantees the previous stage's tile is fully consumed)
+        // ---- stage the activation halo tile: positions x [c0, c0+cn) ----
+            {
+                const float* src = sg.ptr + (size_t)b * sg.bstride;
+                const int ld = sg.ld ? sg.ld : sg.C;
+                if (((sg.C | ld) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+                    const int v4n = st.cn >> 2;
+                    const int total = npos * v4n;
+                    for (int v = tid; v < total; v += NTHREADS) {
+                        const int pos = v / v4n, c4 = v - pos * v4n;
+                        const int hy = pos / halo_w, hx = pos - hy * halo_w;
+                        const int gy = y0 - ph + hy, gx = x0 - pw + hx;
+                        const int c = st.c0 + c4 * 4;
+                        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                        if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < sg.C && !(P.dbg & 2))
+                            val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * P.W + gx) * ld + c);
+                        if constexpr (MODE == 0) {
+                            *reinterpret_cast<f32x4*>(A_lds + pos * arow + c4 * 16) = val;
+                        } else {
+                            unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+                            split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);
+                            split_bf16(val[2], h2, l2); split_bf16(val[3], h3, l3);
+                            uint2 hv = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
+                            uint2 lv = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
+                            *reinterpret_cast<uint2*>(A_lds + pos * arow + c4 * 8) = hv;
+                            *reinterpret_cast<uint2*>(A_lds + pos * arow + st.cn * 2 + c4 * 8) = lv;
                         }
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[g], acc[g], 0, 0, 0);
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[g], acc[g], 0, 0, 0);
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[g], acc[g], 0, 0, 0);
                     }
-                    if (++ks == ksn) {
-                        ks = 0;
-                        if (++tdx == P.kw) { tdx = 0; ++tdy; }
-                        tapoff = (tdy * halo_w + tdx) * arow;
+                } else {
+                    const int total = npos * st.cn;
+                    for (int e = tid; e < total; e += NTHREADS) {
+                        const int pos = e / st.cn, cc = e - pos * st.cn;
+                        const int hy = pos / halo_w, hx = pos - hy * halo_w;
+                        const int gy = y0 - ph + hy, gx = x0 - pw + hx;
+                        const int c = st.c0 + cc;
+                        float val = 0.f;
+                        if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < sg.C)
+                            val = src[((size_t)gy * P.W + gx) * ld + c];
+                        if constexpr (MODE == 0) {
+                            *reinterpret_cast<float*>(A_lds + pos * arow + cc * 4) = val;
+                        } else {
+                            unsigned short h, l;
+                            split_bf16(val, h, l);
+                            *reinterpret_cast<unsigned short*>(A_lds + pos * arow + cc * 2) = h;
+                            *reinterpret_cast<unsigned short*>(A_lds + pos * arow + st.cn * 2 + cc * 2) = l;
+                        }
                     }
                 }
             }
-            if (more) {
-                char* wdst = W_lds + ((ck + 1) & 1) * WBUF;
-#pragma unroll
-                for (int it = 0; it < WIT; ++it) {
-                    const int v = tid + it * NTHREADS;
-                    if (v < WV4) *reinterpret_cast<f32x4*>(wdst + (v / V4ROW) * WROW + (v % V4ROW) * 16) = wr[it];
-                }
+
+            ksn = st.cn / KSTEP;
+            ks = 0; tdx = 0; tdy = 0; tapoff = 0;
+            a_lane = A_lds + (py * halo_w + px) * arow + hh * 16;
+            if (first) {  // very first chunk of the stream: registers -> LDS buffer 0, refill the even set
+                write_lds(wrA, 0);
+                issue_load(wrA);  // chunk 2
+                first = false;
             }
             __syncthreads();
+            new_stage = false;
         }
+        const int buf = (int)(gidx & 1);
+        const char* wb = W_lds + buf * WBUF + j * WROW + hh * 16;
+#pragma unroll
+        for (int q = 0; q < QPC; ++q) {
+            if (ck * QPC + q < st.nq) {
+                if (P.dbg & 1) {
+                } else if constexpr (MODE == 0) {
+                    // fp32: one b128 = 4 consecutive channels; lanes 0-31 take k = 8*ks + s, lanes 32-63 k = 8*ks + 4 + s
+                    f32x4 a4[MW];
+#pragma unroll
+                    for (int m = 0; m < MW; ++m)
+                        a4[m] = *reinterpret_cast<const f32x4*>(a_lane + m * 2 * halo_w * arow + tapoff + ks * 32);
+                    f32x4 b4[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        b4[g] = *reinterpret_cast<const f32x4*>(wb + g * 32 * WROW + q * 32);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int m = 0; m < MW; ++m)
+#pragma unroll
+                            for (int g = 0; g < NG; ++g)
+                                acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m][k], b4[g][k], acc[m][g], 0, 0, 0);
+                } else {
+                    // bf16x3: one b128 = 8 consecutive channels; lanes 0-31 take k = 16*ks + 0..7, lanes 32-63 + 8..15
+                    bf16x8 ah[MW], al[MW];
+#pragma unroll
+                    for (int m = 0; m < MW; ++m) {
+                        const char* ap = a_lane + m * 2 * halo_w * arow + tapoff + ks * 32;
+                        ah[m] = *reinterpret_cast<const bf16x8*>(ap);
+                        al[m] = *reinterpret_cast<const bf16x8*>(ap + st.cn * 2);
+                    }
+                    bf16x8 bh[NG], bl[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        bh[g] = *reinterpret_cast<const bf16x8*>(wb + g * 32 * WROW + q * 32);
+                        bl[g] = *reinterpret_cast<const bf16x8*>(wb + g * 32 * WROW + KC * 2 + q * 32);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MW; ++m) {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[g], acc[m][g], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[g], acc[m][g], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[g], acc[m][g], 0, 0, 0);
+                    }
+                }
+                if (++ks == ksn) {
+                    ks = 0;
+                    if (++tdx == P.kw) { tdx = 0; ++tdy; }
+                    tapoff = (tdy * halo_w + tdx) * arow;
+                }
+            }
+        }
+
+        // hand the next chunk to LDS (other buffer) and request the chunk after the one still in flight
+        const bool last_of_stage = (ck + 1 == stage_chunks(s));
+        const bool stream_has_next = !(last_of_stage && s + 1 >= P.nstage);
+        if (stream_has_next) {
+            if (buf == 0) { write_lds(wrB, 1); issue_load(wrB); }
+            else { write_lds(wrA, 0); issue_load(wrA); }
+        }
+        __syncthreads();
+        ++gidx;
+        if (last_of_stage) { ck = 0; ++s; new_stage = true; } else { ++ck; }
     }
 
-    TileCtx t{b, y0, x0, n_tile, wave, j, hh, P.H, P.W};
-    epi(acc, t);
+    if (P.dbg & 8) {  // ablation: keep the accumulators alive with one store instead of the epilogue
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(const_cast<float*>(P.wpk))[0] = acc[0][0][1];
+        return;
+    }
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        TileCtx t{b, y0, x0, n_tile, 2 * MW * wave + 2 * m, j, hh, P.H, P.W};
+        epi(acc[m], t);
+    }
 }
 
-template <class Epi, int MODE>
+template <class Epi, int MODE, int MW>
 static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tiles, hipStream_t s) {
     const size_t lds = (size_t)plan.a_bytes + 2 * (Epi::NG * 32 * (ModeTraits<MODE>::WROW_DATA + 16));
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<Epi, MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<Epi, MODE, MW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(plan.B * plan.tiles_x * plan.tiles_y, n_tiles);
-    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE>), grid, dim3(NTHREADS), lds, s, plan, epi);
+    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE, MW>), grid, dim3(NTHREADS), lds, s, plan, epi);
     return hipGetLastError();
 }
 
 template <class Epi>
-static hipError_t launch_conv(const ConvPlan& plan, const Epi& epi, int n_tiles, hipStream_t s) {
-    if (plan.prec == VPX_PREC_F32) return launch_conv_m<Epi, 0>(plan, epi, n_tiles, s);
-    if (plan.prec == VPX_PREC_BF16X3) return launch_conv_m<Epi, 1>(plan, epi, n_tiles, s);
+static hipError_t launch_conv(const ConvPlan& plan_in, const Epi& epi, int n_tiles, hipStream_t s) {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("VPX_DBG"); dbg = e ? atoi(e) : 0; }
+    ConvPlan plan = plan_in;
+    plan.dbg = dbg;
+    const int mw = plan.mw > 1 ? 2 : 1;
+    if ((plan.H + TILE_H * mw - 1) / (TILE_H * mw) != plan.tiles_y) return hipErrorInvalidValue;  // host geometry mismatch
+    if (plan.prec == VPX_PREC_F32) return launch_conv_m<Epi, 0, 1>(plan, epi, n_tiles, s);  // fp32 is MFMA-bound: MW=1 only
+    if (plan.prec == VPX_PREC_BF16X3)
+        return mw == 2 ? launch_conv_m<Epi, 1, 2>(plan, epi, n_tiles, s) : launch_conv_m<Epi, 1, 1>(plan, epi, n_tiles, s);
     return hipErrorInvalidValue;
 }
 
@@ -540,7 +600,18 @@ int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, in
 // Channels per activation stage: the smallest stage that still fits the stage table buys the most workgroups per CU
 // (LDS = halo tile + double-buffered weight chunk; 144 registers cap residency at 3 waves/SIMD). Measured on MI355X,
 // fp32, B=32: 64 ch -> 95 TF (1 WG/CU), 32 -> 118 TF (2), 16 -> 120-128 TF (3).  VPX_CS overrides for experiments.
-int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec) {
+int pick_mw(int B, int H, int W, int n_tiles, int prec) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("VPX_MW"); forced = e ? atoi(e) : 0; }
+    if (prec != VPX_PREC_BF16X3) return 1;
+    if (forced == 1 || forced == 2) return forced;
+    // Measured (MI355X, bf16x3, B=32): MW=2 is no faster than MW=1 on 64x64 maps (316 vs 314 TF) and slower on smaller
+    // maps (fewer workgroups) — the kernel is not LDS-read bound — so MW=2 stays an experiment switch (VPX_MW=2).
+    (void)B; (void)H; (void)W; (void)n_tiles;
+    return 1;
+}
+
+int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw) {
     static int forced = -1;
     if (forced < 0) {
         const char* e = getenv("VPX_CS");
@@ -549,22 +620,23 @@ int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int p
     }
     const int kstep = mode_kstep(prec);
     if (forced) return forced < kstep ? kstep : forced;
-    const int npos = (TILE_H + kh - 1) * (TILE_W + kw - 1);
+    const int npos = (TILE_H * mw + kh - 1) * (TILE_W + kw - 1);
     const int wbytes = 2 * ng * 32 * (mode_kc(prec) * 4 + 16);
+    const int wg_cap = mw == 2 ? 2 : 3;  // register-limited residency
     int best = CS_MAX, best_wg = 0;
     for (int cs = kstep; cs <= CS_MAX; cs *= 2) {
         int nst = 0;
         for (int s = 0; s < nseg; ++s) nst += ((segC[s] + kstep - 1) / kstep * kstep + cs - 1) / cs;
         if (nst > MAX_STAGE) continue;
         int wg = (160 * 1024) / (npos * (cs * 4 + 16) + wbytes);
-        if (wg > 3) wg = 3;
+        if (wg > wg_cap) wg = wg_cap;
         if (wg > best_wg || (wg == best_wg && cs > best)) { best = cs; best_wg = wg; }
     }
     return best;
 }
 
-int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw) {
-    const int npos = (TILE_H + kh - 1) * (TILE_W + kw - 1);
+int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw) {
+    const int npos = (TILE_H * mw + kh - 1) * (TILE_W + kw - 1);
     int m = 16;
     for (int i = 0; i < nstage; ++i) {
         const int bytes = npos * (st[i].cn * 4 + 16);

@@ -145,8 +145,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     for (int t = 0; t < T; ++t) {
         ConvPlan P{};
         P.B = B; P.H = H; P.W = Wd; P.kh = d->kh; P.kw = d->kw;
-        P.tiles_x = (Wd + TILE_W - 1) / TILE_W;
-        P.tiles_y = (H + TILE_H - 1) / TILE_H;
+        set_plan_tiles(P, L.mw);
         P.nseg = 2;
         P.seg[0] = ConvSeg{xn ? xn + (size_t)t * HW * Cin : nullptr, (long long)((size_t)T * HW * Cin), Cin, 0};
         const float* hprev = (t == 0) ? h0n : outn + (size_t)(t - 1) * HW * Ch;
@@ -158,7 +157,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             if (src) P.stage[P.nstage++] = L.stage[s];  // absent source == all-zero operand: its K range is skipped
         }
         P.chunks_total = L.chunks_total; P.prec = d->precision;
-        P.a_bytes = conv_a_bytes(L.stage, L.nstage, d->kh, d->kw);
+        P.a_bytes = conv_a_bytes(L.stage, L.nstage, d->kh, d->kw, L.mw);
         P.wpk = wpk;
 
         ConvLSTMStepArgs ea{};

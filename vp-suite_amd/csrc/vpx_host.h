@@ -63,6 +63,7 @@ static inline int check_convlstm_desc(const vpx_convlstm_desc* d) {
 
 struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     int taps, n_tiles, nstage, chunks_total;
+    int mw;                        // forward cell kernel: 32-pixel row tiles per wave
     ConvStage stage[MAX_STAGE];
     size_t n_state, n_x, n_out, n_peep;
     // backward
@@ -79,7 +80,8 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     L.taps = d->kh * d->kw;
     L.n_tiles = (d->Ch + 31) / 32;
     const int segC[2] = {d->Cin, d->Ch};
-    L.nstage = build_stages(L.stage, &L.chunks_total, segC, 2, L.taps, pick_stage_channels(segC, 2, d->kh, d->kw, 4, d->precision), d->precision);
+    L.mw = pick_mw(d->B, d->H, d->W, L.n_tiles, d->precision);
+    L.nstage = build_stages(L.stage, &L.chunks_total, segC, 2, L.taps, pick_stage_channels(segC, 2, d->kh, d->kw, 4, d->precision, L.mw), d->precision);
     if (L.nstage < 0) { set_error("convlstm: too many channel stages (Cin=%d Ch=%d)", d->Cin, d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
     L.n_x = (size_t)d->B * d->T * d->H * d->W * d->Cin;

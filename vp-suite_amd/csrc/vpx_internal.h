@@ -45,6 +45,8 @@ struct ConvPlan {
     int chunks_total;     // weight chunks per N-tile
     int a_bytes;          // LDS bytes reserved for the activation stage
     int prec;             // VPX_PREC_F32 | VPX_PREC_BF16X3: operand mode of the contraction
+    int mw;               // 32-pixel MFMA row tiles per wave (1: 8x16 workgroup tile, 2: 16x16); 0 is read as 1
+    int dbg;              // ablation bits for profiling (VPX_DBG): 1 skip MFMAs, 2 skip activation loads, 4 skip weight loads, 8 skip epilogue
     ConvSeg seg[MAX_SEG];
     ConvStage stage[MAX_STAGE];
     const float* wpk;     // packed weights [n_tiles][chunks_total][NG*32][KC]
@@ -74,8 +76,12 @@ struct PackDesc {
 
 void set_error(const char* fmt, ...);
 int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int prec);
-int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec);
-int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw);
+int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw = 1);
+int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw = 1);
+// rows per wave: 2 (16x16 workgroup tile) when the operand mode profits (bf16x3 is LDS/issue-bound, not MFMA-bound) and
+// the launch still has >= 2 workgroups per CU; else 1
+int pick_mw(int B, int H, int W, int n_tiles, int prec);
+inline void set_plan_tiles(ConvPlan& P, int mw) { P.mw = mw; P.tiles_x = (P.W + TILE_W - 1) / TILE_W; P.tiles_y = (P.H + TILE_H * mw - 1) / (TILE_H * mw); }
 size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng, int prec);
 
 hipError_t launch_pack_weights(const PackDesc& pd, float* dst, hipStream_t s);

@@ -241,9 +241,16 @@ class _STLSTMStepFn(torch.autograd.Function):
             d.flags |= _lib.FLAG_WEIGHTS_PACKED
         reserve = torch.empty(max(rs_bytes, 1), dtype=torch.uint8, device=dev)
         outs = [new_channels_last((B, Ch, H, Wd), dev) for _ in range(5)]
+        if PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         rc = L.vpx_stlstm_step_fwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), *[ptr(w) for w in W5], None,
                                    *[ptr(o) for o in outs], ptr(reserve), rs_bytes, ptr(ws), ws_bytes, _stream())
         check(rc, "vpx_stlstm_step_fwd")
+        if PROFILE is not None:
+            ev1.record()
+            fl, by = stlstm_algorithmic_work(B, Cin, Ch, H, Wd, k)
+            PROFILE.records.append((ev0, ev1, fl, by, 4, "stlstm_fwd"))
         if need_grad:
             ctx.save_for_backward(xs, hs, cs, ms, outs[1], outs[2], *W5, reserve)
             d.flags = flags
@@ -272,6 +279,14 @@ class _STLSTMStepFn(torch.autograd.Function):
                                    ptr(ws), ws_bytes, _stream())
         check(rc, "vpx_stlstm_step_bwd")
         return (dx, dh, dc, dm, *dWs, None, None, None)
+
+
+def stlstm_algorithmic_work(B, Cin, Ch, H, W, k, dt=4):
+    """flops = 2*[(7Ch*Cin + 9Ch^2)*k^2 + 2Ch^2]*H*W per sample; bytes = dt*H*W*(Cin + 3Ch + 5Ch) per
+    sample + the weights once per step."""
+    flops = 2.0 * ((7 * Ch * Cin + 9 * Ch * Ch) * k * k + 2 * Ch * Ch) * H * W * B
+    nbytes = dt * H * W * (Cin + 8 * Ch) * B + dt * ((7 * Ch * Cin + 9 * Ch * Ch) * k * k + 2 * Ch * Ch)
+    return flops, nbytes
 
 
 def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=None):
