@@ -48,27 +48,50 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with
+    tools/collect_profiles.sh on this exact workload); None when the run's configuration differs from the profiled one."""
+    if not (args.model == "convlstm-shi" and args.precision == "bf16x3" and args.batch == 32 and args.mode == "infer"
+            and args.img == 64 and args.channels == 1):
+        return None
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_bench_infer_b32_bf16x3.json"))
+    if not cands:
+        return None
+    with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
+        t = json.load(fh).get("hbm_traffic_bytes_per_launch")
+    return None if t is None else round(t["total"])
+
+
 def cpu_baseline(model, args):
     """Times the oracle's plain-PyTorch CPU restatement (oracle/torch_ref.py) of the same forward on the host cores.
     Bounded sample: batch 4 (BASELINE configs[0]) of the same 10->10 workload, repeated for ~cpu_seconds."""
     from oracle import torch_ref
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    cores = torch.get_num_threads()
+    all_cores = torch.get_num_threads()
     b = 4
     x = torch.rand(b, args.context, args.channels, args.img, args.img)
-    with torch.no_grad():
-        torch_ref.ef_convlstm_forward(sd, x, args.pred)  # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
-            torch_ref.ef_convlstm_forward(sd, x, args.pred)
-            n += 1
-            el = time.perf_counter() - t0
-            if el > args.cpu_seconds or n >= 50:
-                break
-    return {"value": round(n * b * args.pred / el, 2), "unit": "predicted frames/s", "cores": cores, "kind": "port",
+    best = None
+    # PyTorch's default (all host cores) over-subscribes this small problem; report the best of a short thread scan
+    for threads in sorted({all_cores, min(all_cores, 32), min(all_cores, 16)}, reverse=True):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            torch_ref.ef_convlstm_forward(sd, x, args.pred)  # warm-up
+            n, t0 = 0, time.perf_counter()
+            while True:
+                torch_ref.ef_convlstm_forward(sd, x, args.pred)
+                n += 1
+                el = time.perf_counter() - t0
+                if el > args.cpu_seconds / 3 or n >= 50:
+                    break
+        fps = n * b * args.pred / el
+        if best is None or fps > best[0]:
+            best = (fps, threads, n, el)
+    torch.set_num_threads(all_cores)
+    fps, threads, n, el = best
+    return {"value": round(fps, 2), "unit": "predicted frames/s", "cores": threads, "kind": "port",
             "sample": f"oracle/torch_ref.ef_convlstm_forward (PyTorch-CPU restatement of the reference path), "
                       f"batch {b}, {args.context}->{args.pred}, {args.channels}x{args.img}x{args.img}, "
-                      f"{n} iterations in {el:.1f} s"}
+                      f"{n} iterations in {el:.1f} s on {threads} of {all_cores} host threads (best of a 3-point scan)"}
 
 
 def main():
@@ -156,7 +179,8 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": {
                 "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach_tflops / peak, 4), "traffic": None,
+                "frac": round(ach_tflops / peak, 4), "traffic": measured_traffic(args),
+                "algorithmic_bytes_per_launch": round(ps["bytes"] / max(ps["launches"], 1)),
                 "kernel": (f"conv_gemm_kernel<EpiConvLSTM, {args.precision}> (fused ConvLSTM cell step)"
                            if args.model == "convlstm-shi" else
                            f"conv_gemm_kernel<EpiSTGate/EpiSTOut/EpiPlain, {args.precision}> (ST-LSTM cell step, 4 launches)"),

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): rocprofv3 evidence for the bench's dominant kernel. Outputs under gpurun_out/prof_final/.
+# Counters are collected in their own passes with --kernel-trace only (never with sys/hip tracing).
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_final
+rm -rf $OUT; mkdir -p $OUT
+python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline > /dev/null 2>&1   # MIOpen find-db warm-up outside the profiles
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_infer -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_infer.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python3 bench.py --mode train --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_train.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+# keep only the small summaries (kernel_trace.csv of the bench runs is large)
+find $OUT -name "*kernel_trace.csv" -path "*trace_*" -delete
+find $OUT -name "*agent_info.csv" -delete
+du -sh $OUT

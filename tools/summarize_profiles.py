@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_final/ (written by tools/collect_profiles.sh on the GPU box) into the small, tracked summaries
+under profiles/: per-kernel stats of the bench runs and per-launch PMC averages of the dominant kernel, including the
+HBM traffic figure bench.py reports as roofline.traffic (gfx950 correction: FETCH_SIZE counts 64 B per 128-B request of
+a wide coalesced read -> read bytes = 2 * FETCH_SIZE KiB; WRITE_SIZE is exact; MI355X_MICROARCH.md §HBM)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
+DST = os.path.join(ROOT, "profiles")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+DOMINANT = "EpiConvLSTM"
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(SRC, pattern))
+    return f[0] if f else None
+
+
+def pmc_means(d):
+    f = one(f"{d}/*/*counter_collection.csv")
+    agg = collections.defaultdict(list)
+    if f:
+        for r in csv.DictReader(open(f)):
+            if DOMINANT in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in agg.items()}
+
+
+os.makedirs(DST, exist_ok=True)
+for mode in ("infer", "train"):
+    f = one(f"trace_{mode}/*/*kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(DST, f"{ROUND}_bench_{mode}_b32_bf16x3_kernel_stats.csv"))
+    log = os.path.join(SRC, f"bench_{mode}.log")
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith("{")]
+        if lines:
+            open(os.path.join(DST, f"{ROUND}_bench_{mode}_b32_bf16x3_under_rocprof.json"), "w").write(lines[-1])
+
+counters = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    counters.update(pmc_means(d))
+summary = {"kernel": "conv_gemm_kernel<EpiConvLSTM, bf16x3> averaged over the launches of `bench.py --steps 3` "
+                     "(convlstm-shi, B=32, 6 block shapes)",
+           "command": "tools/collect_profiles.sh (rocprofv3 --pmc <counter> --kernel-trace, one pass per counter group)",
+           "counters": counters}
+if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+    rd = 2.0 * counters["FETCH_SIZE"]["mean_per_launch"] * 1024
+    wr = counters["WRITE_SIZE"]["mean_per_launch"] * 1024
+    summary["hbm_traffic_bytes_per_launch"] = {"read": rd, "write": wr, "total": rd + wr,
+                                               "note": "read = 2 * FETCH_SIZE KiB (gfx950 wide-read correction), write = WRITE_SIZE KiB"}
+if "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "GRBM_GUI_ACTIVE" in counters:
+    elapsed_simd_cycles = counters["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8 * 1024
+    summary["mfma_pipe_busy_frac"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / elapsed_simd_cycles
+json.dump(summary, open(os.path.join(DST, f"{ROUND}_pmc_bench_infer_b32_bf16x3.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1)[:1500])
