@@ -15,7 +15,7 @@
  *                                  ConvLSTM(ndrplz) per-layer time loop     vp_suite/model_blocks/conv_lstm_ndrplz.py:112-121
  * vpx_stlstm_step_fwd / _bwd       SpatioTemporalLSTMCell.forward           vp_suite/model_blocks/predrnn.py:57-83
  * vpx_decouple_fwd / _bwd          adapter + normalize + |cos| + mean       vp_suite/models/predrnn_v2.py:197-198,209-211
- * vpx_conv2d_nhwc_fwd              F.conv2d 1x1 / kxk "same", stride 1      vp_suite/models/predrnn_v2.py:223 (conv_last)
+ * vpx_conv2d_nhwc_fwd / _bwd       F.conv2d 1x1 / kxk "same", stride 1      vp_suite/models/predrnn_v2.py:223 (conv_last)
  * vpx_nchw_to_nhwc / nhwc_to_nchw  (layout adaptors at the boundary; the reference is NCHW throughout)
  *
  * Layouts. VPX_LAYOUT_NHWC ("channels last", the library's native layout):
@@ -108,7 +108,7 @@ int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, const float* h
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- decoupling-loss term: mean_{b,ch} |cos(normalize(A*dc), normalize(A*dm))| over H*W ---------------------- */
-/* delta_c/delta_m [B,H,W,Ch] (NHWC) ; adapter [Ch,Ch] ; value: 1 float on device ; workspace >= 2*B*H*W*Ch*4 + 4*B*Ch*4 */
+/* delta_c/delta_m [B,H,W,Ch] (NHWC) ; adapter [Ch,Ch] ; value / dvalue: 1 float on device */
 size_t vpx_decouple_workspace_bytes(int B, int Ch, int H, int W);
 int vpx_decouple_fwd(const float* delta_c, const float* delta_m, const float* adapter, float* value, int B, int Ch,
                      int H, int W, void* workspace, size_t workspace_bytes, void* stream);
@@ -120,6 +120,12 @@ int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* ad
 size_t vpx_conv2d_workspace_bytes(int Ci, int Co, int kh, int kw);
 int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Ci,
                         int Co, int kh, int kw, int precision, void* workspace, size_t workspace_bytes, void* stream);
+
+/* backward of the same convolution: dx [N,H,W,Ci], dw [Co,Ci,kh,kw], db [Co]; each may be NULL (skipped), all OVERWRITTEN */
+size_t vpx_conv2d_bwd_workspace_bytes(int N, int H, int W, int Ci, int Co, int kh, int kw);
+int vpx_conv2d_nhwc_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int N, int H,
+                        int W, int Ci, int Co, int kh, int kw, int precision, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* ---- layout adaptors: src [N,C,H,W] <-> dst [N,H,W,C] -------------------------------------------------------- */
 int vpx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, void* stream);

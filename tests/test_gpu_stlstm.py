@@ -147,3 +147,31 @@ def test_predrnn_full_size_vs_golden(vpx):
         pred, ml = m(frames.cuda(), pred_frames=10)
     assert _relmax(pred[:, :, :, ::4, ::4], g["pred_slice"]) < 1e-4
     assert abs(float(ml["ST-LSTM decouple loss"]) - float(g["decouple"])) < 1e-3 * abs(float(g["decouple"]))
+
+
+def test_decouple_and_conv2d_vs_golden_and_autograd(vpx):
+    """K4 (vpx_decouple_fwd/_bwd) against the reference-generated pin; K5-style conv2d fwd/bwd against torch autograd."""
+    from golden_util import seeded_randn
+    g = load_golden("decouple_tiny")
+    B, Ch, H, W = [int(v) for v in g["shape"]]
+    A = seeded_randn((Ch, Ch, 1, 1), name_seed("decouple.adapter"), 1.0 / np.sqrt(Ch)).cuda().requires_grad_(True)
+    dc = seeded_randn((B, Ch, H, W), name_seed("decouple.dc")).cuda().requires_grad_(True)
+    dm = seeded_randn((B, Ch, H, W), name_seed("decouple.dm")).cuda().requires_grad_(True)
+    v = vpx.ops.decouple_term(dc, dm, A)
+    assert abs(float(v) - float(g["value"])) < 1e-6
+    v.backward()
+    assert _relmax(dc.grad, g["d_dc"]) < GRTOL and _relmax(dm.grad, g["d_dm"]) < GRTOL
+    assert _relmax(A.grad, g["d_adapter"]) < GRTOL
+    for prec, tol in (("f32", 2e-5), ("bf16x3", 1e-4)):
+        for (Ci, Co, k, Hh, Ww) in [(128, 16, 1, 16, 16), (24, 40, 3, 9, 21)]:
+            x = seeded_randn((3, Ci, Hh, Ww), name_seed(f"c2g.x{Ci}{k}"))
+            w = seeded_randn((Co, Ci, k, k), name_seed(f"c2g.w{Ci}{k}"), 1.0 / np.sqrt(Ci * k * k))
+            b = seeded_randn((Co,), name_seed(f"c2g.b{Ci}{k}"), 0.1)
+            gy = seeded_randn((3, Co, Hh, Ww), name_seed(f"c2g.g{Ci}{k}"))
+            ref = [t.clone().requires_grad_(True) for t in (x, w, b)]
+            (torch.nn.functional.conv2d(ref[0], ref[1], ref[2], padding=k // 2) * gy).sum().backward()
+            mine = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+            y = vpx.ops.conv2d_same(mine[0], mine[1], mine[2], precision=prec)
+            (y * gy.cuda()).sum().backward()
+            for a, r in zip(mine, ref):
+                assert _relmax(a.grad, r.grad) < tol, (prec, Ci, k)

@@ -21,7 +21,8 @@ EXPORTED_SYMBOLS = [
     "vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes", "vpx_convlstm_seq_fwd", "vpx_convlstm_seq_bwd",
     "vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes", "vpx_stlstm_step_fwd", "vpx_stlstm_step_bwd",
     "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
-    "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
+    "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_conv2d_bwd_workspace_bytes", "vpx_conv2d_nhwc_bwd",
+    "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
 ]
 
 
@@ -88,6 +89,10 @@ def lib():
         L.vpx_conv2d_workspace_bytes.argtypes = [ctypes.c_int] * 4
         L.vpx_conv2d_nhwc_fwd.restype = ctypes.c_int
         L.vpx_conv2d_nhwc_fwd.argtypes = [vp] * 4 + [ctypes.c_int] * 8 + [vp, sz, vp]
+        L.vpx_conv2d_bwd_workspace_bytes.restype = sz
+        L.vpx_conv2d_bwd_workspace_bytes.argtypes = [ctypes.c_int] * 7
+        L.vpx_conv2d_nhwc_bwd.restype = ctypes.c_int
+        L.vpx_conv2d_nhwc_bwd.argtypes = [vp] * 6 + [ctypes.c_int] * 8 + [vp, sz, vp]
         for name in ("vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw"):
             getattr(L, name).restype = ctypes.c_int
             getattr(L, name).argtypes = [vp, vp] + [ctypes.c_int] * 4 + [vp]

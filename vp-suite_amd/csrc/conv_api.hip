@@ -1,0 +1,185 @@
+// conv_api.hip — plain NHWC stride-1 "same" convolution backward and the decoupling-loss tail, built from the same
+// implicit-GEMM / weight-gradient kernels as the recurrent cells.
+//   vpx_conv2d_nhwc_bwd   dx = conv^T(dy, w) (transposed + tap-flipped packing), dw = wgrad(dy, x), db = colsum(dy)
+//   vpx_decouple_fwd/_bwd adapter 1x1 conv on delta_c / delta_m, per-(b, channel) cosine over H*W, |.|, mean
+//                         (vp_suite/models/predrnn_v2.py:197-198, 209-211)
+#include "vpx_host.h"
+
+using namespace vpx;
+
+namespace {
+
+struct ConvGeo { int N, H, W; };
+
+// y (+)= conv(src; w) with Co outputs; `transposed`: contraction over w's O axis (data gradient). Returns packed floats used.
+int plain_conv(hipStream_t stream, int prec, ConvGeo g, const float* src, int C, int ld, const float* w, long long ld_o,
+               int ld_i, int kh, int kw, int Co, bool transposed, const float* bias, float* out, int out_ld,
+               bool accumulate, float* wpk) {
+    ConvPlan P{};
+    int chunks = 0;
+    const int segC[1] = {C};
+    P.prec = prec;
+    P.nstage = build_stages(P.stage, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, plain_groups(Co), prec), prec);
+    if (P.nstage < 0) { set_error("conv: too many channel stages (C=%d)", C); return VPX_ERR_UNSUPPORTED; }
+    PackDesc pd{};
+    pd.seg[0] = PackSeg{w, ld_o, ld_i, 0, C};
+    memcpy(pd.stage, P.stage, sizeof(ConvStage) * P.nstage);
+    pd.nstage = P.nstage; pd.chunks_total = chunks; pd.prec = prec; pd.taps = kh * kw;
+    fill_plain_pack(pd, Co, 0);
+    pd.transposed = transposed ? 1 : 0; pd.flip = transposed ? 1 : 0;
+    VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+    P.B = g.N; P.H = g.H; P.W = g.W; P.kh = kh; P.kw = kw;
+    set_plan_tiles(P, 1);
+    P.nseg = 1;
+    P.seg[0] = ConvSeg{src, (long long)g.H * g.W * ld, C, ld};
+    P.chunks_total = chunks;
+    P.a_bytes = conv_a_bytes(P.stage, P.nstage, kh, kw);
+    P.wpk = wpk;
+    PlainEpiArgs ea{};
+    ea.bias = bias; ea.Co = Co; ea.split = Co; ea.ng = plain_groups(Co);
+    ea.out0 = out; ea.bstride0 = (long long)g.H * g.W * out_ld; ea.ld0 = out_ld;
+    ea.accumulate = accumulate ? 1 : 0;
+    VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, pd.n_tiles, stream));
+    return VPX_OK;
+}
+
+size_t plain_conv_wpk_floats(int C, int Co, int kh, int kw) {
+    size_t best = 0;
+    ConvStage st[MAX_STAGE];
+    for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16X3; ++prec) {
+        int chunks = 0;
+        const int segC[1] = {C};
+        if (build_stages(st, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, plain_groups(Co), prec), prec) < 0) return 0;
+        const size_t b = packed_weight_bytes(plain_tiles(Co), chunks, plain_groups(Co), prec) / 4;
+        if (b > best) best = b;
+    }
+    return best;
+}
+
+int wgrad_slices(int N, int H, int W) {
+    const long long items = (long long)N * ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+    return (int)(items < 32 ? items : 32);
+}
+
+// dw[Co, C, kh, kw] (+)= wgrad(dy [N,HW,Co], x [N,HW,C])
+int plain_wgrad(hipStream_t stream, int prec, ConvGeo g, const float* dy, int Co, const float* x, int C, int kh, int kw,
+                float* slabs, float* dw) {
+    WgradArgs wa{};
+    wa.T = 1; wa.B = g.N; wa.H = g.H; wa.W = g.W; wa.HW = g.H * g.W; wa.kh = kh; wa.kw = kw;
+    wa.tiles_x = (g.W + TILE_W - 1) / TILE_W; wa.tiles_y = (g.H + TILE_H - 1) / TILE_H;
+    wa.N4 = Co; wa.Cin = C; wa.Ch = 1; wa.Ct = C; wa.ldG = Co; wa.n_out = Co; wa.prec = prec;
+    wa.dG = dy; wa.x = x; wa.x_bstride = (long long)wa.HW * C;
+    wa.n_ctiles = 0;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        if (wa.n_ctiles >= 16) { set_error("conv wgrad: too many input channels (%d)", C); return VPX_ERR_UNSUPPORTED; }
+        wa.ct[wa.n_ctiles++] = WgradCTile{0, c0, (C - c0 < 64) ? C - c0 : 64, c0};
+    }
+    wa.slabs = slabs;
+    const int ns = wgrad_slices(g.N, g.H, g.W);
+    VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, (size_t)ns * kh * kw * Co * C * sizeof(float), stream));
+    VPX_CHECK_HIP(launch_wgrad(wa, ns, stream));
+    VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dw, ns, kh * kw, Co, C, stream));
+    return VPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vpx_conv2d_bwd_workspace_bytes(int N, int H, int W, int Ci, int Co, int kh, int kw) {
+    if (N < 1 || H < 1 || W < 1 || Ci < 1 || Co < 1) return 0;
+    return align256(plain_conv_wpk_floats(Co, Ci, kh, kw) * 4) +
+           align256((size_t)wgrad_slices(N, H, W) * kh * kw * Co * Ci * 4) + 512;
+}
+
+int vpx_conv2d_nhwc_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int N, int H,
+                        int W, int Ci, int Co, int kh, int kw, int precision, void* workspace, size_t workspace_bytes,
+                        void* stream_) {
+    if (!x || !w || !dy || N < 1 || H < 1 || W < 1 || Ci < 1 || Co < 1 || !(kh & 1) || !(kw & 1) || kh > 7 || kw > 7) {
+        set_error("vpx_conv2d_nhwc_bwd: bad argument");
+        return VPX_ERR_ARG;
+    }
+    if (precision != VPX_PREC_F32 && precision != VPX_PREC_BF16X3) { set_error("vpx_conv2d_nhwc_bwd: precision %d not implemented", precision); return VPX_ERR_UNSUPPORTED; }
+    if (!workspace || workspace_bytes < vpx_conv2d_bwd_workspace_bytes(N, H, W, Ci, Co, kh, kw)) { set_error("vpx_conv2d_nhwc_bwd: workspace too small"); return VPX_ERR_WORKSPACE; }
+    hipStream_t stream = (hipStream_t)stream_;
+    Carver ws{(char*)workspace, 0, workspace_bytes};
+    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    float* wpk = ws.take(plain_conv_wpk_floats(Co, Ci, kh, kw));
+    float* slabs = ws.take((size_t)wgrad_slices(N, H, W) * kh * kw * Co * Ci);
+    const ConvGeo g{N, H, W};
+    int rc;
+    if (dx && (rc = plain_conv(stream, precision, g, dy, Co, Co, w, (long long)Ci * kh * kw, kh * kw, kh, kw, Ci, true,
+                               nullptr, dx, Ci, false, wpk))) return rc;
+    if (dw && (rc = plain_wgrad(stream, precision, g, dy, Co, x, Ci, kh, kw, slabs, dw))) return rc;
+    if (db) {
+        VPX_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)Co * sizeof(float), stream));
+        VPX_CHECK_HIP(launch_colsum(dy, db, (long long)N * H * W, Co, stream));
+    }
+    return VPX_OK;
+}
+
+/* ---- decoupling-loss tail ---------------------------------------------------------------------------------- */
+size_t vpx_decouple_workspace_bytes(int B, int Ch, int H, int W) {
+    if (B < 1 || Ch < 1 || H < 1 || W < 1) return 0;
+    const size_t n = (size_t)B * H * W * Ch;
+    return 4 * align256(n * 4) + align256((size_t)B * Ch * 4 * 4) + align256(plain_conv_wpk_floats(Ch, Ch, 1, 1) * 4) +
+           align256((size_t)wgrad_slices(B, H, W) * Ch * Ch * 4) + align256((size_t)Ch * Ch * 4) + 1024;
+}
+
+int vpx_decouple_fwd(const float* delta_c, const float* delta_m, const float* adapter, float* value, int B, int Ch,
+                     int H, int W, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!delta_c || !delta_m || !adapter || !value || B < 1 || Ch < 1 || H < 1 || W < 1) { set_error("vpx_decouple_fwd: bad argument"); return VPX_ERR_ARG; }
+    if (!workspace || workspace_bytes < vpx_decouple_workspace_bytes(B, Ch, H, W)) { set_error("vpx_decouple_fwd: workspace too small"); return VPX_ERR_WORKSPACE; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t n = (size_t)B * H * W * Ch;
+    Carver ws{(char*)workspace, 0, workspace_bytes};
+    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    float* yc = ws.take(n);
+    float* ym = ws.take(n);
+    ws.take(n); ws.take(n);  // (backward's dYc / dYm slots)
+    float* stats = ws.take((size_t)B * Ch * 4);
+    float* wpk = ws.take(plain_conv_wpk_floats(Ch, Ch, 1, 1));
+    const ConvGeo g{B, H, W};
+    int rc;  // exact fp32 for this tiny tail: it feeds a loss value directly
+    if ((rc = plain_conv(stream, VPX_PREC_F32, g, delta_c, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, false, nullptr, yc, Ch, false, wpk))) return rc;
+    if ((rc = plain_conv(stream, VPX_PREC_F32, g, delta_m, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, false, nullptr, ym, Ch, false, wpk))) return rc;
+    VPX_CHECK_HIP(launch_decouple_stats(yc, ym, stats, B, H * W, Ch, stream));
+    VPX_CHECK_HIP(launch_decouple_mean(stats, value, B * Ch, stream));
+    return VPX_OK;
+}
+
+int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* adapter, const float* dvalue,
+                     float* d_delta_c, float* d_delta_m, float* d_adapter, int B, int Ch, int H, int W,
+                     void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!delta_c || !delta_m || !adapter || !dvalue || B < 1 || Ch < 1 || H < 1 || W < 1) { set_error("vpx_decouple_bwd: bad argument"); return VPX_ERR_ARG; }
+    if (!workspace || workspace_bytes < vpx_decouple_workspace_bytes(B, Ch, H, W)) { set_error("vpx_decouple_bwd: workspace too small"); return VPX_ERR_WORKSPACE; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t n = (size_t)B * H * W * Ch;
+    Carver ws{(char*)workspace, 0, workspace_bytes};
+    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    float* yc = ws.take(n);
+    float* ym = ws.take(n);
+    float* dyc = ws.take(n);
+    float* dym = ws.take(n);
+    float* stats = ws.take((size_t)B * Ch * 4);
+    float* wpk = ws.take(plain_conv_wpk_floats(Ch, Ch, 1, 1));
+    float* slabs = ws.take((size_t)wgrad_slices(B, H, W) * Ch * Ch);
+    float* dA2 = ws.take((size_t)Ch * Ch);
+    const ConvGeo g{B, H, W};
+    int rc;
+    // recompute the adapter outputs (cheaper than keeping them alive between forward and backward)
+    if ((rc = plain_conv(stream, VPX_PREC_F32, g, delta_c, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, false, nullptr, yc, Ch, false, wpk))) return rc;
+    if ((rc = plain_conv(stream, VPX_PREC_F32, g, delta_m, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, false, nullptr, ym, Ch, false, wpk))) return rc;
+    VPX_CHECK_HIP(launch_decouple_stats(yc, ym, stats, B, H * W, Ch, stream));
+    VPX_CHECK_HIP(launch_decouple_bwd_pointwise(yc, ym, stats, dvalue, dyc, dym, B, H * W, Ch, stream));
+    if (d_delta_c && (rc = plain_conv(stream, VPX_PREC_F32, g, dyc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_c, Ch, false, wpk))) return rc;
+    if (d_delta_m && (rc = plain_conv(stream, VPX_PREC_F32, g, dym, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_m, Ch, false, wpk))) return rc;
+    if (d_adapter) {
+        if ((rc = plain_wgrad(stream, VPX_PREC_F32, g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter))) return rc;
+        if ((rc = plain_wgrad(stream, VPX_PREC_F32, g, dym, Ch, delta_m, Ch, 1, 1, slabs, dA2))) return rc;
+        VPX_CHECK_HIP(launch_axpy(d_adapter, dA2, (long long)Ch * Ch, stream));
+    }
+    return VPX_OK;
+}
+
+}  // extern "C"

@@ -37,4 +37,90 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H
     return launch_transpose(src, dst, N, H * W, C, s);  // [N][HW][C] -> [N][C][HW]
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// decoupling-loss tail. F.normalize(dim=2, eps=1e-12) then cosine_similarity(dim=2, eps=1e-8), abs, mean.
+// One thread per (b, co) walks the H*W axis (channels are contiguous -> coalesced across the wave).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void decouple_stats_kernel(const float* __restrict__ yc, const float* __restrict__ ym,
+                                      float* __restrict__ stats, int B, int HW, int Ch) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * Ch) return;
+    const int b = idx / Ch, co = idx - b * Ch;
+    const float* pc = yc + (size_t)b * HW * Ch + co;
+    const float* pm = ym + (size_t)b * HW * Ch + co;
+    float scc = 0.f, smm = 0.f, scm = 0.f;
+    for (int p = 0; p < HW; ++p) {
+        const float a = pc[(size_t)p * Ch], m = pm[(size_t)p * Ch];
+        scc += a * a; smm += m * m; scm += a * m;
+    }
+    const float nc = fmaxf(sqrtf(scc), 1e-12f), nm = fmaxf(sqrtf(smm), 1e-12f);
+    // after normalisation |u| = sqrt(scc)/nc, |v| = sqrt(smm)/nm (1 unless degenerate); cos = u.v / max(|u||v|, 1e-8)
+    const float un = sqrtf(scc) / nc, vn = sqrtf(smm) / nm;
+    const float c = (scm / (nc * nm)) / fmaxf(un * vn, 1e-8f);
+    float* st = stats + (size_t)idx * 4;
+    st[0] = scc; st[1] = smm; st[2] = scm; st[3] = fabsf(c);
+}
+
+__global__ void decouple_mean_kernel(const float* __restrict__ stats, float* __restrict__ value, int n) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += stats[(size_t)i * 4 + 3];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *value = red[0] / (float)n;
+}
+
+// d|cos|/dY for the non-degenerate case (norms above the eps clamps; the clamps have zero gradient otherwise)
+__global__ void decouple_bwd_pointwise_kernel(const float* __restrict__ yc, const float* __restrict__ ym,
+                                              const float* __restrict__ stats, const float* __restrict__ dvalue,
+                                              float* __restrict__ dyc, float* __restrict__ dym, int B, int HW, int Ch) {
+    const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long n = (long long)B * HW * Ch;
+    if (e >= n) return;
+    const int co = (int)(e % Ch);
+    const int b = (int)(e / ((long long)HW * Ch));
+    const float* st = stats + ((size_t)b * Ch + co) * 4;
+    const float scc = st[0], smm = st[1], scm = st[2];
+    const float nc = sqrtf(scc), nm = sqrtf(smm);
+    float gc = 0.f, gm = 0.f;
+    if (nc > 1e-12f && nm > 1e-12f) {
+        const float c = scm / (nc * nm);
+        const float g = (c > 0.f ? 1.f : (c < 0.f ? -1.f : 0.f)) * dvalue[0] / (float)(B * Ch);
+        const float a = yc[e], m = ym[e];
+        gc = g * (m / (nc * nm) - c * a / scc);
+        gm = g * (a / (nc * nm) - c * m / smm);
+    }
+    dyc[e] = gc;
+    dym[e] = gm;
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long long n) {
+    const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (e < n) y[e] += x[e];
+}
+
+hipError_t launch_decouple_stats(const float* yc, const float* ym, float* stats, int B, int HW, int Ch, hipStream_t s) {
+    hipLaunchKernelGGL(decouple_stats_kernel, dim3((B * Ch + 63) / 64), dim3(64), 0, s, yc, ym, stats, B, HW, Ch);
+    return hipGetLastError();
+}
+hipError_t launch_decouple_mean(const float* stats, float* value, int n, hipStream_t s) {
+    hipLaunchKernelGGL(decouple_mean_kernel, dim3(1), dim3(256), 0, s, stats, value, n);
+    return hipGetLastError();
+}
+hipError_t launch_decouple_bwd_pointwise(const float* yc, const float* ym, const float* stats, const float* dvalue,
+                                         float* dyc, float* dym, int B, int HW, int Ch, hipStream_t s) {
+    const long long n = (long long)B * HW * Ch;
+    hipLaunchKernelGGL(decouple_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, yc, ym, stats,
+                       dvalue, dyc, dym, B, HW, Ch);
+    return hipGetLastError();
+}
+hipError_t launch_axpy(float* y, const float* x, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, x, n);
+    return hipGetLastError();
+}
+
 }  // namespace vpx

@@ -204,6 +204,14 @@ struct STBwdGateArgs {        // stage B: through the two gate groups
 hipError_t launch_st_bwd_out(const STBwdOutArgs& a, hipStream_t s);
 hipError_t launch_st_bwd_gates(const STBwdGateArgs& a, hipStream_t s);
 
+// ---- decoupling-loss tail (predrnn_v2.py:197-198, 209-211) pointwise/reduction stages ----
+// stats[b, co] = (s_cc, s_mm, s_cm, |cos|) over the H*W axis of Yc = A*delta_c, Ym = A*delta_m (NHWC [B,HW,Ch])
+hipError_t launch_decouple_stats(const float* yc, const float* ym, float* stats, int B, int HW, int Ch, hipStream_t s);
+hipError_t launch_decouple_mean(const float* stats, float* value, int n, hipStream_t s);
+hipError_t launch_decouple_bwd_pointwise(const float* yc, const float* ym, const float* stats, const float* dvalue,
+                                         float* dyc, float* dym, int B, int HW, int Ch, hipStream_t s);
+hipError_t launch_axpy(float* y, const float* x, long long n, hipStream_t s);  // y += x
+
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
 

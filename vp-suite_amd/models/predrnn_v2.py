@@ -4,8 +4,8 @@ Hyper-parameter names/defaults, state_dict keys (`cell_list.{l}.conv_{x,h,m,o}.0
 `cell_list.{l}.conv_last.weight`, `conv_last.weight`, `adapter.weight`), the forward contract
 `forward(x[b,T_total,c,h,w], pred_frames, train=...) -> (pred[b,p,c,h,w], {"ST-LSTM decouple loss": scalar})`,
 scheduled-sampling schedules and the custom train_iter (forward + reversed forward, averaged) follow the reference.
-Every ST-LSTM cell step runs in libvpx_hip (4 fused launches); patchify is a pure permutation, the decoupling-loss tail
-and the 1x1 frame head stay on stock GPU ops this round.
+Every ST-LSTM cell step (4 fused launches), the decoupling-loss tail (K4) and the 1x1 frame head (K5) run in
+libvpx_hip; patchify is a pure permutation and the input blend one elementwise expression.
 The action-conditional variant is outside the hot-path scope (no action dataset in the BASELINE configs)."""
 import math
 
@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..base import VPModel, _progress
 from ..model_blocks import SpatioTemporalLSTMCell as STCell
 
@@ -78,10 +79,8 @@ class PredRNN_V2(VPModel):
         return self(x, pred_frames=1, **kwargs)[0].squeeze(dim=1)
 
     def _decouple_term(self, delta_c, delta_m):
-        b, ch = delta_c.shape[:2]
-        a = F.normalize(self.adapter(delta_c).reshape(b, ch, -1), dim=2)
-        m = F.normalize(self.adapter(delta_m).reshape(b, ch, -1), dim=2)
-        return torch.mean(torch.abs(torch.cosine_similarity(a, m, dim=2)))
+        # adapter 1x1 conv + normalize + |cosine| + mean, fused in libvpx_hip (vpx_decouple_fwd/_bwd)
+        return ops.decouple_term(delta_c, delta_m, self.adapter.weight)
 
     def forward(self, x, pred_frames: int = 1, **kwargs):
         b, total_frames = x.shape[:2]
@@ -110,7 +109,7 @@ class PredRNN_V2(VPModel):
                 inp = net if i == 0 else h_t[i - 1]
                 h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory)
                 decouple.append(self._decouple_term(d_c, d_m))
-            x_gen = self.conv_last(h_t[self.num_layers - 1])
+            x_gen = ops.conv2d_same(h_t[self.num_layers - 1], self.conv_last.weight, None, self.cell_precision)
             next_frames.append(x_gen)
         pred = self._reshape_patch_back(torch.stack(next_frames[-pred_frames:], dim=1))
         loss = torch.mean(torch.stack(decouple, dim=0))

@@ -178,21 +178,96 @@ def convlstm_seq(x, h0, c0, W, b, Wci=None, Wcf=None, Wco=None, *, seq_len, in_c
                                 int(in_channels), need_grad)
 
 
+class _Conv2dSameFn(torch.autograd.Function):
+    """Stride-1 'same' convolution through the library's implicit-GEMM kernel, with explicit backward
+    (data gradient = same kernel with transposed/flipped packing, weight gradient = MFMA wgrad kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, precision):
+        _require_gpu(x, "conv2d_same")
+        xs = to_channels_last(x)
+        N, Ci, H, Wd = xs.shape
+        Co, ci_w, kh, kw = w.shape
+        if ci_w != Ci:
+            raise ValueError(f"conv2d_same: weight expects {ci_w} input channels, input has {Ci}")
+        wc = w.contiguous()
+        bc = None if bias is None else bias.contiguous()
+        L = _lib.lib()
+        ws_bytes = L.vpx_conv2d_workspace_bytes(Ci, Co, kh, kw)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        y = new_channels_last((N, Co, H, Wd), x.device)
+        rc = L.vpx_conv2d_nhwc_fwd(ptr(xs), ptr(wc), ptr(bc), ptr(y), N, H, Wd, Ci, Co, kh, kw, precision, ptr(ws),
+                                   ws_bytes, _stream())
+        check(rc, "vpx_conv2d_nhwc_fwd")
+        ctx.save_for_backward(xs, wc)
+        ctx.has_bias = bias is not None
+        ctx.precision = precision
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, wc = ctx.saved_tensors
+        N, Ci, H, Wd = xs.shape
+        Co, _, kh, kw = wc.shape
+        dys = to_channels_last(dy)
+        needs = ctx.needs_input_grad
+        dx = new_channels_last((N, Ci, H, Wd), xs.device) if needs[0] else None
+        dw = torch.empty_like(wc) if needs[1] else None
+        db = torch.empty(Co, device=xs.device) if (ctx.has_bias and needs[2]) else None
+        L = _lib.lib()
+        ws_bytes = L.vpx_conv2d_bwd_workspace_bytes(N, H, Wd, Ci, Co, kh, kw)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xs.device)
+        rc = L.vpx_conv2d_nhwc_bwd(ptr(xs), ptr(wc), ptr(dys), ptr(dx), ptr(dw), ptr(db), N, H, Wd, Ci, Co, kh, kw,
+                                   ctx.precision, ptr(ws), ws_bytes, _stream())
+        check(rc, "vpx_conv2d_nhwc_bwd")
+        return dx, dw, db, None
+
+
 def conv2d_same(x, w, bias=None, precision="f32"):
-    """Stride-1 'same' convolution on a channels-last [N,C,H,W] tensor through the library's implicit-GEMM kernel
-    (inference only; used for PredRNN's 1x1 frame head, predrnn_v2.py:223)."""
-    _require_gpu(x, "conv2d_same")
-    x = to_channels_last(x)
-    N, Ci, H, Wd = x.shape
-    Co, _, kh, kw = w.shape
-    L = _lib.lib()
-    ws_bytes = L.vpx_conv2d_workspace_bytes(Ci, Co, kh, kw)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-    y = new_channels_last((N, Co, H, Wd), x.device)
-    rc = L.vpx_conv2d_nhwc_fwd(ptr(x), ptr(w.contiguous()), ptr(None if bias is None else bias.contiguous()), ptr(y),
-                               N, H, Wd, Ci, Co, kh, kw, PRECISIONS[precision], ptr(ws), ws_bytes, _stream())
-    check(rc, "vpx_conv2d_nhwc_fwd")
-    return y
+    """y = conv2d(x, w, bias, stride=1, padding=k//2) on a [N,C,H,W] tensor (PredRNN's 1x1 frame head,
+    predrnn_v2.py:223, and any other stride-1 'same' convolution); differentiable."""
+    return _Conv2dSameFn.apply(x, w, bias, PRECISIONS[precision])
+
+
+class _DecoupleFn(torch.autograd.Function):
+    """mean_{b,ch} |cos(normalize(A*delta_c), normalize(A*delta_m))| over H*W  (predrnn_v2.py:197-198, 209-211)."""
+
+    @staticmethod
+    def forward(ctx, delta_c, delta_m, adapter_w):
+        _require_gpu(delta_c, "decouple_term")
+        dc, dm = to_channels_last(delta_c), to_channels_last(delta_m)
+        B, Ch, H, Wd = dc.shape
+        A = adapter_w.reshape(Ch, Ch).contiguous()
+        L = _lib.lib()
+        ws_bytes = L.vpx_decouple_workspace_bytes(B, Ch, H, Wd)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dc.device)
+        value = torch.empty((), device=dc.device)
+        rc = L.vpx_decouple_fwd(ptr(dc), ptr(dm), ptr(A), ptr(value), B, Ch, H, Wd, ptr(ws), ws_bytes, _stream())
+        check(rc, "vpx_decouple_fwd")
+        ctx.save_for_backward(dc, dm, A)
+        ctx.wshape = tuple(adapter_w.shape)
+        return value
+
+    @staticmethod
+    def backward(ctx, dvalue):
+        dc, dm, A = ctx.saved_tensors
+        B, Ch, H, Wd = dc.shape
+        needs = ctx.needs_input_grad
+        g_dc = new_channels_last((B, Ch, H, Wd), dc.device) if needs[0] else None
+        g_dm = new_channels_last((B, Ch, H, Wd), dc.device) if needs[1] else None
+        g_A = torch.empty_like(A) if needs[2] else None
+        L = _lib.lib()
+        ws_bytes = L.vpx_decouple_workspace_bytes(B, Ch, H, Wd)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dc.device)
+        dv = dvalue.contiguous().reshape(1)
+        rc = L.vpx_decouple_bwd(ptr(dc), ptr(dm), ptr(A), ptr(dv), ptr(g_dc), ptr(g_dm), ptr(g_A), B, Ch, H, Wd,
+                                ptr(ws), ws_bytes, _stream())
+        check(rc, "vpx_decouple_bwd")
+        return g_dc, g_dm, (None if g_A is None else g_A.reshape(ctx.wshape))
+
+
+def decouple_term(delta_c, delta_m, adapter_w):
+    return _DecoupleFn.apply(delta_c, delta_m, adapter_w)
 
 
 class STWorkspace:
