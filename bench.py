@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer")
     ap.add_argument("--model", choices=["convlstm-shi", "predrnn-pp"], default="convlstm-shi",
                     help="convlstm-shi = BASELINE configs[1] (the bench line); predrnn-pp = configs[2] (secondary workload)")
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3",
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
                     help="operand mode of the fused cell kernels: f32 = exact fp32 MFMA; bf16x3 = split-bf16 operands, "
                          "3 bf16 MFMAs per product, fp32 accumulate (fp32-level accuracy, parity-tested at 1e-4)")
     ap.add_argument("--img", type=int, default=64)

@@ -1,0 +1,128 @@
+"""Further GPU parity cases: the ndrplz multi-layer sequence block (a4), the ST-LSTM C ABI on reference-layout (NCHW)
+buffers, the BASELINE C4 / C5 shapes (128x128x3), the plain-bf16 operand mode with its own stated tolerance."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from golden_util import fill_state_dict_, load_golden, name_seed, seeded_rand, seeded_randn
+
+pytestmark = pytest.mark.gpu
+
+
+def _relmax(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize("tag", list(gc.NDRPLZ_SEQ_CASES))
+def test_ndrplz_sequence_block_vs_golden(vpx, tag):
+    """ConvLSTM_ndrplz: multi-layer, odd frame sizes, batch_first on/off, return_all_layers; forward + all gradients."""
+    from vp_suite_amd.model_blocks import ConvLSTM_ndrplz
+    Cin, hid, ks, H, W, B, T, bias, batch_first = gc.NDRPLZ_SEQ_CASES[tag]
+    g = load_golden(f"ndrplz_seq_{tag}")
+    blk = ConvLSTM_ndrplz(Cin, hid, ks, len(hid), batch_first=batch_first, bias=bias, return_all_layers=True)
+    fill_state_dict_(blk, name_seed("ndrplz_seq." + tag))
+    blk = blk.cuda()
+    shape = (B, T, Cin, H, W) if batch_first else (T, B, Cin, H, W)
+    x = seeded_rand(shape, name_seed(f"ndrplz_seq.{tag}.x")).cuda().requires_grad_(True)
+    outs, states = blk(x)
+    for i in range(len(hid)):
+        assert _relmax(outs[i], g[f"out{i}"]) < 1e-5 and _relmax(states[i][1], g[f"c{i}"]) < 1e-5
+        assert _relmax(states[i][0], g[f"h{i}"]) < 1e-5
+    sum((o * seeded_randn(o.shape, name_seed(f"ndrplz_seq.{tag}.g{i}")).cuda()).sum() for i, o in enumerate(outs)).backward()
+    assert _relmax(x.grad, g["dx"]) < 5e-5
+    for key, prm in blk.named_parameters():
+        assert _relmax(prm.grad, g["grad." + key]) < 5e-5, key
+    with pytest.raises(NotImplementedError):
+        blk(x, hidden_state=[None])
+
+
+def test_stlstm_c_abi_nchw(vpx):
+    """vpx_stlstm_step_fwd/_bwd called directly on reference-layout (NCHW) buffers."""
+    from golden_util import seeded_state_dict
+    L = vpx._lib.lib()
+    tag = "plain"
+    Cin, Ch, H, W, k, ln, B = gc.STLSTM_CASES[tag]
+    g = load_golden(f"stlstm_{tag}")
+    sd = {kk: v.cuda().contiguous() for kk, v in seeded_state_dict(g, name_seed("stlstm." + tag)).items()}
+    inp = {n: v.cuda().contiguous() for n, v in gc.stlstm_inputs(tag, Cin, Ch, H, W, B).items()}
+    d = vpx._lib.STLSTMDesc(B, Cin, Ch, H, W, k, 0, vpx._lib.LAYOUT_NCHW, vpx._lib.PREC_F32, vpx._lib.FLAG_SAVE_FOR_BWD)
+    ws_bytes, rs_bytes = L.vpx_stlstm_workspace_bytes(ctypes.byref(d)), L.vpx_stlstm_reserve_bytes(ctypes.byref(d))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    rs = torch.empty(rs_bytes, dtype=torch.uint8, device="cuda")
+    outs = [torch.empty(B, Ch, H, W, device="cuda") for _ in range(5)]
+    p = vpx._lib.ptr
+    Ws = [sd["conv_x.0.weight"], sd["conv_h.0.weight"], sd["conv_m.0.weight"], sd["conv_o.0.weight"], sd["conv_last.weight"]]
+    rc = L.vpx_stlstm_step_fwd(ctypes.byref(d), p(inp["x"]), p(inp["h"]), p(inp["c"]), p(inp["m"]), *[p(w) for w in Ws],
+                               None, *[p(o) for o in outs], p(rs), rs_bytes, p(ws), ws_bytes, None)
+    assert rc == 0, L.vpx_last_error()
+    for o, n in zip(outs, ("h_new", "c_new", "m_new", "delta_c", "delta_m")):
+        assert _relmax(o, g[n]) < 1e-5, n
+    grads_in = [inp[n] for n in ("g_h", "g_c", "g_m", "g_dc", "g_dm")]
+    dins = [torch.empty_like(inp[n]) for n in ("x", "h", "c", "m")]
+    dWs = [torch.empty_like(w) for w in Ws]
+    rc = L.vpx_stlstm_step_bwd(ctypes.byref(d), p(inp["x"]), p(inp["h"]), p(inp["c"]), p(inp["m"]), p(outs[1]), p(outs[2]),
+                               *[p(w) for w in Ws], p(rs), rs_bytes, *[p(t) for t in grads_in], *[p(t) for t in dins],
+                               *[p(t) for t in dWs], p(ws), ws_bytes, None)
+    assert rc == 0, L.vpx_last_error()
+    torch.cuda.synchronize()
+    for t, n in zip(dins, ("dx", "dh", "dc", "dm")):
+        assert _relmax(t, g[n]) < 5e-5, n
+    for t, n in zip(dWs, ("conv_x.0.weight", "conv_h.0.weight", "conv_m.0.weight", "conv_o.0.weight", "conv_last.weight")):
+        assert _relmax(t, g["grad." + n]) < 5e-5, n
+
+
+def test_ef_convlstm_128x128x3_vs_oracle(vpx):
+    """BASELINE config C4 shape (KTH-like 128x128x3, 10 -> 20 shortened to 3 -> 2): product vs the pinned torch restatement."""
+    from oracle import torch_ref as tr
+    from vp_suite_amd.models import MODEL_CLASSES
+    m = MODEL_CLASSES["convlstm-shi"]("cuda", img_shape=(3, 128, 128), action_size=0, tensor_value_range=[0.0, 1.0],
+                                      cell_precision="bf16x3")
+    fill_state_dict_(m, name_seed("ef.c4"))
+    m = m.cuda()
+    x = seeded_rand((1, 3, 3, 128, 128), name_seed("ef.c4.x"))
+    with torch.no_grad():
+        ref = tr.ef_convlstm_forward({k: v.cpu() for k, v in m.state_dict().items()}, x, 2)
+        pred, _ = m(x.cuda(), pred_frames=2)
+    assert pred.shape == (1, 2, 3, 128, 128) and _relmax(pred, ref) < 1e-4
+
+
+def test_predrnn_deep_128x128x3_vs_oracle(vpx):
+    """BASELINE config C5 shape: 4 ST-LSTM layers, 128x128x3 (patch 4 -> 48 channels on 32x32 maps)."""
+    from oracle import torch_ref as tr
+    from vp_suite_amd.models import MODEL_CLASSES
+    m = MODEL_CLASSES["predrnn-pp"]("cuda", img_shape=(3, 128, 128), action_size=0, tensor_value_range=[0.0, 1.0],
+                                    num_layers=4, cell_precision="bf16x3")
+    fill_state_dict_(m, name_seed("predrnn.c5"))
+    m = m.cuda().eval()
+    frames = seeded_rand((1, 5, 3, 128, 128), name_seed("predrnn.c5.x"))
+    with torch.no_grad():
+        ref, rdec = tr.predrnn_v2_forward({k: v.cpu() for k, v in m.state_dict().items()}, frames, 2, patch_size=4,
+                                          num_layers=4)
+        pred, ml = m(frames.cuda(), pred_frames=2)
+    assert _relmax(pred, ref) < 1e-4
+    assert abs(float(ml["ST-LSTM decouple loss"]) - float(rdec)) < 1e-3 * abs(float(rdec))
+
+
+def test_plain_bf16_mode_has_its_own_tolerance(vpx):
+    """VPX_PREC_BF16 (bf16 operands, fp32 accumulate and state): NOT a 1e-4 path. Measured error of bf16 autocast vs the
+    fp32 reference is ~2e-3 of the output range; held to 1e-2 here, forward and gradients."""
+    Cin, Ch, H, W, k, B, T, _ = gc.HZZONE_CASES["mid"]
+    inp = {n: v.cuda() for n, v in gc.hzzone_inputs("mid", Cin, Ch, H, W, k, B, T).items()}
+    g = load_golden("hzzone_mid_states")
+    out, hT, cT = vpx.ops.convlstm_seq(inp["x"], inp["h0"], inp["c0"], inp["W"], inp["b"], inp["Wci"], inp["Wcf"], inp["Wco"],
+                                       seq_len=T, in_channels=Cin, precision="bf16")
+    e = _relmax(out, g["out"])
+    assert 1e-5 < e < 1e-2, e   # clearly not fp32-exact, clearly within the bf16 budget
+    g2 = load_golden("hzzone_tiny_states")
+    Cin, Ch, H, W, k, B, T, _ = gc.HZZONE_CASES["tiny"]
+    inp = {n: v.cuda() for n, v in gc.hzzone_inputs("tiny", Cin, Ch, H, W, k, B, T).items()}
+    lv = {n: inp[n].clone().requires_grad_(True) for n in ("x", "W")}
+    out, hT, cT = vpx.ops.convlstm_seq(lv["x"], inp["h0"], inp["c0"], lv["W"], inp["b"], inp["Wci"], inp["Wcf"], inp["Wco"],
+                                       seq_len=T, in_channels=Cin, precision="bf16")
+    ((out * inp["g_out"]).sum() + (hT * inp["g_hT"]).sum() + (cT * inp["g_cT"]).sum()).backward()
+    assert _relmax(lv["W"].grad, g2["dW"]) < 2e-2 and _relmax(lv["x"].grad, g2["dx"]) < 2e-2

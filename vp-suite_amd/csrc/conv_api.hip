@@ -46,7 +46,7 @@ int plain_conv(hipStream_t stream, int prec, ConvGeo g, const float* src, int C,
 size_t plain_conv_wpk_floats(int C, int Co, int kh, int kw) {
     size_t best = 0;
     ConvStage st[MAX_STAGE];
-    for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16X3; ++prec) {
+    for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16; ++prec) {
         int chunks = 0;
         const int segC[1] = {C};
         if (build_stages(st, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, plain_groups(Co), prec), prec) < 0) return 0;
@@ -99,7 +99,7 @@ int vpx_conv2d_nhwc_bwd(const float* x, const float* w, const float* dy, float* 
         set_error("vpx_conv2d_nhwc_bwd: bad argument");
         return VPX_ERR_ARG;
     }
-    if (precision != VPX_PREC_F32 && precision != VPX_PREC_BF16X3) { set_error("vpx_conv2d_nhwc_bwd: precision %d not implemented", precision); return VPX_ERR_UNSUPPORTED; }
+    if ((precision < VPX_PREC_F32 || precision > VPX_PREC_BF16)) { set_error("vpx_conv2d_nhwc_bwd: precision %d not implemented", precision); return VPX_ERR_UNSUPPORTED; }
     if (!workspace || workspace_bytes < vpx_conv2d_bwd_workspace_bytes(N, H, W, Ci, Co, kh, kw)) { set_error("vpx_conv2d_nhwc_bwd: workspace too small"); return VPX_ERR_WORKSPACE; }
     hipStream_t stream = (hipStream_t)stream_;
     Carver ws{(char*)workspace, 0, workspace_bytes};

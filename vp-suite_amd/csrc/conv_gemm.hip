@@ -50,7 +50,7 @@ __device__ __forceinline__ void split_bf16(float v, unsigned short& hi, unsigned
     lo = bf16_bits(v - bf16_to_f32(hi));
 }
 
-__host__ __device__ inline int mode_kstep(int prec) { return prec == VPX_PREC_F32 ? 8 : 16; }   // channels per k-step
+__host__ __device__ inline int mode_kstep(int prec) { return prec == VPX_PREC_F32 ? 8 : 16; }  // bf16x3 and bf16 share one layout   // channels per k-step
 __host__ __device__ inline int mode_kc(int prec) { return prec == VPX_PREC_F32 ? 16 : 32; }     // k-depth of a weight chunk
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -263,6 +263,7 @@ struct EpiPlain {
 template <int MODE> struct ModeTraits;
 template <> struct ModeTraits<0> { static constexpr int KSTEP = 8, KC = 16, WROW_DATA = 16 * 4; };
 template <> struct ModeTraits<1> { static constexpr int KSTEP = 16, KC = 32, WROW_DATA = 32 * 4; };
+template <> struct ModeTraits<2> { static constexpr int KSTEP = 16, KC = 32, WROW_DATA = 32 * 4; };  // plain bf16: hi planes only are read
 
 template <class Epi, int MODE, int MW>
 __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
@@ -443,20 +444,22 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
                     for (int m = 0; m < MW; ++m) {
                         const char* ap = a_lane + m * 2 * halo_w * arow + tapoff + ks * 32;
                         ah[m] = *reinterpret_cast<const bf16x8*>(ap);
-                        al[m] = *reinterpret_cast<const bf16x8*>(ap + st.cn * 2);
+                        if constexpr (MODE == 1) al[m] = *reinterpret_cast<const bf16x8*>(ap + st.cn * 2);
                     }
                     bf16x8 bh[NG], bl[NG];
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         bh[g] = *reinterpret_cast<const bf16x8*>(wb + g * 32 * WROW + q * 32);
-                        bl[g] = *reinterpret_cast<const bf16x8*>(wb + g * 32 * WROW + KC * 2 + q * 32);
+                        if constexpr (MODE == 1) bl[g] = *reinterpret_cast<const bf16x8*>(wb + g * 32 * WROW + KC * 2 + q * 32);
                     }
 #pragma unroll
                     for (int m = 0; m < MW; ++m) {
+                        if constexpr (MODE == 1) {  // bf16x3: the two cross terms; plain bf16 (MODE 2) keeps hi*hi only
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[g], acc[m][g], 0, 0, 0);
+                            for (int g = 0; g < NG; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[g], acc[m][g], 0, 0, 0);
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[g], acc[m][g], 0, 0, 0);
+                            for (int g = 0; g < NG; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[g], acc[m][g], 0, 0, 0);
+                        }
 #pragma unroll
                         for (int g = 0; g < NG; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[g], acc[m][g], 0, 0, 0);
                     }
@@ -519,6 +522,7 @@ static hipError_t launch_conv(const ConvPlan& plan_in, const Epi& epi, int n_til
     if (plan.prec == VPX_PREC_F32) return launch_conv_m<Epi, 0, 1>(plan, epi, n_tiles, s);  // fp32 is MFMA-bound: MW=1 only
     if (plan.prec == VPX_PREC_BF16X3)
         return mw == 2 ? launch_conv_m<Epi, 1, 2>(plan, epi, n_tiles, s) : launch_conv_m<Epi, 1, 1>(plan, epi, n_tiles, s);
+    if (plan.prec == VPX_PREC_BF16) return launch_conv_m<Epi, 2, 1>(plan, epi, n_tiles, s);
     return hipErrorInvalidValue;
 }
 
@@ -603,7 +607,7 @@ int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, in
 int pick_mw(int B, int H, int W, int n_tiles, int prec) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("VPX_MW"); forced = e ? atoi(e) : 0; }
-    if (prec != VPX_PREC_BF16X3) return 1;
+    if (prec != VPX_PREC_BF16X3) return 1;  // MW=2 is only instantiated for bf16x3
     if (forced == 1 || forced == 2) return forced;
     // Measured (MI355X, bf16x3, B=32): MW=2 is no faster than MW=1 on 64x64 maps (316 vs 314 TF) and slower on smaller
     // maps (fewer workgroups) — the kernel is not LDS-read bound — so MW=2 stays an experiment switch (VPX_MW=2).

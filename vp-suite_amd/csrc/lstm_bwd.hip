@@ -277,6 +277,7 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const char* base) {
 
 template <int MAXT>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_bf16x3_kernel(const WgradArgs a, const int tap_base) {
+    const bool lo_terms = a.prec == VPX_PREC_BF16X3;  // plain bf16 uses the hi planes only (uniform branch)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
@@ -387,9 +388,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_bf16x3_kernel(const WgradAr
 #pragma unroll
             for (int t2 = 0; t2 < MAXT; ++t2) {
                 const bf16x8 ah = wg_tr_frag(A_hi + arow + tapoff[t2]);
-                const bf16x8 al = wg_tr_frag(A_lo + arow + tapoff[t2]);
-                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ah, acc[t2], 0, 0, 0);
-                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, al, acc[t2], 0, 0, 0);
+                if (lo_terms) {
+                    const bf16x8 al = wg_tr_frag(A_lo + arow + tapoff[t2]);
+                    acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ah, acc[t2], 0, 0, 0);
+                    acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, al, acc[t2], 0, 0, 0);
+                }
                 acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, ah, acc[t2], 0, 0, 0);
             }
         }
@@ -422,7 +425,7 @@ static hipError_t launch_wgrad_group(const WgradArgs& a, int n_slices, int tap_b
         attr_set = true;
     }
     dim3 grid(((a.N4 + 63) / 64) * a.n_ctiles, n_slices, groups);
-    if (a.prec == VPX_PREC_BF16X3) {
+    if (a.prec == VPX_PREC_BF16X3 || a.prec == VPX_PREC_BF16) {
         static bool attr_set_b = false;
         if (!attr_set_b) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_kernel<NTAPS>),

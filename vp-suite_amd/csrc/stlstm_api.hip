@@ -29,7 +29,7 @@ int check_st_desc(const vpx_stlstm_desc* d) {
     if (d->k < 1 || !(d->k & 1) || d->k > 7) { set_error("stlstm desc: filter size must be odd and <= 7 (got %d)", d->k); return VPX_ERR_ARG; }
     if (d->layout != VPX_LAYOUT_NHWC && d->layout != VPX_LAYOUT_NCHW) { set_error("stlstm desc: unknown layout %d", d->layout); return VPX_ERR_ARG; }
     if (d->layer_norm) { set_error("stlstm: the LayerNorm variant (predrnn.py:24-40) is not implemented yet"); return VPX_ERR_UNSUPPORTED; }
-    if (d->precision != VPX_PREC_F32 && d->precision != VPX_PREC_BF16X3) { set_error("stlstm: precision %d not implemented", d->precision); return VPX_ERR_UNSUPPORTED; }
+    if ((d->precision < VPX_PREC_F32 || d->precision > VPX_PREC_BF16)) { set_error("stlstm: precision %d not implemented", d->precision); return VPX_ERR_UNSUPPORTED; }
     return VPX_OK;
 }
 

@@ -113,7 +113,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
                                    float* dWlast, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!d) { set_error("stlstm desc is NULL"); return VPX_ERR_ARG; }
     if (d->layer_norm) { set_error("stlstm: the LayerNorm variant is not implemented yet"); return VPX_ERR_UNSUPPORTED; }
-    if (d->precision != VPX_PREC_F32 && d->precision != VPX_PREC_BF16X3) { set_error("stlstm: precision %d not implemented", d->precision); return VPX_ERR_UNSUPPORTED; }
+    if ((d->precision < VPX_PREC_F32 || d->precision > VPX_PREC_BF16)) { set_error("stlstm: precision %d not implemented", d->precision); return VPX_ERR_UNSUPPORTED; }
     if (!(d->flags & VPX_FLAG_SAVE_FOR_BWD)) { set_error("vpx_stlstm_step_bwd: desc lacks VPX_FLAG_SAVE_FOR_BWD"); return VPX_ERR_ARG; }
     if (!x || !h || !c || !m || !c_new || !m_new || !Wx || !Wh || !Wm || !Wo || !Wlast || !reserve) {
         set_error("vpx_stlstm_step_bwd: NULL tensor argument");

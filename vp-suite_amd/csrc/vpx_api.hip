@@ -202,7 +202,7 @@ size_t vpx_conv2d_workspace_bytes(int Ci, int Co, int kh, int kw) {
     const int segC[1] = {Ci};
     // sized for the larger of the two operand modes
     size_t best = 0;
-    for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16X3; ++prec) {
+    for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16; ++prec) {
         if (build_stages(st, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, 4, prec), prec) < 0) return 0;
         const size_t b = align256(packed_weight_bytes(plain_tiles(Co), chunks, plain_groups(Co), prec));
         if (b > best) best = b;
@@ -216,7 +216,7 @@ int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
         set_error("vpx_conv2d_nhwc_fwd: bad argument");
         return VPX_ERR_ARG;
     }
-    if (precision != VPX_PREC_F32 && precision != VPX_PREC_BF16X3) { set_error("vpx_conv2d_nhwc_fwd: precision %d not implemented", precision); return VPX_ERR_UNSUPPORTED; }
+    if ((precision < VPX_PREC_F32 || precision > VPX_PREC_BF16)) { set_error("vpx_conv2d_nhwc_fwd: precision %d not implemented", precision); return VPX_ERR_UNSUPPORTED; }
     hipStream_t stream = (hipStream_t)stream_;
     ConvPlan P{};
     int chunks = 0;

@@ -54,7 +54,7 @@ static inline int check_convlstm_desc(const vpx_convlstm_desc* d) {
         set_error("convlstm desc: unknown layout %d", d->layout);
         return VPX_ERR_ARG;
     }
-    if (d->precision != VPX_PREC_F32 && d->precision != VPX_PREC_BF16X3) {
+    if ((d->precision < VPX_PREC_F32 || d->precision > VPX_PREC_BF16)) {
         set_error("convlstm desc: precision %d not implemented (VPX_PREC_F32 and VPX_PREC_BF16X3 are)", d->precision);
         return VPX_ERR_UNSUPPORTED;
     }
