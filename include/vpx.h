@@ -16,6 +16,7 @@
  * vpx_stlstm_step_fwd / _bwd       SpatioTemporalLSTMCell.forward           vp_suite/model_blocks/predrnn.py:57-83
  * vpx_decouple_fwd / _bwd          adapter + normalize + |cos| + mean       vp_suite/models/predrnn_v2.py:197-198,209-211
  * vpx_conv2d_nhwc_fwd / _bwd       F.conv2d 1x1 / kxk "same", stride 1      vp_suite/models/predrnn_v2.py:223 (conv_last)
+ * vpx_conv2d_ex_fwd                Conv2d / ConvTranspose2d + LeakyReLU     vp_suite/models/precipitation_nowcasting/ef_blocks.py:15-49
  * vpx_nchw_to_nhwc / nhwc_to_nchw  (layout adaptors at the boundary; the reference is NCHW throughout)
  *
  * Layouts. VPX_LAYOUT_NHWC ("channels last", the library's native layout):
@@ -126,6 +127,21 @@ size_t vpx_conv2d_bwd_workspace_bytes(int N, int H, int W, int Ci, int Co, int k
 int vpx_conv2d_nhwc_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int N, int H,
                         int W, int Ci, int Co, int kh, int kw, int precision, void* workspace, size_t workspace_bytes,
                         void* stream);
+
+/* ---- general 2-D convolution / transposed convolution with fused bias + LeakyReLU (the EF "stage glue":
+ *      vp_suite/models/precipitation_nowcasting/ef_blocks.py:15-49, layer table ef_conv_lstm.py:36-65) -------------- */
+typedef struct vpx_conv_desc {
+    int32_t N, H, W, Ci, Co;       /* input x [N,H,W,Ci] (NHWC) */
+    int32_t kh, kw, stride, pad;   /* stride 1 or 2; any padding */
+    int32_t transposed;            /* 0: nn.Conv2d weight [Co,Ci,kh,kw]; 1: nn.ConvTranspose2d weight [Ci,Co,kh,kw] */
+    float leaky_slope;             /* LeakyReLU negative slope fused after the bias; 0 = no activation */
+    int32_t precision;             /* VPX_PREC_* */
+} vpx_conv_desc;
+int vpx_conv2d_ex_out_shape(const vpx_conv_desc* d, int* Ho, int* Wo);
+size_t vpx_conv2d_ex_workspace_bytes(const vpx_conv_desc* d);
+/* y [N,Ho,Wo,Co]. A stride-2 transposed convolution runs as 4 output-phase launches of the same kernel. */
+int vpx_conv2d_ex_fwd(const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- layout adaptors: src [N,C,H,W] <-> dst [N,H,W,C] -------------------------------------------------------- */
 int vpx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, void* stream);

@@ -126,3 +126,39 @@ def test_plain_bf16_mode_has_its_own_tolerance(vpx):
                                        seq_len=T, in_channels=Cin, precision="bf16")
     ((out * inp["g_out"]).sum() + (hT * inp["g_hT"]).sum() + (cT * inp["g_cT"]).sum()).backward()
     assert _relmax(lv["W"].grad, g2["dW"]) < 2e-2 and _relmax(lv["x"].grad, g2["dx"]) < 2e-2
+
+
+def test_conv2d_ex_vs_torch(vpx):
+    """vpx_conv2d_ex_fwd (strided conv, transposed conv incl. the 4-phase stride-2 form, fused bias + LeakyReLU) against
+    torch fp64 on the CPU; backward (delegated to ATen) against autograd."""
+    import torch.nn.functional as F
+    cases = [  # (transposed, Ci, Co, k, stride, pad, H, W)
+        (False, 1, 16, 3, 1, 1, 20, 24), (False, 64, 64, 3, 2, 1, 32, 32), (False, 12, 20, 3, 2, 1, 17, 23),
+        (False, 16, 1, 1, 1, 0, 16, 16), (True, 96, 96, 4, 2, 1, 8, 8), (True, 10, 14, 4, 2, 1, 7, 9),
+        (True, 64, 16, 3, 1, 1, 16, 16), (True, 6, 5, 5, 2, 2, 6, 7), (False, 8, 8, 4, 2, 1, 12, 12),
+    ]
+    for prec, tol in (("f32", 2e-5), ("bf16x3", 5e-5)):
+        for tr, Ci, Co, k, s, p, H, W in cases:
+            tag = f"cex.{tr}.{Ci}.{Co}.{k}.{s}"
+            x = seeded_randn((2, Ci, H, W), name_seed(tag + "x"))
+            wshape = (Ci, Co, k, k) if tr else (Co, Ci, k, k)
+            w = seeded_randn(wshape, name_seed(tag + "w"), 1.0 / np.sqrt(Ci * k * k))
+            b = seeded_randn((Co,), name_seed(tag + "b"), 0.1)
+            if tr:
+                ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=s, padding=p)
+            else:
+                ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p)
+            ref = F.leaky_relu(ref, 0.2).float()
+            lv = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+            y = vpx.ops.conv2d_ex(lv[0], lv[1], lv[2], s, p, tr, 0.2, prec)
+            assert y.shape == ref.shape, (tag, y.shape, ref.shape)
+            assert _relmax(y, ref) < tol, (prec, tag, _relmax(y, ref))
+            if prec == "f32":
+                gy = seeded_randn(ref.shape, name_seed(tag + "g"))
+                rl = [t.clone().requires_grad_(True) for t in (x, w, b)]
+                rr = F.conv_transpose2d(rl[0], rl[1], rl[2], stride=s, padding=p) if tr else \
+                    F.conv2d(rl[0], rl[1], rl[2], stride=s, padding=p)
+                (F.leaky_relu(rr, 0.2) * gy).sum().backward()
+                (y * gy.cuda()).sum().backward()
+                for a, r in zip(lv, rl):
+                    assert _relmax(a.grad, r.grad) < 1e-4, tag

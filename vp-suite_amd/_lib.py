@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = [
     "vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes", "vpx_stlstm_step_fwd", "vpx_stlstm_step_bwd",
     "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
     "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_conv2d_bwd_workspace_bytes", "vpx_conv2d_nhwc_bwd",
+    "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd",
     "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
 ]
 
@@ -34,6 +35,11 @@ class ConvLSTMDesc(ctypes.Structure):
 class STLSTMDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("B", "Cin", "Ch", "H", "W", "k", "layer_norm", "layout", "precision",
                                               "flags")]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "W", "Ci", "Co", "kh", "kw", "stride", "pad", "transposed")] + \
+               [("leaky_slope", ctypes.c_float), ("precision", ctypes.c_int32)]
 
 
 class VpxError(RuntimeError):
@@ -93,6 +99,12 @@ def lib():
         L.vpx_conv2d_bwd_workspace_bytes.argtypes = [ctypes.c_int] * 7
         L.vpx_conv2d_nhwc_bwd.restype = ctypes.c_int
         L.vpx_conv2d_nhwc_bwd.argtypes = [vp] * 6 + [ctypes.c_int] * 8 + [vp, sz, vp]
+        L.vpx_conv2d_ex_out_shape.restype = ctypes.c_int
+        L.vpx_conv2d_ex_out_shape.argtypes = [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.vpx_conv2d_ex_workspace_bytes.restype = sz
+        L.vpx_conv2d_ex_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.vpx_conv2d_ex_fwd.restype = ctypes.c_int
+        L.vpx_conv2d_ex_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 4 + [vp, sz, vp]
         for name in ("vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw"):
             getattr(L, name).restype = ctypes.c_int
             getattr(L, name).argtypes = [vp, vp] + [ctypes.c_int] * 4 + [vp]

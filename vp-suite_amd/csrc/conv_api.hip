@@ -183,3 +183,139 @@ int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* ad
 }
 
 }  // extern "C"
+
+/* ---- general conv / transposed conv + bias + LeakyReLU (EF stage glue) -------------------------------------------- */
+namespace {
+
+struct ExGeo { int Ho, Wo; };
+
+int ex_check(const vpx_conv_desc* d, ExGeo& g) {
+    if (!d) { set_error("conv desc is NULL"); return VPX_ERR_ARG; }
+    if (d->N < 1 || d->H < 1 || d->W < 1 || d->Ci < 1 || d->Co < 1 || d->kh < 1 || d->kw < 1 || d->pad < 0) { set_error("conv desc: bad dimension"); return VPX_ERR_ARG; }
+    if (d->stride != 1 && d->stride != 2) { set_error("conv desc: stride %d not implemented (1 or 2)", d->stride); return VPX_ERR_UNSUPPORTED; }
+    if (d->kh > 7 || d->kw > 7) { set_error("conv desc: kernel larger than 7 not implemented"); return VPX_ERR_UNSUPPORTED; }
+    if (d->precision < VPX_PREC_F32 || d->precision > VPX_PREC_BF16) { set_error("conv desc: unknown precision %d", d->precision); return VPX_ERR_UNSUPPORTED; }
+    if (!d->transposed) {
+        g.Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+        g.Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    } else {
+        g.Ho = (d->H - 1) * d->stride - 2 * d->pad + d->kh;
+        g.Wo = (d->W - 1) * d->stride - 2 * d->pad + d->kw;
+        if (d->stride == 1 && (d->kh - 1 - d->pad < 0 || d->kw - 1 - d->pad < 0)) { set_error("conv desc: padding larger than kernel-1 in a transposed conv"); return VPX_ERR_UNSUPPORTED; }
+    }
+    if (g.Ho < 1 || g.Wo < 1) { set_error("conv desc: empty output"); return VPX_ERR_ARG; }
+    return VPX_OK;
+}
+
+// one launch: tile space Ht x Wt, kernel taps th x tw, halo origin (oy, ox), input step `sd`
+int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+              const ExGeo& g, int Ht, int Wt, int th, int tw, int sd, int oy, int ox, const int* tapmap, bool flip,
+              int omap, int oys, int oyo, int oxs, int oxo, float* wpk) {
+    const int prec = d->precision;
+    ConvPlan P{};
+    int chunks = 0;
+    const int segC[1] = {d->Ci};
+    P.prec = prec;
+    const int ng = plain_groups(d->Co);
+    P.nstage = build_stages(P.stage, &chunks, segC, 1, th * tw, pick_stage_channels(segC, 1, th, tw, ng, prec, 1, sd), prec);
+    if (P.nstage < 0) { set_error("conv: too many channel stages (Ci=%d)", d->Ci); return VPX_ERR_UNSUPPORTED; }
+    PackDesc pd{};
+    const int src_taps = d->kh * d->kw;
+    if (!d->transposed) pd.seg[0] = PackSeg{w, (long long)d->Ci * src_taps, src_taps, 0, d->Ci};
+    else pd.seg[0] = PackSeg{w, (long long)d->Co * src_taps, src_taps, 0, d->Ci};
+    memcpy(pd.stage, P.stage, sizeof(ConvStage) * P.nstage);
+    pd.nstage = P.nstage; pd.chunks_total = chunks; pd.prec = prec; pd.taps = th * tw;
+    fill_plain_pack(pd, d->Co, 0);
+    pd.transposed = d->transposed ? 1 : 0;
+    pd.flip = flip ? 1 : 0;
+    if (tapmap) { pd.src_taps = src_taps; for (int i = 0; i < th * tw; ++i) pd.tapmap[i] = tapmap[i]; }
+    VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+    P.B = d->N; P.H = Ht; P.W = Wt; P.kh = th; P.kw = tw;
+    set_plan_tiles(P, 1);
+    P.stride = sd; P.use_org = 1; P.org_y = oy; P.org_x = ox; P.Hin = d->H; P.Win = d->W;
+    P.nseg = 1;
+    P.seg[0] = ConvSeg{x, (long long)d->H * d->W * d->Ci, d->Ci, d->Ci};
+    P.chunks_total = chunks;
+    P.a_bytes = conv_a_bytes(P.stage, P.nstage, th, tw, 1, sd);
+    P.wpk = wpk;
+    PlainEpiArgs ea{};
+    ea.bias = bias; ea.Co = d->Co; ea.split = d->Co; ea.ng = ng;
+    ea.out0 = y; ea.bstride0 = (long long)g.Ho * g.Wo * d->Co; ea.ld0 = d->Co;
+    ea.leaky = d->leaky_slope;
+    ea.omap = omap; ea.oys = oys; ea.oyo = oyo; ea.oxs = oxs; ea.oxo = oxo; ea.Wmem = g.Wo;
+    VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, pd.n_tiles, stream));
+    return VPX_OK;
+}
+
+size_t ex_wpk_floats(const vpx_conv_desc* d) {
+    // upper bound over the launches this descriptor can produce (full tap set, stride as given)
+    ConvStage st[MAX_STAGE];
+    int chunks = 0;
+    const int segC[1] = {d->Ci};
+    const int ng = plain_groups(d->Co);
+    const int sd = d->transposed ? 1 : d->stride;
+    if (build_stages(st, &chunks, segC, 1, d->kh * d->kw, pick_stage_channels(segC, 1, d->kh, d->kw, ng, d->precision, 1, sd), d->precision) < 0) return 0;
+    return packed_weight_bytes(plain_tiles(d->Co), chunks, ng, d->precision) / 4 + 1024;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vpx_conv2d_ex_out_shape(const vpx_conv_desc* d, int* Ho, int* Wo) {
+    ExGeo g;
+    int rc = ex_check(d, g);
+    if (rc != VPX_OK) return rc;
+    if (Ho) *Ho = g.Ho;
+    if (Wo) *Wo = g.Wo;
+    return VPX_OK;
+}
+
+size_t vpx_conv2d_ex_workspace_bytes(const vpx_conv_desc* d) {
+    ExGeo g;
+    if (ex_check(d, g) != VPX_OK) return 0;
+    return align256(ex_wpk_floats(d) * 4) + 512;
+}
+
+int vpx_conv2d_ex_fwd(const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                      void* workspace, size_t workspace_bytes, void* stream_) {
+    ExGeo g;
+    int rc = ex_check(d, g);
+    if (rc != VPX_OK) return rc;
+    if (!x || !w || !y) { set_error("vpx_conv2d_ex_fwd: NULL tensor argument"); return VPX_ERR_ARG; }
+    if (!workspace || workspace_bytes < vpx_conv2d_ex_workspace_bytes(d)) { set_error("vpx_conv2d_ex_fwd: workspace too small"); return VPX_ERR_WORKSPACE; }
+    hipStream_t stream = (hipStream_t)stream_;
+    Carver ws{(char*)workspace, 0, workspace_bytes};
+    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    float* wpk = ws.take(ex_wpk_floats(d));
+    if (!d->transposed)  // y[o] = sum_k x[o*s - pad + k] w[k]
+        return ex_launch(stream, d, x, w, bias, y, g, g.Ho, g.Wo, d->kh, d->kw, d->stride, -d->pad, -d->pad, nullptr, false,
+                         0, 1, 0, 1, 0, wpk);
+    if (d->stride == 1)  // y[o] = sum_k x[o + pad - k] w[k]  ==  correlation with the flipped kernel, origin -(k-1-pad)
+        return ex_launch(stream, d, x, w, bias, y, g, g.Ho, g.Wo, d->kh, d->kw, 1, -(d->kh - 1 - d->pad), -(d->kw - 1 - d->pad),
+                         nullptr, true, 0, 1, 0, 1, 0, wpk);
+    // stride 2: output phase (py, px) is a stride-1 correlation of x with the taps k == (p + pad) mod 2 of that axis
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            const int Ht = (g.Ho - py + 1) / 2, Wt = (g.Wo - px + 1) / 2;
+            if (Ht < 1 || Wt < 1) continue;
+            const int ky0 = (py + d->pad) & 1, kx0 = (px + d->pad) & 1;
+            const int nty = (d->kh - ky0 + 1) / 2, ntx = (d->kw - kx0 + 1) / 2;
+            if (nty < 1 || ntx < 1) {  // no tap feeds this phase: bias (+activation) only — not reachable for k >= 2
+                set_error("vpx_conv2d_ex_fwd: kernel too small for stride 2");
+                return VPX_ERR_UNSUPPORTED;
+            }
+            if (nty * ntx > 16) { set_error("vpx_conv2d_ex_fwd: too many taps per phase"); return VPX_ERR_UNSUPPORTED; }
+            const int basey = (py + d->pad - ky0) / 2, basex = (px + d->pad - kx0) / 2;
+            int tapmap[16];
+            for (int ty = 0; ty < nty; ++ty)
+                for (int tx = 0; tx < ntx; ++tx)
+                    tapmap[ty * ntx + tx] = (ky0 + 2 * (nty - 1 - ty)) * d->kw + (kx0 + 2 * (ntx - 1 - tx));
+            rc = ex_launch(stream, d, x, w, bias, y, g, Ht, Wt, nty, ntx, 1, basey - (nty - 1), basex - (ntx - 1), tapmap, false,
+                           1, 2, py, 2, px, wpk);
+            if (rc != VPX_OK) return rc;
+        }
+    return VPX_OK;
+}
+
+}  // extern "C"

@@ -83,7 +83,7 @@ __global__ void pack_weights_kernel(const PackDesc pd, char* __restrict__ dst) {
             const int chan = n_tile * pd.tile_stride + pd.goff[g] + j;
             if (c < sg.C && chan < pd.nch) {
                 const int row = pd.rowbase[st.seg][g] + n_tile * pd.tile_stride + j;
-                const int tp = pd.flip ? (pd.taps - 1 - tap) : tap;
+                const int tp = pd.src_taps ? pd.tapmap[tap] : (pd.flip ? (pd.taps - 1 - tap) : tap);
                 if (!pd.transposed)
                     v = sg.w[(long long)row * sg.ld_o + (long long)(sg.coff + c) * sg.ld_i + tp];
                 else
@@ -244,8 +244,10 @@ struct EpiPlain {
             for (int r = 0; r < 16; ++r) {
                 int y, x;
                 if (!tile_pixel(t, r, y, x)) continue;
-                float* p = dst + (size_t)t.b * bs + ((size_t)y * t.W + x) * ld + cc;
-                const float v = acc[g][r] + bv;
+                const size_t pix = a.omap ? ((size_t)(y * a.oys + a.oyo) * a.Wmem + (x * a.oxs + a.oxo)) : ((size_t)y * t.W + x);
+                float* p = dst + (size_t)t.b * bs + pix * ld + cc;
+                float v = acc[g][r] + bv;
+                if (a.leaky != 0.0f) v = v > 0.0f ? v : v * a.leaky;
                 *p = a.accumulate ? (*p + v) : v;
             }
         }
@@ -289,9 +291,11 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
     const int n_tile = blockIdx.y;
     constexpr int TH = TILE_H * MW;  // workgroup tile height: every wave owns 2*MW consecutive rows of 16 pixels
     const int x0 = tx * TILE_W, y0 = ty * TH;
-    const int halo_w = TILE_W + P.kw - 1, halo_h = TH + P.kh - 1;
+    const int sd = P.stride > 1 ? P.stride : 1;  // input step per output pixel
+    const int halo_w = (TILE_W - 1) * sd + P.kw, halo_h = (TH - 1) * sd + P.kh;
     const int npos = halo_w * halo_h;
-    const int ph = P.kh / 2, pw = P.kw / 2;
+    const int ph = P.use_org ? -P.org_y : P.kh / 2, pw = P.use_org ? -P.org_x : P.kw / 2;  // halo origin = tile origin*sd - (ph, pw)
+    const int Hin = P.Hin ? P.Hin : P.H, Win = P.Win ? P.Win : P.W;
 
     char* A_lds = smem;
     char* W_lds = smem + P.a_bytes;
@@ -364,11 +368,11 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
                     for (int v = tid; v < total; v += NTHREADS) {
                         const int pos = v / v4n, c4 = v - pos * v4n;
                         const int hy = pos / halo_w, hx = pos - hy * halo_w;
-                        const int gy = y0 - ph + hy, gx = x0 - pw + hx;
+                        const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
                         const int c = st.c0 + c4 * 4;
                         f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                        if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < sg.C && !(P.dbg & 2))
-                            val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * P.W + gx) * ld + c);
+                        if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win && c < sg.C && !(P.dbg & 2))
+                            val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * Win + gx) * ld + c);
                         if constexpr (MODE == 0) {
                             *reinterpret_cast<f32x4*>(A_lds + pos * arow + c4 * 16) = val;
                         } else {
@@ -386,11 +390,11 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
                     for (int e = tid; e < total; e += NTHREADS) {
                         const int pos = e / st.cn, cc = e - pos * st.cn;
                         const int hy = pos / halo_w, hx = pos - hy * halo_w;
-                        const int gy = y0 - ph + hy, gx = x0 - pw + hx;
+                        const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
                         const int c = st.c0 + cc;
                         float val = 0.f;
-                        if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < sg.C)
-                            val = src[((size_t)gy * P.W + gx) * ld + c];
+                        if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win && c < sg.C)
+                            val = src[((size_t)gy * Win + gx) * ld + c];
                         if constexpr (MODE == 0) {
                             *reinterpret_cast<float*>(A_lds + pos * arow + cc * 4) = val;
                         } else {
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
 
             ksn = st.cn / KSTEP;
             ks = 0; tdx = 0; tdy = 0; tapoff = 0;
-            a_lane = A_lds + (py * halo_w + px) * arow + hh * 16;
+            a_lane = A_lds + (py * sd * halo_w + px * sd) * arow + hh * 16;
             if (first) {  // very first chunk of the stream: registers -> LDS buffer 0, refill the even set
                 write_lds(wrA, 0);
                 issue_load(wrA);  // chunk 2
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
                     f32x4 a4[MW];
 #pragma unroll
                     for (int m = 0; m < MW; ++m)
-                        a4[m] = *reinterpret_cast<const f32x4*>(a_lane + m * 2 * halo_w * arow + tapoff + ks * 32);
+                        a4[m] = *reinterpret_cast<const f32x4*>(a_lane + m * 2 * sd * halo_w * arow + tapoff + ks * 32);
                     f32x4 b4[NG];
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
                     bf16x8 ah[MW], al[MW];
 #pragma unroll
                     for (int m = 0; m < MW; ++m) {
-                        const char* ap = a_lane + m * 2 * halo_w * arow + tapoff + ks * 32;
+                        const char* ap = a_lane + m * 2 * sd * halo_w * arow + tapoff + ks * 32;
                         ah[m] = *reinterpret_cast<const bf16x8*>(ap);
                         if constexpr (MODE == 1) al[m] = *reinterpret_cast<const bf16x8*>(ap + st.cn * 2);
                     }
@@ -615,7 +619,7 @@ int pick_mw(int B, int H, int W, int n_tiles, int prec) {
     return 1;
 }
 
-int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw) {
+int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw, int stride) {
     static int forced = -1;
     if (forced < 0) {
         const char* e = getenv("VPX_CS");
@@ -624,7 +628,7 @@ int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int p
     }
     const int kstep = mode_kstep(prec);
     if (forced) return forced < kstep ? kstep : forced;
-    const int npos = (TILE_H * mw + kh - 1) * (TILE_W + kw - 1);
+    const int npos = ((TILE_H * mw - 1) * stride + kh) * ((TILE_W - 1) * stride + kw);
     const int wbytes = 2 * ng * 32 * (mode_kc(prec) * 4 + 16);
     const int wg_cap = mw == 2 ? 2 : 3;  // register-limited residency
     int best = CS_MAX, best_wg = 0;
@@ -639,8 +643,8 @@ int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int p
     return best;
 }
 
-int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw) {
-    const int npos = (TILE_H * mw + kh - 1) * (TILE_W + kw - 1);
+int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw, int stride) {
+    const int npos = ((TILE_H * mw - 1) * stride + kh) * ((TILE_W - 1) * stride + kw);
     int m = 16;
     for (int i = 0; i < nstage; ++i) {
         const int bytes = npos * (st[i].cn * 4 + 16);

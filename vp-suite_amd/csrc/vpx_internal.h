@@ -47,6 +47,11 @@ struct ConvPlan {
     int prec;             // VPX_PREC_F32 | VPX_PREC_BF16X3: operand mode of the contraction
     int mw;               // 32-pixel MFMA row tiles per wave (1: 8x16 workgroup tile, 2: 16x16); 0 is read as 1
     int dbg;              // ablation bits for profiling (VPX_DBG): 1 skip MFMAs, 2 skip activation loads, 4 skip weight loads, 8 skip epilogue
+    // generalised geometry (all 0 = the stride-1 "same" convolution every recurrent cell uses):
+    int stride;           // input step per output pixel (0/1 or 2)
+    int use_org;          // 1: the halo origin of output pixel (0,0) is (org_y, org_x) instead of (-kh/2, -kw/2)
+    int org_y, org_x;
+    int Hin, Win;         // input image size when it differs from the tile-space size H x W (0 = same)
     ConvSeg seg[MAX_SEG];
     ConvStage stage[MAX_STAGE];
     const float* wpk;     // packed weights [n_tiles][chunks_total][NG*32][KC]
@@ -72,12 +77,14 @@ struct PackDesc {
     int nch;              // number of valid output channels
     int transposed;       // 1: contraction runs over the weight's O axis, outputs over its I axis (data-gradient conv)
     int flip;             // 1: spatially flipped taps (data-gradient conv)
+    int src_taps;         // taps of the SOURCE weight tensor when the packed kernel uses a subset / re-ordering of them (0 = same)
+    int tapmap[16];       // with src_taps: packed tap t reads source tap tapmap[t]
 };
 
 void set_error(const char* fmt, ...);
 int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int prec);
-int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw = 1);
-int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw = 1);
+int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw = 1, int stride = 1);
+int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw = 1, int stride = 1);
 // rows per wave: 2 (16x16 workgroup tile) when the operand mode profits (bf16x3 is LDS/issue-bound, not MFMA-bound) and
 // the launch still has >= 2 workgroups per CU; else 1
 int pick_mw(int B, int H, int W, int n_tiles, int prec);
@@ -110,6 +117,9 @@ struct PlainEpiArgs {
     float* out1; long long bstride1; int ld1;
     int accumulate;           // 1: += into destination
     int ng;                   // 32-channel groups per N tile (plain_groups(Co)); tile covers ng*32 output channels
+    float leaky;              // LeakyReLU negative slope applied after the bias (0 = none; 1 would be identity)
+    int omap;                 // 1: tile-space pixel (y,x) is stored at (y*oys + oyo, x*oxs + oxo) of a Wmem-wide image
+    int oys, oyo, oxs, oxo, Wmem;
 };
 hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, int n_tiles, hipStream_t s);
 // N tiling of a plain convolution with Co outputs: 1..4 groups of 32 channels per workgroup, chosen to minimise padding

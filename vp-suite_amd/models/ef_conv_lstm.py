@@ -43,11 +43,38 @@ def _stage(spec: "OrderedDict[str, list]") -> nn.Sequential:
     return nn.Sequential(OrderedDict(layers))
 
 
-def _apply_framewise(subnet: nn.Module, seq: torch.Tensor) -> torch.Tensor:
+def _run_stage(subnet: nn.Sequential, x: torch.Tensor, precision: str) -> torch.Tensor:
+    """Executes a stage built by _stage() on a channels-last [N,C,H,W] batch. Conv2d / ConvTranspose2d layers (with a
+    directly following LeakyReLU fused in) run through libvpx_hip's vpx_conv2d_ex_fwd when the configuration is one it
+    implements; every other layer (pool, ReLU, exotic strides) runs as the stock GPU module."""
+    mods = list(subnet.children())
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        is_conv = isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))
+        if is_conv and x.is_cuda:
+            tr = isinstance(m, nn.ConvTranspose2d)
+            kh, kw = m.kernel_size
+            simple = (m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.dilation == (1, 1)
+                      and m.groups == 1 and (not tr or m.output_padding == (0, 0)))
+            if simple and ops.glue_supported(kh, kw, m.stride[0], m.padding[0], tr):
+                slope = 0.0
+                if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+                    slope = float(mods[i + 1].negative_slope)
+                    i += 1
+                x = ops.conv2d_ex(x, m.weight, m.bias, m.stride[0], m.padding[0], tr, slope, precision)
+                i += 1
+                continue
+        x = m(x)
+        i += 1
+    return x
+
+
+def _apply_framewise(subnet: nn.Module, seq: torch.Tensor, precision: str = "f32") -> torch.Tensor:
     """Runs a 2-D stage on every frame of [B,T,C,H,W], channels-last in and out (B*T is folded into the batch)."""
     b, t = seq.shape[:2]
     flat = ops.to_channels_last(seq).reshape(b * t, *seq.shape[2:])  # a view: NHWC memory folds B,T for free
-    y = subnet(flat.contiguous(memory_format=torch.channels_last))
+    y = _run_stage(subnet, flat.contiguous(memory_format=torch.channels_last), precision)
     y = y.contiguous(memory_format=torch.channels_last)
     return y.view(b, t, *y.shape[1:])
 
@@ -62,7 +89,7 @@ class Encoder(nn.Module):
             setattr(self, f"rnn{index}", rnn)
 
     def forward_by_stage(self, input, subnet, rnn):
-        input = _apply_framewise(subnet, input)
+        input = _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"))
         return rnn(input, None, seq_len=input.shape[1])
 
     def forward(self, input):
@@ -84,7 +111,7 @@ class Forecaster(nn.Module):
 
     def forward_by_stage(self, input, state, pred_frames, subnet, rnn):
         input, _ = rnn(input, state, pred_frames)
-        return _apply_framewise(subnet, input)
+        return _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"))
 
     def forward(self, hidden_states, pred_frames):
         # like the reference (ef_blocks.py:109-110) the top block is addressed as stage3/rnn3 and gets no input

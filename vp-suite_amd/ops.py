@@ -6,7 +6,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvLSTMDesc, STLSTMDesc, check, ptr
+from ._lib import ConvDesc, ConvLSTMDesc, STLSTMDesc, check, ptr
 
 PRECISIONS = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}
 
@@ -227,6 +227,63 @@ def conv2d_same(x, w, bias=None, precision="f32"):
     """y = conv2d(x, w, bias, stride=1, padding=k//2) on a [N,C,H,W] tensor (PredRNN's 1x1 frame head,
     predrnn_v2.py:223, and any other stride-1 'same' convolution); differentiable."""
     return _Conv2dSameFn.apply(x, w, bias, PRECISIONS[precision])
+
+
+class _ConvExFn(torch.autograd.Function):
+    """Conv2d / ConvTranspose2d (stride 1 or 2) + bias + LeakyReLU in ONE library launch (4 for a stride-2 transposed
+    conv) — the EF stage glue of ef_blocks.py:15-49. The forward is the HIP implicit-GEMM kernel; the backward of this
+    glue (7 % of the model's FLOPs) is delegated to ATen's convolution_backward on the saved input."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding, transposed, slope, precision):
+        _require_gpu(x, "conv2d_ex")
+        xs = to_channels_last(x)
+        N, Ci, H, Wd = xs.shape
+        kh, kw = int(w.shape[2]), int(w.shape[3])
+        Co = int(w.shape[1] if transposed else w.shape[0])
+        if int(w.shape[0] if transposed else w.shape[1]) != Ci:
+            raise ValueError(f"conv2d_ex: weight {tuple(w.shape)} does not match {Ci} input channels")
+        wc = w.contiguous()
+        bc = None if bias is None else bias.contiguous()
+        d = ConvDesc(N, H, Wd, Ci, Co, kh, kw, int(stride), int(padding), int(bool(transposed)), float(slope), precision)
+        L = _lib.lib()
+        ho, wo = ctypes.c_int(0), ctypes.c_int(0)
+        check(L.vpx_conv2d_ex_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "vpx_conv2d_ex_out_shape")
+        ws_bytes = L.vpx_conv2d_ex_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        y = new_channels_last((N, Co, ho.value, wo.value), x.device)
+        check(L.vpx_conv2d_ex_fwd(ctypes.byref(d), ptr(xs), ptr(wc), ptr(bc), ptr(y), ptr(ws), ws_bytes, _stream()),
+              "vpx_conv2d_ex_fwd")
+        ctx.save_for_backward(xs, wc, y)
+        ctx.cfg = (int(stride), int(padding), bool(transposed), float(slope), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, wc, y = ctx.saved_tensors
+        stride, padding, transposed, slope, has_bias = ctx.cfg
+        if slope != 0.0:  # LeakyReLU' from the sign of the output (same sign as the pre-activation for slope > 0)
+            dy = dy * torch.where(y > 0, torch.ones((), device=y.device), torch.full((), slope, device=y.device))
+        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]]
+        bias_sizes = [int(wc.shape[1] if transposed else wc.shape[0])] if has_bias else None
+        dx, dw, db = torch.ops.aten.convolution_backward(dy, xs, wc, bias_sizes, [stride, stride], [padding, padding],
+                                                         [1, 1], transposed, [0, 0], 1, mask)
+        return dx, dw, (db if has_bias else None), None, None, None, None, None
+
+
+def conv2d_ex(x, w, bias, stride, padding, transposed=False, leaky_slope=0.0, precision="f32"):
+    return _ConvExFn.apply(x, w, bias, stride, padding, transposed, leaky_slope, PRECISIONS[precision])
+
+
+def glue_supported(kh, kw, stride, padding, transposed) -> bool:
+    """Configurations vpx_conv2d_ex_fwd implements (anything else stays on the stock GPU op)."""
+    if stride not in (1, 2) or kh > 7 or kw > 7 or padding < 0:
+        return False
+    if transposed and stride == 1:
+        return kh - 1 - padding >= 0 and kw - 1 - padding >= 0
+    if transposed and stride == 2:
+        return kh >= 2 and kw >= 2
+    return True
 
 
 class _DecoupleFn(torch.autograd.Function):
