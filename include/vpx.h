@@ -99,14 +99,15 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
                         void* stream);
 
 /* c_new / m_new are the forward's outputs (the operands of conv_o / conv_last). Incoming gradients may be NULL (zero);
- * every gradient output may be NULL (skipped); weight gradients are OVERWRITTEN. */
+ * every gradient output may be NULL (skipped); weight gradients are OVERWRITTEN. ln / dln: the 8 LayerNorm parameter
+ * tensors and their gradients (reference layout [C,H,W]); NULL unless desc.layer_norm. */
 int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c, const float* m,
                         const float* c_new, const float* m_new,
                         const float* Wx, const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
-                        const void* reserve, size_t reserve_bytes, const float* dh_new, const float* dc_new,
-                        const float* dm_new, const float* ddelta_c, const float* ddelta_m, float* dx, float* dh,
-                        float* dc, float* dm, float* dWx, float* dWh, float* dWm, float* dWo, float* dWlast,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        const float* const* ln, const void* reserve, size_t reserve_bytes, const float* dh_new,
+                        const float* dc_new, const float* dm_new, const float* ddelta_c, const float* ddelta_m,
+                        float* dx, float* dh, float* dc, float* dm, float* dWx, float* dWh, float* dWm, float* dWo,
+                        float* dWlast, float* const* dln, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- decoupling-loss term: mean_{b,ch} |cos(normalize(A*dc), normalize(A*dm))| over H*W ---------------------- */
 /* delta_c/delta_m [B,H,W,Ch] (NHWC) ; adapter [Ch,Ch] ; value / dvalue: 1 float on device */

@@ -20,7 +20,7 @@ def _relmax(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-@pytest.mark.parametrize("tag", ["plain", "k3"])
+@pytest.mark.parametrize("tag", ["plain", "k3", "ln"])
 def test_stlstm_cell_vs_golden(vpx, tag):
     from vp_suite_amd.model_blocks import SpatioTemporalLSTMCell
     Cin, Ch, H, W, k, ln, B = gc.STLSTM_CASES[tag]
@@ -43,14 +43,6 @@ def test_stlstm_cell_vs_golden(vpx, tag):
         o2 = cell(inp["x"], inp["h"], inp["c"], inp["m"])
         o3 = cell(inp["x"], inp["h"], inp["c"], inp["m"])
     assert _relmax(o3[0], g["h_new"]) < RTOL and torch.equal(o2[0], o3[0])
-
-
-def test_stlstm_layernorm_fails_loudly(vpx):
-    from vp_suite_amd.model_blocks import SpatioTemporalLSTMCell
-    cell = SpatioTemporalLSTMCell(6, 8, 10, 9, 5, 1, True).cuda()
-    z = torch.zeros(2, 8, 10, 9, device="cuda")
-    with pytest.raises(NotImplementedError):
-        cell(torch.zeros(2, 6, 10, 9, device="cuda"), z, z, z)
 
 
 def test_stlstm_real_shape_vs_oracle(vpx):
@@ -175,3 +167,24 @@ def test_decouple_and_conv2d_vs_golden_and_autograd(vpx):
             (y * gy.cuda()).sum().backward()
             for a, r in zip(mine, ref):
                 assert _relmax(a.grad, r.grad) < tol, (prec, Ci, k)
+
+
+def test_predrnn_layernorm_tiny_vs_golden(vpx):
+    """PredRNN-V2 with layer_norm=True (the upstream default, tests/test_impl_match/_predrnn_v2.py:41): forward, loss and
+    all gradients (incl. the LayerNorm parameters) against the reference-generated pins."""
+    from vp_suite_amd.measure import PredictionLossProvider
+    tag, kw, B, Ttot, P = "tiny_ln", gc.PRED_TINY_LN_KW, 2, 6, 3
+    g = load_golden(f"predrnn_{tag}")
+    c, h, w = kw["img_shape"]
+    frames = seeded_rand((B, Ttot, c, h, w), name_seed(f"predrnn.{tag}.frames")).cuda()
+    m = _predrnn(tag, kw).eval()
+    pred, ml = m(frames, pred_frames=P)
+    assert _relmax(pred, g["eval.pred"]) < 1e-4
+    lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
+    _, loss = lp.get_losses(pred, frames[:, Ttot - P:])
+    loss = loss + ml["ST-LSTM decouple loss"]
+    assert abs(float(loss) - float(g["eval.loss"])) < 1e-4 * abs(float(g["eval.loss"]))
+    loss.backward()
+    named = dict(m.named_parameters())
+    flat = np.concatenate([named[k].grad.detach().cpu().numpy().reshape(-1) for k in sorted(named)])
+    assert _relmax(flat, g["eval.grads_flat"]) < 2e-4

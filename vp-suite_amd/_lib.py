@@ -84,7 +84,7 @@ def lib():
         L.vpx_stlstm_step_fwd.restype = ctypes.c_int
         L.vpx_stlstm_step_fwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 9 + [vp] + [vp] * 5 + [vp, sz, vp, sz, vp]
         L.vpx_stlstm_step_bwd.restype = ctypes.c_int
-        L.vpx_stlstm_step_bwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 11 + [vp, sz] + [vp] * 5 + [vp] * 9 + [vp, sz, vp]
+        L.vpx_stlstm_step_bwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 11 + [vp] + [vp, sz] + [vp] * 5 + [vp] * 9 + [vp] + [vp, sz, vp]
         L.vpx_decouple_workspace_bytes.restype = sz
         L.vpx_decouple_workspace_bytes.argtypes = [ctypes.c_int] * 4
         L.vpx_decouple_fwd.restype = ctypes.c_int

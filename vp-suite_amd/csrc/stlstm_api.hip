@@ -28,7 +28,6 @@ int check_st_desc(const vpx_stlstm_desc* d) {
     if (d->B < 1 || d->Cin < 1 || d->Ch < 1 || d->H < 1 || d->W < 1) { set_error("stlstm desc: non-positive dimension"); return VPX_ERR_ARG; }
     if (d->k < 1 || !(d->k & 1) || d->k > 7) { set_error("stlstm desc: filter size must be odd and <= 7 (got %d)", d->k); return VPX_ERR_ARG; }
     if (d->layout != VPX_LAYOUT_NHWC && d->layout != VPX_LAYOUT_NCHW) { set_error("stlstm desc: unknown layout %d", d->layout); return VPX_ERR_ARG; }
-    if (d->layer_norm) { set_error("stlstm: the LayerNorm variant (predrnn.py:24-40) is not implemented yet"); return VPX_ERR_UNSUPPORTED; }
     if ((d->precision < VPX_PREC_F32 || d->precision > VPX_PREC_BF16)) { set_error("stlstm: precision %d not implemented", d->precision); return VPX_ERR_UNSUPPORTED; }
     return VPX_OK;
 }
@@ -69,6 +68,7 @@ size_t vpx_stlstm_reserve_bytes(const vpx_stlstm_desc* d) {
     STLayout L;
     if (check_st_desc(d) != VPX_OK || st_layout(d, L) != VPX_OK) return 0;
     if (!(d->flags & VPX_FLAG_SAVE_FOR_BWD)) return 0;
+    if (d->layer_norm) return stlstm_ln_reserve_bytes(d);
     // gates_c (3Ch) + gates_m (3Ch) + o + tanh(conv_last): 8 state-sized planes
     return 2 * align256(3 * L.n_state * 4) + 2 * align256(L.n_state * 4);
 }
@@ -76,6 +76,7 @@ size_t vpx_stlstm_reserve_bytes(const vpx_stlstm_desc* d) {
 size_t vpx_stlstm_workspace_bytes(const vpx_stlstm_desc* d) {
     STLayout L;
     if (check_st_desc(d) != VPX_OK || st_layout(d, L) != VPX_OK) return 0;
+    if (d->layer_norm) return stlstm_ln_workspace_bytes(d);
     size_t b = align256(L.wpk_c * 4) + align256(L.wpk_m * 4) + align256(L.wpk_o * 4) + align256(L.wpk_l * 4);
     b += 2 * align256(L.n_state * 4);  // o_pre, lc
     if (d->layout == VPX_LAYOUT_NCHW) b += align256(L.n_x * 4) + 8 * align256(L.n_state * 4);
@@ -115,6 +116,28 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
     float* o_pre = ws.take(L.n_state);
     float* lc = ws.take(L.n_state);
 
+    if (d->layer_norm) {  // unfused LayerNorm path (stlstm_ln_api.hip); same layout adaptation around it
+        if (!ln) { set_error("vpx_stlstm_step_fwd: layer_norm set but ln is NULL"); return VPX_ERR_ARG; }
+        Carver w2{(char*)workspace, 0, workspace_bytes};
+        w2.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+        const float *xn = x, *hn = h, *cn = c, *mn = m;
+        float *outs[5] = {h_new, c_new, m_new, delta_c, delta_m}, *outn[5] = {h_new, c_new, m_new, delta_c, delta_m};
+        if (d->layout == VPX_LAYOUT_NCHW) {
+            float* bx = w2.take(L.n_x);
+            float* st[8];
+            for (auto& p : st) p = w2.take(L.n_state);
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B, Cin, H, Wd, stream)); xn = bx;
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(h, st[0], B, Ch, H, Wd, stream)); hn = st[0];
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(c, st[1], B, Ch, H, Wd, stream)); cn = st[1];
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(m, st[2], B, Ch, H, Wd, stream)); mn = st[2];
+            for (int i = 0; i < 5; ++i) outn[i] = st[3 + i];
+        }
+        rc = stlstm_ln_fwd(d, xn, hn, cn, mn, Wx, Wh, Wm, Wo, Wlast, ln, outn[0], outn[1], outn[2], outn[3], outn[4], reserve, w2, stream);
+        if (rc != VPX_OK) return rc;
+        if (d->layout == VPX_LAYOUT_NCHW)
+            for (int i = 0; i < 5; ++i) VPX_CHECK_HIP(launch_nhwc_to_nchw(outn[i], outs[i], B, Ch, H, Wd, stream));
+        return VPX_OK;
+    }
     const float *xn = x, *hn = h, *cn = c, *mn = m;
     float *hO = h_new, *cO = c_new, *mO = m_new, *dcO = delta_c, *dmO = delta_m;
     if (d->layout == VPX_LAYOUT_NCHW) {
@@ -220,7 +243,6 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         VPX_CHECK_HIP(launch_nhwc_to_nchw(dcO, delta_c, B, Ch, H, Wd, stream));
         VPX_CHECK_HIP(launch_nhwc_to_nchw(dmO, delta_m, B, Ch, H, Wd, stream));
     }
-    (void)ln;
     return VPX_OK;
 }
 

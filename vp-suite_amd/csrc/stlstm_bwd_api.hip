@@ -107,12 +107,12 @@ int run_wgrad(const vpx_stlstm_desc* d, const STBwdLayout& L, const float* dG, i
 extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c,
                                    const float* m, const float* c_new, const float* m_new, const float* Wx,
                                    const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
-                                   const void* reserve, size_t reserve_bytes, const float* dh_new, const float* dc_new,
-                                   const float* dm_new, const float* ddelta_c, const float* ddelta_m, float* dx,
-                                   float* dh, float* dc, float* dm, float* dWx, float* dWh, float* dWm, float* dWo,
-                                   float* dWlast, void* workspace, size_t workspace_bytes, void* stream_) {
+                                   const float* const* ln, const void* reserve, size_t reserve_bytes,
+                                   const float* dh_new, const float* dc_new, const float* dm_new, const float* ddelta_c,
+                                   const float* ddelta_m, float* dx, float* dh, float* dc, float* dm, float* dWx,
+                                   float* dWh, float* dWm, float* dWo, float* dWlast, float* const* dln, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
     if (!d) { set_error("stlstm desc is NULL"); return VPX_ERR_ARG; }
-    if (d->layer_norm) { set_error("stlstm: the LayerNorm variant is not implemented yet"); return VPX_ERR_UNSUPPORTED; }
     if ((d->precision < VPX_PREC_F32 || d->precision > VPX_PREC_BF16)) { set_error("stlstm: precision %d not implemented", d->precision); return VPX_ERR_UNSUPPORTED; }
     if (!(d->flags & VPX_FLAG_SAVE_FOR_BWD)) { set_error("vpx_stlstm_step_bwd: desc lacks VPX_FLAG_SAVE_FOR_BWD"); return VPX_ERR_ARG; }
     if (!x || !h || !c || !m || !c_new || !m_new || !Wx || !Wh || !Wm || !Wo || !Wlast || !reserve) {
@@ -128,6 +128,14 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     const int B = d->B, Cin = d->Cin, Ch = d->Ch, H = d->H, Wd = d->W, k = d->k;
     const size_t HW = (size_t)H * Wd;
     const int ldG = 7 * Ch;
+    if (d->layer_norm) {
+        if (!ln) { set_error("vpx_stlstm_step_bwd: layer_norm set but ln is NULL"); return VPX_ERR_ARG; }
+        if (d->layout != VPX_LAYOUT_NHWC) { set_error("vpx_stlstm_step_bwd: the LayerNorm variant's backward takes NHWC buffers only"); return VPX_ERR_UNSUPPORTED; }
+        Carver w2{(char*)workspace, 0, workspace_bytes};
+        w2.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+        return stlstm_ln_bwd(d, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, ln, reserve, dh_new, dc_new, dm_new, ddelta_c, ddelta_m,
+                             dx, dh, dc, dm, dWx, dWh, dWm, dWo, dWlast, dln, w2, stream);
+    }
 
     Carver ws{(char*)workspace, 0, workspace_bytes};
     ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;

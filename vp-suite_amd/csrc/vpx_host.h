@@ -131,7 +131,95 @@ static inline size_t convlstm_bwd_workspace_bytes(const vpx_convlstm_desc* d, co
     return b;
 }
 
-// backward workspace of one ST-LSTM step (stlstm_bwd_api.hip); 0 until that file provides a real figure
+// ---- plain stride-1 'same' convolution / weight gradient on NHWC tensors (shared by conv_api, stlstm LN path) ----
+struct ConvGeo { int N, H, W; };
+
+// y (+)= conv(src; w) with Co outputs; `transposed`: contraction over w's O axis (data gradient). Returns packed floats used.
+static inline int plain_conv(hipStream_t stream, int prec, ConvGeo g, const float* src, int C, int ld, const float* w, long long ld_o,
+               int ld_i, int kh, int kw, int Co, bool transposed, const float* bias, float* out, int out_ld,
+               bool accumulate, float* wpk) {
+    ConvPlan P{};
+    int chunks = 0;
+    const int segC[1] = {C};
+    P.prec = prec;
+    P.nstage = build_stages(P.stage, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, plain_groups(Co), prec), prec);
+    if (P.nstage < 0) { set_error("conv: too many channel stages (C=%d)", C); return VPX_ERR_UNSUPPORTED; }
+    PackDesc pd{};
+    pd.seg[0] = PackSeg{w, ld_o, ld_i, 0, C};
+    memcpy(pd.stage, P.stage, sizeof(ConvStage) * P.nstage);
+    pd.nstage = P.nstage; pd.chunks_total = chunks; pd.prec = prec; pd.taps = kh * kw;
+    fill_plain_pack(pd, Co, 0);
+    pd.transposed = transposed ? 1 : 0; pd.flip = transposed ? 1 : 0;
+    VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+    P.B = g.N; P.H = g.H; P.W = g.W; P.kh = kh; P.kw = kw;
+    set_plan_tiles(P, 1);
+    P.nseg = 1;
+    P.seg[0] = ConvSeg{src, (long long)g.H * g.W * ld, C, ld};
+    P.chunks_total = chunks;
+    P.a_bytes = conv_a_bytes(P.stage, P.nstage, kh, kw);
+    P.wpk = wpk;
+    PlainEpiArgs ea{};
+    ea.bias = bias; ea.Co = Co; ea.split = Co; ea.ng = plain_groups(Co);
+    ea.out0 = out; ea.bstride0 = (long long)g.H * g.W * out_ld; ea.ld0 = out_ld;
+    ea.accumulate = accumulate ? 1 : 0;
+    VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, pd.n_tiles, stream));
+    return VPX_OK;
+}
+
+static inline size_t plain_conv_wpk_floats(int C, int Co, int kh, int kw) {
+    size_t best = 0;
+    ConvStage st[MAX_STAGE];
+    for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16; ++prec) {
+        int chunks = 0;
+        const int segC[1] = {C};
+        if (build_stages(st, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, plain_groups(Co), prec), prec) < 0) return 0;
+        const size_t b = packed_weight_bytes(plain_tiles(Co), chunks, plain_groups(Co), prec) / 4;
+        if (b > best) best = b;
+    }
+    return best;
+}
+
+static inline int wgrad_slices(int N, int H, int W) {
+    const long long items = (long long)N * ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+    return (int)(items < 32 ? items : 32);
+}
+
+// dw[Co, C, kh, kw] (+)= wgrad(dy [N,HW,Co], x [N,HW,C])
+static inline int plain_wgrad(hipStream_t stream, int prec, ConvGeo g, const float* dy, int Co, const float* x, int C, int kh, int kw,
+                float* slabs, float* dw) {
+    WgradArgs wa{};
+    wa.T = 1; wa.B = g.N; wa.H = g.H; wa.W = g.W; wa.HW = g.H * g.W; wa.kh = kh; wa.kw = kw;
+    wa.tiles_x = (g.W + TILE_W - 1) / TILE_W; wa.tiles_y = (g.H + TILE_H - 1) / TILE_H;
+    wa.N4 = Co; wa.Cin = C; wa.Ch = 1; wa.Ct = C; wa.ldG = Co; wa.n_out = Co; wa.prec = prec;
+    wa.dG = dy; wa.x = x; wa.x_bstride = (long long)wa.HW * C;
+    wa.n_ctiles = 0;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        if (wa.n_ctiles >= 16) { set_error("conv wgrad: too many input channels (%d)", C); return VPX_ERR_UNSUPPORTED; }
+        wa.ct[wa.n_ctiles++] = WgradCTile{0, c0, (C - c0 < 64) ? C - c0 : 64, c0};
+    }
+    wa.slabs = slabs;
+    const int ns = wgrad_slices(g.N, g.H, g.W);
+    VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, (size_t)ns * kh * kw * Co * C * sizeof(float), stream));
+    VPX_CHECK_HIP(launch_wgrad(wa, ns, stream));
+    VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dw, ns, kh * kw, Co, C, stream));
+    return VPX_OK;
+}
+
+
+// backward workspace of one ST-LSTM step (stlstm_bwd_api.hip)
 size_t stlstm_bwd_workspace_bytes(const vpx_stlstm_desc* d);
+// LayerNorm variant (stlstm_ln_api.hip)
+size_t stlstm_ln_reserve_bytes(const vpx_stlstm_desc* d);
+size_t stlstm_ln_workspace_bytes(const vpx_stlstm_desc* d);
+int stlstm_ln_fwd(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c, const float* m,
+                  const float* Wx, const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
+                  const float* const* ln, float* h_new, float* c_new, float* m_new, float* delta_c, float* delta_m,
+                  void* reserve, Carver& ws, hipStream_t stream);
+int stlstm_ln_bwd(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c, const float* m,
+                  const float* Wx, const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
+                  const float* const* ln, const void* reserve, const float* dh_new, const float* dc_new,
+                  const float* dm_new, const float* ddc, const float* ddm, float* dx, float* dh, float* dc, float* dm,
+                  float* dWx, float* dWh, float* dWm, float* dWo, float* dWlast, float* const* dln, Carver& ws,
+                  hipStream_t stream);
 
 }  // namespace vpx

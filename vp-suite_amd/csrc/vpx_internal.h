@@ -211,6 +211,23 @@ struct STBwdGateArgs {        // stage B: through the two gate groups
     float* dc;                // out: dL/dc (may be null)
     float* dm;                // out: direct part of dL/dm = dm_new_total * f' (conv part is accumulated later)
 };
+// ---- LayerNorm ST-LSTM variant (layernorm.hip) ----
+hipError_t launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* xhat,
+                                float* stats, double* partial, int B, long long n, hipStream_t s);
+hipError_t launch_layernorm_bwd(const float* dy, int ldy, int Cb, const int* blk, const float* xhat, const float* stats,
+                                const float* gamma, int B, int HW, int C, double* partial, float* sums, float* du,
+                                float* dgamma, float* dbeta, hipStream_t s);
+struct STLNGateArgs {
+    long long npix; int Ch;
+    const float* xc; const float* hc; const float* mc;   // normalised conv outputs [B,HW,7Ch] / [..,4Ch] / [..,3Ch]
+    const float* c; const float* m;
+    float* c_new; float* m_new; float* delta_c; float* delta_m; float* o_pre;
+    float* mem;                 // [B,HW,2Ch] = cat(c_new, m_new)
+    float* gates_c; float* gates_m;   // [B,HW,3Ch] each or null
+};
+hipError_t launch_st_ln_gates(const STLNGateArgs& a, hipStream_t s);
+hipError_t launch_st_ln_out(const float* o_pre, const float* oc, const float* lc, float* h_new, float* o_save,
+                            float* tl_save, long long n, hipStream_t s);
 hipError_t launch_st_bwd_out(const STBwdOutArgs& a, hipStream_t s);
 hipError_t launch_st_bwd_gates(const STBwdGateArgs& a, hipStream_t s);
 

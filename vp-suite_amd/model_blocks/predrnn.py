@@ -3,8 +3,8 @@
 Same constructor signature and parameter tree (`conv_x.0.weight [7Ch,Cin,k,k]`, `conv_h.0.weight [4Ch,Ch,k,k]`,
 `conv_m.0.weight [3Ch,Ch,k,k]`, `conv_o.0.weight [Ch,2Ch,k,k]`, `conv_last.weight [Ch,2Ch,1,1]`, all bias-free) and the
 same return tuple `(h_new, c_new, m_new, delta_c, delta_m)`. The five convolutions + gate math of :57-83 run as four
-fused implicit-GEMM launches (csrc/stlstm_api.hip). The action-conditional twin (:86-169) is out of scope
-(SURVEY.md §2 row 3); the LayerNorm variant is declared but not yet implemented by the library (fails loudly)."""
+fused implicit-GEMM launches (csrc/stlstm_api.hip); with layer_norm=True the convolutions are normalised one by one
+(csrc/stlstm_ln_api.hip, csrc/layernorm.hip). The action-conditional twin (:86-169) is out of scope."""
 from torch import nn
 
 from .. import ops
@@ -47,7 +47,9 @@ class SpatioTemporalLSTMCell(VPModelBlock):
         return state
 
     def forward(self, x_t, h_t, c_t, m_t):
-        if self.layer_norm:
-            raise NotImplementedError("ST-LSTM with layer_norm=True is not implemented by libvpx_hip yet")
+        ln = ()
+        if self.layer_norm:  # LayerNorm([C,H,W]) after conv_x / conv_h / conv_m / conv_o (predrnn.py:24-40)
+            ln = tuple(p for seq in (self.conv_x, self.conv_h, self.conv_m, self.conv_o) for p in (seq[1].weight, seq[1].bias))
         return ops.stlstm_step(x_t, h_t, c_t, m_t, self.conv_x[0].weight, self.conv_h[0].weight, self.conv_m[0].weight,
-                               self.conv_o[0].weight, self.conv_last.weight, precision=self.precision, wsholder=self._ws)
+                               self.conv_o[0].weight, self.conv_last.weight, precision=self.precision, wsholder=self._ws,
+                               ln=ln)

@@ -346,10 +346,11 @@ class STWorkspace:
 
 
 class _STLSTMStepFn(torch.autograd.Function):
-    """(h_new, c_new, m_new, delta_c, delta_m) = ST-LSTM cell step (predrnn.py:57-83) in one library call."""
+    """(h_new, c_new, m_new, delta_c, delta_m) = ST-LSTM cell step (predrnn.py:57-83) in one library call.
+    `ln` = () or the 8 LayerNorm tensors (x_gamma, x_beta, h_gamma, h_beta, m_gamma, m_beta, o_gamma, o_beta)."""
 
     @staticmethod
-    def forward(ctx, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision, need_grad, wsholder):
+    def forward(ctx, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision, need_grad, wsholder, *ln):
         _require_gpu(x, "stlstm_step")
         dev = x.device
         B, Cin, H, Wd = x.shape
@@ -357,15 +358,17 @@ class _STLSTMStepFn(torch.autograd.Function):
         k = int(Wx.shape[-1])
         xs, hs, cs, ms = (to_channels_last(t) for t in (x, h, c, m))
         W5 = [w.contiguous() for w in (Wx, Wh, Wm, Wo, Wlast)]
+        lnc = [t.contiguous() for t in ln]
+        use_ln = len(lnc) == 8
         flags = _lib.FLAG_SAVE_FOR_BWD if need_grad else 0
-        d = STLSTMDesc(B, Cin, Ch, H, Wd, k, 0, _lib.LAYOUT_NHWC, precision, flags)
+        d = STLSTMDesc(B, Cin, Ch, H, Wd, k, int(use_ln), _lib.LAYOUT_NHWC, precision, flags)
         L = _lib.lib()
         ws_bytes = L.vpx_stlstm_workspace_bytes(ctypes.byref(d))
         if ws_bytes == 0:
             check(-4 if b"not implemented" in L.vpx_last_error() else -1, "vpx_stlstm_workspace_bytes")
         rs_bytes = L.vpx_stlstm_reserve_bytes(ctypes.byref(d))
         key = (B, Cin, Ch, H, Wd, k, precision, flags, tuple((w.data_ptr(), w._version) for w in W5))
-        if wsholder is not None:
+        if wsholder is not None and not use_ln:
             ws, packed = wsholder.get(ws_bytes, dev, key)
         else:
             ws, packed = torch.empty(ws_bytes, dtype=torch.uint8, device=dev), False
@@ -373,10 +376,11 @@ class _STLSTMStepFn(torch.autograd.Function):
             d.flags |= _lib.FLAG_WEIGHTS_PACKED
         reserve = torch.empty(max(rs_bytes, 1), dtype=torch.uint8, device=dev)
         outs = [new_channels_last((B, Ch, H, Wd), dev) for _ in range(5)]
+        ln_arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in lnc]) if use_ln else None
         if PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        rc = L.vpx_stlstm_step_fwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), *[ptr(w) for w in W5], None,
+        rc = L.vpx_stlstm_step_fwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), *[ptr(w) for w in W5], ln_arr,
                                    *[ptr(o) for o in outs], ptr(reserve), rs_bytes, ptr(ws), ws_bytes, _stream())
         check(rc, "vpx_stlstm_step_fwd")
         if PROFILE is not None:
@@ -384,15 +388,18 @@ class _STLSTMStepFn(torch.autograd.Function):
             fl, by = stlstm_algorithmic_work(B, Cin, Ch, H, Wd, k)
             PROFILE.records.append((ev0, ev1, fl, by, 4, "stlstm_fwd"))
         if need_grad:
-            ctx.save_for_backward(xs, hs, cs, ms, outs[1], outs[2], *W5, reserve)
+            ctx.save_for_backward(xs, hs, cs, ms, outs[1], outs[2], *W5, reserve, *lnc)
             d.flags = flags
             ctx.desc = d
             ctx.rs_bytes = rs_bytes
+            ctx.use_ln = use_ln
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, dh_new, dc_new, dm_new, ddc, ddm):
-        xs, hs, cs, ms, c_new, m_new, Wx, Wh, Wm, Wo, Wlast, reserve = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        xs, hs, cs, ms, c_new, m_new, Wx, Wh, Wm, Wo, Wlast, reserve = saved[:12]
+        lnc = list(saved[12:])
         d = ctx.desc
         dev = xs.device
         L = _lib.lib()
@@ -403,14 +410,17 @@ class _STLSTMStepFn(torch.autograd.Function):
         dc = new_channels_last(tuple(cs.shape), dev) if needs[2] else None
         dm = new_channels_last(tuple(ms.shape), dev) if needs[3] else None
         dWs = [torch.empty_like(w) if needs[4 + i] else None for i, w in enumerate((Wx, Wh, Wm, Wo, Wlast))]
+        dln = [torch.empty_like(t) if needs[12 + i] else None for i, t in enumerate(lnc)]
+        ln_arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in lnc]) if ctx.use_ln else None
+        dln_arr = (ctypes.c_void_p * 8)(*[None if t is None else t.data_ptr() for t in dln]) if ctx.use_ln else None
         ws_bytes = L.vpx_stlstm_workspace_bytes(ctypes.byref(d))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         rc = L.vpx_stlstm_step_bwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), ptr(c_new), ptr(m_new), ptr(Wx),
-                                   ptr(Wh), ptr(Wm), ptr(Wo), ptr(Wlast), ptr(reserve), ctx.rs_bytes,
+                                   ptr(Wh), ptr(Wm), ptr(Wo), ptr(Wlast), ln_arr, ptr(reserve), ctx.rs_bytes,
                                    *[ptr(g) for g in gin], ptr(dx), ptr(dh), ptr(dc), ptr(dm), *[ptr(g) for g in dWs],
-                                   ptr(ws), ws_bytes, _stream())
+                                   dln_arr, ptr(ws), ws_bytes, _stream())
         check(rc, "vpx_stlstm_step_bwd")
-        return (dx, dh, dc, dm, *dWs, None, None, None)
+        return (dx, dh, dc, dm, *dWs, None, None, None, *dln)
 
 
 def stlstm_algorithmic_work(B, Cin, Ch, H, W, k, dt=4):
@@ -421,6 +431,10 @@ def stlstm_algorithmic_work(B, Cin, Ch, H, W, k, dt=4):
     return flops, nbytes
 
 
-def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=None):
-    need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (x, h, c, m, Wx, Wh, Wm, Wo, Wlast))
-    return _STLSTMStepFn.apply(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, PRECISIONS[precision], need_grad, wsholder)
+def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=None, ln=()):
+    """ln: () or the 8 LayerNorm parameter tensors [C,H,W] (x_gamma, x_beta, h_.., m_.., o_..) of the LayerNorm variant."""
+    ln = tuple(ln)
+    if len(ln) not in (0, 8):
+        raise ValueError("stlstm_step: ln must hold 0 or 8 tensors")
+    need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (x, h, c, m, Wx, Wh, Wm, Wo, Wlast) + ln)
+    return _STLSTMStepFn.apply(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, PRECISIONS[precision], need_grad, wsholder, *ln)
