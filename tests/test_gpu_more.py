@@ -66,8 +66,8 @@ def test_stlstm_c_abi_nchw(vpx):
     dins = [torch.empty_like(inp[n]) for n in ("x", "h", "c", "m")]
     dWs = [torch.empty_like(w) for w in Ws]
     rc = L.vpx_stlstm_step_bwd(ctypes.byref(d), p(inp["x"]), p(inp["h"]), p(inp["c"]), p(inp["m"]), p(outs[1]), p(outs[2]),
-                               *[p(w) for w in Ws], p(rs), rs_bytes, *[p(t) for t in grads_in], *[p(t) for t in dins],
-                               *[p(t) for t in dWs], p(ws), ws_bytes, None)
+                               *[p(w) for w in Ws], None, p(rs), rs_bytes, *[p(t) for t in grads_in],
+                               *[p(t) for t in dins], *[p(t) for t in dWs], None, p(ws), ws_bytes, None)
     assert rc == 0, L.vpx_last_error()
     torch.cuda.synchronize()
     for t, n in zip(dins, ("dx", "dh", "dc", "dm")):
