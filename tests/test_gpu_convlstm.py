@@ -288,3 +288,21 @@ def test_real_block_shapes_bwd_bf16x3_vs_oracle(vpx, dev, Cin, Ch, H, W):
     (out * g_out.to(dev)).sum().backward()
     for n in P:
         assert _relmax(lv[n].grad, ref[n].grad) < 1e-4, n
+
+
+def test_eight_wave_workgroup_variant_vs_oracle(vpx, dev):
+    """Launches with >= 512 workgroups use the 8-wave (16x16 tile) form of the bf16x3 kernel; make sure that path is
+    exercised (B=16 on a 64x64 map = 512 workgroups) and matches the fp32 oracle, ragged image edges included."""
+    from oracle import torch_ref as tr
+    for (Cin, Ch, H, W, B) in [(16, 64, 64, 64, 16), (8, 32, 72, 40, 24)]:
+        T, k = 2, 3
+        tag = f"mw2.{Cin}.{Ch}.{H}"
+        Wt = seeded_randn((4 * Ch, Cin + Ch, k, k), name_seed(tag + "W"), 1.0 / np.sqrt((Cin + Ch) * 9))
+        b = seeded_randn((4 * Ch,), name_seed(tag + "b"), 0.1)
+        pw = [seeded_randn((1, Ch, H, W), name_seed(tag + n), 0.1) for n in ("ci", "cf", "co")]
+        x = seeded_rand((B, T, Cin, H, W), name_seed(tag + "x"))
+        with torch.no_grad():
+            ro, (rh, rc) = tr.convlstm_hzzone_seq(x, None, T, Wt, b, *pw, padding=1)
+            out, hT, cT = vpx.ops.convlstm_seq(x.to(dev), None, None, Wt.to(dev), b.to(dev), *[p.to(dev) for p in pw],
+                                               seq_len=T, in_channels=Cin, precision="bf16x3")
+        assert _relmax(out, ro) < 2e-5 and _relmax(cT, rc) < 2e-5

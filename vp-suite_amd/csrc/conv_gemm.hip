@@ -267,8 +267,12 @@ template <> struct ModeTraits<0> { static constexpr int KSTEP = 8, KC = 16, WROW
 template <> struct ModeTraits<1> { static constexpr int KSTEP = 16, KC = 32, WROW_DATA = 32 * 4; };
 template <> struct ModeTraits<2> { static constexpr int KSTEP = 16, KC = 32, WROW_DATA = 32 * 4; };  // plain bf16: hi planes only are read
 
+// MW = 1: 4 waves (256 threads) per workgroup, 8x16 pixel tile. MW = 2: 8 waves (512 threads), 16x16 tile — twice the
+// pixels share every weight chunk (the L2->CU load pipe, ~70 GB/s per CU, is what limits the bf16 modes), at <= 128
+// registers so that two such workgroups (16 waves) stay resident per CU.
 template <class Epi, int MODE, int MW>
-__global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
+__global__ __launch_bounds__(NTHREADS * MW, (MW == 2 ? 4 : 3)) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
+    constexpr int NTH = NTHREADS * MW;
     using MT = ModeTraits<MODE>;
     constexpr int KC = MT::KC, KSTEP = MT::KSTEP;
     constexpr int WROW = MT::WROW_DATA + 16;   // padded LDS row of one output channel's chunk slice (odd multiple of 16 B)
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
     constexpr int NTR = NG * 32;               // weight rows (gate groups x 32 channels) per workgroup
     constexpr int WBUF = NTR * WROW;           // one LDS weight buffer
     constexpr int WV4 = NTR * MT::WROW_DATA / 16;              // 16-byte vectors per weight chunk
-    constexpr int WIT = (WV4 + NTHREADS - 1) / NTHREADS;       // staging loads per thread per chunk
+    constexpr int WIT = (WV4 + NTH - 1) / NTH;                 // staging loads per thread per chunk
     constexpr int V4ROW = MT::WROW_DATA / 16;                  // 16-byte vectors per weight row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -300,16 +304,14 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
     char* A_lds = smem;
     char* W_lds = smem + P.a_bytes;
 
-    f32x16 acc[MW][NG];
+    f32x16 acc[NG];
 #pragma unroll
-    for (int m = 0; m < MW; ++m)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][g][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
 
-    // this lane's pixel inside the tile (MFMA row = lane & 31); MFMA tile m of the wave sits 2 rows further down
-    const int py = 2 * MW * wave + (j >> 4), px = j & 15;
+    // this lane's pixel inside the tile (MFMA row = lane & 31): wave w owns tile rows 2w and 2w+1
+    const int py = 2 * wave + (j >> 4), px = j & 15;
     const char* wtile = reinterpret_cast<const char*>(P.wpk) + (size_t)n_tile * P.chunks_total * (NTR * MT::WROW_DATA);
 
     // ---- K loop ------------------------------------------------------------------------------------------------
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
             const f32x4* src = chunk_src(ps, pck);
 #pragma unroll
             for (int it = 0; it < WIT; ++it)
-                if (tid + it * NTHREADS < WV4 && wload) wr[it] = src[tid + it * NTHREADS];
+                if (tid + it * NTH < WV4 && wload) wr[it] = src[tid + it * NTH];
             if (++pck == stage_chunks(ps)) { pck = 0; ++ps; }
         }
     };
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
         char* wdst = W_lds + buf * WBUF;
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
-            const int v = tid + it * NTHREADS;
+            const int v = tid + it * NTH;
             if (v < WV4) *reinterpret_cast<f32x4*>(wdst + (v / V4ROW) * WROW + (v % V4ROW) * 16) = wr[it];
         }
     };
@@ -364,30 +366,64 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
                 const int ld = sg.ld ? sg.ld : sg.C;
                 if (((sg.C | ld) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
                     const int v4n = st.cn >> 2;
-                    const int total = npos * v4n;
-                    for (int v = tid; v < total; v += NTHREADS) {
-                        const int pos = v / v4n, c4 = v - pos * v4n;
-                        const int hy = pos / halo_w, hx = pos - hy * halo_w;
-                        const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
+                    if ((v4n & (v4n - 1)) == 0 && !(P.dbg & 16)) {
+                        // cn/4 is a power of two (always for 16/32/64-channel stages): 256 threads cover 256/v4n halo
+                        // positions per pass and (pos, hy, hx) advance by constants — no integer division in the loop
+                        const int sh = 31 - __builtin_clz(v4n);
+                        const int c4 = tid & (v4n - 1);
+                        const int dpos = NTH >> sh;
+                        const int dhy = dpos / halo_w, dhx = dpos - dhy * halo_w;
+                        int pos = tid >> sh;
+                        int hy = pos / halo_w, hx = pos - hy * halo_w;
                         const int c = st.c0 + c4 * 4;
-                        f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                        if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win && c < sg.C && !(P.dbg & 2))
-                            val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * Win + gx) * ld + c);
-                        if constexpr (MODE == 0) {
-                            *reinterpret_cast<f32x4*>(A_lds + pos * arow + c4 * 16) = val;
-                        } else {
-                            unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-                            split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);
-                            split_bf16(val[2], h2, l2); split_bf16(val[3], h3, l3);
-                            uint2 hv = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
-                            uint2 lv = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
-                            *reinterpret_cast<uint2*>(A_lds + pos * arow + c4 * 8) = hv;
-                            *reinterpret_cast<uint2*>(A_lds + pos * arow + st.cn * 2 + c4 * 8) = lv;
+                        const bool c_ok = c < sg.C && !(P.dbg & 2);
+                        const float* srcc = src + c;
+                        char* dstc = A_lds + (MODE == 0 ? c4 * 16 : c4 * 8);
+                        for (; pos < npos; pos += dpos) {
+                            const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
+                            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                            if (c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win)
+                                val = *reinterpret_cast<const f32x4*>(srcc + ((size_t)gy * Win + gx) * ld);
+                            if constexpr (MODE == 0) {
+                                *reinterpret_cast<f32x4*>(dstc + pos * arow) = val;
+                            } else {
+                                unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+                                split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);
+                                split_bf16(val[2], h2, l2); split_bf16(val[3], h3, l3);
+                                uint2 hv = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
+                                uint2 lv = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
+                                *reinterpret_cast<uint2*>(dstc + pos * arow) = hv;
+                                *reinterpret_cast<uint2*>(dstc + pos * arow + st.cn * 2) = lv;
+                            }
+                            hx += dhx; hy += dhy;
+                            if (hx >= halo_w) { hx -= halo_w; ++hy; }
+                        }
+                    } else {
+                        const int total = npos * v4n;
+                        for (int v = tid; v < total; v += NTH) {
+                            const int pos = v / v4n, c4 = v - pos * v4n;
+                            const int hy = pos / halo_w, hx = pos - hy * halo_w;
+                            const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
+                            const int c = st.c0 + c4 * 4;
+                            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                            if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win && c < sg.C && !(P.dbg & 2))
+                                val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * Win + gx) * ld + c);
+                            if constexpr (MODE == 0) {
+                                *reinterpret_cast<f32x4*>(A_lds + pos * arow + c4 * 16) = val;
+                            } else {
+                                unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+                                split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);
+                                split_bf16(val[2], h2, l2); split_bf16(val[3], h3, l3);
+                                uint2 hv = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
+                                uint2 lv = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
+                                *reinterpret_cast<uint2*>(A_lds + pos * arow + c4 * 8) = hv;
+                                *reinterpret_cast<uint2*>(A_lds + pos * arow + st.cn * 2 + c4 * 8) = lv;
+                            }
                         }
                     }
                 } else {
                     const int total = npos * st.cn;
-                    for (int e = tid; e < total; e += NTHREADS) {
+                    for (int e = tid; e < total; e += NTH) {
                         const int pos = e / st.cn, cc = e - pos * st.cn;
                         const int hy = pos / halo_w, hx = pos - hy * halo_w;
                         const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
@@ -426,10 +462,7 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
                 if (P.dbg & 1) {
                 } else if constexpr (MODE == 0) {
                     // fp32: one b128 = 4 consecutive channels; lanes 0-31 take k = 8*ks + s, lanes 32-63 k = 8*ks + 4 + s
-                    f32x4 a4[MW];
-#pragma unroll
-                    for (int m = 0; m < MW; ++m)
-                        a4[m] = *reinterpret_cast<const f32x4*>(a_lane + m * 2 * sd * halo_w * arow + tapoff + ks * 32);
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(a_lane + tapoff + ks * 32);
                     f32x4 b4[NG];
 #pragma unroll
                     for (int g = 0; g < NG; ++g)
@@ -437,35 +470,36 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int m = 0; m < MW; ++m)
-#pragma unroll
-                            for (int g = 0; g < NG; ++g)
-                                acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m][k], b4[g][k], acc[m][g], 0, 0, 0);
+                        for (int g = 0; g < NG; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k], b4[g][k], acc[g], 0, 0, 0);
                 } else {
                     // bf16x3: one b128 = 8 consecutive channels; lanes 0-31 take k = 16*ks + 0..7, lanes 32-63 + 8..15
-                    bf16x8 ah[MW], al[MW];
+                    const char* ap = a_lane + tapoff + ks * 32;
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+                    bf16x8 al;
+                    if constexpr (MODE == 1) al = *reinterpret_cast<const bf16x8*>(ap + st.cn * 2);
+                    // gates in pairs: keeps the live weight fragments at 2 x (hi, lo) = 16 registers (128-register budget)
 #pragma unroll
-                    for (int m = 0; m < MW; ++m) {
-                        const char* ap = a_lane + m * 2 * sd * halo_w * arow + tapoff + ks * 32;
-                        ah[m] = *reinterpret_cast<const bf16x8*>(ap);
-                        if constexpr (MODE == 1) al[m] = *reinterpret_cast<const bf16x8*>(ap + st.cn * 2);
-                    }
-                    bf16x8 bh[NG], bl[NG];
+                    for (int g0 = 0; g0 < NG; g0 += 2) {
+                        bf16x8 bh[2], bl[2];
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        bh[g] = *reinterpret_cast<const bf16x8*>(wb + g * 32 * WROW + q * 32);
-                        if constexpr (MODE == 1) bl[g] = *reinterpret_cast<const bf16x8*>(wb + g * 32 * WROW + KC * 2 + q * 32);
-                    }
-#pragma unroll
-                    for (int m = 0; m < MW; ++m) {
-                        if constexpr (MODE == 1) {  // bf16x3: the two cross terms; plain bf16 (MODE 2) keeps hi*hi only
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[g], acc[m][g], 0, 0, 0);
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[g], acc[m][g], 0, 0, 0);
+                        for (int gg = 0; gg < 2; ++gg) {
+                            if (g0 + gg < NG) {
+                                bh[gg] = *reinterpret_cast<const bf16x8*>(wb + (g0 + gg) * 32 * WROW + q * 32);
+                                if constexpr (MODE == 1)
+                                    bl[gg] = *reinterpret_cast<const bf16x8*>(wb + (g0 + gg) * 32 * WROW + KC * 2 + q * 32);
+                            }
                         }
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[g], acc[m][g], 0, 0, 0);
+                        for (int gg = 0; gg < 2; ++gg) {
+                            if (g0 + gg < NG) {
+                                if constexpr (MODE == 1) {  // bf16x3: the two cross terms; plain bf16 (MODE 2) keeps hi*hi only
+                                    acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[gg], acc[g0 + gg], 0, 0, 0);
+                                    acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[gg], acc[g0 + gg], 0, 0, 0);
+                                }
+                                acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[gg], acc[g0 + gg], 0, 0, 0);
+                            }
+                        }
                     }
                 }
                 if (++ks == ksn) {
@@ -483,20 +517,17 @@ __global__ __launch_bounds__(NTHREADS, (MW == 2 ? 2 : 3)) void conv_gemm_kernel(
             if (buf == 0) { write_lds(wrB, 1); issue_load(wrB); }
             else { write_lds(wrA, 0); issue_load(wrA); }
         }
-        __syncthreads();
+        if (!(P.dbg & 32)) __syncthreads();  // (bit 32: timing-only ablation of the per-chunk barrier; results are wrong)
         ++gidx;
         if (last_of_stage) { ck = 0; ++s; new_stage = true; } else { ++ck; }
     }
 
     if (P.dbg & 8) {  // ablation: keep the accumulators alive with one store instead of the epilogue
-        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(const_cast<float*>(P.wpk))[0] = acc[0][0][1];
+        if (acc[0][0] == 12345.678f) reinterpret_cast<float*>(const_cast<float*>(P.wpk))[0] = acc[0][1];
         return;
     }
-#pragma unroll
-    for (int m = 0; m < MW; ++m) {
-        TileCtx t{b, y0, x0, n_tile, 2 * MW * wave + 2 * m, j, hh, P.H, P.W};
-        epi(acc[m], t);
-    }
+    TileCtx t{b, y0, x0, n_tile, 2 * wave, j, hh, P.H, P.W};
+    epi(acc, t);
 }
 
 template <class Epi, int MODE, int MW>
@@ -511,7 +542,7 @@ static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tile
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(plan.B * plan.tiles_x * plan.tiles_y, n_tiles);
-    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE, MW>), grid, dim3(NTHREADS), lds, s, plan, epi);
+    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE, MW>), grid, dim3(NTHREADS * MW), lds, s, plan, epi);
     return hipGetLastError();
 }
 
@@ -613,10 +644,9 @@ int pick_mw(int B, int H, int W, int n_tiles, int prec) {
     if (forced < 0) { const char* e = getenv("VPX_MW"); forced = e ? atoi(e) : 0; }
     if (prec != VPX_PREC_BF16X3) return 1;  // MW=2 is only instantiated for bf16x3
     if (forced == 1 || forced == 2) return forced;
-    // Measured (MI355X, bf16x3, B=32): MW=2 is no faster than MW=1 on 64x64 maps (316 vs 314 TF) and slower on smaller
-    // maps (fewer workgroups) — the kernel is not LDS-read bound — so MW=2 stays an experiment switch (VPX_MW=2).
-    (void)B; (void)H; (void)W; (void)n_tiles;
-    return 1;
+    // 8-wave workgroups halve the weight traffic per pixel; worth it only when the launch still fills the chip
+    const long long wgs2 = (long long)B * ((H + 2 * TILE_H - 1) / (2 * TILE_H)) * ((W + TILE_W - 1) / TILE_W) * n_tiles;
+    return wgs2 >= 512 ? 2 : 1;
 }
 
 int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw, int stride) {
@@ -630,7 +660,7 @@ int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int p
     if (forced) return forced < kstep ? kstep : forced;
     const int npos = ((TILE_H * mw - 1) * stride + kh) * ((TILE_W - 1) * stride + kw);
     const int wbytes = 2 * ng * 32 * (mode_kc(prec) * 4 + 16);
-    const int wg_cap = mw == 2 ? 2 : 3;  // register-limited residency
+    const int wg_cap = mw == 2 ? 2 : 3;  // residency: 2 x 8 waves or 3 x 4 waves per CU (register budgets 128 / 168)
     int best = CS_MAX, best_wg = 0;
     for (int cs = kstep; cs <= CS_MAX; cs *= 2) {
         int nst = 0;
