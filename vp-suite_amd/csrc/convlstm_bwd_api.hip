@@ -122,13 +122,13 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         if (need_dx || dh_target) {
             ConvPlan P{};
             P.B = B; P.H = H; P.W = Wd; P.kh = d->kh; P.kw = d->kw;
-            P.tiles_x = (Wd + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_H - 1) / TILE_H;
+            set_plan_tiles(P, L.d_mw);
             P.nseg = 1;
             P.seg[0] = ConvSeg{ga.dG, (long long)(HW * N4), N4, 0};
             P.nstage = L.d_nstage;
             memcpy(P.stage, L.d_stage, sizeof(ConvStage) * L.d_nstage);
             P.chunks_total = L.d_chunks; P.prec = d->precision;
-            P.a_bytes = conv_a_bytes(L.d_stage, L.d_nstage, d->kh, d->kw);
+            P.a_bytes = conv_a_bytes(L.d_stage, L.d_nstage, d->kh, d->kw, L.d_mw);
             P.wpk = wpk;
             PlainEpiArgs ea{};
             ea.Co = n_out; ea.ng = plain_groups(n_out);

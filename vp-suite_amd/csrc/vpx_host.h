@@ -67,7 +67,7 @@ struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     ConvStage stage[MAX_STAGE];
     size_t n_state, n_x, n_out, n_peep;
     // backward
-    int d_nstage, d_chunks;        // data-gradient conv: K stages over the 4Ch gate axis
+    int d_nstage, d_chunks, d_mw;  // data-gradient conv: K stages over the 4Ch gate axis; rows-per-workgroup variant
     ConvStage d_stage[MAX_STAGE];
     int d_tiles_full, d_tiles_h;   // N tiles when producing [dx | dh] resp. only dh
     int n_ctiles;                  // weight-gradient: 64-channel slices of [x | h]
@@ -90,7 +90,8 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     // ---- backward sizing ----
     const int N4 = 4 * d->Ch, Ct = d->Cin + d->Ch;
     const int segD[1] = {N4};
-    L.d_nstage = build_stages(L.d_stage, &L.d_chunks, segD, 1, L.taps, pick_stage_channels(segD, 1, d->kh, d->kw, 4, d->precision), d->precision);
+    L.d_mw = pick_mw(d->B, d->H, d->W, plain_tiles(Ct), d->precision);
+    L.d_nstage = build_stages(L.d_stage, &L.d_chunks, segD, 1, L.taps, pick_stage_channels(segD, 1, d->kh, d->kw, 4, d->precision, L.d_mw), d->precision);
     if (L.d_nstage < 0) { set_error("convlstm: too many channel stages in the data-gradient conv (Ch=%d)", d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.d_tiles_full = plain_tiles(Ct);
     L.d_tiles_h = plain_tiles(d->Ch);
