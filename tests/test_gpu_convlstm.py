@@ -301,8 +301,13 @@ def test_eight_wave_workgroup_variant_vs_oracle(vpx, dev):
         b = seeded_randn((4 * Ch,), name_seed(tag + "b"), 0.1)
         pw = [seeded_randn((1, Ch, H, W), name_seed(tag + n), 0.1) for n in ("ci", "cf", "co")]
         x = seeded_rand((B, T, Cin, H, W), name_seed(tag + "x"))
-        with torch.no_grad():
-            ro, (rh, rc) = tr.convlstm_hzzone_seq(x, None, T, Wt, b, *pw, padding=1)
-            out, hT, cT = vpx.ops.convlstm_seq(x.to(dev), None, None, Wt.to(dev), b.to(dev), *[p.to(dev) for p in pw],
-                                               seq_len=T, in_channels=Cin, precision="bf16x3")
+        g_out = seeded_randn((B, T, Ch, H, W), name_seed(tag + "go"))
+        ref = {"x": x.clone().requires_grad_(True), "W": Wt.clone().requires_grad_(True)}
+        ro, (rh, rc) = tr.convlstm_hzzone_seq(ref["x"], None, T, ref["W"], b, *pw, padding=1)
+        (ro * g_out).sum().backward()
+        lv = {"x": x.to(dev).requires_grad_(True), "W": Wt.to(dev).requires_grad_(True)}
+        out, hT, cT = vpx.ops.convlstm_seq(lv["x"], None, None, lv["W"], b.to(dev), *[p.to(dev) for p in pw],
+                                           seq_len=T, in_channels=Cin, precision="bf16x3")
         assert _relmax(out, ro) < 2e-5 and _relmax(cT, rc) < 2e-5
+        (out * g_out.to(dev)).sum().backward()   # the data-gradient conv takes the 8-wave form as well
+        assert _relmax(lv["x"].grad, ref["x"].grad) < 1e-4 and _relmax(lv["W"].grad, ref["W"].grad) < 1e-4
