@@ -162,3 +162,35 @@ def test_conv2d_ex_vs_torch(vpx):
                 (y * gy.cuda()).sum().backward()
                 for a, r in zip(lv, rl):
                     assert _relmax(a.grad, r.grad) < 1e-4, tag
+
+
+def test_edge_shapes_vs_oracle(vpx):
+    """Edge cases: single sample / single step, maps smaller than one tile, 1 input channel, channel counts that are not
+    multiples of anything, 7x7 and rectangular kernels, inputs longer than seq_len, non-contiguous (NCHW) inputs."""
+    from oracle import torch_ref as tr
+    cases = [  # (Cin, Ch, H, W, kh, kw, B, T)
+        (1, 5, 3, 5, 3, 3, 1, 1), (7, 9, 5, 37, 3, 3, 2, 2), (2, 33, 19, 6, 7, 7, 1, 2), (3, 4, 9, 9, 1, 1, 2, 3),
+        (5, 70, 8, 8, 3, 5, 1, 2), (130, 8, 6, 6, 3, 3, 1, 1),
+    ]
+    for prec, tol in (("f32", 1e-5), ("bf16x3", 3e-5)):
+        for (Cin, Ch, H, W, kh, kw, B, T) in cases:
+            tag = f"edge.{Cin}.{Ch}.{H}.{kh}"
+            Wt = seeded_randn((4 * Ch, Cin + Ch, kh, kw), name_seed(tag + "W"), 1.0 / np.sqrt((Cin + Ch) * kh * kw))
+            b = seeded_randn((4 * Ch,), name_seed(tag + "b"), 0.1)
+            x = seeded_rand((B, T + 1, Cin, H, W), name_seed(tag + "x"))      # one frame more than seq_len
+            h0 = seeded_randn((B, Ch, H, W), name_seed(tag + "h"), 0.5)
+            c0 = seeded_randn((B, Ch, H, W), name_seed(tag + "c"), 0.5)
+            with torch.no_grad():
+                hr, cr = h0, c0
+                ref = []
+                for t in range(T):
+                    hr, cr = tr.convlstm_ndrplz_cell(x[:, t], hr, cr, Wt, b)
+                    ref.append(hr)
+                ref = torch.stack(ref, 1)
+                out, hT, cT = vpx.ops.convlstm_seq(x.cuda(), h0.cuda(), c0.cuda(), Wt.cuda(), b.cuda(), seq_len=T,
+                                                   in_channels=Cin, gate_order=vpx._lib.GATE_IFOG, precision=prec)
+            assert out.shape == (B, T, Ch, H, W)
+            assert _relmax(out, ref) < tol and _relmax(cT, cr) < tol, (prec, tag)
+    with pytest.raises(ValueError):   # empty sequence / batch are rejected like any other bad dimension
+        vpx.ops.convlstm_seq(torch.zeros(1, 0, 3, 4, 4, device="cuda"), None, None, torch.zeros(16, 7, 3, 3, device="cuda"),
+                             None, seq_len=0, in_channels=3)
