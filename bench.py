@@ -99,11 +99,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run always go through RCCL (also at N=1)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import vp_suite_amd
     from vp_suite_amd import ops
@@ -123,7 +125,7 @@ def main():
 
     if args.mode == "train":
         from vp_suite_amd.train import DataParallelTrainer
-        trainer = DataParallelTrainer(model, lr=1e-4, world_size=world)
+        trainer = DataParallelTrainer(model, lr=1e-4, world_size=world, force_collectives=use_dist)
 
         def step():
             trainer.step(x, target, args.pred)
@@ -133,7 +135,7 @@ def main():
                 model(x, pred_frames=args.pred)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -148,7 +150,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.PROFILE = None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -198,7 +200,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.model == "convlstm-shi":
             out["cpu_baseline"] = cpu_baseline(model, args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

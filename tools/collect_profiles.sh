@@ -6,6 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_final
 rm -rf $OUT; mkdir -p $OUT
 python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline > /dev/null 2>&1   # MIOpen find-db warm-up outside the profiles
+python3 bench.py --mode train --steps 2 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_infer -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_infer.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python3 bench.py --mode train --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_train.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1

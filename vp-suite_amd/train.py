@@ -25,7 +25,8 @@ def shard_batch(t: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
 
 
 class DataParallelTrainer:
-    def __init__(self, model, lr: float = 1e-4, world_size: int = None, losses_and_scales=None, device=None):
+    def __init__(self, model, lr: float = 1e-4, world_size: int = None, losses_and_scales=None, device=None,
+                 force_collectives: bool = False):
         self.model = model
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -39,7 +40,8 @@ class DataParallelTrainer:
             n = p.numel()
             p.grad = self.flat_grad[off:off + n].view_as(p)
             off += n
-        if self.world > 1:
+        self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
+        if self.collectives:
             self.broadcast_parameters()
         self.optimizer = torch.optim.Adam(self.params, lr=lr)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, patience=5, factor=0.2, min_lr=1e-6)
@@ -57,9 +59,10 @@ class DataParallelTrainer:
         return total
 
     def reduce_gradients(self):
-        if self.world > 1:
+        if self.collectives:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
-            self.flat_grad.div_(self.world)
+            if self.world > 1:
+                self.flat_grad.div_(self.world)
 
     def step(self, x, target, pred_frames: int, **fwd_kwargs):
         """One optimisation step on this rank's shard. Returns the local loss tensor (no host sync)."""
