@@ -271,7 +271,7 @@ template <> struct ModeTraits<2> { static constexpr int KSTEP = 16, KC = 32, WRO
 // pixels share every weight chunk (the L2->CU load pipe, ~70 GB/s per CU, is what limits the bf16 modes), at <= 128
 // registers so that two such workgroups (16 waves) stay resident per CU.
 template <class Epi, int MODE, int MW>
-__global__ __launch_bounds__(NTHREADS * MW, (MW == 2 ? 4 : 3)) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
+__device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, const int n_tile) {
     constexpr int NTH = NTHREADS * MW;
     using MT = ModeTraits<MODE>;
     constexpr int KC = MT::KC, KSTEP = MT::KSTEP;
@@ -292,7 +292,6 @@ __global__ __launch_bounds__(NTHREADS * MW, (MW == 2 ? 4 : 3)) void conv_gemm_ke
     mt /= P.tiles_x;
     const int ty = mt % P.tiles_y;
     const int b = mt / P.tiles_y;
-    const int n_tile = blockIdx.y;
     constexpr int TH = TILE_H * MW;  // workgroup tile height: every wave owns 2*MW consecutive rows of 16 pixels
     const int x0 = tx * TILE_W, y0 = ty * TH;
     const int sd = P.stride > 1 ? P.stride : 1;  // input step per output pixel
@@ -531,6 +530,20 @@ __global__ __launch_bounds__(NTHREADS * MW, (MW == 2 ? 4 : 3)) void conv_gemm_ke
 }
 
 template <class Epi, int MODE, int MW>
+__global__ __launch_bounds__(NTHREADS * MW, (MW == 2 ? 4 : 3)) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
+    conv_body<Epi, MODE, MW>(P, epi, blockIdx.y);
+}
+
+// Two independent contractions over the same pixel tiling in ONE launch (blockIdx.y < nA -> A, else B): the ST-LSTM's
+// c-group and m-group each fill only one workgroup per CU on 16x16 maps; together they give every CU two.
+template <class EpiA, class EpiB, int MODE>
+__global__ __launch_bounds__(NTHREADS, 3) void conv_gemm_dual_kernel(const ConvPlan PA, const EpiA epiA, const int nA,
+                                                                    const ConvPlan PB, const EpiB epiB) {
+    if ((int)blockIdx.y < nA) conv_body<EpiA, MODE, 1>(PA, epiA, blockIdx.y);
+    else conv_body<EpiB, MODE, 1>(PB, epiB, blockIdx.y - nA);
+}
+
+template <class Epi, int MODE, int MW>
 static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tiles, hipStream_t s) {
     const size_t lds = (size_t)plan.a_bytes + 2 * (Epi::NG * 32 * (ModeTraits<MODE>::WROW_DATA + 16));
     static bool attr_set = false;
@@ -605,6 +618,37 @@ hipError_t launch_st_mgroup_f32(const ConvPlan& plan, const STGateArgs& ea, int 
     EpiSTGate<3> e{ea};
     return launch_conv(plan, e, n_tiles, s);
 }
+template <int MODE>
+static hipError_t launch_st_dual_m(const ConvPlan& pc, const STGateArgs& ec, const ConvPlan& pm, const STGateArgs& em,
+                                   int n_tiles, hipStream_t s) {
+    using KA = EpiSTGate<4>;
+    using KB = EpiSTGate<3>;
+    const size_t lc = (size_t)pc.a_bytes + 2 * (4 * 32 * (ModeTraits<MODE>::WROW_DATA + 16));
+    const size_t lm = (size_t)pm.a_bytes + 2 * (3 * 32 * (ModeTraits<MODE>::WROW_DATA + 16));
+    // both bodies carve LDS as [activation tile | weight buffers] from offset 0 with their own a_bytes: size for the larger
+    const size_t lds = lc > lm ? lc : lm;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dual_kernel<KA, KB, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (lds > 160 * 1024 || pc.tiles_x != pm.tiles_x || pc.tiles_y != pm.tiles_y || pc.B != pm.B) return hipErrorInvalidValue;
+    dim3 grid(pc.B * pc.tiles_x * pc.tiles_y, 2 * n_tiles);
+    hipLaunchKernelGGL((conv_gemm_dual_kernel<KA, KB, MODE>), grid, dim3(NTHREADS), lds, s, pc, KA{ec}, n_tiles, pm, KB{em});
+    return hipGetLastError();
+}
+
+hipError_t launch_st_gates_dual(const ConvPlan& pc, const STGateArgs& ec, const ConvPlan& pm, const STGateArgs& em,
+                                int n_tiles, hipStream_t s) {
+    if (pc.prec != pm.prec) return hipErrorInvalidValue;
+    if (pc.prec == VPX_PREC_F32) return launch_st_dual_m<0>(pc, ec, pm, em, n_tiles, s);
+    if (pc.prec == VPX_PREC_BF16X3) return launch_st_dual_m<1>(pc, ec, pm, em, n_tiles, s);
+    if (pc.prec == VPX_PREC_BF16) return launch_st_dual_m<2>(pc, ec, pm, em, n_tiles, s);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_st_out_f32(const ConvPlan& plan, const STOutArgs& ea, int n_tiles, hipStream_t s) {
     EpiSTOut e{ea};
     return launch_conv(plan, e, n_tiles, s);

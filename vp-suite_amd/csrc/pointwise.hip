@@ -41,24 +41,34 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H
 // decoupling-loss tail. F.normalize(dim=2, eps=1e-12) then cosine_similarity(dim=2, eps=1e-8), abs, mean.
 // One thread per (b, co) walks the H*W axis (channels are contiguous -> coalesced across the wave).
 // ---------------------------------------------------------------------------------------------------------------
+// block = 32 channels x 8 pixel slices: every thread sums its slice of the H*W axis, LDS combines the 8 slices
 __global__ void decouple_stats_kernel(const float* __restrict__ yc, const float* __restrict__ ym,
                                       float* __restrict__ stats, int B, int HW, int Ch) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * Ch) return;
-    const int b = idx / Ch, co = idx - b * Ch;
-    const float* pc = yc + (size_t)b * HW * Ch + co;
-    const float* pm = ym + (size_t)b * HW * Ch + co;
+    __shared__ float red[3][8][32];
+    const int b = blockIdx.x, co = blockIdx.y * 32 + (threadIdx.x & 31), slice = threadIdx.x >> 5;
     float scc = 0.f, smm = 0.f, scm = 0.f;
-    for (int p = 0; p < HW; ++p) {
-        const float a = pc[(size_t)p * Ch], m = pm[(size_t)p * Ch];
-        scc += a * a; smm += m * m; scm += a * m;
+    if (co < Ch) {
+        const float* pc = yc + (size_t)b * HW * Ch + co;
+        const float* pm = ym + (size_t)b * HW * Ch + co;
+        for (int p = slice; p < HW; p += 8) {
+            const float a = pc[(size_t)p * Ch], m = pm[(size_t)p * Ch];
+            scc += a * a; smm += m * m; scm += a * m;
+        }
     }
-    const float nc = fmaxf(sqrtf(scc), 1e-12f), nm = fmaxf(sqrtf(smm), 1e-12f);
-    // after normalisation |u| = sqrt(scc)/nc, |v| = sqrt(smm)/nm (1 unless degenerate); cos = u.v / max(|u||v|, 1e-8)
-    const float un = sqrtf(scc) / nc, vn = sqrtf(smm) / nm;
-    const float c = (scm / (nc * nm)) / fmaxf(un * vn, 1e-8f);
-    float* st = stats + (size_t)idx * 4;
-    st[0] = scc; st[1] = smm; st[2] = scm; st[3] = fabsf(c);
+    red[0][slice][threadIdx.x & 31] = scc;
+    red[1][slice][threadIdx.x & 31] = smm;
+    red[2][slice][threadIdx.x & 31] = scm;
+    __syncthreads();
+    if (slice == 0 && co < Ch) {
+        scc = smm = scm = 0.f;
+        for (int s = 0; s < 8; ++s) { scc += red[0][s][threadIdx.x]; smm += red[1][s][threadIdx.x]; scm += red[2][s][threadIdx.x]; }
+        const float nc = fmaxf(sqrtf(scc), 1e-12f), nm = fmaxf(sqrtf(smm), 1e-12f);
+        // after normalisation |u| = sqrt(scc)/nc, |v| = sqrt(smm)/nm (1 unless degenerate); cos = u.v / max(|u||v|, 1e-8)
+        const float un = sqrtf(scc) / nc, vn = sqrtf(smm) / nm;
+        const float c = (scm / (nc * nm)) / fmaxf(un * vn, 1e-8f);
+        float* st = stats + ((size_t)b * Ch + co) * 4;
+        st[0] = scc; st[1] = smm; st[2] = scm; st[3] = fabsf(c);
+    }
 }
 
 __global__ void decouple_mean_kernel(const float* __restrict__ stats, float* __restrict__ value, int n) {
@@ -104,7 +114,7 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 }
 
 hipError_t launch_decouple_stats(const float* yc, const float* ym, float* stats, int B, int HW, int Ch, hipStream_t s) {
-    hipLaunchKernelGGL(decouple_stats_kernel, dim3((B * Ch + 63) / 64), dim3(64), 0, s, yc, ym, stats, B, HW, Ch);
+    hipLaunchKernelGGL(decouple_stats_kernel, dim3(B, (Ch + 31) / 32), dim3(256), 0, s, yc, ym, stats, B, HW, Ch);
     return hipGetLastError();
 }
 hipError_t launch_decouple_mean(const float* stats, float* value, int n, hipStream_t s) {

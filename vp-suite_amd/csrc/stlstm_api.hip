@@ -206,12 +206,12 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         P.nstage = L.nstage_g; memcpy(P.stage, L.stage_g, sizeof(ConvStage) * L.nstage_g);
         P.chunks_total = L.chunks_g; P.a_bytes = conv_a_bytes(L.stage_g, L.nstage_g, k, k); P.wpk = wpk_c;
         STGateArgs ea{Ch, 1.0f, cn, cO, dcO, o_pre, gates_c};
-        VPX_CHECK_HIP(launch_st_cgroup_f32(P, ea, L.tiles32, stream));
-        // ---- launch 2: m group ----
-        P.seg[1] = ConvSeg{mn, (long long)(HW * Ch), Ch, 0};
-        P.wpk = wpk_m;
+        // ---- launch 2 (merged with 1): m group — the two groups are independent and run as ONE dual launch ----
+        ConvPlan Pm = P;
+        Pm.seg[1] = ConvSeg{mn, (long long)(HW * Ch), Ch, 0};
+        Pm.wpk = wpk_m;
         STGateArgs em{Ch, 1.0f, mn, mO, dmO, nullptr, gates_m};
-        VPX_CHECK_HIP(launch_st_mgroup_f32(P, em, L.tiles32, stream));
+        VPX_CHECK_HIP(launch_st_gates_dual(P, ea, Pm, em, L.tiles32, stream));
     }
     // ---- launch 3: conv_last(mem) 1x1 -> lc ----
     {

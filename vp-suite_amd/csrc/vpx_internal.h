@@ -150,6 +150,9 @@ struct STOutArgs {            // h_new = sigmoid(o_pre + conv_o(mem)) * tanh(con
 hipError_t launch_st_cgroup_f32(const ConvPlan& plan, const STGateArgs& ea, int n_tiles, hipStream_t s);
 hipError_t launch_st_mgroup_f32(const ConvPlan& plan, const STGateArgs& ea, int n_tiles, hipStream_t s);
 hipError_t launch_st_out_f32(const ConvPlan& plan, const STOutArgs& ea, int n_tiles, hipStream_t s);
+// c group and m group of one ST-LSTM step in a single launch (same pixel tiling, n_tiles channel tiles each)
+hipError_t launch_st_gates_dual(const ConvPlan& pc, const STGateArgs& ec, const ConvPlan& pm, const STGateArgs& em,
+                                int n_tiles, hipStream_t s);
 
 // ---- BPTT pieces (lstm_bwd.hip) ----
 struct GateBwdArgs {
