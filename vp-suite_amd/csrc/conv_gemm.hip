@@ -589,25 +589,28 @@ hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, i
     return hipErrorInvalidValue;
 }
 
-int plain_groups(int Co) {
+int plain_groups(int Co, long long m_tiles) {
     int best = 4, best_pad = 1 << 30;
     for (int ng = 4; ng >= 1; --ng) {  // ties -> more groups per tile (fewer re-reads of the activation tile)
         const int w = ng * 32;
         const int padded = (Co + w - 1) / w * w;
         if (padded < best_pad) { best_pad = padded; best = ng; }
     }
+    if (m_tiles > 0) {  // few pixel tiles: trade activation re-reads for workgroups until ~512 are in flight
+        while (best > 1 && m_tiles * plain_tiles_ng(Co, best) < 512) --best;
+    }
     return best;
 }
 
-void fill_plain_pack(PackDesc& pd, int Co, int first) {
-    const int ng = plain_groups(Co);
+void fill_plain_pack(PackDesc& pd, int Co, int first, int ng_in) {
+    const int ng = ng_in > 0 ? ng_in : plain_groups(Co);
     pd.NG = ng;
     for (int s = 0; s < MAX_SEG; ++s)
         for (int g = 0; g < MAX_NG; ++g) pd.rowbase[s][g] = g < ng ? first + g * 32 : -1;
     for (int g = 0; g < MAX_NG; ++g) pd.goff[g] = g * 32;
     pd.tile_stride = ng * 32;
     pd.nch = Co;
-    pd.n_tiles = plain_tiles(Co);
+    pd.n_tiles = plain_tiles_ng(Co, ng);
 }
 
 hipError_t launch_st_cgroup_f32(const ConvPlan& plan, const STGateArgs& ea, int n_tiles, hipStream_t s) {

@@ -143,7 +143,6 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
 
     // ---- weight gradient over all (t, b) images ----
     if (dW) {
-        VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, L.slab_floats * sizeof(float), stream));
         WgradArgs wa{};
         wa.T = T; wa.B = B; wa.H = H; wa.W = Wd; wa.HW = (int)HW; wa.kh = d->kh; wa.kw = d->kw;
         wa.tiles_x = (Wd + TILE_W - 1) / TILE_W; wa.tiles_y = (H + TILE_H - 1) / TILE_H;
@@ -156,6 +155,8 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         for (int i = 0; i < L.n_ctiles; ++i)
             if (L.ct[i].seg == 1 || xn) wa.ct[wa.n_ctiles++] = L.ct[i];  // no input tensor: its columns stay zero
         wa.slabs = slabs;
+        // every launched tile stores all of its slab elements; only the skipped x columns need a clear
+        if (!xn) VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, L.slab_floats * sizeof(float), stream));
         VPX_CHECK_HIP(launch_wgrad(wa, L.n_slices, stream));
         VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dW, L.n_slices, L.taps, N4, Ct, stream));
     }

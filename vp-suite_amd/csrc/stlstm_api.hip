@@ -12,7 +12,7 @@ using namespace vpx;
 namespace {
 
 struct STLayout {
-    int taps, tiles32, tiles128;
+    int taps, tiles32, tiles128, ng_l;
     int nstage_g, chunks_g;            // gate groups: segments (x: Cin, recurrent: Ch), k x k
     ConvStage stage_g[MAX_STAGE];
     int nstage_o, chunks_o;            // conv_o: segments (c_new: Ch, m_new: Ch), k x k
@@ -35,19 +35,20 @@ int check_st_desc(const vpx_stlstm_desc* d) {
 int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
     L.taps = d->k * d->k;
     L.tiles32 = (d->Ch + 31) / 32;
-    L.tiles128 = plain_tiles(d->Ch);
+    L.ng_l = plain_groups(d->Ch, (long long)d->B * ((d->H + TILE_H - 1) / TILE_H) * ((d->W + TILE_W - 1) / TILE_W));
+    L.tiles128 = plain_tiles_ng(d->Ch, L.ng_l);
     const int segG[2] = {d->Cin, d->Ch};
     const int segO[2] = {d->Ch, d->Ch};
     L.nstage_g = build_stages(L.stage_g, &L.chunks_g, segG, 2, L.taps, pick_stage_channels(segG, 2, d->k, d->k, 4, d->precision), d->precision);
     L.nstage_o = build_stages(L.stage_o, &L.chunks_o, segO, 2, L.taps, pick_stage_channels(segO, 2, d->k, d->k, 1, d->precision), d->precision);
-    L.nstage_l = build_stages(L.stage_l, &L.chunks_l, segO, 2, 1, pick_stage_channels(segO, 2, 1, 1, 4, d->precision), d->precision);
+    L.nstage_l = build_stages(L.stage_l, &L.chunks_l, segO, 2, 1, pick_stage_channels(segO, 2, 1, 1, L.ng_l, d->precision), d->precision);
     if (L.nstage_g < 0 || L.nstage_o < 0 || L.nstage_l < 0) { set_error("stlstm: too many channel stages"); return VPX_ERR_UNSUPPORTED; }
     L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
     L.n_x = (size_t)d->B * d->H * d->W * d->Cin;
     L.wpk_c = packed_weight_bytes(L.tiles32, L.chunks_g, 4, d->precision) / 4;
     L.wpk_m = packed_weight_bytes(L.tiles32, L.chunks_g, 3, d->precision) / 4;
     L.wpk_o = packed_weight_bytes(L.tiles32, L.chunks_o, 1, d->precision) / 4;
-    L.wpk_l = packed_weight_bytes(L.tiles128, L.chunks_l, plain_groups(d->Ch), d->precision) / 4;
+    L.wpk_l = packed_weight_bytes(L.tiles128, L.chunks_l, L.ng_l, d->precision) / 4;
     return VPX_OK;
 }
 
@@ -184,7 +185,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         pl.seg[1] = PackSeg{Wlast, (long long)2 * Ch, 1, Ch, Ch};
         memcpy(pl.stage, L.stage_l, sizeof(ConvStage) * L.nstage_l);
         pl.nstage = L.nstage_l; pl.chunks_total = L.chunks_l; pl.prec = d->precision; pl.taps = 1;
-        fill_plain_pack(pl, Ch, 0);
+        fill_plain_pack(pl, Ch, 0, L.ng_l);
         VPX_CHECK_HIP(launch_pack_weights(pl, wpk_l, stream));
     }
 
@@ -222,7 +223,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         P.nstage = L.nstage_l; memcpy(P.stage, L.stage_l, sizeof(ConvStage) * L.nstage_l);
         P.chunks_total = L.chunks_l; P.a_bytes = conv_a_bytes(L.stage_l, L.nstage_l, 1, 1); P.wpk = wpk_l;
         PlainEpiArgs ea{};
-        ea.Co = Ch; ea.split = Ch; ea.out0 = lc; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch; ea.ng = plain_groups(Ch);
+        ea.Co = Ch; ea.split = Ch; ea.out0 = lc; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch; ea.ng = L.ng_l;
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.tiles128, stream));
     }
     // ---- launch 4: conv_o(mem) + output gate ----

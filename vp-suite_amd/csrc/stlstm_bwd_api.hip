@@ -17,17 +17,18 @@ struct STBwdLayout {
     int taps, Ch, Cin;
     size_t n_state, n_x, n_g7;
     // dgrad plans: stage tables + chunk counts + N tiles
-    struct DG { int nstage, chunks, tiles; ConvStage stage[MAX_STAGE]; size_t wpk; } o, l, x, h, m;
+    struct DG { int nstage, chunks, tiles, ng; ConvStage stage[MAX_STAGE]; size_t wpk; } o, l, x, h, m;
     int n_slices;
     size_t slab_floats;
 };
 
-int mk_dg(STBwdLayout::DG& g, const int* segC, int nseg, int k, int n_out, int prec) {
+int mk_dg(STBwdLayout::DG& g, const int* segC, int nseg, int k, int n_out, int prec, long long m_tiles) {
     const int taps = k * k;
-    g.nstage = build_stages(g.stage, &g.chunks, segC, nseg, taps, pick_stage_channels(segC, nseg, k, k, 4, prec), prec);
+    g.ng = plain_groups(n_out, m_tiles);
+    g.nstage = build_stages(g.stage, &g.chunks, segC, nseg, taps, pick_stage_channels(segC, nseg, k, k, g.ng, prec), prec);
     if (g.nstage < 0) return -1;
-    g.tiles = plain_tiles(n_out);
-    g.wpk = packed_weight_bytes(g.tiles, g.chunks, plain_groups(n_out), prec) / 4;
+    g.tiles = plain_tiles_ng(n_out, g.ng);
+    g.wpk = packed_weight_bytes(g.tiles, g.chunks, g.ng, prec) / 4;
     return 0;
 }
 
@@ -39,8 +40,9 @@ int st_bwd_layout(const vpx_stlstm_desc* d, STBwdLayout& L) {
     L.n_g7 = L.n_state * 7;
     const int s1[1] = {Ch}, s3[3] = {3 * Ch, Ch, 3 * Ch}, s4[1] = {4 * Ch}, s3m[1] = {3 * Ch};
     const int pr = d->precision;
-    if (mk_dg(L.o, s1, 1, d->k, 2 * Ch, pr) || mk_dg(L.l, s1, 1, 1, 2 * Ch, pr) || mk_dg(L.x, s3, 3, d->k, Cin, pr) ||
-        mk_dg(L.h, s4, 1, d->k, Ch, pr) || mk_dg(L.m, s3m, 1, d->k, Ch, pr)) {
+    const long long mt = (long long)d->B * ((d->W + TILE_W - 1) / TILE_W) * ((d->H + TILE_H - 1) / TILE_H);
+    if (mk_dg(L.o, s1, 1, d->k, 2 * Ch, pr, mt) || mk_dg(L.l, s1, 1, 1, 2 * Ch, pr, mt) || mk_dg(L.x, s3, 3, d->k, Cin, pr, mt) ||
+        mk_dg(L.h, s4, 1, d->k, Ch, pr, mt) || mk_dg(L.m, s3m, 1, d->k, Ch, pr, mt)) {
         set_error("stlstm bwd: too many channel stages (Ch=%d)", Ch);
         return VPX_ERR_UNSUPPORTED;
     }
@@ -95,10 +97,14 @@ int run_wgrad(const vpx_stlstm_desc* d, const STBwdLayout& L, const float* dG, i
     }
     wa.slabs = slabs;
     const int taps = k * k;
-    const size_t used = (size_t)L.n_slices * taps * n_out * wa.Ct;
-    VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, used * sizeof(float), stream));
-    VPX_CHECK_HIP(launch_wgrad(wa, L.n_slices, stream));
-    VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dW, L.n_slices, taps, n_out, wa.Ct, stream));
+    // K slices: enough for ~1024 workgroups, no more (every slice costs a slab write + a reduce read of the whole dW)
+    const int out_tiles = ((N + 63) / 64) * wa.n_ctiles * ((taps + 8) / 9);
+    int ns = (1024 + out_tiles - 1) / out_tiles;
+    if (ns > L.n_slices) ns = L.n_slices;
+    if (ns < 1) ns = 1;
+    // (no slab clear: every workgroup of every slice stores its full tile, so each slab element is written once)
+    VPX_CHECK_HIP(launch_wgrad(wa, ns, stream));
+    VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dW, ns, taps, n_out, wa.Ct, stream));
     return VPX_OK;
 }
 
@@ -189,7 +195,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     auto pack_plain_T = [&](PackDesc& pd, const STBwdLayout::DG& g, int taps, int n_out) {
         memcpy(pd.stage, g.stage, sizeof(ConvStage) * g.nstage);
         pd.nstage = g.nstage; pd.chunks_total = g.chunks; pd.prec = d->precision; pd.taps = taps;
-        fill_plain_pack(pd, n_out, 0);
+        fill_plain_pack(pd, n_out, 0, g.ng);
         pd.transposed = 1; pd.flip = 1;
     };
 
@@ -207,7 +213,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         ConvPlan P = plan_for(L.o, k, wpk_o);
         P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG};
         PlainEpiArgs ea{};
-        ea.Co = 2 * Ch; ea.split = Ch; ea.ng = plain_groups(2 * Ch);
+        ea.Co = 2 * Ch; ea.split = Ch; ea.ng = L.o.ng;
         ea.out0 = dcn_conv; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
         ea.out1 = dmn_conv; ea.bstride1 = (long long)(HW * Ch); ea.ld1 = Ch;
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.o.tiles, stream));
@@ -246,7 +252,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         P.seg[1] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG};
         P.seg[2] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG};
         PlainEpiArgs ea{};
-        ea.Co = Cin; ea.split = Cin; ea.ng = plain_groups(Cin); ea.out0 = dxn; ea.bstride0 = (long long)(HW * Cin); ea.ld0 = Cin;
+        ea.Co = Cin; ea.split = Cin; ea.ng = L.x.ng; ea.out0 = dxn; ea.bstride0 = (long long)(HW * Cin); ea.ld0 = Cin;
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.x.tiles, stream));
     }
     if (dhn) {
@@ -257,7 +263,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         ConvPlan P = plan_for(L.h, k, wpk_h);
         P.nseg = 1; P.seg[0] = ConvSeg{dG7, (long long)(HW * ldG), 4 * Ch, ldG};
         PlainEpiArgs ea{};
-        ea.Co = Ch; ea.split = Ch; ea.ng = plain_groups(Ch); ea.out0 = dhn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
+        ea.Co = Ch; ea.split = Ch; ea.ng = L.h.ng; ea.out0 = dhn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.h.tiles, stream));
     }
     if (dm) {
@@ -268,7 +274,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         ConvPlan P = plan_for(L.m, k, wpk_m);
         P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG};
         PlainEpiArgs ea{};
-        ea.Co = Ch; ea.split = Ch; ea.ng = plain_groups(Ch); ea.out0 = dmn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
+        ea.Co = Ch; ea.split = Ch; ea.ng = L.m.ng; ea.out0 = dmn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
         ea.accumulate = 1;  // onto dm_new_total * f' written by stage C
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.m.tiles, stream));
     }

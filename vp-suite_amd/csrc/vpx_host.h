@@ -143,13 +143,15 @@ static inline int plain_conv(hipStream_t stream, int prec, ConvGeo g, const floa
     int chunks = 0;
     const int segC[1] = {C};
     P.prec = prec;
-    P.nstage = build_stages(P.stage, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, plain_groups(Co), prec), prec);
+    const long long m_tiles = (long long)g.N * ((g.H + TILE_H - 1) / TILE_H) * ((g.W + TILE_W - 1) / TILE_W);
+    const int ng = plain_groups(Co, m_tiles);
+    P.nstage = build_stages(P.stage, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, ng, prec), prec);
     if (P.nstage < 0) { set_error("conv: too many channel stages (C=%d)", C); return VPX_ERR_UNSUPPORTED; }
     PackDesc pd{};
     pd.seg[0] = PackSeg{w, ld_o, ld_i, 0, C};
     memcpy(pd.stage, P.stage, sizeof(ConvStage) * P.nstage);
     pd.nstage = P.nstage; pd.chunks_total = chunks; pd.prec = prec; pd.taps = kh * kw;
-    fill_plain_pack(pd, Co, 0);
+    fill_plain_pack(pd, Co, 0, ng);
     pd.transposed = transposed ? 1 : 0; pd.flip = transposed ? 1 : 0;
     VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
     P.B = g.N; P.H = g.H; P.W = g.W; P.kh = kh; P.kw = kw;
@@ -160,7 +162,7 @@ static inline int plain_conv(hipStream_t stream, int prec, ConvGeo g, const floa
     P.a_bytes = conv_a_bytes(P.stage, P.nstage, kh, kw);
     P.wpk = wpk;
     PlainEpiArgs ea{};
-    ea.bias = bias; ea.Co = Co; ea.split = Co; ea.ng = plain_groups(Co);
+    ea.bias = bias; ea.Co = Co; ea.split = Co; ea.ng = ng;
     ea.out0 = out; ea.bstride0 = (long long)g.H * g.W * out_ld; ea.ld0 = out_ld;
     ea.accumulate = accumulate ? 1 : 0;
     VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, pd.n_tiles, stream));
@@ -168,21 +170,31 @@ static inline int plain_conv(hipStream_t stream, int prec, ConvGeo g, const floa
 }
 
 static inline size_t plain_conv_wpk_floats(int C, int Co, int kh, int kw) {
+    // upper bound over operand modes, N tilings (ng = 1..4) and the stage sizes they select
     size_t best = 0;
     ConvStage st[MAX_STAGE];
-    for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16; ++prec) {
-        int chunks = 0;
-        const int segC[1] = {C};
-        if (build_stages(st, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, plain_groups(Co), prec), prec) < 0) return 0;
-        const size_t b = packed_weight_bytes(plain_tiles(Co), chunks, plain_groups(Co), prec) / 4;
-        if (b > best) best = b;
-    }
+    for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16; ++prec)
+        for (int ng = 1; ng <= 4; ++ng) {
+            int chunks = 0;
+            const int segC[1] = {C};
+            if (build_stages(st, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, ng, prec), prec) < 0) return 0;
+            const size_t b = packed_weight_bytes(1, chunks, plain_rows_bound(Co) / 32, prec) / 4;
+            if (b > best) best = b;
+        }
     return best;
 }
 
+// upper bound of the K slices of a plain weight gradient (sizes the slab workspace)
 static inline int wgrad_slices(int N, int H, int W) {
     const long long items = (long long)N * ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
     return (int)(items < 32 ? items : 32);
+}
+// slices actually launched: enough for ~1024 workgroups (each slice costs a slab write + a reduce read of all of dW)
+static inline int wgrad_pick_slices(int cap, int rows, int n_ctiles, int taps) {
+    const int out_tiles = ((rows + 63) / 64) * n_ctiles * ((taps + 8) / 9);
+    int ns = (1024 + out_tiles - 1) / out_tiles;
+    if (ns > cap) ns = cap;
+    return ns < 1 ? 1 : ns;
 }
 
 // dw[Co, C, kh, kw] (+)= wgrad(dy [N,HW,Co], x [N,HW,C])
@@ -199,8 +211,7 @@ static inline int plain_wgrad(hipStream_t stream, int prec, ConvGeo g, const flo
         wa.ct[wa.n_ctiles++] = WgradCTile{0, c0, (C - c0 < 64) ? C - c0 : 64, c0};
     }
     wa.slabs = slabs;
-    const int ns = wgrad_slices(g.N, g.H, g.W);
-    VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, (size_t)ns * kh * kw * Co * C * sizeof(float), stream));
+    const int ns = wgrad_pick_slices(wgrad_slices(g.N, g.H, g.W), Co, wa.n_ctiles, kh * kw);
     VPX_CHECK_HIP(launch_wgrad(wa, ns, stream));
     VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dw, ns, kh * kw, Co, C, stream));
     return VPX_OK;

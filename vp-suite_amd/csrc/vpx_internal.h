@@ -122,12 +122,17 @@ struct PlainEpiArgs {
     int oys, oyo, oxs, oxo, Wmem;
 };
 hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, int n_tiles, hipStream_t s);
-// N tiling of a plain convolution with Co outputs: 1..4 groups of 32 channels per workgroup, chosen to minimise padding
-int plain_groups(int Co);
-inline int plain_tiles(int Co) { const int w = plain_groups(Co) * 32; return (Co + w - 1) / w; }
+// N tiling of a plain convolution with Co outputs: ng = 1..4 groups of 32 channels per workgroup. Chosen to minimise
+// channel padding; when the launch has few pixel tiles (m_tiles given), narrower tiles are preferred until the grid
+// reaches ~2 workgroups per CU (a 128-wide tile on a 16x16 map at B=32 would leave 3/4 of the chip idle).
+int plain_groups(int Co, long long m_tiles = -1);
+inline int plain_tiles_ng(int Co, int ng) { return (Co + 32 * ng - 1) / (32 * ng); }
+inline int plain_tiles(int Co) { return plain_tiles_ng(Co, plain_groups(Co)); }
+// upper bound of the packed-weight rows over every tiling plain_groups() can return: Co rounded up to 128
+inline int plain_rows_bound(int Co) { return (Co + 127) / 128 * 128; }
 // fills NG / rowbase / goff / tile_stride / nch / n_tiles of a pack descriptor for a plain conv whose outputs start at
-// row (or column, if transposed) `first` of every segment's weight tensor
-void fill_plain_pack(PackDesc& pd, int Co, int first);
+// row (or column, if transposed) `first` of every segment's weight tensor; ng <= 0: plain_groups(Co)
+void fill_plain_pack(PackDesc& pd, int Co, int first, int ng = 0);
 
 // ---- ST-LSTM (predrnn.py:57-83) epilogues; all tensors NHWC [B,HW,Ch] ----
 struct STGateArgs {           // "c group": acc = (i, f, g, o_pre) from [x | h];  "m group": acc = (i', f', g') from [x | m]
