@@ -13,6 +13,6 @@ pw = [torch.randn(1, Ch, H, W, device=dev) * 0.1 for _ in range(3)]
 h0 = torch.randn(B, Ch, H, W, device=dev) * 0.5
 with torch.no_grad():
     for _ in range(3):
-        v.ops.convlstm_seq(x, h0, h0, Wt, b, *pw, seq_len=T, in_channels=Cin)
+        v.ops.convlstm_seq(x, h0, h0, Wt, b, *pw, seq_len=T, in_channels=Cin, precision=os.environ.get("PREC", "bf16x3"))
 torch.cuda.synchronize()
 print("done")

@@ -7,7 +7,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvpx_hip.so")
+# VPX_LIB: developer override to A/B two builds of the library inside one GPU session (tools/ab_*); never a fallback
+LIB_PATH = os.environ.get("VPX_LIB") or os.path.join(_HERE, "libvpx_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 GATE_IFGO, GATE_IFOG = 0, 1

@@ -141,31 +141,50 @@ struct EpiConvLSTM {
             bo = a.bias[a.gate_pos[3] * Ch + ch];
         }
         const size_t img = (size_t)t.b * t.H * t.W;
+        // RB pixels per batch: their state / peephole loads are all issued before the first gate is evaluated, so a wave
+        // exposes 16/RB memory latencies instead of 16 (stores may alias loads, the compiler will not hoist them itself)
+        constexpr int RB = 4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int y, x;
-            if (!tile_pixel(t, r, y, x)) continue;
-            const size_t pix = (size_t)y * t.W + x;
-            const size_t sidx = (img + pix) * Ch + ch;
-            const float cp = a.c_in ? a.c_in[sidx] : 0.0f;
-            float ai = acc[0][r] + bi, af = acc[1][r] + bf, ag = acc[2][r] + bg, ao = acc[3][r] + bo;
-            if (a.wci) {  // peepholes on the previous cell state (conv_lstm_hzzone.py:64-65)
-                ai += a.wci[pix * Ch + ch] * cp;
-                af += a.wcf[pix * Ch + ch] * cp;
+        for (int r0 = 0; r0 < 16; r0 += RB) {
+            bool ok[RB];
+            size_t pixv[RB];
+            float cpv[RB], wi[RB], wf[RB], wo[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                int y, x;
+                ok[u] = tile_pixel(t, r0 + u, y, x);
+                pixv[u] = (size_t)y * t.W + x;
+                cpv[u] = 0.f; wi[u] = 0.f; wf[u] = 0.f; wo[u] = 0.f;
+                if (ok[u]) {
+                    if (a.c_in) cpv[u] = a.c_in[(img + pixv[u]) * Ch + ch];
+                    if (a.wci) { wi[u] = a.wci[pixv[u] * Ch + ch]; wf[u] = a.wcf[pixv[u] * Ch + ch]; }
+                    if (a.wco) wo[u] = a.wco[pixv[u] * Ch + ch];
+                }
             }
-            const float i_ = sigmoid_f(ai), f_ = sigmoid_f(af), g_ = tanh_f(ag);
-            const float cn = f_ * cp + i_ * g_;
-            if (a.wco) ao += a.wco[pix * Ch + ch] * cn;  // peephole on the NEW cell state (:67)
-            const float o_ = sigmoid_f(ao);
-            const float hn = o_ * tanh_f(cn);
-            a.c_out[sidx] = cn;
-            a.h_out[(size_t)t.b * a.h_bstride + pix * Ch + ch] = hn;
-            if (a.gates) {
-                float* gs = a.gates + (img + pix) * 4 * Ch + ch;
-                gs[0] = i_;
-                gs[Ch] = f_;
-                gs[2 * Ch] = g_;
-                gs[3 * Ch] = o_;
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                if (!ok[u]) continue;
+                const int r = r0 + u;
+                const size_t pix = pixv[u];
+                const size_t sidx = (img + pix) * Ch + ch;
+                const float cp = cpv[u];
+                // peepholes on the previous cell state (conv_lstm_hzzone.py:64-65); absent peepholes contribute 0
+                const float ai = acc[0][r] + bi + wi[u] * cp, af = acc[1][r] + bf + wf[u] * cp;
+                const float ag = acc[2][r] + bg;
+                const float i_ = sigmoid_f(ai), f_ = sigmoid_f(af), g_ = tanh_f(ag);
+                const float cn = f_ * cp + i_ * g_;
+                const float ao = acc[3][r] + bo + wo[u] * cn;  // peephole on the NEW cell state (:67)
+                const float o_ = sigmoid_f(ao);
+                const float hn = o_ * tanh_f(cn);
+                a.c_out[sidx] = cn;
+                a.h_out[(size_t)t.b * a.h_bstride + pix * Ch + ch] = hn;
+                if (a.gates) {
+                    float* gs = a.gates + (img + pix) * 4 * Ch + ch;
+                    gs[0] = i_;
+                    gs[Ch] = f_;
+                    gs[2 * Ch] = g_;
+                    gs[3 * Ch] = o_;
+                }
             }
         }
     }
@@ -262,6 +281,29 @@ struct EpiPlain {
 // cn lo-bf16; a weight row is one chunk of one output channel: KC fp32, or KC hi followed by KC lo.
 // ---------------------------------------------------------------------------------------------------------------
 
+// one 4-channel vector of the activation halo tile -> LDS (fp32 as is; bf16 modes: hi half-row, then lo half-row)
+template <int MODE>
+__device__ __forceinline__ void stage_store(char* dst, int lo_off, const f32x4 val) {
+    if constexpr (MODE == 0) {
+        *reinterpret_cast<f32x4*>(dst) = val;
+    } else {
+        unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+        split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);
+        split_bf16(val[2], h2, l2); split_bf16(val[3], h3, l3);
+        uint2 hv = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
+        uint2 lv = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
+        *reinterpret_cast<uint2*>(dst) = hv;
+        *reinterpret_cast<uint2*>(dst + lo_off) = lv;
+    }
+}
+
+// timing ablations (VPX_DBG bits) exist only in builds with -DVPX_ABLATE; the product kernel carries none of the tests
+#ifdef VPX_ABLATE
+#define DBGBIT(b) (P.dbg & (b))
+#else
+#define DBGBIT(b) false
+#endif
+
 template <int MODE> struct ModeTraits;
 template <> struct ModeTraits<0> { static constexpr int KSTEP = 8, KC = 16, WROW_DATA = 16 * 4; };
 template <> struct ModeTraits<1> { static constexpr int KSTEP = 16, KC = 32, WROW_DATA = 32 * 4; };
@@ -314,31 +356,41 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
     const char* wtile = reinterpret_cast<const char*>(P.wpk) + (size_t)n_tile * P.chunks_total * (NTR * MT::WROW_DATA);
 
     // ---- K loop ------------------------------------------------------------------------------------------------
-    // Weight chunks form ONE stream over all active stages: chunk g sits in LDS buffer g&1; chunks g+1 and g+2 are in
-    // flight in two register sets (wrA: even chunks, wrB: odd chunks), i.e. global loads are issued two chunk
-    // iterations before their LDS write, and a stage boundary costs no weight bubble.
-    const bool wload = !(P.dbg & 4);
+    // Weight chunks form ONE contiguous stream over all stages (chunk ids run on across stage boundaries): chunk g sits
+    // in LDS buffer g&1; chunks g+1 and g+2 are in flight in two register sets (wrA: even chunks, wrB: odd chunks), i.e.
+    // global loads are issued two chunk iterations before their LDS write, and a stage boundary costs no weight bubble.
+    // The loop keeps its scalar bookkeeping minimal (one cursor per stream, incremental tap offsets): scalar and vector
+    // ALU work between two MFMA groups delays the wave's next MFMA issue.
+    constexpr int CHUNK_BYTES = NTR * MT::WROW_DATA;
+    // prefetch cursor: (stage, chunks left in it, this thread's source address). Stages of absent operands are not in
+    // the plan, so the packed stream can have gaps at stage boundaries — the cursor jumps to the next stage's chunk0.
     auto stage_chunks = [&](int s) { return (P.stage[s].nq + QPC - 1) / QPC; };
-    auto chunk_src = [&](int s, int ck) {
-        return reinterpret_cast<const f32x4*>(wtile + (size_t)(P.stage[s].chunk0 + ck) * (NTR * MT::WROW_DATA));
-    };
-    int ps = 0, pck = 0;  // prefetch cursor: next chunk to request from global memory
+    int ps = 0, prem = P.nstage > 0 ? stage_chunks(0) : 0;
+    const char* wnext = wtile + (size_t)(P.nstage > 0 ? P.stage[0].chunk0 : 0) * CHUNK_BYTES + tid * 16;
     auto issue_load = [&](f32x4 (&wr)[WIT]) {  // returns silently past the end of the stream
         if (ps < P.nstage) {
-            const f32x4* src = chunk_src(ps, pck);
 #pragma unroll
             for (int it = 0; it < WIT; ++it)
-                if (tid + it * NTH < WV4 && wload) wr[it] = src[tid + it * NTH];
-            if (++pck == stage_chunks(ps)) { pck = 0; ++ps; }
+                if (tid + it * NTH < WV4 && !DBGBIT(4)) wr[it] = *reinterpret_cast<const f32x4*>(wnext + it * NTH * 16);
+            wnext += CHUNK_BYTES;
+            if (--prem == 0 && ++ps < P.nstage) {
+                prem = stage_chunks(ps);
+                wnext = wtile + (size_t)P.stage[ps].chunk0 * CHUNK_BYTES + tid * 16;
+            }
         }
     };
+    // LDS destination of this thread's staging vectors (row padding applied once)
+    int wdst_off[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int v = tid + it * NTH;
+        wdst_off[it] = (v / V4ROW) * WROW + (v % V4ROW) * 16;
+    }
     auto write_lds = [&](const f32x4 (&wr)[WIT], int buf) {
         char* wdst = W_lds + buf * WBUF;
 #pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int v = tid + it * NTH;
-            if (v < WV4) *reinterpret_cast<f32x4*>(wdst + (v / V4ROW) * WROW + (v % V4ROW) * 16) = wr[it];
-        }
+        for (int it = 0; it < WIT; ++it)
+            if (tid + it * NTH < WV4) *reinterpret_cast<f32x4*>(wdst + wdst_off[it]) = wr[it];
     };
     f32x4 wrA[WIT], wrB[WIT];
 #pragma unroll
@@ -346,182 +398,184 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
     issue_load(wrA);  // chunk 0
     issue_load(wrB);  // chunk 1
 
-    int s = 0, ck = 0;        // compute cursor
-    long long gidx = 0;       // chunks consumed so far (parity selects LDS buffer / register set)
-    int ks = 0, tdx = 0, tdy = 0, tapoff = 0, arow = 16, ksn = 1;
-    const char* a_lane = A_lds;
-    ConvStage st{};
-    bool new_stage = true;
-    bool first = true;
-    while (s < P.nstage) {
-        if (new_stage) {
-            st = P.stage[s];
-            const ConvSeg sg = P.seg[st.seg];
-            arow = st.cn * 4 + 16;  // bytes per halo position (odd multiple of 16 B -> conflict-free b128 reads)
-            // (the barrier that ended the previous chunk guarantees the previous stage's tile is fully consumed)
+    int gidx = 0;  // chunks consumed so far (parity selects LDS buffer / register set)
+    const char* wb0 = W_lds + j * WROW + hh * 16;
+    for (int s = 0; s < P.nstage; ++s) {
+        const ConvStage st = P.stage[s];
+        const ConvSeg sg = P.seg[st.seg];
+        const int arow = st.cn * 4 + 16;  // bytes per halo position (odd multiple of 16 B -> conflict-free b128 reads)
+        // (the barrier that ended the previous chunk guarantees the previous stage's tile is fully consumed)
         // ---- stage the activation halo tile: positions x [c0, c0+cn) ----
-            {
-                const float* src = sg.ptr + (size_t)b * sg.bstride;
-                const int ld = sg.ld ? sg.ld : sg.C;
-                if (((sg.C | ld) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-                    const int v4n = st.cn >> 2;
-                    if ((v4n & (v4n - 1)) == 0 && !(P.dbg & 16)) {
-                        // cn/4 is a power of two (always for 16/32/64-channel stages): 256 threads cover 256/v4n halo
-                        // positions per pass and (pos, hy, hx) advance by constants — no integer division in the loop
-                        const int sh = 31 - __builtin_clz(v4n);
-                        const int c4 = tid & (v4n - 1);
-                        const int dpos = NTH >> sh;
-                        const int dhy = dpos / halo_w, dhx = dpos - dhy * halo_w;
-                        int pos = tid >> sh;
-                        int hy = pos / halo_w, hx = pos - hy * halo_w;
-                        const int c = st.c0 + c4 * 4;
-                        const bool c_ok = c < sg.C && !(P.dbg & 2);
-                        const float* srcc = src + c;
-                        char* dstc = A_lds + (MODE == 0 ? c4 * 16 : c4 * 8);
-                        for (; pos < npos; pos += dpos) {
+        {
+            const float* src = sg.ptr + (size_t)b * sg.bstride;
+            const int ld = sg.ld ? sg.ld : sg.C;
+            if (((sg.C | ld) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+                const int v4n = st.cn >> 2;
+                if ((v4n & (v4n - 1)) == 0) {
+                    // cn/4 is a power of two (always for 16/32/64-channel stages): 256 threads cover 256/v4n halo
+                    // positions per pass and (pos, hy, hx) advance by constants — no integer division in the loop
+                    const int sh = 31 - __builtin_clz(v4n);
+                    const int c4 = tid & (v4n - 1);
+                    const int dpos = NTH >> sh;
+                    const int dhy = dpos / halo_w, dhx = dpos - dhy * halo_w;
+                    int pos = tid >> sh;
+                    int hy = pos / halo_w, hx = pos - hy * halo_w;
+                    const int c = st.c0 + c4 * 4;
+                    const bool c_ok = c < sg.C && !DBGBIT(2);
+                    const float* srcc = src + c;
+                    char* dstc = A_lds + (MODE == 0 ? c4 * 16 : c4 * 8);
+                    if (P.dbg & 16) {
+                    for (; pos < npos; pos += dpos) {
+                        const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
+                        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                        if (c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win)
+                            val = *reinterpret_cast<const f32x4*>(srcc + ((size_t)gy * Win + gx) * ld);
+                        stage_store<MODE>(dstc + pos * arow, st.cn * 2, val);
+                        hx += dhx; hy += dhy;
+                        if (hx >= halo_w) { hx -= halo_w; ++hy; }
+                    }
+                    } else {
+                    // AU loads in flight per thread before the first conversion: one exposed memory latency per AU
+                    // positions instead of one per position (the MFMA fragment registers are dead here)
+                    constexpr int AU = (MW == 2 ? 3 : 4);
+                    for (; pos < npos; pos += dpos * AU) {
+                        f32x4 val[AU];
+#pragma unroll
+                        for (int u = 0; u < AU; ++u) {
                             const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
-                            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                            if (c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win)
-                                val = *reinterpret_cast<const f32x4*>(srcc + ((size_t)gy * Win + gx) * ld);
-                            if constexpr (MODE == 0) {
-                                *reinterpret_cast<f32x4*>(dstc + pos * arow) = val;
-                            } else {
-                                unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-                                split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);
-                                split_bf16(val[2], h2, l2); split_bf16(val[3], h3, l3);
-                                uint2 hv = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
-                                uint2 lv = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
-                                *reinterpret_cast<uint2*>(dstc + pos * arow) = hv;
-                                *reinterpret_cast<uint2*>(dstc + pos * arow + st.cn * 2) = lv;
-                            }
+                            val[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (pos + u * dpos < npos && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win)
+                                val[u] = *reinterpret_cast<const f32x4*>(srcc + ((size_t)gy * Win + gx) * ld);
                             hx += dhx; hy += dhy;
                             if (hx >= halo_w) { hx -= halo_w; ++hy; }
                         }
-                    } else {
-                        const int total = npos * v4n;
-                        for (int v = tid; v < total; v += NTH) {
-                            const int pos = v / v4n, c4 = v - pos * v4n;
-                            const int hy = pos / halo_w, hx = pos - hy * halo_w;
-                            const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
-                            const int c = st.c0 + c4 * 4;
-                            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                            if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win && c < sg.C && !(P.dbg & 2))
-                                val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * Win + gx) * ld + c);
-                            if constexpr (MODE == 0) {
-                                *reinterpret_cast<f32x4*>(A_lds + pos * arow + c4 * 16) = val;
-                            } else {
-                                unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
-                                split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);
-                                split_bf16(val[2], h2, l2); split_bf16(val[3], h3, l3);
-                                uint2 hv = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
-                                uint2 lv = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
-                                *reinterpret_cast<uint2*>(A_lds + pos * arow + c4 * 8) = hv;
-                                *reinterpret_cast<uint2*>(A_lds + pos * arow + st.cn * 2 + c4 * 8) = lv;
-                            }
-                        }
+#pragma unroll
+                        for (int u = 0; u < AU; ++u)
+                            if (pos + u * dpos < npos) stage_store<MODE>(dstc + (pos + u * dpos) * arow, st.cn * 2, val[u]);
+                    }
                     }
                 } else {
-                    const int total = npos * st.cn;
-                    for (int e = tid; e < total; e += NTH) {
-                        const int pos = e / st.cn, cc = e - pos * st.cn;
+                    const int total = npos * v4n;
+                    for (int v = tid; v < total; v += NTH) {
+                        const int pos = v / v4n, c4 = v - pos * v4n;
                         const int hy = pos / halo_w, hx = pos - hy * halo_w;
                         const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
-                        const int c = st.c0 + cc;
-                        float val = 0.f;
-                        if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win && c < sg.C)
-                            val = src[((size_t)gy * Win + gx) * ld + c];
+                        const int c = st.c0 + c4 * 4;
+                        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                        if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win && c < sg.C && !DBGBIT(2))
+                            val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * Win + gx) * ld + c);
                         if constexpr (MODE == 0) {
-                            *reinterpret_cast<float*>(A_lds + pos * arow + cc * 4) = val;
+                            *reinterpret_cast<f32x4*>(A_lds + pos * arow + c4 * 16) = val;
                         } else {
-                            unsigned short h, l;
-                            split_bf16(val, h, l);
-                            *reinterpret_cast<unsigned short*>(A_lds + pos * arow + cc * 2) = h;
-                            *reinterpret_cast<unsigned short*>(A_lds + pos * arow + st.cn * 2 + cc * 2) = l;
+                            unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
+                            split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);
+                            split_bf16(val[2], h2, l2); split_bf16(val[3], h3, l3);
+                            uint2 hv = {(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h3 << 16)};
+                            uint2 lv = {(unsigned)l0 | ((unsigned)l1 << 16), (unsigned)l2 | ((unsigned)l3 << 16)};
+                            *reinterpret_cast<uint2*>(A_lds + pos * arow + c4 * 8) = hv;
+                            *reinterpret_cast<uint2*>(A_lds + pos * arow + st.cn * 2 + c4 * 8) = lv;
                         }
                     }
                 }
+            } else {
+                const int total = npos * st.cn;
+                for (int e = tid; e < total; e += NTH) {
+                    const int pos = e / st.cn, cc = e - pos * st.cn;
+                    const int hy = pos / halo_w, hx = pos - hy * halo_w;
+                    const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
+                    const int c = st.c0 + cc;
+                    float val = 0.f;
+                    if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win && c < sg.C)
+                        val = src[((size_t)gy * Win + gx) * ld + c];
+                    if constexpr (MODE == 0) {
+                        *reinterpret_cast<float*>(A_lds + pos * arow + cc * 4) = val;
+                    } else {
+                        unsigned short h, l;
+                        split_bf16(val, h, l);
+                        *reinterpret_cast<unsigned short*>(A_lds + pos * arow + cc * 2) = h;
+                        *reinterpret_cast<unsigned short*>(A_lds + pos * arow + st.cn * 2 + cc * 2) = l;
+                    }
+                }
             }
-
-            ksn = st.cn / KSTEP;
-            ks = 0; tdx = 0; tdy = 0; tapoff = 0;
-            a_lane = A_lds + (py * sd * halo_w + px * sd) * arow + hh * 16;
-            if (first) {  // very first chunk of the stream: registers -> LDS buffer 0, refill the even set
-                write_lds(wrA, 0);
-                issue_load(wrA);  // chunk 2
-                first = false;
-            }
-            __syncthreads();
-            new_stage = false;
         }
-        const int buf = (int)(gidx & 1);
-        const char* wb = W_lds + buf * WBUF + j * WROW + hh * 16;
+
+
+        const int ksn = st.cn / KSTEP;
+        const int tap_dx = arow, tap_dy = (halo_w - P.kw) * arow;  // tap offset steps: next column / wrap to next row
+        int ks = 0, tdx = 0, tapoff = 0;
+        const char* a_lane = A_lds + (py * sd * halo_w + px * sd) * arow + hh * 16;
+        if (s == 0) {  // very first chunk of the stream: registers -> LDS buffer 0, refill the even set
+            write_lds(wrA, 0);
+            issue_load(wrA);  // chunk 2
+        }
+        __syncthreads();
+        for (int kq = 0; kq < st.nq; kq += QPC) {
+            const int buf = gidx & 1;
+            const char* wb = wb0 + buf * WBUF;
 #pragma unroll
-        for (int q = 0; q < QPC; ++q) {
-            if (ck * QPC + q < st.nq) {
-                if (P.dbg & 1) {
-                } else if constexpr (MODE == 0) {
-                    // fp32: one b128 = 4 consecutive channels; lanes 0-31 take k = 8*ks + s, lanes 32-63 k = 8*ks + 4 + s
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(a_lane + tapoff + ks * 32);
-                    f32x4 b4[NG];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g)
-                        b4[g] = *reinterpret_cast<const f32x4*>(wb + g * 32 * WROW + q * 32);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
+            for (int q = 0; q < QPC; ++q) {
+                if (q == 0 || kq + q < st.nq) {
+                if (DBGBIT(1)) {
+                    } else if constexpr (MODE == 0) {
+                        // fp32: one b128 = 4 consecutive channels; lanes 0-31 take k = 8*ks + s, lanes 32-63 k = 8*ks + 4 + s
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(a_lane + tapoff + ks * 32);
+                        f32x4 b4[NG];
+    #pragma unroll
                         for (int g = 0; g < NG; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k], b4[g][k], acc[g], 0, 0, 0);
-                } else {
-                    // bf16x3: one b128 = 8 consecutive channels; lanes 0-31 take k = 16*ks + 0..7, lanes 32-63 + 8..15
-                    const char* ap = a_lane + tapoff + ks * 32;
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
-                    bf16x8 al;
-                    if constexpr (MODE == 1) al = *reinterpret_cast<const bf16x8*>(ap + st.cn * 2);
-                    // gates in pairs: keeps the live weight fragments at 2 x (hi, lo) = 16 registers (128-register budget)
-#pragma unroll
-                    for (int g0 = 0; g0 < NG; g0 += 2) {
-                        bf16x8 bh[2], bl[2];
-#pragma unroll
-                        for (int gg = 0; gg < 2; ++gg) {
-                            if (g0 + gg < NG) {
-                                bh[gg] = *reinterpret_cast<const bf16x8*>(wb + (g0 + gg) * 32 * WROW + q * 32);
-                                if constexpr (MODE == 1)
-                                    bl[gg] = *reinterpret_cast<const bf16x8*>(wb + (g0 + gg) * 32 * WROW + KC * 2 + q * 32);
-                            }
-                        }
-#pragma unroll
-                        for (int gg = 0; gg < 2; ++gg) {
-                            if (g0 + gg < NG) {
-                                if constexpr (MODE == 1) {  // bf16x3: the two cross terms; plain bf16 (MODE 2) keeps hi*hi only
-                                    acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[gg], acc[g0 + gg], 0, 0, 0);
-                                    acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[gg], acc[g0 + gg], 0, 0, 0);
+                            b4[g] = *reinterpret_cast<const f32x4*>(wb + g * 32 * WROW + q * 32);
+    #pragma unroll
+                        for (int k = 0; k < 4; ++k)
+    #pragma unroll
+                            for (int g = 0; g < NG; ++g)
+                                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k], b4[g][k], acc[g], 0, 0, 0);
+                    } else {
+                        // bf16x3: one b128 = 8 consecutive channels; lanes 0-31 take k = 16*ks + 0..7, lanes 32-63 + 8..15
+                        const char* ap = a_lane + tapoff + ks * 32;
+                        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+                        bf16x8 al;
+                        if constexpr (MODE == 1) al = *reinterpret_cast<const bf16x8*>(ap + st.cn * 2);
+                        // gates in pairs: keeps the live weight fragments at 2 x (hi, lo) = 16 registers (128-register budget)
+    #pragma unroll
+                        for (int g0 = 0; g0 < NG; g0 += 2) {
+                            bf16x8 bh[2], bl[2];
+    #pragma unroll
+                            for (int gg = 0; gg < 2; ++gg) {
+                                if (g0 + gg < NG) {
+                                    bh[gg] = *reinterpret_cast<const bf16x8*>(wb + (g0 + gg) * 32 * WROW + q * 32);
+                                    if constexpr (MODE == 1)
+                                        bl[gg] = *reinterpret_cast<const bf16x8*>(wb + (g0 + gg) * 32 * WROW + KC * 2 + q * 32);
                                 }
-                                acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[gg], acc[g0 + gg], 0, 0, 0);
+                            }
+    #pragma unroll
+                            for (int gg = 0; gg < 2; ++gg) {
+                                if (g0 + gg < NG) {
+                                    if constexpr (MODE == 1) {  // bf16x3: the two cross terms; plain bf16 (MODE 2) keeps hi*hi only
+                                        acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[gg], acc[g0 + gg], 0, 0, 0);
+                                        acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[gg], acc[g0 + gg], 0, 0, 0);
+                                    }
+                                    acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[gg], acc[g0 + gg], 0, 0, 0);
+                                }
                             }
                         }
                     }
-                }
-                if (++ks == ksn) {
-                    ks = 0;
-                    if (++tdx == P.kw) { tdx = 0; ++tdy; }
-                    tapoff = (tdy * halo_w + tdx) * arow;
+    if (++ks == ksn) {
+                        ks = 0;
+                        tapoff += tap_dx;
+                        if (++tdx == P.kw) { tdx = 0; tapoff += tap_dy; }
+                    }
                 }
             }
+            // hand the next chunk to LDS (other buffer) and request the chunk after the one still in flight
+            if (kq + QPC < st.nq || s + 1 < P.nstage) {
+                if (buf == 0) { write_lds(wrB, 1); issue_load(wrB); }
+                else { write_lds(wrA, 0); issue_load(wrA); }
+            }
+            if (!DBGBIT(32)) __syncthreads();  // (bit 32: timing-only ablation of the per-chunk barrier; results are wrong)
+            ++gidx;
         }
-
-        // hand the next chunk to LDS (other buffer) and request the chunk after the one still in flight
-        const bool last_of_stage = (ck + 1 == stage_chunks(s));
-        const bool stream_has_next = !(last_of_stage && s + 1 >= P.nstage);
-        if (stream_has_next) {
-            if (buf == 0) { write_lds(wrB, 1); issue_load(wrB); }
-            else { write_lds(wrA, 0); issue_load(wrA); }
-        }
-        if (!(P.dbg & 32)) __syncthreads();  // (bit 32: timing-only ablation of the per-chunk barrier; results are wrong)
-        ++gidx;
-        if (last_of_stage) { ck = 0; ++s; new_stage = true; } else { ++ck; }
     }
 
-    if (P.dbg & 8) {  // ablation: keep the accumulators alive with one store instead of the epilogue
+    if (DBGBIT(8)) {  // ablation: keep the accumulators alive with one store instead of the epilogue
         if (acc[0][0] == 12345.678f) reinterpret_cast<float*>(const_cast<float*>(P.wpk))[0] = acc[0][1];
         return;
     }
