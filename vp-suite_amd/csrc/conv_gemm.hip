@@ -312,7 +312,7 @@ template <> struct ModeTraits<2> { static constexpr int KSTEP = 16, KC = 32, WRO
 // MW = 1: 4 waves (256 threads) per workgroup, 8x16 pixel tile. MW = 2: 8 waves (512 threads), 16x16 tile — twice the
 // pixels share every weight chunk (the L2->CU load pipe, ~70 GB/s per CU, is what limits the bf16 modes), at <= 128
 // registers so that two such workgroups (16 waves) stay resident per CU.
-template <class Epi, int MODE, int MW>
+template <class Epi, int MODE, int MW, int MS = 1>
 __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, const int n_tile) {
     constexpr int NTH = NTHREADS * MW;
     using MT = ModeTraits<MODE>;
@@ -334,7 +334,7 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
     mt /= P.tiles_x;
     const int ty = mt % P.tiles_y;
     const int b = mt / P.tiles_y;
-    constexpr int TH = TILE_H * MW;  // workgroup tile height: every wave owns 2*MW consecutive rows of 16 pixels
+    constexpr int TH = TILE_H * MW * MS;  // workgroup tile height: every wave owns MS sub-tiles of 2 rows x 16 pixels
     const int x0 = tx * TILE_W, y0 = ty * TH;
     const int sd = P.stride > 1 ? P.stride : 1;  // input step per output pixel
     const int halo_w = (TILE_W - 1) * sd + P.kw, halo_h = (TH - 1) * sd + P.kh;
@@ -344,21 +344,25 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
 
     char* A_lds = smem;
     char* W_lds = smem + P.a_bytes;
+    if (DBGBIT(256)) return;  // ablation: launch + dispatch floor
 
-    f32x16 acc[NG];
+    f32x16 acc[MS][NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int m = 0; m < MS; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][g][r] = 0.0f;
 
-    // this lane's pixel inside the tile (MFMA row = lane & 31): wave w owns tile rows 2w and 2w+1
-    const int py = 2 * wave + (j >> 4), px = j & 15;
+    // this lane's pixel inside the tile (MFMA row = lane & 31): wave w owns tile rows 2*MS*w .. 2*MS*w + 2*MS-1
+    const int py = 2 * MS * wave + (j >> 4), px = j & 15;
     const char* wtile = reinterpret_cast<const char*>(P.wpk) + (size_t)n_tile * P.chunks_total * (NTR * MT::WROW_DATA);
 
     // ---- K loop ------------------------------------------------------------------------------------------------
-    // Weight chunks form ONE contiguous stream over all stages (chunk ids run on across stage boundaries): chunk g sits
-    // in LDS buffer g&1; chunks g+1 and g+2 are in flight in two register sets (wrA: even chunks, wrB: odd chunks), i.e.
-    // global loads are issued two chunk iterations before their LDS write, and a stage boundary costs no weight bubble.
+    // Weight chunks form one stream over all stages: chunk g is multiplied out of LDS buffer g&1 while chunk g+1 travels
+    // from L2 into registers (requested at the top of the iteration, stored to the other buffer after the MFMAs); a
+    // stage boundary costs no weight bubble. One register set and no parity-dependent register choice: the two-set
+    // variant made the compiler copy sets and wait for a load right after issuing it.
     // The loop keeps its scalar bookkeeping minimal (one cursor per stream, incremental tap offsets): scalar and vector
     // ALU work between two MFMA groups delays the wave's next MFMA issue.
     constexpr int CHUNK_BYTES = NTR * MT::WROW_DATA;
@@ -390,13 +394,12 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
         char* wdst = W_lds + buf * WBUF;
 #pragma unroll
         for (int it = 0; it < WIT; ++it)
-            if (tid + it * NTH < WV4) *reinterpret_cast<f32x4*>(wdst + wdst_off[it]) = wr[it];
+            if (tid + it * NTH < WV4 && !DBGBIT(64)) *reinterpret_cast<f32x4*>(wdst + wdst_off[it]) = wr[it];
     };
-    f32x4 wrA[WIT], wrB[WIT];
+    f32x4 wr[WIT];
 #pragma unroll
-    for (int it = 0; it < WIT; ++it) { wrA[it] = f32x4{0.f, 0.f, 0.f, 0.f}; wrB[it] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    issue_load(wrA);  // chunk 0
-    issue_load(wrB);  // chunk 1
+    for (int it = 0; it < WIT; ++it) wr[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue_load(wr);  // chunk 0
 
     int gidx = 0;  // chunks consumed so far (parity selects LDS buffer / register set)
     const char* wb0 = W_lds + j * WROW + hh * 16;
@@ -409,7 +412,8 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
         {
             const float* src = sg.ptr + (size_t)b * sg.bstride;
             const int ld = sg.ld ? sg.ld : sg.C;
-            if (((sg.C | ld) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+            if (DBGBIT(128)) {
+                } else if (((sg.C | ld) & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
                 const int v4n = st.cn >> 2;
                 if ((v4n & (v4n - 1)) == 0) {
                     // cn/4 is a power of two (always for 16/32/64-channel stages): 256 threads cover 256/v4n halo
@@ -437,7 +441,7 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
                     } else {
                     // AU loads in flight per thread before the first conversion: one exposed memory latency per AU
                     // positions instead of one per position (the MFMA fragment registers are dead here)
-                    constexpr int AU = (MW == 2 ? 3 : 4);
+                    constexpr int AU = (MW >= 2 ? 3 : 4);
                     for (; pos < npos; pos += dpos * AU) {
                         f32x4 val[AU];
 #pragma unroll
@@ -504,41 +508,49 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
         const int tap_dx = arow, tap_dy = (halo_w - P.kw) * arow;  // tap offset steps: next column / wrap to next row
         int ks = 0, tdx = 0, tapoff = 0;
         const char* a_lane = A_lds + (py * sd * halo_w + px * sd) * arow + hh * 16;
-        if (s == 0) {  // very first chunk of the stream: registers -> LDS buffer 0, refill the even set
-            write_lds(wrA, 0);
-            issue_load(wrA);  // chunk 2
-        }
+        const int sub_off = 2 * sd * halo_w * arow;  // next sub-tile of this wave: two tile rows further down
+        if (s == 0) write_lds(wr, 0);  // very first chunk of the stream
         __syncthreads();
         for (int kq = 0; kq < st.nq; kq += QPC) {
             const int buf = gidx & 1;
             const char* wb = wb0 + buf * WBUF;
+            const bool has_next = kq + QPC < st.nq || s + 1 < P.nstage;
+            if (has_next) issue_load(wr);  // chunk g+1 travels while chunk g is multiplied
 #pragma unroll
             for (int q = 0; q < QPC; ++q) {
                 if (q == 0 || kq + q < st.nq) {
-                if (DBGBIT(1)) {
+                    if (DBGBIT(1)) {
                     } else if constexpr (MODE == 0) {
                         // fp32: one b128 = 4 consecutive channels; lanes 0-31 take k = 8*ks + s, lanes 32-63 k = 8*ks + 4 + s
-                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(a_lane + tapoff + ks * 32);
+                        f32x4 a4[MS];
+#pragma unroll
+                        for (int m = 0; m < MS; ++m)
+                            a4[m] = *reinterpret_cast<const f32x4*>(a_lane + m * sub_off + tapoff + ks * 32);
                         f32x4 b4[NG];
-    #pragma unroll
+#pragma unroll
                         for (int g = 0; g < NG; ++g)
                             b4[g] = *reinterpret_cast<const f32x4*>(wb + g * 32 * WROW + q * 32);
-    #pragma unroll
+#pragma unroll
                         for (int k = 0; k < 4; ++k)
-    #pragma unroll
+#pragma unroll
                             for (int g = 0; g < NG; ++g)
-                                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[k], b4[g][k], acc[g], 0, 0, 0);
+#pragma unroll
+                                for (int m = 0; m < MS; ++m)
+                                    acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m][k], b4[g][k], acc[m][g], 0, 0, 0);
                     } else {
                         // bf16x3: one b128 = 8 consecutive channels; lanes 0-31 take k = 16*ks + 0..7, lanes 32-63 + 8..15
-                        const char* ap = a_lane + tapoff + ks * 32;
-                        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
-                        bf16x8 al;
-                        if constexpr (MODE == 1) al = *reinterpret_cast<const bf16x8*>(ap + st.cn * 2);
-                        // gates in pairs: keeps the live weight fragments at 2 x (hi, lo) = 16 registers (128-register budget)
-    #pragma unroll
+                        bf16x8 ah[MS], al[MS];
+#pragma unroll
+                        for (int m = 0; m < MS; ++m) {
+                            const char* ap = a_lane + m * sub_off + tapoff + ks * 32;
+                            ah[m] = *reinterpret_cast<const bf16x8*>(ap);
+                            if constexpr (MODE == 1) al[m] = *reinterpret_cast<const bf16x8*>(ap + st.cn * 2);
+                        }
+                        // gates in pairs: keeps the live weight fragments at 2 x (hi, lo) = 16 registers
+#pragma unroll
                         for (int g0 = 0; g0 < NG; g0 += 2) {
                             bf16x8 bh[2], bl[2];
-    #pragma unroll
+#pragma unroll
                             for (int gg = 0; gg < 2; ++gg) {
                                 if (g0 + gg < NG) {
                                     bh[gg] = *reinterpret_cast<const bf16x8*>(wb + (g0 + gg) * 32 * WROW + q * 32);
@@ -546,46 +558,49 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
                                         bl[gg] = *reinterpret_cast<const bf16x8*>(wb + (g0 + gg) * 32 * WROW + KC * 2 + q * 32);
                                 }
                             }
-    #pragma unroll
+#pragma unroll
                             for (int gg = 0; gg < 2; ++gg) {
                                 if (g0 + gg < NG) {
-                                    if constexpr (MODE == 1) {  // bf16x3: the two cross terms; plain bf16 (MODE 2) keeps hi*hi only
-                                        acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[gg], acc[g0 + gg], 0, 0, 0);
-                                        acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[gg], acc[g0 + gg], 0, 0, 0);
+#pragma unroll
+                                    for (int m = 0; m < MS; ++m) {
+                                        f32x16& c = acc[m][g0 + gg];
+                                        if constexpr (MODE == 1) {  // bf16x3: the two cross terms; plain bf16 (MODE 2) keeps hi*hi only
+                                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[gg], c, 0, 0, 0);
+                                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[gg], c, 0, 0, 0);
+                                        }
+                                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[gg], c, 0, 0, 0);
                                     }
-                                    acc[g0 + gg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[gg], acc[g0 + gg], 0, 0, 0);
                                 }
                             }
                         }
                     }
-    if (++ks == ksn) {
+                    if (++ks == ksn) {
                         ks = 0;
                         tapoff += tap_dx;
                         if (++tdx == P.kw) { tdx = 0; tapoff += tap_dy; }
                     }
                 }
             }
-            // hand the next chunk to LDS (other buffer) and request the chunk after the one still in flight
-            if (kq + QPC < st.nq || s + 1 < P.nstage) {
-                if (buf == 0) { write_lds(wrB, 1); issue_load(wrB); }
-                else { write_lds(wrA, 0); issue_load(wrA); }
-            }
+            if (has_next) write_lds(wr, buf ^ 1);  // every wave finished reading that buffer before the last barrier
             if (!DBGBIT(32)) __syncthreads();  // (bit 32: timing-only ablation of the per-chunk barrier; results are wrong)
             ++gidx;
         }
     }
 
     if (DBGBIT(8)) {  // ablation: keep the accumulators alive with one store instead of the epilogue
-        if (acc[0][0] == 12345.678f) reinterpret_cast<float*>(const_cast<float*>(P.wpk))[0] = acc[0][1];
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(const_cast<float*>(P.wpk))[0] = acc[MS - 1][0][1];
         return;
     }
-    TileCtx t{b, y0, x0, n_tile, 2 * wave, j, hh, P.H, P.W};
-    epi(acc, t);
+#pragma unroll
+    for (int m = 0; m < MS; ++m) {
+        TileCtx t{b, y0, x0, n_tile, 2 * (MS * wave + m), j, hh, P.H, P.W};
+        epi(acc[m], t);
+    }
 }
 
-template <class Epi, int MODE, int MW>
-__global__ __launch_bounds__(NTHREADS * MW, (MW == 2 ? 4 : 3)) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
-    conv_body<Epi, MODE, MW>(P, epi, blockIdx.y);
+template <class Epi, int MODE, int MW, int MS = 1>
+__global__ __launch_bounds__(NTHREADS * MW, (MS == 2 ? 2 : (MW >= 2 ? 4 : 3))) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
+    conv_body<Epi, MODE, MW, MS>(P, epi, blockIdx.y);
 }
 
 // Two independent contractions over the same pixel tiling in ONE launch (blockIdx.y < nA -> A, else B): the ST-LSTM's
@@ -597,19 +612,19 @@ __global__ __launch_bounds__(NTHREADS, 3) void conv_gemm_dual_kernel(const ConvP
     else conv_body<EpiB, MODE, 1>(PB, epiB, blockIdx.y - nA);
 }
 
-template <class Epi, int MODE, int MW>
+template <class Epi, int MODE, int MW, int MS = 1>
 static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tiles, hipStream_t s) {
     const size_t lds = (size_t)plan.a_bytes + 2 * (Epi::NG * 32 * (ModeTraits<MODE>::WROW_DATA + 16));
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<Epi, MODE, MW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<Epi, MODE, MW, MS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid(plan.B * plan.tiles_x * plan.tiles_y, n_tiles);
-    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE, MW>), grid, dim3(NTHREADS * MW), lds, s, plan, epi);
+    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE, MW, MS>), grid, dim3(NTHREADS * MW), lds, s, plan, epi);
     return hipGetLastError();
 }
 
@@ -619,11 +634,16 @@ static hipError_t launch_conv(const ConvPlan& plan_in, const Epi& epi, int n_til
     if (dbg < 0) { const char* e = getenv("VPX_DBG"); dbg = e ? atoi(e) : 0; }
     ConvPlan plan = plan_in;
     plan.dbg = dbg;
-    const int mw = plan.mw > 1 ? 2 : 1;
+    const int mw = plan.mw >= 4 ? 4 : (plan.mw > 1 ? 2 : 1);
     if ((plan.H + TILE_H * mw - 1) / (TILE_H * mw) != plan.tiles_y) return hipErrorInvalidValue;  // host geometry mismatch
     if (plan.prec == VPX_PREC_F32) return launch_conv_m<Epi, 0, 1>(plan, epi, n_tiles, s);  // fp32 is MFMA-bound: MW=1 only
-    if (plan.prec == VPX_PREC_BF16X3)
+    if (plan.prec == VPX_PREC_BF16X3) {
+        static int ms = -1;  // 16x16 tile as 4 waves x 2 sub-tiles (VPX_MS=2) instead of 8 waves x 1
+        if (ms < 0) { const char* e = getenv("VPX_MS"); ms = e ? atoi(e) : 1; }
+        if (mw == 4) return launch_conv_m<Epi, 1, 4>(plan, epi, n_tiles, s);
+        if (mw == 2 && ms == 2) return launch_conv_m<Epi, 1, 1, 2>(plan, epi, n_tiles, s);
         return mw == 2 ? launch_conv_m<Epi, 1, 2>(plan, epi, n_tiles, s) : launch_conv_m<Epi, 1, 1>(plan, epi, n_tiles, s);
+    }
     if (plan.prec == VPX_PREC_BF16) return launch_conv_m<Epi, 2, 1>(plan, epi, n_tiles, s);
     return hipErrorInvalidValue;
 }
@@ -744,7 +764,7 @@ int pick_mw(int B, int H, int W, int n_tiles, int prec) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("VPX_MW"); forced = e ? atoi(e) : 0; }
     if (prec != VPX_PREC_BF16X3) return 1;  // MW=2 is only instantiated for bf16x3
-    if (forced == 1 || forced == 2) return forced;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
     // 8-wave workgroups halve the weight traffic per pixel; worth it only when the launch still fills the chip
     const long long wgs2 = (long long)B * ((H + 2 * TILE_H - 1) / (2 * TILE_H)) * ((W + TILE_W - 1) / TILE_W) * n_tiles;
     return wgs2 >= 512 ? 2 : 1;
@@ -761,7 +781,7 @@ int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int p
     if (forced) return forced < kstep ? kstep : forced;
     const int npos = ((TILE_H * mw - 1) * stride + kh) * ((TILE_W - 1) * stride + kw);
     const int wbytes = 2 * ng * 32 * (mode_kc(prec) * 4 + 16);
-    const int wg_cap = mw == 2 ? 2 : 3;  // residency: 2 x 8 waves or 3 x 4 waves per CU (register budgets 128 / 168)
+    const int wg_cap = mw == 4 ? 1 : (mw == 2 ? 2 : 3);  // residency: 2 x 8 waves or 3 x 4 waves per CU (register budgets 128 / 168)
     int best = CS_MAX, best_wg = 0;
     for (int cs = kstep; cs <= CS_MAX; cs *= 2) {
         int nst = 0;
