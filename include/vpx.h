@@ -66,6 +66,11 @@ typedef struct vpx_stlstm_desc {
 
 int vpx_version(void);
 const char* vpx_last_error(void);
+/* Run-to-run bit reproducibility (the counterpart of torch.use_deterministic_algorithms, which the reference inherits
+ * from PyTorch). Default 0: convolutions on small feature maps split their contraction over workgroups and combine
+ * partial sums with floating-point atomics (results equal up to fp32 summation order, ~1e-7 relative). 1: no atomics
+ * anywhere (slower on 16x16 / 32x32 maps). Process-wide; returns the previous setting. */
+int vpx_set_deterministic(int on);
 
 /* ---- ConvLSTM over a sequence ------------------------------------------------------------------------------ */
 size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d); /* scratch, contents undefined between calls */

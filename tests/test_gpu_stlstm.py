@@ -42,7 +42,15 @@ def test_stlstm_cell_vs_golden(vpx, tag):
     with torch.no_grad():
         o2 = cell(inp["x"], inp["h"], inp["c"], inp["m"])
         o3 = cell(inp["x"], inp["h"], inp["c"], inp["m"])
-    assert _relmax(o3[0], g["h_new"]) < RTOL and torch.equal(o2[0], o3[0])
+        assert _relmax(o3[0], g["h_new"]) < RTOL and _relmax(o2[0], o3[0]) < 1e-6
+        # small maps split the contraction over workgroups (atomic partial sums): bit-reproducible only on request
+        torch.use_deterministic_algorithms(True)
+        try:
+            d2 = cell(inp["x"], inp["h"], inp["c"], inp["m"])
+            d3 = cell(inp["x"], inp["h"], inp["c"], inp["m"])
+        finally:
+            torch.use_deterministic_algorithms(False)
+    assert _relmax(d3[0], g["h_new"]) < RTOL and torch.equal(d2[0], d3[0])
 
 
 def test_stlstm_real_shape_vs_oracle(vpx):

@@ -18,7 +18,7 @@ FLAG_SAVE_FOR_BWD = 1
 FLAG_WEIGHTS_PACKED = 2
 
 EXPORTED_SYMBOLS = [
-    "vpx_version", "vpx_last_error",
+    "vpx_version", "vpx_last_error", "vpx_set_deterministic",
     "vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes", "vpx_convlstm_seq_fwd", "vpx_convlstm_seq_bwd",
     "vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes", "vpx_stlstm_step_fwd", "vpx_stlstm_step_bwd",
     "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
@@ -72,6 +72,8 @@ def lib():
         sz = ctypes.c_size_t
         L.vpx_version.restype = ctypes.c_int
         L.vpx_last_error.restype = ctypes.c_char_p
+        L.vpx_set_deterministic.restype = ctypes.c_int
+        L.vpx_set_deterministic.argtypes = [ctypes.c_int]
         for name in ("vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes"):
             getattr(L, name).restype = sz
             getattr(L, name).argtypes = [ctypes.POINTER(ConvLSTMDesc)]

@@ -116,6 +116,7 @@ hipError_t launch_pack_weights(const PackDesc& pd, float* dst, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------
 struct TileCtx {
     int b, y0, x0, n_tile, prow, j, hh, H, W;  // prow = first row (inside the workgroup tile) of this 32-pixel MFMA tile
+    int kz;                                    // K-split index of this workgroup (0 when the contraction is not split)
 };
 
 // accumulator register r of a 32x32 MFMA tile holds row (r&3) + 8*(r>>2) + 4*hh; wave-local pixel index = that row.
@@ -128,6 +129,7 @@ __device__ __forceinline__ bool tile_pixel(const TileCtx& t, int r, int& y, int&
 
 struct EpiConvLSTM {
     static constexpr int NG = 4;
+    static constexpr bool SPLITK = false;
     ConvLSTMStepArgs a;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], const TileCtx& t) const {
         const int ch = t.n_tile * 32 + t.j;
@@ -194,6 +196,7 @@ struct EpiConvLSTM {
 template <int NGROUPS>
 struct EpiSTGate {
     static constexpr int NG = NGROUPS;
+    static constexpr bool SPLITK = false;
     STGateArgs a;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[NGROUPS], const TileCtx& t) const {
         const int ch = t.n_tile * 32 + t.j;
@@ -225,6 +228,7 @@ struct EpiSTGate {
 
 struct EpiSTOut {
     static constexpr int NG = 1;
+    static constexpr bool SPLITK = false;
     STOutArgs a;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[1], const TileCtx& t) const {
         const int ch = t.n_tile * 32 + t.j;
@@ -246,13 +250,14 @@ struct EpiSTOut {
 template <int NGP>
 struct EpiPlain {
     static constexpr int NG = NGP;
+    static constexpr bool SPLITK = true;
     PlainEpiArgs a;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[NGP], const TileCtx& t) const {
 #pragma unroll
         for (int g = 0; g < NGP; ++g) {
             const int co = t.n_tile * (NGP * 32) + g * 32 + t.j;
             if (co >= a.Co) continue;
-            const float bv = a.bias ? a.bias[co] : 0.0f;
+            const float bv = (a.bias && t.kz == 0) ? a.bias[co] : 0.0f;
             float* dst;
             long long bs;
             int ld, cc;
@@ -266,6 +271,10 @@ struct EpiPlain {
                 const size_t pix = a.omap ? ((size_t)(y * a.oys + a.oyo) * a.Wmem + (x * a.oxs + a.oxo)) : ((size_t)y * t.W + x);
                 float* p = dst + (size_t)t.b * bs + pix * ld + cc;
                 float v = acc[g][r] + bv;
+                if (a.ksplit > 1) {  // K split over workgroups: partial sums meet in memory (destination pre-zeroed or +=)
+                    unsafeAtomicAdd(p, v);
+                    continue;
+                }
                 if (a.leaky != 0.0f) v = v > 0.0f ? v : v * a.leaky;
                 *p = a.accumulate ? (*p + v) : v;
             }
@@ -369,15 +378,19 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
     // prefetch cursor: (stage, chunks left in it, this thread's source address). Stages of absent operands are not in
     // the plan, so the packed stream can have gaps at stage boundaries — the cursor jumps to the next stage's chunk0.
     auto stage_chunks = [&](int s) { return (P.stage[s].nq + QPC - 1) / QPC; };
-    int ps = 0, prem = P.nstage > 0 ? stage_chunks(0) : 0;
-    const char* wnext = wtile + (size_t)(P.nstage > 0 ? P.stage[0].chunk0 : 0) * CHUNK_BYTES + tid * 16;
+    // K split (plain convolutions on small maps): workgroup z of ksplit owns the stages [s_begin, s_end)
+    const int ksplit = P.ksplit > 1 ? P.ksplit : 1;
+    const int kz = ksplit > 1 ? (int)blockIdx.z : 0;
+    const int s_begin = kz * P.nstage / ksplit, s_end = (kz + 1) * P.nstage / ksplit;
+    int ps = s_begin, prem = s_begin < s_end ? stage_chunks(s_begin) : 0;
+    const char* wnext = wtile + (size_t)(s_begin < s_end ? P.stage[s_begin].chunk0 : 0) * CHUNK_BYTES + tid * 16;
     auto issue_load = [&](f32x4 (&wr)[WIT]) {  // returns silently past the end of the stream
-        if (ps < P.nstage) {
+        if (ps < s_end) {
 #pragma unroll
             for (int it = 0; it < WIT; ++it)
                 if (tid + it * NTH < WV4 && !DBGBIT(4)) wr[it] = *reinterpret_cast<const f32x4*>(wnext + it * NTH * 16);
             wnext += CHUNK_BYTES;
-            if (--prem == 0 && ++ps < P.nstage) {
+            if (--prem == 0 && ++ps < s_end) {
                 prem = stage_chunks(ps);
                 wnext = wtile + (size_t)P.stage[ps].chunk0 * CHUNK_BYTES + tid * 16;
             }
@@ -403,7 +416,7 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
 
     int gidx = 0;  // chunks consumed so far (parity selects LDS buffer / register set)
     const char* wb0 = W_lds + j * WROW + hh * 16;
-    for (int s = 0; s < P.nstage; ++s) {
+    for (int s = s_begin; s < s_end; ++s) {
         const ConvStage st = P.stage[s];
         const ConvSeg sg = P.seg[st.seg];
         const int arow = st.cn * 4 + 16;  // bytes per halo position (odd multiple of 16 B -> conflict-free b128 reads)
@@ -509,12 +522,12 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
         int ks = 0, tdx = 0, tapoff = 0;
         const char* a_lane = A_lds + (py * sd * halo_w + px * sd) * arow + hh * 16;
         const int sub_off = 2 * sd * halo_w * arow;  // next sub-tile of this wave: two tile rows further down
-        if (s == 0) write_lds(wr, 0);  // very first chunk of the stream
+        if (s == s_begin) write_lds(wr, 0);  // very first chunk of the stream
         __syncthreads();
         for (int kq = 0; kq < st.nq; kq += QPC) {
             const int buf = gidx & 1;
             const char* wb = wb0 + buf * WBUF;
-            const bool has_next = kq + QPC < st.nq || s + 1 < P.nstage;
+            const bool has_next = kq + QPC < st.nq || s + 1 < s_end;
             if (has_next) issue_load(wr);  // chunk g+1 travels while chunk g is multiplied
 #pragma unroll
             for (int q = 0; q < QPC; ++q) {
@@ -593,7 +606,7 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
     }
 #pragma unroll
     for (int m = 0; m < MS; ++m) {
-        TileCtx t{b, y0, x0, n_tile, 2 * (MS * wave + m), j, hh, P.H, P.W};
+        TileCtx t{b, y0, x0, n_tile, 2 * (MS * wave + m), j, hh, P.H, P.W, kz};
         epi(acc[m], t);
     }
 }
@@ -623,7 +636,7 @@ static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tile
         attr_set = true;
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    dim3 grid(plan.B * plan.tiles_x * plan.tiles_y, n_tiles);
+    dim3 grid(plan.B * plan.tiles_x * plan.tiles_y, n_tiles, plan.ksplit > 1 ? plan.ksplit : 1);
     hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE, MW, MS>), grid, dim3(NTHREADS * MW), lds, s, plan, epi);
     return hipGetLastError();
 }
@@ -634,6 +647,7 @@ static hipError_t launch_conv(const ConvPlan& plan_in, const Epi& epi, int n_til
     if (dbg < 0) { const char* e = getenv("VPX_DBG"); dbg = e ? atoi(e) : 0; }
     ConvPlan plan = plan_in;
     plan.dbg = dbg;
+    if (!Epi::SPLITK) plan.ksplit = 0;  // only the plain epilogue can combine partial sums
     const int mw = plan.mw >= 4 ? 4 : (plan.mw > 1 ? 2 : 1);
     if ((plan.H + TILE_H * mw - 1) / (TILE_H * mw) != plan.tiles_y) return hipErrorInvalidValue;  // host geometry mismatch
     if (plan.prec == VPX_PREC_F32) return launch_conv_m<Epi, 0, 1>(plan, epi, n_tiles, s);  // fp32 is MFMA-bound: MW=1 only
@@ -653,7 +667,11 @@ hipError_t launch_convlstm_step_f32(const ConvPlan& plan, const ConvLSTMStepArgs
     return launch_conv(plan, e, n_tiles, s);
 }
 
-hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, int n_tiles, hipStream_t s) {
+hipError_t launch_conv_plain_f32(const ConvPlan& plan_in, const PlainEpiArgs& ea_in, int n_tiles, hipStream_t s) {
+    ConvPlan plan = plan_in;
+    PlainEpiArgs ea = ea_in;
+    plan.ksplit = ea.ksplit = (plan.ksplit > 1 && plan.ksplit <= plan.nstage) ? plan.ksplit : 0;
+    if (plan.ksplit > 1 && ea.leaky != 0.0f) return hipErrorInvalidValue;  // partial sums cannot be activated
     switch (ea.ng) {
         case 1: return launch_conv(plan, EpiPlain<1>{ea}, n_tiles, s);
         case 2: return launch_conv(plan, EpiPlain<2>{ea}, n_tiles, s);
@@ -670,10 +688,20 @@ int plain_groups(int Co, long long m_tiles) {
         const int padded = (Co + w - 1) / w * w;
         if (padded < best_pad) { best_pad = padded; best = ng; }
     }
-    if (m_tiles > 0) {  // few pixel tiles: trade activation re-reads for workgroups until ~512 are in flight
-        while (best > 1 && m_tiles * plain_tiles_ng(Co, best) < 512) --best;
-    }
+    (void)m_tiles;  // occupancy on small maps comes from the K split (pick_ksplit), not from narrower N tiles
     return best;
+}
+
+int pick_ksplit(long long wgs, int nstage) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("VPX_KSPLIT"); forced = e ? atoi(e) : 0; }
+    if (g_deterministic) return 1;
+    int k = 1;
+    if (forced > 0) k = forced;
+    else if (wgs > 0 && wgs < 384) k = (int)((768 + wgs - 1) / wgs);  // aim at ~3 workgroups per CU
+    if (k > nstage) k = nstage;
+    if (k > 16) k = 16;
+    return k < 1 ? 1 : k;
 }
 
 void fill_plain_pack(PackDesc& pd, int Co, int first, int ng_in) {

@@ -197,7 +197,7 @@ __global__ void st_ln_out_kernel(const float* __restrict__ o_pre, const float* _
                                  long long n) {
     const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (e >= n) return;
-    const float o_ = ln_sigmoid(o_pre[e] + oc[e]);
+    const float o_ = ln_sigmoid(o_pre[e] + (oc ? oc[e] : 0.0f));  // oc == null: o_pre already holds the full pre-activation
     const float tl = ln_tanh(lc[e]);
     h_new[e] = o_ * tl;
     if (o_save) { o_save[e] = o_; tl_save[e] = tl; }

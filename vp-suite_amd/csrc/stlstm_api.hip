@@ -12,7 +12,8 @@ using namespace vpx;
 namespace {
 
 struct STLayout {
-    int taps, tiles32, tiles128, ng_l;
+    int taps, tiles32, tiles128, ng_l, ksplit_l;
+    int o_split, o_ng, o_tiles;   // conv_o as a K-split plain conv accumulating into o_pre (small maps) instead of the fused launch
     int nstage_g, chunks_g;            // gate groups: segments (x: Cin, recurrent: Ch), k x k
     ConvStage stage_g[MAX_STAGE];
     int nstage_o, chunks_o;            // conv_o: segments (c_new: Ch, m_new: Ch), k x k
@@ -40,15 +41,28 @@ int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
     const int segG[2] = {d->Cin, d->Ch};
     const int segO[2] = {d->Ch, d->Ch};
     L.nstage_g = build_stages(L.stage_g, &L.chunks_g, segG, 2, L.taps, pick_stage_channels(segG, 2, d->k, d->k, 4, d->precision), d->precision);
-    L.nstage_o = build_stages(L.stage_o, &L.chunks_o, segO, 2, L.taps, pick_stage_channels(segO, 2, d->k, d->k, 1, d->precision), d->precision);
+    const long long m_tiles = (long long)d->B * ((d->H + TILE_H - 1) / TILE_H) * ((d->W + TILE_W - 1) / TILE_W);
+    // conv_o: fused with the output gate (32 channels per workgroup) when that fills the chip; on small maps a 128-wide
+    // K-split plain convolution adds conv_o(mem) into o_pre and a pointwise kernel applies the gate
+    L.o_ng = 1; L.o_tiles = L.tiles32; L.o_split = 0;
+    if (m_tiles * L.tiles32 < 384 && !d->layer_norm) {
+        const int ng = plain_groups(d->Ch);
+        ConvStage st[MAX_STAGE];
+        int ch = 0;
+        const int ns = build_stages(st, &ch, segO, 2, L.taps, pick_stage_channels(segO, 2, d->k, d->k, ng, d->precision), d->precision);
+        const int ks = ns > 0 ? pick_ksplit(m_tiles * plain_tiles_ng(d->Ch, ng), ns) : 1;
+        if (ks > 1) { L.o_split = ks; L.o_ng = ng; L.o_tiles = plain_tiles_ng(d->Ch, ng); }
+    }
+    L.nstage_o = build_stages(L.stage_o, &L.chunks_o, segO, 2, L.taps, pick_stage_channels(segO, 2, d->k, d->k, L.o_ng, d->precision), d->precision);
     L.nstage_l = build_stages(L.stage_l, &L.chunks_l, segO, 2, 1, pick_stage_channels(segO, 2, 1, 1, L.ng_l, d->precision), d->precision);
     if (L.nstage_g < 0 || L.nstage_o < 0 || L.nstage_l < 0) { set_error("stlstm: too many channel stages"); return VPX_ERR_UNSUPPORTED; }
     L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
     L.n_x = (size_t)d->B * d->H * d->W * d->Cin;
     L.wpk_c = packed_weight_bytes(L.tiles32, L.chunks_g, 4, d->precision) / 4;
     L.wpk_m = packed_weight_bytes(L.tiles32, L.chunks_g, 3, d->precision) / 4;
-    L.wpk_o = packed_weight_bytes(L.tiles32, L.chunks_o, 1, d->precision) / 4;
+    L.wpk_o = packed_weight_bytes(L.o_tiles, L.chunks_o, L.o_ng, d->precision) / 4;
     L.wpk_l = packed_weight_bytes(L.tiles128, L.chunks_l, L.ng_l, d->precision) / 4;
+    L.ksplit_l = pick_ksplit(m_tiles * L.tiles128, L.nstage_l);
     return VPX_OK;
 }
 
@@ -175,9 +189,8 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         po.seg[0] = PackSeg{Wo, (long long)2 * Ch * L.taps, L.taps, 0, Ch};
         po.seg[1] = PackSeg{Wo, (long long)2 * Ch * L.taps, L.taps, Ch, Ch};
         memcpy(po.stage, L.stage_o, sizeof(ConvStage) * L.nstage_o);
-        po.nstage = L.nstage_o; po.chunks_total = L.chunks_o; po.prec = d->precision; po.n_tiles = L.tiles32; po.taps = L.taps; po.NG = 1;
-        for (int s = 0; s < 2; ++s) { po.rowbase[s][0] = 0; for (int g = 1; g < 4; ++g) po.rowbase[s][g] = -1; }
-        po.tile_stride = 32; po.nch = Ch;
+        po.nstage = L.nstage_o; po.chunks_total = L.chunks_o; po.prec = d->precision; po.taps = L.taps;
+        fill_plain_pack(po, Ch, 0, L.o_ng);  // ng = 1: 32 output channels per N tile (the fused launch's layout)
         VPX_CHECK_HIP(launch_pack_weights(po, wpk_o, stream));
         // conv_last 1x1: Wlast [Ch, 2Ch, 1, 1]
         PackDesc pl{};
@@ -224,6 +237,8 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         P.chunks_total = L.chunks_l; P.a_bytes = conv_a_bytes(L.stage_l, L.nstage_l, 1, 1); P.wpk = wpk_l;
         PlainEpiArgs ea{};
         ea.Co = Ch; ea.split = Ch; ea.out0 = lc; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch; ea.ng = L.ng_l;
+        P.ksplit = L.ksplit_l;
+        if (P.ksplit > 1) VPX_CHECK_HIP(hipMemsetAsync(lc, 0, L.n_state * sizeof(float), stream));
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.tiles128, stream));
     }
     // ---- launch 4: conv_o(mem) + output gate ----
@@ -234,8 +249,17 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         P.seg[1] = ConvSeg{mO, (long long)(HW * Ch), Ch, 0};
         P.nstage = L.nstage_o; memcpy(P.stage, L.stage_o, sizeof(ConvStage) * L.nstage_o);
         P.chunks_total = L.chunks_o; P.a_bytes = conv_a_bytes(L.stage_o, L.nstage_o, k, k); P.wpk = wpk_o;
-        STOutArgs ea{Ch, o_pre, lc, hO, o_save, tl_save};
-        VPX_CHECK_HIP(launch_st_out_f32(P, ea, L.tiles32, stream));
+        if (L.o_split > 1) {
+            PlainEpiArgs pa{};
+            pa.Co = Ch; pa.split = Ch; pa.out0 = o_pre; pa.bstride0 = (long long)(HW * Ch); pa.ld0 = Ch; pa.ng = L.o_ng;
+            pa.accumulate = 1;  // o_pre already holds o_x + o_h (c-group launch)
+            P.ksplit = L.o_split;
+            VPX_CHECK_HIP(launch_conv_plain_f32(P, pa, L.o_tiles, stream));
+            VPX_CHECK_HIP(launch_st_ln_out(o_pre, nullptr, lc, hO, o_save, tl_save, (long long)L.n_state, stream));
+        } else {
+            STOutArgs ea{Ch, o_pre, lc, hO, o_save, tl_save};
+            VPX_CHECK_HIP(launch_st_out_f32(P, ea, L.tiles32, stream));
+        }
     }
     if (d->layout == VPX_LAYOUT_NCHW) {
         VPX_CHECK_HIP(launch_nhwc_to_nchw(hO, h_new, B, Ch, H, Wd, stream));

@@ -17,7 +17,7 @@ struct STBwdLayout {
     int taps, Ch, Cin;
     size_t n_state, n_x, n_g7;
     // dgrad plans: stage tables + chunk counts + N tiles
-    struct DG { int nstage, chunks, tiles, ng; ConvStage stage[MAX_STAGE]; size_t wpk; } o, l, x, h, m;
+    struct DG { int nstage, chunks, tiles, ng, ksplit; ConvStage stage[MAX_STAGE]; size_t wpk; } o, l, x, h, m;
     int n_slices;
     size_t slab_floats;
 };
@@ -28,6 +28,7 @@ int mk_dg(STBwdLayout::DG& g, const int* segC, int nseg, int k, int n_out, int p
     g.nstage = build_stages(g.stage, &g.chunks, segC, nseg, taps, pick_stage_channels(segC, nseg, k, k, g.ng, prec), prec);
     if (g.nstage < 0) return -1;
     g.tiles = plain_tiles_ng(n_out, g.ng);
+    g.ksplit = pick_ksplit(m_tiles * g.tiles, g.nstage);  // 16x16 maps: 64 pixel tiles per launch, K = gates*Ch*k*k is long
     g.wpk = packed_weight_bytes(g.tiles, g.chunks, g.ng, prec) / 4;
     return 0;
 }
@@ -199,6 +200,16 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         pd.transposed = 1; pd.flip = 1;
     };
 
+    // K-split data gradients add their partial sums atomically: destinations that are not accumulated into start at zero
+    auto split_plan = [&](ConvPlan& P, const STBwdLayout::DG& g, float* o0, float* o1, size_t n, bool accumulate) -> hipError_t {
+        P.ksplit = g.ksplit;
+        if (g.ksplit > 1 && !accumulate) {
+            hipError_t e = hipMemsetAsync(o0, 0, n * sizeof(float), stream);
+            if (e == hipSuccess && o1) e = hipMemsetAsync(o1, 0, n * sizeof(float), stream);
+            return e;
+        }
+        return hipSuccess;
+    };
     // ---- A: through h_new = o * tanh(conv_last(mem)) ----
     {
         STBwdOutArgs a{(long long)L.n_state, Ch, ldG, 3 * Ch, g_h, o_save, tl_save, dG7, dlc};
@@ -216,6 +227,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         ea.Co = 2 * Ch; ea.split = Ch; ea.ng = L.o.ng;
         ea.out0 = dcn_conv; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
         ea.out1 = dmn_conv; ea.bstride1 = (long long)(HW * Ch); ea.ld1 = Ch;
+        VPX_CHECK_HIP(split_plan(P, L.o, dcn_conv, dmn_conv, L.n_state, false));
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.o.tiles, stream));
 
         PackDesc pl{};
@@ -225,6 +237,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         ConvPlan Q = plan_for(L.l, 1, wpk_l);
         Q.nseg = 1; Q.seg[0] = ConvSeg{dlc, (long long)(HW * Ch), Ch, 0};
         ea.accumulate = 1;
+        VPX_CHECK_HIP(split_plan(Q, L.l, dcn_conv, dmn_conv, L.n_state, true));
         VPX_CHECK_HIP(launch_conv_plain_f32(Q, ea, L.l.tiles, stream));
     }
     // ---- C: gate groups ----
@@ -253,6 +266,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         P.seg[2] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG};
         PlainEpiArgs ea{};
         ea.Co = Cin; ea.split = Cin; ea.ng = L.x.ng; ea.out0 = dxn; ea.bstride0 = (long long)(HW * Cin); ea.ld0 = Cin;
+        VPX_CHECK_HIP(split_plan(P, L.x, dxn, nullptr, L.n_x, false));
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.x.tiles, stream));
     }
     if (dhn) {
@@ -264,6 +278,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         P.nseg = 1; P.seg[0] = ConvSeg{dG7, (long long)(HW * ldG), 4 * Ch, ldG};
         PlainEpiArgs ea{};
         ea.Co = Ch; ea.split = Ch; ea.ng = L.h.ng; ea.out0 = dhn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
+        VPX_CHECK_HIP(split_plan(P, L.h, dhn, nullptr, L.n_state, false));
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.h.tiles, stream));
     }
     if (dm) {
@@ -276,6 +291,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         PlainEpiArgs ea{};
         ea.Co = Ch; ea.split = Ch; ea.ng = L.m.ng; ea.out0 = dmn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
         ea.accumulate = 1;  // onto dm_new_total * f' written by stage C
+        VPX_CHECK_HIP(split_plan(P, L.m, dmn, nullptr, L.n_state, true));
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.m.tiles, stream));
     }
     // ---- E: weight gradients ----

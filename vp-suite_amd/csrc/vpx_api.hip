@@ -17,6 +17,8 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int g_deterministic = 0;
+
 }  // namespace vpx
 
 using namespace vpx;
@@ -24,6 +26,7 @@ using namespace vpx;
 extern "C" {
 
 int vpx_version(void) { return VPX_VERSION; }
+int vpx_set_deterministic(int on) { const int prev = vpx::g_deterministic; vpx::g_deterministic = on ? 1 : 0; return prev; }
 const char* vpx_last_error(void) { return g_err; }
 
 int vpx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, void* stream) {

@@ -165,6 +165,12 @@ static inline int plain_conv(hipStream_t stream, int prec, ConvGeo g, const floa
     ea.bias = bias; ea.Co = Co; ea.split = Co; ea.ng = ng;
     ea.out0 = out; ea.bstride0 = (long long)g.H * g.W * out_ld; ea.ld0 = out_ld;
     ea.accumulate = accumulate ? 1 : 0;
+    // small maps: split K over workgroups (atomic partial sums) — needs a dense or already-initialised destination
+    P.ksplit = pick_ksplit(m_tiles * pd.n_tiles, P.nstage);
+    if (P.ksplit > 1 && !accumulate) {
+        if (out_ld == Co) VPX_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)g.N * g.H * g.W * Co * sizeof(float), stream));
+        else P.ksplit = 1;
+    }
     VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, pd.n_tiles, stream));
     return VPX_OK;
 }

@@ -46,6 +46,7 @@ struct ConvPlan {
     int a_bytes;          // LDS bytes reserved for the activation stage
     int prec;             // VPX_PREC_F32 | VPX_PREC_BF16X3: operand mode of the contraction
     int mw;               // 32-pixel MFMA row tiles per wave (1: 8x16 workgroup tile, 2: 16x16); 0 is read as 1
+    int ksplit;           // > 1: the stage list is split over blockIdx.z (plain epilogue only; partial sums via atomics)
     int dbg;              // ablation bits for profiling (VPX_DBG): 1 skip MFMAs, 2 skip activation loads, 4 skip weight loads, 8 skip epilogue
     // generalised geometry (all 0 = the stride-1 "same" convolution every recurrent cell uses):
     int stride;           // input step per output pixel (0/1 or 2)
@@ -116,16 +117,19 @@ struct PlainEpiArgs {
     float* out0; long long bstride0; int ld0;   // NHWC, ld = channels per pixel of the destination tensor
     float* out1; long long bstride1; int ld1;
     int accumulate;           // 1: += into destination
+    int ksplit;               // copy of ConvPlan::ksplit (> 1: atomic accumulation, bias from split 0, no activation)
     int ng;                   // 32-channel groups per N tile (plain_groups(Co)); tile covers ng*32 output channels
     float leaky;              // LeakyReLU negative slope applied after the bias (0 = none; 1 would be identity)
     int omap;                 // 1: tile-space pixel (y,x) is stored at (y*oys + oyo, x*oxs + oxo) of a Wmem-wide image
     int oys, oyo, oxs, oxo, Wmem;
 };
 hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, int n_tiles, hipStream_t s);
-// N tiling of a plain convolution with Co outputs: ng = 1..4 groups of 32 channels per workgroup. Chosen to minimise
-// channel padding; when the launch has few pixel tiles (m_tiles given), narrower tiles are preferred until the grid
-// reaches ~2 workgroups per CU (a 128-wide tile on a 16x16 map at B=32 would leave 3/4 of the chip idle).
+// N tiling of a plain convolution with Co outputs: ng = 1..4 groups of 32 channels per workgroup, chosen to minimise
+// channel padding (ties -> wider tiles: fewer re-reads of the activation tile).
 int plain_groups(int Co, long long m_tiles = -1);
+// K split of a plain convolution whose grid would have only `wgs` workgroups: number of stage ranges (1 = no split)
+int pick_ksplit(long long wgs, int nstage);
+extern int g_deterministic;  // vpx_set_deterministic(): 1 = never split K (no floating-point atomics)
 inline int plain_tiles_ng(int Co, int ng) { return (Co + 32 * ng - 1) / (32 * ng); }
 inline int plain_tiles(int Co) { return plain_tiles_ng(Co, plain_groups(Co)); }
 // upper bound of the packed-weight rows over every tiling plain_groups() can return: Co rounded up to 128

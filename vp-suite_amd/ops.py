@@ -28,11 +28,25 @@ PROFILE = None  # set to a KernelProfile() to collect
 
 
 def _require_gpu(t: torch.Tensor, what: str):
+    _sync_determinism()
     if not t.is_cuda:
         raise _lib.VpxError(f"{what}: tensors must live on the GPU (got device '{t.device}'). The hot path runs only as "
                             f"HIP kernels on MI355X; there is no CPU fallback.")
     if t.dtype != torch.float32:
         raise ValueError(f"{what}: expected float32 tensors, got {t.dtype}")
+
+
+_det_state = None
+
+
+def _sync_determinism():
+    """Mirrors torch.use_deterministic_algorithms() into the library (deterministic mode forbids the K-split
+    convolutions' floating-point atomics, see include/vpx.h). Called at the start of every op, before any size query."""
+    global _det_state
+    det = torch.are_deterministic_algorithms_enabled()
+    if det != _det_state:
+        _lib.lib().vpx_set_deterministic(int(det))
+        _det_state = det
 
 
 def _stream():
@@ -124,6 +138,7 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, dhT, dcT):
+        _sync_determinism()
         x, h0c, c0c, Wc, wci, wcf, wco, out, reserve = ctx.saved_tensors
         d = ctx.desc
         dev = out.device
@@ -206,6 +221,7 @@ class _Conv2dSameFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _sync_determinism()
         xs, wc = ctx.saved_tensors
         N, Ci, H, Wd = xs.shape
         Co, _, kh, kw = wc.shape
@@ -260,6 +276,7 @@ class _ConvExFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _sync_determinism()
         xs, wc, y = ctx.saved_tensors
         stride, padding, transposed, slope, has_bias = ctx.cfg
         if slope != 0.0:  # LeakyReLU' from the sign of the output (same sign as the pre-activation for slope > 0)
@@ -307,6 +324,7 @@ class _DecoupleFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dvalue):
+        _sync_determinism()
         dc, dm, A = ctx.saved_tensors
         B, Ch, H, Wd = dc.shape
         needs = ctx.needs_input_grad
@@ -367,7 +385,7 @@ class _STLSTMStepFn(torch.autograd.Function):
         if ws_bytes == 0:
             check(-4 if b"not implemented" in L.vpx_last_error() else -1, "vpx_stlstm_workspace_bytes")
         rs_bytes = L.vpx_stlstm_reserve_bytes(ctypes.byref(d))
-        key = (B, Cin, Ch, H, Wd, k, precision, flags, tuple((w.data_ptr(), w._version) for w in W5))
+        key = (B, Cin, Ch, H, Wd, k, precision, flags, _det_state, tuple((w.data_ptr(), w._version) for w in W5))
         if wsholder is not None and not use_ln:
             ws, packed = wsholder.get(ws_bytes, dev, key)
         else:
@@ -397,6 +415,7 @@ class _STLSTMStepFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dh_new, dc_new, dm_new, ddc, ddm):
+        _sync_determinism()
         saved = ctx.saved_tensors
         xs, hs, cs, ms, c_new, m_new, Wx, Wh, Wm, Wo, Wlast, reserve = saved[:12]
         lnc = list(saved[12:])
