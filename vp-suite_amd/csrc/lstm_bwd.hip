@@ -275,8 +275,12 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const char* base) {
     return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-template <int MAXT>
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_bf16x3_kernel(const WgradArgs a, const int tap_base) {
+// Items (t, b, tile) are software-pipelined through registers: while the MFMAs of item i run out of LDS, the global
+// loads of item i+1 (GPRE dG vectors + APRE activation vectors per thread) are in flight; they are split to hi/lo bf16
+// and stored to LDS after the barrier that ends item i. PIPE = 0 keeps the plain load-store-multiply order (fewer
+// registers: two workgroups per CU).
+template <int MAXT, int APRE, int PIPE>
+__global__ __launch_bounds__(NTHREADS, (PIPE ? 1 : 2)) void wgrad_bf16x3_kernel(const WgradArgs a, const int tap_base) {
     const bool lo_terms = a.prec == VPX_PREC_BF16X3;  // plain bf16 uses the hi planes only (uniform branch)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_bf16x3_kernel(const WgradAr
     char* G_lo = smem + 128 * 128;
     char* A_hi = smem + 2 * 128 * 128;
     char* A_lo = A_hi + npos * 128;
+    constexpr int GPRE = 128 * 16 / NTHREADS;  // dG vectors per thread and item (8)
 
     f32x16 acc[MAXT];
 #pragma unroll
@@ -316,70 +321,105 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_bf16x3_kernel(const WgradAr
     const int tiles = a.tiles_x * a.tiles_y;
     const long long n_items = (long long)a.T * a.B * tiles;
     const int n0 = nt_id * 64;
-    for (long long w = blockIdx.y; w < n_items; w += gridDim.y) {
+    const int ldG = a.ldG ? a.ldG : a.N4;
+    const int q4 = tid & 15;              // this thread's 4-channel column in both tiles (NTHREADS is a multiple of 16)
+    const int n_col = n0 + q4 * 4, c_col = ct.c0 + q4 * 4;
+
+    constexpr int NV = PIPE ? APRE : 4;  // PIPE = 0 streams the tiles through 4 vectors at a time
+    f32x4 gv[PIPE ? GPRE : 4], av[NV];
+    struct ItemGeo { const float* src; const float* dg; int C, y0, x0; bool g_vec, a_vec; };
+    // geometry of item w; returns false when the item contributes nothing (absent h at t = 0)
+    auto item_geo = [&](long long w, ItemGeo& g) -> bool {
         const int tile = (int)(w % tiles);
         const long long tb = w / tiles;
         const int b = (int)(tb % a.B);
         const int t = (int)(tb / a.B);
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-        const int y0 = ty * TILE_H, x0 = tx * TILE_W;
-        const float* src;
-        int C;
+        g.y0 = ty * TILE_H; g.x0 = tx * TILE_W;
         if (ct.seg == 0) {
-            src = a.x + (size_t)b * a.x_bstride + (size_t)t * a.x_tstride;
-            C = a.Cin;
+            g.src = a.x + (size_t)b * a.x_bstride + (size_t)t * a.x_tstride;
+            g.C = a.Cin;
         } else {
-            C = a.Ch;
-            if (t > 0) src = a.hseq + (size_t)b * a.h_bstride + (size_t)(t - 1) * a.h_tstride;
-            else if (a.h0) src = a.h0 + (size_t)b * a.HW * a.Ch;
-            else continue;
+            g.C = a.Ch;
+            if (t > 0) g.src = a.hseq + (size_t)b * a.h_bstride + (size_t)(t - 1) * a.h_tstride;
+            else if (a.h0) g.src = a.h0 + (size_t)b * a.HW * a.Ch;
+            else return false;
         }
-        const int ldG = a.ldG ? a.ldG : a.N4;
-        const float* dg = a.dG + ((size_t)t * a.B + b) * a.HW * ldG;
-        __syncthreads();
-        // ---- stage dG tile: 128 pixels x 64 rows, split to hi/lo bf16 ----
-        const bool g_vec = ((a.N4 | ldG) & 3) == 0 && (reinterpret_cast<uintptr_t>(dg) & 15) == 0;
-        for (int v = tid; v < 128 * 16; v += NTHREADS) {
-            const int pp = v >> 4, q4 = v & 15;
-            const int gy = y0 + (pp >> 4), gx = x0 + (pp & 15);
-            const int n = n0 + q4 * 4;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (gy < a.H && gx < a.W) {
-                const float* rowp = dg + ((size_t)gy * a.W + gx) * ldG;
-                if (g_vec) { if (n < a.N4) val = *reinterpret_cast<const f32x4*>(rowp + n); }
+        g.dg = a.dG + ((size_t)t * a.B + b) * a.HW * ldG;
+        g.g_vec = ((a.N4 | ldG) & 3) == 0 && (reinterpret_cast<uintptr_t>(g.dg) & 15) == 0;
+        g.a_vec = (g.C & 3) == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0;
+        return true;
+    };
+    // vectors [u0, u0 + NU) of this thread: dG tile (128 pixels x 64 rows) and activation halo tile (npos x 64 channels)
+    auto load_g = [&](const ItemGeo& g, int u0, auto nu, auto& dst) {
+#pragma unroll
+        for (int u = 0; u < nu; ++u) {
+            const int pp = (tid >> 4) + (u0 + u) * (NTHREADS / 16);
+            const int gy = g.y0 + (pp >> 4), gx = g.x0 + (pp & 15);
+            dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (pp < 128 && gy < a.H && gx < a.W) {
+                const float* rowp = g.dg + ((size_t)gy * a.W + gx) * ldG;
+                if (g.g_vec) { if (n_col < a.N4) dst[u] = *reinterpret_cast<const f32x4*>(rowp + n_col); }
                 else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n + e < a.N4) val[e] = rowp[n + e];
+                    for (int e = 0; e < 4; ++e) if (n_col + e < a.N4) dst[u][e] = rowp[n_col + e];
                 }
             }
-            uint2 hi, lo;
-            wg_split4(val, hi, lo);
-            *reinterpret_cast<uint2*>(G_hi + pp * 128 + q4 * 8) = hi;
-            *reinterpret_cast<uint2*>(G_lo + pp * 128 + q4 * 8) = lo;
         }
-        // ---- stage activation halo tile: npos x 64 channels ----
-        const bool a_vec = (C & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-        for (int v = tid; v < npos * 16; v += NTHREADS) {
-            const int pos = v >> 4, q4 = v & 15;
+    };
+    auto store_g = [&](int u0, auto nu, const auto& srcv) {
+#pragma unroll
+        for (int u = 0; u < nu; ++u) {
+            const int pp = (tid >> 4) + (u0 + u) * (NTHREADS / 16);
+            if (pp < 128) {
+                uint2 hi, lo;
+                wg_split4(srcv[u], hi, lo);
+                *reinterpret_cast<uint2*>(G_hi + pp * 128 + q4 * 8) = hi;
+                *reinterpret_cast<uint2*>(G_lo + pp * 128 + q4 * 8) = lo;
+            }
+        }
+    };
+    auto load_a = [&](const ItemGeo& g, int u0, auto nu, auto& dst) {
+#pragma unroll
+        for (int u = 0; u < nu; ++u) {
+            const int pos = (tid >> 4) + (u0 + u) * (NTHREADS / 16);
             const int hy = pos / halo_w, hx = pos - hy * halo_w;
-            const int gy = y0 - ph + hy, gx = x0 - pw + hx;
-            const int c = ct.c0 + q4 * 4;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                const float* rowp = src + ((size_t)gy * a.W + gx) * C;
-                if (a_vec) { if (c < C) val = *reinterpret_cast<const f32x4*>(rowp + c); }
+            const int gy = g.y0 - ph + hy, gx = g.x0 - pw + hx;
+            dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (pos < npos && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const float* rowp = g.src + ((size_t)gy * a.W + gx) * g.C;
+                if (g.a_vec) { if (c_col < g.C) dst[u] = *reinterpret_cast<const f32x4*>(rowp + c_col); }
                 else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (c + e < C) val[e] = rowp[c + e];
+                    for (int e = 0; e < 4; ++e) if (c_col + e < g.C) dst[u][e] = rowp[c_col + e];
                 }
             }
-            uint2 hi, lo;
-            wg_split4(val, hi, lo);
-            *reinterpret_cast<uint2*>(A_hi + pos * 128 + q4 * 8) = hi;
-            *reinterpret_cast<uint2*>(A_lo + pos * 128 + q4 * 8) = lo;
         }
-        __syncthreads();
-        // ---- 8 k-steps (tile rows) of 16 pixels ----
+    };
+    auto store_a = [&](int u0, auto nu, const auto& srcv) {
+#pragma unroll
+        for (int u = 0; u < nu; ++u) {
+            const int pos = (tid >> 4) + (u0 + u) * (NTHREADS / 16);
+            if (pos < npos) {
+                uint2 hi, lo;
+                wg_split4(srcv[u], hi, lo);
+                *reinterpret_cast<uint2*>(A_hi + pos * 128 + q4 * 8) = hi;
+                *reinterpret_cast<uint2*>(A_lo + pos * 128 + q4 * 8) = lo;
+            }
+        }
+    };
+    auto load_item = [&](long long w) -> bool {  // whole item into (gv, av): PIPE only
+        ItemGeo g;
+        if (!item_geo(w, g)) return false;
+        load_g(g, 0, std::integral_constant<int, PIPE ? GPRE : 4>{}, gv);
+        load_a(g, 0, std::integral_constant<int, NV>{}, av);
+        return true;
+    };
+    auto store_item = [&]() {
+        store_g(0, std::integral_constant<int, PIPE ? GPRE : 4>{}, gv);
+        store_a(0, std::integral_constant<int, NV>{}, av);
+    };
+    auto multiply = [&]() {  // 8 k-steps (tile rows) of 16 pixels
 #pragma unroll 2
         for (int s = 0; s < TILE_H; ++s) {
             const bf16x8 gh = wg_tr_frag(G_hi + g_lane + s * 16 * 128);
@@ -395,6 +435,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_bf16x3_kernel(const WgradAr
                 }
                 acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, ah, acc[t2], 0, 0, 0);
             }
+        }
+    };
+
+    if constexpr (PIPE) {
+        long long w = blockIdx.y;
+        bool have = w < n_items && load_item(w);
+        while (w < n_items) {
+            __syncthreads();  // every wave is done reading the previous item's planes
+            if (have) store_item();
+            __syncthreads();
+            const bool had = have;
+            w += gridDim.y;
+            have = w < n_items && load_item(w);  // next item's loads fly while this one is multiplied
+            if (had) multiply();
+        }
+    } else {
+        for (long long w = blockIdx.y; w < n_items; w += gridDim.y) {
+            ItemGeo g;
+            if (!item_geo(w, g)) continue;  // (uniform: depends on the item and the column tile only)
+            __syncthreads();
+            for (int u0 = 0; u0 < GPRE; u0 += 4) { load_g(g, u0, std::integral_constant<int, 4>{}, gv); store_g(u0, std::integral_constant<int, 4>{}, gv); }
+            for (int u0 = 0; u0 * (NTHREADS / 16) < npos; u0 += 4) { load_a(g, u0, std::integral_constant<int, 4>{}, av); store_a(u0, std::integral_constant<int, 4>{}, av); }
+            __syncthreads();
+            multiply();
         }
     }
     const int col = ct.cglobal + wc * 32 + i;
@@ -426,14 +490,29 @@ static hipError_t launch_wgrad_group(const WgradArgs& a, int n_slices, int tap_b
     }
     dim3 grid(((a.N4 + 63) / 64) * a.n_ctiles, n_slices, groups);
     if (a.prec == VPX_PREC_BF16X3 || a.prec == VPX_PREC_BF16) {
-        static bool attr_set_b = false;
-        if (!attr_set_b) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_kernel<NTAPS>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // activation vectors per thread and item: halo positions * 16 / 256 (3x3: 12, 5x5: 15, 7x7: 20)
+        const int npos = (TILE_H + a.kh - 1) * (TILE_W + a.kw - 1);
+        const int apre = (npos * 16 + NTHREADS - 1) / NTHREADS;
+        // The item pipeline needs the whole register file (one workgroup per CU). It pays when LDS allows only one
+        // workgroup anyway (5x5 and larger: > 80 KB of planes); 3x3 keeps two workgroups per CU overlapping each other
+        // (measured, ConvLSTM training step: 47.3 ms without vs 54.2 ms with). VPX_WGRAD_PIPE=0/1 forces it.
+        static int pipe_force = -2;
+        if (pipe_force == -2) { const char* e = getenv("VPX_WGRAD_PIPE"); pipe_force = e ? atoi(e) : -1; }
+        const int pipe_env = pipe_force >= 0 ? pipe_force : (lds > 80 * 1024 ? 1 : 0);
+        auto go = [&](auto kern) -> hipError_t {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            attr_set_b = true;
+            hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, a, tap_base);
+            return hipGetLastError();
+        };
+        if (apre > 20) return hipErrorInvalidValue;  // kernels beyond 7x7 are not instantiated
+        if (pipe_env) {
+            if (apre <= 8) return go(&wgrad_bf16x3_kernel<NTAPS, 8, 1>);
+            if (apre <= 12) return go(&wgrad_bf16x3_kernel<NTAPS, 12, 1>);
+            if (apre <= 15) return go(&wgrad_bf16x3_kernel<NTAPS, 15, 1>);
+            return go(&wgrad_bf16x3_kernel<NTAPS, 20, 1>);
         }
-        hipLaunchKernelGGL(wgrad_bf16x3_kernel<NTAPS>, grid, dim3(NTHREADS), lds, s, a, tap_base);
+        return go(&wgrad_bf16x3_kernel<NTAPS, 0, 0>);
     } else {
         hipLaunchKernelGGL(wgrad_kernel<NTAPS>, grid, dim3(NTHREADS), lds, s, a, tap_base);
     }
