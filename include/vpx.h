@@ -17,6 +17,8 @@
  * vpx_decouple_fwd / _bwd          adapter + normalize + |cos| + mean       vp_suite/models/predrnn_v2.py:197-198,209-211
  * vpx_conv2d_nhwc_fwd / _bwd       F.conv2d 1x1 / kxk "same", stride 1      vp_suite/models/predrnn_v2.py:223 (conv_last)
  * vpx_conv2d_ex_fwd                Conv2d / ConvTranspose2d + LeakyReLU     vp_suite/models/precipitation_nowcasting/ef_blocks.py:15-49
+ * vpx_mse_loss                     MSE measure + loss provider              vp_suite/base/base_measure.py:55-57, measure/loss_provider.py:48-51
+ * vpx_adam_step                    torch.optim.Adam(model.parameters(), lr)  vp_suite/vpsuite.py:353, base/base_model.py:174-176
  * vpx_nchw_to_nhwc / nhwc_to_nchw  (layout adaptors at the boundary; the reference is NCHW throughout)
  *
  * Layouts. VPX_LAYOUT_NHWC ("channels last", the library's native layout):
@@ -122,6 +124,20 @@ int vpx_decouple_fwd(const float* delta_c, const float* delta_m, const float* ad
 int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* adapter, const float* dvalue,
                      float* d_delta_c, float* d_delta_m, float* d_adapter, int B, int Ch, int H, int W,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- training tail (the caller side of the path: base_model.py:168-176, vpsuite.py:353) ------------------------- */
+/* loss = scale * mean_{b,t} sum_{c,h,w} (pred - target)^2   (base_measure.py:55-57, image_wise.py:25, loss_provider.py:48-51)
+ * pred/target: n_elements = B*T*C*H*W floats in any (identical) layout, n_frames = B*T; loss: 1 float on device;
+ * dpred (nullable): d loss / d pred, written in the same pass. Deterministic (fixed reduction order, double partials). */
+size_t vpx_mse_loss_workspace_bytes(void);
+int vpx_mse_loss(const float* pred, const float* target, long long n_elements, long long n_frames, float scale,
+                 float* loss, float* dpred, void* workspace, size_t workspace_bytes, void* stream);
+/* One torch.optim.Adam step (amsgrad off) over flat, 16-byte aligned buckets of n floats; step >= 1 is the iteration
+ * count after this update; grad is multiplied by grad_scale first (1/world_size after a summing all-reduce).
+ * Hyper-parameters are doubles: the derived scalars (1 - beta, lr / (1 - beta1^t), ...) are formed in double as PyTorch
+ * forms them in Python floats, and rounded to fp32 once. */
+int vpx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
 
 /* ---- plain stride-1 "same" convolution, NHWC, optional bias; y [N,H,W,Co] = conv(x [N,H,W,Ci], w [Co,Ci,kh,kw]) --- */
 size_t vpx_conv2d_workspace_bytes(int Ci, int Co, int kh, int kw);

@@ -202,3 +202,21 @@ def predrnn_v2_forward(sd, frames, pred_frames, *, patch_size, num_layers, layer
         frames_out.append(x_gen)
     pred = reshape_patch_back(torch.stack(frames_out[-pred_frames:], dim=1), patch_size)
     return pred, decoupling_loss_scale * torch.mean(torch.stack(dec, dim=0))
+
+
+def adam_step_ref(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    """numpy restatement of one torch.optim.Adam update (torch/optim/adam.py::_single_tensor_adam, amsgrad=False,
+    maximize=False; pinned torch==1.10.1, requirements.txt:13 — the formula is unchanged in the torch 2.10 here), the
+    optimizer vp_suite/vpsuite.py:353 builds. float32 arithmetic like PyTorch; returns (p, m, v)."""
+    import numpy as np
+    f32 = np.float32
+    g = (g.astype(f32) * f32(grad_scale)).astype(f32)
+    if weight_decay:
+        g = g + f32(weight_decay) * p
+    m = (f32(beta1) * m + f32(1.0 - beta1) * g).astype(f32)
+    v = (f32(beta2) * v + f32(1.0 - beta2) * g * g).astype(f32)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = (np.sqrt(v) / f32(np.sqrt(bc2)) + f32(eps)).astype(f32)
+    p = (p - f32(lr / bc1) * (m / denom)).astype(f32)
+    return p, m, v

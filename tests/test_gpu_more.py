@@ -194,3 +194,71 @@ def test_edge_shapes_vs_oracle(vpx):
     with pytest.raises(ValueError):   # empty sequence / batch are rejected like any other bad dimension
         vpx.ops.convlstm_seq(torch.zeros(1, 0, 3, 4, 4, device="cuda"), None, None, torch.zeros(16, 7, 3, 3, device="cuda"),
                              None, seq_len=0, in_channels=3)
+
+
+@pytest.mark.gpu
+def test_mse_loss_kernel_vs_oracle(vpx):
+    """vpx_mse_loss (value + gradient in one pass) against the restated measure (base_measure.py:55-57), incl. a
+    channels-last prediction and an element count that is not a multiple of the vector width."""
+    from oracle.torch_ref import mse_measure as mse_ref
+    from vp_suite_amd import ops
+    for shape, cl in (((3, 4, 1, 16, 16), False), ((2, 3, 3, 9, 7), True), ((4, 10, 1, 64, 64), False)):
+        pred = seeded_rand(shape, name_seed("mse.p" + str(shape))).cuda()
+        tgt = seeded_rand(shape, name_seed("mse.t" + str(shape))).cuda()
+        if cl:
+            pred = ops.to_channels_last(pred.flatten(0, 1)).unflatten(0, shape[:2])
+        pred.requires_grad_(True)
+        loss = ops.mse_loss(pred, tgt, 1.0)
+        (loss * 3.0).backward()
+        pr = pred.detach().cpu().clone().requires_grad_(True)
+        ref = mse_ref(pr, tgt.cpu())
+        (ref * 3.0).backward()
+        assert abs(float(loss) - float(ref)) < 1e-6 * abs(float(ref)), shape
+        assert _relmax(pred.grad, pr.grad) < 1e-6, shape
+
+
+@pytest.mark.gpu
+def test_flat_adam_kernel_vs_oracle_and_torch(vpx):
+    """vpx_adam_step over flat buckets against the numpy restatement and torch.optim.Adam (vpsuite.py:353), 3 steps,
+    odd length (tail path), grad_scale folding the data-parallel mean."""
+    from oracle.torch_ref import adam_step_ref
+    from vp_suite_amd import ops
+    n = 100003
+    p0 = seeded_randn((n,), name_seed("adam.p")).numpy()
+    p, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    dp, dm, dv = torch.from_numpy(p0.copy()).cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in (1, 2, 3):
+        g = (seeded_randn((n,), name_seed(f"adam.g{step}")).numpy() * (10.0 ** (step - 2))).astype(np.float32)
+        p, m, v = adam_step_ref(p, g, m, v, step, 1e-3, grad_scale=0.5)
+        ops.adam_step(dp, torch.from_numpy(g).cuda(), dm, dv, step, 1e-3, grad_scale=0.5)
+        assert np.abs(dp.cpu().numpy() - p).max() < 3e-7, step
+        assert _relmax(dm, m) < 1e-6 and _relmax(dv, v) < 1e-6
+
+
+@pytest.mark.gpu
+def test_flat_adam_drives_train_iter_like_torch_adam(vpx):
+    """FlatAdam.from_module as the drop-in for torch.optim.Adam(model.parameters()) inside the reference harness
+    (train_iter: zero_grad -> backward -> step, base_model.py:174-176): same parameters after 3 iterations, and the
+    golden pins of the reference run (params_after3)."""
+    from vp_suite_amd.measure import PredictionLossProvider
+    from vp_suite_amd.train import FlatAdam
+    import golden_cases as gc
+    from test_gpu_models import _ef
+    kw, B, T, P = gc.EF_TINY_KW, 2, 3, 2
+    g = load_golden("ef_tiny")
+    c, h, w = kw["img_shape"]
+    frames = seeded_rand((B, T + P, c, h, w), name_seed("ef.tiny.frames")).cuda()
+    lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
+    cfg = {"device": "cuda", "context_frames": T, "pred_frames": P, "val_rec_criterion": "mse"}
+    data = {"frames": frames, "actions": torch.zeros(B, T + P - 1, 0)}
+    m = _ef(vpx, "tiny", kw)
+    opt = FlatAdam.from_module(m, lr=1e-3)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=5, factor=0.2, min_lr=1e-6)  # vpsuite.py:354
+    for _ in range(3):
+        m.train_iter(cfg, [data], opt, lp, epoch=0)
+    sched.step(1.0)
+    named = dict(m.named_parameters())
+    pflat = np.concatenate([named[k].detach().cpu().numpy().reshape(-1) for k in sorted(named)])
+    assert np.abs(pflat[::3] - g["params_after3_s3"]).max() < 2e-5
+    sd = m.state_dict()  # parameters stay ordinary, individually addressable tensors
+    assert all(sd[k].shape == v.shape for k, v in named.items())

@@ -187,3 +187,20 @@ def test_torch_ref_predrnn(tag, kw, B, Ttot, P):
         mask[torch.from_numpy(g["train.random_flip"]) < eta] = 1
         pred_t, _ = tr.predrnn_v2_forward(sd, frames, P, mask_true=mask, **common)
         assert np.abs(pred_t.numpy() - g["train.pred"]).max() < 1e-5
+
+
+def test_adam_restatement_matches_torch_adam():
+    """Pins oracle.torch_ref.adam_step_ref to PyTorch's own Adam (the optimizer the reference constructs, vpsuite.py:353)."""
+    import numpy as np, torch
+    from oracle.torch_ref import adam_step_ref
+    rng = np.random.default_rng(5)
+    p0 = rng.standard_normal(1000).astype(np.float32)
+    grads = [rng.standard_normal(1000).astype(np.float32) * s for s in (1.0, 1e-3, 30.0)]
+    tp = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([tp], lr=1e-3)
+    p, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    for step, g in enumerate(grads, 1):
+        tp.grad = torch.from_numpy(g.copy())
+        opt.step()
+        p, m, v = adam_step_ref(p, g, m, v, step, 1e-3)
+        assert np.abs(p - tp.detach().numpy()).max() < 2e-7, step

@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = [
     "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_conv2d_bwd_workspace_bytes", "vpx_conv2d_nhwc_bwd",
     "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd",
     "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
+    "vpx_mse_loss_workspace_bytes", "vpx_mse_loss", "vpx_adam_step",
 ]
 
 
@@ -108,6 +109,12 @@ def lib():
         L.vpx_conv2d_ex_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
         L.vpx_conv2d_ex_fwd.restype = ctypes.c_int
         L.vpx_conv2d_ex_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 4 + [vp, sz, vp]
+        L.vpx_mse_loss_workspace_bytes.restype = sz
+        L.vpx_mse_loss_workspace_bytes.argtypes = []
+        L.vpx_mse_loss.restype = ctypes.c_int
+        L.vpx_mse_loss.argtypes = [vp, vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_float, vp, vp, vp, sz, vp]
+        L.vpx_adam_step.restype = ctypes.c_int
+        L.vpx_adam_step.argtypes = [vp] * 4 + [ctypes.c_longlong] + [ctypes.c_double] * 5 + [ctypes.c_int, ctypes.c_double, vp]
         for name in ("vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw"):
             getattr(L, name).restype = ctypes.c_int
             getattr(L, name).argtypes = [vp, vp] + [ctypes.c_int] * 4 + [vp]

@@ -345,6 +345,64 @@ def decouple_term(delta_c, delta_m, adapter_w):
     return _DecoupleFn.apply(delta_c, delta_m, adapter_w)
 
 
+def _is_dense(t: torch.Tensor) -> bool:
+    """True when the tensor's elements tile one memory block without gaps or overlap (any dimension order)."""
+    expect = 1
+    for size, stride in sorted(((s, st) for s, st in zip(t.shape, t.stride()) if s > 1), key=lambda p: p[1]):
+        if stride != expect:
+            return False
+        expect *= size
+    return True
+
+
+class _MSELossFn(torch.autograd.Function):
+    """scale * mean_{b,t} sum_{c,h,w} (pred - target)^2 with d/dpred produced in the same pass
+    (base_measure.py:55-57, image_wise.py:25, loss_provider.py:48-51)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, scale):
+        _require_gpu(pred, "mse_loss")
+        if pred.ndim != 5 or target.ndim != 5:
+            raise ValueError("Mean Squared Error (MSE) / L2 Loss expects 5-D inputs!")
+        if pred.shape != target.shape:
+            raise ValueError("Output images and target images are of different shape!")
+        p = pred if _is_dense(pred) else pred.contiguous()
+        # the sum runs over memory order, so the target only has to share the prediction's memory layout
+        tg = target if (target.stride() == p.stride() and target.dtype == p.dtype) else torch.empty_like(p).copy_(target)
+        L = _lib.lib()
+        ws_bytes = L.vpx_mse_loss_workspace_bytes()
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=p.device)
+        loss = torch.empty((), device=p.device)
+        need = ctx.needs_input_grad[0]
+        g = torch.empty_like(p) if need else None
+        rc = L.vpx_mse_loss(ptr(p), ptr(tg), p.numel(), p.shape[0] * p.shape[1], float(scale), ptr(loss), ptr(g),
+                            ptr(ws), ws_bytes, _stream())
+        check(rc, "vpx_mse_loss")
+        ctx.g = g
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        g, ctx.g = ctx.g, None
+        return (None if g is None else g.mul_(dloss)), None, None
+
+
+def mse_loss(pred, target, scale: float = 1.0):
+    return _MSELossFn.apply(pred, target, scale)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    """One torch.optim.Adam update of flat fp32 buckets, in place (vpsuite.py:353; torch/optim/adam.py semantics)."""
+    _require_gpu(param, "adam_step")
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() == param.numel()):
+            raise ValueError("adam_step: buckets must be contiguous float32 GPU tensors of equal size")
+    rc = _lib.lib().vpx_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr),
+                                  float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
+                                  float(grad_scale), _stream())
+    check(rc, "vpx_adam_step")
+
+
 class STWorkspace:
     """Per-cell workspace that lets consecutive steps of one forward pass skip the weight repack
     (VPX_FLAG_WEIGHTS_PACKED): valid while the weights' version counters and the problem shape are unchanged."""
