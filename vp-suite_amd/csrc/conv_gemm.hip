@@ -658,7 +658,7 @@ static hipError_t launch_conv(const ConvPlan& plan_in, const Epi& epi, int n_til
         if (mw == 2 && ms == 2) return launch_conv_m<Epi, 1, 1, 2>(plan, epi, n_tiles, s);
         return mw == 2 ? launch_conv_m<Epi, 1, 2>(plan, epi, n_tiles, s) : launch_conv_m<Epi, 1, 1>(plan, epi, n_tiles, s);
     }
-    if (plan.prec == VPX_PREC_BF16) return launch_conv_m<Epi, 2, 1>(plan, epi, n_tiles, s);
+    if (plan.prec == VPX_PREC_BF16) return mw == 2 ? launch_conv_m<Epi, 2, 2>(plan, epi, n_tiles, s) : launch_conv_m<Epi, 2, 1>(plan, epi, n_tiles, s);
     return hipErrorInvalidValue;
 }
 
@@ -791,8 +791,8 @@ int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, in
 int pick_mw(int B, int H, int W, int n_tiles, int prec) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("VPX_MW"); forced = e ? atoi(e) : 0; }
-    if (prec != VPX_PREC_BF16X3) return 1;  // MW=2 is only instantiated for bf16x3
-    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    if (prec == VPX_PREC_F32) return 1;  // fp32 is MFMA-bound: the 8-wave form is not instantiated
+    if (forced == 1 || forced == 2 || (forced == 4 && prec == VPX_PREC_BF16X3)) return forced;
     // 8-wave workgroups halve the weight traffic per pixel; worth it only when the launch still fills the chip
     const long long wgs2 = (long long)B * ((H + 2 * TILE_H - 1) / (2 * TILE_H)) * ((W + TILE_W - 1) / TILE_W) * n_tiles;
     return wgs2 >= 512 ? 2 : 1;
