@@ -220,3 +220,24 @@ def adam_step_ref(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight
     denom = (np.sqrt(v) / f32(np.sqrt(bc2)) + f32(eps)).astype(f32)
     p = (p - f32(lr / bc1) * (m / denom)).astype(f32)
     return p, m, v
+
+
+def phydnet_single_step_convlstm(sd, frames, actions, hidden_dims, action_conditional):
+    """Functional restatement of SingleStepConvLSTM (vp_suite/model_blocks/phydnet.py:117-175) rolled over the frames
+    of `frames` [B,T,C,H,W] (first_timestep on t = 0): per step, optional action inflation + concat (:150-152), then
+    the ConvLSTMCell stack (:154-158, cells of conv_lstm_ndrplz.py:28-43). Returns (outputs per step, H list, C list)."""
+    import torch
+    B, T, _, Hh, Ww = frames.shape
+    n_layers = len(hidden_dims)
+    H = [frames.new_zeros(B, hd, Hh, Ww) for hd in hidden_dims]
+    C = [frames.new_zeros(B, hd, Hh, Ww) for hd in hidden_dims]
+    outs = []
+    for t in range(T):
+        inp = frames[:, t]
+        if action_conditional:
+            inp = torch.cat([inp, actions[:, t].unsqueeze(-1).unsqueeze(-1).expand(-1, -1, Hh, Ww)], dim=-3)
+        for j in range(n_layers):
+            H[j], C[j] = convlstm_ndrplz_cell(inp if j == 0 else H[j - 1], H[j], C[j], sd[f"cell_list.{j}.conv.weight"],
+                                              sd[f"cell_list.{j}.conv.bias"])
+        outs.append(H[-1])
+    return outs, H, C

@@ -86,3 +86,10 @@ PRED_TINY_KW = dict(img_shape=(1, 16, 16), action_size=0, tensor_value_range=[0.
                     num_layers=2, num_hidden=[8, 8], filter_size=5)
 PRED_TINY_LN_KW = dict(img_shape=(2, 16, 24), action_size=0, tensor_value_range=[0.0, 1.0], patch_size=2,
                        num_layers=3, num_hidden=[8, 8, 8], filter_size=3, layer_norm=True)
+
+
+# PhyDNet SingleStepConvLSTM (phydnet.py:117-175): tag -> (input_size, input_dim, hidden_dims, n_layers, kernel, action_conditional, action_size, B, steps)
+PHY_SSC_CASES = {
+    "plain": ((12, 10), 4, [8, 6], 2, (3, 3), False, 0, 2, 3),
+    "action": ((9, 11), 3, [6], 1, (3, 3), True, 2, 2, 3),
+}

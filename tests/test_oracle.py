@@ -204,3 +204,22 @@ def test_adam_restatement_matches_torch_adam():
         opt.step()
         p, m, v = adam_step_ref(p, g, m, v, step, 1e-3)
         assert np.abs(p - tp.detach().numpy()).max() < 2e-7, step
+
+
+@pytest.mark.parametrize("tag", ["plain", "action"])
+def test_torch_ref_phydnet_single_step_convlstm(tag):
+    """oracle restatement of PhyDNet's SingleStepConvLSTM against the reference-generated fixture."""
+    import torch
+    import golden_cases as gc
+    from golden_util import load_golden, name_seed, seeded_rand, seeded_randn, seeded_state_dict
+    from oracle.torch_ref import phydnet_single_step_convlstm
+    isz, idim, hdims, nl, ks, ac, asz, B, steps = gc.PHY_SSC_CASES[tag]
+    g = load_golden(f"phy_ssc_{tag}")
+    sd = seeded_state_dict(g, name_seed("phy_ssc." + tag))
+    frames = seeded_rand((B, steps, idim, *isz), name_seed(f"phy_ssc.{tag}.frames"))
+    actions = seeded_randn((B, steps, max(asz, 1)), name_seed(f"phy_ssc.{tag}.actions"))[:, :, :asz]
+    outs, H, C = phydnet_single_step_convlstm(sd, frames, actions, hdims, ac)
+    for t in range(steps):
+        assert (outs[t] - torch.from_numpy(g[f"out{t}"])).abs().max() < 1e-6
+    for j in range(nl):
+        assert (C[j] - torch.from_numpy(g[f"C{j}"])).abs().max() < 1e-6

@@ -140,6 +140,31 @@ def gen_ndrplz():
 # --------------------------------------------------------------------------------------------------------------
 # a5: ST-LSTM cell step; K4: decoupling tail
 # --------------------------------------------------------------------------------------------------------------
+def gen_phydnet_ssc():
+    """rank-4 widening: PhyDNet's single-step ConvLSTM stack (vp_suite/model_blocks/phydnet.py:117-175), rolled out for
+    a few frames incl. the first_timestep reset and the action-inflation concat; gradients w.r.t. frames and weights."""
+    from vp_suite.model_blocks.phydnet import SingleStepConvLSTM
+    for tag, (isz, idim, hdims, nl, ks, ac, asz, B, steps) in PHY_SSC_CASES.items():
+        blk = SingleStepConvLSTM(isz, idim, hdims, nl, ks, ac, asz, "cpu")
+        fill_state_dict_(blk, name_seed("phy_ssc." + tag))
+        frames = seeded_rand((B, steps, idim, *isz), name_seed(f"phy_ssc.{tag}.frames")).requires_grad_(True)
+        actions = seeded_randn((B, steps, max(asz, 1)), name_seed(f"phy_ssc.{tag}.actions"))[:, :, :asz]
+        loss, arrays = 0.0, {}
+        for t in range(steps):
+            (H, C), out = blk(frames[:, t], actions[:, t], first_timestep=(t == 0))
+            gt = seeded_randn(out[-1].shape, name_seed(f"phy_ssc.{tag}.g{t}"))
+            loss = loss + (out[-1] * gt).sum()
+            arrays[f"out{t}"] = _np(out[-1])
+        for j in range(nl):
+            arrays[f"H{j}"] = _np(H[j]); arrays[f"C{j}"] = _np(C[j])
+        loss.backward()
+        arrays["dframes"] = _np(frames.grad)
+        for key, prm in blk.named_parameters():
+            arrays["grad." + key] = _np(prm.grad)
+        arrays.update(_sd_meta(blk))
+        _save(f"phy_ssc_{tag}", **arrays)
+
+
 def gen_stlstm():
     from vp_suite.model_blocks import SpatioTemporalLSTMCell
     for tag, (Cin, Ch, H, W, k, ln, B) in STLSTM_CASES.items():
@@ -320,7 +345,7 @@ def gen_predrnn():
 
 
 GENERATORS = {"hzzone": gen_hzzone, "ndrplz": gen_ndrplz, "stlstm": gen_stlstm, "decouple": gen_decouple,
-              "ef": gen_ef, "predrnn": gen_predrnn}
+              "ef": gen_ef, "predrnn": gen_predrnn, "phy_ssc": gen_phydnet_ssc}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
