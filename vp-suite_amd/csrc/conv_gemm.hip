@@ -20,22 +20,6 @@ namespace vpx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Gate nonlinearities on the hardware exp2/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each). |abs error| < 3e-7 for both,
-// far inside the 1e-4 parity budget; the libm expf/tanhf they replace cost ~20 VALU each and made the bf16x3 kernel
-// VALU-bound (9.4 VALU per MFMA measured).  VPX_ACCURATE_MATH=1 at build time restores libm.
-#ifdef VPX_ACCURATE_MATH
-__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
-__device__ __forceinline__ float tanh_f(float v) { return tanhf(v); }
-#else
-__device__ __forceinline__ float sigmoid_f(float v) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v));
-}
-__device__ __forceinline__ float tanh_f(float v) {
-    // tanh(v) = 1 - 2 / (1 + e^{2v}); saturates cleanly for large |v| (exp2 -> inf / 0)
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * v));
-}
-#endif
-
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned short bf16_bits(float v) {

@@ -133,4 +133,42 @@ hipError_t launch_axpy(float* y, const float* x, long long n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- ConvLSTM gate / state update on pre-activations (K-split step on small maps) ---------------------------------
+// Same arithmetic as EpiConvLSTM (conv_gemm.hip): peepholes on the previous cell for i,f and on the NEW cell for o
+// (conv_lstm_hzzone.py:62-68). One thread per (pixel, channel); `pre` may alias ea.gates (a thread reads its four
+// values before it writes them).
+__global__ __launch_bounds__(256) void convlstm_pointwise_kernel(const ConvLSTMStepArgs a, const float* pre, int B, long long HW) {
+    const long long e = blockIdx.x * 256LL + threadIdx.x;
+    const int Ch = a.Ch;
+    if (e >= (long long)B * HW * Ch) return;
+    const int ch = (int)(e % Ch);
+    const long long bp = e / Ch;          // b * HW + pix
+    const long long pix = bp % HW;
+    const int b = (int)(bp / HW);
+    const float* p4 = pre + bp * 4 * Ch + ch;
+    float ai = p4[a.gate_pos[0] * Ch], af = p4[a.gate_pos[1] * Ch], ag = p4[a.gate_pos[2] * Ch], ao = p4[a.gate_pos[3] * Ch];
+    if (a.bias) {
+        ai += a.bias[a.gate_pos[0] * Ch + ch]; af += a.bias[a.gate_pos[1] * Ch + ch];
+        ag += a.bias[a.gate_pos[2] * Ch + ch]; ao += a.bias[a.gate_pos[3] * Ch + ch];
+    }
+    const float cp = a.c_in ? a.c_in[e] : 0.0f;
+    if (a.wci) { ai += a.wci[pix * Ch + ch] * cp; af += a.wcf[pix * Ch + ch] * cp; }
+    const float i_ = sigmoid_f(ai), f_ = sigmoid_f(af), g_ = tanh_f(ag);
+    const float cn = f_ * cp + i_ * g_;
+    if (a.wco) ao += a.wco[pix * Ch + ch] * cn;
+    const float o_ = sigmoid_f(ao);
+    a.c_out[e] = cn;
+    a.h_out[(size_t)b * a.h_bstride + pix * Ch + ch] = o_ * tanh_f(cn);
+    if (a.gates) {
+        float* gs = a.gates + bp * 4 * Ch + ch;
+        gs[0] = i_; gs[Ch] = f_; gs[2 * Ch] = g_; gs[3 * Ch] = o_;
+    }
+}
+
+hipError_t launch_convlstm_pointwise(const ConvLSTMStepArgs& ea, const float* pre, int B, long long HW, hipStream_t s) {
+    const long long n = (long long)B * HW * ea.Ch;
+    hipLaunchKernelGGL(convlstm_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ea, pre, B, HW);
+    return hipGetLastError();
+}
+
 }  // namespace vpx

@@ -49,11 +49,17 @@ size_t vpx_convlstm_reserve_bytes(const vpx_convlstm_desc* d) {
     return align256((size_t)d->T * L.n_state * 4 * sizeof(float)) + align256((size_t)d->T * L.n_state * sizeof(float));
 }
 
+static size_t convlstm_wpk_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
+    return L.split ? packed_weight_bytes(L.s_tiles, L.s_chunks, L.s_ng, d->precision)
+                   : packed_weight_bytes(L.n_tiles, L.chunks_total, 4, d->precision);
+}
+
 size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
     ConvLSTMLayout L;
     if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
     // forward: packed weights + cell scratch (+ NCHW staging)
-    size_t fwd = align256(packed_weight_bytes(L.n_tiles, L.chunks_total, 4, d->precision)) + align256(L.n_state * sizeof(float));
+    size_t fwd = align256(convlstm_wpk_bytes(d, L)) + align256(L.n_state * sizeof(float));
+    if (L.split) fwd += align256(4 * L.n_state * sizeof(float));  // gate pre-activations of one step
     if (d->layout == VPX_LAYOUT_NCHW)
         fwd += align256(L.n_x * 4) + align256(L.n_out * 4) + 4 * align256(L.n_state * 4) + 3 * align256(L.n_peep * 4);
     // backward (only with SAVE_FOR_BWD): packed dgrad weights + dG for all steps + dh/dc carries + wgrad K-slice slabs
@@ -88,8 +94,9 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     const size_t HW = (size_t)H * Wd;
     Carver ws{(char*)workspace, 0, workspace_bytes};
     ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
-    float* wpk = ws.take(packed_weight_bytes(L.n_tiles, L.chunks_total, 4, d->precision) / sizeof(float));
+    float* wpk = ws.take(convlstm_wpk_bytes(d, L) / sizeof(float));
     float* c_scratch = ws.take(L.n_state);
+    float* pre_scratch = L.split ? ws.take(4 * L.n_state) : nullptr;
 
     // ---- layout adaptation (reference NCHW -> native NHWC) ----
     const float *xn = x, *h0n = h0, *c0n = c0, *wci = Wci, *wcf = Wcf, *wco = Wco;
@@ -124,17 +131,25 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     const long long ld_o = (long long)(Cin + Ch) * L.taps;
     pd.seg[0] = PackSeg{W, ld_o, L.taps, 0, Cin};
     pd.seg[1] = PackSeg{W, ld_o, L.taps, Cin, Ch};
-    memcpy(pd.stage, L.stage, sizeof(ConvStage) * L.nstage);
-    pd.nstage = L.nstage;
-    pd.chunks_total = L.chunks_total; pd.prec = d->precision;
-    pd.n_tiles = L.n_tiles;
+    pd.prec = d->precision;
     pd.taps = L.taps;
-    pd.NG = 4;
-    for (int g = 0; g < 4; ++g) { pd.rowbase[0][g] = pd.rowbase[1][g] = gp[g] * Ch; pd.goff[g] = 0; }
-    pd.tile_stride = 32;
-    pd.nch = Ch;
     pd.transposed = 0;
     pd.flip = 0;
+    if (L.split) {  // plain layout: output channel n = reference row n of W (gate-major), s_ng * 32 rows per N tile
+        memcpy(pd.stage, L.s_stage, sizeof(ConvStage) * L.s_nstage);
+        pd.nstage = L.s_nstage;
+        pd.chunks_total = L.s_chunks;
+        fill_plain_pack(pd, 4 * Ch, 0, L.s_ng);
+    } else {
+        memcpy(pd.stage, L.stage, sizeof(ConvStage) * L.nstage);
+        pd.nstage = L.nstage;
+        pd.chunks_total = L.chunks_total;
+        pd.n_tiles = L.n_tiles;
+        pd.NG = 4;
+        for (int g = 0; g < 4; ++g) { pd.rowbase[0][g] = pd.rowbase[1][g] = gp[g] * Ch; pd.goff[g] = 0; }
+        pd.tile_stride = 32;
+        pd.nch = Ch;
+    }
     VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
 
     float* gates_all = nullptr;
@@ -148,19 +163,21 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     for (int t = 0; t < T; ++t) {
         ConvPlan P{};
         P.B = B; P.H = H; P.W = Wd; P.kh = d->kh; P.kw = d->kw;
-        set_plan_tiles(P, L.mw);
+        set_plan_tiles(P, L.split ? 1 : L.mw);
         P.nseg = 2;
         P.seg[0] = ConvSeg{xn ? xn + (size_t)t * HW * Cin : nullptr, (long long)((size_t)T * HW * Cin), Cin, 0};
         const float* hprev = (t == 0) ? h0n : outn + (size_t)(t - 1) * HW * Ch;
         const long long hprev_bs = (long long)((t == 0) ? HW * Ch : (size_t)T * HW * Ch);
         P.seg[1] = ConvSeg{hprev, hprev_bs, Ch, 0};
+        const ConvStage* stages = L.split ? L.s_stage : L.stage;
+        const int nstages = L.split ? L.s_nstage : L.nstage;
         P.nstage = 0;
-        for (int s = 0; s < L.nstage; ++s) {
-            const float* src = P.seg[L.stage[s].seg].ptr;
-            if (src) P.stage[P.nstage++] = L.stage[s];  // absent source == all-zero operand: its K range is skipped
+        for (int s = 0; s < nstages; ++s) {
+            const float* src = P.seg[stages[s].seg].ptr;
+            if (src) P.stage[P.nstage++] = stages[s];  // absent source == all-zero operand: its K range is skipped
         }
-        P.chunks_total = L.chunks_total; P.prec = d->precision;
-        P.a_bytes = conv_a_bytes(L.stage, L.nstage, d->kh, d->kw, L.mw);
+        P.chunks_total = L.split ? L.s_chunks : L.chunks_total; P.prec = d->precision;
+        P.a_bytes = conv_a_bytes(stages, nstages, d->kh, d->kw, L.split ? 1 : L.mw);
         P.wpk = wpk;
 
         ConvLSTMStepArgs ea{};
@@ -179,7 +196,20 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         ea.wci = wci; ea.wcf = wcf; ea.wco = wco;
         ea.h_out = outn + (size_t)t * HW * Ch;
         ea.h_bstride = (long long)((size_t)T * HW * Ch);
-        VPX_CHECK_HIP(launch_convlstm_step_f32(P, ea, L.n_tiles, stream));
+        if (L.split) {
+            // pre-activations of all four gates by a K-split plain convolution (atomic partial sums), then the gates
+            float* pre = ea.gates ? ea.gates : pre_scratch;  // with SAVE_FOR_BWD the reserve slot doubles as scratch
+            VPX_CHECK_HIP(hipMemsetAsync(pre, 0, 4 * L.n_state * sizeof(float), stream));
+            PlainEpiArgs pa{};
+            pa.Co = 4 * Ch; pa.split = 4 * Ch; pa.ng = L.s_ng;
+            pa.out0 = pre; pa.bstride0 = (long long)(HW * 4 * Ch); pa.ld0 = 4 * Ch;
+            P.ksplit = L.split;
+            if (P.nstage == 0) P.ksplit = 0;
+            if (P.nstage > 0) VPX_CHECK_HIP(launch_conv_plain_f32(P, pa, L.s_tiles, stream));
+            VPX_CHECK_HIP(launch_convlstm_pointwise(ea, pre, B, (long long)HW, stream));
+        } else {
+            VPX_CHECK_HIP(launch_convlstm_step_f32(P, ea, L.n_tiles, stream));
+        }
     }
 
     // ---- final states ----

@@ -65,6 +65,9 @@ struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     int taps, n_tiles, nstage, chunks_total;
     int mw;                        // forward cell kernel: 32-pixel row tiles per wave
     ConvStage stage[MAX_STAGE];
+    // small maps: the step as a K-split plain convolution into a gate buffer + a pointwise gate kernel (0 = fused launch)
+    int split, s_ng, s_tiles, s_nstage, s_chunks;
+    ConvStage s_stage[MAX_STAGE];
     size_t n_state, n_x, n_out, n_peep;
     // backward
     int d_nstage, d_chunks, d_mw;  // data-gradient conv: K stages over the 4Ch gate axis; rows-per-workgroup variant
@@ -83,6 +86,19 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     L.mw = pick_mw(d->B, d->H, d->W, L.n_tiles, d->precision);
     L.nstage = build_stages(L.stage, &L.chunks_total, segC, 2, L.taps, pick_stage_channels(segC, 2, d->kh, d->kw, 4, d->precision, L.mw), d->precision);
     if (L.nstage < 0) { set_error("convlstm: too many channel stages (Cin=%d Ch=%d)", d->Cin, d->Ch); return VPX_ERR_UNSUPPORTED; }
+    L.split = 0;
+    {
+        const long long m_tiles = (long long)d->B * ((d->H + TILE_H - 1) / TILE_H) * ((d->W + TILE_W - 1) / TILE_W);
+        // the fused launch would leave most CUs idle (small batches / maps). Measured on MI355X, bf16x3, (96,96,16x16):
+        // B=4 (24 workgroups fused) 20 -> 39 TF with the split; B=32 (192 workgroups) 157 -> 140 TF, so the bar is < 160
+        if (m_tiles * L.n_tiles < 160) {
+            const int ng = plain_groups(4 * d->Ch);
+            const int tiles = plain_tiles_ng(4 * d->Ch, ng);
+            L.s_nstage = build_stages(L.s_stage, &L.s_chunks, segC, 2, L.taps, pick_stage_channels(segC, 2, d->kh, d->kw, ng, d->precision), d->precision);
+            const int ks = L.s_nstage > 0 ? pick_ksplit(m_tiles * tiles, L.s_nstage) : 1;
+            if (ks > 1) { L.split = ks; L.s_ng = ng; L.s_tiles = tiles; }
+        }
+    }
     L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
     L.n_x = (size_t)d->B * d->T * d->H * d->W * d->Cin;
     L.n_out = (size_t)d->B * d->T * d->H * d->W * d->Ch;

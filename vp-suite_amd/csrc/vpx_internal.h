@@ -109,6 +109,8 @@ struct ConvLSTMStepArgs {
     float* gates;             // [B,H,W,4Ch] post-activation (i,f,g,o) or null
 };
 hipError_t launch_convlstm_step_f32(const ConvPlan& plan, const ConvLSTMStepArgs& ea, int n_tiles, hipStream_t s);
+// pointwise half of the K-split step: pre-activations pre [B*HW, 4Ch] (reference gate order) -> gates, c, h (pointwise.hip)
+hipError_t launch_convlstm_pointwise(const ConvLSTMStepArgs& ea, const float* pre, int B, long long HW, hipStream_t s);
 
 // Plain epilogue: y = conv (+bias), channels [0,split) -> out0, [split, Co) -> out1 (either may be null = dropped).
 struct PlainEpiArgs {
@@ -253,5 +255,24 @@ hipError_t launch_axpy(float* y, const float* x, long long n, hipStream_t s);  /
 
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
+
+#ifdef __HIPCC__
+// Gate nonlinearities on the hardware exp2/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each). |abs error| < 3e-7 for both,
+// far inside the 1e-4 parity budget; the libm expf/tanhf they replace cost ~20 VALU each and made the bf16x3 kernel
+// VALU-bound (9.4 VALU per MFMA measured).  VPX_ACCURATE_MATH=1 at build time restores libm.
+#ifdef VPX_ACCURATE_MATH
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float tanh_f(float v) { return tanhf(v); }
+#else
+__device__ __forceinline__ float sigmoid_f(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v));
+}
+__device__ __forceinline__ float tanh_f(float v) {
+    // tanh(v) = 1 - 2 / (1 + e^{2v}); saturates cleanly for large |v| (exp2 -> inf / 0)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * v));
+}
+#endif
+
+#endif
 
 }  // namespace vpx
