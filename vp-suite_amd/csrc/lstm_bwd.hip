@@ -267,11 +267,11 @@ __device__ __forceinline__ void wg_split4(const f32x4 v, uint2& hi, uint2& lo) {
     hi = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
     lo = uint2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
 }
-__device__ __forceinline__ bf16x8 wg_tr_frag(const char* base) {
-    // two transposing reads: rows (pixels) +0..3 and +4..7 of this lane half's 8-pixel group; 64 columns x 2 B per row
+__device__ __forceinline__ bf16x8 wg_tr_frag(const char* base, const int pitch = 128) {
+    // two transposing reads: rows (pixels) +0..3 and +4..7 of this lane half's 8-pixel group; `pitch` bytes per pixel row
     typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
     const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base));
-    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base + 4 * 128));
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base + 4 * pitch));
     return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
@@ -279,8 +279,13 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const char* base) {
 // loads of item i+1 (GPRE dG vectors + APRE activation vectors per thread) are in flight; they are split to hi/lo bf16
 // and stored to LDS after the barrier that ends item i. PIPE = 0 keeps the plain load-store-multiply order (fewer
 // registers: two workgroups per CU).
-template <int MAXT, int APRE, int PIPE>
-__global__ __launch_bounds__(NTHREADS, (PIPE ? 1 : 2)) void wgrad_bf16x3_kernel(const WgradArgs a, const int tap_base) {
+// RB = 2: eight waves, 128 rows x 64 channels per workgroup — the activation halo tile (the larger of the two) is staged
+// once for twice the rows, at two waves per SIMD (256 registers each) with the item pipeline on.
+template <int MAXT, int APRE, int PIPE, int RB>
+__global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void wgrad_bf16x3_kernel(const WgradArgs a, const int tap_base) {
+    constexpr int NTH = NTHREADS * RB;
+    constexpr int GROW = 64 * RB;   // dG rows per workgroup
+    constexpr int GP = GROW * 2;    // bytes per pixel row of a dG plane
     const bool lo_terms = a.prec == VPX_PREC_BF16X3;  // plain bf16 uses the hi planes only (uniform branch)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -293,12 +298,13 @@ __global__ __launch_bounds__(NTHREADS, (PIPE ? 1 : 2)) void wgrad_bf16x3_kernel(
     const int tap0 = tap_base + blockIdx.z * MAXT;
     const int halo_w = TILE_W + a.kw - 1, halo_h = TILE_H + a.kh - 1, npos = halo_w * halo_h;
     const int ph = a.kh / 2, pw = a.kw / 2;
-    // LDS planes, row = 64 channels x bf16 = 128 B: G_hi [128 px], G_lo [128 px], A_hi [npos], A_lo [npos]
+    // LDS planes: G_hi / G_lo [128 px][GROW rows] bf16, A_hi / A_lo [npos][64 channels] bf16 (128 B per position)
     char* G_hi = smem;
-    char* G_lo = smem + 128 * 128;
-    char* A_hi = smem + 2 * 128 * 128;
+    char* G_lo = smem + 128 * GP;
+    char* A_hi = smem + 2 * 128 * GP;
     char* A_lo = A_hi + npos * 128;
-    constexpr int GPRE = 128 * 16 / NTHREADS;  // dG vectors per thread and item (8)
+    constexpr int GVPR = GROW / 4;              // 4-float vectors per pixel row of the dG tile
+    constexpr int GPRE = 128 * GVPR / NTH;      // dG vectors per thread and item (8)
 
     f32x16 acc[MAXT];
 #pragma unroll
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(NTHREADS, (PIPE ? 1 : 2)) void wgrad_bf16x3_kernel(
 
     // transposing-read address pattern of this lane inside its 16-lane group: row q, columns 4p..4p+3
     const int L = lane & 15, q = L >> 2, p = L & 3, half16 = (lane >> 4) & 1;
-    const int g_lane = ((8 * hh + q) * 64 + wn * 32 + 16 * half16 + 4 * p) * 2;  // bytes, + tile-row * 16 * 128
+    const int g_lane = ((8 * hh + q) * GROW + wn * 32 + 16 * half16 + 4 * p) * 2;  // bytes, + tile-row * 16 * GP
     const int a_lane = ((8 * hh + q) * 64 + wc * 32 + 16 * half16 + 4 * p) * 2;  // bytes, + position offset * 128
     int tapoff[MAXT];
 #pragma unroll
@@ -320,10 +326,11 @@ __global__ __launch_bounds__(NTHREADS, (PIPE ? 1 : 2)) void wgrad_bf16x3_kernel(
 
     const int tiles = a.tiles_x * a.tiles_y;
     const long long n_items = (long long)a.T * a.B * tiles;
-    const int n0 = nt_id * 64;
+    const int n0 = nt_id * GROW;
     const int ldG = a.ldG ? a.ldG : a.N4;
-    const int q4 = tid & 15;              // this thread's 4-channel column in both tiles (NTHREADS is a multiple of 16)
-    const int n_col = n0 + q4 * 4, c_col = ct.c0 + q4 * 4;
+    const int q4 = tid & 15;              // this thread's 4-channel column of the activation tile
+    const int qg = tid & (GVPR - 1);      // ... and its 4-row column of the dG tile
+    const int n_col = n0 + qg * 4, c_col = ct.c0 + q4 * 4;
 
     constexpr int NV = PIPE ? APRE : 4;  // PIPE = 0 streams the tiles through 4 vectors at a time
     f32x4 gv[PIPE ? GPRE : 4], av[NV];
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(NTHREADS, (PIPE ? 1 : 2)) void wgrad_bf16x3_kernel(
     auto load_g = [&](const ItemGeo& g, int u0, auto nu, auto& dst) {
 #pragma unroll
         for (int u = 0; u < nu; ++u) {
-            const int pp = (tid >> 4) + (u0 + u) * (NTHREADS / 16);
+            const int pp = tid / GVPR + (u0 + u) * (NTH / GVPR);
             const int gy = g.y0 + (pp >> 4), gx = g.x0 + (pp & 15);
             dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (pp < 128 && gy < a.H && gx < a.W) {
@@ -370,19 +377,19 @@ __global__ __launch_bounds__(NTHREADS, (PIPE ? 1 : 2)) void wgrad_bf16x3_kernel(
     auto store_g = [&](int u0, auto nu, const auto& srcv) {
 #pragma unroll
         for (int u = 0; u < nu; ++u) {
-            const int pp = (tid >> 4) + (u0 + u) * (NTHREADS / 16);
+            const int pp = tid / GVPR + (u0 + u) * (NTH / GVPR);
             if (pp < 128) {
                 uint2 hi, lo;
                 wg_split4(srcv[u], hi, lo);
-                *reinterpret_cast<uint2*>(G_hi + pp * 128 + q4 * 8) = hi;
-                *reinterpret_cast<uint2*>(G_lo + pp * 128 + q4 * 8) = lo;
+                *reinterpret_cast<uint2*>(G_hi + pp * GP + qg * 8) = hi;
+                *reinterpret_cast<uint2*>(G_lo + pp * GP + qg * 8) = lo;
             }
         }
     };
     auto load_a = [&](const ItemGeo& g, int u0, auto nu, auto& dst) {
 #pragma unroll
         for (int u = 0; u < nu; ++u) {
-            const int pos = (tid >> 4) + (u0 + u) * (NTHREADS / 16);
+            const int pos = (tid >> 4) + (u0 + u) * (NTH / 16);
             const int hy = pos / halo_w, hx = pos - hy * halo_w;
             const int gy = g.y0 - ph + hy, gx = g.x0 - pw + hx;
             dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(NTHREADS, (PIPE ? 1 : 2)) void wgrad_bf16x3_kernel(
     auto store_a = [&](int u0, auto nu, const auto& srcv) {
 #pragma unroll
         for (int u = 0; u < nu; ++u) {
-            const int pos = (tid >> 4) + (u0 + u) * (NTHREADS / 16);
+            const int pos = (tid >> 4) + (u0 + u) * (NTH / 16);
             if (pos < npos) {
                 uint2 hi, lo;
                 wg_split4(srcv[u], hi, lo);
@@ -422,8 +429,8 @@ __global__ __launch_bounds__(NTHREADS, (PIPE ? 1 : 2)) void wgrad_bf16x3_kernel(
     auto multiply = [&]() {  // 8 k-steps (tile rows) of 16 pixels
 #pragma unroll 2
         for (int s = 0; s < TILE_H; ++s) {
-            const bf16x8 gh = wg_tr_frag(G_hi + g_lane + s * 16 * 128);
-            const bf16x8 gl = wg_tr_frag(G_lo + g_lane + s * 16 * 128);
+            const bf16x8 gh = wg_tr_frag(G_hi + g_lane + s * 16 * GP, GP);
+            const bf16x8 gl = wg_tr_frag(G_lo + g_lane + s * 16 * GP, GP);
             const int arow = a_lane + s * halo_w * 128;
 #pragma unroll
             for (int t2 = 0; t2 < MAXT; ++t2) {
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(NTHREADS, (PIPE ? 1 : 2)) void wgrad_bf16x3_kernel(
             if (!item_geo(w, g)) continue;  // (uniform: depends on the item and the column tile only)
             __syncthreads();
             for (int u0 = 0; u0 < GPRE; u0 += 4) { load_g(g, u0, std::integral_constant<int, 4>{}, gv); store_g(u0, std::integral_constant<int, 4>{}, gv); }
-            for (int u0 = 0; u0 * (NTHREADS / 16) < npos; u0 += 4) { load_a(g, u0, std::integral_constant<int, 4>{}, av); store_a(u0, std::integral_constant<int, 4>{}, av); }
+            for (int u0 = 0; u0 * (NTH / 16) < npos; u0 += 4) { load_a(g, u0, std::integral_constant<int, 4>{}, av); store_a(u0, std::integral_constant<int, 4>{}, av); }
             __syncthreads();
             multiply();
         }
@@ -492,27 +499,28 @@ static hipError_t launch_wgrad_group(const WgradArgs& a, int n_slices, int tap_b
     if (a.prec == VPX_PREC_BF16X3 || a.prec == VPX_PREC_BF16) {
         // activation vectors per thread and item: halo positions * 16 / 256 (3x3: 12, 5x5: 15, 7x7: 20)
         const int npos = (TILE_H + a.kh - 1) * (TILE_W + a.kw - 1);
-        const int apre = (npos * 16 + NTHREADS - 1) / NTHREADS;
-        // The item pipeline needs the whole register file (one workgroup per CU). It pays when LDS allows only one
-        // workgroup anyway (5x5 and larger: > 80 KB of planes); 3x3 keeps two workgroups per CU overlapping each other
-        // (measured, ConvLSTM training step: 47.3 ms without vs 54.2 ms with). VPX_WGRAD_PIPE=0/1 forces it.
-        static int pipe_force = -2;
-        if (pipe_force == -2) { const char* e = getenv("VPX_WGRAD_PIPE"); pipe_force = e ? atoi(e) : -1; }
-        const int pipe_env = pipe_force >= 0 ? pipe_force : (lds > 80 * 1024 ? 1 : 0);
-        auto go = [&](auto kern) -> hipError_t {
+        auto go = [&](auto kern, dim3 g, int nth, size_t lds_bytes) -> hipError_t {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, s, a, tap_base);
+            hipLaunchKernelGGL(kern, g, dim3(nth), lds_bytes, s, a, tap_base);
             return hipGetLastError();
         };
-        if (apre > 20) return hipErrorInvalidValue;  // kernels beyond 7x7 are not instantiated
-        if (pipe_env) {
-            if (apre <= 8) return go(&wgrad_bf16x3_kernel<NTAPS, 8, 1>);
-            if (apre <= 12) return go(&wgrad_bf16x3_kernel<NTAPS, 12, 1>);
-            if (apre <= 15) return go(&wgrad_bf16x3_kernel<NTAPS, 15, 1>);
-            return go(&wgrad_bf16x3_kernel<NTAPS, 20, 1>);
+        static int rb_env = -1;  // VPX_WGRAD_RB=1 forces the 4-wave, 64-row form
+        if (rb_env < 0) { const char* e = getenv("VPX_WGRAD_RB"); rb_env = e ? atoi(e) : 0; }
+        // 8 waves / 128 rows / pipelined items when the 4-wave form's planes (> 80 KB: 5x5 and larger) allow one workgroup
+        // per CU anyway; 3x3 keeps two independent 4-wave workgroups per CU (measured, training step: ConvLSTM 3x3
+        // 46.2 ms vs 50.9 ms with the 8-wave form; PredRNN 5x5 134.7 ms vs 127.6 ms). VPX_WGRAD_RB=1/2 forces a form.
+        if (a.N4 >= 128 && rb_env != 1 && (lds > 80 * 1024 || rb_env == 2)) {
+            const int apre2 = (npos * 16 + 2 * NTHREADS - 1) / (2 * NTHREADS);
+            dim3 g2(((a.N4 + 127) / 128) * a.n_ctiles, n_slices, groups);
+            const size_t lds2 = 2 * 128 * 256 + (size_t)npos * 128 * 2;
+            if (apre2 > 10 || lds2 > 160 * 1024) return hipErrorInvalidValue;  // kernels beyond 7x7 are not instantiated
+            if (apre2 <= 4) return go(&wgrad_bf16x3_kernel<NTAPS, 4, 1, 2>, g2, 2 * NTHREADS, lds2);
+            if (apre2 <= 6) return go(&wgrad_bf16x3_kernel<NTAPS, 6, 1, 2>, g2, 2 * NTHREADS, lds2);
+            if (apre2 <= 8) return go(&wgrad_bf16x3_kernel<NTAPS, 8, 1, 2>, g2, 2 * NTHREADS, lds2);
+            return go(&wgrad_bf16x3_kernel<NTAPS, 10, 1, 2>, g2, 2 * NTHREADS, lds2);
         }
-        return go(&wgrad_bf16x3_kernel<NTAPS, 0, 0>);
+        return go(&wgrad_bf16x3_kernel<NTAPS, 0, 0, 1>, grid, NTHREADS, lds);
     } else {
         hipLaunchKernelGGL(wgrad_kernel<NTAPS>, grid, dim3(NTHREADS), lds, s, a, tap_base);
     }
