@@ -44,6 +44,17 @@ for mode in ("infer", "train"):
         if lines:
             open(os.path.join(DST, f"{ROUND}_bench_{mode}_b32_bf16x3_under_rocprof.json"), "w").write(lines[-1])
 
+for tag, name in (("infer_f32", "bench_infer_b32_f32"), ("predrnn_infer", "bench_predrnn_infer_b32_bf16x3"),
+                  ("predrnn_train", "bench_predrnn_train_b32_bf16x3")):
+    f = one(f"trace_{tag}/*/*kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(DST, f"{ROUND}_{name}_kernel_stats.csv"))
+    log = os.path.join(SRC, f"bench_{tag}.log")
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith("{")]
+        if lines:
+            open(os.path.join(DST, f"{ROUND}_{name}_under_rocprof.json"), "w").write(lines[-1])
+
 counters = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     counters.update(pmc_means(d))
