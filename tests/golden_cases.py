@@ -93,3 +93,17 @@ PHY_SSC_CASES = {
     "plain": ((12, 10), 4, [8, 6], 2, (3, 3), False, 0, 2, 3),
     "action": ((9, 11), 3, [6], 1, (3, 3), True, 2, 2, 3),
 }
+
+# ActionConditionalSpatioTemporalLSTMCell (predrnn.py:86-169): tag -> (Cin, Ch, H, W, k, layer_norm, B)
+ACSTLSTM_CASES = {
+    "plain": (5, 8, 9, 10, 5, False, 2),
+    "ln": (4, 8, 8, 7, 3, True, 2),
+}
+
+
+def acstlstm_inputs(tag, Cin, Ch, H, W, B):
+    p = f"acstlstm.{tag}."
+    d = {"x": seeded_randn((B, Cin, H, W), name_seed(p + "x"))}
+    for n in ("h", "c", "m", "a", "g_h", "g_c", "g_m", "g_dc", "g_dm"):
+        d[n] = seeded_randn((B, Ch, H, W), name_seed(p + n), 0.5 if n in ("h", "c", "m", "a") else 1.0)
+    return d

@@ -185,6 +185,25 @@ def gen_stlstm():
         _save(f"stlstm_{tag}", **arrays)
 
 
+def gen_acstlstm():
+    """rank-3 widening: the action-conditional ST-LSTM cell (vp_suite/model_blocks/predrnn.py:86-169), one step + grads."""
+    from vp_suite.model_blocks.predrnn import ActionConditionalSpatioTemporalLSTMCell
+    for tag, (Cin, Ch, H, W, k, ln, B) in ACSTLSTM_CASES.items():
+        cell = ActionConditionalSpatioTemporalLSTMCell(Cin, Ch, H, W, k, 1, ln)
+        fill_state_dict_(cell, name_seed("acstlstm." + tag))
+        inp = acstlstm_inputs(tag, Cin, Ch, H, W, B)
+        lv = {n: inp[n].clone().requires_grad_(True) for n in ("x", "h", "c", "m", "a")}
+        outs = cell(lv["x"], lv["h"], lv["c"], lv["m"], lv["a"])
+        sum((o * inp[g]).sum() for o, g in zip(outs, ("g_h", "g_c", "g_m", "g_dc", "g_dm"))).backward()
+        arrays = dict(h_new=_np(outs[0]), c_new=_np(outs[1]), m_new=_np(outs[2]), delta_c=_np(outs[3]), delta_m=_np(outs[4]))
+        for n in lv:
+            arrays["d" + n] = _np(lv[n].grad)
+        for key, prm in cell.named_parameters():
+            arrays["grad." + key] = _np(prm.grad)
+        arrays.update(_sd_meta(cell))
+        _save(f"acstlstm_{tag}", **arrays)
+
+
 def gen_decouple():
     import torch.nn.functional as F
     B, Ch, H, W = 2, 8, 6, 5
@@ -345,7 +364,7 @@ def gen_predrnn():
 
 
 GENERATORS = {"hzzone": gen_hzzone, "ndrplz": gen_ndrplz, "stlstm": gen_stlstm, "decouple": gen_decouple,
-              "ef": gen_ef, "predrnn": gen_predrnn, "phy_ssc": gen_phydnet_ssc}
+              "ef": gen_ef, "predrnn": gen_predrnn, "phy_ssc": gen_phydnet_ssc, "acstlstm": gen_acstlstm}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
