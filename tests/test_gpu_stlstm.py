@@ -196,3 +196,30 @@ def test_predrnn_layernorm_tiny_vs_golden(vpx):
     named = dict(m.named_parameters())
     flat = np.concatenate([named[k].grad.detach().cpu().numpy().reshape(-1) for k in sorted(named)])
     assert _relmax(flat, g["eval.grads_flat"]) < 2e-4
+
+
+@pytest.mark.gpu
+def test_flat_adam_invalidates_packed_weight_caches(vpx):
+    """The ST-LSTM cell re-uses its packed weights while (data_ptr, _version) of the parameters are unchanged; the
+    flat-bucket Adam kernel updates parameters outside autograd and must bump the versions: two training steps of a tiny
+    PredRNN through FlatAdam equal two steps through torch.optim.Adam."""
+    import copy
+    from vp_suite_amd.train import FlatAdam
+    from vp_suite_amd.models import MODEL_CLASSES
+    torch.manual_seed(3)
+    kw = dict(img_shape=(1, 16, 16), action_size=0, tensor_value_range=[0.0, 1.0], num_layers=2, num_hidden=[8, 8],
+              patch_size=2, filter_size=3)
+    m1 = MODEL_CLASSES["predrnn-pp"]("cuda", **kw).to("cuda")
+    m2 = copy.deepcopy(m1)
+    frames = torch.rand(2, 6, 1, 16, 16, device="cuda")
+    o1, o2 = torch.optim.Adam(m1.parameters(), lr=1e-2), FlatAdam.from_module(m2, lr=1e-2)
+    for _ in range(2):
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad()
+            pred, losses = m(frames, pred_frames=3, train=False)
+            (((pred - frames[:, 3:]) ** 2).mean() + sum(losses.values())).backward()
+            o.step()
+    with torch.no_grad():
+        p1, _ = m1(frames, pred_frames=3)
+        p2, _ = m2(frames, pred_frames=3)
+    assert (p1 - p2).abs().max() < 1e-5

@@ -190,7 +190,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             ea.gates = gates_all + (size_t)t * L.n_state * 4;
         } else {
             ea.c_in = (t == 0) ? c0n : c_scratch;
-            ea.c_out = c_scratch;
+            ea.c_out = (t == T - 1 && cTn) ? cTn : c_scratch;  // the last step writes c_T where the caller wants it
             ea.gates = nullptr;
         }
         ea.wci = wci; ea.wcf = wcf; ea.wco = wco;
@@ -213,8 +213,8 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     }
 
     // ---- final states ----
-    const float* c_last = save ? cs_all + (size_t)(T - 1) * L.n_state : c_scratch;
-    if (cTn) VPX_CHECK_HIP(hipMemcpyAsync(cTn, c_last, L.n_state * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (cTn && save)
+        VPX_CHECK_HIP(hipMemcpyAsync(cTn, cs_all + (size_t)(T - 1) * L.n_state, L.n_state * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (hTn)
         VPX_CHECK_HIP(hipMemcpy2DAsync(hTn, HW * Ch * sizeof(float), outn + (size_t)(T - 1) * HW * Ch,
                                        (size_t)T * HW * Ch * sizeof(float), HW * Ch * sizeof(float), B,

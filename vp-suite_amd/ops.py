@@ -61,6 +61,34 @@ def to_channels_last(t: torch.Tensor) -> torch.Tensor:
     return t.permute(perm).contiguous().permute(inv)
 
 
+_cl_cache = {}
+
+
+def _cached_channels_last(p: torch.Tensor) -> torch.Tensor:
+    """Channels-last copy of a parameter tensor, re-used while the SAME tensor object is unchanged (identity checked
+    through a weak reference — a recycled address can never hit — plus (_version, data_ptr)): the peephole tensors
+    [1,Ch,H,W] of a ConvLSTM block are converted once per optimizer step instead of once per call. Writes through
+    `.data` do not bump `_version`; code doing that must call `ops.clear_layout_cache()`."""
+    import weakref
+    ent = _cl_cache.get(id(p))
+    if ent is not None:
+        ref, version, addr, cl = ent
+        if ref() is p and version == p._version and addr == p.data_ptr():
+            return cl
+    if len(_cl_cache) > 256:
+        _cl_cache.clear()
+    cl = to_channels_last(p.detach())
+    try:
+        _cl_cache[id(p)] = (weakref.ref(p), p._version, p.data_ptr(), cl)
+    except TypeError:
+        pass
+    return cl
+
+
+def clear_layout_cache():
+    _cl_cache.clear()
+
+
 def is_channels_last(t: torch.Tensor) -> bool:
     nd = t.dim()
     perm = list(range(nd - 3)) + [nd - 2, nd - 1, nd - 3]
@@ -100,9 +128,9 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
         h0c = None if h0 is None else to_channels_last(h0)
         c0c = None if c0 is None else to_channels_last(c0)
         peep = Wci is not None
-        wci = to_channels_last(Wci) if peep else None
-        wcf = to_channels_last(Wcf) if peep else None
-        wco = to_channels_last(Wco) if peep else None
+        wci = _cached_channels_last(Wci) if peep else None
+        wcf = _cached_channels_last(Wcf) if peep else None
+        wco = _cached_channels_last(Wco) if peep else None
         Wc = W.contiguous()
         bc = None if b is None else b.contiguous()
         d = ConvLSTMDesc(B, T, Cin, Ch, H, Wd, kh, kw, gate_order, _lib.LAYOUT_NHWC, precision,
@@ -115,13 +143,13 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         reserve = torch.empty(max(rs_bytes, 1), dtype=torch.uint8, device=dev)
         out = new_channels_last((B, T, Ch, H, Wd), dev)
-        hT = new_channels_last((B, Ch, H, Wd), dev)
+        hT = out[:, T - 1]  # h_T IS the last slice of the output slab: a view, no copy
         cT = new_channels_last((B, Ch, H, Wd), dev)
         if PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         rc = L.vpx_convlstm_seq_fwd(ctypes.byref(d), ptr(x), ptr(h0c), ptr(c0c), ptr(Wc), ptr(bc), ptr(wci), ptr(wcf),
-                                    ptr(wco), ptr(out), ptr(hT), ptr(cT), ptr(reserve), rs_bytes, ptr(ws), ws_bytes,
+                                    ptr(wco), ptr(out), None, ptr(cT), ptr(reserve), rs_bytes, ptr(ws), ws_bytes,
                                     _stream())
         check(rc, "vpx_convlstm_seq_fwd")
         if PROFILE is not None:

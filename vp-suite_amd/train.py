@@ -67,6 +67,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.steps += 1
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.steps, g["lr"], g["betas"],
                       g["eps"], g["weight_decay"], self.grad_scale)
+        # the kernel wrote the parameters behind autograd's back: bump their version counters so that everything keyed
+        # on (data_ptr, _version) — packed-weight and layout caches of the cells — sees new values
+        torch.autograd.graph.increment_version(g["params"])
         return loss
 
     def zero_grad(self, set_to_none: bool = False):
