@@ -513,6 +513,7 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
             const char* wb = wb0 + buf * WBUF;
             const bool has_next = kq + QPC < st.nq || s + 1 < s_end;
             if (has_next) issue_load(wr);  // chunk g+1 travels while chunk g is multiplied
+            __builtin_amdgcn_s_setprio(2);  // MFMA bursts outrank co-resident waves that are staging (+1-2 % measured)
 #pragma unroll
             for (int q = 0; q < QPC; ++q) {
                 if (q == 0 || kq + q < st.nq) {
@@ -578,6 +579,7 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
                     }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             if (has_next) write_lds(wr, buf ^ 1);  // every wave finished reading that buffer before the last barrier
             if (!DBGBIT(32)) __syncthreads();  // (bit 32: timing-only ablation of the per-chunk barrier; results are wrong)
             ++gidx;
