@@ -684,7 +684,9 @@ int pick_ksplit(long long wgs, int nstage) {
     if (g_deterministic) return 1;
     int k = 1;
     if (forced > 0) k = forced;
-    else if (wgs > 0 && wgs < 384) k = (int)((768 + wgs - 1) / wgs);  // aim at ~3 workgroups per CU
+    // aim at one workgroup per CU: measured on 16x16 maps (64 pixel tiles), PredRNN forward 25.8 ms with 12 splits,
+    // 24.7 ms with 4, 28.7 ms with 3; ConvLSTM (96,96,16x16) B=32 (192 workgroups) 155 TF fused, 164 TF with 2 splits
+    else if (wgs > 0 && wgs < 256) k = (int)((256 + wgs - 1) / wgs);
     if (k > nstage) k = nstage;
     if (k > 16) k = 16;
     return k < 1 ? 1 : k;

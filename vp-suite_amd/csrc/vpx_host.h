@@ -89,9 +89,11 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     L.split = 0;
     {
         const long long m_tiles = (long long)d->B * ((d->H + TILE_H - 1) / TILE_H) * ((d->W + TILE_W - 1) / TILE_W);
-        // the fused launch would leave most CUs idle (small batches / maps). Measured on MI355X, bf16x3, (96,96,16x16):
-        // B=4 (24 workgroups fused) 20 -> 39 TF with the split; B=32 (192 workgroups) 157 -> 140 TF, so the bar is < 160
-        if (m_tiles * L.n_tiles < 160) {
+        // the fused launch would leave CUs idle (small batches / maps). Measured on MI355X, bf16x3, (96,96,16x16):
+        // B=4 (24 workgroups fused) 20 -> 39 TF with the split; B=32 (192 workgroups) 155 -> 164 TF with 2 splits
+        static int bar = -1;  // VPX_SPLIT_BAR: experiment override of the workgroup-count bar below
+        if (bar < 0) { const char* e = getenv("VPX_SPLIT_BAR"); bar = e ? atoi(e) : 256; }
+        if (m_tiles * L.n_tiles < bar) {
             const int ng = plain_groups(4 * d->Ch);
             const int tiles = plain_tiles_ng(4 * d->Ch, ng);
             L.s_nstage = build_stages(L.s_stage, &L.s_chunks, segC, 2, L.taps, pick_stage_channels(segC, 2, d->kh, d->kw, ng, d->precision), d->precision);
