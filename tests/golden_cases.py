@@ -107,3 +107,9 @@ def acstlstm_inputs(tag, Cin, Ch, H, W, B):
     for n in ("h", "c", "m", "a", "g_h", "g_c", "g_m", "g_dc", "g_dm"):
         d[n] = seeded_randn((B, Ch, H, W), name_seed(p + n), 0.5 if n in ("h", "c", "m", "a") else 1.0)
     return d
+
+# TrajGRU (traj_gru.py:74-214): tag -> (in_c, enc_c, H, W, L, B, T, mode)   mode: "full" | "noinput"
+TRAJGRU_CASES = {
+    "full": (4, 8, 10, 9, 3, 2, 3, "full"),
+    "noinput": (4, 8, 8, 8, 5, 2, 2, "noinput"),
+}

@@ -311,3 +311,30 @@ def test_action_conditional_stlstm_cell_vs_golden(vpx, tag):
         assert _relmax(lv[n].grad, g["d" + n]) < 5e-5, n
     for key, prm in cell.named_parameters():
         assert _relmax(prm.grad, g["grad." + key]) < 5e-5, key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["full", "noinput"])
+def test_trajgru_block_vs_golden(vpx, tag):
+    """TrajGRU (traj_gru.py:164-214): convolutions on the library kernel, warp + GRU gates in ATen; encoder form
+    (inputs, zero state) and forecaster form (inputs=None) against the reference fixture, incl. gradients."""
+    from vp_suite_amd.model_blocks import TrajGRU
+    in_c, enc_c, H, W, L, B, T, mode = gc.TRAJGRU_CASES[tag]
+    g = load_golden(f"trajgru_{tag}")
+    blk = TrajGRU("cuda", in_c, enc_c, H, W, L=L)
+    fill_state_dict_(blk, name_seed("trajgru." + tag))
+    blk = blk.cuda()
+    x = seeded_rand((B, T, in_c, H, W), name_seed(f"trajgru.{tag}.x")).cuda().requires_grad_(True)
+    h0 = seeded_randn((B, enc_c, H, W), name_seed(f"trajgru.{tag}.h0"), 0.5).cuda().requires_grad_(True)
+    out, hT = blk(x, None, T) if mode == "full" else blk(None, h0, T)
+    assert _relmax(out, g["out"]) < 2e-5 and _relmax(hT, g["hT"]) < 2e-5
+    (out * seeded_randn(out.shape, name_seed(f"trajgru.{tag}.g")).cuda()).sum().backward()
+    if mode == "full":
+        assert _relmax(x.grad, g["dx"]) < 1e-4
+    else:
+        assert _relmax(h0.grad, g["dh0"]) < 1e-4
+    for key, prm in blk.named_parameters():
+        if "grad." + key in g:
+            assert _relmax(prm.grad, g["grad." + key]) < 1e-4, key
+    with pytest.raises(ValueError):
+        blk(None, None, 1)

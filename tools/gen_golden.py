@@ -204,6 +204,29 @@ def gen_acstlstm():
         _save(f"acstlstm_{tag}", **arrays)
 
 
+def gen_trajgru():
+    """rank-4 widening: TrajGRU block (vp_suite/model_blocks/traj_gru.py:164-214), encoder form (inputs + zero state)
+    and forecaster form (inputs=None, given state); outputs + gradients."""
+    from vp_suite.model_blocks.traj_gru import TrajGRU
+    for tag, (in_c, enc_c, H, W, L, B, T, mode) in TRAJGRU_CASES.items():
+        blk = TrajGRU("cpu", in_c, enc_c, H, W, L=L)
+        fill_state_dict_(blk, name_seed("trajgru." + tag))
+        x = seeded_rand((B, T, in_c, H, W), name_seed(f"trajgru.{tag}.x")).requires_grad_(True)
+        h0 = seeded_randn((B, enc_c, H, W), name_seed(f"trajgru.{tag}.h0"), 0.5).requires_grad_(True)
+        out, hT = blk(x, None, T) if mode == "full" else blk(None, h0, T)
+        (out * seeded_randn(out.shape, name_seed(f"trajgru.{tag}.g"))).sum().backward()
+        arrays = dict(out=_np(out), hT=_np(hT))
+        if mode == "full":
+            arrays["dx"] = _np(x.grad)
+        else:
+            arrays["dh0"] = _np(h0.grad)
+        for key, prm in blk.named_parameters():
+            if prm.grad is not None:
+                arrays["grad." + key] = _np(prm.grad)
+        arrays.update(_sd_meta(blk))
+        _save(f"trajgru_{tag}", **arrays)
+
+
 def gen_decouple():
     import torch.nn.functional as F
     B, Ch, H, W = 2, 8, 6, 5
@@ -364,7 +387,7 @@ def gen_predrnn():
 
 
 GENERATORS = {"hzzone": gen_hzzone, "ndrplz": gen_ndrplz, "stlstm": gen_stlstm, "decouple": gen_decouple,
-              "ef": gen_ef, "predrnn": gen_predrnn, "phy_ssc": gen_phydnet_ssc, "acstlstm": gen_acstlstm}
+              "ef": gen_ef, "predrnn": gen_predrnn, "phy_ssc": gen_phydnet_ssc, "acstlstm": gen_acstlstm, "trajgru": gen_trajgru}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
