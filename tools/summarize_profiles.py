@@ -23,14 +23,30 @@ def one(pattern):
     return f[0] if f else None
 
 
+# One "cell step" is either one fused launch (EpiConvLSTM) or, on nearly-empty grids, the K-split trio
+# EpiPlain<4> conv + convlstm_pointwise_kernel (+ a buffer clear that the counters do not see as a kernel).
+SPLIT_PARTS = ("EpiPlain<4>", "convlstm_pointwise_kernel")
+
+
 def pmc_means(d):
     f = one(f"{d}/*/*counter_collection.csv")
     agg = collections.defaultdict(list)
+    step_sum = collections.defaultdict(float)
+    steps = collections.defaultdict(int)
     if f:
         for r in csv.DictReader(open(f)):
-            if DOMINANT in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in agg.items()}
+            name, c, v = r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])
+            if DOMINANT in name:
+                agg[c].append(v)
+            if DOMINANT in name or any(p in name for p in SPLIT_PARTS):
+                step_sum[c] += v
+            if DOMINANT in name or "convlstm_pointwise_kernel" in name:
+                steps[c] += 1
+    out = {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in agg.items()}
+    for k in out:
+        out[k]["cell_steps"] = steps[k]
+        out[k]["mean_per_cell_step"] = step_sum[k] / max(steps[k], 1)
+    return out
 
 
 os.makedirs(DST, exist_ok=True)
@@ -63,10 +79,14 @@ summary = {"kernel": "conv_gemm_kernel<EpiConvLSTM, bf16x3> averaged over the la
            "command": "tools/collect_profiles.sh (rocprofv3 --pmc <counter> --kernel-trace, one pass per counter group)",
            "counters": counters}
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-    rd = 2.0 * counters["FETCH_SIZE"]["mean_per_launch"] * 1024
-    wr = counters["WRITE_SIZE"]["mean_per_launch"] * 1024
+    # per CELL STEP (fused launches and K-split trios alike): the unit bench.py's algorithmic_bytes_per_launch uses
+    rd = 2.0 * counters["FETCH_SIZE"]["mean_per_cell_step"] * 1024
+    wr = counters["WRITE_SIZE"]["mean_per_cell_step"] * 1024
     summary["hbm_traffic_bytes_per_launch"] = {"read": rd, "write": wr, "total": rd + wr,
-                                               "note": "read = 2 * FETCH_SIZE KiB (gfx950 wide-read correction), write = WRITE_SIZE KiB"}
+                                               "note": "per cell step; read = 2 * FETCH_SIZE KiB (gfx950 wide-read correction), write = WRITE_SIZE KiB"}
+    rd1 = 2.0 * counters["FETCH_SIZE"]["mean_per_launch"] * 1024
+    wr1 = counters["WRITE_SIZE"]["mean_per_launch"] * 1024
+    summary["hbm_traffic_bytes_per_fused_launch"] = {"read": rd1, "write": wr1, "total": rd1 + wr1}
 if "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "GRBM_GUI_ACTIVE" in counters:
     elapsed_simd_cycles = counters["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8 * 1024
     summary["mfma_pipe_busy_frac"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / elapsed_simd_cycles
