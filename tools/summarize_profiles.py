@@ -50,18 +50,30 @@ def pmc_means(d):
 
 
 os.makedirs(DST, exist_ok=True)
+
+
+def batch_tag(log_name, default="b128"):
+    log = os.path.join(SRC, log_name)
+    if os.path.exists(log):
+        for l in open(log):
+            if l.startswith("{"):
+                return "b%d" % json.loads(l)["config"]["per_gpu_batch"]
+    return default
+
+
+BT = batch_tag("bench_infer.log")
 for mode in ("infer", "train"):
     f = one(f"trace_{mode}/*/*kernel_stats.csv")
     if f:
-        shutil.copy(f, os.path.join(DST, f"{ROUND}_bench_{mode}_b32_bf16x3_kernel_stats.csv"))
+        shutil.copy(f, os.path.join(DST, f"{ROUND}_bench_{mode}_{BT}_bf16x3_kernel_stats.csv"))
     log = os.path.join(SRC, f"bench_{mode}.log")
     if os.path.exists(log):
         lines = [l for l in open(log) if l.startswith("{")]
         if lines:
-            open(os.path.join(DST, f"{ROUND}_bench_{mode}_b32_bf16x3_under_rocprof.json"), "w").write(lines[-1])
+            open(os.path.join(DST, f"{ROUND}_bench_{mode}_{BT}_bf16x3_under_rocprof.json"), "w").write(lines[-1])
 
-for tag, name in (("infer_f32", "bench_infer_b32_f32"), ("predrnn_infer", "bench_predrnn_infer_b32_bf16x3"),
-                  ("predrnn_train", "bench_predrnn_train_b32_bf16x3")):
+for tag, name in (("infer_f32", f"bench_infer_{BT}_f32"), ("predrnn_infer", f"bench_predrnn_infer_{BT}_bf16x3"),
+                  ("predrnn_train", f"bench_predrnn_train_{BT}_bf16x3")):
     f = one(f"trace_{tag}/*/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"{ROUND}_{name}_kernel_stats.csv"))
@@ -75,7 +87,7 @@ counters = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     counters.update(pmc_means(d))
 summary = {"kernel": "conv_gemm_kernel<EpiConvLSTM, bf16x3> averaged over the launches of `bench.py --steps 3` "
-                     "(convlstm-shi, B=32, 6 block shapes)",
+                     f"(convlstm-shi, {BT}, 6 block shapes)",
            "command": "tools/collect_profiles.sh (rocprofv3 --pmc <counter> --kernel-trace, one pass per counter group)",
            "counters": counters}
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
@@ -90,5 +102,5 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
 if "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "GRBM_GUI_ACTIVE" in counters:
     elapsed_simd_cycles = counters["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8 * 1024
     summary["mfma_pipe_busy_frac"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / elapsed_simd_cycles
-json.dump(summary, open(os.path.join(DST, f"{ROUND}_pmc_bench_infer_b32_bf16x3.json"), "w"), indent=1)
+json.dump(summary, open(os.path.join(DST, f"{ROUND}_pmc_bench_infer_{BT}_bf16x3.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:1500])
