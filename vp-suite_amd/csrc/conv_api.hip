@@ -130,6 +130,17 @@ int ex_check(const vpx_conv_desc* d, ExGeo& g) {
     return VPX_OK;
 }
 
+// workgroup form of a glue launch: the 8-wave / 16x16-pixel tile when the grid stays large (pick_mw's rule) and the
+// stride-1 halo keeps two such workgroups per CU; VPX_GLUE_MW=1/2 forces a form (experiments)
+static int ex_mw(const vpx_conv_desc* d, int Ht, int Wt, int sd) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("VPX_GLUE_MW"); forced = e ? atoi(e) : 0; }
+    if (d->precision == VPX_PREC_F32) return 1;
+    if (forced == 1 || forced == 2) return forced;
+    if (sd != 1) return 1;
+    return pick_mw(d->N, Ht, Wt, plain_tiles(d->Co), d->precision);
+}
+
 // one launch: tile space Ht x Wt, kernel taps th x tw, halo origin (oy, ox), input step `sd`
 int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
               const ExGeo& g, int Ht, int Wt, int th, int tw, int sd, int oy, int ox, const int* tapmap, bool flip,
@@ -140,7 +151,8 @@ int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const 
     const int segC[1] = {d->Ci};
     P.prec = prec;
     const int ng = plain_groups(d->Co);
-    P.nstage = build_stages(P.stage, &chunks, segC, 1, th * tw, pick_stage_channels(segC, 1, th, tw, ng, prec, 1, sd), prec);
+    const int mw = ex_mw(d, Ht, Wt, sd);
+    P.nstage = build_stages(P.stage, &chunks, segC, 1, th * tw, pick_stage_channels(segC, 1, th, tw, ng, prec, mw, sd), prec);
     if (P.nstage < 0) { set_error("conv: too many channel stages (Ci=%d)", d->Ci); return VPX_ERR_UNSUPPORTED; }
     PackDesc pd{};
     const int src_taps = d->kh * d->kw;
@@ -154,12 +166,12 @@ int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const 
     if (tapmap) { pd.src_taps = src_taps; for (int i = 0; i < th * tw; ++i) pd.tapmap[i] = tapmap[i]; }
     VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
     P.B = d->N; P.H = Ht; P.W = Wt; P.kh = th; P.kw = tw;
-    set_plan_tiles(P, 1);
+    set_plan_tiles(P, mw);
     P.stride = sd; P.use_org = 1; P.org_y = oy; P.org_x = ox; P.Hin = d->H; P.Win = d->W;
     P.nseg = 1;
     P.seg[0] = ConvSeg{x, (long long)d->H * d->W * d->Ci, d->Ci, d->Ci};
     P.chunks_total = chunks;
-    P.a_bytes = conv_a_bytes(P.stage, P.nstage, th, tw, 1, sd);
+    P.a_bytes = conv_a_bytes(P.stage, P.nstage, th, tw, mw, sd);
     P.wpk = wpk;
     PlainEpiArgs ea{};
     ea.bias = bias; ea.Co = d->Co; ea.split = d->Co; ea.ng = ng;
@@ -177,8 +189,13 @@ size_t ex_wpk_floats(const vpx_conv_desc* d) {
     const int segC[1] = {d->Ci};
     const int ng = plain_groups(d->Co);
     const int sd = d->transposed ? 1 : d->stride;
-    if (build_stages(st, &chunks, segC, 1, d->kh * d->kw, pick_stage_channels(segC, 1, d->kh, d->kw, ng, d->precision, 1, sd), d->precision) < 0) return 0;
-    return packed_weight_bytes(plain_tiles(d->Co), chunks, ng, d->precision) / 4 + 1024;
+    size_t best = 0;
+    for (int mw = 1; mw <= 2; ++mw) {  // upper bound over both workgroup forms (their stage sizes differ)
+        if (build_stages(st, &chunks, segC, 1, d->kh * d->kw, pick_stage_channels(segC, 1, d->kh, d->kw, ng, d->precision, mw, sd), d->precision) < 0) return 0;
+        const size_t b = packed_weight_bytes(plain_tiles(d->Co), chunks, ng, d->precision) / 4 + 1024;
+        if (b > best) best = b;
+    }
+    return best;
 }
 
 }  // namespace
