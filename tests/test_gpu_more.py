@@ -338,3 +338,34 @@ def test_trajgru_block_vs_golden(vpx, tag):
             assert _relmax(prm.grad, g["grad." + key]) < 1e-4, key
     with pytest.raises(ValueError):
         blk(None, None, 1)
+
+
+@pytest.mark.gpu
+def test_small_grids_fused_and_split_paths_agree(vpx):
+    """On nearly-empty grids the ConvLSTM step runs as a K-split convolution + pointwise gates (atomics); with
+    torch.use_deterministic_algorithms(True) the same shapes take the fused launch. Both must meet the oracle, the
+    deterministic one bit-reproducibly, forward and backward."""
+    from oracle import torch_ref as tr
+    Cin, Ch, H, W, B, T = 24, 40, 16, 16, 4, 3
+    Wt = seeded_randn((4 * Ch, Cin + Ch, 3, 3), name_seed("sg.W"), 1.0 / np.sqrt((Cin + Ch) * 9))
+    b = seeded_randn((4 * Ch,), name_seed("sg.b"), 0.1)
+    x = seeded_rand((B, T, Cin, H, W), name_seed("sg.x"))
+    pw = [seeded_randn((1, Ch, H, W), name_seed("sg.p%d" % i), 0.1) for i in range(3)]
+    xr = x.clone().requires_grad_(True)
+    Wr = Wt.clone().requires_grad_(True)
+    ref, _ = tr.convlstm_hzzone_seq(xr, None, T, Wr, b, *pw)
+    (ref ** 2).sum().backward()
+    runs = {}
+    for det in (False, True, True):
+        torch.use_deterministic_algorithms(det)
+        try:
+            xg = x.cuda().requires_grad_(True)
+            Wg = Wt.cuda().requires_grad_(True)
+            out, hT, cT = vpx.ops.convlstm_seq(xg, None, None, Wg, b.cuda(), *[p.cuda() for p in pw], seq_len=T,
+                                               in_channels=Cin)
+            (out ** 2).sum().backward()
+        finally:
+            torch.use_deterministic_algorithms(False)
+        assert _relmax(out, ref) < 1e-5 and _relmax(xg.grad, xr.grad) < 5e-5 and _relmax(Wg.grad, Wr.grad) < 5e-5, det
+        runs.setdefault(det, []).append(out.detach().clone())
+    assert torch.equal(runs[True][0], runs[True][1])
