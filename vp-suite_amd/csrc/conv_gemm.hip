@@ -306,7 +306,7 @@ template <> struct ModeTraits<2> { static constexpr int KSTEP = 16, KC = 32, WRO
 // pixels share every weight chunk (the L2->CU load pipe, ~70 GB/s per CU, is what limits the bf16 modes), at <= 128
 // registers so that two such workgroups (16 waves) stay resident per CU.
 template <class Epi, int MODE, int MW, int MS = 1>
-__device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, const int n_tile) {
+__device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, const int n_tile, const int m_tile) {
     constexpr int NTH = NTHREADS * MW;
     using MT = ModeTraits<MODE>;
     constexpr int KC = MT::KC, KSTEP = MT::KSTEP;
@@ -322,7 +322,7 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
 
-    int mt = blockIdx.x;
+    int mt = m_tile;
     const int tx = mt % P.tiles_x;
     mt /= P.tiles_x;
     const int ty = mt % P.tiles_y;
@@ -597,9 +597,33 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
     }
 }
 
+// XCD-aware workgroup -> tile mapping. The hardware hands consecutive workgroup ids to the 8 XCDs round-robin, and every
+// XCD has its own L2. The launch is a 1-D grid over (pixel tile, N tile) pairs (gridDim.y carries the N-tile count for
+// the decode only when the launcher could not flatten); id L runs on XCD L % 8 as that XCD's (L / 8)-th workgroup.
+// Each XCD gets a CONTIGUOUS range of the tile sequence, N tile fastest: the N tiles of one pixel tile (they read the same
+// activation halo) and neighbouring pixel tiles (overlapping halos) then run back to back on ONE XCD and meet in its L2
+// instead of each fetching from HBM.
+__device__ __forceinline__ bool xcd_tile(const ConvPlan& P, unsigned L, unsigned n_tiles_y, int& m_tile, int& n_tile) {
+    const int n_tiles = P.grid_n;
+    if (n_tiles <= 0) {  // legacy 2-D launch: x = pixel tile, y = N tile
+        m_tile = (int)L; n_tile = (int)blockIdx.y;
+        return true;
+    }
+    const long long total = (long long)P.grid_m * n_tiles;
+    const long long per_xcd = (total + 7) / 8;
+    const long long s = (long long)(L & 7) * per_xcd + (L >> 3);
+    if ((long long)(L >> 3) >= per_xcd || s >= total) return false;
+    m_tile = (int)(s / n_tiles);
+    n_tile = (int)(s - (long long)m_tile * n_tiles);
+    (void)n_tiles_y;
+    return true;
+}
+
 template <class Epi, int MODE, int MW, int MS = 1>
 __global__ __launch_bounds__(NTHREADS * MW, (MS == 2 ? 2 : (MW >= 2 ? 4 : 3))) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
-    conv_body<Epi, MODE, MW, MS>(P, epi, blockIdx.y);
+    int m_tile, n_tile;
+    if (!xcd_tile(P, blockIdx.x, gridDim.y, m_tile, n_tile)) return;
+    conv_body<Epi, MODE, MW, MS>(P, epi, n_tile, m_tile);
 }
 
 // Two independent contractions over the same pixel tiling in ONE launch (blockIdx.y < nA -> A, else B): the ST-LSTM's
@@ -607,8 +631,16 @@ __global__ __launch_bounds__(NTHREADS * MW, (MS == 2 ? 2 : (MW >= 2 ? 4 : 3))) v
 template <class EpiA, class EpiB, int MODE>
 __global__ __launch_bounds__(NTHREADS, 3) void conv_gemm_dual_kernel(const ConvPlan PA, const EpiA epiA, const int nA,
                                                                     const ConvPlan PB, const EpiB epiB) {
-    if ((int)blockIdx.y < nA) conv_body<EpiA, MODE, 1>(PA, epiA, blockIdx.y);
-    else conv_body<EpiB, MODE, 1>(PB, epiB, blockIdx.y - nA);
+    int m_tile, n_tile;
+    if (!xcd_tile(PA, blockIdx.x, gridDim.y, m_tile, n_tile)) return;
+    if (n_tile < nA) conv_body<EpiA, MODE, 1>(PA, epiA, n_tile, m_tile);
+    else conv_body<EpiB, MODE, 1>(PB, epiB, n_tile - nA, m_tile);
+}
+
+static bool xcd_map_enabled() {  // VPX_XCD_MAP=0 restores the plain 2-D grid (experiments)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VPX_XCD_MAP"); on = e ? atoi(e) : 1; }
+    return on != 0;
 }
 
 template <class Epi, int MODE, int MW, int MS = 1>
@@ -622,8 +654,13 @@ static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tile
         attr_set = true;
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    dim3 grid(plan.B * plan.tiles_x * plan.tiles_y, n_tiles, plan.ksplit > 1 ? plan.ksplit : 1);
-    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE, MW, MS>), grid, dim3(NTHREADS * MW), lds, s, plan, epi);
+    ConvPlan p2 = plan;
+    p2.grid_m = plan.B * plan.tiles_x * plan.tiles_y;
+    p2.grid_n = xcd_map_enabled() ? n_tiles : 0;
+    const long long per_xcd = ((long long)p2.grid_m * n_tiles + 7) / 8;
+    dim3 grid = p2.grid_n ? dim3((unsigned)(per_xcd * 8), 1, plan.ksplit > 1 ? plan.ksplit : 1)
+                          : dim3(p2.grid_m, n_tiles, plan.ksplit > 1 ? plan.ksplit : 1);
+    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE, MW, MS>), grid, dim3(NTHREADS * MW), lds, s, p2, epi);
     return hipGetLastError();
 }
 
@@ -728,8 +765,13 @@ static hipError_t launch_st_dual_m(const ConvPlan& pc, const STGateArgs& ec, con
         attr_set = true;
     }
     if (lds > 160 * 1024 || pc.tiles_x != pm.tiles_x || pc.tiles_y != pm.tiles_y || pc.B != pm.B) return hipErrorInvalidValue;
-    dim3 grid(pc.B * pc.tiles_x * pc.tiles_y, 2 * n_tiles);
-    hipLaunchKernelGGL((conv_gemm_dual_kernel<KA, KB, MODE>), grid, dim3(NTHREADS), lds, s, pc, KA{ec}, n_tiles, pm, KB{em});
+    ConvPlan pc2 = pc;
+    pc2.grid_m = pc.B * pc.tiles_x * pc.tiles_y;
+    pc2.grid_n = 0;  // the two groups have different weights and sources: interleaving them per XCD measured 2.6 % slower
+    (void)&xcd_map_enabled;
+    const long long per_xcd = ((long long)pc2.grid_m * 2 * n_tiles + 7) / 8;
+    dim3 grid = pc2.grid_n ? dim3((unsigned)(per_xcd * 8), 1) : dim3(pc2.grid_m, 2 * n_tiles);
+    hipLaunchKernelGGL((conv_gemm_dual_kernel<KA, KB, MODE>), grid, dim3(NTHREADS), lds, s, pc2, KA{ec}, n_tiles, pm, KB{em});
     return hipGetLastError();
 }
 

@@ -46,6 +46,7 @@ struct ConvPlan {
     int a_bytes;          // LDS bytes reserved for the activation stage
     int prec;             // VPX_PREC_F32 | VPX_PREC_BF16X3: operand mode of the contraction
     int mw;               // 32-pixel MFMA row tiles per wave (1: 8x16 workgroup tile, 2: 16x16); 0 is read as 1
+    int grid_m, grid_n;   // set by the launcher: pixel tiles / N tiles of the flattened, XCD-aware 1-D grid (grid_n = 0: 2-D grid)
     int ksplit;           // > 1: the stage list is split over blockIdx.z (plain epilogue only; partial sums via atomics)
     int dbg;              // ablation bits for profiling (VPX_DBG): 1 skip MFMAs, 2 skip activation loads, 4 skip weight loads, 8 skip epilogue
     // generalised geometry (all 0 = the stride-1 "same" convolution every recurrent cell uses):
