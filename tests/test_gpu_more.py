@@ -137,6 +137,17 @@ def test_conv2d_ex_vs_torch(vpx):
         (False, 16, 1, 1, 1, 0, 16, 16), (True, 96, 96, 4, 2, 1, 8, 8), (True, 10, 14, 4, 2, 1, 7, 9),
         (True, 64, 16, 3, 1, 1, 16, 16), (True, 6, 5, 5, 2, 2, 6, 7), (False, 8, 8, 4, 2, 1, 12, 12),
     ]
+    # the backward is delegated to ATen; on these exotic shapes MIOpen's solver search is unstable on this image (it
+    # aborted ~10 % of full-suite runs inside miopen find), so the wiring is checked on ATen's native kernels. The
+    # models' own shapes go through MIOpen in test_gpu_models.py / the training bench.
+    vpx.ops.GLUE_BACKWARD_NATIVE = True
+    try:
+        _conv2d_ex_cases(vpx, cases, F)
+    finally:
+        vpx.ops.GLUE_BACKWARD_NATIVE = False
+
+
+def _conv2d_ex_cases(vpx, cases, F):
     for prec, tol in (("f32", 2e-5), ("bf16x3", 5e-5)):
         for tr, Ci, Co, k, s, p, H, W in cases:
             tag = f"cex.{tr}.{Ci}.{Co}.{k}.{s}"

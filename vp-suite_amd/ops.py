@@ -273,6 +273,9 @@ def conv2d_same(x, w, bias=None, precision="f32"):
     return _Conv2dSameFn.apply(x, w, bias, PRECISIONS[precision])
 
 
+GLUE_BACKWARD_NATIVE = False  #: True: the glue convolutions' backward avoids MIOpen (slow; for robustness experiments / tests)
+
+
 class _ConvExFn(torch.autograd.Function):
     """Conv2d / ConvTranspose2d (stride 1 or 2) + bias + LeakyReLU in ONE library launch (4 for a stride-2 transposed
     conv) — the EF stage glue of ef_blocks.py:15-49. The forward is the HIP implicit-GEMM kernel; the backward of this
@@ -311,8 +314,12 @@ class _ConvExFn(torch.autograd.Function):
             dy = dy * torch.where(y > 0, torch.ones((), device=y.device), torch.full((), slope, device=y.device))
         mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]]
         bias_sizes = [int(wc.shape[1] if transposed else wc.shape[0])] if has_bias else None
-        dx, dw, db = torch.ops.aten.convolution_backward(dy, xs, wc, bias_sizes, [stride, stride], [padding, padding],
-                                                         [1, 1], transposed, [0, 0], 1, mask)
+        # ATen's convolution backward = MIOpen NHWC kernels (2.5x faster per training step than ATen's native fallback).
+        # GLUE_BACKWARD_NATIVE routes it around MIOpen (tests with exotic shapes: MIOpen's solver search aborted the
+        # process in ~10 % of the runs of one such test on this image, inside miopen find, never on the models' shapes).
+        with torch.backends.cudnn.flags(enabled=not GLUE_BACKWARD_NATIVE):
+            dx, dw, db = torch.ops.aten.convolution_backward(dy, xs, wc, bias_sizes, [stride, stride], [padding, padding],
+                                                             [1, 1], transposed, [0, 0], 1, mask)
         return dx, dw, (db if has_bias else None), None, None, None, None, None
 
 
