@@ -16,7 +16,7 @@
  * vpx_stlstm_step_fwd / _bwd       SpatioTemporalLSTMCell.forward           vp_suite/model_blocks/predrnn.py:57-83
  * vpx_decouple_fwd / _bwd          adapter + normalize + |cos| + mean       vp_suite/models/predrnn_v2.py:197-198,209-211
  * vpx_conv2d_nhwc_fwd / _bwd       F.conv2d 1x1 / kxk "same", stride 1      vp_suite/models/predrnn_v2.py:223 (conv_last)
- * vpx_conv2d_ex_fwd                Conv2d / ConvTranspose2d + LeakyReLU     vp_suite/models/precipitation_nowcasting/ef_blocks.py:15-49
+ * vpx_conv2d_ex_fwd / _bwd         Conv2d / ConvTranspose2d + LeakyReLU     vp_suite/models/precipitation_nowcasting/ef_blocks.py:15-49
  * vpx_mse_loss                     MSE measure + loss provider              vp_suite/base/base_measure.py:55-57, measure/loss_provider.py:48-51
  * vpx_adam_step                    torch.optim.Adam(model.parameters(), lr)  vp_suite/vpsuite.py:353, base/base_model.py:174-176
  * vpx_nchw_to_nhwc / nhwc_to_nchw  (layout adaptors at the boundary; the reference is NCHW throughout)
@@ -158,11 +158,20 @@ typedef struct vpx_conv_desc {
     int32_t transposed;            /* 0: nn.Conv2d weight [Co,Ci,kh,kw]; 1: nn.ConvTranspose2d weight [Ci,Co,kh,kw] */
     float leaky_slope;             /* LeakyReLU negative slope fused after the bias; 0 = no activation */
     int32_t precision;             /* VPX_PREC_* */
+    int32_t out_pad_h, out_pad_w;  /* transposed only: nn.ConvTranspose2d output_padding (0 .. stride-1) */
 } vpx_conv_desc;
 int vpx_conv2d_ex_out_shape(const vpx_conv_desc* d, int* Ho, int* Wo);
 size_t vpx_conv2d_ex_workspace_bytes(const vpx_conv_desc* d);
 /* y [N,Ho,Wo,Co]. A stride-2 transposed convolution runs as 4 output-phase launches of the same kernel. */
 int vpx_conv2d_ex_fwd(const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of the same layer (the reference gets it from autograd over nn.Conv2d / nn.ConvTranspose2d, ef_blocks.py:15-49):
+ * dy [N,Ho,Wo,Co] is the gradient w.r.t. the convolution output BEFORE bias/activation handling is undone by the caller
+ * (i.e. already multiplied by LeakyReLU'); dx [N,H,W,Ci] and dw (layout of w) are written, either may be NULL.
+ * dx is the adjoint layer run forward (transposed <-> plain, through vpx_conv2d_ex_fwd's kernels); dw contracts dy with
+ * the stride-decimated sub-images of x (or x with those of dy) on the MFMA weight-gradient kernel. Needs kh, kw >= stride. */
+size_t vpx_conv2d_ex_bwd_workspace_bytes(const vpx_conv_desc* d);
+int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, const float* dy, float* dx, float* dw,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- layout adaptors: src [N,C,H,W] <-> dst [N,H,W,C] -------------------------------------------------------- */

@@ -129,22 +129,22 @@ def test_plain_bf16_mode_has_its_own_tolerance(vpx):
 
 
 def test_conv2d_ex_vs_torch(vpx):
-    """vpx_conv2d_ex_fwd (strided conv, transposed conv incl. the 4-phase stride-2 form, fused bias + LeakyReLU) against
-    torch fp64 on the CPU; backward (delegated to ATen) against autograd."""
+    """vpx_conv2d_ex_fwd / _bwd (strided conv, transposed conv incl. the 4-phase stride-2 form, fused bias + LeakyReLU)
+    against torch fp64 / autograd on the CPU."""
     import torch.nn.functional as F
     cases = [  # (transposed, Ci, Co, k, stride, pad, H, W)
         (False, 1, 16, 3, 1, 1, 20, 24), (False, 64, 64, 3, 2, 1, 32, 32), (False, 12, 20, 3, 2, 1, 17, 23),
         (False, 16, 1, 1, 1, 0, 16, 16), (True, 96, 96, 4, 2, 1, 8, 8), (True, 10, 14, 4, 2, 1, 7, 9),
         (True, 64, 16, 3, 1, 1, 16, 16), (True, 6, 5, 5, 2, 2, 6, 7), (False, 8, 8, 4, 2, 1, 12, 12),
     ]
-    # the backward is delegated to ATen; on these exotic shapes MIOpen's solver search is unstable on this image (it
-    # aborted ~10 % of full-suite runs inside miopen find), so the wiring is checked on ATen's native kernels. The
-    # models' own shapes go through MIOpen in test_gpu_models.py / the training bench.
-    vpx.ops.GLUE_BACKWARD_NATIVE = True
+    _conv2d_ex_cases(vpx, cases, F)   # backward: vpx_conv2d_ex_bwd (adjoint layer + strided MFMA weight gradient)
+    # the ATen fallback wiring (used when the kernel is smaller than the stride), on ATen's native kernels: MIOpen's
+    # solver search aborted ~10 % of full-suite runs on these exotic shapes
+    vpx.ops.GLUE_BACKWARD_HIP, vpx.ops.GLUE_BACKWARD_NATIVE = False, True
     try:
-        _conv2d_ex_cases(vpx, cases, F)
+        _conv2d_ex_cases(vpx, cases[:3], F)
     finally:
-        vpx.ops.GLUE_BACKWARD_NATIVE = False
+        vpx.ops.GLUE_BACKWARD_HIP, vpx.ops.GLUE_BACKWARD_NATIVE = True, False
 
 
 def _conv2d_ex_cases(vpx, cases, F):
@@ -164,7 +164,7 @@ def _conv2d_ex_cases(vpx, cases, F):
             y = vpx.ops.conv2d_ex(lv[0], lv[1], lv[2], s, p, tr, 0.2, prec)
             assert y.shape == ref.shape, (tag, y.shape, ref.shape)
             assert _relmax(y, ref) < tol, (prec, tag, _relmax(y, ref))
-            if prec == "f32":
+            if True:  # gradients in both operand modes (bf16x3 keeps fp32-level accuracy)
                 gy = seeded_randn(ref.shape, name_seed(tag + "g"))
                 rl = [t.clone().requires_grad_(True) for t in (x, w, b)]
                 rr = F.conv_transpose2d(rl[0], rl[1], rl[2], stride=s, padding=p) if tr else \
@@ -172,7 +172,7 @@ def _conv2d_ex_cases(vpx, cases, F):
                 (F.leaky_relu(rr, 0.2) * gy).sum().backward()
                 (y * gy.cuda()).sum().backward()
                 for a, r in zip(lv, rl):
-                    assert _relmax(a.grad, r.grad) < 1e-4, tag
+                    assert _relmax(a.grad, r.grad) < 1e-4, (prec, tag)
 
 
 def test_edge_shapes_vs_oracle(vpx):

@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = [
     "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
     "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_conv2d_bwd_workspace_bytes", "vpx_conv2d_nhwc_bwd",
     "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd",
+    "vpx_conv2d_ex_bwd_workspace_bytes", "vpx_conv2d_ex_bwd",
     "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
     "vpx_mse_loss_workspace_bytes", "vpx_mse_loss", "vpx_adam_step",
 ]
@@ -41,7 +42,8 @@ class STLSTMDesc(ctypes.Structure):
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "W", "Ci", "Co", "kh", "kw", "stride", "pad", "transposed")] + \
-               [("leaky_slope", ctypes.c_float), ("precision", ctypes.c_int32)]
+               [("leaky_slope", ctypes.c_float), ("precision", ctypes.c_int32), ("out_pad_h", ctypes.c_int32),
+                ("out_pad_w", ctypes.c_int32)]
 
 
 class VpxError(RuntimeError):
@@ -109,6 +111,10 @@ def lib():
         L.vpx_conv2d_ex_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
         L.vpx_conv2d_ex_fwd.restype = ctypes.c_int
         L.vpx_conv2d_ex_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 4 + [vp, sz, vp]
+        L.vpx_conv2d_ex_bwd_workspace_bytes.restype = sz
+        L.vpx_conv2d_ex_bwd_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.vpx_conv2d_ex_bwd.restype = ctypes.c_int
+        L.vpx_conv2d_ex_bwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 5 + [vp, sz, vp]
         L.vpx_mse_loss_workspace_bytes.restype = sz
         L.vpx_mse_loss_workspace_bytes.argtypes = []
         L.vpx_mse_loss.restype = ctypes.c_int

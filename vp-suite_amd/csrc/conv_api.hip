@@ -122,8 +122,9 @@ int ex_check(const vpx_conv_desc* d, ExGeo& g) {
         g.Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
         g.Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
     } else {
-        g.Ho = (d->H - 1) * d->stride - 2 * d->pad + d->kh;
-        g.Wo = (d->W - 1) * d->stride - 2 * d->pad + d->kw;
+        if (d->out_pad_h < 0 || d->out_pad_w < 0 || d->out_pad_h >= d->stride || d->out_pad_w >= d->stride) { set_error("conv desc: output padding must be in [0, stride)"); return VPX_ERR_ARG; }
+        g.Ho = (d->H - 1) * d->stride - 2 * d->pad + d->kh + d->out_pad_h;
+        g.Wo = (d->W - 1) * d->stride - 2 * d->pad + d->kw + d->out_pad_w;
         if (d->stride == 1 && (d->kh - 1 - d->pad < 0 || d->kw - 1 - d->pad < 0)) { set_error("conv desc: padding larger than kernel-1 in a transposed conv"); return VPX_ERR_UNSUPPORTED; }
     }
     if (g.Ho < 1 || g.Wo < 1) { set_error("conv desc: empty output"); return VPX_ERR_ARG; }
@@ -182,6 +183,9 @@ int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const 
     return VPX_OK;
 }
 
+int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const float* w, const float* bias, float* y, float* wpk,
+               hipStream_t stream);
+
 size_t ex_wpk_floats(const vpx_conv_desc* d) {
     // upper bound over the launches this descriptor can produce (full tap set, stride as given)
     ConvStage st[MAX_STAGE];
@@ -224,10 +228,19 @@ int vpx_conv2d_ex_fwd(const vpx_conv_desc* d, const float* x, const float* w, co
     if (rc != VPX_OK) return rc;
     if (!x || !w || !y) { set_error("vpx_conv2d_ex_fwd: NULL tensor argument"); return VPX_ERR_ARG; }
     if (!workspace || workspace_bytes < vpx_conv2d_ex_workspace_bytes(d)) { set_error("vpx_conv2d_ex_fwd: workspace too small"); return VPX_ERR_WORKSPACE; }
-    hipStream_t stream = (hipStream_t)stream_;
     Carver ws{(char*)workspace, 0, workspace_bytes};
     ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
     float* wpk = ws.take(ex_wpk_floats(d));
+    return ex_forward(d, g, x, w, bias, y, wpk, (hipStream_t)stream_);
+}
+
+}  // extern "C"
+
+namespace {
+
+int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const float* w, const float* bias, float* y, float* wpk,
+               hipStream_t stream) {
+    int rc;
     if (!d->transposed)  // y[o] = sum_k x[o*s - pad + k] w[k]
         return ex_launch(stream, d, x, w, bias, y, g, g.Ho, g.Wo, d->kh, d->kw, d->stride, -d->pad, -d->pad, nullptr, false,
                          0, 1, 0, 1, 0, wpk);
@@ -255,6 +268,122 @@ int vpx_conv2d_ex_fwd(const vpx_conv_desc* d, const float* x, const float* w, co
                            1, 2, py, 2, px, wpk);
             if (rc != VPX_OK) return rc;
         }
+    return VPX_OK;
+}
+
+constexpr long long GLUE_SLAB_FLOATS = 4ll << 20;  // K-slice slab budget of the glue weight gradients (16 MB)
+
+// dW[r][c][ky][kx] = sum_{b,y,x} G[b,y,x,r] * A[b, s*y + ky - p, s*x + kx - p, c]   (G: [N,Hg,Wg,Rg], A: [N,Ha,Wa,Ca], NHWC).
+// ky - p = s*a + ry: the taps of one residue (ry, rx) slide over the sub-image A[s*i + ry, s*j + rx] with offsets a —
+// one stride-1 weight-gradient launch per residue on the MFMA kernel, its taps scattered into dW by the reduce.
+int strided_wgrad(hipStream_t stream, int prec, int N, int Hg, int Wg, const float* G, int Rg, int Ha, int Wa, const float* A,
+                  int Ca, int kh, int kw, int s, int p, float* slabs, float* dW) {
+    auto fdiv = [](int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); };
+    for (int ry = 0; ry < s; ++ry)
+        for (int rx = 0; rx < s; ++rx) {
+            // taps of this residue: ky = ky0, ky0 + s, ...
+            int ky0 = ((p + ry) % s + s) % s, kx0 = ((p + rx) % s + s) % s;
+            const int nty = ky0 < kh ? (kh - ky0 + s - 1) / s : 0, ntx = kx0 < kw ? (kw - kx0 + s - 1) / s : 0;
+            if (nty < 1 || ntx < 1) continue;
+            if (nty * ntx > 16 && s != 1) { set_error("conv wgrad: too many taps per residue"); return VPX_ERR_UNSUPPORTED; }
+            WgradArgs wa{};
+            wa.T = 1; wa.B = N; wa.H = Hg; wa.W = Wg; wa.HW = Hg * Wg; wa.kh = nty; wa.kw = ntx;
+            wa.tiles_x = (Wg + TILE_W - 1) / TILE_W; wa.tiles_y = (Hg + TILE_H - 1) / TILE_H;
+            wa.N4 = Rg; wa.Cin = Ca; wa.Ch = 1; wa.Ct = Ca; wa.ldG = Rg; wa.n_out = Rg; wa.prec = prec;
+            wa.dG = G; wa.x = A; wa.x_bstride = (long long)Ha * Wa * Ca;
+            wa.a_sub = 1; wa.a_sy = s; wa.a_sx = s; wa.a_oy = ry; wa.a_ox = rx;
+            wa.a_Hs = (Ha - ry + s - 1) / s; wa.a_Ws = (Wa - rx + s - 1) / s; wa.a_Wfull = Wa;
+            wa.use_org = 1; wa.org_y = fdiv(ky0 - p - ry, s); wa.org_x = fdiv(kx0 - p - rx, s);
+            wa.n_ctiles = 0;
+            for (int c0 = 0; c0 < Ca; c0 += 64) {
+                if (wa.n_ctiles >= 16) { set_error("conv wgrad: too many channels (%d)", Ca); return VPX_ERR_UNSUPPORTED; }
+                wa.ct[wa.n_ctiles++] = WgradCTile{0, c0, (Ca - c0 < 64) ? Ca - c0 : 64, c0};
+            }
+            wa.slabs = slabs;
+            const int taps = nty * ntx;
+            // K slices: ~1024 workgroups, bounded by the work items and by the slab budget (GLUE_SLAB_FLOATS, or 32 slices
+            // when one slice alone is that large). Layers with few rows x channels (1->16, 16->1) get all their
+            // parallelism from the slices.
+            const long long items = (long long)N * wa.tiles_x * wa.tiles_y;
+            const long long per_slice = (long long)taps * Rg * Ca;
+            long long cap = GLUE_SLAB_FLOATS / per_slice;
+            if (cap < 32) cap = 32;
+            int ns = wgrad_pick_slices((int)(cap < items ? cap : items), Rg, wa.n_ctiles, taps);
+            VPX_CHECK_HIP(launch_wgrad(wa, ns, stream));
+            if (s == 1) {
+                VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dW, ns, taps, Rg, Ca, stream));
+            } else {
+                int tapmap[16];
+                for (int ty = 0; ty < nty; ++ty)
+                    for (int tx = 0; tx < ntx; ++tx) tapmap[ty * ntx + tx] = (ky0 + s * ty) * kw + (kx0 + s * tx);
+                VPX_CHECK_HIP(launch_wgrad_reduce_map(slabs, dW, ns, taps, Rg, Ca, kh * kw, tapmap, stream));
+            }
+        }
+    return VPX_OK;
+}
+
+// the adjoint layer of d (what maps dy to dx), as a forward descriptor
+int ex_adjoint(const vpx_conv_desc* d, const ExGeo& g, vpx_conv_desc& a) {
+    a = *d;
+    a.H = g.Ho; a.W = g.Wo; a.Ci = d->Co; a.Co = d->Ci; a.leaky_slope = 0.0f;
+    a.out_pad_h = a.out_pad_w = 0;
+    if (!d->transposed) {  // dx = conv_transpose2d(dy, w, stride, pad, output_padding = the rows/cols the forward conv dropped)
+        a.transposed = 1;
+        a.out_pad_h = (d->H + 2 * d->pad - d->kh) % d->stride;
+        a.out_pad_w = (d->W + 2 * d->pad - d->kw) % d->stride;
+    } else {               // dx = conv2d(dy, w, stride, pad)
+        a.transposed = 0;
+    }
+    ExGeo ga;
+    if (ex_check(&a, ga) != VPX_OK) return VPX_ERR_UNSUPPORTED;
+    if (ga.Ho != d->H || ga.Wo != d->W) { set_error("conv bwd: adjoint shape %dx%d != input %dx%d", ga.Ho, ga.Wo, d->H, d->W); return VPX_ERR_UNSUPPORTED; }
+    return VPX_OK;
+}
+
+size_t ex_bwd_slab_floats(const vpx_conv_desc* d, const ExGeo& g) {
+    // a residue launch uses <= max(32 slices, GLUE_SLAB_FLOATS / slice) slices of <= kh*kw*Ci*Co floats
+    (void)g;
+    const size_t full = (size_t)32 * d->kh * d->kw * d->Ci * d->Co;
+    return full > (size_t)GLUE_SLAB_FLOATS ? full : (size_t)GLUE_SLAB_FLOATS;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vpx_conv2d_ex_bwd_workspace_bytes(const vpx_conv_desc* d) {
+    ExGeo g;
+    vpx_conv_desc a;
+    if (ex_check(d, g) != VPX_OK || ex_adjoint(d, g, a) != VPX_OK) return 0;
+    return align256(ex_wpk_floats(&a) * 4) + align256(ex_bwd_slab_floats(d, g) * 4) + 1024;
+}
+
+int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, const float* dy, float* dx, float* dw,
+                      void* workspace, size_t workspace_bytes, void* stream_) {
+    ExGeo g;
+    int rc = ex_check(d, g);
+    if (rc != VPX_OK) return rc;
+    vpx_conv_desc a;
+    if ((rc = ex_adjoint(d, g, a)) != VPX_OK) return rc;
+    if (d->kh < d->stride || d->kw < d->stride) { set_error("vpx_conv2d_ex_bwd: kernel smaller than the stride"); return VPX_ERR_UNSUPPORTED; }
+    if (!x || !w || !dy) { set_error("vpx_conv2d_ex_bwd: NULL tensor argument"); return VPX_ERR_ARG; }
+    if (!workspace || workspace_bytes < vpx_conv2d_ex_bwd_workspace_bytes(d)) { set_error("vpx_conv2d_ex_bwd: workspace too small"); return VPX_ERR_WORKSPACE; }
+    hipStream_t stream = (hipStream_t)stream_;
+    Carver ws{(char*)workspace, 0, workspace_bytes};
+    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    float* wpk = ws.take(ex_wpk_floats(&a));
+    float* slabs = ws.take(ex_bwd_slab_floats(d, g));
+    if (dx) {
+        ExGeo ga{d->H, d->W};
+        if ((rc = ex_forward(&a, ga, dy, w, nullptr, dx, wpk, stream)) != VPX_OK) return rc;
+    }
+    if (dw) {
+        if (!d->transposed)  // dW[co][ci][ky][kx] = sum dy[b,oy,ox,co] x[b, s*oy + ky - p, s*ox + kx - p, ci]
+            rc = strided_wgrad(stream, d->precision, d->N, g.Ho, g.Wo, dy, d->Co, d->H, d->W, x, d->Ci, d->kh, d->kw, d->stride, d->pad, slabs, dw);
+        else                 // dW[ci][co][ky][kx] = sum x[b,i,j,ci] dy[b, s*i + ky - p, s*j + kx - p, co]
+            rc = strided_wgrad(stream, d->precision, d->N, d->H, d->W, x, d->Ci, g.Ho, g.Wo, dy, d->Co, d->kh, d->kw, d->stride, d->pad, slabs, dw);
+        if (rc != VPX_OK) return rc;
+    }
     return VPX_OK;
 }
 

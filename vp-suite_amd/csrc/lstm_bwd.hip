@@ -108,6 +108,18 @@ hipError_t launch_colsum(const float* m, float* out, long long rows, int cols, h
 // LDS: dG tile [128 px][64 rows] (32 KiB) + activation halo tile [halo positions][64 ch].
 // Each wave owns a 32 (rows) x 32 (channels) output block for up to WG_MAXT taps: acc[tap] += dG^T (px-contracted) A_tap.
 // ---------------------------------------------------------------------------------------------------------------
+// activation pixel (gy, gx) of the map the taps slide over -> element offset (in pixels) inside the source image, or false
+__device__ __forceinline__ bool wg_apix(const WgradArgs& a, int gy, int gx, long long& pix) {
+    if (a.a_sub) {
+        if (gy < 0 || gy >= a.a_Hs || gx < 0 || gx >= a.a_Ws) return false;
+        pix = (long long)(gy * a.a_sy + a.a_oy) * a.a_Wfull + (gx * a.a_sx + a.a_ox);
+        return true;
+    }
+    if (gy < 0 || gy >= a.H || gx < 0 || gx >= a.W) return false;
+    pix = (long long)gy * a.W + gx;
+    return true;
+}
+
 template <int MAXT>  // MAXT = exact number of taps this launch handles (branch-free MFMA block)
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, const int tap_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
     const WgradCTile ct = a.ct[ct_id];
     const int tap0 = tap_base + blockIdx.z * MAXT;
     const int halo_w = TILE_W + a.kw - 1, halo_h = TILE_H + a.kh - 1, npos = halo_w * halo_h;
-    const int ph = a.kh / 2, pw = a.kw / 2;
+    const int ph = a.use_org ? -a.org_y : a.kh / 2, pw = a.use_org ? -a.org_x : a.kw / 2;
     float* G_lds = reinterpret_cast<float*>(smem);                 // [128][64]
     float* A_lds = reinterpret_cast<float*>(smem + 128 * 64 * 4);  // [npos][64]
 
@@ -193,8 +205,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
                 const int gy = y0 - ph + hy, gx = x0 - pw + hx;
                 const int c = ct.c0 + q4 * 4;
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < C)
-                    val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * a.W + gx) * C + c);
+                long long pix;
+                if (c < C && wg_apix(a, gy, gx, pix))
+                    val = *reinterpret_cast<const f32x4*>(src + pix * C + c);
                 *reinterpret_cast<f32x4*>(A_lds + pos * 64 + q4 * 4) = val;
             }
         } else {
@@ -204,7 +217,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
                 const int gy = y0 - ph + hy, gx = x0 - pw + hx;
                 const int c = ct.c0 + q;
                 float val = 0.f;
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c < C) val = src[((size_t)gy * a.W + gx) * C + c];
+                long long pix;
+                if (c < C && wg_apix(a, gy, gx, pix)) val = src[pix * C + c];
                 A_lds[pos * 64 + q] = val;
             }
         }
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
     const WgradCTile ct = a.ct[ct_id];
     const int tap0 = tap_base + blockIdx.z * MAXT;
     const int halo_w = TILE_W + a.kw - 1, halo_h = TILE_H + a.kh - 1, npos = halo_w * halo_h;
-    const int ph = a.kh / 2, pw = a.kw / 2;
+    const int ph = a.use_org ? -a.org_y : a.kh / 2, pw = a.use_org ? -a.org_x : a.kw / 2;
     // LDS planes: G_hi / G_lo [128 px][GROW rows] bf16, A_hi / A_lo [npos][64 channels] bf16 (128 B per position)
     char* G_hi = smem;
     char* G_lo = smem + 128 * GP;
@@ -393,8 +407,9 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
             const int hy = pos / halo_w, hx = pos - hy * halo_w;
             const int gy = g.y0 - ph + hy, gx = g.x0 - pw + hx;
             dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (pos < npos && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                const float* rowp = g.src + ((size_t)gy * a.W + gx) * g.C;
+            long long pix;
+            if (pos < npos && wg_apix(a, gy, gx, pix)) {
+                const float* rowp = g.src + pix * g.C;
                 if (g.a_vec) { if (c_col < g.C) dst[u] = *reinterpret_cast<const f32x4*>(rowp + c_col); }
                 else {
 #pragma unroll
@@ -551,8 +566,9 @@ hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s) {
 }
 
 // dW[n][c][tap] (OIHW, ld = Ct*taps) = sum_s slab[s][tap][n][c]
+struct TapMap { int real_taps; int map[16]; };  // real_taps = 0: identity (launch taps == tensor taps)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dW, int n_slices, int taps,
-                                    int N4, int Ct) {
+                                    int N4, int Ct, const TapMap tm) {
     const long long total = (long long)N4 * Ct * taps;
     const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -561,16 +577,30 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
     long long r = e / Ct;
     const int n = (int)(r % N4);
     const int tap = (int)(r / N4);
+    int real_taps = taps, dst_tap = tap;
+    if (tm.real_taps) { real_taps = tm.real_taps; dst_tap = tm.map[tap]; if (dst_tap < 0) return; }
     float acc = 0.f;
     const size_t slab_sz = (size_t)taps * N4 * Ct;
     for (int s = 0; s < n_slices; ++s) acc += slabs[(size_t)s * slab_sz + e];
-    dW[((size_t)n * Ct + c) * taps + tap] = acc;
+    dW[((size_t)n * Ct + c) * real_taps + dst_tap] = acc;
 }
 
 hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s) {
     const long long total = (long long)N4 * Ct * taps;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
-                       taps, N4, Ct);
+                       taps, N4, Ct, TapMap{});
+    return hipGetLastError();
+}
+
+hipError_t launch_wgrad_reduce_map(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int real_taps,
+                                   const int* tapmap, hipStream_t s) {
+    if (taps > 16) return hipErrorInvalidValue;
+    TapMap tm{};
+    tm.real_taps = real_taps;
+    for (int i = 0; i < taps; ++i) tm.map[i] = tapmap[i];
+    const long long total = (long long)N4 * Ct * taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
+                       taps, N4, Ct, tm);
     return hipGetLastError();
 }
 

@@ -203,9 +203,18 @@ struct WgradArgs {
     int n_ctiles;
     WgradCTile ct[16];
     float* slabs;             // [n_slices][taps][N4][Ct]
+    // generalisation for strided / transposed convolutions (conv_api.hip); all 0 = the stride-1 "same" case above
+    int a_sub;                // 1: the activation operand is the sub-image (gy*a_sy + a_oy, gx*a_sx + a_ox) of a larger image
+    int a_sy, a_sx, a_oy, a_ox;
+    int a_Hs, a_Ws;           // valid rows / columns of the sub-image
+    int a_Wfull;              // pixels per row of the full image (the batch stride is x_bstride)
+    int use_org, org_y, org_x;  // tap (0,0) reads activation pixel (y + org_y, x + org_x) instead of (y - kh/2, x - kw/2)
 };
 hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s);
+// same, but launch tap t lands at tap index tapmap[t] of a dW with real_taps taps per (row, channel); tapmap[t] < 0: dropped
+hipError_t launch_wgrad_reduce_map(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int real_taps,
+                                   const int* tapmap, hipStream_t s);
 
 // ---- ST-LSTM backward pointwise stages ----
 struct STBwdOutArgs {         // stage A: through h_new = o * tanh(lc)

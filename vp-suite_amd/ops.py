@@ -273,7 +273,8 @@ def conv2d_same(x, w, bias=None, precision="f32"):
     return _Conv2dSameFn.apply(x, w, bias, PRECISIONS[precision])
 
 
-GLUE_BACKWARD_NATIVE = False  #: True: the glue convolutions' backward avoids MIOpen (slow; for robustness experiments / tests)
+GLUE_BACKWARD_HIP = True       #: backward of the glue convolutions through vpx_conv2d_ex_bwd (False: ATen / MIOpen)
+GLUE_BACKWARD_NATIVE = False   #: ATen fallback only: avoid MIOpen (slow; for robustness experiments)
 
 
 class _ConvExFn(torch.autograd.Function):
@@ -292,7 +293,7 @@ class _ConvExFn(torch.autograd.Function):
             raise ValueError(f"conv2d_ex: weight {tuple(w.shape)} does not match {Ci} input channels")
         wc = w.contiguous()
         bc = None if bias is None else bias.contiguous()
-        d = ConvDesc(N, H, Wd, Ci, Co, kh, kw, int(stride), int(padding), int(bool(transposed)), float(slope), precision)
+        d = ConvDesc(N, H, Wd, Ci, Co, kh, kw, int(stride), int(padding), int(bool(transposed)), float(slope), precision, 0, 0)
         L = _lib.lib()
         ho, wo = ctypes.c_int(0), ctypes.c_int(0)
         check(L.vpx_conv2d_ex_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "vpx_conv2d_ex_out_shape")
@@ -303,6 +304,7 @@ class _ConvExFn(torch.autograd.Function):
               "vpx_conv2d_ex_fwd")
         ctx.save_for_backward(xs, wc, y)
         ctx.cfg = (int(stride), int(padding), bool(transposed), float(slope), bias is not None)
+        ctx.desc = d
         return y
 
     @staticmethod
@@ -313,10 +315,25 @@ class _ConvExFn(torch.autograd.Function):
         if slope != 0.0:  # LeakyReLU' from the sign of the output (same sign as the pre-activation for slope > 0)
             dy = dy * torch.where(y > 0, torch.ones((), device=y.device), torch.full((), slope, device=y.device))
         mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]]
+        d = ctx.desc
+        if GLUE_BACKWARD_HIP and d.kh >= d.stride and d.kw >= d.stride:
+            # library path: dx = the adjoint layer on the implicit-GEMM kernel, dw on the MFMA weight-gradient kernel
+            L = _lib.lib()
+            dyc = to_channels_last(dy)
+            ws_bytes = L.vpx_conv2d_ex_bwd_workspace_bytes(ctypes.byref(d))
+            if ws_bytes == 0:
+                check(-4 if b"not implemented" in L.vpx_last_error() else -1, "vpx_conv2d_ex_bwd_workspace_bytes")
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+            dx = new_channels_last(tuple(xs.shape), dy.device) if mask[0] else None
+            dw = torch.empty_like(wc) if mask[1] else None
+            check(L.vpx_conv2d_ex_bwd(ctypes.byref(d), ptr(xs), ptr(wc), ptr(dyc), ptr(dx), ptr(dw), ptr(ws), ws_bytes,
+                                      _stream()), "vpx_conv2d_ex_bwd")
+            db = dy.sum(dim=(0, 2, 3)) if mask[2] else None
+            return dx, dw, (db if has_bias else None), None, None, None, None, None
         bias_sizes = [int(wc.shape[1] if transposed else wc.shape[0])] if has_bias else None
-        # ATen's convolution backward = MIOpen NHWC kernels (2.5x faster per training step than ATen's native fallback).
-        # GLUE_BACKWARD_NATIVE routes it around MIOpen (tests with exotic shapes: MIOpen's solver search aborted the
-        # process in ~10 % of the runs of one such test on this image, inside miopen find, never on the models' shapes).
+        # fallback (kernel smaller than the stride): ATen's convolution backward = MIOpen NHWC kernels.
+        # GLUE_BACKWARD_NATIVE additionally routes it around MIOpen (MIOpen's solver search aborted the process in ~10 % of
+        # the runs of a test with exotic shapes on this image, inside miopen find).
         with torch.backends.cudnn.flags(enabled=not GLUE_BACKWARD_NATIVE):
             dx, dw, db = torch.ops.aten.convolution_backward(dy, xs, wc, bias_sizes, [stride, stride], [padding, padding],
                                                              [1, 1], transposed, [0, 0], 1, mask)
