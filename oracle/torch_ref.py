@@ -241,3 +241,79 @@ def phydnet_single_step_convlstm(sd, frames, actions, hidden_dims, action_condit
                                               sd[f"cell_list.{j}.conv.bias"])
         outs.append(H[-1])
     return outs, H, C
+
+
+def acstlstm_cell(x, h, c, m, a, p, layer_norm=False, forget_bias=1.0):
+    """Functional restatement of ActionConditionalSpatioTemporalLSTMCell.forward (vp_suite/model_blocks/predrnn.py:139-169):
+    six biased convolutions, conv_h(h) * conv_a(a) gating (:144), optional LayerNorm([C,H,W]) after conv_x/h/a/m/o."""
+    import torch
+    import torch.nn.functional as F
+    nh = c.shape[1]
+
+    def conv(name, t):
+        w = p[f"{name}.0.weight"]
+        y = F.conv2d(t, w, p[f"{name}.0.bias"], padding=w.shape[-1] // 2)
+        if layer_norm:
+            y = F.layer_norm(y, y.shape[1:], p[f"{name}.1.weight"], p[f"{name}.1.bias"])
+        return y
+    xc, hc, ac, mc = conv("conv_x", x), conv("conv_h", h), conv("conv_a", a), conv("conv_m", m)
+    i_x, f_x, g_x, i_xp, f_xp, g_xp, o_x = torch.split(xc, nh, dim=1)
+    i_h, f_h, g_h, o_h = torch.split(hc * ac, nh, dim=1)
+    i_m, f_m, g_m = torch.split(mc, nh, dim=1)
+    i_t, f_t, g_t = torch.sigmoid(i_x + i_h), torch.sigmoid(f_x + f_h + forget_bias), torch.tanh(g_x + g_h)
+    delta_c = i_t * g_t
+    c_new = f_t * c + delta_c
+    i_p, f_p, g_p = torch.sigmoid(i_xp + i_m), torch.sigmoid(f_xp + f_m + forget_bias), torch.tanh(g_xp + g_m)
+    delta_m = i_p * g_p
+    m_new = f_p * m + delta_m
+    mem = torch.cat((c_new, m_new), 1)
+    o_t = torch.sigmoid(o_x + o_h + conv("conv_o", mem))
+    h_new = o_t * torch.tanh(F.conv2d(mem, p["conv_last.weight"], p["conv_last.bias"]))
+    return h_new, c_new, m_new, delta_c, delta_m
+
+
+def trajgru_seq(inputs, states, seq_len, p, L, slope=0.2):
+    """Functional restatement of TrajGRU.forward (vp_suite/model_blocks/traj_gru.py:164-214; zoneout 0): i2h over all
+    frames, per step flow generation (:134-146), L bilinear warps of h (:148-162, default grid_sample alignment), 1x1 ret
+    conv and the GRU gate arithmetic (:190-203)."""
+    import torch
+    import torch.nn.functional as F
+    nf = p["ret.weight"].shape[0] // 3
+
+    def conv(name, t, pad):
+        return F.conv2d(t, p[name + ".weight"], p[name + ".bias"], padding=pad)
+    ref = inputs if inputs is not None else states
+    if states is None:
+        states = inputs.new_zeros(inputs.shape[0], nf, *inputs.shape[-2:])
+    H, W = states.shape[-2:]
+    if inputs is not None:
+        b, _, c, h, w = inputs.shape
+        i2h = conv("i2h", inputs[:, :seq_len].reshape(-1, c, h, w), 1).reshape(b, seq_len, 3 * nf, H, W)
+        i2h = torch.split(i2h, nf, dim=2)
+    else:
+        i2h = None
+    xx = torch.arange(W).view(1, 1, 1, W).expand(1, 1, H, W)
+    yy = torch.arange(H).view(1, 1, H, 1).expand(1, 1, H, W)
+    grid = torch.cat((xx, yy), 1).to(ref.dtype)
+    prev, outs = states, []
+    for t in range(seq_len):
+        f1 = conv("h2f_conv1", prev, 2)
+        if inputs is not None:
+            f1 = conv("i2f_conv1", inputs[:, t], 2) + f1
+        flows = torch.split(conv("flows_conv", F.leaky_relu(f1, slope), 2), 2, dim=1)
+        warped = []
+        for flow in flows:
+            vg = grid - flow
+            vx = 2.0 * vg[:, 0] / max(W - 1, 1) - 1.0
+            vy = 2.0 * vg[:, 1] / max(H - 1, 1) - 1.0
+            warped.append(F.grid_sample(prev, torch.stack((vx, vy), -1), align_corners=False))
+        h2h = torch.split(F.conv2d(torch.cat(warped, 1), p["ret.weight"], p["ret.bias"]), nf, dim=1)
+        if i2h is not None:
+            r = torch.sigmoid(i2h[0][:, t] + h2h[0]); u = torch.sigmoid(i2h[1][:, t] + h2h[1])
+            n = F.leaky_relu(i2h[2][:, t] + r * h2h[2], slope)
+        else:
+            r = torch.sigmoid(h2h[0]); u = torch.sigmoid(h2h[1])
+            n = F.leaky_relu(r * h2h[2], slope)
+        prev = u * prev + (1 - u) * n
+        outs.append(prev)
+    return torch.stack(outs, 1), prev

@@ -38,6 +38,28 @@ def test_workspace_queries_run_without_gpu(vpx):
     assert b"odd" in L.vpx_last_error()
 
 
+def test_conv_desc_layout_and_shape_calculus(vpx):
+    """The ctypes mirror of vpx_conv_desc matches the C struct (every field influences the C side's answer), and the
+    output-shape rules are those of nn.Conv2d / nn.ConvTranspose2d (ef_blocks.py:15-49 builds exactly these layers)."""
+    import torch
+    L = vpx._lib.lib()
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    for tr, k, s, p, op, H, W in ((0, 3, 2, 1, 0, 64, 64), (0, 3, 2, 1, 0, 17, 23), (1, 4, 2, 1, 0, 16, 16), (1, 3, 2, 1, 1, 9, 12),
+                                  (1, 3, 1, 1, 0, 8, 8), (0, 1, 1, 0, 0, 5, 7)):
+        d = vpx._lib.ConvDesc(2, H, W, 6, 5, k, k, s, p, tr, 0.2, 0, op, op)
+        assert L.vpx_conv2d_ex_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == 0
+        layer = (torch.nn.ConvTranspose2d(6, 5, k, s, p, output_padding=op) if tr else torch.nn.Conv2d(6, 5, k, s, p))
+        ref = layer(torch.zeros(1, 6, H, W)).shape
+        assert (ho.value, wo.value) == (ref[2], ref[3]), (tr, k, s, p, op)
+        assert L.vpx_conv2d_ex_workspace_bytes(ctypes.byref(d)) > 0
+        assert L.vpx_conv2d_ex_bwd_workspace_bytes(ctypes.byref(d)) > 0
+    bad = vpx._lib.ConvDesc(2, 8, 8, 6, 5, 3, 3, 2, 1, 1, 0.0, 0, 2, 0)   # output padding must stay below the stride
+    assert L.vpx_conv2d_ex_out_shape(ctypes.byref(bad), ctypes.byref(ho), ctypes.byref(wo)) != 0
+    assert b"output padding" in L.vpx_last_error()
+    bad = vpx._lib.ConvDesc(2, 8, 8, 6, 5, 3, 3, 3, 1, 0, 0.0, 0, 0, 0)   # stride 3 is not implemented
+    assert L.vpx_conv2d_ex_workspace_bytes(ctypes.byref(bad)) == 0
+
+
 def test_no_cpu_fallback(vpx):
     """The product path must fail loudly on CPU tensors instead of silently computing on the host."""
     from vp_suite_amd.model_blocks import ConvLSTM

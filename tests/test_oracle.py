@@ -223,3 +223,36 @@ def test_torch_ref_phydnet_single_step_convlstm(tag):
         assert (outs[t] - torch.from_numpy(g[f"out{t}"])).abs().max() < 1e-6
     for j in range(nl):
         assert (C[j] - torch.from_numpy(g[f"C{j}"])).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["plain", "ln"])
+def test_torch_ref_action_conditional_stlstm(tag):
+    """oracle restatement of the action-conditional ST-LSTM cell against the reference-generated fixture."""
+    import torch
+    import golden_cases as gc
+    from golden_util import load_golden, name_seed, seeded_state_dict
+    from oracle.torch_ref import acstlstm_cell
+    Cin, Ch, H, W, k, ln, B = gc.ACSTLSTM_CASES[tag]
+    g = load_golden(f"acstlstm_{tag}")
+    sd = seeded_state_dict(g, name_seed("acstlstm." + tag))
+    inp = gc.acstlstm_inputs(tag, Cin, Ch, H, W, B)
+    outs = acstlstm_cell(inp["x"], inp["h"], inp["c"], inp["m"], inp["a"], sd, layer_norm=ln)
+    for o, n in zip(outs, ("h_new", "c_new", "m_new", "delta_c", "delta_m")):
+        assert (o - torch.from_numpy(g[n])).abs().max() < 2e-6, n
+
+
+@pytest.mark.parametrize("tag", ["full", "noinput"])
+def test_torch_ref_trajgru(tag):
+    """oracle restatement of the TrajGRU block against the reference-generated fixture."""
+    import torch
+    import golden_cases as gc
+    from golden_util import load_golden, name_seed, seeded_rand, seeded_randn, seeded_state_dict
+    from oracle.torch_ref import trajgru_seq
+    in_c, enc_c, H, W, L, B, T, mode = gc.TRAJGRU_CASES[tag]
+    g = load_golden(f"trajgru_{tag}")
+    sd = seeded_state_dict(g, name_seed("trajgru." + tag))
+    x = seeded_rand((B, T, in_c, H, W), name_seed(f"trajgru.{tag}.x"))
+    h0 = seeded_randn((B, enc_c, H, W), name_seed(f"trajgru.{tag}.h0"), 0.5)
+    out, hT = trajgru_seq(x, None, T, sd, L) if mode == "full" else trajgru_seq(None, h0, T, sd, L)
+    assert (out - torch.from_numpy(g["out"])).abs().max() < 2e-6
+    assert (hT - torch.from_numpy(g["hT"])).abs().max() < 2e-6
