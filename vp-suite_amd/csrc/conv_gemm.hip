@@ -628,13 +628,13 @@ __global__ __launch_bounds__(NTHREADS * MW, (MS == 2 ? 2 : (MW >= 2 ? 4 : 3))) v
 
 // Two independent contractions over the same pixel tiling in ONE launch (blockIdx.y < nA -> A, else B): the ST-LSTM's
 // c-group and m-group each fill only one workgroup per CU on 16x16 maps; together they give every CU two.
-template <class EpiA, class EpiB, int MODE>
-__global__ __launch_bounds__(NTHREADS, 3) void conv_gemm_dual_kernel(const ConvPlan PA, const EpiA epiA, const int nA,
-                                                                    const ConvPlan PB, const EpiB epiB) {
+template <class EpiA, class EpiB, int MODE, int MW>
+__global__ __launch_bounds__(NTHREADS * MW, (MW == 2 ? 4 : 3)) void conv_gemm_dual_kernel(const ConvPlan PA, const EpiA epiA, const int nA,
+                                                                                          const ConvPlan PB, const EpiB epiB) {
     int m_tile, n_tile;
     if (!xcd_tile(PA, blockIdx.x, gridDim.y, m_tile, n_tile)) return;
-    if (n_tile < nA) conv_body<EpiA, MODE, 1>(PA, epiA, n_tile, m_tile);
-    else conv_body<EpiB, MODE, 1>(PB, epiB, n_tile - nA, m_tile);
+    if (n_tile < nA) conv_body<EpiA, MODE, MW>(PA, epiA, n_tile, m_tile);
+    else conv_body<EpiB, MODE, MW>(PB, epiB, n_tile - nA, m_tile);
 }
 
 static bool xcd_map_enabled() {  // VPX_XCD_MAP=0 restores the plain 2-D grid (experiments)
@@ -748,7 +748,7 @@ hipError_t launch_st_mgroup_f32(const ConvPlan& plan, const STGateArgs& ea, int 
     EpiSTGate<3> e{ea};
     return launch_conv(plan, e, n_tiles, s);
 }
-template <int MODE>
+template <int MODE, int MW>
 static hipError_t launch_st_dual_m(const ConvPlan& pc, const STGateArgs& ec, const ConvPlan& pm, const STGateArgs& em,
                                    int n_tiles, hipStream_t s) {
     using KA = EpiSTGate<4>;
@@ -759,7 +759,7 @@ static hipError_t launch_st_dual_m(const ConvPlan& pc, const STGateArgs& ec, con
     const size_t lds = lc > lm ? lc : lm;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dual_kernel<KA, KB, MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dual_kernel<KA, KB, MODE, MW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -771,16 +771,18 @@ static hipError_t launch_st_dual_m(const ConvPlan& pc, const STGateArgs& ec, con
     (void)&xcd_map_enabled;
     const long long per_xcd = ((long long)pc2.grid_m * 2 * n_tiles + 7) / 8;
     dim3 grid = pc2.grid_n ? dim3((unsigned)(per_xcd * 8), 1) : dim3(pc2.grid_m, 2 * n_tiles);
-    hipLaunchKernelGGL((conv_gemm_dual_kernel<KA, KB, MODE>), grid, dim3(NTHREADS), lds, s, pc2, KA{ec}, n_tiles, pm, KB{em});
+    hipLaunchKernelGGL((conv_gemm_dual_kernel<KA, KB, MODE, MW>), grid, dim3(NTHREADS * MW), lds, s, pc2, KA{ec}, n_tiles, pm, KB{em});
     return hipGetLastError();
 }
 
 hipError_t launch_st_gates_dual(const ConvPlan& pc, const STGateArgs& ec, const ConvPlan& pm, const STGateArgs& em,
                                 int n_tiles, hipStream_t s) {
     if (pc.prec != pm.prec) return hipErrorInvalidValue;
-    if (pc.prec == VPX_PREC_F32) return launch_st_dual_m<0>(pc, ec, pm, em, n_tiles, s);
-    if (pc.prec == VPX_PREC_BF16X3) return launch_st_dual_m<1>(pc, ec, pm, em, n_tiles, s);
-    if (pc.prec == VPX_PREC_BF16) return launch_st_dual_m<2>(pc, ec, pm, em, n_tiles, s);
+    const bool mw2 = pc.mw == 2 && pm.mw == 2;
+    if ((pc.H + TILE_H * (mw2 ? 2 : 1) - 1) / (TILE_H * (mw2 ? 2 : 1)) != pc.tiles_y) return hipErrorInvalidValue;
+    if (pc.prec == VPX_PREC_F32) return launch_st_dual_m<0, 1>(pc, ec, pm, em, n_tiles, s);
+    if (pc.prec == VPX_PREC_BF16X3) return mw2 ? launch_st_dual_m<1, 2>(pc, ec, pm, em, n_tiles, s) : launch_st_dual_m<1, 1>(pc, ec, pm, em, n_tiles, s);
+    if (pc.prec == VPX_PREC_BF16) return mw2 ? launch_st_dual_m<2, 2>(pc, ec, pm, em, n_tiles, s) : launch_st_dual_m<2, 1>(pc, ec, pm, em, n_tiles, s);
     return hipErrorInvalidValue;
 }
 

@@ -13,6 +13,7 @@ namespace {
 
 struct STLayout {
     int taps, tiles32, tiles128, ng_l, ksplit_l;
+    int mw_g;                     // workgroup form of the dual gate launch (2: 8 waves, 16x16 pixels)
     int o_split, o_ng, o_tiles;   // conv_o as a K-split plain conv accumulating into o_pre (small maps) instead of the fused launch
     int nstage_g, chunks_g;            // gate groups: segments (x: Cin, recurrent: Ch), k x k
     ConvStage stage_g[MAX_STAGE];
@@ -40,7 +41,8 @@ int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
     L.tiles128 = plain_tiles_ng(d->Ch, L.ng_l);
     const int segG[2] = {d->Cin, d->Ch};
     const int segO[2] = {d->Ch, d->Ch};
-    L.nstage_g = build_stages(L.stage_g, &L.chunks_g, segG, 2, L.taps, pick_stage_channels(segG, 2, d->k, d->k, 4, d->precision), d->precision);
+    L.mw_g = d->layer_norm ? 1 : pick_mw(d->B, d->H, d->W, 2 * L.tiles32, d->precision);
+    L.nstage_g = build_stages(L.stage_g, &L.chunks_g, segG, 2, L.taps, pick_stage_channels(segG, 2, d->k, d->k, 4, d->precision, L.mw_g), d->precision);
     const long long m_tiles = (long long)d->B * ((d->H + TILE_H - 1) / TILE_H) * ((d->W + TILE_W - 1) / TILE_W);
     // conv_o: fused with the output gate (32 channels per workgroup) when that fills the chip; on small maps a 128-wide
     // K-split plain convolution adds conv_o(mem) into o_pre and a pointwise kernel applies the gate
@@ -214,11 +216,12 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
     // ---- launch 1: c group ----
     {
         ConvPlan P = base_plan(d, k);
+        set_plan_tiles(P, L.mw_g);
         P.nseg = 2;
         P.seg[0] = ConvSeg{xn, (long long)(HW * Cin), Cin, 0};
         P.seg[1] = ConvSeg{hn, (long long)(HW * Ch), Ch, 0};
         P.nstage = L.nstage_g; memcpy(P.stage, L.stage_g, sizeof(ConvStage) * L.nstage_g);
-        P.chunks_total = L.chunks_g; P.a_bytes = conv_a_bytes(L.stage_g, L.nstage_g, k, k); P.wpk = wpk_c;
+        P.chunks_total = L.chunks_g; P.a_bytes = conv_a_bytes(L.stage_g, L.nstage_g, k, k, L.mw_g); P.wpk = wpk_c;
         STGateArgs ea{Ch, 1.0f, cn, cO, dcO, o_pre, gates_c};
         // ---- launch 2 (merged with 1): m group — the two groups are independent and run as ONE dual launch ----
         ConvPlan Pm = P;
