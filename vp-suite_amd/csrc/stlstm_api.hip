@@ -13,7 +13,7 @@ namespace {
 
 struct STLayout {
     int taps, tiles32, tiles128, ng_l, ksplit_l;
-    int mw_g;                     // workgroup form of the dual gate launch (2: 8 waves, 16x16 pixels)
+    int mw_g, mw_o;               // workgroup form of the dual gate launch / the conv_o launch (2: 8 waves, 16x16 pixels)
     int o_split, o_ng, o_tiles;   // conv_o as a K-split plain conv accumulating into o_pre (small maps) instead of the fused launch
     int nstage_g, chunks_g;            // gate groups: segments (x: Cin, recurrent: Ch), k x k
     ConvStage stage_g[MAX_STAGE];
@@ -55,7 +55,8 @@ int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
         const int ks = ns > 0 ? pick_ksplit(m_tiles * plain_tiles_ng(d->Ch, ng), ns) : 1;
         if (ks > 1) { L.o_split = ks; L.o_ng = ng; L.o_tiles = plain_tiles_ng(d->Ch, ng); }
     }
-    L.nstage_o = build_stages(L.stage_o, &L.chunks_o, segO, 2, L.taps, pick_stage_channels(segO, 2, d->k, d->k, L.o_ng, d->precision), d->precision);
+    L.mw_o = d->layer_norm ? 1 : pick_mw(d->B, d->H, d->W, L.o_tiles, d->precision);
+    L.nstage_o = build_stages(L.stage_o, &L.chunks_o, segO, 2, L.taps, pick_stage_channels(segO, 2, d->k, d->k, L.o_ng, d->precision, L.mw_o), d->precision);
     L.nstage_l = build_stages(L.stage_l, &L.chunks_l, segO, 2, 1, pick_stage_channels(segO, 2, 1, 1, L.ng_l, d->precision), d->precision);
     if (L.nstage_g < 0 || L.nstage_o < 0 || L.nstage_l < 0) { set_error("stlstm: too many channel stages"); return VPX_ERR_UNSUPPORTED; }
     L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
@@ -247,11 +248,12 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
     // ---- launch 4: conv_o(mem) + output gate ----
     {
         ConvPlan P = base_plan(d, k);
+        set_plan_tiles(P, L.mw_o);
         P.nseg = 2;
         P.seg[0] = ConvSeg{cO, (long long)(HW * Ch), Ch, 0};
         P.seg[1] = ConvSeg{mO, (long long)(HW * Ch), Ch, 0};
         P.nstage = L.nstage_o; memcpy(P.stage, L.stage_o, sizeof(ConvStage) * L.nstage_o);
-        P.chunks_total = L.chunks_o; P.a_bytes = conv_a_bytes(L.stage_o, L.nstage_o, k, k); P.wpk = wpk_o;
+        P.chunks_total = L.chunks_o; P.a_bytes = conv_a_bytes(L.stage_o, L.nstage_o, k, k, L.mw_o); P.wpk = wpk_o;
         if (L.o_split > 1) {
             PlainEpiArgs pa{};
             pa.Co = Ch; pa.split = Ch; pa.out0 = o_pre; pa.bstride0 = (long long)(HW * Ch); pa.ld0 = Ch; pa.ng = L.o_ng;

@@ -17,7 +17,7 @@ struct STBwdLayout {
     int taps, Ch, Cin;
     size_t n_state, n_x, n_g7;
     // dgrad plans: stage tables + chunk counts + N tiles
-    struct DG { int nstage, chunks, tiles, ng, ksplit; ConvStage stage[MAX_STAGE]; size_t wpk; } o, l, x, h, m;
+    struct DG { int nstage, chunks, tiles, ng, ksplit, mw; ConvStage stage[MAX_STAGE]; size_t wpk; } o, l, x, h, m;
     int n_slices;
     size_t slab_floats;
 };
@@ -25,7 +25,8 @@ struct STBwdLayout {
 int mk_dg(STBwdLayout::DG& g, const int* segC, int nseg, int k, int n_out, int prec, long long m_tiles) {
     const int taps = k * k;
     g.ng = plain_groups(n_out, m_tiles);
-    g.nstage = build_stages(g.stage, &g.chunks, segC, nseg, taps, pick_stage_channels(segC, nseg, k, k, g.ng, prec), prec);
+    g.mw = pick_mw_tiles(m_tiles, plain_tiles_ng(n_out, g.ng), prec);  // 8-wave form when the grid stays large
+    g.nstage = build_stages(g.stage, &g.chunks, segC, nseg, taps, pick_stage_channels(segC, nseg, k, k, g.ng, prec, g.mw), prec);
     if (g.nstage < 0) return -1;
     g.tiles = plain_tiles_ng(n_out, g.ng);
     g.ksplit = pick_ksplit(m_tiles * g.tiles, g.nstage);  // 16x16 maps: 64 pixel tiles per launch, K = gates*Ch*k*k is long
@@ -188,9 +189,9 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         ConvPlan P{};
         P.prec = d->precision;
         P.B = B; P.H = H; P.W = Wd; P.kh = kk; P.kw = kk;
-        P.tiles_x = (Wd + TILE_W - 1) / TILE_W; P.tiles_y = (H + TILE_H - 1) / TILE_H;
+        set_plan_tiles(P, g.mw);
         P.nstage = g.nstage; memcpy(P.stage, g.stage, sizeof(ConvStage) * g.nstage);
-        P.chunks_total = g.chunks; P.a_bytes = conv_a_bytes(g.stage, g.nstage, kk, kk); P.wpk = wpk;
+        P.chunks_total = g.chunks; P.a_bytes = conv_a_bytes(g.stage, g.nstage, kk, kk, g.mw); P.wpk = wpk;
         return P;
     };
     auto pack_plain_T = [&](PackDesc& pd, const STBwdLayout::DG& g, int taps, int n_out) {

@@ -90,6 +90,8 @@ int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw = 1, in
 // rows per wave: 2 (16x16 workgroup tile) when the operand mode profits (bf16x3 is LDS/issue-bound, not MFMA-bound) and
 // the launch still has >= 2 workgroups per CU; else 1
 int pick_mw(int B, int H, int W, int n_tiles, int prec);
+// same rule from the number of 8x16 pixel tiles of the launch (the 8-wave form halves it)
+inline int pick_mw_tiles(long long m_tiles, int n_tiles, int prec) { return (prec != 0 /* VPX_PREC_F32 */ && m_tiles / 2 * n_tiles >= 512) ? 2 : 1; }
 inline void set_plan_tiles(ConvPlan& P, int mw) { P.mw = mw; P.tiles_x = (P.W + TILE_W - 1) / TILE_W; P.tiles_y = (P.H + TILE_H * mw - 1) / (TILE_H * mw); }
 size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng, int prec);
 
