@@ -35,14 +35,16 @@ __device__ __forceinline__ void split_bf16(float v, unsigned short& hi, unsigned
 }
 
 __host__ __device__ inline int mode_kstep(int prec) { return prec == VPX_PREC_F32 ? 8 : 16; }  // bf16x3 and bf16 share one layout   // channels per k-step
-__host__ __device__ inline int mode_kc(int prec) { return prec == VPX_PREC_F32 ? 16 : 32; }     // k-depth of a weight chunk
+// k-depth of a weight chunk = qpc k-steps (2 by default; 3 for 3x3 kernels in the bf16 modes: 9 k-steps per 16-channel stage
+// are then exactly 3 chunks instead of 4.5 -> 5 with a half-empty last one)
+__host__ __device__ inline int mode_kc(int prec, int qpc = 2) { return mode_kstep(prec) * (qpc == 3 ? 3 : 2); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // weight repack: reference OIHW -> [n_tile][chunk][n = g*32+j, g < NG][kk]  (kk = position inside the KC-deep chunk)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void pack_weights_kernel(const PackDesc pd, char* __restrict__ dst) {
     const int ntr = pd.NG * 32;                       // rows per chunk
-    const int kc = mode_kc(pd.prec);                  // k-depth of a chunk
+    const int kc = mode_kc(pd.prec, pd.qpc);          // k-depth of a chunk
     const int row_bytes = kc * 4;                     // fp32: kc floats; bf16x3: kc hi-bf16 then kc lo-bf16
     const long long total = (long long)pd.n_tiles * pd.chunks_total * ntr * kc;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
@@ -87,7 +89,7 @@ __global__ void pack_weights_kernel(const PackDesc pd, char* __restrict__ dst) {
 }
 
 hipError_t launch_pack_weights(const PackDesc& pd, float* dst, hipStream_t s) {
-    const long long total = (long long)pd.n_tiles * pd.chunks_total * pd.NG * 32 * mode_kc(pd.prec);
+    const long long total = (long long)pd.n_tiles * pd.chunks_total * pd.NG * 32 * mode_kc(pd.prec, pd.qpc);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
@@ -114,6 +116,7 @@ __device__ __forceinline__ bool tile_pixel(const TileCtx& t, int r, int& y, int&
 struct EpiConvLSTM {
     static constexpr int NG = 4;
     static constexpr bool SPLITK = false;
+    static constexpr bool Q3OK = true;
     ConvLSTMStepArgs a;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[4], const TileCtx& t) const {
         const int ch = t.n_tile * 32 + t.j;
@@ -181,6 +184,7 @@ template <int NGROUPS>
 struct EpiSTGate {
     static constexpr int NG = NGROUPS;
     static constexpr bool SPLITK = false;
+    static constexpr bool Q3OK = false;
     STGateArgs a;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[NGROUPS], const TileCtx& t) const {
         const int ch = t.n_tile * 32 + t.j;
@@ -213,6 +217,7 @@ struct EpiSTGate {
 struct EpiSTOut {
     static constexpr int NG = 1;
     static constexpr bool SPLITK = false;
+    static constexpr bool Q3OK = false;
     STOutArgs a;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[1], const TileCtx& t) const {
         const int ch = t.n_tile * 32 + t.j;
@@ -235,6 +240,7 @@ template <int NGP>
 struct EpiPlain {
     static constexpr int NG = NGP;
     static constexpr bool SPLITK = true;
+    static constexpr bool Q3OK = true;
     PlainEpiArgs a;
     __device__ __forceinline__ void operator()(const f32x16 (&acc)[NGP], const TileCtx& t) const {
 #pragma unroll
@@ -297,18 +303,19 @@ __device__ __forceinline__ void stage_store(char* dst, int lo_off, const f32x4 v
 #define DBGBIT(b) false
 #endif
 
-template <int MODE> struct ModeTraits;
-template <> struct ModeTraits<0> { static constexpr int KSTEP = 8, KC = 16, WROW_DATA = 16 * 4; };
-template <> struct ModeTraits<1> { static constexpr int KSTEP = 16, KC = 32, WROW_DATA = 32 * 4; };
-template <> struct ModeTraits<2> { static constexpr int KSTEP = 16, KC = 32, WROW_DATA = 32 * 4; };  // plain bf16: hi planes only are read
+template <int MODE, int QPCN = 2> struct ModeTraits {  // QPCN = k-steps per weight chunk (2 or 3)
+    static constexpr int KSTEP = MODE == 0 ? 8 : 16;   // plain bf16 (MODE 2) shares the bf16x3 layout, only hi planes are read
+    static constexpr int KC = KSTEP * QPCN;
+    static constexpr int WROW_DATA = KC * 4;           // fp32: KC floats; bf16 modes: KC hi-bf16 then KC lo-bf16
+};
 
 // MW = 1: 4 waves (256 threads) per workgroup, 8x16 pixel tile. MW = 2: 8 waves (512 threads), 16x16 tile — twice the
 // pixels share every weight chunk (the L2->CU load pipe, ~70 GB/s per CU, is what limits the bf16 modes), at <= 128
 // registers so that two such workgroups (16 waves) stay resident per CU.
-template <class Epi, int MODE, int MW, int MS = 1>
+template <class Epi, int MODE, int MW, int MS = 1, int QPCN = 2>
 __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, const int n_tile, const int m_tile) {
     constexpr int NTH = NTHREADS * MW;
-    using MT = ModeTraits<MODE>;
+    using MT = ModeTraits<MODE, QPCN>;
     constexpr int KC = MT::KC, KSTEP = MT::KSTEP;
     constexpr int WROW = MT::WROW_DATA + 16;   // padded LDS row of one output channel's chunk slice (odd multiple of 16 B)
     constexpr int QPC = KC / KSTEP;            // k-steps per chunk (2 in both modes)
@@ -619,11 +626,11 @@ __device__ __forceinline__ bool xcd_tile(const ConvPlan& P, unsigned L, unsigned
     return true;
 }
 
-template <class Epi, int MODE, int MW, int MS = 1>
+template <class Epi, int MODE, int MW, int MS = 1, int QPCN = 2>
 __global__ __launch_bounds__(NTHREADS * MW, (MS == 2 ? 2 : (MW >= 2 ? 4 : 3))) void conv_gemm_kernel(const ConvPlan P, const Epi epi) {
     int m_tile, n_tile;
     if (!xcd_tile(P, blockIdx.x, gridDim.y, m_tile, n_tile)) return;
-    conv_body<Epi, MODE, MW, MS>(P, epi, n_tile, m_tile);
+    conv_body<Epi, MODE, MW, MS, QPCN>(P, epi, n_tile, m_tile);
 }
 
 // Two independent contractions over the same pixel tiling in ONE launch (blockIdx.y < nA -> A, else B): the ST-LSTM's
@@ -643,12 +650,12 @@ static bool xcd_map_enabled() {  // VPX_XCD_MAP=0 restores the plain 2-D grid (e
     return on != 0;
 }
 
-template <class Epi, int MODE, int MW, int MS = 1>
+template <class Epi, int MODE, int MW, int MS = 1, int QPCN = 2>
 static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tiles, hipStream_t s) {
-    const size_t lds = (size_t)plan.a_bytes + 2 * (Epi::NG * 32 * (ModeTraits<MODE>::WROW_DATA + 16));
+    const size_t lds = (size_t)plan.a_bytes + 2 * (Epi::NG * 32 * (ModeTraits<MODE, QPCN>::WROW_DATA + 16));
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<Epi, MODE, MW, MS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<Epi, MODE, MW, MS, QPCN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -660,7 +667,7 @@ static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tile
     const long long per_xcd = ((long long)p2.grid_m * n_tiles + 7) / 8;
     dim3 grid = p2.grid_n ? dim3((unsigned)(per_xcd * 8), 1, plan.ksplit > 1 ? plan.ksplit : 1)
                           : dim3(p2.grid_m, n_tiles, plan.ksplit > 1 ? plan.ksplit : 1);
-    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE, MW, MS>), grid, dim3(NTHREADS * MW), lds, s, p2, epi);
+    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE, MW, MS, QPCN>), grid, dim3(NTHREADS * MW), lds, s, p2, epi);
     return hipGetLastError();
 }
 
@@ -673,15 +680,27 @@ static hipError_t launch_conv(const ConvPlan& plan_in, const Epi& epi, int n_til
     if (!Epi::SPLITK) plan.ksplit = 0;  // only the plain epilogue can combine partial sums
     const int mw = plan.mw >= 4 ? 4 : (plan.mw > 1 ? 2 : 1);
     if ((plan.H + TILE_H * mw - 1) / (TILE_H * mw) != plan.tiles_y) return hipErrorInvalidValue;  // host geometry mismatch
-    if (plan.prec == VPX_PREC_F32) return launch_conv_m<Epi, 0, 1>(plan, epi, n_tiles, s);  // fp32 is MFMA-bound: MW=1 only
+    if (plan.prec == VPX_PREC_F32) return plan.qpc == 3 ? hipErrorInvalidValue : launch_conv_m<Epi, 0, 1>(plan, epi, n_tiles, s);  // fp32 is MFMA-bound: MW=1 only
     if (plan.prec == VPX_PREC_BF16X3) {
         static int ms = -1;  // 16x16 tile as 4 waves x 2 sub-tiles (VPX_MS=2) instead of 8 waves x 1
         if (ms < 0) { const char* e = getenv("VPX_MS"); ms = e ? atoi(e) : 1; }
+        if constexpr (Epi::Q3OK) {  // 3 k-steps per weight chunk (ConvLSTM cell and its data gradient on 3x3 kernels)
+            if (plan.qpc == 3 && mw <= 2 && ms != 2)
+                return mw == 2 ? launch_conv_m<Epi, 1, 2, 1, 3>(plan, epi, n_tiles, s) : launch_conv_m<Epi, 1, 1, 1, 3>(plan, epi, n_tiles, s);
+        }
+        if (plan.qpc == 3) return hipErrorInvalidValue;  // the weights were packed for a form that is not instantiated
         if (mw == 4) return launch_conv_m<Epi, 1, 4>(plan, epi, n_tiles, s);
         if (mw == 2 && ms == 2) return launch_conv_m<Epi, 1, 1, 2>(plan, epi, n_tiles, s);
         return mw == 2 ? launch_conv_m<Epi, 1, 2>(plan, epi, n_tiles, s) : launch_conv_m<Epi, 1, 1>(plan, epi, n_tiles, s);
     }
-    if (plan.prec == VPX_PREC_BF16) return mw == 2 ? launch_conv_m<Epi, 2, 2>(plan, epi, n_tiles, s) : launch_conv_m<Epi, 2, 1>(plan, epi, n_tiles, s);
+    if (plan.prec == VPX_PREC_BF16) {
+        if constexpr (Epi::Q3OK) {
+            if (plan.qpc == 3 && mw <= 2)
+                return mw == 2 ? launch_conv_m<Epi, 2, 2, 1, 3>(plan, epi, n_tiles, s) : launch_conv_m<Epi, 2, 1, 1, 3>(plan, epi, n_tiles, s);
+        }
+        if (plan.qpc == 3) return hipErrorInvalidValue;
+        return mw == 2 ? launch_conv_m<Epi, 2, 2>(plan, epi, n_tiles, s) : launch_conv_m<Epi, 2, 1>(plan, epi, n_tiles, s);
+    }
     return hipErrorInvalidValue;
 }
 
@@ -794,8 +813,8 @@ hipError_t launch_st_out_f32(const ConvPlan& plan, const STOutArgs& ea, int n_ti
 // ---------------------------------------------------------------------------------------------------------------
 // host-side plan helpers
 // ---------------------------------------------------------------------------------------------------------------
-int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int prec) {
-    const int kstep = mode_kstep(prec), qpc = mode_kc(prec) / kstep;
+int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int prec, int qpc_in) {
+    const int kstep = mode_kstep(prec), qpc = (qpc_in == 3 && prec != VPX_PREC_F32) ? 3 : 2;
     if (cs % kstep) cs = (cs + kstep - 1) / kstep * kstep;
     int n = 0, chunk = 0;
     for (int sgi = 0; sgi < nseg; ++sgi) {
@@ -830,7 +849,7 @@ int pick_mw(int B, int H, int W, int n_tiles, int prec) {
     return wgs2 >= 512 ? 2 : 1;
 }
 
-int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw, int stride) {
+int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw, int stride, int qpc) {
     static int forced = -1;
     if (forced < 0) {
         const char* e = getenv("VPX_CS");
@@ -840,7 +859,7 @@ int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int p
     const int kstep = mode_kstep(prec);
     if (forced) return forced < kstep ? kstep : forced;
     const int npos = ((TILE_H * mw - 1) * stride + kh) * ((TILE_W - 1) * stride + kw);
-    const int wbytes = 2 * ng * 32 * (mode_kc(prec) * 4 + 16);
+    const int wbytes = 2 * ng * 32 * (mode_kc(prec, qpc) * 4 + 16);
     const int wg_cap = mw == 4 ? 1 : (mw == 2 ? 2 : 3);  // residency: 2 x 8 waves or 3 x 4 waves per CU (register budgets 128 / 168)
     int best = CS_MAX, best_wg = 0;
     for (int cs = kstep; cs <= CS_MAX; cs *= 2) {
@@ -864,8 +883,8 @@ int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw, int st
     return (m + 15) / 16 * 16;
 }
 
-size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng, int prec) {
-    return (size_t)n_tiles * chunks_total * ng * 32 * mode_kc(prec) * sizeof(float);
+size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng, int prec, int qpc) {
+    return (size_t)n_tiles * chunks_total * ng * 32 * mode_kc(prec, qpc) * sizeof(float);
 }
 
 }  // namespace vpx

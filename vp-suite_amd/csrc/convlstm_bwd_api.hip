@@ -34,7 +34,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     const size_t HW = (size_t)H * Wd;
     Carver ws{(char*)workspace, 0, workspace_bytes};
     ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
-    float* wpk = ws.take(packed_weight_bytes(L.d_tiles_full, L.d_chunks, 4, d->precision) / sizeof(float));
+    float* wpk = ws.take(packed_weight_bytes(L.d_tiles_full, L.d_chunks, 4, d->precision, L.d_qpc) / sizeof(float));
     float* dG_all = ws.take((size_t)T * L.n_state * 4);
     float* dh_buf = ws.take(L.n_state);
     float* dc_buf = ws.take(L.n_state);
@@ -94,7 +94,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         PackDesc pd{};
         pd.seg[0] = PackSeg{W, (long long)Ct * L.taps, L.taps, 0, N4};
         memcpy(pd.stage, L.d_stage, sizeof(ConvStage) * L.d_nstage);
-        pd.nstage = L.d_nstage; pd.chunks_total = L.d_chunks; pd.prec = d->precision; pd.taps = L.taps;
+        pd.nstage = L.d_nstage; pd.chunks_total = L.d_chunks; pd.prec = d->precision; pd.taps = L.taps; pd.qpc = L.d_qpc;
         fill_plain_pack(pd, n_out, col_start);
         pd.transposed = 1; pd.flip = 1;
         VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
@@ -127,7 +127,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
             P.seg[0] = ConvSeg{ga.dG, (long long)(HW * N4), N4, 0};
             P.nstage = L.d_nstage;
             memcpy(P.stage, L.d_stage, sizeof(ConvStage) * L.d_nstage);
-            P.chunks_total = L.d_chunks; P.prec = d->precision;
+            P.chunks_total = L.d_chunks; P.prec = d->precision; P.qpc = L.d_qpc;
             P.a_bytes = conv_a_bytes(L.d_stage, L.d_nstage, d->kh, d->kw, L.d_mw);
             P.wpk = wpk;
             PlainEpiArgs ea{};

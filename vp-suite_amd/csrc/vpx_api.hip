@@ -51,7 +51,7 @@ size_t vpx_convlstm_reserve_bytes(const vpx_convlstm_desc* d) {
 
 static size_t convlstm_wpk_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
     return L.split ? packed_weight_bytes(L.s_tiles, L.s_chunks, L.s_ng, d->precision)
-                   : packed_weight_bytes(L.n_tiles, L.chunks_total, 4, d->precision);
+                   : packed_weight_bytes(L.n_tiles, L.chunks_total, 4, d->precision, L.qpc);
 }
 
 size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
@@ -144,6 +144,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         memcpy(pd.stage, L.stage, sizeof(ConvStage) * L.nstage);
         pd.nstage = L.nstage;
         pd.chunks_total = L.chunks_total;
+        pd.qpc = L.qpc;
         pd.n_tiles = L.n_tiles;
         pd.NG = 4;
         for (int g = 0; g < 4; ++g) { pd.rowbase[0][g] = pd.rowbase[1][g] = gp[g] * Ch; pd.goff[g] = 0; }
@@ -177,6 +178,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             if (src) P.stage[P.nstage++] = stages[s];  // absent source == all-zero operand: its K range is skipped
         }
         P.chunks_total = L.split ? L.s_chunks : L.chunks_total; P.prec = d->precision;
+        P.qpc = L.split ? 0 : L.qpc;
         P.a_bytes = conv_a_bytes(stages, nstages, d->kh, d->kw, L.split ? 1 : L.mw);
         P.wpk = wpk;
 

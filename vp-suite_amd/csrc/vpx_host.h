@@ -61,9 +61,29 @@ static inline int check_convlstm_desc(const vpx_convlstm_desc* d) {
     return VPX_OK;
 }
 
+// Three k-steps per weight chunk when that removes the half-empty chunk at the end of every stage (the tap count is a
+// multiple of 3, e.g. 3x3: 9 k-steps per 16-channel stage = 3 chunks instead of 5) and the larger weight buffers do not
+// lower the number of resident workgroups. bf16 modes only. VPX_QPC=2/3 forces it.
+static inline int pick_qpc(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("VPX_QPC"); forced = e ? atoi(e) : 0; }
+    if (prec == VPX_PREC_F32 || (kh * kw) % 3 != 0 || mw > 2) return 2;
+    if (forced == 2 || forced == 3) return forced;
+    auto residency = [&](int qpc) {
+        const int cs = pick_stage_channels(segC, nseg, kh, kw, ng, prec, mw, 1, qpc);
+        const int npos = (TILE_H * mw + kh - 1) * (TILE_W + kw - 1);
+        const int lds = npos * (cs * 4 + 16) + 2 * ng * 32 * ((prec == VPX_PREC_F32 ? 8 : 16) * qpc * 4 + 16);
+        int wg = (160 * 1024) / lds;
+        const int cap = mw == 2 ? 2 : 3;
+        return wg > cap ? cap : wg;
+    };
+    return residency(3) >= residency(2) ? 3 : 2;
+}
+
 struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     int taps, n_tiles, nstage, chunks_total;
     int mw;                        // forward cell kernel: 32-pixel row tiles per wave
+    int qpc, d_qpc;                // k-steps per weight chunk of the forward cell / data-gradient launches (2 or 3)
     ConvStage stage[MAX_STAGE];
     // small maps: the step as a K-split plain convolution into a gate buffer + a pointwise gate kernel (0 = fused launch)
     int split, s_ng, s_tiles, s_nstage, s_chunks;
@@ -84,7 +104,8 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     L.n_tiles = (d->Ch + 31) / 32;
     const int segC[2] = {d->Cin, d->Ch};
     L.mw = pick_mw(d->B, d->H, d->W, L.n_tiles, d->precision);
-    L.nstage = build_stages(L.stage, &L.chunks_total, segC, 2, L.taps, pick_stage_channels(segC, 2, d->kh, d->kw, 4, d->precision, L.mw), d->precision);
+    L.qpc = pick_qpc(segC, 2, d->kh, d->kw, 4, d->precision, L.mw);
+    L.nstage = build_stages(L.stage, &L.chunks_total, segC, 2, L.taps, pick_stage_channels(segC, 2, d->kh, d->kw, 4, d->precision, L.mw, 1, L.qpc), d->precision, L.qpc);
     if (L.nstage < 0) { set_error("convlstm: too many channel stages (Cin=%d Ch=%d)", d->Cin, d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.split = 0;
     {
@@ -113,7 +134,8 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     const int N4 = 4 * d->Ch, Ct = d->Cin + d->Ch;
     const int segD[1] = {N4};
     L.d_mw = pick_mw(d->B, d->H, d->W, plain_tiles(Ct), d->precision);
-    L.d_nstage = build_stages(L.d_stage, &L.d_chunks, segD, 1, L.taps, pick_stage_channels(segD, 1, d->kh, d->kw, 4, d->precision, L.d_mw), d->precision);
+    L.d_qpc = pick_qpc(segD, 1, d->kh, d->kw, 4, d->precision, L.d_mw);
+    L.d_nstage = build_stages(L.d_stage, &L.d_chunks, segD, 1, L.taps, pick_stage_channels(segD, 1, d->kh, d->kw, 4, d->precision, L.d_mw, 1, L.d_qpc), d->precision, L.d_qpc);
     if (L.d_nstage < 0) { set_error("convlstm: too many channel stages in the data-gradient conv (Ch=%d)", d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.d_tiles_full = plain_tiles(Ct);
     L.d_tiles_h = plain_tiles(d->Ch);
@@ -142,7 +164,7 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
 
 
 static inline size_t convlstm_bwd_workspace_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
-    size_t b = align256(packed_weight_bytes(L.d_tiles_full, L.d_chunks, 4, d->precision));  // upper bound over both tilings
+    size_t b = align256(packed_weight_bytes(L.d_tiles_full, L.d_chunks, 4, d->precision, L.d_qpc));  // upper bound over both tilings
     b += align256((size_t)d->T * L.n_state * 4 * sizeof(float));  // dG, all steps
     b += 2 * align256(L.n_state * sizeof(float));                 // dh, dc carries
     b += align256(L.slab_floats * sizeof(float));

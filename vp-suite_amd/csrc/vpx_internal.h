@@ -47,6 +47,7 @@ struct ConvPlan {
     int prec;             // VPX_PREC_F32 | VPX_PREC_BF16X3: operand mode of the contraction
     int mw;               // 32-pixel MFMA row tiles per wave (1: 8x16 workgroup tile, 2: 16x16); 0 is read as 1
     int grid_m, grid_n;   // set by the launcher: pixel tiles / N tiles of the flattened, XCD-aware 1-D grid (grid_n = 0: 2-D grid)
+    int qpc;              // k-steps per weight chunk the weights were packed with (0/2: two; 3: three, bf16 modes only)
     int ksplit;           // > 1: the stage list is split over blockIdx.z (plain epilogue only; partial sums via atomics)
     int dbg;              // ablation bits for profiling (VPX_DBG): 1 skip MFMAs, 2 skip activation loads, 4 skip weight loads, 8 skip epilogue
     // generalised geometry (all 0 = the stride-1 "same" convolution every recurrent cell uses):
@@ -71,6 +72,7 @@ struct PackDesc {
     PackSeg seg[MAX_SEG];
     ConvStage stage[MAX_STAGE];
     int nstage, chunks_total, n_tiles, taps;
+    int qpc;              // k-steps per chunk (0/2 or 3), see mode_kc()
     int prec;             // operand mode the packing is for (must match the ConvPlan that consumes it)
     int NG;               // groups per tile actually used (rows of unused groups are zero)
     int rowbase[MAX_SEG][MAX_NG];  // per segment: source output-row of (channel 0, tile 0) for group g; -1 = none
@@ -84,8 +86,8 @@ struct PackDesc {
 };
 
 void set_error(const char* fmt, ...);
-int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int prec);
-int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw = 1, int stride = 1);
+int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int prec, int qpc = 2);
+int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw = 1, int stride = 1, int qpc = 2);
 int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw = 1, int stride = 1);
 // rows per wave: 2 (16x16 workgroup tile) when the operand mode profits (bf16x3 is LDS/issue-bound, not MFMA-bound) and
 // the launch still has >= 2 workgroups per CU; else 1
@@ -93,7 +95,7 @@ int pick_mw(int B, int H, int W, int n_tiles, int prec);
 // same rule from the number of 8x16 pixel tiles of the launch (the 8-wave form halves it)
 inline int pick_mw_tiles(long long m_tiles, int n_tiles, int prec) { return (prec != 0 /* VPX_PREC_F32 */ && m_tiles / 2 * n_tiles >= 512) ? 2 : 1; }
 inline void set_plan_tiles(ConvPlan& P, int mw) { P.mw = mw; P.tiles_x = (P.W + TILE_W - 1) / TILE_W; P.tiles_y = (P.H + TILE_H * mw - 1) / (TILE_H * mw); }
-size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng, int prec);
+size_t packed_weight_bytes(int n_tiles, int chunks_total, int ng, int prec, int qpc = 2);
 
 hipError_t launch_pack_weights(const PackDesc& pd, float* dst, hipStream_t s);
 
