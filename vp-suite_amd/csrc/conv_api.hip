@@ -294,11 +294,8 @@ int strided_wgrad(hipStream_t stream, int prec, int N, int Hg, int Wg, const flo
             wa.a_sub = 1; wa.a_sy = s; wa.a_sx = s; wa.a_oy = ry; wa.a_ox = rx;
             wa.a_Hs = (Ha - ry + s - 1) / s; wa.a_Ws = (Wa - rx + s - 1) / s; wa.a_Wfull = Wa;
             wa.use_org = 1; wa.org_y = fdiv(ky0 - p - ry, s); wa.org_x = fdiv(kx0 - p - rx, s);
-            wa.n_ctiles = 0;
-            for (int c0 = 0; c0 < Ca; c0 += 64) {
-                if (wa.n_ctiles >= 16) { set_error("conv wgrad: too many channels (%d)", Ca); return VPX_ERR_UNSUPPORTED; }
-                wa.ct[wa.n_ctiles++] = WgradCTile{0, c0, (Ca - c0 < 64) ? Ca - c0 : 64, c0};
-            }
+            wa.n_ctiles = wgrad_make_ctiles(wa.ct, 16, Ca, 0, 0);
+            if (wa.n_ctiles < 0) { set_error("conv wgrad: too many channels (%d)", Ca); return VPX_ERR_UNSUPPORTED; }
             wa.slabs = slabs;
             const int taps = nty * ntx;
             // K slices: ~1024 workgroups, bounded by the work items and by the slab budget (GLUE_SLAB_FLOATS, or 32 slices

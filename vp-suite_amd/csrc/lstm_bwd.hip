@@ -120,6 +120,16 @@ __device__ __forceinline__ bool wg_apix(const WgradArgs& a, int gy, int gx, long
     return true;
 }
 
+// activation source of column half `h` for item (t, b): null when the half is unused or its operand absent (zero hidden
+// state at t = 0 contributes nothing); C = channels per pixel of that source
+__device__ __forceinline__ const float* wg_half_src(const WgradArgs& a, const WgradCHalf& h, int t, int b, int& C) {
+    C = h.seg == 0 ? a.Cin : a.Ch;
+    if (h.cn == 0) return nullptr;
+    if (h.seg == 0) return a.x + (size_t)b * a.x_bstride + (size_t)t * a.x_tstride;
+    if (t > 0) return a.hseq + (size_t)b * a.h_bstride + (size_t)(t - 1) * a.h_tstride;
+    return a.h0 ? a.h0 + (size_t)b * a.HW * a.Ch : nullptr;
+}
+
 template <int MAXT>  // MAXT = exact number of taps this launch handles (branch-free MFMA block)
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, const int tap_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -154,6 +164,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
     const int tiles = a.tiles_x * a.tiles_y;
     const long long n_items = (long long)a.T * a.B * tiles;
     const int n0 = nt_id * 64;  // first gate row of this workgroup
+    const int myhalf = (tid >> 3) & 1;  // the vector staging loop keeps a thread on one 4-channel column (v & 15 == tid & 15)
+    const WgradCHalf myh = ct.h[myhalf];
     for (long long w = blockIdx.y; w < n_items; w += gridDim.y) {
         const int tile = (int)(w % tiles);
         const long long tb = w / tiles;
@@ -161,18 +173,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
         const int t = (int)(tb / a.B);
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         const int y0 = ty * TILE_H, x0 = tx * TILE_W;
-        // activation source of this item
-        const float* src;
-        int C;
-        if (ct.seg == 0) {
-            src = a.x + (size_t)b * a.x_bstride + (size_t)t * a.x_tstride;
-            C = a.Cin;
-        } else {
-            C = a.Ch;
-            if (t > 0) src = a.hseq + (size_t)b * a.h_bstride + (size_t)(t - 1) * a.h_tstride;
-            else if (a.h0) src = a.h0 + (size_t)b * a.HW * a.Ch;
-            else continue;  // zero hidden state at t = 0 contributes nothing (uniform branch)
-        }
+        // activation sources of this item's two column halves; this thread stages columns of half `myhalf`
+        int C0, C1;
+        const float* src0 = wg_half_src(a, ct.h[0], t, b, C0);
+        const float* src1 = wg_half_src(a, ct.h[1], t, b, C1);
+        if (!src0 && !src1) continue;  // (uniform branch)
+        const float* src = myhalf ? src1 : src0;
+        const int C = myhalf ? C1 : C0;
+        const bool a_vec = (!src0 || ((C0 & 3) == 0 && (reinterpret_cast<uintptr_t>(src0) & 15) == 0)) &&
+                           (!src1 || ((C1 & 3) == 0 && (reinterpret_cast<uintptr_t>(src1) & 15) == 0));
         const int ldG = a.ldG ? a.ldG : a.N4;
         const float* dg = a.dG + ((size_t)t * a.B + b) * a.HW * ldG;
         __syncthreads();
@@ -197,16 +206,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
                 G_lds[p * 64 + q] = val;
             }
         }
-        // ---- stage activation halo tile: npos x 64 channels [ct.c0, ct.c0 + 64) ----
-        if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        // ---- stage activation halo tile: npos x (2 halves x 32 channels) ----
+        if (a_vec) {
             for (int v = tid; v < npos * 16; v += NTHREADS) {
                 const int pos = v >> 4, q4 = v & 15;
                 const int hy = pos / halo_w, hx = pos - hy * halo_w;
                 const int gy = y0 - ph + hy, gx = x0 - pw + hx;
-                const int c = ct.c0 + q4 * 4;
+                const int c = myh.c0 + (q4 & 7) * 4;
                 f32x4 val = {0.f, 0.f, 0.f, 0.f};
                 long long pix;
-                if (c < C && wg_apix(a, gy, gx, pix))
+                if (src && c < C && wg_apix(a, gy, gx, pix))
                     val = *reinterpret_cast<const f32x4*>(src + pix * C + c);
                 *reinterpret_cast<f32x4*>(A_lds + pos * 64 + q4 * 4) = val;
             }
@@ -215,10 +224,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
                 const int pos = e >> 6, q = e & 63;
                 const int hy = pos / halo_w, hx = pos - hy * halo_w;
                 const int gy = y0 - ph + hy, gx = x0 - pw + hx;
-                const int c = ct.c0 + q;
+                const int eh = q >> 5;  // (= (tid >> 5) & 1 here, not myhalf)
+                const float* esrc = eh ? src1 : src0;
+                const int eC = eh ? C1 : C0;
+                const int c = ct.h[eh].c0 + (q & 31);
                 float val = 0.f;
                 long long pix;
-                if (c < C && wg_apix(a, gy, gx, pix)) val = src[pix * C + c];
+                if (esrc && c < eC && wg_apix(a, gy, gx, pix)) val = esrc[pix * eC + c];
                 A_lds[pos * 64 + q] = val;
             }
         }
@@ -239,8 +251,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
         }
     }
     // ---- slab[slice][tap][row][Ct] = acc (each element written exactly once per launch) ----
-    const int col = ct.cglobal + wc * 32 + i;  // channel inside the concatenated [x | h] axis
-    const bool col_ok = (wc * 32 + i) < ct.cn;
+    const int col = ct.h[wc].cglobal + i;  // channel inside the concatenated [x | h] axis
+    const bool col_ok = i < ct.h[wc].cn;
     const int n_out = a.n_out ? a.n_out : a.N4;
     float* slab = a.slabs + (size_t)blockIdx.y * a.kh * a.kw * n_out * a.Ct;
 #pragma unroll
@@ -289,6 +301,8 @@ __device__ __forceinline__ bf16x8 wg_tr_frag(const char* base, const int pitch =
     return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
+__device__ __forceinline__ int wg_aswz(const int off) { return off ^ ((off >> 2) & 0x40); }  // 128-byte rows, see GSWZ
+
 // Items (t, b, tile) are software-pipelined through registers: while the MFMAs of item i run out of LDS, the global
 // loads of item i+1 (GPRE dG vectors + APRE activation vectors per thread) are in flight; they are split to hi/lo bf16
 // and stored to LDS after the barrier that ends item i. PIPE = 0 keeps the plain load-store-multiply order (fewer
@@ -328,7 +342,14 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
 
     // transposing-read address pattern of this lane inside its 16-lane group: row q, columns 4p..4p+3
     const int L = lane & 15, q = L >> 2, p = L & 3, half16 = (lane >> 4) & 1;
-    const int g_lane = ((8 * hh + q) * GROW + wn * 32 + 16 * half16 + 4 * p) * 2;  // bytes, + tile-row * 16 * GP
+    // Bank swizzle: a half-wave's transposing read covers 4 consecutive rows x 64 B. At a row pitch of 128 B (256 B)
+    // rows r and r+2 (all four rows) start in the same bank, so the 64-byte segment index of a row is XORed with
+    // row bits: 128-B rows: segment ^= (row >> 1) & 1, 256-B rows: segment ^= row & 3 — the four rows of a read then
+    // occupy four different 16-bank groups. For the dG planes the row bits come from the lane only (free); for the
+    // activation planes they depend on the tap shift (wg_aswz per access).
+    constexpr int GSWZ = RB == 2 ? 0xC0 : 0x40;
+    int g_lane = ((8 * hh + q) * GROW + wn * 32 + 16 * half16 + 4 * p) * 2;  // bytes, + tile-row * 16 * GP
+    g_lane ^= (g_lane >> 2) & GSWZ;
     const int a_lane = ((8 * hh + q) * 64 + wc * 32 + 16 * half16 + 4 * p) * 2;  // bytes, + position offset * 128
     int tapoff[MAXT];
 #pragma unroll
@@ -344,12 +365,14 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
     const int ldG = a.ldG ? a.ldG : a.N4;
     const int q4 = tid & 15;              // this thread's 4-channel column of the activation tile
     const int qg = tid & (GVPR - 1);      // ... and its 4-row column of the dG tile
-    const int n_col = n0 + qg * 4, c_col = ct.c0 + q4 * 4;
+    const int myhalf = q4 >> 3;           // column half this thread stages
+    const WgradCHalf myh = ct.h[myhalf];
+    const int n_col = n0 + qg * 4, c_col = myh.c0 + (q4 & 7) * 4;
 
     constexpr int NV = PIPE ? APRE : 4;  // PIPE = 0 streams the tiles through 4 vectors at a time
     f32x4 gv[PIPE ? GPRE : 4], av[NV];
     struct ItemGeo { const float* src; const float* dg; int C, y0, x0; bool g_vec, a_vec; };
-    // geometry of item w; returns false when the item contributes nothing (absent h at t = 0)
+    // geometry of item w; returns false when the item contributes nothing (absent h at t = 0 in both column halves)
     auto item_geo = [&](long long w, ItemGeo& g) -> bool {
         const int tile = (int)(w % tiles);
         const long long tb = w / tiles;
@@ -357,15 +380,12 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
         const int t = (int)(tb / a.B);
         const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
         g.y0 = ty * TILE_H; g.x0 = tx * TILE_W;
-        if (ct.seg == 0) {
-            g.src = a.x + (size_t)b * a.x_bstride + (size_t)t * a.x_tstride;
-            g.C = a.Cin;
-        } else {
-            g.C = a.Ch;
-            if (t > 0) g.src = a.hseq + (size_t)b * a.h_bstride + (size_t)(t - 1) * a.h_tstride;
-            else if (a.h0) g.src = a.h0 + (size_t)b * a.HW * a.Ch;
-            else return false;
-        }
+        int C0, C1;
+        const float* src0 = wg_half_src(a, ct.h[0], t, b, C0);
+        const float* src1 = wg_half_src(a, ct.h[1], t, b, C1);
+        if (!src0 && !src1) return false;
+        g.src = myhalf ? src1 : src0;  // null: this half stages zeros
+        g.C = myhalf ? C1 : C0;
         g.dg = a.dG + ((size_t)t * a.B + b) * a.HW * ldG;
         g.g_vec = ((a.N4 | ldG) & 3) == 0 && (reinterpret_cast<uintptr_t>(g.dg) & 15) == 0;
         g.a_vec = (g.C & 3) == 0 && (reinterpret_cast<uintptr_t>(g.src) & 15) == 0;
@@ -395,8 +415,10 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
             if (pp < 128) {
                 uint2 hi, lo;
                 wg_split4(srcv[u], hi, lo);
-                *reinterpret_cast<uint2*>(G_hi + pp * GP + qg * 8) = hi;
-                *reinterpret_cast<uint2*>(G_lo + pp * GP + qg * 8) = lo;
+                int off = pp * GP + qg * 8;
+                off ^= (off >> 2) & GSWZ;
+                *reinterpret_cast<uint2*>(G_hi + off) = hi;
+                *reinterpret_cast<uint2*>(G_lo + off) = lo;
             }
         }
     };
@@ -408,7 +430,7 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
             const int gy = g.y0 - ph + hy, gx = g.x0 - pw + hx;
             dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             long long pix;
-            if (pos < npos && wg_apix(a, gy, gx, pix)) {
+            if (pos < npos && g.src && wg_apix(a, gy, gx, pix)) {
                 const float* rowp = g.src + pix * g.C;
                 if (g.a_vec) { if (c_col < g.C) dst[u] = *reinterpret_cast<const f32x4*>(rowp + c_col); }
                 else {
@@ -425,8 +447,9 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
             if (pos < npos) {
                 uint2 hi, lo;
                 wg_split4(srcv[u], hi, lo);
-                *reinterpret_cast<uint2*>(A_hi + pos * 128 + q4 * 8) = hi;
-                *reinterpret_cast<uint2*>(A_lo + pos * 128 + q4 * 8) = lo;
+                const int off = wg_aswz(pos * 128 + q4 * 8);
+                *reinterpret_cast<uint2*>(A_hi + off) = hi;
+                *reinterpret_cast<uint2*>(A_lo + off) = lo;
             }
         }
     };
@@ -449,9 +472,10 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
             const int arow = a_lane + s * halo_w * 128;
 #pragma unroll
             for (int t2 = 0; t2 < MAXT; ++t2) {
-                const bf16x8 ah = wg_tr_frag(A_hi + arow + tapoff[t2]);
+                const int aoff = wg_aswz(arow + tapoff[t2]);
+                const bf16x8 ah = wg_tr_frag(A_hi + aoff);
                 if (lo_terms) {
-                    const bf16x8 al = wg_tr_frag(A_lo + arow + tapoff[t2]);
+                    const bf16x8 al = wg_tr_frag(A_lo + aoff);
                     acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ah, acc[t2], 0, 0, 0);
                     acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, al, acc[t2], 0, 0, 0);
                 }
@@ -483,8 +507,8 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
             multiply();
         }
     }
-    const int col = ct.cglobal + wc * 32 + i;
-    const bool col_ok = (wc * 32 + i) < ct.cn;
+    const int col = ct.h[wc].cglobal + i;
+    const bool col_ok = i < ct.h[wc].cn;
     const int n_out = a.n_out ? a.n_out : a.N4;
     float* slab = a.slabs + (size_t)blockIdx.y * a.kh * a.kw * n_out * a.Ct;
 #pragma unroll

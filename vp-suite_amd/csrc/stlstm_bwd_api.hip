@@ -88,15 +88,8 @@ int run_wgrad(const vpx_stlstm_desc* d, const STBwdLayout& L, const float* dG, i
     wa.dG = dG;
     wa.x = src0; wa.x_bstride = (long long)wa.HW * C0; wa.x_tstride = 0;
     wa.hseq = nullptr; wa.h0 = src1;
-    wa.n_ctiles = 0;
-    for (int c0 = 0; c0 < C0; c0 += 64) {
-        if (wa.n_ctiles >= 16) { set_error("stlstm bwd: too many channels for the weight-gradient kernel"); return VPX_ERR_UNSUPPORTED; }
-        wa.ct[wa.n_ctiles++] = WgradCTile{0, c0, (C0 - c0 < 64) ? C0 - c0 : 64, c0};
-    }
-    for (int c0 = 0; c0 < C1; c0 += 64) {
-        if (wa.n_ctiles >= 16) { set_error("stlstm bwd: too many channels for the weight-gradient kernel"); return VPX_ERR_UNSUPPORTED; }
-        wa.ct[wa.n_ctiles++] = WgradCTile{1, c0, (C1 - c0 < 64) ? C1 - c0 : 64, C0 + c0};
-    }
+    wa.n_ctiles = wgrad_make_ctiles(wa.ct, 16, C0, C1, C0);
+    if (wa.n_ctiles < 0) { set_error("stlstm bwd: too many channels for the weight-gradient kernel"); return VPX_ERR_UNSUPPORTED; }
     wa.slabs = slabs;
     const int taps = k * k;
     // K slices: enough for ~1024 workgroups, no more (every slice costs a slab write + a reduce read of the whole dW)

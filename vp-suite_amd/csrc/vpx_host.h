@@ -139,15 +139,8 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     if (L.d_nstage < 0) { set_error("convlstm: too many channel stages in the data-gradient conv (Ch=%d)", d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.d_tiles_full = plain_tiles(Ct);
     L.d_tiles_h = plain_tiles(d->Ch);
-    L.n_ctiles = 0;
-    for (int c0 = 0; c0 < d->Cin; c0 += 64) {
-        if (L.n_ctiles >= 16) { set_error("convlstm: too many channels for the weight-gradient kernel"); return VPX_ERR_UNSUPPORTED; }
-        L.ct[L.n_ctiles++] = WgradCTile{0, c0, (d->Cin - c0 < 64) ? d->Cin - c0 : 64, c0};
-    }
-    for (int c0 = 0; c0 < d->Ch; c0 += 64) {
-        if (L.n_ctiles >= 16) { set_error("convlstm: too many channels for the weight-gradient kernel"); return VPX_ERR_UNSUPPORTED; }
-        L.ct[L.n_ctiles++] = WgradCTile{1, c0, (d->Ch - c0 < 64) ? d->Ch - c0 : 64, d->Cin + c0};
-    }
+    L.n_ctiles = wgrad_make_ctiles(L.ct, 16, d->Cin, d->Ch, d->Cin);
+    if (L.n_ctiles < 0) { set_error("convlstm: too many channels for the weight-gradient kernel"); return VPX_ERR_UNSUPPORTED; }
     {
         const int tiles = ((d->W + TILE_W - 1) / TILE_W) * ((d->H + TILE_H - 1) / TILE_H);
         const long long items = (long long)d->T * d->B * tiles;
@@ -255,11 +248,8 @@ static inline int plain_wgrad(hipStream_t stream, int prec, ConvGeo g, const flo
     wa.tiles_x = (g.W + TILE_W - 1) / TILE_W; wa.tiles_y = (g.H + TILE_H - 1) / TILE_H;
     wa.N4 = Co; wa.Cin = C; wa.Ch = 1; wa.Ct = C; wa.ldG = Co; wa.n_out = Co; wa.prec = prec;
     wa.dG = dy; wa.x = x; wa.x_bstride = (long long)wa.HW * C;
-    wa.n_ctiles = 0;
-    for (int c0 = 0; c0 < C; c0 += 64) {
-        if (wa.n_ctiles >= 16) { set_error("conv wgrad: too many input channels (%d)", C); return VPX_ERR_UNSUPPORTED; }
-        wa.ct[wa.n_ctiles++] = WgradCTile{0, c0, (C - c0 < 64) ? C - c0 : 64, c0};
-    }
+    wa.n_ctiles = wgrad_make_ctiles(wa.ct, 16, C, 0, 0);
+    if (wa.n_ctiles < 0) { set_error("conv wgrad: too many input channels (%d)", C); return VPX_ERR_UNSUPPORTED; }
     wa.slabs = slabs;
     const int ns = wgrad_pick_slices(wgrad_slices(g.N, g.H, g.W), Co, wa.n_ctiles, kh * kw);
     VPX_CHECK_HIP(launch_wgrad(wa, ns, stream));

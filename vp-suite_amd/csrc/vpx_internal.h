@@ -191,7 +191,24 @@ inline int gate_bwd_blocks(int HW, int Ch) { return (HW * Ch + 255) / 256; }
 hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s);
 hipError_t launch_colsum(const float* m, float* out, long long rows, int cols, hipStream_t s);
 
-struct WgradCTile { int seg, c0, cn, cglobal; };   // 64-channel slice [c0, c0+cn) of segment seg; cglobal = column in [x|h]
+// A workgroup's 64 activation columns are two 32-channel halves (one per wave column), each its own slice
+// [c0, c0+cn) of segment seg (0 = x, 1 = h); cglobal = column in [x|h]. Halves are paired in order ACROSS the
+// segments, so 96 + 96 channels make three full tiles instead of four with two half-empty ones. cn = 0: unused half.
+struct WgradCHalf { int seg, c0, cn, cglobal; };
+struct WgradCTile { WgradCHalf h[2]; };
+// tiles for C0 channels of segment 0 (0 = no such operand) and C1 of segment 1 whose first column is cg1; -1: > cap tiles
+static inline int wgrad_make_ctiles(WgradCTile* ct, int cap, int C0, int C1, int cg1) {
+    int nh = 0;
+    for (int seg = 0; seg < 2; ++seg) {
+        const int C = seg ? C1 : C0, cg = seg ? cg1 : 0;
+        for (int c0 = 0; c0 < C; c0 += 32, ++nh) {
+            if (nh >= 2 * cap) return -1;
+            ct[nh >> 1].h[nh & 1] = WgradCHalf{seg, c0, (C - c0 < 32) ? C - c0 : 32, cg + c0};
+        }
+    }
+    if (nh & 1) ct[nh >> 1].h[1] = WgradCHalf{0, 0, 0, 0};
+    return (nh + 1) >> 1;
+}
 struct WgradArgs {
     int T, B, H, W, HW, kh, kw, tiles_x, tiles_y;
     int N4, Cin, Ch, Ct;      // contraction-side rows (e.g. 4Ch gate rows), segment channel counts, Ct = Cin + Ch
