@@ -104,7 +104,7 @@ hipError_t launch_colsum(const float* m, float* out, long long rows, int cols, h
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// weight gradient. Work item = (t, b, spatial tile); slice `blockIdx.y` owns items slice, slice + n_slices, ...
+// weight gradient. Work item = (t, b, spatial tile); slice `s` (see wg_block) owns items slice, slice + n_slices, ...
 // LDS: dG tile [128 px][64 rows] (32 KiB) + activation halo tile [halo positions][64 ch].
 // Each wave owns a 32 (rows) x 32 (channels) output block for up to WG_MAXT taps: acc[tap] += dG^T (px-contracted) A_tap.
 // ---------------------------------------------------------------------------------------------------------------
@@ -130,15 +130,32 @@ __device__ __forceinline__ const float* wg_half_src(const WgradArgs& a, const Wg
     return a.h0 ? a.h0 + (size_t)b * a.HW * a.Ch : nullptr;
 }
 
+// Logical block (bx = row tile x column tile, slice) of hardware block blockIdx.x. Consecutive hardware blocks go to the
+// eight XCDs round robin; the workgroups of one K slice read the same dG / activation tiles (every row tile needs the
+// slice's activation tiles, every column tile its dG tiles), so a slice's blocks are given to ONE XCD, back to back, and
+// meet in its L2. false: padding block of the rounded-up launch.
+__device__ __forceinline__ bool wg_block(const WgradArgs& a, int& bx, int& slice) {
+    const long long total = (long long)a.grid_x * a.grid_slices;
+    const long long per_xcd = (total + 7) / 8;
+    const unsigned L = blockIdx.x;
+    const long long v = (long long)(L & 7) * per_xcd + (L >> 3);
+    if ((long long)(L >> 3) >= per_xcd || v >= total) return false;
+    slice = (int)(v / a.grid_x);
+    bx = (int)(v - (long long)slice * a.grid_x);
+    return true;
+}
+
 template <int MAXT>  // MAXT = exact number of taps this launch handles (branch-free MFMA block)
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, const int tap_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int wn = wave >> 1, wc = wave & 1;
+    int bx, slice;
+    if (!wg_block(a, bx, slice)) return;
     const int n_ct = a.n_ctiles;
-    const int ct_id = blockIdx.x % n_ct;
-    const int nt_id = blockIdx.x / n_ct;
+    const int ct_id = bx % n_ct;
+    const int nt_id = bx / n_ct;
     const WgradCTile ct = a.ct[ct_id];
     const int tap0 = tap_base + blockIdx.z * MAXT;
     const int halo_w = TILE_W + a.kw - 1, halo_h = TILE_H + a.kh - 1, npos = halo_w * halo_h;
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
     const int n0 = nt_id * 64;  // first gate row of this workgroup
     const int myhalf = (tid >> 3) & 1;  // the vector staging loop keeps a thread on one 4-channel column (v & 15 == tid & 15)
     const WgradCHalf myh = ct.h[myhalf];
-    for (long long w = blockIdx.y; w < n_items; w += gridDim.y) {
+    for (long long w = slice; w < n_items; w += a.grid_slices) {
         const int tile = (int)(w % tiles);
         const long long tb = w / tiles;
         const int b = (int)(tb % a.B);
@@ -254,7 +271,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
     const int col = ct.h[wc].cglobal + i;  // channel inside the concatenated [x | h] axis
     const bool col_ok = i < ct.h[wc].cn;
     const int n_out = a.n_out ? a.n_out : a.N4;
-    float* slab = a.slabs + (size_t)blockIdx.y * a.kh * a.kw * n_out * a.Ct;
+    float* slab = a.slabs + (size_t)slice * a.kh * a.kw * n_out * a.Ct;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         float* st = slab + (size_t)(tap0 + t) * n_out * a.Ct;
@@ -319,9 +336,11 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int wn = wave >> 1, wc = wave & 1;
+    int bx, slice;
+    if (!wg_block(a, bx, slice)) return;
     const int n_ct = a.n_ctiles;
-    const int ct_id = blockIdx.x % n_ct;
-    const int nt_id = blockIdx.x / n_ct;
+    const int ct_id = bx % n_ct;
+    const int nt_id = bx / n_ct;
     const WgradCTile ct = a.ct[ct_id];
     const int tap0 = tap_base + blockIdx.z * MAXT;
     const int halo_w = TILE_W + a.kw - 1, halo_h = TILE_H + a.kh - 1, npos = halo_w * halo_h;
@@ -485,19 +504,19 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
     };
 
     if constexpr (PIPE) {
-        long long w = blockIdx.y;
+        long long w = slice;
         bool have = w < n_items && load_item(w);
         while (w < n_items) {
             __syncthreads();  // every wave is done reading the previous item's planes
             if (have) store_item();
             __syncthreads();
             const bool had = have;
-            w += gridDim.y;
+            w += a.grid_slices;
             have = w < n_items && load_item(w);  // next item's loads fly while this one is multiplied
             if (had) multiply();
         }
     } else {
-        for (long long w = blockIdx.y; w < n_items; w += gridDim.y) {
+        for (long long w = slice; w < n_items; w += a.grid_slices) {
             ItemGeo g;
             if (!item_geo(w, g)) continue;  // (uniform: depends on the item and the column tile only)
             __syncthreads();
@@ -510,7 +529,7 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
     const int col = ct.h[wc].cglobal + i;
     const bool col_ok = i < ct.h[wc].cn;
     const int n_out = a.n_out ? a.n_out : a.N4;
-    float* slab = a.slabs + (size_t)blockIdx.y * a.kh * a.kw * n_out * a.Ct;
+    float* slab = a.slabs + (size_t)slice * a.kh * a.kw * n_out * a.Ct;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         float* st = slab + (size_t)(tap0 + t) * n_out * a.Ct;
@@ -526,7 +545,7 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
 }
 
 template <int NTAPS>
-static hipError_t launch_wgrad_group(const WgradArgs& a, int n_slices, int tap_base, int groups, size_t lds, hipStream_t s) {
+static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int tap_base, int groups, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NTAPS>),
@@ -534,7 +553,13 @@ static hipError_t launch_wgrad_group(const WgradArgs& a, int n_slices, int tap_b
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid(((a.N4 + 63) / 64) * a.n_ctiles, n_slices, groups);
+    auto xcd_grid = [&](WgradArgs& w, int gx) {  // see wg_block
+        w.grid_x = gx; w.grid_slices = n_slices;
+        const long long total = (long long)gx * n_slices;
+        return dim3((unsigned)(8 * ((total + 7) / 8)), 1, groups);
+    };
+    WgradArgs a = a_in;
+    const dim3 grid = xcd_grid(a, ((a.N4 + 63) / 64) * a.n_ctiles);
     if (a.prec == VPX_PREC_BF16X3 || a.prec == VPX_PREC_BF16) {
         // activation vectors per thread and item: halo positions * 16 / 256 (3x3: 12, 5x5: 15, 7x7: 20)
         const int npos = (TILE_H + a.kh - 1) * (TILE_W + a.kw - 1);
@@ -551,7 +576,7 @@ static hipError_t launch_wgrad_group(const WgradArgs& a, int n_slices, int tap_b
         // 46.2 ms vs 50.9 ms with the 8-wave form; PredRNN 5x5 134.7 ms vs 127.6 ms). VPX_WGRAD_RB=1/2 forces a form.
         if (a.N4 >= 128 && rb_env != 1 && (lds > 80 * 1024 || rb_env == 2)) {
             const int apre2 = (npos * 16 + 2 * NTHREADS - 1) / (2 * NTHREADS);
-            dim3 g2(((a.N4 + 127) / 128) * a.n_ctiles, n_slices, groups);
+            const dim3 g2 = xcd_grid(a, ((a.N4 + 127) / 128) * a.n_ctiles);
             const size_t lds2 = 2 * 128 * 256 + (size_t)npos * 128 * 2;
             if (apre2 > 10 || lds2 > 160 * 1024) return hipErrorInvalidValue;  // kernels beyond 7x7 are not instantiated
             if (apre2 <= 4) return go(&wgrad_bf16x3_kernel<NTAPS, 4, 1, 2>, g2, 2 * NTHREADS, lds2);

@@ -230,6 +230,8 @@ struct WgradArgs {
     int a_Hs, a_Ws;           // valid rows / columns of the sub-image
     int a_Wfull;              // pixels per row of the full image (the batch stride is x_bstride)
     int use_org, org_y, org_x;  // tap (0,0) reads activation pixel (y + org_y, x + org_x) instead of (y - kh/2, x - kw/2)
+    int dbg;                    // timing ablations, -DVPX_ABLATE builds only (VPX_WG_DBG: 1 = no multiply, 2 = stage the first item only)
+    int grid_x, grid_slices;    // set by launch_wgrad: logical grid (row tile x column tile, K slice) behind the XCD-aware 1-D launch
 };
 hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s);
