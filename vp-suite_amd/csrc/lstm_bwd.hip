@@ -544,6 +544,250 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradient, split-bf16 operands, tap-group form: 8 waves = 2 (gate rows) x 2 (channel halves) x 2 (TAP GROUPS).
+// The 64 x 64 x MAXT output tile of a workgroup is spread over 512 threads, so a wave carries ceil(MAXT/2) accumulator
+// tiles (80 registers for 3x3) instead of nine: the k-loop has the registers to keep a whole k-step's LDS reads in
+// flight under the MFMAs, and an item's global loads (GPRE + APRE vectors per thread) wait in registers for a full item.
+// LDS holds TWO item buffers. Per item and wave:   group 0:  multiply(i)  -> split+store(i+1) -> load(i+2)
+//                                                   group 1:  split+store(i+1) -> load(i+2) -> multiply(i)
+// (one barrier per item). Every SIMD hosts one wave of each group, so the VALU work of the hi/lo split runs under the
+// other wave's MFMAs. TH = tile rows per item (8: kernels up to 3x3; 4: up to 7x7 — two buffers must fit 160 KB).
+// ---------------------------------------------------------------------------------------------------------------
+// workgroup barrier that orders LDS traffic only: outstanding global loads (the next item, held in registers) stay in flight
+__device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int MAXT, int TH, int APRE>
+__global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, const int tap_base) {
+    constexpr int NTH = 512;
+    constexpr int TA = (MAXT + 1) / 2, TB = MAXT - TA;  // taps of group 0 / group 1
+    constexpr int NPX = TH * TILE_W;                    // pixels per item
+    constexpr int GPRE = NPX * 16 / NTH;                // dG vectors per thread and item
+    const bool lo_terms = a.prec == VPX_PREC_BF16X3;    // plain bf16 uses the hi planes only (uniform branch)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (readfirstlane: wave-uniform values the compiler cannot prove uniform — they then live in SGPRs, the item walk
+    // and the group branches run on the scalar unit, and the column-tile record is read with scalar loads)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hh = lane >> 5;
+    const int tg = wave >> 2, wn = (wave >> 1) & 1, wc = wave & 1;
+    int bx, slice;
+    if (!wg_block(a, bx, slice)) return;
+    bx = __builtin_amdgcn_readfirstlane(bx); slice = __builtin_amdgcn_readfirstlane(slice);
+    const int n_ct = a.n_ctiles;
+    const int ct_id = __builtin_amdgcn_readfirstlane(bx % n_ct);
+    const WgradCHalf ch0 = a.ct[ct_id].h[0], ch1 = a.ct[ct_id].h[1];
+    const int n0 = __builtin_amdgcn_readfirstlane((bx / n_ct) * 64);
+    const int tap0 = tap_base + blockIdx.z * MAXT + (tg ? TA : 0);
+    const int halo_w = TILE_W + a.kw - 1, halo_h = TH + a.kh - 1, npos = halo_w * halo_h;
+    const int ph = a.use_org ? -a.org_y : a.kh / 2, pw = a.use_org ? -a.org_x : a.kw / 2;
+    // one item buffer: G_hi | G_lo [NPX px][64 rows] bf16, A_hi | A_lo [npos][64 channels] bf16 (128 B per pixel / position)
+    const int G_LO = NPX * 128, A_HI = 2 * NPX * 128, A_LO = A_HI + npos * 128, BUF = A_LO + npos * 128;
+
+    f32x16 acc[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    const int L = lane & 15, q = L >> 2, p = L & 3, half16 = (lane >> 4) & 1;
+    int g_lane = ((8 * hh + q) * 64 + wn * 32 + 16 * half16 + 4 * p) * 2;
+    g_lane ^= (g_lane >> 2) & 0x40;  // bank swizzle of the 128-byte rows, see wgrad_bf16x3_kernel
+    const int a_lane = ((8 * hh + q) * 64 + wc * 32 + 16 * half16 + 4 * p) * 2;
+    int tapoff[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        const int tp = tap0 + t;
+        const int dy = tp / a.kw, dx = tp - dy * a.kw;
+        tapoff[t] = (dy * halo_w + dx) * 128;
+    }
+
+    // ---- item walk: slice, slice + n_slices, ... as a mixed-radix counter (tx, ty, b, t): no division per item ----
+    const int tiles_x = (a.W + TILE_W - 1) / TILE_W, tiles_y = (a.H + TH - 1) / TH, tiles = tiles_x * tiles_y;
+    const int ns = a.grid_slices;
+    const int d_tx = __builtin_amdgcn_readfirstlane(ns % tiles_x), d_ty = __builtin_amdgcn_readfirstlane((ns / tiles_x) % tiles_y);
+    const int d_b = __builtin_amdgcn_readfirstlane((ns / tiles) % a.B), d_t = __builtin_amdgcn_readfirstlane(ns / (tiles * a.B));
+    struct Item { int tx, ty, b, t; };
+    auto advance = [&](Item& it) {
+        it.tx += d_tx; if (it.tx >= tiles_x) { it.tx -= tiles_x; ++it.ty; }
+        it.ty += d_ty; if (it.ty >= tiles_y) { it.ty -= tiles_y; ++it.b; }
+        it.b += d_b;   if (it.b >= a.B) { it.b -= a.B; ++it.t; }
+        it.t += d_t;
+    };
+    // a tile whose present halves all read h sees nothing at t = 0 without an initial state: start at the first item with t > 0
+    const bool skip_t0 = !a.h0 && (ch0.cn == 0 || ch0.seg == 1) && (ch1.cn == 0 || ch1.seg == 1);
+    Item cur;
+    {
+        int w = slice;
+        const int first = skip_t0 ? a.B * tiles : 0;
+        if (w < first) w += (first - w + ns - 1) / ns * ns;
+        const int tile = w % tiles, tb = w / tiles;
+        cur.ty = __builtin_amdgcn_readfirstlane(tile / tiles_x);
+        cur.tx = __builtin_amdgcn_readfirstlane(tile - cur.ty * tiles_x);
+        cur.b = __builtin_amdgcn_readfirstlane(tb % a.B);
+        cur.t = __builtin_amdgcn_readfirstlane(tb / a.B);
+    }
+
+    // ---- staging: this thread's 4-wide column of both tiles and its pixel / halo rows prow + 32 u ----
+    const int q4 = tid & 15, prow = tid >> 4;
+    const int myhalf = q4 >> 3;
+    const WgradCHalf myh = myhalf ? ch1 : ch0;
+    const int ldG = a.ldG ? a.ldG : a.N4;
+    const int n_col = n0 + q4 * 4, c_col = myh.c0 + (q4 & 7) * 4;
+    int hyx[APRE];  // halo position of vector u: (row << 16) | column, -1: beyond the halo tile
+#pragma unroll
+    for (int u = 0; u < APRE; ++u) {
+        const int pos = prow + 32 * u;
+        const int hy = pos / halo_w;
+        hyx[u] = pos < npos ? ((hy << 16) | (pos - hy * halo_w)) : -1;
+    }
+    // Every load is issued unconditionally (16-byte vectors; the host routes unaligned / ragged-channel operands to the
+    // older kernels): out-of-range vectors read a safe address and are zeroed at store time through `okmask`. Straight-
+    // line issue matters: loads under divergent branches make the compiler drain vmcnt between them, one latency each.
+    f32x4 gv[GPRE], av[APRE];
+    unsigned okmask = 0;  // bit u: gv[u] valid, bit 16 + u: av[u] valid (of the item held in registers)
+    auto load_item = [&](const Item& it) {
+        const int y0 = it.ty * TH, x0 = it.tx * TILE_W;
+        int C0, C1;
+        const float* src0 = wg_half_src(a, ch0, it.t, it.b, C0);
+        const float* src1 = wg_half_src(a, ch1, it.t, it.b, C1);
+        const float* src = myhalf ? src1 : src0;  // null: this half stages zeros
+        const int C = myhalf ? C1 : C0;
+        const float* dg = a.dG + ((size_t)it.t * a.B + it.b) * a.HW * ldG;
+        const bool a_ok = src != nullptr && c_col < C;
+        if (!src) src = a.dG;
+        okmask = 0;
+#pragma unroll
+        for (int u = 0; u < GPRE; ++u) {
+            const int pp = prow + 32 * u;
+            const int gy = y0 + (pp >> 4), gx = x0 + (pp & 15);
+            const bool ok = gy < a.H && gx < a.W && n_col < a.N4;
+            gv[u] = *reinterpret_cast<const f32x4*>(dg + (ok ? (gy * a.W + gx) * ldG + n_col : 0));
+            okmask |= (ok ? 1u : 0u) << u;
+        }
+#pragma unroll
+        for (int u = 0; u < APRE; ++u) {
+            const int gy = y0 - ph + (hyx[u] >> 16), gx = x0 - pw + (hyx[u] & 0xffff);
+            long long pix = 0;
+            const bool ok = wg_apix(a, gy, gx, pix) && hyx[u] >= 0 && a_ok;
+            av[u] = *reinterpret_cast<const f32x4*>(src + (ok ? (int)pix * C + c_col : 0));
+            okmask |= (ok ? 1u : 0u) << (16 + u);
+        }
+    };
+    auto store_item = [&](char* buf) {
+#pragma unroll
+        for (int u = 0; u < GPRE; ++u) {
+            uint2 hi, lo;
+            wg_split4((okmask >> u) & 1 ? gv[u] : f32x4{0.f, 0.f, 0.f, 0.f}, hi, lo);
+            int off = (prow + 32 * u) * 128 + q4 * 8;
+            off ^= (off >> 2) & 0x40;
+            *reinterpret_cast<uint2*>(buf + off) = hi;
+            *reinterpret_cast<uint2*>(buf + G_LO + off) = lo;
+        }
+#pragma unroll
+        for (int u = 0; u < APRE; ++u) {
+            if (hyx[u] >= 0) {
+                uint2 hi, lo;
+                wg_split4((okmask >> (16 + u)) & 1 ? av[u] : f32x4{0.f, 0.f, 0.f, 0.f}, hi, lo);
+                const int off = wg_aswz((prow + 32 * u) * 128 + q4 * 8);
+                *reinterpret_cast<uint2*>(buf + A_HI + off) = hi;
+                *reinterpret_cast<uint2*>(buf + A_LO + off) = lo;
+            }
+        }
+    };
+    // TH k-steps (tile rows) of 16 pixels. ONE copy of the loop serves both wave groups (two copies made the compiler
+    // spill the prefetched vectors): the TB taps both groups have, in batches of <= 3 with the three terms issued term-major
+    // (consecutive MFMAs accumulate into different tiles), then group 0's extra tap under a scalar branch.
+    auto tap_batch = [&](const char* buf, const bf16x8& gh, const bf16x8& gl, int arow, auto t0_c, auto nb_c, auto lo_c) {
+        constexpr int T0 = decltype(t0_c)::value, NB = decltype(nb_c)::value;
+        constexpr bool LO = decltype(lo_c)::value;
+        bf16x8 ah[NB], al[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int aoff = wg_aswz(arow + tapoff[T0 + j]);
+            ah[j] = wg_tr_frag(buf + A_HI + aoff);
+            if constexpr (LO) al[j] = wg_tr_frag(buf + A_LO + aoff);
+        }
+        if constexpr (LO) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[T0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl, ah[j], acc[T0 + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[T0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, al[j], acc[T0 + j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[T0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh, ah[j], acc[T0 + j], 0, 0, 0);
+    };
+    auto multiply = [&](const char* buf, auto lo_c) {
+        constexpr bool LO = decltype(lo_c)::value;
+#pragma unroll 1
+        for (int s = 0; s < TH; ++s) {
+            const bf16x8 gh = wg_tr_frag(buf + g_lane + s * 16 * 128);
+            bf16x8 gl = gh;
+            if constexpr (LO) gl = wg_tr_frag(buf + G_LO + g_lane + s * 16 * 128);
+            const int arow = a_lane + s * halo_w * 128;
+            if constexpr (TB >= 1) tap_batch(buf, gh, gl, arow, std::integral_constant<int, 0>{}, std::integral_constant<int, (TB < 3 ? TB : 3)>{}, lo_c);
+            if constexpr (TB >= 4) tap_batch(buf, gh, gl, arow, std::integral_constant<int, 3>{}, std::integral_constant<int, TB - 3>{}, lo_c);
+            if constexpr (TA > TB) {
+                if (tg == 0) tap_batch(buf, gh, gl, arow, std::integral_constant<int, TB>{}, std::integral_constant<int, 1>{}, lo_c);
+            }
+        }
+    };
+    auto multiply_g = [&](const char* buf) {  // (wave-uniform branch)
+        if (lo_terms) multiply(buf, std::true_type{});
+        else multiply(buf, std::false_type{});
+    };
+
+    Item nxt = cur;
+    advance(nxt);
+    if (cur.t < a.T) { load_item(cur); store_item(smem); }
+    if (nxt.t < a.T) load_item(nxt);
+    __syncthreads();
+    int bsel = 0;
+    while (cur.t < a.T) {
+        char* bcur = smem + bsel * BUF;
+        char* bnxt = smem + (bsel ^ 1) * BUF;
+        Item nn = nxt;
+        advance(nn);
+        // group 0: multiply, then stage; group 1: stage, then multiply — as ONE copy of each (a three-phase loop the
+        // compiler must not unroll)
+#ifdef VPX_ABLATE  // timing-only variants (results are wrong): 1 no multiply, 2 no split+store, 4 no global loads, 8 same order in both groups
+        const bool do_mul = !(a.dbg & 1), do_st = !(a.dbg & 2), do_ld = !(a.dbg & 4);
+        const int stage_phase = (tg == 1 && !(a.dbg & 8)) ? 0 : 2;
+#else
+        constexpr bool do_mul = true, do_st = true, do_ld = true;
+        const int stage_phase = tg == 1 ? 0 : 2;
+#endif
+#pragma nounroll
+        for (int phase = 0; phase < 3; ++phase) {
+            if (phase == 1) { if (do_mul) multiply_g(bcur); }
+            else if (phase == stage_phase) {
+                if (nxt.t < a.T && do_st) store_item(bnxt);
+                if (nn.t < a.T && do_ld) load_item(nn);
+            }
+        }
+        wg_lds_barrier();  // (not __syncthreads(): its fence would also wait for the global loads just issued)
+        cur = nxt; nxt = nn; bsel ^= 1;
+    }
+
+    const WgradCHalf oh = wc ? ch1 : ch0;
+    const int col = oh.cglobal + i;
+    const bool col_ok = i < oh.cn;
+    const int n_out = a.n_out ? a.n_out : a.N4;
+    float* slab = a.slabs + (size_t)slice * a.kh * a.kw * n_out * a.Ct;
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        if (tg == 1 && t >= TB) break;
+        float* st = slab + (size_t)(tap0 + t) * n_out * a.Ct;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (n < a.N4 && col_ok) {
+                const int row = a.blk ? (a.rowblk[n / a.blk] * a.blk + n % a.blk) : n;
+                st[(size_t)row * a.Ct + col] = acc[t][r];
+            }
+        }
+    }
+}
+
 template <int NTAPS>
 static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int tap_base, int groups, size_t lds, hipStream_t s) {
     static bool attr_set = false;
@@ -559,6 +803,9 @@ static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int ta
         return dim3((unsigned)(8 * ((total + 7) / 8)), 1, groups);
     };
     WgradArgs a = a_in;
+#ifdef VPX_ABLATE
+    { const char* e = getenv("VPX_WG_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
     const dim3 grid = xcd_grid(a, ((a.N4 + 63) / 64) * a.n_ctiles);
     if (a.prec == VPX_PREC_BF16X3 || a.prec == VPX_PREC_BF16) {
         // activation vectors per thread and item: halo positions * 16 / 256 (3x3: 12, 5x5: 15, 7x7: 20)
@@ -569,6 +816,33 @@ static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int ta
             hipLaunchKernelGGL(kern, g, dim3(nth), lds_bytes, s, a, tap_base);
             return hipGetLastError();
         };
+        // tap-group form (wgrad_tg_kernel): two item buffers of TH x 16 pixels must fit the 160 KB
+        static int tg_env = -1;  // VPX_WGRAD_TG=0 falls back to the older forms below (experiments)
+        if (tg_env < 0) { const char* e = getenv("VPX_WGRAD_TG"); tg_env = e ? atoi(e) : 1; }
+        if constexpr (NTAPS >= 2) {
+            const long long items = (long long)a.T * a.B * ((a.W + TILE_W - 1) / TILE_W) * ((a.H + 3) / 4);
+            // 16-byte vector loads only: aligned bases, channel counts and strides in multiples of 4 floats
+            auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+            const int ldG = a.ldG ? a.ldG : a.N4;
+            bool vec = ((a.N4 | ldG) & 3) == 0 && al16(a.dG);
+            for (int c = 0; c < a.n_ctiles; ++c)
+                for (int h = 0; h < 2; ++h) {
+                    if (a.ct[c].h[h].cn == 0) continue;
+                    if (a.ct[c].h[h].seg == 0) vec = vec && (a.Cin & 3) == 0 && al16(a.x) && ((a.x_bstride | a.x_tstride) & 3) == 0;
+                    else vec = vec && (a.Ch & 3) == 0 && al16(a.hseq) && al16(a.h0) && ((a.h_bstride | a.h_tstride) & 3) == 0;
+                }
+            if (tg_env && vec && items + n_slices < (1ll << 31)) {
+                if (a.kh <= 3 && a.kw <= 3) {
+                    const size_t l2 = 2 * (size_t)(2 * 128 * 128 + 2 * npos * 128);
+                    return go(&wgrad_tg_kernel<NTAPS, 8, 6>, grid, 512, l2);
+                }
+                const int npos4 = (4 + a.kh - 1) * (TILE_W + a.kw - 1);
+                if (npos4 <= 256) {
+                    const size_t l2 = 2 * (size_t)(2 * 64 * 128 + 2 * npos4 * 128);
+                    return go(&wgrad_tg_kernel<NTAPS, 4, 8>, grid, 512, l2);
+                }
+            }
+        }
         static int rb_env = -1;  // VPX_WGRAD_RB=1 forces the 4-wave, 64-row form
         if (rb_env < 0) { const char* e = getenv("VPX_WGRAD_RB"); rb_env = e ? atoi(e) : 0; }
         // 8 waves / 128 rows / pipelined items when the 4-wave form's planes (> 80 KB: 5x5 and larger) allow one workgroup
