@@ -411,11 +411,24 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
         return true;
     };
     // vectors [u0, u0 + NU) of this thread: dG tile (128 pixels x 64 rows) and activation halo tile (npos x 64 channels)
-    auto load_g = [&](const ItemGeo& g, int u0, auto nu, auto& dst) {
+    // (the register-pipelined 8-wave forms keep the conditional loads: there the masks cost spills — PredRNN 5x5 step 401 vs 311 ms)
+    constexpr bool UNCOND = RB == 1 && !PIPE;
+    // a.vec_all (host-checked: every operand 16-byte aligned, channel counts and strides multiples of 4): the loads are
+    // issued unconditionally — out-of-range vectors read a safe address and are zeroed at store time through the returned
+    // mask. Loads under divergent branches make the compiler drain vmcnt between them (one memory latency EACH).
+    auto load_g = [&](const ItemGeo& g, int u0, auto nu, auto& dst) -> unsigned {
+        unsigned mask = 0;
 #pragma unroll
         for (int u = 0; u < nu; ++u) {
             const int pp = tid / GVPR + (u0 + u) * (NTH / GVPR);
             const int gy = g.y0 + (pp >> 4), gx = g.x0 + (pp & 15);
+            if (UNCOND && a.vec_all) {
+                const bool ok = pp < 128 && gy < a.H && gx < a.W && n_col < a.N4;
+                dst[u] = *reinterpret_cast<const f32x4*>(g.dg + (ok ? ((size_t)gy * a.W + gx) * ldG + n_col : 0));
+                mask |= (ok ? 1u : 0u) << u;
+                continue;
+            }
+            mask |= 1u << u;
             dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (pp < 128 && gy < a.H && gx < a.W) {
                 const float* rowp = g.dg + ((size_t)gy * a.W + gx) * ldG;
@@ -426,14 +439,15 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
                 }
             }
         }
+        return mask;
     };
-    auto store_g = [&](int u0, auto nu, const auto& srcv) {
+    auto store_g = [&](int u0, auto nu, const auto& srcv, unsigned mask) {
 #pragma unroll
         for (int u = 0; u < nu; ++u) {
             const int pp = tid / GVPR + (u0 + u) * (NTH / GVPR);
             if (pp < 128) {
                 uint2 hi, lo;
-                wg_split4(srcv[u], hi, lo);
+                wg_split4((mask >> u) & 1 ? srcv[u] : f32x4{0.f, 0.f, 0.f, 0.f}, hi, lo);
                 int off = pp * GP + qg * 8;
                 off ^= (off >> 2) & GSWZ;
                 *reinterpret_cast<uint2*>(G_hi + off) = hi;
@@ -441,14 +455,22 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
             }
         }
     };
-    auto load_a = [&](const ItemGeo& g, int u0, auto nu, auto& dst) {
+    auto load_a = [&](const ItemGeo& g, int u0, auto nu, auto& dst) -> unsigned {
+        unsigned mask = 0;
 #pragma unroll
         for (int u = 0; u < nu; ++u) {
             const int pos = (tid >> 4) + (u0 + u) * (NTH / 16);
             const int hy = pos / halo_w, hx = pos - hy * halo_w;
             const int gy = g.y0 - ph + hy, gx = g.x0 - pw + hx;
+            long long pix = 0;
+            if (UNCOND && a.vec_all) {
+                const bool ok = wg_apix(a, gy, gx, pix) && pos < npos && g.src != nullptr && c_col < g.C;
+                dst[u] = *reinterpret_cast<const f32x4*>((g.src ? g.src : g.dg) + (ok ? pix * g.C + c_col : 0));
+                mask |= (ok ? 1u : 0u) << u;
+                continue;
+            }
+            mask |= 1u << u;
             dst[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            long long pix;
             if (pos < npos && g.src && wg_apix(a, gy, gx, pix)) {
                 const float* rowp = g.src + pix * g.C;
                 if (g.a_vec) { if (c_col < g.C) dst[u] = *reinterpret_cast<const f32x4*>(rowp + c_col); }
@@ -458,30 +480,32 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
                 }
             }
         }
+        return mask;
     };
-    auto store_a = [&](int u0, auto nu, const auto& srcv) {
+    auto store_a = [&](int u0, auto nu, const auto& srcv, unsigned mask) {
 #pragma unroll
         for (int u = 0; u < nu; ++u) {
             const int pos = (tid >> 4) + (u0 + u) * (NTH / 16);
             if (pos < npos) {
                 uint2 hi, lo;
-                wg_split4(srcv[u], hi, lo);
+                wg_split4((mask >> u) & 1 ? srcv[u] : f32x4{0.f, 0.f, 0.f, 0.f}, hi, lo);
                 const int off = wg_aswz(pos * 128 + q4 * 8);
                 *reinterpret_cast<uint2*>(A_hi + off) = hi;
                 *reinterpret_cast<uint2*>(A_lo + off) = lo;
             }
         }
     };
+    unsigned gmask = 0, amask = 0;  // validity of the vectors held in (gv, av): PIPE only
     auto load_item = [&](long long w) -> bool {  // whole item into (gv, av): PIPE only
         ItemGeo g;
         if (!item_geo(w, g)) return false;
-        load_g(g, 0, std::integral_constant<int, PIPE ? GPRE : 4>{}, gv);
-        load_a(g, 0, std::integral_constant<int, NV>{}, av);
+        gmask = load_g(g, 0, std::integral_constant<int, PIPE ? GPRE : 4>{}, gv);
+        amask = load_a(g, 0, std::integral_constant<int, NV>{}, av);
         return true;
     };
     auto store_item = [&]() {
-        store_g(0, std::integral_constant<int, PIPE ? GPRE : 4>{}, gv);
-        store_a(0, std::integral_constant<int, NV>{}, av);
+        store_g(0, std::integral_constant<int, PIPE ? GPRE : 4>{}, gv, gmask);
+        store_a(0, std::integral_constant<int, NV>{}, av, amask);
     };
     auto multiply = [&]() {  // 8 k-steps (tile rows) of 16 pixels
 #pragma unroll 2
@@ -520,8 +544,8 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
             ItemGeo g;
             if (!item_geo(w, g)) continue;  // (uniform: depends on the item and the column tile only)
             __syncthreads();
-            for (int u0 = 0; u0 < GPRE; u0 += 4) { load_g(g, u0, std::integral_constant<int, 4>{}, gv); store_g(u0, std::integral_constant<int, 4>{}, gv); }
-            for (int u0 = 0; u0 * (NTH / 16) < npos; u0 += 4) { load_a(g, u0, std::integral_constant<int, 4>{}, av); store_a(u0, std::integral_constant<int, 4>{}, av); }
+            for (int u0 = 0; u0 < GPRE; u0 += 4) { const unsigned m = load_g(g, u0, std::integral_constant<int, 4>{}, gv); store_g(u0, std::integral_constant<int, 4>{}, gv, m); }
+            for (int u0 = 0; u0 * (NTH / 16) < npos; u0 += 4) { const unsigned m = load_a(g, u0, std::integral_constant<int, 4>{}, av); store_a(u0, std::integral_constant<int, 4>{}, av, m); }
             __syncthreads();
             multiply();
         }
@@ -816,12 +840,7 @@ static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int ta
             hipLaunchKernelGGL(kern, g, dim3(nth), lds_bytes, s, a, tap_base);
             return hipGetLastError();
         };
-        // tap-group form (wgrad_tg_kernel): two item buffers of TH x 16 pixels must fit the 160 KB
-        static int tg_env = -1;  // VPX_WGRAD_TG=0 falls back to the older forms below (experiments)
-        if (tg_env < 0) { const char* e = getenv("VPX_WGRAD_TG"); tg_env = e ? atoi(e) : 1; }
-        if constexpr (NTAPS >= 2) {
-            const long long items = (long long)a.T * a.B * ((a.W + TILE_W - 1) / TILE_W) * ((a.H + 3) / 4);
-            // 16-byte vector loads only: aligned bases, channel counts and strides in multiples of 4 floats
+        {   // 16-byte vector loads throughout: aligned bases, channel counts and strides in multiples of 4 floats
             auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
             const int ldG = a.ldG ? a.ldG : a.N4;
             bool vec = ((a.N4 | ldG) & 3) == 0 && al16(a.dG);
@@ -831,15 +850,19 @@ static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int ta
                     if (a.ct[c].h[h].seg == 0) vec = vec && (a.Cin & 3) == 0 && al16(a.x) && ((a.x_bstride | a.x_tstride) & 3) == 0;
                     else vec = vec && (a.Ch & 3) == 0 && al16(a.hseq) && al16(a.h0) && ((a.h_bstride | a.h_tstride) & 3) == 0;
                 }
-            if (tg_env && vec && items + n_slices < (1ll << 31)) {
+            a.vec_all = vec ? 1 : 0;
+        }
+        // tap-group form (wgrad_tg_kernel)
+        static int tg_env = -1;  // VPX_WGRAD_TG=0 falls back to the older forms below (experiments)
+        if (tg_env < 0) { const char* e = getenv("VPX_WGRAD_TG"); tg_env = e ? atoi(e) : 1; }
+        if constexpr (NTAPS >= 2) {
+            const long long items = (long long)a.T * a.B * ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H);
+            if (tg_env && a.vec_all && items + n_slices < (1ll << 31)) {
+                // kernels up to 3x3: two buffers of 8 x 16 pixels fit the LDS. Larger kernels would need 4-row items (halo
+                // overhead 2.5x for 5x5): measured slower than the 128-row form below (PredRNN 5x5 step 332 vs 311 ms)
                 if (a.kh <= 3 && a.kw <= 3) {
                     const size_t l2 = 2 * (size_t)(2 * 128 * 128 + 2 * npos * 128);
                     return go(&wgrad_tg_kernel<NTAPS, 8, 6>, grid, 512, l2);
-                }
-                const int npos4 = (4 + a.kh - 1) * (TILE_W + a.kw - 1);
-                if (npos4 <= 256) {
-                    const size_t l2 = 2 * (size_t)(2 * 64 * 128 + 2 * npos4 * 128);
-                    return go(&wgrad_tg_kernel<NTAPS, 4, 8>, grid, 512, l2);
                 }
             }
         }

@@ -231,6 +231,7 @@ struct WgradArgs {
     int a_Wfull;              // pixels per row of the full image (the batch stride is x_bstride)
     int use_org, org_y, org_x;  // tap (0,0) reads activation pixel (y + org_y, x + org_x) instead of (y - kh/2, x - kw/2)
     int dbg;                    // timing ablations, -DVPX_ABLATE builds only (VPX_WG_DBG: 1 = no multiply, 2 = stage the first item only)
+    int vec_all;                // set by launch_wgrad: every operand allows 16-byte vector loads (bf16 forms: unconditional load issue)
     int grid_x, grid_slices;    // set by launch_wgrad: logical grid (row tile x column tile, K slice) behind the XCD-aware 1-D launch
 };
 hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s);
