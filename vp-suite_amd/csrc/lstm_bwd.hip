@@ -293,6 +293,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
 // the MFMA fragments straight from the row-major tiles — no software transpose, no pre-shifted copies per tap.
 // k-step = one tile row (16 pixels): lanes 0-31 take pixels 0-7, lanes 32-63 pixels 8-15 (two tr reads of 4 rows each).
 // ---------------------------------------------------------------------------------------------------------------
+// out-of-range vectors of the unconditional loads read this instead (no mask, no select afterwards)
+__device__ const float wg_zero16[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
+
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -411,11 +414,12 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
         return true;
     };
     // vectors [u0, u0 + NU) of this thread: dG tile (128 pixels x 64 rows) and activation halo tile (npos x 64 channels)
-    // (the register-pipelined 8-wave forms keep the conditional loads: there the masks cost spills — PredRNN 5x5 step 401 vs 311 ms)
+    // (not in the register-pipelined 8-wave forms: measured slower there — PredRNN 5x5 training step 394 vs 310 ms; the
+    // prefetched vectors are spilled as soon as they are all in flight at once)
     constexpr bool UNCOND = RB == 1 && !PIPE;
     // a.vec_all (host-checked: every operand 16-byte aligned, channel counts and strides multiples of 4): the loads are
-    // issued unconditionally — out-of-range vectors read a safe address and are zeroed at store time through the returned
-    // mask. Loads under divergent branches make the compiler drain vmcnt between them (one memory latency EACH).
+    // issued unconditionally — out-of-range vectors read wg_zero16. Loads under divergent branches make the compiler
+    // drain vmcnt between them (one memory latency EACH). (The returned mask only serves the ragged path's callers.)
     auto load_g = [&](const ItemGeo& g, int u0, auto nu, auto& dst) -> unsigned {
         unsigned mask = 0;
 #pragma unroll
@@ -424,8 +428,8 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
             const int gy = g.y0 + (pp >> 4), gx = g.x0 + (pp & 15);
             if (UNCOND && a.vec_all) {
                 const bool ok = pp < 128 && gy < a.H && gx < a.W && n_col < a.N4;
-                dst[u] = *reinterpret_cast<const f32x4*>(g.dg + (ok ? ((size_t)gy * a.W + gx) * ldG + n_col : 0));
-                mask |= (ok ? 1u : 0u) << u;
+                dst[u] = *reinterpret_cast<const f32x4*>(ok ? g.dg + ((size_t)gy * a.W + gx) * ldG + n_col : wg_zero16);
+                mask |= 1u << u;
                 continue;
             }
             mask |= 1u << u;
@@ -465,8 +469,8 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
             long long pix = 0;
             if (UNCOND && a.vec_all) {
                 const bool ok = wg_apix(a, gy, gx, pix) && pos < npos && g.src != nullptr && c_col < g.C;
-                dst[u] = *reinterpret_cast<const f32x4*>((g.src ? g.src : g.dg) + (ok ? pix * g.C + c_col : 0));
-                mask |= (ok ? 1u : 0u) << u;
+                dst[u] = *reinterpret_cast<const f32x4*>(ok ? g.src + pix * g.C + c_col : wg_zero16);
+                mask |= 1u << u;
                 continue;
             }
             mask |= 1u << u;
@@ -665,10 +669,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
         hyx[u] = pos < npos ? ((hy << 16) | (pos - hy * halo_w)) : -1;
     }
     // Every load is issued unconditionally (16-byte vectors; the host routes unaligned / ragged-channel operands to the
-    // older kernels): out-of-range vectors read a safe address and are zeroed at store time through `okmask`. Straight-
-    // line issue matters: loads under divergent branches make the compiler drain vmcnt between them, one latency each.
+    // older kernels): out-of-range vectors read wg_zero16. Straight-line issue matters: loads under divergent branches
+    // make the compiler drain vmcnt between them, one latency each.
     f32x4 gv[GPRE], av[APRE];
-    unsigned okmask = 0;  // bit u: gv[u] valid, bit 16 + u: av[u] valid (of the item held in registers)
     auto load_item = [&](const Item& it) {
         const int y0 = it.ty * TH, x0 = it.tx * TILE_W;
         int C0, C1;
@@ -678,30 +681,26 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
         const int C = myhalf ? C1 : C0;
         const float* dg = a.dG + ((size_t)it.t * a.B + it.b) * a.HW * ldG;
         const bool a_ok = src != nullptr && c_col < C;
-        if (!src) src = a.dG;
-        okmask = 0;
 #pragma unroll
         for (int u = 0; u < GPRE; ++u) {
             const int pp = prow + 32 * u;
             const int gy = y0 + (pp >> 4), gx = x0 + (pp & 15);
             const bool ok = gy < a.H && gx < a.W && n_col < a.N4;
-            gv[u] = *reinterpret_cast<const f32x4*>(dg + (ok ? (gy * a.W + gx) * ldG + n_col : 0));
-            okmask |= (ok ? 1u : 0u) << u;
+            gv[u] = *reinterpret_cast<const f32x4*>(ok ? dg + (gy * a.W + gx) * ldG + n_col : wg_zero16);
         }
 #pragma unroll
         for (int u = 0; u < APRE; ++u) {
             const int gy = y0 - ph + (hyx[u] >> 16), gx = x0 - pw + (hyx[u] & 0xffff);
             long long pix = 0;
             const bool ok = wg_apix(a, gy, gx, pix) && hyx[u] >= 0 && a_ok;
-            av[u] = *reinterpret_cast<const f32x4*>(src + (ok ? (int)pix * C + c_col : 0));
-            okmask |= (ok ? 1u : 0u) << (16 + u);
+            av[u] = *reinterpret_cast<const f32x4*>(ok ? src + (int)pix * C + c_col : wg_zero16);
         }
     };
     auto store_item = [&](char* buf) {
 #pragma unroll
         for (int u = 0; u < GPRE; ++u) {
             uint2 hi, lo;
-            wg_split4((okmask >> u) & 1 ? gv[u] : f32x4{0.f, 0.f, 0.f, 0.f}, hi, lo);
+            wg_split4(gv[u], hi, lo);
             int off = (prow + 32 * u) * 128 + q4 * 8;
             off ^= (off >> 2) & 0x40;
             *reinterpret_cast<uint2*>(buf + off) = hi;
@@ -711,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
         for (int u = 0; u < APRE; ++u) {
             if (hyx[u] >= 0) {
                 uint2 hi, lo;
-                wg_split4((okmask >> (16 + u)) & 1 ? av[u] : f32x4{0.f, 0.f, 0.f, 0.f}, hi, lo);
+                wg_split4(av[u], hi, lo);
                 const int off = wg_aswz((prow + 32 * u) * 128 + q4 * 8);
                 *reinterpret_cast<uint2*>(buf + A_HI + off) = hi;
                 *reinterpret_cast<uint2*>(buf + A_LO + off) = lo;
