@@ -311,3 +311,34 @@ def test_eight_wave_workgroup_variant_vs_oracle(vpx, dev):
         assert _relmax(out, ro) < 2e-5 and _relmax(cT, rc) < 2e-5
         (out * g_out.to(dev)).sum().backward()   # the data-gradient conv takes the 8-wave form as well
         assert _relmax(lv["x"].grad, ref["x"].grad) < 1e-4 and _relmax(lv["W"].grad, ref["W"].grad) < 1e-4
+
+
+@pytest.mark.parametrize("k", [1, 3, 5])
+@pytest.mark.parametrize("Cin,with_x,with_h0", [(16, True, True), (3, True, False), (16, False, True)])
+def test_weight_gradient_forms_bf16x3_vs_oracle(vpx, dev, k, Cin, with_x, with_h0):
+    """Every launch form of the bf16x3 weight gradient against fp32 autograd of the oracle: 1x1 (single tap), 3x3 (tap-group
+    kernel: two LDS item buffers, multi-item walks per K slice, column tiles pairing x and h halves), 5x5 (8-wave / 128-row
+    form), a ragged channel count (scalar-load path), no input tensor, zero vs given initial state, ragged image edges."""
+    from oracle import torch_ref as tr
+    B, T, Ch, H, W = 12, 3, 32, 40, 24
+    tag = f"wgforms.{k}.{Cin}.{int(with_x)}.{int(with_h0)}"
+    Wt = seeded_randn((4 * Ch, Cin + Ch, k, k), name_seed(tag + "W"), 1.0 / np.sqrt((Cin + Ch) * k * k))
+    b = seeded_randn((4 * Ch,), name_seed(tag + "b"), 0.1)
+    pw = [seeded_randn((1, Ch, H, W), name_seed(tag + n), 0.1) for n in ("ci", "cf", "co")]
+    x = seeded_rand((B, T, Cin, H, W), name_seed(tag + "x")) if with_x else None
+    st = (seeded_randn((B, Ch, H, W), name_seed(tag + "h0"), 0.5), seeded_randn((B, Ch, H, W), name_seed(tag + "c0"), 0.5)) \
+        if with_h0 else None
+    g_out = seeded_randn((B, T, Ch, H, W), name_seed(tag + "go"))
+    rW, rb = Wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ro, _ = tr.convlstm_hzzone_seq(x, st, T, rW, rb, *pw, padding=k // 2)
+    (ro * g_out).sum().backward()
+    lW, lb = Wt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    out, hT, cT = vpx.ops.convlstm_seq(None if x is None else x.to(dev), None if st is None else st[0].to(dev),
+                                       None if st is None else st[1].to(dev), lW, lb, *[p.to(dev) for p in pw],
+                                       seq_len=T, in_channels=Cin, precision="bf16x3")
+    assert _relmax(out, ro) < 2e-5
+    (out * g_out.to(dev)).sum().backward()
+    # without an input tensor the x columns of dW get no contribution on either side (exact zeros)
+    assert _relmax(lW.grad, rW.grad) < 1e-4 and _relmax(lb.grad, rb.grad) < 1e-4
+    if not with_x:
+        assert torch.count_nonzero(lW.grad[:, :Cin]) == 0
