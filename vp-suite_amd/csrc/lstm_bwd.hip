@@ -718,8 +718,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
         }
     };
     // TH k-steps (tile rows) of 16 pixels. ONE copy of the loop serves both wave groups (two copies made the compiler
-    // spill the prefetched vectors): the TB taps both groups have, in batches of <= 3 with the three terms issued term-major
-    // (consecutive MFMAs accumulate into different tiles), then group 0's extra tap under a scalar branch.
+    // spill the prefetched vectors): the TB taps both groups have as one batch with the three terms issued term-major
+    // (consecutive MFMAs accumulate into different tiles), then group 0's extra tap under a scalar branch. Measured
+    // alternatives (64ch 64x64 block, B=128: this 4.32 ms): batches of <= 3 taps without unrolling 4.65; a branch-free block
+    // of TA taps with a repeated tap in group 1's spare slot 5.24; the odd tap split over k between the groups 5.66; an
+    // explicit sched_barrier-fenced read-ahead pipeline 5.31 — each loses to spills of the prefetched vectors.
     auto tap_batch = [&](const char* buf, const bf16x8& gh, const bf16x8& gl, int arow, auto t0_c, auto nb_c, auto lo_c) {
         constexpr int T0 = decltype(t0_c)::value, NB = decltype(nb_c)::value;
         constexpr bool LO = decltype(lo_c)::value;
@@ -741,14 +744,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
     };
     auto multiply = [&](const char* buf, auto lo_c) {
         constexpr bool LO = decltype(lo_c)::value;
-#pragma unroll 1
+#pragma unroll 2
         for (int s = 0; s < TH; ++s) {
             const bf16x8 gh = wg_tr_frag(buf + g_lane + s * 16 * 128);
             bf16x8 gl = gh;
             if constexpr (LO) gl = wg_tr_frag(buf + G_LO + g_lane + s * 16 * 128);
             const int arow = a_lane + s * halo_w * 128;
-            if constexpr (TB >= 1) tap_batch(buf, gh, gl, arow, std::integral_constant<int, 0>{}, std::integral_constant<int, (TB < 3 ? TB : 3)>{}, lo_c);
-            if constexpr (TB >= 4) tap_batch(buf, gh, gl, arow, std::integral_constant<int, 3>{}, std::integral_constant<int, TB - 3>{}, lo_c);
+            if constexpr (TB >= 1) tap_batch(buf, gh, gl, arow, std::integral_constant<int, 0>{}, std::integral_constant<int, TB>{}, lo_c);
             if constexpr (TA > TB) {
                 if (tg == 0) tap_batch(buf, gh, gl, arow, std::integral_constant<int, TB>{}, std::integral_constant<int, 1>{}, lo_c);
             }
