@@ -9,20 +9,21 @@ for line in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VAL
   rocprofv3 --pmc $line --kernel-trace --output-format csv -d $OUT/p$i -- python3 bench.py --mode train --steps 1 --warmup 1 --batch ${BB:-32} --no-cpu-baseline > /dev/null 2>&1
 done
 python3 - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, os
+KERNEL = os.environ.get("WG_KERNEL", "wgrad_tg_kernel<9, 8, 6>")  # the 3x3 tap-group form; WG_KERNEL=... for another
 agg = collections.defaultdict(list); dur = []
 for f in glob.glob("gpurun_out/pmc_wgrad/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "wgrad_bf16x3_kernel<9, 0, 0, 1>" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob("gpurun_out/pmc_wgrad/p1/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "wgrad_bf16x3_kernel<9, 0, 0, 1>" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 m = {k: sum(v) / len(v) for k, v in agg.items()}
 us = sum(dur) / len(dur) / 1e3
 cyc = m["GRBM_GUI_ACTIVE"] / 8
-print(f"wgrad<9>: {len(dur)} launches, avg {us:.0f} us, {cyc/us/1e3:.2f} GHz, MFMA busy {m['SQ_VALU_MFMA_BUSY_CYCLES']/(1024*cyc)*100:.1f} %")
+print(f"{KERNEL}: {len(dur)} launches, avg {us:.0f} us, {cyc/us/1e3:.2f} GHz, MFMA busy {m['SQ_VALU_MFMA_BUSY_CYCLES']/(1024*cyc)*100:.1f} %")
 for k in sorted(m): print(f"  {k:28s} {m[k]:16.0f}")
 PY
 find $OUT -name "*.csv" -delete
