@@ -97,7 +97,8 @@ def cpu_baseline(model, args):
     return {"value": round(fps, 2), "unit": "predicted frames/s", "cores": threads, "kind": "port",
             "sample": f"oracle/torch_ref.ef_convlstm_forward (PyTorch-CPU restatement of the reference path), "
                       f"batch {b}, {args.context}->{args.pred}, {args.channels}x{args.img}x{args.img}, "
-                      f"{n} iterations in {el:.1f} s on {threads} of {all_cores} host threads (best of a 3-point scan)"}
+                      f"{n} iterations in {el:.1f} s on {threads} of {all_cores} host threads (best point of a 3-point thread scan, "
+                      f"~{args.cpu_seconds:.0f} s of CPU work in total)"}
 
 
 def main():
