@@ -575,12 +575,13 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradient, split-bf16 operands, tap-group form: 8 waves = 2 (gate rows) x 2 (channel halves) x 2 (TAP GROUPS).
 // The 64 x 64 x MAXT output tile of a workgroup is spread over 512 threads, so a wave carries ceil(MAXT/2) accumulator
-// tiles (80 registers for 3x3) instead of nine: the k-loop has the registers to keep a whole k-step's LDS reads in
-// flight under the MFMAs, and an item's global loads (GPRE + APRE vectors per thread) wait in registers for a full item.
+// tiles (80 registers for 3x3) instead of nine: room for the hi-plane fragments of a whole k-step in flight under the
+// MFMAs and for an item's global loads (GPRE + APRE vectors per thread), which wait in registers for a full item.
 // LDS holds TWO item buffers. Per item and wave:   group 0:  multiply(i)  -> split+store(i+1) -> load(i+2)
 //                                                   group 1:  split+store(i+1) -> load(i+2) -> multiply(i)
 // (one barrier per item). Every SIMD hosts one wave of each group, so the VALU work of the hi/lo split runs under the
-// other wave's MFMAs. TH = tile rows per item (8: kernels up to 3x3; 4: up to 7x7 — two buffers must fit 160 KB).
+// other wave's MFMAs (waves w and w+4 of a workgroup share a SIMD). TH = tile rows per item: two buffers must fit the
+// 160 KB, i.e. TH = 8 for kernels up to 3x3 (the only instantiation; TH = 4 for 5x5 lost to the 128-row form).
 // ---------------------------------------------------------------------------------------------------------------
 // workgroup barrier that orders LDS traffic only: outstanding global loads (the next item, held in registers) stay in flight
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
