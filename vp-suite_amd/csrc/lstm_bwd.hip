@@ -586,7 +586,9 @@ __global__ __launch_bounds__(NTHREADS * RB, (RB == 2 ? 2 : (PIPE ? 1 : 2))) void
 // workgroup barrier that orders LDS traffic only: outstanding global loads (the next item, held in registers) stay in flight
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int MAXT, int TH, int APRE>
+// DB = false: ONE item buffer (5x5 / 7x7 halo tiles: two do not fit) — every wave stores item i, multiplies it with the
+// loads of item i+1 in flight, two barriers per item; the tap groups still halve the accumulator registers.
+template <int MAXT, int TH, int APRE, bool DB = true>
 __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, const int tap_base) {
     constexpr int NTH = 512;
     constexpr int TA = (MAXT + 1) / 2, TB = MAXT - TA;  // taps of group 0 / group 1
@@ -764,11 +766,23 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
 
     Item nxt = cur;
     advance(nxt);
-    if (cur.t < a.T) { load_item(cur); store_item(smem); }
-    if (nxt.t < a.T) load_item(nxt);
+    if constexpr (!DB) {
+        if (cur.t < a.T) load_item(cur);
+        while (cur.t < a.T) {
+            wg_lds_barrier();  // every wave is done reading the previous item
+            store_item(smem);
+            wg_lds_barrier();
+            if (nxt.t < a.T) load_item(nxt);  // in flight during the multiply
+            multiply_g(smem);
+            cur = nxt;
+            advance(nxt);
+        }
+    }
+    if (DB && cur.t < a.T) { load_item(cur); store_item(smem); }
+    if (DB && nxt.t < a.T) load_item(nxt);
     __syncthreads();
     int bsel = 0;
-    while (cur.t < a.T) {
+    while (DB && cur.t < a.T) {
         char* bcur = smem + bsel * BUF;
         char* bnxt = smem + (bsel ^ 1) * BUF;
         Item nn = nxt;
@@ -866,6 +880,10 @@ static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int ta
                     const size_t l2 = 2 * (size_t)(2 * 128 * 128 + 2 * npos * 128);
                     return go(&wgrad_tg_kernel<NTAPS, 8, 6>, grid, 512, l2);
                 }
+                static int tg1_env = -1;  // VPX_WGRAD_TG1=0: larger kernels on the 128-row form below
+                if (tg1_env < 0) { const char* e = getenv("VPX_WGRAD_TG1"); tg1_env = e ? atoi(e) : 1; }
+                if (tg1_env && npos <= 256)  // up to 5x5: one item buffer, 8 activation vectors per thread
+                    return go(&wgrad_tg_kernel<NTAPS, 8, 8, false>, grid, 512, (size_t)(2 * 128 * 128 + 2 * npos * 128));
             }
         }
         static int rb_env = -1;  // VPX_WGRAD_RB=1 forces the 4-wave, 64-row form
