@@ -734,7 +734,7 @@ int plain_groups(int Co, long long m_tiles) {
     return best;
 }
 
-int pick_ksplit(long long wgs, int nstage) {
+int pick_ksplit(long long wgs, int nstage, bool bwd) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("VPX_KSPLIT"); forced = e ? atoi(e) : 0; }
     if (g_deterministic) return 1;
@@ -743,6 +743,10 @@ int pick_ksplit(long long wgs, int nstage) {
     // aim at one workgroup per CU: measured on 16x16 maps (64 pixel tiles), PredRNN forward 25.8 ms with 12 splits,
     // 24.7 ms with 4, 28.7 ms with 3; ConvLSTM (96,96,16x16) B=32 (192 workgroups) 155 TF fused, 164 TF with 2 splits
     else if (wgs > 0 && wgs < 256) k = (int)((256 + wgs - 1) / wgs);
+    // data-gradient convs at exactly one workgroup per CU unsplit (PredRNN's 16x16 maps at B=128: 256 pixel tiles x 1 N
+    // tile): two halves of K per tile give every CU a second workgroup to overlap with (training step 260.5 -> 252.9 ms;
+    // 4 splits 269.4). Not in the forward pass: its split convs pay a clear + a separate output pass (inference 58.9 -> 60.1 ms)
+    else if (bwd && wgs >= 256 && wgs < 384) k = 2;
     if (k > nstage) k = nstage;
     if (k > 16) k = 16;
     return k < 1 ? 1 : k;

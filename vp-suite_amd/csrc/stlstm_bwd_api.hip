@@ -29,7 +29,7 @@ int mk_dg(STBwdLayout::DG& g, const int* segC, int nseg, int k, int n_out, int p
     g.nstage = build_stages(g.stage, &g.chunks, segC, nseg, taps, pick_stage_channels(segC, nseg, k, k, g.ng, prec, g.mw), prec);
     if (g.nstage < 0) return -1;
     g.tiles = plain_tiles_ng(n_out, g.ng);
-    g.ksplit = pick_ksplit(m_tiles * g.tiles, g.nstage);  // 16x16 maps: 64 pixel tiles per launch, K = gates*Ch*k*k is long
+    g.ksplit = pick_ksplit(m_tiles * g.tiles, g.nstage, true);  // 16x16 maps: 64 pixel tiles per launch, K = gates*Ch*k*k is long
     g.wpk = packed_weight_bytes(g.tiles, g.chunks, g.ng, prec) / 4;
     return 0;
 }

@@ -135,7 +135,7 @@ hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, i
 // channel padding (ties -> wider tiles: fewer re-reads of the activation tile).
 int plain_groups(int Co, long long m_tiles = -1);
 // K split of a plain convolution whose grid would have only `wgs` workgroups: number of stage ranges (1 = no split)
-int pick_ksplit(long long wgs, int nstage);
+int pick_ksplit(long long wgs, int nstage, bool bwd = false);  // bwd: a data-gradient conv (see the rule in conv_gemm.hip)
 extern int g_deterministic;  // vpx_set_deterministic(): 1 = never split K (no floating-point atomics)
 inline int plain_tiles_ng(int Co, int ng) { return (Co + 32 * ng - 1) / (32 * ng); }
 inline int plain_tiles(int Co) { return plain_tiles_ng(Co, plain_groups(Co)); }
