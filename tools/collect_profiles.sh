@@ -1,5 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 evidence for the bench's dominant kernel. Outputs under gpurun_out/prof_final/.
+# gpurun MERGES the outputs into the local gpurun_out/: remove the local gpurun_out/prof_final first (or rely on
+# summarize_profiles.py picking the newest file of each kind).
 # Counters are collected in their own passes with --kernel-trace only (never with sys/hip tracing).
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"

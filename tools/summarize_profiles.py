@@ -19,8 +19,10 @@ DOMINANT = "EpiConvLSTM"
 
 
 def one(pattern):
+    # gpurun MERGES each call's outputs into the local gpurun_out/: files of earlier collections (other pids in the
+    # name) stay next to the new ones, so always take the most recent match
     f = glob.glob(os.path.join(SRC, pattern))
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None
 
 
 # One "cell step" is either one fused launch (EpiConvLSTM) or, on nearly-empty grids, the K-split trio
