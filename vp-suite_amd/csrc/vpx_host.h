@@ -80,6 +80,13 @@ static inline int pick_qpc(const int* segC, int nseg, int kh, int kw, int ng, in
     return residency(3) >= residency(2) ? 3 : 2;
 }
 
+// workgroups a weight-gradient launch aims at (K slices x output tiles); VPX_WGRAD_WGS overrides (experiments)
+static inline int wgrad_target_wgs() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VPX_WGRAD_WGS"); v = e ? atoi(e) : 1024; }
+    return v;
+}
+
 struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     int taps, n_tiles, nstage, chunks_total;
     int mw;                        // forward cell kernel: 32-pixel row tiles per wave
@@ -145,7 +152,7 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
         const int tiles = ((d->W + TILE_W - 1) / TILE_W) * ((d->H + TILE_H - 1) / TILE_H);
         const long long items = (long long)d->T * d->B * tiles;
         const int out_tiles = ((N4 + 63) / 64) * L.n_ctiles * ((L.taps + 8) / 9);
-        long long ns = (1024 + out_tiles - 1) / out_tiles;
+        long long ns = (wgrad_target_wgs() + out_tiles - 1) / out_tiles;
         if (ns > items) ns = items;
         if (ns > 256) ns = 256;
         if (ns < 1) ns = 1;
@@ -235,7 +242,7 @@ static inline int wgrad_slices(int N, int H, int W) {
 // slices actually launched: enough for ~1024 workgroups (each slice costs a slab write + a reduce read of all of dW)
 static inline int wgrad_pick_slices(int cap, int rows, int n_ctiles, int taps) {
     const int out_tiles = ((rows + 63) / 64) * n_ctiles * ((taps + 8) / 9);
-    int ns = (1024 + out_tiles - 1) / out_tiles;
+    int ns = (wgrad_target_wgs() + out_tiles - 1) / out_tiles;
     if (ns > cap) ns = cap;
     return ns < 1 ? 1 : ns;
 }
