@@ -98,9 +98,14 @@ int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* ad
     if (d_delta_c && (rc = plain_conv(stream, VPX_PREC_F32, g, dyc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_c, Ch, false, wpk))) return rc;
     if (d_delta_m && (rc = plain_conv(stream, VPX_PREC_F32, g, dym, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_m, Ch, false, wpk))) return rc;
     if (d_adapter) {
-        if ((rc = plain_wgrad(stream, VPX_PREC_F32, g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter))) return rc;
-        if ((rc = plain_wgrad(stream, VPX_PREC_F32, g, dym, Ch, delta_m, Ch, 1, 1, slabs, dA2))) return rc;
-        VPX_CHECK_HIP(launch_axpy(d_adapter, dA2, (long long)Ch * Ch, stream));
+        if (dym == dyc + n && (((uintptr_t)delta_c ^ (uintptr_t)delta_m) & 15) == 0) {
+            // both pairs in ONE launch (the c and m halves are two "time steps"): one weight gradient + reduce instead of two + an add
+            if ((rc = plain_wgrad(stream, VPX_PREC_F32, g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter, delta_m))) return rc;
+        } else {
+            if ((rc = plain_wgrad(stream, VPX_PREC_F32, g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter))) return rc;
+            if ((rc = plain_wgrad(stream, VPX_PREC_F32, g, dym, Ch, delta_m, Ch, 1, 1, slabs, dA2))) return rc;
+            VPX_CHECK_HIP(launch_axpy(d_adapter, dA2, (long long)Ch * Ch, stream));
+        }
     }
     return VPX_OK;
 }

@@ -108,6 +108,9 @@ hipError_t launch_colsum(const float* m, float* out, long long rows, int cols, h
 // LDS: dG tile [128 px][64 rows] (32 KiB) + activation halo tile [halo positions][64 ch].
 // Each wave owns a 32 (rows) x 32 (channels) output block for up to WG_MAXT taps: acc[tap] += dG^T (px-contracted) A_tap.
 // ---------------------------------------------------------------------------------------------------------------
+// out-of-range vectors of the unconditional loads read this instead (no mask, no select afterwards)
+__device__ const float wg_zero16[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
+
 // activation pixel (gy, gx) of the map the taps slide over -> element offset (in pixels) inside the source image, or false
 __device__ __forceinline__ bool wg_apix(const WgradArgs& a, int gy, int gx, long long& pix) {
     if (a.a_sub) {
@@ -204,14 +207,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
         __syncthreads();
         // ---- stage dG tile: 128 pixels x 64 rows ----
         if (((a.N4 | ldG) & 3) == 0 && (reinterpret_cast<uintptr_t>(dg) & 15) == 0) {
+            // (unconditional loads, out-of-range vectors from wg_zero16: see the bf16 forms — loads under a branch are drained one by one)
+#pragma unroll 4
             for (int v = tid; v < 128 * 16; v += NTHREADS) {
                 const int p = v >> 4, q4 = v & 15;
                 const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
                 const int n = n0 + q4 * 4;
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (gy < a.H && gx < a.W && n < a.N4)
-                    val = *reinterpret_cast<const f32x4*>(dg + ((size_t)gy * a.W + gx) * ldG + n);
-                *reinterpret_cast<f32x4*>(G_lds + p * 64 + q4 * 4) = val;
+                const bool ok = gy < a.H && gx < a.W && n < a.N4;
+                *reinterpret_cast<f32x4*>(G_lds + p * 64 + q4 * 4) =
+                    *reinterpret_cast<const f32x4*>(ok ? dg + ((size_t)gy * a.W + gx) * ldG + n : wg_zero16);
             }
         } else {
             for (int e = tid; e < 128 * 64; e += NTHREADS) {
@@ -225,16 +229,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
         }
         // ---- stage activation halo tile: npos x (2 halves x 32 channels) ----
         if (a_vec) {
+#pragma unroll 4
             for (int v = tid; v < npos * 16; v += NTHREADS) {
                 const int pos = v >> 4, q4 = v & 15;
                 const int hy = pos / halo_w, hx = pos - hy * halo_w;
                 const int gy = y0 - ph + hy, gx = x0 - pw + hx;
                 const int c = myh.c0 + (q4 & 7) * 4;
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                long long pix;
-                if (src && c < C && wg_apix(a, gy, gx, pix))
-                    val = *reinterpret_cast<const f32x4*>(src + pix * C + c);
-                *reinterpret_cast<f32x4*>(A_lds + pos * 64 + q4 * 4) = val;
+                long long pix = 0;
+                const bool ok = wg_apix(a, gy, gx, pix) && src && c < C;
+                *reinterpret_cast<f32x4*>(A_lds + pos * 64 + q4 * 4) =
+                    *reinterpret_cast<const f32x4*>(ok ? src + pix * C + c : wg_zero16);
             }
         } else {
             for (int e = tid; e < npos * 64; e += NTHREADS) {
@@ -293,9 +297,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WgradArgs a, c
 // the MFMA fragments straight from the row-major tiles — no software transpose, no pre-shifted copies per tap.
 // k-step = one tile row (16 pixels): lanes 0-31 take pixels 0-7, lanes 32-63 pixels 8-15 (two tr reads of 4 rows each).
 // ---------------------------------------------------------------------------------------------------------------
-// out-of-range vectors of the unconditional loads read this instead (no mask, no select afterwards)
-__device__ const float wg_zero16[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
-
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 

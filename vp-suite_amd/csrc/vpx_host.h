@@ -248,10 +248,13 @@ static inline int wgrad_pick_slices(int cap, int rows, int n_ctiles, int taps) {
 }
 
 // dw[Co, C, kh, kw] (+)= wgrad(dy [N,HW,Co], x [N,HW,C])
+// x2: a second operand pair in the same launch — dw = wgrad(dy, x) + wgrad(dy + N*HW*Co, x2) (the two pairs become
+// "time steps" 0 and 1 of one item walk; x2 may live anywhere, its distance from x is just the step stride)
 static inline int plain_wgrad(hipStream_t stream, int prec, ConvGeo g, const float* dy, int Co, const float* x, int C, int kh, int kw,
-                float* slabs, float* dw) {
+                float* slabs, float* dw, const float* x2 = nullptr) {
     WgradArgs wa{};
-    wa.T = 1; wa.B = g.N; wa.H = g.H; wa.W = g.W; wa.HW = g.H * g.W; wa.kh = kh; wa.kw = kw;
+    wa.T = x2 ? 2 : 1; wa.x_tstride = x2 ? (long long)(x2 - x) : 0;
+    wa.B = g.N; wa.H = g.H; wa.W = g.W; wa.HW = g.H * g.W; wa.kh = kh; wa.kw = kw;
     wa.tiles_x = (g.W + TILE_W - 1) / TILE_W; wa.tiles_y = (g.H + TILE_H - 1) / TILE_H;
     wa.N4 = Co; wa.Cin = C; wa.Ch = 1; wa.Ct = C; wa.ldG = Co; wa.n_out = Co; wa.prec = prec;
     wa.dG = dy; wa.x = x; wa.x_bstride = (long long)wa.HW * C;
