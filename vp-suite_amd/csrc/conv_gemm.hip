@@ -724,11 +724,16 @@ hipError_t launch_conv_plain_f32(const ConvPlan& plan_in, const PlainEpiArgs& ea
 }
 
 int plain_groups(int Co, long long m_tiles) {
-    int best = 4, best_pad = 1 << 30;
-    for (int ng = 4; ng >= 1; --ng) {  // ties -> more groups per tile (fewer re-reads of the activation tile)
-        const int w = ng * 32;
-        const int padded = (Co + w - 1) / w * w;
-        if (padded < best_pad) { best_pad = padded; best = ng; }
+    // Every N tile stages the activation halo tile again, so the narrowest padding is not the cheapest split: cost of a
+    // pixel tile ~ n_tiles * (STAGE + ng) in units of one 32-channel group's MFMA work, STAGE = 2 (the data-gradient
+    // conv of the 64+96-channel ConvLSTM, Co = 160 at 32x32, B=128: five 32-wide tiles 921 us, two 96-wide tiles 862 us
+    // although they multiply 20 % padding). Ties -> more groups per tile.
+    constexpr int STAGE = 2;
+    int best = 4, best_cost = 1 << 30;
+    for (int ng = 4; ng >= 1; --ng) {
+        const int tiles = (Co + ng * 32 - 1) / (ng * 32);
+        const int cost = tiles * (STAGE + ng);
+        if (cost < best_cost) { best_cost = cost; best = ng; }
     }
     (void)m_tiles;  // occupancy on small maps comes from the K split (pick_ksplit), not from narrower N tiles
     return best;
