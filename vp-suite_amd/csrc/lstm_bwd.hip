@@ -3,6 +3,9 @@
 //   convlstm_gate_bwd_kernel  HBM-bound: d(pre-activations) from (dh, dc), carries dc, reduces peephole grads over b
 //   wgrad_kernel              dW partials: M = 64 gate rows, N = 64 input channels, all taps of a tap group at once,
 //                             K = pixels of the (t, b, tile) work items of one K-slice; fp32 MFMA 32x32x2
+//   wgrad_tg_kernel           the same contraction on split-bf16 operands (bf16x3 / bf16), 8 waves = rows x channel halves x
+//                             tap groups, transposing LDS reads; two item buffers (up to 3x3) or one (5x5)
+//   wgrad_bf16x3_kernel       older bf16 forms: 4-wave (ragged / unaligned operands, 1x1) and 8-wave 128-row (7x7 and larger)
 //   wgrad_reduce_kernel       sums the K-slices and writes the reference's OIHW layout
 //   colsum_kernel             bias gradient
 #include "vpx_internal.h"
