@@ -50,7 +50,9 @@ enum { VPX_PREC_F32 = 0    /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 operands 
        VPX_PREC_BF16 = 2   /* bf16 operands, fp32 accumulate, fp32 state and I/O */ };
 enum { VPX_FLAG_SAVE_FOR_BWD = 1 /* forward fills `reserve` (gate activations + cell states per step) */,
        VPX_FLAG_WEIGHTS_PACKED = 2 /* ST-LSTM: `workspace` still holds the repacked weights of a previous call with the
-                                      SAME weight values and desc (caller keeps one workspace per cell per forward) */ };
+                                      SAME weight values and desc (caller keeps one workspace per cell per forward; the
+                                      backward has its own workspace and additionally needs the same set of requested
+                                      data gradients dx / dh / dm as the call that packed) */ };
 
 typedef struct vpx_convlstm_desc {
     int32_t B, T, Cin, Ch, H, W, kh, kw; /* padding is kh/2, kw/2 ("same"), stride 1 — the only form the cells use */

@@ -223,3 +223,31 @@ def test_flat_adam_invalidates_packed_weight_caches(vpx):
         p1, _ = m1(frames, pred_frames=3)
         p2, _ = m2(frames, pred_frames=3)
     assert (p1 - p2).abs().max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_backward_weight_pack_reuse_matches_repacking(vpx, monkeypatch):
+    """The ST-LSTM backward keeps its five transposed weight packs in a per-cell workspace while the weights are unchanged
+    (VPX_FLAG_WEIGHTS_PACKED); VPX_NO_BWD_HOLDER=1 repacks on every call. Two optimizer steps (the weights change in
+    between, the packs must follow) give the same model either way."""
+    import copy
+    from vp_suite_amd.models import MODEL_CLASSES
+    torch.manual_seed(5)
+    kw = dict(img_shape=(1, 16, 16), action_size=0, tensor_value_range=[0.0, 1.0], num_layers=2, num_hidden=[8, 8],
+              patch_size=2, filter_size=3)
+    m1 = MODEL_CLASSES["predrnn-pp"]("cuda", **kw).to("cuda")
+    m2 = copy.deepcopy(m1)
+    frames = torch.rand(2, 6, 1, 16, 16, device="cuda")
+    for m, env in ((m1, None), (m2, "1")):
+        if env is None:
+            monkeypatch.delenv("VPX_NO_BWD_HOLDER", raising=False)
+        else:
+            monkeypatch.setenv("VPX_NO_BWD_HOLDER", env)
+        o = torch.optim.Adam(m.parameters(), lr=1e-2)
+        for _ in range(2):
+            o.zero_grad()
+            pred, losses = m(frames, pred_frames=3, train=False)
+            (((pred - frames[:, 3:]) ** 2).mean() + sum(losses.values())).backward()
+            o.step()
+    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert (p1 - p2).abs().max() < 1e-6, n1

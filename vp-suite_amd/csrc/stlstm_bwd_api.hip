@@ -138,6 +138,10 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
                              dx, dh, dc, dm, dWx, dWh, dWm, dWo, dWlast, dln, w2, stream);
     }
 
+    // VPX_FLAG_WEIGHTS_PACKED: `workspace` is the one a previous backward call of the SAME cell, weights, shape and set of
+    // requested data gradients left behind — its five transposed weight packs are reused (PredRNN: 57 cell steps per
+    // training step share four cells' weights)
+    const bool packed = (d->flags & VPX_FLAG_WEIGHTS_PACKED) != 0;
     Carver ws{(char*)workspace, 0, workspace_bytes};
     ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
     float* dG7 = ws.take(L.n_g7);
@@ -214,7 +218,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         PackDesc pd{};
         pd.seg[0] = PackSeg{Wo, (long long)2 * Ch * L.taps, L.taps, 0, Ch};
         pack_plain_T(pd, L.o, L.taps, 2 * Ch);
-        VPX_CHECK_HIP(launch_pack_weights(pd, wpk_o, stream));
+        if (!packed) VPX_CHECK_HIP(launch_pack_weights(pd, wpk_o, stream));
         ConvPlan P = plan_for(L.o, k, wpk_o);
         P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG};
         PlainEpiArgs ea{};
@@ -227,7 +231,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         PackDesc pl{};
         pl.seg[0] = PackSeg{Wlast, (long long)2 * Ch, 1, 0, Ch};
         pack_plain_T(pl, L.l, 1, 2 * Ch);
-        VPX_CHECK_HIP(launch_pack_weights(pl, wpk_l, stream));
+        if (!packed) VPX_CHECK_HIP(launch_pack_weights(pl, wpk_l, stream));
         ConvPlan Q = plan_for(L.l, 1, wpk_l);
         Q.nseg = 1; Q.seg[0] = ConvSeg{dlc, (long long)(HW * Ch), Ch, 0};
         ea.accumulate = 1;
@@ -252,7 +256,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         pd.seg[1] = PackSeg{Wx, ldo, L.taps, 6 * Ch, Ch};       // dG7 block  o           <-> Wx row block 6
         pd.seg[2] = PackSeg{Wx, ldo, L.taps, 3 * Ch, 3 * Ch};   // dG7 blocks (i',f',g')  <-> Wx row blocks 3,4,5
         pack_plain_T(pd, L.x, L.taps, Cin);
-        VPX_CHECK_HIP(launch_pack_weights(pd, wpk_x, stream));
+        if (!packed) VPX_CHECK_HIP(launch_pack_weights(pd, wpk_x, stream));
         ConvPlan P = plan_for(L.x, k, wpk_x);
         P.nseg = 3;
         P.seg[0] = ConvSeg{dG7, (long long)(HW * ldG), 3 * Ch, ldG};
@@ -267,7 +271,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         PackDesc pd{};
         pd.seg[0] = PackSeg{Wh, (long long)Ch * L.taps, L.taps, 0, 4 * Ch};
         pack_plain_T(pd, L.h, L.taps, Ch);
-        VPX_CHECK_HIP(launch_pack_weights(pd, wpk_h, stream));
+        if (!packed) VPX_CHECK_HIP(launch_pack_weights(pd, wpk_h, stream));
         ConvPlan P = plan_for(L.h, k, wpk_h);
         P.nseg = 1; P.seg[0] = ConvSeg{dG7, (long long)(HW * ldG), 4 * Ch, ldG};
         PlainEpiArgs ea{};
@@ -279,7 +283,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         PackDesc pd{};
         pd.seg[0] = PackSeg{Wm, (long long)Ch * L.taps, L.taps, 0, 3 * Ch};
         pack_plain_T(pd, L.m, L.taps, Ch);
-        VPX_CHECK_HIP(launch_pack_weights(pd, wpk_m, stream));
+        if (!packed) VPX_CHECK_HIP(launch_pack_weights(pd, wpk_m, stream));
         ConvPlan P = plan_for(L.m, k, wpk_m);
         P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG};
         PlainEpiArgs ea{};

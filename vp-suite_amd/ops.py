@@ -2,6 +2,7 @@
 ([B,T,C,H,W], [B,C,H,W]) but live channels-last in memory (NHWC) so that kernels get coalesced channel rows and the
 glue convolutions of the models (MIOpen, channels_last) exchange activations with them without a copy."""
 import ctypes
+import os
 
 import torch
 
@@ -462,6 +463,12 @@ class STWorkspace:
     def __init__(self):
         self.buf = None
         self.key = None
+        self.bwd = None  # the backward's own holder (different workspace layout, transposed packs)
+
+    def backward_holder(self):
+        if self.bwd is None:
+            self.bwd = STWorkspace()
+        return self.bwd
 
     def get(self, nbytes, device, key):
         """Returns (buffer, packed_valid)."""
@@ -521,6 +528,8 @@ class _STLSTMStepFn(torch.autograd.Function):
             ctx.desc = d
             ctx.rs_bytes = rs_bytes
             ctx.use_ln = use_ln
+            ctx.bwd_holder = wsholder.backward_holder() if (wsholder is not None and not use_ln) else None
+            ctx.wkey = key
         return tuple(outs)
 
     @staticmethod
@@ -543,11 +552,19 @@ class _STLSTMStepFn(torch.autograd.Function):
         ln_arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in lnc]) if ctx.use_ln else None
         dln_arr = (ctypes.c_void_p * 8)(*[None if t is None else t.data_ptr() for t in dln]) if ctx.use_ln else None
         ws_bytes = L.vpx_stlstm_workspace_bytes(ctypes.byref(d))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        flags0 = d.flags
+        if ctx.bwd_holder is not None and not os.environ.get("VPX_NO_BWD_HOLDER"):
+            # (which transposed packs a call makes depends on the data gradients it is asked for)
+            ws, packed = ctx.bwd_holder.get(ws_bytes, dev, (ctx.wkey, dx is not None, dh is not None, dm is not None))
+            if packed:
+                d.flags = flags0 | _lib.FLAG_WEIGHTS_PACKED
+        else:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         rc = L.vpx_stlstm_step_bwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), ptr(c_new), ptr(m_new), ptr(Wx),
                                    ptr(Wh), ptr(Wm), ptr(Wo), ptr(Wlast), ln_arr, ptr(reserve), ctx.rs_bytes,
                                    *[ptr(g) for g in gin], ptr(dx), ptr(dh), ptr(dc), ptr(dm), *[ptr(g) for g in dWs],
                                    dln_arr, ptr(ws), ws_bytes, _stream())
+        d.flags = flags0
         check(rc, "vpx_stlstm_step_bwd")
         return (dx, dh, dc, dm, *dWs, None, None, None, *dln)
 
