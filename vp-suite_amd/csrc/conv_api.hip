@@ -42,6 +42,21 @@ int vpx_conv2d_nhwc_bwd(const float* x, const float* w, const float* dy, float* 
 }
 
 /* ---- decoupling-loss tail ---------------------------------------------------------------------------------- */
+}  // extern "C"
+// The adapter (1x1, Ch -> Ch; transposed = its adjoint) applied to the c and the m operand. When both the sources and the
+// destinations are adjacent in memory ([2, B, HW, Ch]: the cell step hands out delta_c | delta_m as one block, the
+// workspace slots are adjacent) the pair is ONE convolution over 2B images — these launches are latency-bound (K = Ch).
+static int decouple_adapter_pair(hipStream_t stream, ConvGeo g, const float* sc, const float* sm, const float* adapter,
+                                 float* oc, float* om, size_t n, int Ch, bool transposed, float* wpk) {
+    int rc;
+    if (sm == sc + n && om == oc + n) {
+        const ConvGeo g2{2 * g.N, g.H, g.W};
+        return plain_conv(stream, VPX_PREC_F32, g2, sc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, transposed, nullptr, oc, Ch, false, wpk);
+    }
+    if ((rc = plain_conv(stream, VPX_PREC_F32, g, sc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, transposed, nullptr, oc, Ch, false, wpk))) return rc;
+    return plain_conv(stream, VPX_PREC_F32, g, sm, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, transposed, nullptr, om, Ch, false, wpk);
+}
+extern "C" {
 size_t vpx_decouple_workspace_bytes(int B, int Ch, int H, int W) {
     if (B < 1 || Ch < 1 || H < 1 || W < 1) return 0;
     const size_t n = (size_t)B * H * W * Ch;
@@ -64,8 +79,7 @@ int vpx_decouple_fwd(const float* delta_c, const float* delta_m, const float* ad
     float* wpk = ws.take(plain_conv_wpk_floats(Ch, Ch, 1, 1));
     const ConvGeo g{B, H, W};
     int rc;  // exact fp32 for this tiny tail: it feeds a loss value directly
-    if ((rc = plain_conv(stream, VPX_PREC_F32, g, delta_c, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, false, nullptr, yc, Ch, false, wpk))) return rc;
-    if ((rc = plain_conv(stream, VPX_PREC_F32, g, delta_m, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, false, nullptr, ym, Ch, false, wpk))) return rc;
+    if ((rc = decouple_adapter_pair(stream, g, delta_c, delta_m, adapter, yc, ym, n, Ch, false, wpk))) return rc;
     VPX_CHECK_HIP(launch_decouple_stats(yc, ym, stats, B, H * W, Ch, stream));
     VPX_CHECK_HIP(launch_decouple_mean(stats, value, B * Ch, stream));
     return VPX_OK;
@@ -91,12 +105,15 @@ int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* ad
     const ConvGeo g{B, H, W};
     int rc;
     // recompute the adapter outputs (cheaper than keeping them alive between forward and backward)
-    if ((rc = plain_conv(stream, VPX_PREC_F32, g, delta_c, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, false, nullptr, yc, Ch, false, wpk))) return rc;
-    if ((rc = plain_conv(stream, VPX_PREC_F32, g, delta_m, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, false, nullptr, ym, Ch, false, wpk))) return rc;
+    if ((rc = decouple_adapter_pair(stream, g, delta_c, delta_m, adapter, yc, ym, n, Ch, false, wpk))) return rc;
     VPX_CHECK_HIP(launch_decouple_stats(yc, ym, stats, B, H * W, Ch, stream));
     VPX_CHECK_HIP(launch_decouple_bwd_pointwise(yc, ym, stats, dvalue, dyc, dym, B, H * W, Ch, stream));
-    if (d_delta_c && (rc = plain_conv(stream, VPX_PREC_F32, g, dyc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_c, Ch, false, wpk))) return rc;
-    if (d_delta_m && (rc = plain_conv(stream, VPX_PREC_F32, g, dym, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_m, Ch, false, wpk))) return rc;
+    if (d_delta_c && d_delta_m) {
+        if ((rc = decouple_adapter_pair(stream, g, dyc, dym, adapter, d_delta_c, d_delta_m, n, Ch, true, wpk))) return rc;
+    } else {
+        if (d_delta_c && (rc = plain_conv(stream, VPX_PREC_F32, g, dyc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_c, Ch, false, wpk))) return rc;
+        if (d_delta_m && (rc = plain_conv(stream, VPX_PREC_F32, g, dym, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_m, Ch, false, wpk))) return rc;
+    }
     if (d_adapter) {
         if (dym == dyc + n && (((uintptr_t)delta_c ^ (uintptr_t)delta_m) & 15) == 0) {
             // both pairs in ONE launch (the c and m halves are two "time steps"): one weight gradient + reduce instead of two + an add

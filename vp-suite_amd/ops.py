@@ -381,8 +381,12 @@ class _DecoupleFn(torch.autograd.Function):
         dc, dm, A = ctx.saved_tensors
         B, Ch, H, Wd = dc.shape
         needs = ctx.needs_input_grad
-        g_dc = new_channels_last((B, Ch, H, Wd), dc.device) if needs[0] else None
-        g_dm = new_channels_last((B, Ch, H, Wd), dc.device) if needs[1] else None
+        if needs[0] and needs[1]:
+            gg = new_channels_last((2 * B, Ch, H, Wd), dc.device)  # adjacent: one adjoint conv for the pair
+            g_dc, g_dm = gg[:B], gg[B:]
+        else:
+            g_dc = new_channels_last((B, Ch, H, Wd), dc.device) if needs[0] else None
+            g_dm = new_channels_last((B, Ch, H, Wd), dc.device) if needs[1] else None
         g_A = torch.empty_like(A) if needs[2] else None
         L = _lib.lib()
         ws_bytes = L.vpx_decouple_workspace_bytes(B, Ch, H, Wd)
@@ -510,7 +514,9 @@ class _STLSTMStepFn(torch.autograd.Function):
         if packed:
             d.flags |= _lib.FLAG_WEIGHTS_PACKED
         reserve = torch.empty(max(rs_bytes, 1), dtype=torch.uint8, device=dev)
-        outs = [new_channels_last((B, Ch, H, Wd), dev) for _ in range(5)]
+        outs = [new_channels_last((B, Ch, H, Wd), dev) for _ in range(3)]
+        dd = new_channels_last((2 * B, Ch, H, Wd), dev)  # delta_c | delta_m adjacent: the decoupling tail runs the pair as one conv
+        outs += [dd[:B], dd[B:]]
         ln_arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in lnc]) if use_ln else None
         if PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
