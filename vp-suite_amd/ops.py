@@ -313,8 +313,9 @@ class _ConvExFn(torch.autograd.Function):
         _sync_determinism()
         xs, wc, y = ctx.saved_tensors
         stride, padding, transposed, slope, has_bias = ctx.cfg
-        if slope != 0.0:  # LeakyReLU' from the sign of the output (same sign as the pre-activation for slope > 0)
-            dy = dy * torch.where(y > 0, torch.ones((), device=y.device), torch.full((), slope, device=y.device))
+        if slope != 0.0:  # LeakyReLU' from the sign of the output (same sign as the pre-activation for slope > 0): one pass
+            dy = torch.ops.aten.leaky_relu_backward(dy, y, slope, True) if slope > 0.0 else \
+                dy * torch.where(y > 0, torch.ones((), device=y.device), torch.full((), slope, device=y.device))
         mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]]
         d = ctx.desc
         if GLUE_BACKWARD_HIP and d.kh >= d.stride and d.kw >= d.stride:
