@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
 """bench.py — predicted frames/s of the convlstm-shi hot path (BASELINE.json metric) on N MI355X GPUs of one node.
 
-Workload (config.workload): the default `convlstm-shi` model (EF-ConvLSTM, vp_suite/models/precipitation_nowcasting/
-ef_conv_lstm.py:31-65) on MovingMNIST-shaped synthetic frames [B, 10+10, 1, 64, 64], 10 context -> 10 predicted frames
-(BASELINE.json configs[1]). One "step" = one pass of the hot path over one batch: mode=infer is VPModel.forward under
-no_grad; mode=train is forward + MSE + backward + gradient all-reduce (RCCL) + Adam. Batch-sharded data parallel,
-per-GPU batch fixed (weak scaling), no data-path collective in infer mode.
+Headline workload (config.workload): the default `convlstm-shi` model (EF-ConvLSTM, vp_suite/models/
+precipitation_nowcasting/ef_conv_lstm.py:31-65) on MovingMNIST-shaped synthetic frames [B, 10+10, 1, 64, 64], 10 context ->
+10 predicted frames (BASELINE.json configs[1]). One "step" = one pass of the hot path over one batch: mode=infer is
+VPModel.forward under no_grad; mode=train is the model's training iteration (forward + MSE + backward, PredRNN:
+forward and time-reversed forward) + gradient all-reduce (RCCL) + Adam. Batch-sharded data parallel, per-GPU batch
+fixed (weak scaling), no data-path collective in infer mode.
+
+Launch forms:
+  python bench.py --gpus 1 ...                   one process
+  python bench.py --gpus N ...   (N > 1)         spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+                                                 CHILD process before anything touches the GPU, relays its output and exit code
+  python -m torch.distributed.run ... bench.py   one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the environment)
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
   roofline     — live HIP-event timing of the dominant kernel (fused ConvLSTM cell), algorithmic FLOPs / duration
   cpu_baseline — the oracle's PyTorch-CPU restatement of the same forward, timed on the host cores (rank 0, N=1 only)
+  extras       — further configurations (small batch, training step, exact fp32, predrnn-pp, 128x128x3 10->20), each timed
+                 for >= --extras-seconds with its own roofline (N=1: 8 entries; N>1: the training / C4-shaped entries that
+                 carry the gradient all-reduce)
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 # MI355X_MICROARCH.md: f32 matrix 157.3 TF, bf16 dense ~2.5 PF. The split-bf16 mode ("bf16x3") spends three bf16 MFMAs
 # per algorithmic product, so the dense peak of THAT arithmetic is 2500 / 3 algorithmic TFLOP/s.
@@ -36,8 +46,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128,
-                    help="per-GPU batch. 128 fills the chip on every block of the model (throughput 37.1 / 40.5 / 42.9 / 43.1 k "
-                         "frames/s at 32 / 64 / 128 / 256); the reference's default training batch_size is 32 (defaults.py:37-64)")
+                    help="per-GPU batch. 128 fills the chip on every block of the model; the reference's default training "
+                         "batch_size is 32 (defaults.py:37-64); both, and batch 4, are reported in `extras`")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer")
     ap.add_argument("--model", choices=["convlstm-shi", "predrnn-pp"], default="convlstm-shi",
                     help="convlstm-shi = BASELINE configs[1] (the bench line); predrnn-pp = configs[2] (secondary workload)")
@@ -48,19 +58,137 @@ def parse():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--context", type=int, default=10)
     ap.add_argument("--pred", type=int, default=10)
+    ap.add_argument("--layers", type=int, default=None, help="predrnn-pp: num_layers (default 3; BASELINE configs[4] 'deep' = 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--extras-seconds", type=float, default=3.0, help="minimum timed region of each `extras` entry")
     return ap.parse_args()
 
 
-def measured_traffic(args):
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a child process.
+    Nothing in this process has touched the GPU yet (no torch.cuda call, not even `import torch`), and the child is a
+    fresh process — never an exec of a GPU-initialised one."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required for RCCL on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+class Spec:
+    """One measured configuration."""
+
+    def __init__(self, name, model="convlstm-shi", mode="infer", batch=128, precision="bf16x3", img=64, channels=1,
+                 context=10, pred=10, layers=None):
+        self.name, self.model, self.mode, self.batch, self.precision = name, model, mode, batch, precision
+        self.img, self.channels, self.context, self.pred, self.layers = img, channels, context, pred, layers
+
+    def workload(self):
+        deep = f", num_layers={self.layers}" if self.layers else ""
+        return (f"{self.model} (default hyper-parameters{deep}) on MovingMNIST-shaped synthetic frames "
+                f"{self.channels}x{self.img}x{self.img}, {self.context}->{self.pred}, random-init weights")
+
+
+class Runner:
+    def __init__(self, spec, dev, rank, world, use_dist):
+        import torch
+        from vp_suite_amd.models import MODEL_CLASSES
+        self.spec, self.dev, self.rank, self.world, self.use_dist = spec, dev, rank, world, use_dist
+        torch.manual_seed(0)  # identical random-init weights on every rank
+        kw = dict(img_shape=(spec.channels, spec.img, spec.img), action_size=0, tensor_value_range=[0.0, 1.0],
+                  cell_precision=spec.precision)
+        if spec.layers:
+            kw["num_layers"] = spec.layers
+        self.model = MODEL_CLASSES[spec.model](str(dev), **kw).to(dev)
+        with torch.no_grad():
+            for n, p in self.model.named_parameters():
+                if n.split(".")[-1] in ("Wci", "Wcf", "Wco"):
+                    p.normal_(0.0, 0.1)  # exercise the peephole path (reference init is zeros)
+        torch.manual_seed(42 + rank)
+        frames = torch.rand(spec.batch, spec.context + spec.pred, spec.channels, spec.img, spec.img, device=dev)
+        complete = self.model.NEEDS_COMPLETE_INPUT
+        self.x, self.target = (frames if complete else frames[:, :spec.context]), frames[:, spec.context:]
+        self.semantics = "VPModel.forward under no_grad"
+        if spec.mode == "train":
+            from vp_suite_amd.train import DataParallelTrainer
+            self.trainer = DataParallelTrainer(self.model, lr=1e-4, world_size=world, force_collectives=use_dist)
+            self.semantics = ("model.training_loss (PredRNN_V2.train_iter semantics: train-time sampling mask, forward + "
+                              "time-reversed forward averaged) + backward + flat-bucket all-reduce + fused Adam"
+                              if spec.model == "predrnn-pp" else
+                              "forward + MSE + backward (BPTT) + flat-bucket all-reduce + fused Adam")
+
+    def step(self):
+        import torch
+        if self.spec.mode == "train":
+            self.trainer.step(self.x, self.target, self.spec.pred)
+        else:
+            with torch.no_grad():
+                self.model(self.x, pred_frames=self.spec.pred)
+
+    def barrier(self):
+        import torch
+        import torch.distributed as dist
+        if self.use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize brackets; MAX over ranks."""
+        import torch
+        import torch.distributed as dist
+        from vp_suite_amd import ops
+        for _ in range(warmup):
+            self.step()
+        prof = ops.KernelProfile()
+        ops.PROFILE = prof
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        ops.PROFILE = None
+        if self.use_dist:
+            t = torch.tensor([elapsed], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, prof.summary()
+
+    def calibrated_steps(self, seconds):
+        """Step count for a timed region of at least `seconds` (same count on every rank)."""
+        import torch
+        import torch.distributed as dist
+        el, _ = self.timed(2, 2)
+        n = max(3, int(math.ceil(seconds / max(el / 2, 1e-6))))
+        if self.use_dist:
+            t = torch.tensor([n], device=self.dev, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n = int(t.item())
+        return n
+
+
+def measured_traffic(spec):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with
-    tools/collect_profiles.sh on this exact workload); None when the run's configuration differs from the profiled one."""
-    if not (args.model == "convlstm-shi" and args.precision == "bf16x3" and args.mode == "infer"
-            and args.img == 64 and args.channels == 1):
+    tools/collect_profiles.sh on this exact workload: separate --pmc FETCH_SIZE / WRITE_SIZE passes, read = 2 x FETCH_SIZE
+    per the gfx950 correction); None when no committed pass matches the configuration."""
+    if not (spec.img == 64 and spec.channels == 1 and spec.context == 10 and spec.pred == 10):
+        return None
+    tag = {"convlstm-shi": ""}.get(spec.model)
+    if tag is None:
         return None
     cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
-                   if f.endswith(f"_pmc_bench_infer_b{args.batch}_bf16x3.json"))
+                   if f.endswith(f"_pmc_bench_{spec.mode}_b{spec.batch}_{spec.precision}.json"))
     if not cands:
         return None
     with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
@@ -68,106 +196,145 @@ def measured_traffic(args):
     return None if t is None else round(t["total"])
 
 
-def cpu_baseline(model, args):
+def roofline(spec, ps):
+    ach_tflops = ps["flops"] / (ps["ms"] * 1e-3) / 1e12 if ps["ms"] > 0 else 0.0
+    ach_gbs = ps["bytes"] / (ps["ms"] * 1e-3) / 1e9 if ps["ms"] > 0 else 0.0
+    peak = PEAK_TFLOPS[spec.precision]
+    launches = max(ps["launches"], 1)
+    return {
+        "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+        "frac": round(ach_tflops / peak, 4), "traffic": measured_traffic(spec),
+        "algorithmic_bytes_per_launch": round(ps["bytes"] / launches),
+        "kernel": (f"conv_gemm_kernel<EpiConvLSTM, {spec.precision}> (fused ConvLSTM cell step, forward)"
+                   if spec.model == "convlstm-shi" else
+                   f"conv_gemm_kernel<EpiSTGate/EpiSTOut/EpiPlain, {spec.precision}> (ST-LSTM cell step, forward)"),
+        "note": ("achieved = algorithmic fp32 FLOPs / kernel time. bf16x3 issues 3 bf16 MFMAs per algorithmic "
+                 "product: peak = 2500 TF dense bf16 / 3, i.e. frac is the share of the bf16 MFMA pipe's dense "
+                 "peak the kernel keeps busy; frac_of_bf16_dense_peak prices the same time against the plain 2500 TF"
+                 if spec.precision == "bf16x3" else
+                 ("plain bf16 operands: outside the 1e-4 parity bar, reported as an extra" if spec.precision == "bf16"
+                  else "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)")),
+        "frac_of_bf16_dense_peak": (round(ach_tflops / BF16_DENSE_TFLOPS, 4) if spec.precision != "f32" else None),
+        "vs_fp32_matrix_peak": round(ach_tflops / PEAK_TFLOPS["f32"], 4),
+        "launches": ps["launches"], "avg_launch_us": round(ps["ms"] * 1e3 / launches, 2),
+        "algorithmic_gflop_per_launch": round(ps["flops"] / launches / 1e9, 3),
+        "hbm_view": {"achieved_GBps": round(ach_gbs, 1), "peak_GBps": HBM_PEAK_GBS, "frac": round(ach_gbs / HBM_PEAK_GBS, 4),
+                     "note": "north-star 'fraction of HBM roofline' of the fused cell: algorithmic bytes / kernel time; "
+                             "the cell is MFMA-bound (>=339 FLOP/B), so this stays far below 0.5 at 1e-4 parity (SURVEY.md §8d)"},
+    }
+
+
+def run_extra(spec, dev, rank, world, use_dist, seconds):
+    import torch
+    r = Runner(spec, dev, rank, world, use_dist)
+    steps = r.calibrated_steps(seconds)
+    elapsed, ps = r.timed(steps, 1)
+    out = {"name": spec.name, "workload": spec.workload(), "mode": spec.mode, "semantics": r.semantics,
+           "dtype": spec.precision, "per_gpu_batch": spec.batch, "global_batch": spec.batch * world, "n_gpus": world,
+           "steps": steps, "timed_region_s": round(elapsed, 3), "ms_per_step": round(elapsed / steps * 1e3, 4),
+           "value": round(world * spec.batch * spec.pred * steps / elapsed, 2), "unit": "frames/s",
+           "roofline": roofline(spec, ps)}
+    for k in ("note", "hbm_view", "vs_fp32_matrix_peak"):
+        out["roofline"].pop(k, None)
+    del r
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(model, spec, seconds):
     """Times the oracle's plain-PyTorch CPU restatement (oracle/torch_ref.py) of the same forward on the host cores.
-    Bounded sample: batch 4 (BASELINE configs[0]) of the same 10->10 workload, repeated for ~cpu_seconds."""
+    Bounded sample: batch 4 (BASELINE configs[0]) of the same 10->10 workload, repeated for ~seconds."""
+    import torch
     from oracle import torch_ref
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     all_cores = torch.get_num_threads()
     b = 4
-    x = torch.rand(b, args.context, args.channels, args.img, args.img)
+    x = torch.rand(b, spec.context, spec.channels, spec.img, spec.img)
     best = None
     # PyTorch's default (all host cores) over-subscribes this small problem; report the best of a short thread scan
     for threads in sorted({all_cores, min(all_cores, 32), min(all_cores, 16)}, reverse=True):
         torch.set_num_threads(threads)
         with torch.no_grad():
-            torch_ref.ef_convlstm_forward(sd, x, args.pred)  # warm-up
+            torch_ref.ef_convlstm_forward(sd, x, spec.pred)  # warm-up
             n, t0 = 0, time.perf_counter()
             while True:
-                torch_ref.ef_convlstm_forward(sd, x, args.pred)
+                torch_ref.ef_convlstm_forward(sd, x, spec.pred)
                 n += 1
                 el = time.perf_counter() - t0
-                if el > args.cpu_seconds / 3 or n >= 50:
+                if el > seconds / 3 or n >= 50:
                     break
-        fps = n * b * args.pred / el
+        fps = n * b * spec.pred / el
         if best is None or fps > best[0]:
             best = (fps, threads, n, el)
     torch.set_num_threads(all_cores)
     fps, threads, n, el = best
     return {"value": round(fps, 2), "unit": "predicted frames/s", "cores": threads, "kind": "port",
             "sample": f"oracle/torch_ref.ef_convlstm_forward (PyTorch-CPU restatement of the reference path), "
-                      f"batch {b}, {args.context}->{args.pred}, {args.channels}x{args.img}x{args.img}, "
-                      f"{n} iterations in {el:.1f} s on {threads} of {all_cores} host threads (best point of a 3-point thread scan, "
-                      f"~{args.cpu_seconds:.0f} s of CPU work in total)"}
+                      f"batch {b}, {spec.context}->{spec.pred}, {spec.channels}x{spec.img}x{spec.img}, "
+                      f"{n} iterations in {el:.1f} s on {threads} of {all_cores} host threads (the best point of a 3-point "
+                      f"thread scan {{all, 32, 16}}, not all cores: the batch-4 problem over-subscribes them; "
+                      f"~{seconds:.0f} s of CPU work in total)"}
+
+
+def extras_for(world):
+    if world == 1:
+        return [
+            Spec("headline_sustained"),
+            Spec("infer_b4", batch=4),
+            Spec("infer_b32", batch=32),
+            Spec("train_b32", mode="train", batch=32),
+            Spec("train_b128", mode="train", batch=128),
+            Spec("infer_b128_f32", precision="f32"),
+            Spec("predrnn_infer_b128", model="predrnn-pp"),
+            Spec("c4_infer_b4_128x128x3_10to20", batch=4, img=128, channels=3, pred=20),
+            Spec("c4_train_b4_128x128x3_10to20", mode="train", batch=4, img=128, channels=3, pred=20),
+        ]
+    # N > 1: the entries in which ranks exchange gradients (the north-star's DP-scaling figure), at the default batch and
+    # at BASELINE configs[3]'s 4 samples per GPU
+    return [
+        Spec("train_b128", mode="train", batch=128),
+        Spec("c4_train_b4_128x128x3_10to20", mode="train", batch=4, img=128, channels=3, pred=20),
+        Spec("c4_infer_b4_128x128x3_10to20", batch=4, img=128, channels=3, pred=20),
+    ]
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" in os.environ and world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus={world}", file=sys.stderr)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        print(f"[bench] rank {rank}: local rank {local_rank} has no GPU ({ndev} visible); one process per GPU is required",
+              file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run always go through RCCL (also at N=1)
+    use_dist = "RANK" in os.environ  # under torch.distributed.run always go through RCCL (also at N=1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        world = dist.get_world_size()  # the size RCCL reports
 
-    import vp_suite_amd
-    from vp_suite_amd import ops
-    from vp_suite_amd.models import MODEL_CLASSES
+    import vp_suite_amd  # noqa: F401
 
-    torch.manual_seed(0)  # identical random-init weights on every rank
-    model = MODEL_CLASSES[args.model](str(dev), img_shape=(args.channels, args.img, args.img), action_size=0,
-                                      tensor_value_range=[0.0, 1.0], cell_precision=args.precision).to(dev)
-    complete = model.NEEDS_COMPLETE_INPUT
-    with torch.no_grad():
-        for n, p in model.named_parameters():
-            if n.split(".")[-1] in ("Wci", "Wcf", "Wco"):
-                p.normal_(0.0, 0.1)  # exercise the peephole path (reference init is zeros)
-    torch.manual_seed(42 + rank)
-    frames = torch.rand(args.batch, args.context + args.pred, args.channels, args.img, args.img, device=dev)
-    x, target = (frames if complete else frames[:, :args.context]), frames[:, args.context:]
+    spec = Spec("headline", model=args.model, mode=args.mode, batch=args.batch, precision=args.precision, img=args.img,
+                channels=args.channels, context=args.context, pred=args.pred, layers=args.layers)
+    runner = Runner(spec, dev, rank, world, use_dist)
+    elapsed, ps = runner.timed(args.steps, args.warmup)
 
-    if args.mode == "train":
-        from vp_suite_amd.train import DataParallelTrainer
-        trainer = DataParallelTrainer(model, lr=1e-4, world_size=world, force_collectives=use_dist)
-
-        def step():
-            trainer.step(x, target, args.pred)
-    else:
-        def step():
-            with torch.no_grad():
-                model(x, pred_frames=args.pred)
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    prof = ops.KernelProfile()
-    ops.PROFILE = prof
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ops.PROFILE = None
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    out = None
     if rank == 0:
-        ps = prof.summary()
-        ach_tflops = ps["flops"] / (ps["ms"] * 1e-3) / 1e12 if ps["ms"] > 0 else 0.0
-        ach_gbs = ps["bytes"] / (ps["ms"] * 1e-3) / 1e9 if ps["ms"] > 0 else 0.0
-        peak = PEAK_TFLOPS[args.precision]
-        frames_total = world * args.batch * args.pred * args.steps
+        frames_total = world * spec.batch * spec.pred * args.steps
         out = {
             "metric": "predicted frames/sec (whole node), MovingMNIST 64x64 10->10",
             "value": round(frames_total / elapsed, 2),
@@ -179,35 +346,32 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": args.precision,
+            "dtype": spec.precision,
             "data": "synthetic",
-            "config": {"workload": f"{args.model} (default hyper-parameters) on MovingMNIST-shaped synthetic frames "
-                                   f"{args.channels}x{args.img}x{args.img}, {args.context}->{args.pred}, "
-                                   f"random-init weights",
-                       "mode": args.mode, "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}"},
-            "roofline": {
-                "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(ach_tflops / peak, 4), "traffic": measured_traffic(args),
-                "algorithmic_bytes_per_launch": round(ps["bytes"] / max(ps["launches"], 1)),
-                "kernel": (f"conv_gemm_kernel<EpiConvLSTM, {args.precision}> (fused ConvLSTM cell step)"
-                           if args.model == "convlstm-shi" else
-                           f"conv_gemm_kernel<EpiSTGate/EpiSTOut/EpiPlain, {args.precision}> (ST-LSTM cell step, 4 launches)"),
-                "note": ("achieved = algorithmic fp32 FLOPs / kernel time. bf16x3 issues 3 bf16 MFMAs per algorithmic "
-                         "product: peak = 2500 TF dense bf16 / 3, i.e. frac is the share of the bf16 MFMA pipe's dense "
-                         "peak the kernel keeps busy" if args.precision == "bf16x3" else
-                         ("plain bf16 operands: outside the 1e-4 parity bar, reported as an extra" if args.precision == "bf16"
-                          else "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)")),
-                "frac_of_bf16_dense_peak": (round(ach_tflops / BF16_DENSE_TFLOPS, 4) if args.precision != "f32" else None),
-                "vs_fp32_matrix_peak": round(ach_tflops / PEAK_TFLOPS["f32"], 4),
-                "launches": ps["launches"], "avg_launch_us": round(ps["ms"] * 1e3 / max(ps["launches"], 1), 2),
-                "algorithmic_gflop_per_launch": round(ps["flops"] / max(ps["launches"], 1) / 1e9, 3),
-                "hbm_view": {"achieved_GBps": round(ach_gbs, 1), "peak_GBps": HBM_PEAK_GBS,
-                             "frac": round(ach_gbs / HBM_PEAK_GBS, 4)},
-            },
+            "config": {"workload": spec.workload(), "mode": spec.mode, "semantics": runner.semantics,
+                       "per_gpu_batch": spec.batch, "global_batch": spec.batch * world, "parallelism": f"dp{world}",
+                       "ranks": world, "backend": ("nccl (RCCL)" if use_dist else "single process")},
+            "roofline": roofline(spec, ps),
         }
-        if world == 1 and not args.no_cpu_baseline and args.model == "convlstm-shi":
-            out["cpu_baseline"] = cpu_baseline(model, args)
+    cpu_model = runner.model if (world == 1 and not args.no_cpu_baseline and spec.model == "convlstm-shi") else None
+    if cpu_model is None:
+        del runner
+        torch.cuda.empty_cache()
+
+    extras = []
+    if not args.no_extras:
+        for es in extras_for(world):
+            try:
+                extras.append(run_extra(es, dev, rank, world, use_dist, args.extras_seconds))
+            except Exception as exc:  # an extra must never take the headline down; say what happened instead
+                if use_dist:
+                    raise
+                extras.append({"name": es.name, "error": f"{type(exc).__name__}: {exc}"})
+    if rank == 0:
+        if extras:
+            out["extras"] = extras
+        if cpu_model is not None:
+            out["cpu_baseline"] = cpu_baseline(cpu_model, spec, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

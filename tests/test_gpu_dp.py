@@ -1,0 +1,132 @@
+"""The fused data-parallel path (train.DataParallelTrainer on the GPU: flat parameter + gradient buckets, 1/W folded into
+the Adam kernel) executed with world_size = 2 ARITHMETIC on one device: two replicas, one batch shard each, the
+"all-reduce" a hand-written sum of the two shard gradients. The result must equal the single-process update on the
+global batch (harness semantics base_model.py:162-179). RCCL itself refuses two ranks on one GPU, so
+the collective is the only piece this test replaces; `bench.py --gpus N` runs it for real."""
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from golden_util import name_seed, seeded_rand
+from test_gpu_models import _ef
+
+pytestmark = pytest.mark.gpu
+
+
+class _FakeWorld:
+    """Sum-all-reduce over the replicas living in this process: every replica deposits its bucket, the reduction
+    happens when the last one arrived, then every bucket holds the sum (what ncclAllReduce(SUM) leaves)."""
+
+    def __init__(self, n):
+        self.n, self.pending = n, []
+
+    def all_reduce(self, t):
+        self.pending.append(t)
+        if len(self.pending) == self.n:
+            total = torch.stack(self.pending).sum(dim=0)
+            for p in self.pending:
+                p.copy_(total)
+            self.pending = []
+
+    def broadcast(self, t, src):
+        pass  # replicas are built from identical seeds
+
+
+def _flat(m):
+    named = dict(m.named_parameters())
+    return torch.cat([named[k].detach().reshape(-1) for k in sorted(named)]).cpu().numpy()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_fused_dp_world2_equals_global_batch_update(vpx, precision):
+    from vp_suite_amd.train import DataParallelTrainer
+    kw = dict(gc.EF_TINY_KW, cell_precision=precision)
+    B, T, P = 4, 3, 2
+    c, h, w = kw["img_shape"]
+    frames = seeded_rand((B, T + P, c, h, w), name_seed("dp.frames")).cuda()
+
+    ref = _ef(vpx, "tiny", kw)
+    tr_ref = DataParallelTrainer(ref, lr=1e-3, world_size=1)
+    world = _FakeWorld(2)
+    reps = [_ef(vpx, "tiny", kw) for _ in range(2)]
+    trs = [DataParallelTrainer(m, lr=1e-3, world_size=2, all_reduce=world.all_reduce, broadcast=world.broadcast)
+           for m in reps]
+    assert all(t.fused and t.collectives for t in trs)
+    for step in range(3):
+        tr_ref.step(frames[:, :T], frames[:, T:], P)
+        # ranks run concurrently in reality; here: both backward passes, then the exchange, then both updates
+        for r, t in enumerate(trs):
+            t.backward_shard(frames[2 * r:2 * r + 2, :T], frames[2 * r:2 * r + 2, T:], P)
+        shard_sum = trs[0].flat_grad + trs[1].flat_grad
+        for t in trs:
+            t.reduce_gradients()
+        assert torch.equal(trs[0].flat_grad, shard_sum) and torch.equal(trs[1].flat_grad, shard_sum)
+        assert trs[0].optimizer.grad_scale == 0.5
+        # mean over the global batch = (sum of shard means) / 2: the summed bucket is 2x the global-batch gradient
+        g_ref = tr_ref.flat_grad
+        err = float((shard_sum * 0.5 - g_ref).abs().max() / g_ref.abs().max())
+        assert err < (2e-5 if precision == "f32" else 1e-4), (step, err)
+        for t in trs:
+            t.optimizer.step()
+    want = _flat(ref)
+    for m in reps:
+        # Adam's first steps move every weight by ~lr regardless of gradient scale; compare absolutely (lr = 1e-3)
+        assert np.abs(_flat(m) - want).max() < 2e-5
+    assert np.array_equal(_flat(reps[0]), _flat(reps[1]))
+
+
+def test_trainer_runs_predrnn_training_semantics(vpx):
+    """DataParallelTrainer.step on PredRNN-V2 = the model's own train_iter (predrnn_v2.py:319-365): training-time mask,
+    forward + reversed forward averaged, training_iteration bumped — same parameters as train_iter with FlatAdam."""
+    from vp_suite_amd.measure import PredictionLossProvider
+    from vp_suite_amd.models import MODEL_CLASSES
+    from vp_suite_amd.train import DataParallelTrainer, FlatAdam
+    from golden_util import fill_state_dict_
+    kw = dict(gc.PRED_TINY_KW, scheduled_sampling=False)
+    B, T, P = 2, 3, 2
+    c, h, w = kw["img_shape"]
+    frames = seeded_rand((B, T + P, c, h, w), name_seed("dp.predrnn.frames")).cuda()
+
+    def build():
+        m = MODEL_CLASSES["predrnn-pp"]("cuda", **kw)
+        fill_state_dict_(m, name_seed("dp.predrnn"))
+        return m.to("cuda")
+    a, b = build(), build()
+    tr = DataParallelTrainer(a, lr=1e-3, world_size=1)
+    opt = FlatAdam.from_module(b, lr=1e-3)
+    lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
+    cfg = {"device": "cuda", "context_frames": T, "pred_frames": P, "val_rec_criterion": "mse"}
+    data = {"frames": frames, "actions": torch.zeros(B, T + P - 1, 0)}
+    for _ in range(2):
+        tr.step(frames, frames[:, T:], P)
+        b.train_iter(cfg, [data], opt, lp, epoch=0)
+    assert a.training_iteration == b.training_iteration == 3
+    assert np.abs(_flat(a) - _flat(b)).max() < 1e-6
+
+
+def test_flat_adam_survives_set_to_none_and_keeps_state(vpx):
+    """p.grad = None (torch's zero_grad default) must not make FlatAdam step on a stale bucket; state_dict
+    carries the moments."""
+    from vp_suite_amd.train import FlatAdam
+    m = _ef(vpx, "tiny", gc.EF_TINY_KW)
+    twin = _ef(vpx, "tiny", gc.EF_TINY_KW)
+    opt, opt2 = FlatAdam.from_module(m, lr=1e-3), torch.optim.Adam(twin.parameters(), lr=1e-3)
+    frames = seeded_rand((2, 5, 1, 16, 16), name_seed("ef.tiny.frames")).cuda()
+    for _ in range(2):
+        for model, o in ((m, opt), (twin, opt2)):
+            for p in model.parameters():
+                p.grad = None  # what nn.Module.zero_grad(set_to_none=True) does
+            pred, _ = model(frames[:, :3], pred_frames=2)
+            ((pred - frames[:, 3:]) ** 2).sum().backward()
+            o.step()
+    assert np.abs(_flat(m) - _flat(twin)).max() < 2e-6
+    base = opt.flat_grad.untyped_storage().data_ptr()
+    assert all(p.grad.untyped_storage().data_ptr() == base for p in m.parameters())
+    sd = opt.state_dict()
+    assert sd["flat_adam"]["steps"] == 2 and float(sd["flat_adam"]["exp_avg_sq"].abs().sum()) > 0
+    fresh = FlatAdam.from_module(_ef(vpx, "tiny", gc.EF_TINY_KW), lr=1e-3)
+    fresh.load_state_dict(sd)
+    assert fresh.steps == 2 and torch.equal(fresh.exp_avg, opt.exp_avg)
+    with pytest.raises(ValueError):
+        FlatAdam([{"params": list(m.parameters())}], opt.flat_param, opt.flat_grad)

@@ -156,3 +156,70 @@ def test_channels_last_helpers(vpx):
     fl, by = vpx.ops.convlstm_algorithmic_work(1, 1, 64, 64, 64, 64, 3, 3)
     assert abs(fl - 2.416e9) < 1e7  # BASELINE.md §4 headline cell: 2.416 GFLOP per sample-step
     assert abs(by - (5.243e6 + 4.326e6)) < 2e4
+
+
+def test_peephole_modes_and_gpu_reference_checkpoints(vpx):
+    """on GPU devices the reference's peepholes are plain tensors (conv_lstm_hzzone.py:30-32) — absent from
+    state_dict, never trained. Such checkpoints must load (strict), and train_peepholes=False reproduces the behaviour."""
+    from vp_suite_amd.models import MODEL_CLASSES
+    EF = MODEL_CLASSES["convlstm-shi"]
+    m = EF("cpu", **gc.EF_TINY_KW)
+    full = {k: torch.randn_like(v) for k, v in m.state_dict().items()}
+    gpu_ckpt = {k: v for k, v in full.items() if k.split(".")[-1] not in ("Wci", "Wcf", "Wco")}
+    assert len(gpu_ckpt) == len(full) - 18
+    m.load_state_dict(gpu_ckpt)  # strict: missing peephole keys are tolerated, values stay zero
+    assert float(m.encoder.rnn2.Wcf.abs().sum()) == 0.0
+    assert torch.equal(m.encoder.rnn2._conv.weight, full["encoder.rnn2._conv.weight"])
+    with pytest.raises(RuntimeError):  # anything else missing is still an error
+        m.load_state_dict({k: v for k, v in gpu_ckpt.items() if k != "encoder.rnn2._conv.bias"})
+
+    fixed = EF("cpu", train_peepholes=False, **gc.EF_TINY_KW)
+    assert list(fixed.state_dict().keys()) == list(gpu_ckpt.keys())
+    assert not any(n.split(".")[-1] in ("Wci", "Wcf", "Wco") for n, _ in fixed.named_parameters())
+    assert fixed.encoder.rnn1.Wci.requires_grad is False and fixed.config["train_peepholes"] is False
+    fixed.load_state_dict(gpu_ckpt)
+    fixed.load_state_dict(full)  # a CPU-built reference checkpoint: values taken, still not trainable
+    assert torch.equal(fixed.forecaster.rnn3.Wco, full["forecaster.rnn3.Wco"])
+    pickle.loads(pickle.dumps(fixed))
+
+
+def test_flat_adam_relinks_broken_views(vpx):
+    """FlatAdam._relink (CPU-checkable part of ADVICE r1): a None / foreign .grad is re-homed into the flat bucket with
+    its values before the update reads the bucket."""
+    from vp_suite_amd.train import FlatAdam
+    lin = torch.nn.Linear(3, 2)
+    opt = FlatAdam.from_module(lin, lr=1e-3)
+    base = opt.flat_grad.untyped_storage().data_ptr()
+    lin.weight.grad = None
+    lin.bias.grad = torch.full((2,), 7.0)
+    opt._relink()
+    assert all(p.grad.untyped_storage().data_ptr() == base for p in lin.parameters())
+    assert float(opt.flat_grad[:6].abs().sum()) == 0.0 and torch.equal(opt.flat_grad[6:], torch.full((2,), 7.0))
+    assert all(p.data.untyped_storage().data_ptr() == opt.flat_param.untyped_storage().data_ptr() for p in lin.parameters())
+
+
+def test_bench_spawns_ranks_before_touching_the_gpu(vpx, monkeypatch):
+    """`python bench.py --gpus N` (no launcher) must start N ranks under torch.distributed.run as a CHILD process."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--mode", "train"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--mode", "train"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    names = [s.name for s in bench.extras_for(1)]
+    assert {"infer_b4", "infer_b32", "train_b32", "train_b128", "infer_b128_f32", "predrnn_infer_b128"} <= set(names)
+    assert any(s.mode == "train" for s in bench.extras_for(8))

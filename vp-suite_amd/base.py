@@ -96,14 +96,20 @@ class VPModel(nn.Module):
                 total = total + value
         return total
 
+    def training_loss(self, inp, targets, pred_frames, loss_provider, **fwd_kwargs):
+        """The scalar one training iteration differentiates (base_model.py:165-171): prediction losses + model losses.
+        Models with their own iteration semantics override it (PredRNN-V2); `train.DataParallelTrainer` calls it too,
+        so data-parallel training runs exactly what `train_iter` runs."""
+        predictions, model_losses = self(inp, pred_frames=pred_frames, **fwd_kwargs)
+        return self._total_loss(predictions, targets, model_losses, loss_provider)
+
     def train_iter(self, config, loader, optimizer, loss_provider, epoch):
         """One pass over `loader`: forward, loss (+ model losses), zero_grad, backward, optimizer step
         (base_model.py:162-179)."""
         loop = _progress(loader)
         for data in loop:
             inp, targets, actions = self.unpack_data(data, config)
-            predictions, model_losses = self(inp, pred_frames=config["pred_frames"], actions=actions)
-            total = self._total_loss(predictions, targets, model_losses, loss_provider)
+            total = self.training_loss(inp, targets, config["pred_frames"], loss_provider, actions=actions)
             optimizer.zero_grad()
             total.backward()
             optimizer.step()

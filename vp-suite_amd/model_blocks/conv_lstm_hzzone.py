@@ -4,9 +4,12 @@ Same constructor signature, parameter names/shapes/init (`_conv.weight [4Ch,Cin+
 [1,Ch,H,W]` zeros) and return convention `(stack(h_t) [B,T,Ch,H,W], (h_T, c_T))`. The python time loop with its
 cat/conv2d/chunk/sigmoid/tanh op sequence (:52-70) is replaced by one call into libvpx_hip.so.
 
-Divergence (documented): on non-CPU devices the reference silently de-registers the peephole tensors
-(`nn.Parameter(...).to(device)` yields a plain tensor, :30-32); here they are always real parameters, as on the
-reference's CPU path (the oracle)."""
+Peepholes: on non-CPU devices the reference silently de-registers the peephole tensors (`nn.Parameter(...).to(device)`
+yields a plain tensor, :30-32): a GPU-built reference model keeps them at zero, never trains them and has no `Wci/Wcf/Wco`
+keys in its state_dict. `train_peepholes=True` (default) keeps them real parameters, as on the reference's CPU path (the
+oracle); `train_peepholes=False` reproduces the reference's GPU behaviour (fixed tensors, no gradient, not in
+state_dict). Either way a state_dict WITHOUT peephole keys (a GPU-trained reference checkpoint) loads under
+strict=True, the peepholes keeping their current values (zeros after construction)."""
 import torch
 from torch import nn
 
@@ -22,7 +25,10 @@ class ConvLSTM(VPModelBlock):
 
     precision = "f32"  #: arithmetic of the fused cell kernel: "f32" (exact), "bf16x3", "bf16"
 
-    def __init__(self, device, in_channels, enc_channels, state_h, state_w, kernel_size, stride=1, padding=1):
+    _PEEPHOLES = ("Wci", "Wcf", "Wco")
+
+    def __init__(self, device, in_channels, enc_channels, state_h, state_w, kernel_size, stride=1, padding=1,
+                 train_peepholes=True):
         super().__init__()
         if stride != 1 or 2 * padding != kernel_size - 1:
             # the recurrence feeds h (state size) back through the same conv: only stride-1 "same" convs are consistent
@@ -31,10 +37,27 @@ class ConvLSTM(VPModelBlock):
         self._conv = nn.Conv2d(in_channels + enc_channels, 4 * enc_channels, kernel_size, stride, padding)
         self.state_h, self.state_w = state_h, state_w
         shape = (1, enc_channels, state_h, state_w)
-        self.Wci = nn.Parameter(torch.zeros(shape))
-        self.Wcf = nn.Parameter(torch.zeros(shape))
-        self.Wco = nn.Parameter(torch.zeros(shape))
+        self.train_peepholes = bool(train_peepholes)
+        for name in self._PEEPHOLES:
+            if self.train_peepholes:
+                setattr(self, name, nn.Parameter(torch.zeros(shape)))
+            else:  # the reference's GPU behaviour: plain tensors that follow .to(), absent from state_dict / parameters()
+                self.register_buffer(name, torch.zeros(shape), persistent=False)
         self.in_c, self.enc_c = in_channels, enc_channels
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Checkpoints of GPU-built reference models hold no peephole keys (see the module docstring): not an error."""
+        n0 = len(missing_keys)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        peep = {prefix + n for n in self._PEEPHOLES}
+        missing_keys[n0:] = [k for k in missing_keys[n0:] if k not in peep]
+        if not self.train_peepholes:  # CPU-built reference checkpoints do carry them: take the values, stay untrained
+            for n in self._PEEPHOLES:
+                if prefix + n in state_dict:
+                    with torch.no_grad():
+                        getattr(self, n).copy_(state_dict[prefix + n])
+                    if prefix + n in unexpected_keys:
+                        unexpected_keys.remove(prefix + n)
 
     def forward(self, inputs, states, seq_len):
         """inputs [B,T,Cin,H,W] or None (zero input every step); states (h, c) or None (zero states)."""

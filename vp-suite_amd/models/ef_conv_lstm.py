@@ -182,6 +182,7 @@ class EF_ConvLSTM(Encoder_Forecaster):
     final_conv_1_name, final_conv_1_c, final_conv_1_k, final_conv_1_s, final_conv_1_p = "identity", 16, 3, 1, 1
     final_conv_2_name, final_conv_2_k, final_conv_2_s, final_conv_2_p = "conv3_3", 1, 1, 0
     cell_precision = "f32"  #: arithmetic of the fused ConvLSTM kernels ("f32" | "bf16x3" | "bf16")
+    train_peepholes: bool = True  #: False = the reference's behaviour on GPU devices (peepholes fixed, not in state_dict)
 
     def _build_encoder_decoder(self):
         enc_convs, enc_rnns, dec_convs, dec_rnns = [], [], [], []
@@ -210,6 +211,6 @@ class EF_ConvLSTM(Encoder_Forecaster):
 
     def _rnn(self, c_in, c_state, h, w, k, s, p):
         blk = ConvLSTM(device=self.device, in_channels=c_in, enc_channels=c_state, state_h=h, state_w=w,
-                       kernel_size=k, stride=s, padding=p)
+                       kernel_size=k, stride=s, padding=p, train_peepholes=self.train_peepholes)
         blk.precision = self.cell_precision
         return blk

@@ -185,21 +185,34 @@ class PredRNN_V2(VPModel):
     def _rng_device(self):
         return self.conv_last.weight.device
 
+    def training_loss(self, inp, targets, pred_frames, loss_provider, reversed_pair=None, **fwd_kwargs):
+        """Loss of ONE training iteration (predrnn_v2.py:326-352): forward with the training-time sampling mask; with
+        `reverse_input` the same on the time-reversed sequence, the two losses averaged; bumps `training_iteration`.
+        `reversed_pair` = (input, target) of the reversed sequence as `unpack_data(reverse=True)` makes them; by default
+        the flip of the complete input sequence (identical whenever the data holds exactly context+pred frames)."""
+        fwd_kwargs.pop("train", None)
+        preds, ml = self(inp, pred_frames=pred_frames, train=True, **fwd_kwargs)
+        total = self._total_loss(preds, targets, ml, loss_provider)
+        if self.reverse_input:
+            if reversed_pair is None:
+                inp_r = torch.flip(inp, dims=[1])
+                reversed_pair = (inp_r, inp_r[:, inp.shape[1] - pred_frames:])
+            inp_r, targets_r = reversed_pair
+            preds_r, ml_r = self(inp_r, pred_frames=pred_frames, train=True, **fwd_kwargs)
+            total = (total + self._total_loss(preds_r, targets_r, ml_r, loss_provider)) / 2
+        self.training_iteration += 1
+        return total
+
     def train_iter(self, config, loader, optimizer, loss_provider, epoch):
         """forward on the sequence and on its time-reversal, losses averaged, one optimizer step; counts training
         iterations for the sampling schedule (predrnn_v2.py:319-365)."""
         loop = _progress(loader)
         for data in loop:
             inp, targets, actions = self.unpack_data(data, config)
-            preds, ml = self(inp, pred_frames=config["pred_frames"], actions=actions, train=True)
-            total = self._total_loss(preds, targets, ml, loss_provider)
-            if self.reverse_input:
-                inp_r, targets_r, _ = self.unpack_data(data, config, reverse=True)
-                preds_r, ml_r = self(inp_r, pred_frames=config["pred_frames"], actions=actions, train=True)
-                total = (total + self._total_loss(preds_r, targets_r, ml_r, loss_provider)) / 2
+            rev = self.unpack_data(data, config, reverse=True)[:2] if self.reverse_input else None
+            total = self.training_loss(inp, targets, config["pred_frames"], loss_provider, actions=actions, reversed_pair=rev)
             optimizer.zero_grad()
             total.backward()
             optimizer.step()
-            self.training_iteration += 1
             if hasattr(loop, "set_postfix"):
                 loop.set_postfix(loss=total.item())

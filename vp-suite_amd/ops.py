@@ -218,6 +218,8 @@ def convlstm_seq(x, h0, c0, W, b, Wci=None, Wcf=None, Wco=None, *, seq_len, in_c
     # grad mode is always off INSIDE Function.forward, so decide here whether the forward must fill the reserve
     need_grad = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (x, h0, c0, W, b, Wci, Wcf, Wco))
+    if x is not None and x.dim() == 5 and x.shape[1] > seq_len:
+        x = x[:, :seq_len]  # sliced here, outside the Function: autograd pads dx back to x's shape
     return _ConvLSTMSeqFn.apply(x, h0, c0, W, b, Wci, Wcf, Wco, int(seq_len), int(gate_order), PRECISIONS[precision],
                                 int(in_channels), need_grad)
 
@@ -436,13 +438,17 @@ class _MSELossFn(torch.autograd.Function):
         rc = L.vpx_mse_loss(ptr(p), ptr(tg), p.numel(), p.shape[0] * p.shape[1], float(scale), ptr(loss), ptr(g),
                             ptr(ws), ws_bytes, _stream())
         check(rc, "vpx_mse_loss")
-        ctx.g = g
+        if need:
+            ctx.save_for_backward(g)
+        ctx.need = need
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        g, ctx.g = ctx.g, None
-        return (None if g is None else g.mul_(dloss)), None, None
+        if not ctx.need:
+            return None, None, None
+        (g,) = ctx.saved_tensors  # out of place: a second backward through the same node (retain_graph) stays correct
+        return g * dloss, None, None
 
 
 def mse_loss(pred, target, scale: float = 1.0):

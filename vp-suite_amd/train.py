@@ -4,6 +4,8 @@ SURVEY.md §2.1), restating the training semantics of the reference around it:
   loss      MSE summed over (c,h,w), averaged over t then b, scale 1.0 (+ model losses)   base_measure.py:57, base_model.py:168-171
   optimizer Adam(lr) + ReduceLROnPlateau(patience=5, factor=0.2, min_lr=1e-6) on val MSE    vpsuite.py:353-355
   loop      zero_grad -> backward -> step                                                   base_model.py:174-176
+  PredRNN   forward + time-reversed forward averaged, training_iteration += 1               predrnn_v2.py:319-365
+            (through the model's `training_loss` hook, so the trainer runs each model's own train_iter semantics)
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for tests). The only
 exchange is ONE all-reduce of ONE flat fp32 gradient bucket per step: every parameter's .grad is a view into the
@@ -24,13 +26,33 @@ def shard_batch(t: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
     return t[rank * per:(rank + 1) * per]
 
 
+def _link_views(params, flat, attr):
+    """Makes `p.<attr>` (data or grad) of every parameter a view into the flat bucket, preserving current values."""
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            view = flat[off:off + n].view_as(p)
+            if attr == "data":
+                view.copy_(p.data)
+                p.data = view
+            else:
+                if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+                p.grad = view
+            off += n
+
+
 class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr) (vpsuite.py:353) as ONE HIP kernel over flat buckets: `params` are views into
     `flat_param`, their .grad views into `flat_grad`. A torch Optimizer (param_groups / state_dict / zero_grad), so LR
-    schedulers such as ReduceLROnPlateau (vpsuite.py:354) drive it unchanged."""
+    schedulers such as ReduceLROnPlateau (vpsuite.py:354) drive it unchanged. One parameter group only."""
 
     def __init__(self, params, flat_param, flat_grad, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            raise ValueError("FlatAdam: a single parameter group only (the flat buckets carry one set of hyper-parameters)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.flat_param, self.flat_grad = flat_param, flat_grad
         self.exp_avg = torch.zeros_like(flat_param)
         self.exp_avg_sq = torch.zeros_like(flat_param)
@@ -46,15 +68,39 @@ class FlatAdam(torch.optim.Optimizer):
         dev = params[0].device
         flat_p = torch.empty(total, dtype=torch.float32, device=dev)
         flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
-        with torch.no_grad():
-            for p in params:
-                n = p.numel()
-                flat_p[off:off + n].copy_(p.reshape(-1))
-                p.data = flat_p[off:off + n].view_as(p)
-                p.grad = flat_g[off:off + n].view_as(p)
-                off += n
+        _link_views(params, flat_p, "data")
+        _link_views(params, flat_g, "grad")
         return cls(params, flat_p, flat_g, lr=lr, **kw)
+
+    def add_param_group(self, param_group):
+        if getattr(self, "param_groups", None):
+            raise ValueError("FlatAdam: a single parameter group only")
+        super().add_param_group(param_group)
+
+    def _relink(self):
+        """The update reads flat_grad and writes flat_param, so both must still back the parameters. `zero_grad(
+        set_to_none=True)` (torch's default on a plain Optimizer), `p.grad = None` or `model.to()` break the link and
+        autograd then accumulates into fresh tensors: detect that here and repair it instead of stepping on stale data."""
+        gbase = self.flat_grad.untyped_storage().data_ptr()
+        pbase = self.flat_param.untyped_storage().data_ptr()
+        off = 0
+        for p in self.param_groups[0]["params"]:
+            n = p.numel()
+            if p.data.untyped_storage().data_ptr() != pbase:
+                if p.device != self.flat_param.device:
+                    raise RuntimeError("FlatAdam: a parameter left the device of its flat bucket (model.to() after the "
+                                       "optimizer was built); rebuild the optimizer with FlatAdam.from_module")
+                view = self.flat_param[off:off + n].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+            if p.grad is None:
+                self.flat_grad[off:off + n].zero_()
+                p.grad = self.flat_grad[off:off + n].view_as(p)
+            elif p.grad.untyped_storage().data_ptr() != gbase:
+                view = self.flat_grad[off:off + n].view_as(p)
+                view.copy_(p.grad)
+                p.grad = view
+            off += n
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -63,6 +109,7 @@ class FlatAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._relink()
         g = self.param_groups[0]
         self.steps += 1
         ops.adam_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.steps, g["lr"], g["betas"],
@@ -75,35 +122,46 @@ class FlatAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()  # grads stay views of the bucket
 
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["flat_adam"] = {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "steps": self.steps}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        fa = state_dict.pop("flat_adam", None)
+        super().load_state_dict(state_dict)
+        if fa is not None:
+            self.exp_avg.copy_(fa["exp_avg"])
+            self.exp_avg_sq.copy_(fa["exp_avg_sq"])
+            self.steps = int(fa["steps"])
+
 
 class DataParallelTrainer:
+    """`all_reduce` is the collective of the single exchange step (default torch.distributed.all_reduce(SUM)); tests
+    replace it to execute the world>1 arithmetic (sum of shard gradients, 1/W folded into the update) on one device."""
+
     def __init__(self, model, lr: float = 1e-4, world_size: int = None, losses_and_scales=None, device=None,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, all_reduce=None, broadcast=None):
         self.model = model
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = device if device is not None else self.params[0].device
         self.loss_provider = PredictionLossProvider({"device": dev, "losses_and_scales": losses_and_scales or {"mse": 1.0}})
+        self._all_reduce = all_reduce if all_reduce is not None else (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        self._broadcast = broadcast if broadcast is not None else (lambda t, src: dist.broadcast(t, src=src))
         # one flat gradient bucket; parameter grads are views into it
         total = sum(p.numel() for p in self.params)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
         for p in self.params:
-            n = p.numel()
-            p.grad = self.flat_grad[off:off + n].view_as(p)
-            off += n
+            p.grad = None
+        _link_views(self.params, self.flat_grad, "grad")
         self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
         self.fused = torch.device(dev).type == "cuda"
         if self.fused:
             # parameters become views of ONE flat bucket as well, so the update is one kernel over (param, grad, m, v)
             self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
-            off = 0
-            with torch.no_grad():
-                for p in self.params:
-                    n = p.numel()
-                    self.flat_param[off:off + n].copy_(p.reshape(-1))
-                    p.data = self.flat_param[off:off + n].view_as(p)
-                    off += n
+            _link_views(self.params, self.flat_param, "data")
         if self.collectives:
             self.broadcast_parameters()
         self.optimizer = FlatAdam(self.params, self.flat_param, self.flat_grad, lr=lr) if self.fused \
@@ -113,10 +171,11 @@ class DataParallelTrainer:
     def broadcast_parameters(self, src: int = 0):
         with torch.no_grad():
             if getattr(self, "fused", False):
-                dist.broadcast(self.flat_param, src=src)  # one message for the whole model
+                self._broadcast(self.flat_param, src)  # one message for the whole model
+                torch.autograd.graph.increment_version(self.params)
                 return
             for p in self.params:
-                dist.broadcast(p.data, src=src)
+                self._broadcast(p.data, src)
 
     def loss(self, predictions, targets, model_losses):
         _, total = self.loss_provider.get_losses(predictions, targets)
@@ -125,9 +184,22 @@ class DataParallelTrainer:
                 total = total + value
         return total
 
+    def backward_shard(self, x, target, pred_frames: int, **fwd_kwargs):
+        """Forward + loss + backward on this rank's shard; leaves the shard's gradient in `flat_grad`. Models with their
+        own training semantics (PredRNN-V2: scheduled sampling, reversed pass) provide `training_loss`."""
+        self.flat_grad.zero_()
+        hook = getattr(self.model, "training_loss", None)
+        if hook is not None:
+            total = hook(x, target, pred_frames, self.loss_provider, **fwd_kwargs)
+        else:
+            predictions, model_losses = self.model(x, pred_frames=pred_frames, **fwd_kwargs)
+            total = self.loss(predictions, target, model_losses)
+        total.backward()
+        return total.detach()
+
     def reduce_gradients(self):
         if self.collectives:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM)
+            self._all_reduce(self.flat_grad)
             if self.world > 1:
                 if self.fused:
                     self.optimizer.grad_scale = 1.0 / self.world  # folded into the update kernel
@@ -136,13 +208,10 @@ class DataParallelTrainer:
 
     def step(self, x, target, pred_frames: int, **fwd_kwargs):
         """One optimisation step on this rank's shard. Returns the local loss tensor (no host sync)."""
-        self.flat_grad.zero_()
-        predictions, model_losses = self.model(x, pred_frames=pred_frames, **fwd_kwargs)
-        total = self.loss(predictions, target, model_losses)
-        total.backward()
+        total = self.backward_shard(x, target, pred_frames, **fwd_kwargs)
         self.reduce_gradients()
         self.optimizer.step()
-        return total.detach()
+        return total
 
     @torch.no_grad()
     def validate(self, batches, pred_frames: int):
@@ -152,7 +221,7 @@ class DataParallelTrainer:
         self.model.train()
         v = torch.stack(vals).mean()
         if self.world > 1:
-            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            self._all_reduce(v)
             v = v / self.world
         self.scheduler.step(v.item())
         return v
