@@ -75,6 +75,12 @@ const char* vpx_last_error(void);
  * partial sums with floating-point atomics (results equal up to fp32 summation order, ~1e-7 relative). 1: no atomics
  * anywhere (slower on 16x16 / 32x32 maps). Process-wide; returns the previous setting. */
 int vpx_set_deterministic(int on);
+/* Kernel-selection switches for A/B measurements and parity tests inside one process (results never depend on them beyond
+ * fp32 summation order). Returns the previous value, or a negative error code for an unknown option.
+ *   VPX_OPT_CELL2        0 = the first-generation fused cell kernel everywhere; 1 (default) = the second-generation kernel
+ *                        (pre-split operands, LDS-DMA staging) where it applies and fills the chip; 2 = wherever it applies */
+#define VPX_OPT_CELL2 1
+int vpx_set_option(int option, int value);
 
 /* ---- ConvLSTM over a sequence ------------------------------------------------------------------------------ */
 size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d); /* scratch, contents undefined between calls */

@@ -98,11 +98,16 @@ def test_trainer_runs_predrnn_training_semantics(vpx):
     lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
     cfg = {"device": "cuda", "context_frames": T, "pred_frames": P, "val_rec_criterion": "mse"}
     data = {"frames": frames, "actions": torch.zeros(B, T + P - 1, 0)}
-    for _ in range(2):
-        tr.step(frames, frames[:, T:], P)
-        b.train_iter(cfg, [data], opt, lp, epoch=0)
+    torch.use_deterministic_algorithms(True)  # no K-split atomics: both runs sum in the same order
+    try:
+        for _ in range(2):
+            tr.step(frames, frames[:, T:], P)
+            b.train_iter(cfg, [data], opt, lp, epoch=0)
+    finally:
+        torch.use_deterministic_algorithms(False)
     assert a.training_iteration == b.training_iteration == 3
-    assert np.abs(_flat(a) - _flat(b)).max() < 1e-6
+    # a semantic difference (no reversed pass, test-time mask) moves every weight by ~lr = 1e-3 per step
+    assert np.abs(_flat(a) - _flat(b)).max() < 2e-5
 
 
 def test_flat_adam_survives_set_to_none_and_keeps_state(vpx):

@@ -17,8 +17,10 @@ PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 FLAG_SAVE_FOR_BWD = 1
 FLAG_WEIGHTS_PACKED = 2
 
+OPT_CELL2 = 1
+
 EXPORTED_SYMBOLS = [
-    "vpx_version", "vpx_last_error", "vpx_set_deterministic",
+    "vpx_version", "vpx_last_error", "vpx_set_deterministic", "vpx_set_option",
     "vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes", "vpx_convlstm_seq_fwd", "vpx_convlstm_seq_bwd",
     "vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes", "vpx_stlstm_step_fwd", "vpx_stlstm_step_bwd",
     "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
@@ -77,6 +79,8 @@ def lib():
         L.vpx_last_error.restype = ctypes.c_char_p
         L.vpx_set_deterministic.restype = ctypes.c_int
         L.vpx_set_deterministic.argtypes = [ctypes.c_int]
+        L.vpx_set_option.restype = ctypes.c_int
+        L.vpx_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
         for name in ("vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes"):
             getattr(L, name).restype = sz
             getattr(L, name).argtypes = [ctypes.POINTER(ConvLSTMDesc)]

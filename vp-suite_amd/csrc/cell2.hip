@@ -1,0 +1,398 @@
+// cell2.hip — second-generation fused ConvLSTM step for gfx950: split-bf16 ("bf16x3") arithmetic on PRE-SPLIT operands,
+// one 8-wave workgroup per CU owning a 32x16-pixel tile x (4 gates x 32 channels), every operand byte moved
+// HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) with the next stage in flight across the chunk barriers.
+// Computes exactly what conv_gemm_kernel<EpiConvLSTM, bf16x3> computes (same operand split, same accumulation order:
+// outputs are identical up to fp32 summation order); restates conv_lstm_hzzone.py:59-68 / conv_lstm_ndrplz.py:31-41 like it.
+//
+// Why a second kernel (measured on the first one): with 256-pixel tiles every CU pulled 3 MB of packed
+// weights per launch through its load path (43 us of a 243 us launch), each workgroup converted its activation halo
+// fp32 -> (hi, lo) itself (n_tiles x halo overlap = 2.5-3.8x redundant VALU work) and the staging phases of the two
+// co-resident workgroups hardly overlapped the other's MFMA phases (MFMA-only 160 us + everything-else 126 us -> 243 us).
+// Here: 512 pixels share every weight chunk (half the traffic), operands arrive split (staging is a pure copy, no VALU,
+// no registers), and the copy of stage s+1 / chunk c+2 runs under the MFMAs of stage s / chunk c.
+//
+// Split tensor format ("sp"): per pixel, per group of 8 channels: 8 hi bf16 (16 B) then 8 lo bf16 (16 B); a pixel row is
+// C*4 bytes like the fp32 row it replaces. Producers: split_convert_kernel (block input x, initial state h0) and the
+// cell epilogue itself (h_t for step t+1 — and for the weight-gradient kernel, which contracts the same operands).
+//
+// LDS images are "lane linear": a 16-byte piece lands at base + piece*16, and every fragment read of the MFMA loop
+// is base(lane) + immediate with consecutive lanes on consecutive 16-byte slots -> conflict-free without padding:
+//   activation stage (16 channels): [plane = part*2 + khalf][pos (34x18 halo, padded to 640)][16 B]   40 KiB, x2 buffers
+//   weight chunk (one tap row = 3 k-steps of 16): [q = dx][part][khalf][n = gate*32 + j][16 B]       24 KiB, x3 ring
+#include <stdlib.h>
+
+#include "vpx_internal.h"
+
+namespace vpx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int C2_HALO_W = 18;                   // 16 + 3 - 1
+constexpr int C2_NPOS = 34 * C2_HALO_W;         // 612 halo positions of a 32x16 tile
+constexpr int C2_PLANE_POS = 640;               // padded so that 4 planes are exactly 5 pieces per thread (512 threads)
+constexpr int C2_PLANE = C2_PLANE_POS * 16;
+constexpr int C2_ABUF = 4 * C2_PLANE;           // 40960 B
+constexpr int C2_WCHUNK = 3 * 2 * 2 * 128 * 16; // 24576 B
+constexpr int C2_LDS = 2 * C2_ABUF + 3 * C2_WCHUNK;  // 155648 B <= 160 KiB
+
+__device__ const float c2_zero16[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};  // source of out-of-image pieces
+
+__device__ __forceinline__ unsigned short c2_bf16_bits(float v) {
+    __bf16 h = (__bf16)v;  // v_cvt_pk_bf16_f32: round to nearest even (same split as conv_gemm.hip's split_bf16)
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ void c2_split(float v, unsigned& hi, unsigned& lo) {
+    const unsigned short h = c2_bf16_bits(v);
+    hi = h;
+    lo = c2_bf16_bits(v - __builtin_bit_cast(float, (unsigned)h << 16));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 NHWC [npix][C] -> split format. One thread per (pixel, 8-channel group). HBM-bound, 8 B per element.
+__global__ __launch_bounds__(256) void split_convert_kernel(const float* __restrict__ src, char* __restrict__ dst,
+                                                            long long ngroups, int gpp /* groups per pixel = C/8 */) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ngroups) return;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + idx * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + idx * 8 + 4);
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c2_split(a[i], h[i], l[i]); c2_split(b[i], h[4 + i], l[4 + i]); }
+    uint4 hv = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    uint4 lv = {l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    *reinterpret_cast<uint4*>(dst + idx * 32) = hv;
+    *reinterpret_cast<uint4*>(dst + idx * 32 + 16) = lv;
+    (void)gpp;
+}
+
+hipError_t launch_split_convert(const float* src, void* dst, long long npix, int C, hipStream_t s) {
+    const long long ngroups = npix * (C / 8);
+    const long long blocks = (ngroups + 255) / 256;
+    hipLaunchKernelGGL(split_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, reinterpret_cast<char*>(dst), ngroups, C / 8);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight repack: reference OIHW [4Ch, Cin+Ch, 3, 3] -> [n_tile][chunk = stage*3 + dy][q = dx][part][khalf][n][8 bf16]
+__global__ void cell2_pack_kernel(const Cell2Pack pk, char* __restrict__ dst) {
+    const long long total = (long long)pk.n_tiles * pk.chunks_total * (C2_WCHUNK / 2);  // bf16 elements
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e & 7);
+        long long r = e >> 3;
+        const int n = (int)(r & 127); r >>= 7;
+        const int khalf = (int)(r & 1); r >>= 1;
+        const int part = (int)(r & 1); r >>= 1;
+        const int q = (int)(r % 3); r /= 3;
+        const int chunk = (int)(r % pk.chunks_total);
+        const int n_tile = (int)(r / pk.chunks_total);
+        const int stage = chunk / 3, dy = chunk - stage * 3;
+        const int g = n >> 5, j = n & 31;
+        const int ch = n_tile * 32 + j;
+        float v = 0.0f;
+        if (ch < pk.Ch) {
+            const int row = pk.gate_pos[g] * pk.Ch + ch;
+            const int col = pk.stage_col[stage] + khalf * 8 + i;   // column in [x | h]
+            v = pk.w[((long long)row * pk.Ct + col) * 9 + dy * 3 + q];
+        }
+        unsigned hi, lo;
+        c2_split(v, hi, lo);
+        reinterpret_cast<unsigned short*>(dst)[e] = (unsigned short)(part ? lo : hi);
+    }
+}
+
+hipError_t launch_cell2_pack(const Cell2Pack& pk, void* dst, hipStream_t s) {
+    const long long total = (long long)pk.n_tiles * pk.chunks_total * (C2_WCHUNK / 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cell2_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
+    return hipGetLastError();
+}
+
+size_t cell2_packed_bytes(int n_tiles, int chunks_total) { return (size_t)n_tiles * chunks_total * C2_WCHUNK; }
+
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void c2_dma16(const char* g, char* lds_wave_base) {
+    // 64 lanes x 16 B: lane l's bytes land at lds_wave_base + 16*l (M0 = wave-uniform base)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ int c2_px(int i) { return (i & 16) ? ((i + 14) & 15) : (i & 15); }
+
+#define C2_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__device__ __forceinline__ void c2_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// The ConvLSTM epilogue (conv_lstm_hzzone.py:62-68), plus the split copy of h_t for the next step / the weight gradient.
+// Addressing: one 24-bit multiply per pixel (pixel index x Ch), every array is a wave-uniform base + that 32-bit element
+// offset; FULL = the tile lies inside the image (no per-pixel bounds test). The first-generation epilogue spent ~45
+// address instructions per pixel, 14 of them quarter-rate 32-bit multiplies — invisible next to a second resident
+// workgroup, a quarter of the tile time with one workgroup per CU.
+struct Cell2Epi {
+    ConvLSTMStepArgs a;
+    char* h_sp;               // split h_t [B][HW][Ch] (or null)
+    long long h_sp_bstride;   // bytes between batch items
+
+    template <bool FULL>
+    __device__ __forceinline__ void run(const f32x16 (&acc)[4], int b, int y0, int x0, int n_tile, int prow, int j, int hh,
+                                        int H, int W) const {
+        const int ch = n_tile * 32 + j;
+        if (ch >= a.Ch) return;
+        const unsigned Ch = (unsigned)a.Ch;
+        float bi = 0.f, bf = 0.f, bg = 0.f, bo = 0.f;
+        if (a.bias) {
+            bi = a.bias[a.gate_pos[0] * Ch + ch];
+            bf = a.bias[a.gate_pos[1] * Ch + ch];
+            bg = a.bias[a.gate_pos[2] * Ch + ch];
+            bo = a.bias[a.gate_pos[3] * Ch + ch];
+        }
+        const size_t img = (size_t)b * H * W;                       // wave-uniform
+        const float* const cin_b = a.c_in ? a.c_in + img * Ch : nullptr;
+        float* const cout_b = a.c_out + img * Ch;
+        float* const hout_b = a.h_out + (size_t)b * a.h_bstride;
+        float* const g0 = a.gates ? a.gates + img * 4 * Ch : nullptr;
+        char* const hsp_b = h_sp ? h_sp + (size_t)b * h_sp_bstride : nullptr;
+        const int che = ch & ~1;
+        const unsigned sp_off = (unsigned)((che >> 3) * 32 + (che & 7) * 2 + ((j & 1) ? 16 : 0));
+        const int rowpix = (y0 + prow) * W + x0;                    // wave-uniform: pixel index of (tile row prow, column 0)
+        constexpr int RB = 8;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += RB) {
+            bool ok[RB];
+            unsigned eo[RB], po[RB];
+            float cpv[RB], wi[RB], wf[RB], wo[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int r = r0 + u;
+                const int k = (r & 3) + 8 * ((r >> 2) & 1) + 4 * hh;        // column inside the sub-tile row before rotation
+                const int row = r >> 3;                                    // accumulator registers 8..15 hold the odd row
+                const int px = row ? ((k + 14) & 15) : k;                  // c2_px
+                const int pix = rowpix + row * W + px;
+                ok[u] = FULL || (y0 + prow + row < H && x0 + px < W);
+                po[u] = __umul24((unsigned)pix, Ch);
+                eo[u] = po[u] + (unsigned)ch;
+                cpv[u] = 0.f; wi[u] = 0.f; wf[u] = 0.f; wo[u] = 0.f;
+                if (ok[u]) {
+                    if (cin_b) cpv[u] = cin_b[eo[u]];
+                    if (a.wci) { wi[u] = a.wci[eo[u]]; wf[u] = a.wcf[eo[u]]; }
+                    if (a.wco) wo[u] = a.wco[eo[u]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                if (!ok[u]) continue;   // uniform over the lanes of a 32-lane half (depends on r and hh only)
+                const int r = r0 + u;
+                const float cp = cpv[u];
+                const float ai = acc[0][r] + bi + wi[u] * cp, af = acc[1][r] + bf + wf[u] * cp;
+                const float ag = acc[2][r] + bg;
+                const float i_ = sigmoid_f(ai), f_ = sigmoid_f(af), g_ = tanh_f(ag);
+                const float cn = f_ * cp + i_ * g_;
+                const float ao = acc[3][r] + bo + wo[u] * cn;
+                const float o_ = sigmoid_f(ao);
+                const float hn = o_ * tanh_f(cn);
+                cout_b[eo[u]] = cn;
+                hout_b[eo[u]] = hn;
+                if (g0) {
+                    const unsigned go = 4u * po[u] + (unsigned)ch;
+                    g0[go] = i_;
+                    g0[go + Ch] = f_;
+                    g0[go + 2 * Ch] = g_;
+                    g0[go + 3 * Ch] = o_;
+                }
+                if (hsp_b) {
+                    unsigned hi, lo;
+                    c2_split(hn, hi, lo);
+                    // neighbour lane (j ^ 1) inside the quad: quad_perm [1,0,3,2] = 0xB1
+                    const unsigned nhi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, true);
+                    const unsigned nlo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, true);
+                    const unsigned word = (j & 1) ? (nlo | (lo << 16)) : (hi | (nhi << 16));
+                    *reinterpret_cast<unsigned*>(hsp_b + (4u * po[u] + sp_off)) = word;
+                }
+            }
+        }
+    }
+};
+
+// Fragment registers of the MFMA loop: three activation sets (one per tap column dx, so the set of dx = 0 can be refilled
+// for the next chunk while dx = 2 is still being multiplied) and two weight sets (even / odd gate group).
+struct C2Frags {
+    bf16x8 ah[3][2], al[3][2];
+    bf16x8 bh[2], bl[2];
+};
+
+__global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const Cell2Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hh = lane >> 5;
+
+    // XCD-aware tile decode (same rule as conv_gemm.hip's xcd_tile: N tile fastest, contiguous ranges per XCD)
+    const unsigned L = blockIdx.x;
+    const long long total = (long long)P.grid_m * P.n_tiles;
+    const long long per_xcd = (total + 7) / 8;
+    const long long sidx = (long long)(L & 7) * per_xcd + (L >> 3);
+    if ((long long)(L >> 3) >= per_xcd || sidx >= total) return;
+    int mt = (int)(sidx / P.n_tiles);
+    const int n_tile = (int)(sidx - (long long)mt * P.n_tiles);
+    const int tx = mt % P.tiles_x;
+    mt /= P.tiles_x;
+    const int ty = mt % P.tiles_y;
+    const int b = mt / P.tiles_y;
+    const int x0 = tx * 16, y0 = ty * 32;
+
+    char* const Abuf = smem;
+    char* const Wbuf = smem + 2 * C2_ABUF;
+
+    // this thread's five pieces of an activation stage: piece = tid + 512 u -> (plane, halo position)
+    int pixoff[5], choff[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int piece = tid + 512 * u;
+        const int plane = piece / C2_PLANE_POS, pos = piece - plane * C2_PLANE_POS;
+        const int hy = pos / C2_HALO_W, hx = pos - hy * C2_HALO_W;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = pos < C2_NPOS && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+        pixoff[u] = ok ? gy * P.W + gx : -1;
+        choff[u] = (plane & 1) * 32 + (plane >> 1) * 16;  // plane = part*2 + khalf; pixel row: [group][hi 16 B | lo 16 B]
+    }
+    const int dma_off = (wave * 64) * 16;  // wave-uniform LDS offset of this wave's 64 pieces inside a 512-piece pass
+    const char* const wtile = P.wpk + (size_t)n_tile * P.chunks_total * C2_WCHUNK + tid * 16;
+
+    auto issue_A = [&](int s, int buf) {
+        const Cell2Stage st = P.stage[s];
+        const Cell2Seg sg = P.seg[st.seg];
+        const char* base = sg.sp + (size_t)b * sg.bstride + st.c0 * 4;
+        const size_t prow = (size_t)sg.C * 4;
+        char* dst = Abuf + buf * C2_ABUF + dma_off;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const char* src = pixoff[u] >= 0 ? base + (size_t)pixoff[u] * prow + choff[u] : reinterpret_cast<const char*>(c2_zero16);
+            c2_dma16(src, dst + u * 8192);
+        }
+    };
+    auto issue_W = [&](int chunk, int buf) {
+        const char* src = wtile + (size_t)chunk * C2_WCHUNK;
+        char* dst = Wbuf + buf * C2_WCHUNK + dma_off;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) c2_dma16(src + u * 8192, dst + u * 8192);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][g][r] = 0.0f;
+
+    // MFMA row j of a sub-tile = pixel (row j>>4, column c2_px(j)): the odd row's columns are rotated by 14 so that the 16
+    // lanes a ds_read_b128 serves per cycle ({0-3,12-15,20-27} / {4-11,16-19,28-31}) fall on 16 different 16-byte bank
+    // groups although the halo row pitch is 18 slots (unrotated: two 2-way conflicts per group)
+    const int a_lane = hh * C2_PLANE + ((4 * wave + (j >> 4)) * C2_HALO_W + c2_px(j)) * 16;
+    const int w_lane = hh * 2048 + j * 16;
+    C2Frags F;
+    auto load_A = [&](const char* A, int dy, int dx) {   // the four activation fragments of tap (dy, dx) -> set dx
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int off = ((2 * m + dy) * C2_HALO_W + dx) * 16;
+            F.ah[dx][m] = *reinterpret_cast<const bf16x8*>(A + off);
+            F.al[dx][m] = *reinterpret_cast<const bf16x8*>(A + 2 * C2_PLANE + off);
+        }
+    };
+    auto load_B = [&](const char* Wb, int dx, int g) {   // the two weight fragments of (k-step dx, gate g) -> set g & 1
+        F.bh[g & 1] = *reinterpret_cast<const bf16x8*>(Wb + dx * 8192 + g * 512);
+        F.bl[g & 1] = *reinterpret_cast<const bf16x8*>(Wb + dx * 8192 + 4096 + g * 512);
+    };
+
+    // Pipeline (chunk c = tap row dy of stage s; weight ring of three chunks, two activation buffers):
+    //   sync point P_c sits before the 9th of the 12 gate groups of chunk c: wait for this thread's pieces of chunk c+1 (and
+    //   of stage s+1 when c is the stage's last chunk) -> barrier -> issue the copy of chunk c+2 (its ring slot was last read
+    //   in chunk c-1, which every wave has left) and, in a stage's first chunk, of stage s+1's halo tile. The last group of
+    //   chunk c then already reads the first fragments of chunk c+1: no LDS latency is exposed at a chunk boundary, and a
+    //   copy has a whole chunk (weights) or two (activations) of MFMA time to land.
+    const int S = P.nstage;
+    if (S > 0) {
+        issue_A(0, 0);
+        issue_W(P.stage[0].chunk0, 0);
+        issue_W(P.stage[0].chunk0 + 1, 1);
+        C2_WAIT_VM(3);  // stage 0 and chunk 0 have landed (chunk 1 may still fly)
+        c2_barrier();
+        load_A(Abuf + a_lane, 0, 0);
+        load_B(Wbuf + w_lane, 0, 0);
+    }
+    for (int s = 0; s < S; ++s) {
+        const bool more = s + 1 < S;
+        const char* A = Abuf + (s & 1) * C2_ABUF + a_lane;
+        const char* An = Abuf + ((s + 1) & 1) * C2_ABUF + a_lane;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const char* Wb = Wbuf + dy * C2_WCHUNK + w_lane;
+            const char* Wn = Wbuf + ((dy + 1) % 3) * C2_WCHUNK + w_lane;
+            const bool has_next = dy < 2 || more;   // another chunk follows this one
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                const int dx = n >> 2, g = n & 3;
+                if (n == 8) {
+                    // ---- sync point P_c ----
+                    if (dy == 1 && more) C2_WAIT_VM(5); else C2_WAIT_VM(0);   // dy == 1: stage s+1's tile may still fly
+                    c2_barrier();
+                    if (dy == 0) {
+                        issue_W(P.stage[s].chunk0 + 2, 2);
+                        if (more) issue_A(s + 1, (s + 1) & 1);
+                    } else if (more) {
+                        issue_W(P.stage[s + 1].chunk0 + dy - 1, dy - 1);
+                    }
+                }
+                // ---- fragments of the next gate group ----
+                if (n < 11) {
+                    const int ndx = (n + 1) >> 2, ng = (n + 1) & 3;
+                    load_B(Wb, ndx, ng);
+                    if (ng == 0) load_A(A, dy, ndx);
+                } else if (has_next) {
+                    load_B(Wn, 0, 0);
+                    load_A(dy < 2 ? A : An, dy < 2 ? dy + 1 : 0, 0);
+                }
+                // ---- 6 MFMAs of gate group (dx, g) ----
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    f32x16 c = acc[m][g];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.al[dx][m], F.bh[g & 1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah[dx][m], F.bl[g & 1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.ah[dx][m], F.bh[g & 1], c, 0, 0, 0);
+                    acc[m][g] = c;
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+    }
+    const bool full = y0 + 32 <= P.H && x0 + 16 <= P.W;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (full) epi.run<true>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, P.H, P.W);
+        else epi.run<false>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, P.H, P.W);
+    }
+}
+
+hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    Cell2Plan p = plan;
+    p.grid_m = plan.B * plan.tiles_x * plan.tiles_y;
+    const long long per_xcd = ((long long)p.grid_m * p.n_tiles + 7) / 8;
+    Cell2Epi epi{ea, reinterpret_cast<char*>(h_sp), h_sp_bstride};
+    hipLaunchKernelGGL(cell2_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), C2_LDS, s, p, epi);
+    return hipGetLastError();
+}
+
+}  // namespace vpx

@@ -18,6 +18,7 @@ void set_error(const char* fmt, ...) {
 }
 
 int g_deterministic = 0;
+int g_cell2_mode = -1;
 
 }  // namespace vpx
 
@@ -28,6 +29,15 @@ extern "C" {
 int vpx_version(void) { return VPX_VERSION; }
 int vpx_set_deterministic(int on) { const int prev = vpx::g_deterministic; vpx::g_deterministic = on ? 1 : 0; return prev; }
 const char* vpx_last_error(void) { return g_err; }
+int vpx_set_option(int option, int value) {
+    if (option == VPX_OPT_CELL2) {
+        const int prev = cell2_mode();
+        vpx::g_cell2_mode = value < 0 ? 0 : (value > 2 ? 2 : value);
+        return prev;
+    }
+    set_error("vpx_set_option: unknown option %d", option);
+    return VPX_ERR_ARG;
+}
 
 int vpx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, void* stream) {
     if (!src || !dst || N < 1 || C < 1 || H < 1 || W < 1) { set_error("vpx_nchw_to_nhwc: bad argument"); return VPX_ERR_ARG; }
@@ -60,6 +70,8 @@ size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
     // forward: packed weights + cell scratch (+ NCHW staging)
     size_t fwd = align256(convlstm_wpk_bytes(d, L)) + align256(L.n_state * sizeof(float));
     if (L.split) fwd += align256(4 * L.n_state * sizeof(float));  // gate pre-activations of one step
+    if (L.v2)  // packed weights of cell2 + split copies of x, h0 and a two-slot ring of h_t
+        fwd += align256(cell2_packed_bytes(L.n_tiles, 3 * ((d->Cin + d->Ch) / 16))) + align256(L.n_x * 4) + 3 * align256(L.n_state * 4);
     if (d->layout == VPX_LAYOUT_NCHW)
         fwd += align256(L.n_x * 4) + align256(L.n_out * 4) + 4 * align256(L.n_state * 4) + 3 * align256(L.n_peep * 4);
     // backward (only with SAVE_FOR_BWD): packed dgrad weights + dG for all steps + dh/dc carries + wgrad K-slice slabs
@@ -97,6 +109,14 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     float* wpk = ws.take(convlstm_wpk_bytes(d, L) / sizeof(float));
     float* c_scratch = ws.take(L.n_state);
     float* pre_scratch = L.split ? ws.take(4 * L.n_state) : nullptr;
+    char *wpk2 = nullptr, *x_sp = nullptr, *h0_sp = nullptr, *h_ring[2] = {nullptr, nullptr};
+    if (L.v2) {
+        wpk2 = (char*)ws.take(cell2_packed_bytes(L.n_tiles, 3 * ((Cin + Ch) / 16)) / sizeof(float));
+        x_sp = (char*)ws.take(L.n_x);
+        h0_sp = (char*)ws.take(L.n_state);
+        h_ring[0] = (char*)ws.take(L.n_state);
+        h_ring[1] = (char*)ws.take(L.n_state);
+    }
 
     // ---- layout adaptation (reference NCHW -> native NHWC) ----
     const float *xn = x, *h0n = h0, *c0n = c0, *wci = Wci, *wcf = Wcf, *wco = Wco;
@@ -135,7 +155,16 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     pd.taps = L.taps;
     pd.transposed = 0;
     pd.flip = 0;
-    if (L.split) {  // plain layout: output channel n = reference row n of W (gate-major), s_ng * 32 rows per N tile
+    if (L.v2) {
+        Cell2Pack pk{};
+        pk.w = W; pk.Ch = Ch; pk.Ct = Cin + Ch; pk.n_tiles = L.n_tiles; pk.chunks_total = 3 * ((Cin + Ch) / 16);
+        memcpy(pk.gate_pos, gp, sizeof(gp));
+        for (int s = 0; s < (Cin + Ch) / 16; ++s) pk.stage_col[s] = 16 * s;  // x stages first, then h: columns of [x | h] in order
+        VPX_CHECK_HIP(launch_cell2_pack(pk, wpk2, stream));
+        // operands of the steps in split form: the whole input sequence and the initial hidden state, once
+        if (xn) VPX_CHECK_HIP(launch_split_convert(xn, x_sp, (long long)B * T * (long long)HW, Cin, stream));
+        if (h0n) VPX_CHECK_HIP(launch_split_convert(h0n, h0_sp, (long long)B * (long long)HW, Ch, stream));
+    } else if (L.split) {  // plain layout: output channel n = reference row n of W (gate-major), s_ng * 32 rows per N tile
         memcpy(pd.stage, L.s_stage, sizeof(ConvStage) * L.s_nstage);
         pd.nstage = L.s_nstage;
         pd.chunks_total = L.s_chunks;
@@ -151,7 +180,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         pd.tile_stride = 32;
         pd.nch = Ch;
     }
-    VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+    if (!L.v2) VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
 
     float* gates_all = nullptr;
     float* cs_all = nullptr;
@@ -198,7 +227,20 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         ea.wci = wci; ea.wcf = wcf; ea.wco = wco;
         ea.h_out = outn + (size_t)t * HW * Ch;
         ea.h_bstride = (long long)((size_t)T * HW * Ch);
-        if (L.split) {
+        if (L.v2) {
+            Cell2Plan P2{};
+            P2.B = B; P2.H = H; P2.W = Wd; P2.tiles_x = (Wd + 15) / 16; P2.tiles_y = (H + 31) / 32; P2.n_tiles = L.n_tiles;
+            P2.chunks_total = 3 * ((Cin + Ch) / 16);
+            P2.wpk = wpk2;
+            const char* hprev_sp = (t == 0) ? (h0n ? h0_sp : nullptr) : h_ring[(t - 1) & 1];
+            P2.seg[0] = Cell2Seg{xn ? x_sp + (size_t)t * HW * Cin * 4 : nullptr, (long long)((size_t)T * HW * Cin * 4), Cin, 0};
+            P2.seg[1] = Cell2Seg{hprev_sp, (long long)(HW * Ch * 4), Ch, 0};
+            P2.nstage = 0;
+            if (xn) for (int c0 = 0; c0 < Cin; c0 += 16) P2.stage[P2.nstage++] = Cell2Stage{0, c0, 3 * (c0 / 16), 0};
+            if (hprev_sp) for (int c0 = 0; c0 < Ch; c0 += 16) P2.stage[P2.nstage++] = Cell2Stage{1, c0, 3 * ((Cin + c0) / 16), 0};
+            // the split copy of h_t feeds step t+1 only: the last step does not need it
+            VPX_CHECK_HIP(launch_cell2(P2, ea, (t + 1 < T) ? h_ring[t & 1] : nullptr, (long long)(HW * Ch * 4), stream));
+        } else if (L.split) {
             // pre-activations of all four gates by a K-split plain convolution (atomic partial sums), then the gates
             float* pre = ea.gates ? ea.gates : pre_scratch;  // with SAVE_FOR_BWD the reserve slot doubles as scratch
             VPX_CHECK_HIP(hipMemsetAsync(pre, 0, 4 * L.n_state * sizeof(float), stream));

@@ -87,8 +87,27 @@ static inline int wgrad_target_wgs() {
     return v;
 }
 
+// Second-generation fused cell (cell2.hip) applies to: bf16x3, 3x3, channel counts in whole 16-channel stages, maps
+// taller than half a 32x16 tile, and a launch of at least one workgroup per CU. VPX_CELL2=0 disables it, =2 forces it
+// wherever the shape allows (experiments).
+extern int g_cell2_mode;  // vpx_api.hip: -1 = not yet read from the environment
+static inline int cell2_mode() {
+    if (g_cell2_mode < 0) { const char* e = getenv("VPX_CELL2"); g_cell2_mode = e ? atoi(e) : 1; }
+    return g_cell2_mode;
+}
+static inline bool cell2_applicable(const vpx_convlstm_desc* d) {
+    if (cell2_mode() == 0) return false;
+    if (d->precision != VPX_PREC_BF16X3 || d->kh != 3 || d->kw != 3) return false;
+    if ((d->Cin & 15) || (d->Ch & 15) || (d->Cin + d->Ch) / 16 > MAX_STAGE) return false;
+    if (d->H <= 16) return false;
+    if (cell2_mode() == 2) return true;
+    const long long wgs = (long long)d->B * ((d->H + 31) / 32) * ((d->W + 15) / 16) * ((d->Ch + 31) / 32);
+    return wgs >= 256;
+}
+
 struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     int taps, n_tiles, nstage, chunks_total;
+    int v2;                        // 1: the forward steps run on cell2_kernel (pre-split operands)
     int mw;                        // forward cell kernel: 32-pixel row tiles per wave
     int qpc, d_qpc;                // k-steps per weight chunk of the forward cell / data-gradient launches (2 or 3)
     ConvStage stage[MAX_STAGE];
@@ -133,6 +152,7 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
             if (ks > 1) { L.split = ks; L.s_ng = ng; L.s_tiles = tiles; }
         }
     }
+    L.v2 = (!L.split && cell2_applicable(d)) ? 1 : 0;
     L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
     L.n_x = (size_t)d->B * d->T * d->H * d->W * d->Cin;
     L.n_out = (size_t)d->B * d->T * d->H * d->W * d->Ch;

@@ -114,6 +114,26 @@ struct ConvLSTMStepArgs {
     float* gates;             // [B,H,W,4Ch] post-activation (i,f,g,o) or null
 };
 hipError_t launch_convlstm_step_f32(const ConvPlan& plan, const ConvLSTMStepArgs& ea, int n_tiles, hipStream_t s);
+// ---- second-generation fused cell (cell2.hip): bf16x3, 3x3, pre-split operands, all-DMA staging ----
+struct Cell2Seg { const char* sp; long long bstride; int C; int _pad; };   // split tensor, BYTES between batch items, channels (multiple of 16)
+struct Cell2Stage { int seg, c0, chunk0, _p; };                            // 16 channels [c0, c0+16) of a segment; first weight chunk
+struct Cell2Plan {
+    int B, H, W, tiles_x, tiles_y, n_tiles, nstage, chunks_total, grid_m, _p;
+    Cell2Seg seg[2];
+    Cell2Stage stage[MAX_STAGE];
+    const char* wpk;          // [n_tiles][chunks_total][24576 B]
+};
+struct Cell2Pack {
+    const float* w;           // reference OIHW [4Ch, Ct, 3, 3]
+    int Ch, Ct, n_tiles, chunks_total;
+    int gate_pos[4];
+    int stage_col[MAX_STAGE]; // column in [x | h] of the first channel of packed stage s (chunks 3s .. 3s+2)
+};
+hipError_t launch_split_convert(const float* src, void* dst, long long npix, int C, hipStream_t s);  // fp32 NHWC -> split format
+hipError_t launch_cell2_pack(const Cell2Pack& pk, void* dst, hipStream_t s);
+size_t cell2_packed_bytes(int n_tiles, int chunks_total);
+hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s);
+
 // pointwise half of the K-split step: pre-activations pre [B*HW, 4Ch] (reference gate order) -> gates, c, h (pointwise.hip)
 hipError_t launch_convlstm_pointwise(const ConvLSTMStepArgs& ea, const float* pre, int B, long long HW, hipStream_t s);
 
