@@ -114,9 +114,15 @@ size_t cell2_packed_bytes(int n_tiles, int chunks_total) { return (size_t)n_tile
 
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void c2_dma16(const char* g, char* lds_wave_base) {
-    // 64 lanes x 16 B: lane l's bytes land at lds_wave_base + 16*l (M0 = wave-uniform base)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    // 64 lanes x 16 B: lane l's bytes land at lds_wave_base + 16*l (M0 = wave-uniform base).
+    // Inline asm on purpose: while a compiler-visible LDS-DMA (__builtin_amdgcn_global_load_lds) is pending, hipcc's
+    // waitcnt pass treats it as an access to BOTH memory and LDS and degrades every later wait to lgkmcnt(0) / vmcnt(0)
+    // — the MFMA loop then waited for the fragments it had just requested (72 % matrix-pipe use by a lone wave, measured).
+    // Hidden in asm, the loop's ds_reads get counted waits; the DMA's own completion is waited for by hand (C2_WAIT_VM)
+    // at the sync points, and compiler-made vmcnt waits (epilogue loads) only become stricter by the extra queue entries.
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds)) : "memory", "m0");
 }
 
 __device__ __forceinline__ int c2_px(int i) { return (i & 16) ? ((i + 14) & 15) : (i & 15); }
@@ -219,6 +225,15 @@ struct Cell2Epi {
     }
 };
 
+#ifdef VPX_ABLATE
+// developer build only (make ablate): per-wave s_memtime stamps of ONE workgroup (block id = Cell2Plan::_p), read back with
+// vpx_dbg_cell2_stamps(). Never compiled into the product library.
+__device__ unsigned long long c2_stamps[8 * 64];
+#define C2_STAMP(slot) do { if (stamp_on && lane == 0) c2_stamps[wave * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C2_STAMP(slot) do { } while (0)
+#endif
+
 // Fragment registers of the MFMA loop: three activation sets (one per tap column dx, so the set of dx = 0 can be refilled
 // for the next chunk while dx = 2 is still being multiplied) and two weight sets (even / odd gate group).
 struct C2Frags {
@@ -248,6 +263,10 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
 
     char* const Abuf = smem;
     char* const Wbuf = smem + 2 * C2_ABUF;
+#ifdef VPX_ABLATE
+    const bool stamp_on = (int)L == P._p;
+#endif
+    C2_STAMP(0);
 
     // this thread's five pieces of an activation stage: piece = tid + 512 u -> (plane, halo position)
     int pixoff[5], choff[5];
@@ -264,23 +283,33 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
     const int dma_off = (wave * 64) * 16;  // wave-uniform LDS offset of this wave's 64 pieces inside a 512-piece pass
     const char* const wtile = P.wpk + (size_t)n_tile * P.chunks_total * C2_WCHUNK + tid * 16;
 
+    // one 16-byte piece per call: the copies of a sync point are spread over the following gate groups (one or two pieces
+    // behind each group's MFMAs) instead of issued as a burst — a burst right after the barrier kept all eight waves off
+    // the matrix pipe for the 0.3-0.8k cycles the 3-8 LDS-DMA issues take (measured with in-kernel stamps)
+    // scalars of a stage (wave-uniform arithmetic on kernel arguments, no memory access)
+    const int nx = P.nx, S = P.nx + P.nh;
+    const char* const xb = P.seg[0].sp + (size_t)b * P.seg[0].bstride;
+    const char* const hb = P.seg[1].sp + (size_t)b * P.seg[1].bstride;
+    const unsigned xrow = (unsigned)P.seg[0].C * 4u, hrow = (unsigned)P.seg[1].C * 4u;
+    auto stage_chunk0 = [&](int s) { return 3 * (s < nx ? s : P.hs_off + s - nx); };
+    auto issue_A1 = [&](int s, int buf, int u) {
+        const bool isx = s < nx;
+        const char* base = isx ? xb + s * 64 : hb + (s - nx) * 64;   // 16 channels = 64 bytes of a split pixel row
+        const unsigned prow = isx ? xrow : hrow;
+        const char* src = pixoff[u] >= 0 ? base + (size_t)((unsigned)pixoff[u] * (unsigned long long)prow) + choff[u]
+                                         : reinterpret_cast<const char*>(c2_zero16);
+        c2_dma16(src, Abuf + buf * C2_ABUF + dma_off + u * 8192);
+    };
+    auto issue_W1 = [&](int chunk, int buf, int u) {
+        c2_dma16(wtile + (size_t)chunk * C2_WCHUNK + u * 8192, Wbuf + buf * C2_WCHUNK + dma_off + u * 8192);
+    };
     auto issue_A = [&](int s, int buf) {
-        const Cell2Stage st = P.stage[s];
-        const Cell2Seg sg = P.seg[st.seg];
-        const char* base = sg.sp + (size_t)b * sg.bstride + st.c0 * 4;
-        const size_t prow = (size_t)sg.C * 4;
-        char* dst = Abuf + buf * C2_ABUF + dma_off;
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const char* src = pixoff[u] >= 0 ? base + (size_t)pixoff[u] * prow + choff[u] : reinterpret_cast<const char*>(c2_zero16);
-            c2_dma16(src, dst + u * 8192);
-        }
+        for (int u = 0; u < 5; ++u) issue_A1(s, buf, u);
     };
     auto issue_W = [&](int chunk, int buf) {
-        const char* src = wtile + (size_t)chunk * C2_WCHUNK;
-        char* dst = Wbuf + buf * C2_WCHUNK + dma_off;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) c2_dma16(src + u * 8192, dst + u * 8192);
+        for (int u = 0; u < 3; ++u) issue_W1(chunk, buf, u);
     };
 
     f32x16 acc[2][4];
@@ -316,18 +345,20 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
     //   in chunk c-1, which every wave has left) and, in a stage's first chunk, of stage s+1's halo tile. The last group of
     //   chunk c then already reads the first fragments of chunk c+1: no LDS latency is exposed at a chunk boundary, and a
     //   copy has a whole chunk (weights) or two (activations) of MFMA time to land.
-    const int S = P.nstage;
     if (S > 0) {
         issue_A(0, 0);
-        issue_W(P.stage[0].chunk0, 0);
-        issue_W(P.stage[0].chunk0 + 1, 1);
+        issue_W(stage_chunk0(0), 0);
+        issue_W(stage_chunk0(0) + 1, 1);
+        C2_STAMP(1);
         C2_WAIT_VM(3);  // stage 0 and chunk 0 have landed (chunk 1 may still fly)
         c2_barrier();
+        C2_STAMP(2);
         load_A(Abuf + a_lane, 0, 0);
         load_B(Wbuf + w_lane, 0, 0);
     }
     for (int s = 0; s < S; ++s) {
         const bool more = s + 1 < S;
+        const int ck_cur = stage_chunk0(s), ck_next = stage_chunk0(s + 1);
         const char* A = Abuf + (s & 1) * C2_ABUF + a_lane;
         const char* An = Abuf + ((s + 1) & 1) * C2_ABUF + a_lane;
 #pragma unroll
@@ -340,14 +371,11 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
                 const int dx = n >> 2, g = n & 3;
                 if (n == 8) {
                     // ---- sync point P_c ----
+                    if (s < 3) C2_STAMP(3 + (s * 3 + dy) * 3);
                     if (dy == 1 && more) C2_WAIT_VM(5); else C2_WAIT_VM(0);   // dy == 1: stage s+1's tile may still fly
+                    if (s < 3) C2_STAMP(4 + (s * 3 + dy) * 3);
                     c2_barrier();
-                    if (dy == 0) {
-                        issue_W(P.stage[s].chunk0 + 2, 2);
-                        if (more) issue_A(s + 1, (s + 1) & 1);
-                    } else if (more) {
-                        issue_W(P.stage[s + 1].chunk0 + dy - 1, dy - 1);
-                    }
+                    if (s < 3) C2_STAMP(5 + (s * 3 + dy) * 3);
                 }
                 // ---- fragments of the next gate group ----
                 if (n < 11) {
@@ -369,14 +397,33 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
                     acc[m][g] = c;
                 }
                 __builtin_amdgcn_s_setprio(0);
+                // ---- this sync point's copies, spread behind the MFMAs of groups 8..11: weights first (3 pieces), then the
+                //      next stage's halo tile (5 pieces) — the vmcnt waits at the sync points count on exactly this order ----
+                if (n >= 8) {
+                    const int k = n - 8;   // 0..3
+                    if (dy == 0) {
+                        if (k < 3) issue_W1(ck_cur + 2, 2, k);
+                        if (more) {
+                            if (k == 2) issue_A1(s + 1, (s + 1) & 1, 0);
+                            if (k == 3) {
+#pragma unroll
+                                for (int u = 1; u < 5; ++u) issue_A1(s + 1, (s + 1) & 1, u);
+                            }
+                        }
+                    } else if (more && k < 3) {
+                        issue_W1(ck_next + dy - 1, dy - 1, k);
+                    }
+                }
             }
         }
     }
+    C2_STAMP(40);
     const bool full = y0 + 32 <= P.H && x0 + 16 <= P.W;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         if (full) epi.run<true>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, P.H, P.W);
         else epi.run<false>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, P.H, P.W);
+        C2_STAMP(41 + m);
     }
 }
 
@@ -389,6 +436,9 @@ hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void*
     }
     Cell2Plan p = plan;
     p.grid_m = plan.B * plan.tiles_x * plan.tiles_y;
+#ifdef VPX_ABLATE
+    { const char* e = getenv("VPX_C2_STAMP_BLOCK"); p._p = e ? atoi(e) : -1; }
+#endif
     const long long per_xcd = ((long long)p.grid_m * p.n_tiles + 7) / 8;
     Cell2Epi epi{ea, reinterpret_cast<char*>(h_sp), h_sp_bstride};
     hipLaunchKernelGGL(cell2_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), C2_LDS, s, p, epi);
@@ -396,3 +446,9 @@ hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void*
 }
 
 }  // namespace vpx
+
+#ifdef VPX_ABLATE
+extern "C" int vpx_dbg_cell2_stamps(unsigned long long* out512) {
+    return (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(vpx::c2_stamps), sizeof(unsigned long long) * 512);
+}
+#endif

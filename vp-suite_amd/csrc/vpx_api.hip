@@ -235,9 +235,9 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             const char* hprev_sp = (t == 0) ? (h0n ? h0_sp : nullptr) : h_ring[(t - 1) & 1];
             P2.seg[0] = Cell2Seg{xn ? x_sp + (size_t)t * HW * Cin * 4 : nullptr, (long long)((size_t)T * HW * Cin * 4), Cin, 0};
             P2.seg[1] = Cell2Seg{hprev_sp, (long long)(HW * Ch * 4), Ch, 0};
-            P2.nstage = 0;
-            if (xn) for (int c0 = 0; c0 < Cin; c0 += 16) P2.stage[P2.nstage++] = Cell2Stage{0, c0, 3 * (c0 / 16), 0};
-            if (hprev_sp) for (int c0 = 0; c0 < Ch; c0 += 16) P2.stage[P2.nstage++] = Cell2Stage{1, c0, 3 * ((Cin + c0) / 16), 0};
+            P2.nx = xn ? Cin / 16 : 0;
+            P2.nh = hprev_sp ? Ch / 16 : 0;
+            P2.hs_off = Cin / 16;
             // the split copy of h_t feeds step t+1 only: the last step does not need it
             VPX_CHECK_HIP(launch_cell2(P2, ea, (t + 1 < T) ? h_ring[t & 1] : nullptr, (long long)(HW * Ch * 4), stream));
         } else if (L.split) {

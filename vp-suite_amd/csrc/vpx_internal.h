@@ -116,11 +116,13 @@ struct ConvLSTMStepArgs {
 hipError_t launch_convlstm_step_f32(const ConvPlan& plan, const ConvLSTMStepArgs& ea, int n_tiles, hipStream_t s);
 // ---- second-generation fused cell (cell2.hip): bf16x3, 3x3, pre-split operands, all-DMA staging ----
 struct Cell2Seg { const char* sp; long long bstride; int C; int _pad; };   // split tensor, BYTES between batch items, channels (multiple of 16)
-struct Cell2Stage { int seg, c0, chunk0, _p; };                            // 16 channels [c0, c0+16) of a segment; first weight chunk
+// K stages (16 channels x 9 taps each) run x first, then h: nx / nh stages of the operands PRESENT in this launch (an
+// absent operand — no input tensor, zero initial state — is skipped); stage k of h reads packed weight chunks
+// 3 * (hs_off + k) .. +2, stage k of x chunks 3k .. 3k+2. No per-stage table: everything the loop needs is scalar
+// arithmetic on these fields (a table walk cost an s_load + s_waitcnt lgkmcnt(0) per copy inside the MFMA loop).
 struct Cell2Plan {
-    int B, H, W, tiles_x, tiles_y, n_tiles, nstage, chunks_total, grid_m, _p;
+    int B, H, W, tiles_x, tiles_y, n_tiles, nx, nh, hs_off, chunks_total, grid_m, _p;
     Cell2Seg seg[2];
-    Cell2Stage stage[MAX_STAGE];
     const char* wpk;          // [n_tiles][chunks_total][24576 B]
 };
 struct Cell2Pack {
