@@ -167,7 +167,7 @@ struct Cell2Epi {
         const int che = ch & ~1;
         const unsigned sp_off = (unsigned)((che >> 3) * 32 + (che & 7) * 2 + ((j & 1) ? 16 : 0));
         const int rowpix = (y0 + prow) * W + x0;                    // wave-uniform: pixel index of (tile row prow, column 0)
-        constexpr int RB = 8;
+        constexpr int RB = 16;
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += RB) {
             bool ok[RB];
