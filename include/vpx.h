@@ -173,14 +173,16 @@ size_t vpx_conv2d_ex_workspace_bytes(const vpx_conv_desc* d);
 /* y [N,Ho,Wo,Co]. A stride-2 transposed convolution runs as 4 output-phase launches of the same kernel. */
 int vpx_conv2d_ex_fwd(const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                       void* workspace, size_t workspace_bytes, void* stream);
-/* Backward of the same layer (the reference gets it from autograd over nn.Conv2d / nn.ConvTranspose2d, ef_blocks.py:15-49):
- * dy [N,Ho,Wo,Co] is the gradient w.r.t. the convolution output BEFORE bias/activation handling is undone by the caller
- * (i.e. already multiplied by LeakyReLU'); dx [N,H,W,Ci] and dw (layout of w) are written, either may be NULL.
+/* Backward of the same layer (the reference gets it from autograd over nn.Conv2d / nn.ConvTranspose2d (+ LeakyReLU),
+ * ef_blocks.py:15-49): dy [N,Ho,Wo,Co] is the gradient w.r.t. the layer OUTPUT (after bias and activation); y is that
+ * output as vpx_conv2d_ex_fwd produced it — needed (and only read) when d->leaky_slope != 0: the activation derivative is
+ * taken from its sign. dx [N,H,W,Ci], dw (layout of w) and db [Co] are written; each may be NULL. db and the LeakyReLU'
+ * scaling are one pass over dy, summed in a fixed order (bit-reproducible).
  * dx is the adjoint layer run forward (transposed <-> plain, through vpx_conv2d_ex_fwd's kernels); dw contracts dy with
  * the stride-decimated sub-images of x (or x with those of dy) on the MFMA weight-gradient kernel. Needs kh, kw >= stride. */
 size_t vpx_conv2d_ex_bwd_workspace_bytes(const vpx_conv_desc* d);
-int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, const float* dy, float* dx, float* dw,
-                      void* workspace, size_t workspace_bytes, void* stream);
+int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, const float* y, const float* dy, float* dx,
+                      float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- layout adaptors: src [N,C,H,W] <-> dst [N,H,W,C] -------------------------------------------------------- */
 int vpx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, void* stream);

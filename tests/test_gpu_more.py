@@ -366,17 +366,52 @@ def test_small_grids_fused_and_split_paths_agree(vpx):
     Wr = Wt.clone().requires_grad_(True)
     ref, _ = tr.convlstm_hzzone_seq(xr, None, T, Wr, b, *pw)
     (ref ** 2).sum().backward()
+    br = b.clone().requires_grad_(True)
+    ref2, _ = tr.convlstm_hzzone_seq(x, None, T, Wt, br, *pw)
+    (ref2 ** 2).sum().backward()
     runs = {}
     for det in (False, True, True):
         torch.use_deterministic_algorithms(det)
         try:
             xg = x.cuda().requires_grad_(True)
             Wg = Wt.cuda().requires_grad_(True)
-            out, hT, cT = vpx.ops.convlstm_seq(xg, None, None, Wg, b.cuda(), *[p.cuda() for p in pw], seq_len=T,
-                                               in_channels=Cin)
+            bg = b.cuda().requires_grad_(True)
+            pg = [p.cuda().requires_grad_(True) for p in pw]
+            out, hT, cT = vpx.ops.convlstm_seq(xg, None, None, Wg, bg, *pg, seq_len=T, in_channels=Cin)
             (out ** 2).sum().backward()
         finally:
             torch.use_deterministic_algorithms(False)
         assert _relmax(out, ref) < 1e-5 and _relmax(xg.grad, xr.grad) < 5e-5 and _relmax(Wg.grad, Wr.grad) < 5e-5, det
-        runs.setdefault(det, []).append(out.detach().clone())
-    assert torch.equal(runs[True][0], runs[True][1])
+        assert _relmax(bg.grad, br.grad) < 5e-5, det
+        runs.setdefault(det, []).append([t.detach().clone() for t in (out, xg.grad, Wg.grad, bg.grad, *[p.grad for p in pg])])
+    # deterministic mode: bit-identical forward AND every gradient (dx, dW, db, peepholes) — ADVICE r1: the bias gradient
+    # used float atomics regardless of the mode
+    for a, c in zip(runs[True][0], runs[True][1]):
+        assert torch.equal(a, c)
+
+
+def test_bias_gradients_are_bit_reproducible(vpx):
+    """db of the ConvLSTM block and of the glue layers sums in a fixed order in EVERY mode (no atomics): two runs agree
+    bit for bit on a shape with several thousand partial rows, and match a float64 column sum."""
+    Cin, Ch, H, W, B, T = 16, 32, 32, 32, 6, 3
+    Wt = seeded_randn((4 * Ch, Cin + Ch, 3, 3), name_seed("db.W"), 1.0 / np.sqrt((Cin + Ch) * 9)).cuda()
+    x = seeded_rand((B, T, Cin, H, W), name_seed("db.x")).cuda()
+    got = []
+    for _ in range(2):
+        bg = seeded_randn((4 * Ch,), name_seed("db.b"), 0.1).cuda().requires_grad_(True)
+        out, _, _ = vpx.ops.convlstm_seq(x, None, None, Wt, bg, seq_len=T, in_channels=Cin, gate_order=vpx._lib.GATE_IFOG)
+        (out ** 2).sum().backward()
+        got.append(bg.grad.clone())
+    assert torch.equal(got[0], got[1])
+    w = seeded_randn((24, 16, 3, 3), name_seed("db.gw"), 0.1).cuda()
+    xs = seeded_randn((10, 16, 40, 40), name_seed("db.gx")).cuda()
+    gy = seeded_randn((10, 24, 20, 20), name_seed("db.gy")).cuda()
+    res = []
+    for _ in range(2):
+        bb = torch.zeros(24, device="cuda", requires_grad=True)
+        y = vpx.ops.conv2d_ex(xs, w, bb, 2, 1, False, 0.2, "f32")
+        (y * gy).sum().backward()
+        res.append(bb.grad.clone())
+    assert torch.equal(res[0], res[1])
+    want = (gy.double() * torch.where(y > 0, 1.0, 0.2).double()).sum(dim=(0, 2, 3))
+    assert _relmax(res[0], want.float()) < 1e-5

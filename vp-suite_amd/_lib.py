@@ -118,7 +118,7 @@ def lib():
         L.vpx_conv2d_ex_bwd_workspace_bytes.restype = sz
         L.vpx_conv2d_ex_bwd_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
         L.vpx_conv2d_ex_bwd.restype = ctypes.c_int
-        L.vpx_conv2d_ex_bwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 5 + [vp, sz, vp]
+        L.vpx_conv2d_ex_bwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7 + [vp, sz, vp]
         L.vpx_mse_loss_workspace_bytes.restype = sz
         L.vpx_mse_loss_workspace_bytes.argtypes = []
         L.vpx_mse_loss.restype = ctypes.c_int

@@ -12,7 +12,7 @@ extern "C" {
 size_t vpx_conv2d_bwd_workspace_bytes(int N, int H, int W, int Ci, int Co, int kh, int kw) {
     if (N < 1 || H < 1 || W < 1 || Ci < 1 || Co < 1) return 0;
     return align256(plain_conv_wpk_floats(Co, Ci, kh, kw) * 4) +
-           align256((size_t)wgrad_slices(N, H, W) * kh * kw * Co * Ci * 4) + 512;
+           align256((size_t)wgrad_slices(N, H, W) * kh * kw * Co * Ci * 4) + align256((size_t)COLSUM_BLOCKS * Co * 4) + 512;
 }
 
 int vpx_conv2d_nhwc_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int N, int H,
@@ -29,15 +29,13 @@ int vpx_conv2d_nhwc_bwd(const float* x, const float* w, const float* dy, float* 
     ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
     float* wpk = ws.take(plain_conv_wpk_floats(Co, Ci, kh, kw));
     float* slabs = ws.take((size_t)wgrad_slices(N, H, W) * kh * kw * Co * Ci);
+    float* db_part = ws.take((size_t)COLSUM_BLOCKS * Co);
     const ConvGeo g{N, H, W};
     int rc;
     if (dx && (rc = plain_conv(stream, precision, g, dy, Co, Co, w, (long long)Ci * kh * kw, kh * kw, kh, kw, Ci, true,
                                nullptr, dx, Ci, false, wpk))) return rc;
     if (dw && (rc = plain_wgrad(stream, precision, g, dy, Co, x, Ci, kh, kw, slabs, dw))) return rc;
-    if (db) {
-        VPX_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)Co * sizeof(float), stream));
-        VPX_CHECK_HIP(launch_colsum(dy, db, (long long)N * H * W, Co, stream));
-    }
+    if (db) VPX_CHECK_HIP(launch_colsum(dy, nullptr, 0.f, nullptr, db, db_part, (long long)N * H * W, Co, stream));
     return VPX_OK;
 }
 
@@ -374,11 +372,14 @@ size_t vpx_conv2d_ex_bwd_workspace_bytes(const vpx_conv_desc* d) {
     ExGeo g;
     vpx_conv_desc a;
     if (ex_check(d, g) != VPX_OK || ex_adjoint(d, g, a) != VPX_OK) return 0;
-    return align256(ex_wpk_floats(&a) * 4) + align256(ex_bwd_slab_floats(d, g) * 4) + 1024;
+    // + the LeakyReLU'-scaled copy of dy and the bias-gradient partials
+    const size_t n_dy = (size_t)d->N * g.Ho * g.Wo * d->Co;
+    return align256(ex_wpk_floats(&a) * 4) + align256(ex_bwd_slab_floats(d, g) * 4) + align256(n_dy * 4) +
+           align256((size_t)COLSUM_BLOCKS * d->Co * 4) + 1024;
 }
 
-int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, const float* dy, float* dx, float* dw,
-                      void* workspace, size_t workspace_bytes, void* stream_) {
+int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, const float* y, const float* dy, float* dx,
+                      float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream_) {
     ExGeo g;
     int rc = ex_check(d, g);
     if (rc != VPX_OK) return rc;
@@ -392,6 +393,19 @@ int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, co
     ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
     float* wpk = ws.take(ex_wpk_floats(&a));
     float* slabs = ws.take(ex_bwd_slab_floats(d, g));
+    const size_t n_dy = (size_t)d->N * g.Ho * g.Wo * d->Co;
+    float* dys = ws.take(n_dy);
+    float* db_part = ws.take((size_t)COLSUM_BLOCKS * d->Co);
+    if (d->leaky_slope != 0.0f) {
+        // d(pre-activation) = dy * LeakyReLU'(.), the derivative read off the sign of the forward OUTPUT (same sign as the
+        // pre-activation for a positive slope) — one pass that also yields the bias gradient
+        if (!y) { set_error("vpx_conv2d_ex_bwd: y (forward output) is required when leaky_slope != 0"); return VPX_ERR_ARG; }
+        if (d->leaky_slope < 0.0f) { set_error("vpx_conv2d_ex_bwd: negative leaky_slope is not implemented"); return VPX_ERR_UNSUPPORTED; }
+        VPX_CHECK_HIP(launch_colsum(dy, y, d->leaky_slope, dys, db, db_part, (long long)d->N * g.Ho * g.Wo, d->Co, stream));
+        dy = dys;
+    } else if (db) {
+        VPX_CHECK_HIP(launch_colsum(dy, nullptr, 0.f, nullptr, db, db_part, (long long)d->N * g.Ho * g.Wo, d->Co, stream));
+    }
     if (dx) {
         ExGeo ga{d->H, d->W};
         if ((rc = ex_forward(&a, ga, dy, w, nullptr, dx, wpk, stream)) != VPX_OK) return rc;

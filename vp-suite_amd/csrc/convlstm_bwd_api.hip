@@ -41,6 +41,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     float* slabs = ws.take(L.slab_floats);
     const int gb_blocks = gate_bwd_blocks((int)HW, Ch);
     float* db_part = ws.take((size_t)T * gb_blocks * N4);
+    float* db_part2 = ws.take((size_t)COLSUM_BLOCKS * N4);
 
     // ---- layout adaptation ----
     const float *xn = x, *h0n = h0, *c0n = c0, *outn = out, *doutn = dout, *dhTn = dhT, *dcTn = dcT;
@@ -158,10 +159,8 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         VPX_CHECK_HIP(launch_wgrad(wa, L.n_slices, stream));
         VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dW, L.n_slices, L.taps, N4, Ct, stream));
     }
-    if (db) {
-        VPX_CHECK_HIP(hipMemsetAsync(db, 0, (size_t)N4 * sizeof(float), stream));
-        VPX_CHECK_HIP(launch_colsum(db_part, db, (long long)T * gb_blocks, N4, stream));  // block partials from the gate-backward kernel
-    }
+    if (db)  // block partials from the gate-backward kernel, summed in a fixed order
+        VPX_CHECK_HIP(launch_colsum(db_part, nullptr, 0.f, nullptr, db, db_part2, (long long)T * gb_blocks, N4, stream));
     if (d->layout == VPX_LAYOUT_NCHW) {
         if (dx) VPX_CHECK_HIP(launch_nhwc_to_nchw(dxn, dx, B * T, Cin, H, Wd, stream));
         if (dh0) VPX_CHECK_HIP(launch_nhwc_to_nchw(dh0n, dh0, B, Ch, H, Wd, stream));

@@ -17,13 +17,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void convlstm_gate_bwd_kernel(const GateBwdArgs a) {
-    extern __shared__ float db_lds[];  // [4Ch] block-local bias-gradient sums (only when a.db_partial)
+    __shared__ float db_vals[4][256];  // per-thread bias-gradient sums of this block (only when a.db_partial)
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int HW = a.HW, Ch = a.Ch;
-    if (a.db_partial) {
-        for (int n = threadIdx.x; n < 4 * Ch; n += 256) db_lds[n] = 0.0f;
-        __syncthreads();
-    }
     const bool active = idx < HW * Ch;
     const int pix = active ? idx / Ch : 0, ch = active ? idx - pix * Ch : 0;
     float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;
@@ -64,45 +60,79 @@ __global__ __launch_bounds__(256) void convlstm_gate_bwd_kernel(const GateBwdArg
         a.dwco[pc] += dpo;
     }
     }  // active
-    if (a.db_partial) {  // bias gradient: LDS float atomics within the block, one plain row per block to HBM
-        if (active) {
-            atomicAdd(&db_lds[a.gate_pos[0] * Ch + ch], sb0);
-            atomicAdd(&db_lds[a.gate_pos[1] * Ch + ch], sb1);
-            atomicAdd(&db_lds[a.gate_pos[2] * Ch + ch], sb2);
-            atomicAdd(&db_lds[a.gate_pos[3] * Ch + ch], sb3);
-        }
+    if (a.db_partial) {
+        // bias gradient, bit-reproducible: thread k of the block owns channel (start + k) % Ch; output (gate, c) is the sum
+        // over the block's positions of channel c in increasing k — a fixed order, no atomics; one plain row per block
+        db_vals[0][threadIdx.x] = sb0; db_vals[1][threadIdx.x] = sb1;   // inactive threads hold zeros
+        db_vals[2][threadIdx.x] = sb2; db_vals[3][threadIdx.x] = sb3;
         __syncthreads();
-        for (int n = threadIdx.x; n < 4 * Ch; n += 256) a.db_partial[(size_t)blockIdx.x * 4 * Ch + n] = db_lds[n];
+        const int start_ch = (int)(((long long)blockIdx.x * 256) % Ch);
+        for (int n = threadIdx.x; n < 4 * Ch; n += 256) {
+            const int gl = n / Ch, c = n - gl * Ch;
+            float acc = 0.f;
+            for (int k = (c - start_ch + Ch) % Ch; k < 256; k += Ch) acc += db_vals[gl][k];
+            a.db_partial[(size_t)blockIdx.x * 4 * Ch + a.gate_pos[gl] * Ch + c] = acc;
+        }
     }
 }
 
 hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s) {
-    const size_t lds = a.db_partial ? (size_t)4 * a.Ch * sizeof(float) : 0;
-    hipLaunchKernelGGL(convlstm_gate_bwd_kernel, dim3(gate_bwd_blocks(a.HW, a.Ch)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(convlstm_gate_bwd_kernel, dim3(gate_bwd_blocks(a.HW, a.Ch)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// column sums of a [rows][cols] matrix, atomically added to out[cols] (bias gradient)
-__global__ void colsum_kernel(const float* __restrict__ m, float* __restrict__ out, long long rows, int cols,
-                              long long rows_per_block) {
+// Column sums of a [rows][cols] matrix (bias gradients), bit-reproducible: level 1 sums row ranges into partial[block][cols]
+// (within a block the threads of one column add their strided rows, then a fixed-order LDS combine), level 2 adds the
+// block rows in order. Optional LeakyReLU': with `y` given, the summed (and, if `scaled` is given, stored) value is
+// m * (y > 0 ? 1 : slope) — the glue's activation derivative from the sign of the forward output.
+__global__ __launch_bounds__(256) void colsum_l1_kernel(const float* __restrict__ m, const float* __restrict__ y, float slope,
+                                                        float* __restrict__ scaled, float* __restrict__ partial, long long rows,
+                                                        int cols, long long rows_per_block) {
+    __shared__ float comb[256];
     const long long r0 = blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    for (int c0 = 0; c0 < cols; c0 += 256) {
+        const int cw = cols - c0 < 256 ? cols - c0 : 256;
+        const int rpp = 256 / cw;                    // rows handled per pass
+        const int t = threadIdx.x, col = c0 + t % cw, roff = t / cw;
         float acc = 0.f;
-        for (long long r = r0; r < r1; ++r) acc += m[r * cols + c];
-        atomicAdd(out + c, acc);
+        if (roff < rpp)
+            for (long long r = r0 + roff; r < r1; r += rpp) {
+                float v = m[r * cols + col];
+                if (y) {
+                    v *= y[r * cols + col] > 0.0f ? 1.0f : slope;
+                    if (scaled) scaled[r * cols + col] = v;
+                }
+                acc += v;
+            }
+        comb[t] = roff < rpp ? acc : 0.f;
+        __syncthreads();
+        if (t < cw) {
+            float sum = 0.f;
+            for (int k = 0; k < rpp; ++k) sum += comb[k * cw + t];
+            if (partial) partial[(size_t)blockIdx.x * cols + c0 + t] = sum;
+        }
+        __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void colsum_l2_kernel(const float* __restrict__ partial, float* __restrict__ out, int nrows, int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float sum = 0.f;
+    for (int r = 0; r < nrows; ++r) sum += partial[(size_t)r * cols + c];
+    out[c] = sum;
+}
 
-hipError_t launch_colsum(const float* m, float* out, long long rows, int cols, hipStream_t s) {
-    int blocks = 512;
+hipError_t launch_colsum(const float* m, const float* y, float slope, float* scaled, float* out, float* partial_ws,
+                         long long rows, int cols, hipStream_t s) {
+    int blocks = COLSUM_BLOCKS;
     if (rows < blocks) blocks = (int)rows;
     const long long rpb = (rows + blocks - 1) / blocks;
     blocks = (int)((rows + rpb - 1) / rpb);
-    int threads = cols < 256 ? ((cols + 63) / 64 * 64) : 256;
-    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(threads), 0, s, m, out, rows, cols, rpb);
+    hipLaunchKernelGGL(colsum_l1_kernel, dim3(blocks), dim3(256), 0, s, m, y, slope, scaled, out ? partial_ws : nullptr, rows, cols, rpb);
+    if (out) hipLaunchKernelGGL(colsum_l2_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial_ws, out, blocks, cols);
     return hipGetLastError();
 }
 

@@ -189,6 +189,7 @@ static inline size_t convlstm_bwd_workspace_bytes(const vpx_convlstm_desc* d, co
     b += 2 * align256(L.n_state * sizeof(float));                 // dh, dc carries
     b += align256(L.slab_floats * sizeof(float));
     b += align256((size_t)d->T * gate_bwd_blocks(d->H * d->W, d->Ch) * 4 * d->Ch * sizeof(float));  // bias-gradient partials
+    b += align256((size_t)COLSUM_BLOCKS * 4 * d->Ch * sizeof(float));                                // ... and their second level
     if (d->layout == VPX_LAYOUT_NCHW) {
         // staged copies of x, out, dout, dx + states (h0,c0,dhT,dcT,dh0,dc0) + 6 peephole-sized buffers
         b += 2 * align256(L.n_x * 4) + 2 * align256(L.n_out * 4) + 6 * align256(L.n_state * 4) + 6 * align256(L.n_peep * 4);

@@ -211,7 +211,11 @@ struct GateBwdArgs {
 };
 inline int gate_bwd_blocks(int HW, int Ch) { return (HW * Ch + 255) / 256; }
 hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s);
-hipError_t launch_colsum(const float* m, float* out, long long rows, int cols, hipStream_t s);
+// out[c] = sum_r m[r][c] (* LeakyReLU'(y[r][c]) when y != null, the scaled matrix optionally stored), bit-reproducible;
+// partial_ws: COLSUM_BLOCKS * cols floats of scratch
+constexpr int COLSUM_BLOCKS = 512;
+hipError_t launch_colsum(const float* m, const float* y, float slope, float* scaled, float* out, float* partial_ws,
+                         long long rows, int cols, hipStream_t s);
 
 // A workgroup's 64 activation columns are two 32-channel halves (one per wave column), each its own slice
 // [c0, c0+cn) of segment seg (0 = x, 1 = h); cglobal = column in [x|h]. Halves are paired in order ACROSS the

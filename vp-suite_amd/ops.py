@@ -282,8 +282,8 @@ GLUE_BACKWARD_NATIVE = False   #: ATen fallback only: avoid MIOpen (slow; for ro
 
 class _ConvExFn(torch.autograd.Function):
     """Conv2d / ConvTranspose2d (stride 1 or 2) + bias + LeakyReLU in ONE library launch (4 for a stride-2 transposed
-    conv) — the EF stage glue of ef_blocks.py:15-49. The forward is the HIP implicit-GEMM kernel; the backward of this
-    glue (7 % of the model's FLOPs) is delegated to ATen's convolution_backward on the saved input."""
+    conv) — the EF stage glue of ef_blocks.py:15-49. Forward and backward (LeakyReLU', bias / data / weight gradients)
+    run in libvpx_hip; ATen only for kernels smaller than their stride."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, padding, transposed, slope, precision):
@@ -315,13 +315,11 @@ class _ConvExFn(torch.autograd.Function):
         _sync_determinism()
         xs, wc, y = ctx.saved_tensors
         stride, padding, transposed, slope, has_bias = ctx.cfg
-        if slope != 0.0:  # LeakyReLU' from the sign of the output (same sign as the pre-activation for slope > 0): one pass
-            dy = torch.ops.aten.leaky_relu_backward(dy, y, slope, True) if slope > 0.0 else \
-                dy * torch.where(y > 0, torch.ones((), device=y.device), torch.full((), slope, device=y.device))
         mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]]
         d = ctx.desc
-        if GLUE_BACKWARD_HIP and d.kh >= d.stride and d.kw >= d.stride:
-            # library path: dx = the adjoint layer on the implicit-GEMM kernel, dw on the MFMA weight-gradient kernel
+        if GLUE_BACKWARD_HIP and d.kh >= d.stride and d.kw >= d.stride and slope >= 0.0:
+            # library path: LeakyReLU' + bias gradient in one pass over dy, dx = the adjoint layer on the implicit-GEMM kernel,
+            # dw on the MFMA weight-gradient kernel
             L = _lib.lib()
             dyc = to_channels_last(dy)
             ws_bytes = L.vpx_conv2d_ex_bwd_workspace_bytes(ctypes.byref(d))
@@ -330,14 +328,17 @@ class _ConvExFn(torch.autograd.Function):
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
             dx = new_channels_last(tuple(xs.shape), dy.device) if mask[0] else None
             dw = torch.empty_like(wc) if mask[1] else None
-            check(L.vpx_conv2d_ex_bwd(ctypes.byref(d), ptr(xs), ptr(wc), ptr(dyc), ptr(dx), ptr(dw), ptr(ws), ws_bytes,
-                                      _stream()), "vpx_conv2d_ex_bwd")
-            db = dy.sum(dim=(0, 2, 3)) if mask[2] else None
-            return dx, dw, (db if has_bias else None), None, None, None, None, None
-        bias_sizes = [int(wc.shape[1] if transposed else wc.shape[0])] if has_bias else None
-        # fallback (kernel smaller than the stride): ATen's convolution backward = MIOpen NHWC kernels.
+            db = torch.empty(d.Co, device=dy.device) if mask[2] else None
+            check(L.vpx_conv2d_ex_bwd(ctypes.byref(d), ptr(xs), ptr(wc), ptr(y), ptr(dyc), ptr(dx), ptr(dw), ptr(db), ptr(ws),
+                                      ws_bytes, _stream()), "vpx_conv2d_ex_bwd")
+            return dx, dw, db, None, None, None, None, None
+        # fallback (kernel smaller than the stride, negative slope): ATen's convolution backward = MIOpen NHWC kernels.
         # GLUE_BACKWARD_NATIVE additionally routes it around MIOpen (MIOpen's solver search aborted the process in ~10 % of
         # the runs of a test with exotic shapes on this image, inside miopen find).
+        if slope != 0.0:  # LeakyReLU' from the sign of the output (same sign as the pre-activation for slope > 0)
+            dy = torch.ops.aten.leaky_relu_backward(dy, y, slope, True) if slope > 0.0 else \
+                dy * torch.where(y > 0, torch.ones((), device=y.device), torch.full((), slope, device=y.device))
+        bias_sizes = [int(wc.shape[1] if transposed else wc.shape[0])] if has_bias else None
         with torch.backends.cudnn.flags(enabled=not GLUE_BACKWARD_NATIVE):
             dx, dw, db = torch.ops.aten.convolution_backward(dy, xs, wc, bias_sizes, [stride, stride], [padding, padding],
                                                              [1, 1], transposed, [0, 0], 1, mask)
