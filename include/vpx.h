@@ -184,6 +184,35 @@ size_t vpx_conv2d_ex_bwd_workspace_bytes(const vpx_conv_desc* d);
 int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, const float* y, const float* dy, float* dx,
                       float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
+/* y = act(conv(x, w) + bias [+ y]): the stride-1 "same" convolution of vpx_conv2d_nhwc_fwd with an optional accumulate
+ * into the destination (two convolutions summed into one output) and LeakyReLU (slope >= 0, 0 = none) applied to the sum.
+ * Workspace: vpx_conv2d_workspace_bytes(Ci, Co, kh, kw). */
+int vpx_conv2d_nhwc_fwd_ex(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Ci, int Co,
+                           int kh, int kw, int precision, int accumulate, float leaky_slope, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* dys = dy * LeakyReLU'(y) (from the sign of the activated output y) and db[c] = sum_rows dys[.][c], one pass over
+ * [rows][cols] matrices, fixed summation order. dys and db may each be NULL. */
+size_t vpx_leaky_bwd_workspace_bytes(int cols);
+int vpx_leaky_bwd(const float* dy, const float* y, float slope, float* dys, float* db, long long rows, int cols, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* y[i] += x[i] */
+int vpx_axpy(float* y, const float* x, long long n, void* stream);
+
+/* ---- TrajGRU step pieces (vp_suite/model_blocks/traj_gru.py:148-162, 190-203), NHWC -------------------------------- *
+ * warp: warped[b,p, l*C + c] = bilinear sample of h[b,:,:,c] at pixel p displaced by -flows[b,p,2l..2l+1] with the
+ *       reference's normalisation (divide by W-1 / H-1, grid_sample align_corners=False, zero padding); C % 4 == 0.
+ *       backward: dh += scatter (float atomics; dh may be NULL), dflows written (may be NULL).
+ * gates: r = s(i0+h0), u = s(i1+h1), m = act(i2 + r*h2), next = u*prev + (1-u)*m; i2h (a [HW,3C] slice per batch item,
+ *       batch stride in elements) may be NULL; act 0 = LeakyReLU(slope) (slope 0 = ReLU), 1 = sigmoid; save [B,HW,3C]
+ *       receives (r, u, m) for the backward, which writes di2h (may be NULL), dh2h and dprev = u * dnext. */
+int vpx_trajgru_warp_fwd(const float* h, const float* flows, float* warped, int B, int H, int W, int C, int L, void* stream);
+int vpx_trajgru_warp_bwd(const float* h, const float* flows, const float* dwarped, float* dh, float* dflows, int B, int H, int W,
+                         int C, int L, void* stream);
+int vpx_trajgru_gates_fwd(const float* i2h, long long i2h_bstride, const float* h2h, const float* prev, float* next, float* save,
+                          int B, int HW, int C, int act, float slope, void* stream);
+int vpx_trajgru_gates_bwd(const float* dnext, const float* h2h, const float* prev, const float* save, float* di2h,
+                          long long di2h_bstride, float* dh2h, float* dprev, int B, int HW, int C, int act, float slope, void* stream);
+
 /* ---- layout adaptors: src [N,C,H,W] <-> dst [N,H,W,C] -------------------------------------------------------- */
 int vpx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, void* stream);
 int vpx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, void* stream);

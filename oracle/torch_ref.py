@@ -129,6 +129,19 @@ def ef_convlstm_forward(sd, x, pred_frames):
     def rnn(prefix, inputs, states, T):
         return convlstm_hzzone_seq(inputs, states, T, sd[prefix + "._conv.weight"], sd[prefix + "._conv.bias"],
                                    sd[prefix + ".Wci"], sd[prefix + ".Wcf"], sd[prefix + ".Wco"], padding=1)
+    return _ef_forward(sd, x, pred_frames, rnn)
+
+
+def ef_trajgru_forward(sd, x, pred_frames, L=13):
+    """sd: reference-named state dict of EF_TrajGRU (ef_traj_gru.py; default layer table, any channel widths, one L)."""
+    def rnn(prefix, inputs, states, T):
+        p = {k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + ".")}
+        return trajgru_seq(inputs, states, T, p, L)
+    return _ef_forward(sd, x, pred_frames, rnn)
+
+
+def _ef_forward(sd, x, pred_frames, rnn):
+    """Encoder-Forecaster skeleton (ef_blocks.py:52-128): rnn(prefix, inputs, states, T) -> (outputs, state)."""
     B, T = x.shape[:2]
     cur = x
     enc_states = []

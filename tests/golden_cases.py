@@ -108,6 +108,11 @@ def acstlstm_inputs(tag, Cin, Ch, H, W, B):
         d[n] = seeded_randn((B, Ch, H, W), name_seed(p + n), 0.5 if n in ("h", "c", "m", "a") else 1.0)
     return d
 
+# EF_TrajGRU (ef_traj_gru.py) tiny model: kwargs, B, context, pred
+EF_TRAJGRU_TINY_KW = dict(img_shape=(2, 16, 16), action_size=0, tensor_value_range=[0.0, 1.0],
+                          enc_c=[4, 8, 8, 12, 12, 12], dec_c=[12, 12, 12, 12, 8, 4], final_conv_1_c=4,
+                          enc_rnn_L=[3, 3, 3], dec_rnn_L=[3, 3, 3])
+
 # TrajGRU (traj_gru.py:74-214): tag -> (in_c, enc_c, H, W, L, B, T, mode)   mode: "full" | "noinput"
 TRAJGRU_CASES = {
     "full": (4, 8, 10, 9, 3, 2, 3, "full"),

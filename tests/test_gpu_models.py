@@ -122,3 +122,33 @@ def test_ef_convlstm_full_size_bf16x3_vs_golden(vpx):
         pred, _ = m(x.cuda(), pred_frames=10)
     err = _relmax(pred[:, :, :, ::4, ::4], g["pred_slice"])
     assert err < 1e-4, err
+
+
+def test_ef_trajgru_model_vs_golden(vpx):
+    """EF_TrajGRU ("trajgru", ef_traj_gru.py): forward, MSE loss and every parameter gradient of the tiny model against
+    the reference-generated fixture; shape contract of the default 64x64 model (L = 13, ret with 13*96 input channels)."""
+    from vp_suite_amd.models import MODEL_CLASSES
+    kw = gc.EF_TRAJGRU_TINY_KW
+    g = load_golden("ef_trajgru_tiny")
+    m = MODEL_CLASSES["trajgru"]("cuda", **kw)
+    assert list(m.state_dict().keys()) == list(json.loads(str(g["sd_shapes"])).keys())
+    fill_state_dict_(m, name_seed("ef_trajgru.tiny"))
+    m = m.cuda()
+    c, h, w = kw["img_shape"]
+    frames = seeded_rand((2, 5, c, h, w), name_seed("ef_trajgru.tiny.frames")).cuda()
+    pred, ml = m(frames[:, :3], pred_frames=2)
+    assert ml is None and _relmax(pred, g["pred"]) < RTOL
+    from vp_suite_amd.measure import PredictionLossProvider
+    _, loss = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}}).get_losses(pred, frames[:, 3:])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    for k, p in m.named_parameters():
+        if "grad." + k in g:
+            assert _relmax(p.grad, g["grad." + k]) < 2e-4, k
+        else:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+    big = MODEL_CLASSES["trajgru"]("cuda", img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0],
+                                   cell_precision="bf16x3").cuda()
+    with torch.no_grad():
+        out, _ = big(torch.rand(2, 4, 1, 64, 64, device="cuda"), pred_frames=3)
+    assert out.shape == (2, 3, 1, 64, 64) and bool(torch.isfinite(out).all())

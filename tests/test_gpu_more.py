@@ -327,8 +327,9 @@ def test_action_conditional_stlstm_cell_vs_golden(vpx, tag):
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["full", "noinput"])
 def test_trajgru_block_vs_golden(vpx, tag):
-    """TrajGRU (traj_gru.py:164-214): convolutions on the library kernel, warp + GRU gates in ATen; encoder form
-    (inputs, zero state) and forecaster form (inputs=None) against the reference fixture, incl. gradients."""
+    """TrajGRU (traj_gru.py:164-214) as one library-backed sequence op (flow convolutions, bilinear warps, 1x1 ret, GRU
+    gates: all HIP, explicit BPTT); encoder form (inputs, zero state) and forecaster form (inputs=None) against the
+    reference fixture, incl. gradients; then both operand modes against each other and the block's restrictions."""
     from vp_suite_amd.model_blocks import TrajGRU
     in_c, enc_c, H, W, L, B, T, mode = gc.TRAJGRU_CASES[tag]
     g = load_golden(f"trajgru_{tag}")
@@ -349,6 +350,15 @@ def test_trajgru_block_vs_golden(vpx, tag):
             assert _relmax(prm.grad, g["grad." + key]) < 1e-4, key
     with pytest.raises(ValueError):
         blk(None, None, 1)
+    blk.precision = "bf16x3"
+    with torch.no_grad():
+        o3, _ = blk(x.detach(), None, T) if mode == "full" else blk(None, h0.detach(), T)
+    assert _relmax(o3, g["out"]) < 5e-5
+    from vp_suite_amd.model_blocks.traj_gru import Activation
+    with pytest.raises(NotImplementedError):
+        TrajGRU("cuda", in_c, enc_c, H, W, L=L, act_type=Activation("relu"))
+    with pytest.raises(NotImplementedError):
+        TrajGRU("cuda", in_c, enc_c, H, W, L=L, zoneout=0.1)
 
 
 @pytest.mark.gpu

@@ -223,3 +223,19 @@ def test_bench_spawns_ranks_before_touching_the_gpu(vpx, monkeypatch):
     names = [s.name for s in bench.extras_for(1)]
     assert {"infer_b4", "infer_b32", "train_b32", "train_b128", "infer_b128_f32", "predrnn_infer_b128"} <= set(names)
     assert any(s.mode == "train" for s in bench.extras_for(8))
+
+
+def test_ef_trajgru_registry_and_state_dict_contract(vpx):
+    """"trajgru" is registered under the reference's key; parameter names / shapes / order equal the reference's."""
+    from vp_suite_amd.models import MODEL_CLASSES
+    from vp_suite_amd.model_blocks.traj_gru import Activation
+    g = load_golden("ef_trajgru_tiny")
+    shapes = json.loads(str(g["sd_shapes"]))
+    m = MODEL_CLASSES["trajgru"]("cpu", **gc.EF_TRAJGRU_TINY_KW)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys()) and all(list(sd[k].shape) == shapes[k] for k in shapes)
+    assert m.encoder.rnn1.ret.weight.shape == (3 * 8, 3 * 8, 1, 1)   # L * C inputs, 3C outputs
+    assert Activation("leaky", 0.3).negative_slope == 0.3 and float(Activation("relu")(torch.tensor(-1.0))) == 0.0
+    with pytest.raises(NotImplementedError):
+        Activation("swish")(torch.zeros(1))
+    pickle.loads(pickle.dumps(m))

@@ -256,3 +256,23 @@ def test_torch_ref_trajgru(tag):
     out, hT = trajgru_seq(x, None, T, sd, L) if mode == "full" else trajgru_seq(None, h0, T, sd, L)
     assert (out - torch.from_numpy(g["out"])).abs().max() < 2e-6
     assert (hT - torch.from_numpy(g["hT"])).abs().max() < 2e-6
+
+
+def test_torch_ref_ef_trajgru_model():
+    """oracle/torch_ref.ef_trajgru_forward (EF skeleton + trajgru_seq) pinned to the reference's EF_TrajGRU fixture: prediction,
+    loss and every parameter gradient."""
+    import golden_cases as gc
+    from oracle import torch_ref as tr
+    g = load_golden("ef_trajgru_tiny")
+    sd = {k: v.clone().requires_grad_(True) for k, v in seeded_state_dict(g, name_seed("ef_trajgru.tiny")).items()}
+    c, h, w = gc.EF_TRAJGRU_TINY_KW["img_shape"]
+    frames = seeded_rand((2, 5, c, h, w), name_seed("ef_trajgru.tiny.frames"))
+    pred = tr.ef_trajgru_forward(sd, frames[:, :3], 2, L=3)
+    assert np.abs(pred.detach().numpy() - g["pred"]).max() < 2e-6
+    loss = tr.mse_measure(pred, frames[:, 3:])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    for k, v in sd.items():
+        if "grad." + k in g:
+            ref = g["grad." + k]
+            assert np.abs(v.grad.numpy() - ref).max() < 1e-5 * (np.abs(ref).max() + 1e-30) + 1e-9, k

@@ -227,6 +227,26 @@ def gen_trajgru():
         _save(f"trajgru_{tag}", **arrays)
 
 
+def gen_ef_trajgru():
+    """EF_TrajGRU tiny model (ef_traj_gru.py + ef_blocks.py): forward, loss and every parameter gradient."""
+    from vp_suite.models import MODEL_CLASSES
+    from golden_cases import EF_TRAJGRU_TINY_KW as kw
+    B, T, P = 2, 3, 2
+    m = MODEL_CLASSES["trajgru"]("cpu", **kw)
+    fill_state_dict_(m, name_seed("ef_trajgru.tiny"))
+    c, h, w = kw["img_shape"]
+    frames = seeded_rand((B, T + P, c, h, w), name_seed("ef_trajgru.tiny.frames"))
+    pred, _ = m(frames[:, :T], pred_frames=P)
+    loss = ((pred - frames[:, T:]) ** 2).sum(dim=(4, 3, 2)).mean(dim=1).mean(dim=0)
+    loss.backward()
+    arrays = dict(pred=_np(pred), loss=_np(loss))
+    for key, prm in m.named_parameters():
+        if prm.grad is not None:   # the top forecaster block gets no input: its i2h / i2f_conv1 parameters are unused
+            arrays["grad." + key] = _np(prm.grad)
+    arrays.update(_sd_meta(m))
+    _save("ef_trajgru_tiny", **arrays)
+
+
 def gen_decouple():
     import torch.nn.functional as F
     B, Ch, H, W = 2, 8, 6, 5
@@ -387,7 +407,7 @@ def gen_predrnn():
 
 
 GENERATORS = {"hzzone": gen_hzzone, "ndrplz": gen_ndrplz, "stlstm": gen_stlstm, "decouple": gen_decouple,
-              "ef": gen_ef, "predrnn": gen_predrnn, "phy_ssc": gen_phydnet_ssc, "acstlstm": gen_acstlstm, "trajgru": gen_trajgru}
+              "ef": gen_ef, "predrnn": gen_predrnn, "phy_ssc": gen_phydnet_ssc, "acstlstm": gen_acstlstm, "trajgru": gen_trajgru, "ef_trajgru": gen_ef_trajgru}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

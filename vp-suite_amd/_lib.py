@@ -27,6 +27,8 @@ EXPORTED_SYMBOLS = [
     "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_conv2d_bwd_workspace_bytes", "vpx_conv2d_nhwc_bwd",
     "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd",
     "vpx_conv2d_ex_bwd_workspace_bytes", "vpx_conv2d_ex_bwd",
+    "vpx_conv2d_nhwc_fwd_ex", "vpx_leaky_bwd_workspace_bytes", "vpx_leaky_bwd", "vpx_axpy",
+    "vpx_trajgru_warp_fwd", "vpx_trajgru_warp_bwd", "vpx_trajgru_gates_fwd", "vpx_trajgru_gates_bwd",
     "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
     "vpx_mse_loss_workspace_bytes", "vpx_mse_loss", "vpx_adam_step",
 ]
@@ -119,6 +121,23 @@ def lib():
         L.vpx_conv2d_ex_bwd_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
         L.vpx_conv2d_ex_bwd.restype = ctypes.c_int
         L.vpx_conv2d_ex_bwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7 + [vp, sz, vp]
+        ll, fl, ci = ctypes.c_longlong, ctypes.c_float, ctypes.c_int
+        L.vpx_conv2d_nhwc_fwd_ex.restype = ci
+        L.vpx_conv2d_nhwc_fwd_ex.argtypes = [vp] * 4 + [ci] * 9 + [fl, vp, sz, vp]
+        L.vpx_leaky_bwd_workspace_bytes.restype = sz
+        L.vpx_leaky_bwd_workspace_bytes.argtypes = [ci]
+        L.vpx_leaky_bwd.restype = ci
+        L.vpx_leaky_bwd.argtypes = [vp, vp, fl, vp, vp, ll, ci, vp, sz, vp]
+        L.vpx_axpy.restype = ci
+        L.vpx_axpy.argtypes = [vp, vp, ll, vp]
+        L.vpx_trajgru_warp_fwd.restype = ci
+        L.vpx_trajgru_warp_fwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
+        L.vpx_trajgru_warp_bwd.restype = ci
+        L.vpx_trajgru_warp_bwd.argtypes = [vp] * 5 + [ci] * 5 + [vp]
+        L.vpx_trajgru_gates_fwd.restype = ci
+        L.vpx_trajgru_gates_fwd.argtypes = [vp, ll, vp, vp, vp, vp, ci, ci, ci, ci, fl, vp]
+        L.vpx_trajgru_gates_bwd.restype = ci
+        L.vpx_trajgru_gates_bwd.argtypes = [vp, vp, vp, vp, vp, ll, vp, vp, ci, ci, ci, ci, fl, vp]
         L.vpx_mse_loss_workspace_bytes.restype = sz
         L.vpx_mse_loss_workspace_bytes.argtypes = []
         L.vpx_mse_loss.restype = ctypes.c_int

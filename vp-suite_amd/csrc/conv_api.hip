@@ -39,6 +39,23 @@ int vpx_conv2d_nhwc_bwd(const float* x, const float* w, const float* dy, float* 
     return VPX_OK;
 }
 
+/* y = act(conv(x, w) + bias [+ y]): stride-1 "same" convolution with an optional accumulate into the destination (a second
+ * convolution summed into the same output, e.g. TrajGRU's i2f + h2f, traj_gru.py:134-142) and LeakyReLU on the sum. */
+int vpx_conv2d_nhwc_fwd_ex(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Ci, int Co,
+                           int kh, int kw, int precision, int accumulate, float leaky_slope, void* workspace,
+                           size_t workspace_bytes, void* stream_) {
+    if (!x || !w || !y || N < 1 || H < 1 || W < 1 || Ci < 1 || Co < 1 || !(kh & 1) || !(kw & 1) || kh > 7 || kw > 7 || leaky_slope < 0.0f) {
+        set_error("vpx_conv2d_nhwc_fwd_ex: bad argument");
+        return VPX_ERR_ARG;
+    }
+    if ((precision < VPX_PREC_F32 || precision > VPX_PREC_BF16)) { set_error("vpx_conv2d_nhwc_fwd_ex: precision %d not implemented", precision); return VPX_ERR_UNSUPPORTED; }
+    if (!workspace || workspace_bytes < vpx_conv2d_workspace_bytes(Ci, Co, kh, kw)) { set_error("vpx_conv2d_nhwc_fwd_ex: workspace too small"); return VPX_ERR_WORKSPACE; }
+    float* wpk = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const ConvGeo g{N, H, W};
+    return plain_conv((hipStream_t)stream_, precision, g, x, Ci, Ci, w, (long long)Ci * kh * kw, kh * kw, kh, kw, Co, false, bias, y, Co,
+                      accumulate != 0, wpk, leaky_slope);
+}
+
 /* ---- decoupling-loss tail ---------------------------------------------------------------------------------- */
 }  // extern "C"
 // The adapter (1x1, Ch -> Ch; transposed = its adjoint) applied to the c and the m operand. When both the sources and the
@@ -314,7 +331,7 @@ int strided_wgrad(hipStream_t stream, int prec, int N, int Hg, int Wg, const flo
             wa.a_sub = 1; wa.a_sy = s; wa.a_sx = s; wa.a_oy = ry; wa.a_ox = rx;
             wa.a_Hs = (Ha - ry + s - 1) / s; wa.a_Ws = (Wa - rx + s - 1) / s; wa.a_Wfull = Wa;
             wa.use_org = 1; wa.org_y = fdiv(ky0 - p - ry, s); wa.org_x = fdiv(kx0 - p - rx, s);
-            wa.n_ctiles = wgrad_make_ctiles(wa.ct, 16, Ca, 0, 0);
+            wa.n_ctiles = wgrad_make_ctiles(wa.ct, WG_MAX_CTILES, Ca, 0, 0);
             if (wa.n_ctiles < 0) { set_error("conv wgrad: too many channels (%d)", Ca); return VPX_ERR_UNSUPPORTED; }
             wa.slabs = slabs;
             const int taps = nty * ntx;

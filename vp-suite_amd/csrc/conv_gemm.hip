@@ -265,8 +265,9 @@ struct EpiPlain {
                     unsafeAtomicAdd(p, v);
                     continue;
                 }
+                if (a.accumulate) v += *p;   // the activation applies to the completed sum (two convolutions into one output)
                 if (a.leaky != 0.0f) v = v > 0.0f ? v : v * a.leaky;
-                *p = a.accumulate ? (*p + v) : v;
+                *p = v;
             }
         }
     }
@@ -432,7 +433,7 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
                     const bool c_ok = c < sg.C && !DBGBIT(2);
                     const float* srcc = src + c;
                     char* dstc = A_lds + (MODE == 0 ? c4 * 16 : c4 * 8);
-                    if (P.dbg & 16) {
+                    if (DBGBIT(16)) {
                     for (; pos < npos; pos += dpos) {
                         const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
                         f32x4 val = {0.f, 0.f, 0.f, 0.f};

@@ -152,7 +152,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         wa.x = xn; wa.x_bstride = (long long)((size_t)T * HW * Cin); wa.x_tstride = (long long)(HW * Cin);
         wa.hseq = outn; wa.h_bstride = (long long)((size_t)T * HW * Ch); wa.h_tstride = (long long)(HW * Ch);
         wa.h0 = h0n;
-        wa.n_ctiles = wgrad_make_ctiles(wa.ct, 16, xn ? Cin : 0, Ch, Cin);  // no input tensor: its columns stay zero
+        wa.n_ctiles = wgrad_make_ctiles(wa.ct, WG_MAX_CTILES, xn ? Cin : 0, Ch, Cin);  // no input tensor: its columns stay zero
         wa.slabs = slabs;
         // every launched tile stores all of its slab elements; only the skipped x columns need a clear
         if (!xn) VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, L.slab_floats * sizeof(float), stream));

@@ -88,7 +88,7 @@ int run_wgrad(const vpx_stlstm_desc* d, const STBwdLayout& L, const float* dG, i
     wa.dG = dG;
     wa.x = src0; wa.x_bstride = (long long)wa.HW * C0; wa.x_tstride = 0;
     wa.hseq = nullptr; wa.h0 = src1;
-    wa.n_ctiles = wgrad_make_ctiles(wa.ct, 16, C0, C1, C0);
+    wa.n_ctiles = wgrad_make_ctiles(wa.ct, WG_MAX_CTILES, C0, C1, C0);
     if (wa.n_ctiles < 0) { set_error("stlstm bwd: too many channels for the weight-gradient kernel"); return VPX_ERR_UNSUPPORTED; }
     wa.slabs = slabs;
     const int taps = k * k;

@@ -120,7 +120,7 @@ struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     ConvStage d_stage[MAX_STAGE];
     int d_tiles_full, d_tiles_h;   // N tiles when producing [dx | dh] resp. only dh
     int n_ctiles;                  // weight-gradient: 64-channel slices of [x | h]
-    WgradCTile ct[16];
+    WgradCTile ct[WG_MAX_CTILES];
     int n_slices;                  // weight-gradient K slices
     size_t slab_floats;
 };
@@ -166,7 +166,7 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     if (L.d_nstage < 0) { set_error("convlstm: too many channel stages in the data-gradient conv (Ch=%d)", d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.d_tiles_full = plain_tiles(Ct);
     L.d_tiles_h = plain_tiles(d->Ch);
-    L.n_ctiles = wgrad_make_ctiles(L.ct, 16, d->Cin, d->Ch, d->Cin);
+    L.n_ctiles = wgrad_make_ctiles(L.ct, WG_MAX_CTILES, d->Cin, d->Ch, d->Cin);
     if (L.n_ctiles < 0) { set_error("convlstm: too many channels for the weight-gradient kernel"); return VPX_ERR_UNSUPPORTED; }
     {
         const int tiles = ((d->W + TILE_W - 1) / TILE_W) * ((d->H + TILE_H - 1) / TILE_H);
@@ -203,7 +203,7 @@ struct ConvGeo { int N, H, W; };
 // y (+)= conv(src; w) with Co outputs; `transposed`: contraction over w's O axis (data gradient). Returns packed floats used.
 static inline int plain_conv(hipStream_t stream, int prec, ConvGeo g, const float* src, int C, int ld, const float* w, long long ld_o,
                int ld_i, int kh, int kw, int Co, bool transposed, const float* bias, float* out, int out_ld,
-               bool accumulate, float* wpk) {
+               bool accumulate, float* wpk, float leaky = 0.0f) {
     ConvPlan P{};
     int chunks = 0;
     const int segC[1] = {C};
@@ -230,8 +230,9 @@ static inline int plain_conv(hipStream_t stream, int prec, ConvGeo g, const floa
     ea.bias = bias; ea.Co = Co; ea.split = Co; ea.ng = ng;
     ea.out0 = out; ea.bstride0 = (long long)g.H * g.W * out_ld; ea.ld0 = out_ld;
     ea.accumulate = accumulate ? 1 : 0;
+    ea.leaky = leaky;
     // small maps: split K over workgroups (atomic partial sums) — needs a dense or already-initialised destination
-    P.ksplit = pick_ksplit(m_tiles * pd.n_tiles, P.nstage);
+    P.ksplit = leaky != 0.0f ? 1 : pick_ksplit(m_tiles * pd.n_tiles, P.nstage);   // partial sums cannot be activated
     if (P.ksplit > 1 && !accumulate) {
         if (out_ld == Co) VPX_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)g.N * g.H * g.W * Co * sizeof(float), stream));
         else P.ksplit = 1;
@@ -279,7 +280,7 @@ static inline int plain_wgrad(hipStream_t stream, int prec, ConvGeo g, const flo
     wa.tiles_x = (g.W + TILE_W - 1) / TILE_W; wa.tiles_y = (g.H + TILE_H - 1) / TILE_H;
     wa.N4 = Co; wa.Cin = C; wa.Ch = 1; wa.Ct = C; wa.ldG = Co; wa.n_out = Co; wa.prec = prec;
     wa.dG = dy; wa.x = x; wa.x_bstride = (long long)wa.HW * C;
-    wa.n_ctiles = wgrad_make_ctiles(wa.ct, 16, C, 0, 0);
+    wa.n_ctiles = wgrad_make_ctiles(wa.ct, WG_MAX_CTILES, C, 0, 0);
     if (wa.n_ctiles < 0) { set_error("conv wgrad: too many input channels (%d)", C); return VPX_ERR_UNSUPPORTED; }
     wa.slabs = slabs;
     const int ns = wgrad_pick_slices(wgrad_slices(g.N, g.H, g.W), Co, wa.n_ctiles, kh * kw);

@@ -220,6 +220,7 @@ hipError_t launch_colsum(const float* m, const float* y, float slope, float* sca
 // A workgroup's 64 activation columns are two 32-channel halves (one per wave column), each its own slice
 // [c0, c0+cn) of segment seg (0 = x, 1 = h); cglobal = column in [x|h]. Halves are paired in order ACROSS the
 // segments, so 96 + 96 channels make three full tiles instead of four with two half-empty ones. cn = 0: unused half.
+constexpr int WG_MAX_CTILES = 24;   // 64-channel column tiles of a weight gradient: up to 1536 activation channels (TrajGRU's ret: L*C = 1248)
 struct WgradCHalf { int seg, c0, cn, cglobal; };
 struct WgradCTile { WgradCHalf h[2]; };
 // tiles for C0 channels of segment 0 (0 = no such operand) and C1 of segment 1 whose first column is cg1; -1: > cap tiles
@@ -248,7 +249,7 @@ struct WgradArgs {
     const float* hseq; long long h_bstride, h_tstride;     // forward outputs: h_{t-1} = hseq[b, t-1]
     const float* h0;          // [B,HW,Ch] or null
     int n_ctiles;
-    WgradCTile ct[16];
+    WgradCTile ct[WG_MAX_CTILES];
     float* slabs;             // [n_slices][taps][N4][Ct]
     // generalisation for strided / transposed convolutions (conv_api.hip); all 0 = the stride-1 "same" case above
     int a_sub;                // 1: the activation operand is the sub-image (gy*a_sy + a_oy, gx*a_sx + a_ox) of a larger image

@@ -1,33 +1,41 @@
-"""TrajGRU (Shi et al. 2017) — drop-in for vp_suite/model_blocks/traj_gru.py:74-214 on the same Encoder-Forecaster
-skeleton as the ConvLSTM block.
+"""TrajGRU (Shi et al. 2017) — drop-in for vp_suite/model_blocks/traj_gru.py:74-214 on the Encoder-Forecaster skeleton
+(SURVEY.md §8f rank 4).
 
-Composite: the five convolutions (i2h 3x3 over all frames at once, i2f / h2f / flows 5x5, ret 1x1) run on the library's
-implicit-GEMM kernel (`ops.conv2d_same`, forward and backward); the bilinear warp (`F.grid_sample`, :148-162) and the GRU
-gate arithmetic (:190-203) are ATen ops. Same constructor signature, parameter names / shapes and return convention
-`(stack(h_t) [B,T,C,H,W], h_T)`. Restrictions (raise NotImplementedError): i2h stride 1 with "same" padding and no
-dilation — what the reference's own encoder/forecaster configuration uses."""
-import torch
-import torch.nn.functional as F
+The block owns the reference's five convolutions under the reference's names (`i2h`, `i2f_conv1`, `h2f_conv1`, `flows_conv`,
+`ret`: same shapes, same default init, same state_dict) and hands the whole sequence to ONE library-backed autograd
+Function (`traj_ops.trajgru_seq`): flow generation, the L bilinear warps, the 1x1 `ret` convolution and the GRU gates run
+as HIP launches forward and backward (csrc/trajgru.hip + the implicit-GEMM convolution kernel); there is no per-step
+Python autograd graph and no ATen compute op. Return convention `(h_1..h_T as [B,T,C,H,W], h_T)` as in the reference.
+
+Restrictions (NotImplementedError): i2h must be a stride-1 "same" convolution without dilation and the activation a
+LeakyReLU with positive slope — what the reference's own encoder / forecaster configuration (ef_traj_gru.py) uses;
+zoneout > 0 (the reference's expression `torch.where(dropout2d(zeros), ...)` raises on a current torch: float mask)."""
 from torch import nn
 
-from .. import ops
+from .. import traj_ops
 from ..base import VPModelBlock
 
 
 class Activation:
+    """Activation selector with the reference's constructor contract `(act_type, negative_slope=0.2, inplace=True)`
+    (traj_gru.py:8-28). The block reads `kind` / `negative_slope` and runs the activation inside its kernels; calling the
+    object applies it to a tensor (API compatibility for user code)."""
+    KINDS = ("leaky", "relu", "sigmoid")
+
     def __init__(self, act_type, negative_slope=0.2, inplace=True):
-        self._act_type = act_type
-        self.negative_slope = negative_slope
-        self.inplace = inplace
+        self._act_type, self.negative_slope, self.inplace = act_type, negative_slope, inplace
+
+    @property
+    def kind(self):
+        if self._act_type not in self.KINDS:
+            raise NotImplementedError
+        return self._act_type
 
     def __call__(self, input):
-        if self._act_type == 'leaky':
-            return F.leaky_relu(input, negative_slope=self.negative_slope, inplace=self.inplace)
-        elif self._act_type == 'relu':
-            return F.relu(input, inplace=self.inplace)
-        elif self._act_type == 'sigmoid':
-            return torch.sigmoid(input)
-        raise NotImplementedError
+        import torch.nn.functional as F
+        fn = {"leaky": lambda t: F.leaky_relu(t, self.negative_slope, self.inplace), "relu": lambda t: F.relu(t, self.inplace),
+              "sigmoid": lambda t: t.sigmoid()}
+        return fn[self.kind](input)
 
 
 class TrajGRU(VPModelBlock):
@@ -36,83 +44,39 @@ class TrajGRU(VPModelBlock):
     CODE_REFERENCE = "https://github.com/Hzzone/Precipitation-Nowcasting"
     MATCHES_REFERENCE = "Yes"
 
-    precision = "f32"
+    precision = "f32"  #: arithmetic of the convolution kernels: "f32" (exact), "bf16x3", "bf16"
 
     def __init__(self, device, in_c, enc_c, state_h, state_w, zoneout=0.0, L=5, i2h_kernel=(3, 3), i2h_stride=(1, 1),
                  i2h_pad=(1, 1), h2h_kernel=(5, 5), h2h_dilate=(1, 1),
                  act_type=Activation('leaky', negative_slope=0.2, inplace=True)):
         super().__init__()
-        if tuple(i2h_stride) != (1, 1) or tuple(2 * p for p in i2h_pad) != tuple(k - 1 for k in i2h_kernel):
-            raise NotImplementedError("TrajGRU block: i2h must be a stride-1 'same' convolution")
+        same = tuple(i2h_stride) == (1, 1) and all(2 * p == k - 1 for p, k in zip(i2h_pad, i2h_kernel)) and i2h_kernel[0] == i2h_kernel[1]
+        if not same:
+            raise NotImplementedError("TrajGRU block: i2h must be a square stride-1 'same' convolution")
+        if h2h_kernel[0] % 2 != 1 or h2h_kernel[1] % 2 != 1:
+            raise AssertionError("Only support odd number, get h2h_kernel= %s" % str(h2h_kernel))
+        if getattr(act_type, "_act_type", None) != "leaky" or not act_type.negative_slope > 0:
+            raise NotImplementedError("TrajGRU block: the activation must be LeakyReLU with a positive slope")
+        if zoneout > 0.0:
+            raise NotImplementedError("TrajGRU block: zoneout > 0 is not implemented (the reference's zoneout expression "
+                                      "fails on current torch: torch.where needs a boolean mask)")
         self.device = device
         self._num_filter = enc_c
         self._state_height, self._state_width = state_h, state_w
+        self._h2h_kernel, self._h2h_dilate = h2h_kernel, h2h_dilate   # kept like the reference keeps them: unused by TrajGRU
         self._act_type = act_type
         self._L = L
         self._zoneout = zoneout
+        # reset / update / candidate projections of the input; flow generator (input and hidden branch, 32 features);
+        # 2L flow channels; 1x1 mixing of the L warped states (traj_gru.py:99-132)
         self.i2h = nn.Conv2d(in_c, enc_c * 3, i2h_kernel, i2h_stride, i2h_pad)
-        self.i2f_conv1 = nn.Conv2d(in_c, 32, (5, 5), 1, (2, 2))
-        self.h2f_conv1 = nn.Conv2d(enc_c, 32, (5, 5), 1, (2, 2))
-        self.flows_conv = nn.Conv2d(32, L * 2, (5, 5), 1, (2, 2))
+        self.i2f_conv1 = nn.Conv2d(in_c, traj_ops.FLOW_FEATURES, (5, 5), 1, (2, 2))
+        self.h2f_conv1 = nn.Conv2d(enc_c, traj_ops.FLOW_FEATURES, (5, 5), 1, (2, 2))
+        self.flows_conv = nn.Conv2d(traj_ops.FLOW_FEATURES, L * 2, (5, 5), 1, (2, 2))
         self.ret = nn.Conv2d(enc_c * L, enc_c * 3, (1, 1), 1)
 
-    def _conv(self, mod, t):
-        return ops.conv2d_same(t, mod.weight, mod.bias, precision=self.precision)
-
-    def _flow_generator(self, inputs, states):
-        f_conv1 = self._conv(self.h2f_conv1, states)
-        if inputs is not None:
-            f_conv1 = self._act_type(self._conv(self.i2f_conv1, inputs) + f_conv1)
-        else:  # a library op's output must not be modified in place (autograd would bypass its backward): out of place
-            act = self._act_type
-            f_conv1 = Activation(act._act_type, act.negative_slope, False)(f_conv1) if isinstance(act, Activation) else act(f_conv1.clone())
-        return torch.split(self._conv(self.flows_conv, f_conv1), 2, dim=1)
-
-    def _warp(self, input, flow, grid):
-        # traj_gru.py:148-162: pixel grid + flow, normalised to [-1, 1], bilinear grid_sample (default alignment)
-        B, C, H, W = input.shape
-        vgrid = grid + flow
-        vx = 2.0 * vgrid[:, 0] / max(W - 1, 1) - 1.0
-        vy = 2.0 * vgrid[:, 1] / max(H - 1, 1) - 1.0
-        return F.grid_sample(input, torch.stack((vx, vy), dim=-1), align_corners=False)
-
     def forward(self, inputs, states, seq_len):
-        if inputs is None and states is None:
-            raise ValueError("TrajGRU received 'None' both in input and state")
-        ref = inputs if inputs is not None else states
-        dev = ref.device
-        if states is None:
-            states = torch.zeros((inputs.shape[0], self._num_filter, self._state_height, self._state_width),
-                                 dtype=torch.float, device=dev)
-        nf = self._num_filter
-        if inputs is not None:
-            b, _, c, h, w = inputs.shape
-            i2h = self._conv(self.i2h, inputs[:, :seq_len].reshape(-1, c, h, w))   # all frames in one launch (:171-173)
-            i2h = i2h.reshape(b, seq_len, *i2h.shape[1:])
-            i2h_slice = torch.split(i2h, nf, dim=2)
-        else:
-            i2h_slice = None
-        H, W = states.shape[-2:]
-        xx = torch.arange(0, W, device=dev).view(1, 1, 1, W).expand(1, 1, H, W)
-        yy = torch.arange(0, H, device=dev).view(1, 1, H, 1).expand(1, 1, H, W)
-        grid = torch.cat((xx, yy), 1).float()
-        prev_h, outputs, next_h = states, [], None
-        for t in range(seq_len):
-            flows = self._flow_generator(inputs[:, t] if inputs is not None else None, prev_h)
-            warped = torch.cat([self._warp(prev_h, -flow, grid) for flow in flows], dim=1)
-            h2h_slice = torch.split(self._conv(self.ret, warped), nf, dim=1)
-            if i2h_slice is not None:
-                reset_gate = torch.sigmoid(i2h_slice[0][:, t] + h2h_slice[0])
-                update_gate = torch.sigmoid(i2h_slice[1][:, t] + h2h_slice[1])
-                new_mem = self._act_type(i2h_slice[2][:, t] + reset_gate * h2h_slice[2])
-            else:
-                reset_gate = torch.sigmoid(h2h_slice[0])
-                update_gate = torch.sigmoid(h2h_slice[1])
-                new_mem = self._act_type(reset_gate * h2h_slice[2])
-            next_h = update_gate * prev_h + (1 - update_gate) * new_mem
-            if self._zoneout > 0.0:
-                mask = F.dropout2d(torch.zeros_like(prev_h), p=self._zoneout)
-                next_h = torch.where(mask.bool(), next_h, prev_h)
-            outputs.append(next_h)
-            prev_h = next_h
-        return torch.stack(outputs, dim=1), next_h
+        """inputs [B,T,Cin,H,W] or None; states h_0 [B,C,H,W] or None (zeros)."""
+        params = [t for m in (self.i2h, self.i2f_conv1, self.h2f_conv1, self.flows_conv, self.ret) for t in (m.weight, m.bias)]
+        return traj_ops.trajgru_seq(inputs, states, params, seq_len=seq_len, L=self._L, slope=float(self._act_type.negative_slope),
+                                    state_hw=(self._state_height, self._state_width), precision=self.precision)
