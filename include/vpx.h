@@ -213,6 +213,22 @@ int vpx_trajgru_gates_fwd(const float* i2h, long long i2h_bstride, const float* 
 int vpx_trajgru_gates_bwd(const float* dnext, const float* h2h, const float* prev, const float* save, float* di2h,
                           long long di2h_bstride, float* dh2h, float* dprev, int B, int HW, int C, int act, float slope, void* stream);
 
+/* ---- action-conditional ST-LSTM cell, pointwise half (vp_suite/model_blocks/predrnn.py:139-169), NHWC ---------------- *
+ * gates: from the conv outputs xc [npix,7Ch] (i,f,g,i',f',g',o), hc [npix,4Ch], ac [npix,4Ch] (multiplies hc; NULL = plain
+ *        ST-LSTM arithmetic), mc [npix,3Ch] and the states c, m: c_new, m_new, delta_c, delta_m, o_pre = o_x + o_h*o_a,
+ *        mem = (c_new | m_new) [npix,2Ch]; save [npix,6Ch] (post-activation gates) feeds the backward, which takes the
+ *        gradients of c_new / m_new / delta_c / delta_m / o_pre / mem (each may be NULL = zero).
+ * out:   h_new = sigmoid(o_pre + oc) * tanh(lc); backward: d_o (gradient of the sigmoid argument) and d_lc. */
+int vpx_acst_gates_fwd(const float* xc, const float* hc, const float* ac, const float* mc, const float* c, const float* m,
+                       float* c_new, float* m_new, float* delta_c, float* delta_m, float* o_pre, float* mem, float* save,
+                       long long npix, int Ch, float forget_bias, void* stream);
+int vpx_acst_gates_bwd(const float* hc, const float* ac, const float* c, const float* m, const float* save, const float* d_cn,
+                       const float* d_mn, const float* d_dc, const float* d_dm, const float* d_opre, const float* d_mem, float* dxc,
+                       float* dhc, float* dac, float* dmc, float* dc, float* dm, long long npix, int Ch, void* stream);
+int vpx_st_out_fwd(const float* o_pre, const float* oc, const float* lc, float* h_new, float* o_save, float* tl_save, long long n,
+                   void* stream);
+int vpx_st_out_bwd(const float* dh, const float* o, const float* tl, float* d_o, float* d_lc, long long n, void* stream);
+
 /* ---- layout adaptors: src [N,C,H,W] <-> dst [N,H,W,C] -------------------------------------------------------- */
 int vpx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, void* stream);
 int vpx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, void* stream);

@@ -285,6 +285,52 @@ def acstlstm_cell(x, h, c, m, a, p, layer_norm=False, forget_bias=1.0):
     return h_new, c_new, m_new, delta_c, delta_m
 
 
+def predrnn_v2_action_forward(sd, frames, actions, pred_frames, *, patch_size, num_layers, layer_norm=False, residual=True,
+                              decoupling_loss_scale=100.0):
+    """Action-conditional PredRNN-V2 forward in eval mode (vp_suite/models/predrnn_v2.py:131-230 with action_conditional =
+    conv_actions_on_input = reverse_scheduled_sampling = True, as the model forces them, :64-67): stride-2 5x5 convolutions
+    of frame and action map (:178-188), action-conditional cells (:190-201), stride-2 transposed convolutions with
+    `output_size` (:212-218), reverse-scheduled-sampling test mask (:300-309: ground truth for the context, own output after)."""
+    import torch
+    import torch.nn.functional as F
+    B, Ttot = frames.shape[:2]
+    ctx = Ttot - pred_frames
+    xp = reshape_patch(frames, patch_size)
+    ph, pw = xp.shape[-2:]
+    ap = actions[..., None, None].expand(-1, -1, -1, ph, pw)
+    k = sd["conv_input1.weight"].shape[-1]
+    nh = [sd[f"cell_list.{i}.conv_h.0.weight"].shape[1] for i in range(num_layers)]
+    rh, rw = ph // 4, pw // 4
+    h_t = [torch.zeros(B, nh[i], rh, rw) for i in range(num_layers)]
+    c_t = [torch.zeros(B, nh[i], rh, rw) for i in range(num_layers)]
+    memory = torch.zeros(B, nh[0], rh, rw)
+    x_gen, outs, dec = None, [], []
+
+    def deconv(t, name, size):
+        w = sd[name + ".weight"]
+        base = [(t.shape[-2 + d] - 1) * 2 - 2 * (k // 2) + k for d in (0, 1)]
+        return F.conv_transpose2d(t, w, stride=2, padding=k // 2, output_padding=(size[0] - base[0], size[1] - base[1]))
+    for t in range(Ttot - 1):
+        net = xp[:, t] if (t < 1 or t - 1 < ctx - 1) else x_gen   # mask = 1 for the first ctx-1 blended steps, 0 after
+        s1 = net.shape[-2:]
+        net = in1 = F.conv2d(net, sd["conv_input1.weight"], stride=2, padding=k // 2)
+        s2 = net.shape[-2:]
+        net = in2 = F.conv2d(net, sd["conv_input2.weight"], stride=2, padding=k // 2)
+        act = F.conv2d(F.conv2d(ap[:, t], sd["action_conv_input1.weight"], stride=2, padding=k // 2),
+                       sd["action_conv_input2.weight"], stride=2, padding=k // 2)
+        for i in range(num_layers):
+            inp = net if i == 0 else h_t[i - 1]
+            p = {kk[len(f"cell_list.{i}."):]: v for kk, v in sd.items() if kk.startswith(f"cell_list.{i}.")}
+            h_t[i], c_t[i], memory, dc, dm = acstlstm_cell(inp, h_t[i], c_t[i], memory, act, p, layer_norm)
+            dec.append(decouple_term(dc, dm, sd["adapter.weight"]))
+        top = h_t[num_layers - 1]
+        x_gen = deconv(top + in2 if residual else top, "deconv_output1", s2)
+        x_gen = deconv(x_gen + in1 if residual else x_gen, "deconv_output2", s1)
+        outs.append(x_gen)
+    pred = reshape_patch_back(torch.stack(outs[-pred_frames:], dim=1), patch_size)
+    return pred, decoupling_loss_scale * torch.mean(torch.stack(dec, dim=0))
+
+
 def trajgru_seq(inputs, states, seq_len, p, L, slope=0.2):
     """Functional restatement of TrajGRU.forward (vp_suite/model_blocks/traj_gru.py:164-214; zoneout 0): i2h over all
     frames, per step flow generation (:134-146), L bilinear warps of h (:148-162, default grid_sample alignment), 1x1 ret

@@ -88,6 +88,12 @@ PRED_TINY_LN_KW = dict(img_shape=(2, 16, 24), action_size=0, tensor_value_range=
                        num_layers=3, num_hidden=[8, 8, 8], filter_size=3, layer_norm=True)
 
 
+# action-conditional PredRNN-V2 (predrnn_v2.py:62-121, 178-221): tag -> extra kwargs on top of PRED_ACTION_KW
+PRED_ACTION_KW = dict(img_shape=(1, 32, 32), action_size=3, tensor_value_range=[0.0, 1.0], patch_size=2, num_layers=2,
+                      num_hidden=[8, 8], filter_size=5, action_conditional=True)
+PRED_ACTION_CASES = {"residual": dict(residual_on_action_conv=True), "plain": dict(residual_on_action_conv=False),
+                     "ln": dict(residual_on_action_conv=True, layer_norm=True)}
+
 # PhyDNet SingleStepConvLSTM (phydnet.py:117-175): tag -> (input_size, input_dim, hidden_dims, n_layers, kernel, action_conditional, action_size, B, steps)
 PHY_SSC_CASES = {
     "plain": ((12, 10), 4, [8, 6], 2, (3, 3), False, 0, 2, 3),

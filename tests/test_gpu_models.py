@@ -152,3 +152,38 @@ def test_ef_trajgru_model_vs_golden(vpx):
     with torch.no_grad():
         out, _ = big(torch.rand(2, 4, 1, 64, 64, device="cuda"), pred_frames=3)
     assert out.shape == (2, 3, 1, 64, 64) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("tag", list(gc.PRED_ACTION_CASES))
+def test_predrnn_action_conditional_vs_golden(vpx, tag):
+    """Action-conditional PredRNN-V2 (predrnn_v2.py:62-121, 143-149, 178-221): `action_conditional=True` x
+    {residual_on_action_conv, layer_norm} — prediction, decoupling loss, total loss and all gradients against the
+    reference fixtures; the reference's argument checks."""
+    from vp_suite_amd.measure import PredictionLossProvider
+    from vp_suite_amd.models import MODEL_CLASSES
+    from golden_util import seeded_randn
+    g = load_golden(f"predrnn_action_{tag}")
+    kw = dict(gc.PRED_ACTION_KW, **gc.PRED_ACTION_CASES[tag])
+    m = MODEL_CLASSES["predrnn-pp"]("cuda", **kw)
+    assert m.conv_actions_on_input and m.reverse_scheduled_sampling and not hasattr(m, "conv_last")
+    assert list(m.state_dict().keys()) == list(json.loads(str(g["sd_shapes"])).keys())
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"])
+    fill_state_dict_(m, name_seed("predrnn_action." + tag))
+    m = m.cuda().eval()
+    c, h, w = kw["img_shape"]
+    frames = seeded_rand((2, 5, c, h, w), name_seed(f"predrnn_action.{tag}.frames")).cuda()
+    actions = seeded_randn((2, 5, kw["action_size"]), name_seed(f"predrnn_action.{tag}.actions")).cuda()
+    pred, ml = m(frames, pred_frames=2, actions=actions)
+    assert _relmax(pred, g["pred"]) < RTOL
+    assert abs(float(ml["ST-LSTM decouple loss"]) - float(g["decouple"])) < 1e-4 * abs(float(g["decouple"]))
+    _, loss = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}}).get_losses(pred, frames[:, 3:])
+    loss = loss + ml["ST-LSTM decouple loss"]
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    named = dict(m.named_parameters())
+    flat = np.concatenate([named[k].grad.detach().cpu().numpy().reshape(-1) for k in sorted(named)])
+    assert _relmax(flat, g["grads_flat"]) < 2e-4
+    with pytest.raises(ValueError):
+        m(frames, pred_frames=2)                                  # actions are mandatory
+    with pytest.raises(ValueError):
+        m(frames, pred_frames=2, actions=actions[..., :2])        # wrong action size

@@ -276,3 +276,21 @@ def test_torch_ref_ef_trajgru_model():
         if "grad." + k in g:
             ref = g["grad." + k]
             assert np.abs(v.grad.numpy() - ref).max() < 1e-5 * (np.abs(ref).max() + 1e-30) + 1e-9, k
+
+
+@pytest.mark.parametrize("tag", ["residual", "plain", "ln"])
+def test_torch_ref_predrnn_action_model(tag):
+    """oracle/torch_ref.predrnn_v2_action_forward pinned to the reference's action-conditional PredRNN-V2 fixtures."""
+    import golden_cases as gc
+    from oracle import torch_ref as tr
+    g = load_golden(f"predrnn_action_{tag}")
+    kw, extra = gc.PRED_ACTION_KW, gc.PRED_ACTION_CASES[tag]
+    sd = seeded_state_dict(g, name_seed("predrnn_action." + tag))
+    c, h, w = kw["img_shape"]
+    frames = seeded_rand((2, 5, c, h, w), name_seed(f"predrnn_action.{tag}.frames"))
+    actions = seeded_randn((2, 5, kw["action_size"]), name_seed(f"predrnn_action.{tag}.actions"))
+    with torch.no_grad():
+        pred, dec = tr.predrnn_v2_action_forward(sd, frames, actions, 2, patch_size=kw["patch_size"], num_layers=kw["num_layers"],
+                                                 layer_norm=extra.get("layer_norm", False), residual=extra["residual_on_action_conv"])
+    assert np.abs(pred.numpy() - g["pred"]).max() < 5e-6
+    assert abs(float(dec) - float(g["decouple"])) < 1e-5 * abs(float(g["decouple"]))

@@ -227,6 +227,32 @@ def gen_trajgru():
         _save(f"trajgru_{tag}", **arrays)
 
 
+def gen_predrnn_action():
+    """Action-conditional PredRNN-V2 (predrnn_v2.py:62-121, 143-149, 178-221 + ActionConditionalSpatioTemporalLSTMCell):
+    eval forward (reverse scheduled sampling is forced by the model), decoupling loss, loss and all gradients."""
+    from vp_suite.models import MODEL_CLASSES
+    from golden_cases import PRED_ACTION_KW, PRED_ACTION_CASES
+    PR = MODEL_CLASSES["predrnn-pp"]
+    B, Ttot, P = 2, 5, 2
+    c, h, w = PRED_ACTION_KW["img_shape"]
+    for tag, extra in PRED_ACTION_CASES.items():
+        frames = seeded_rand((B, Ttot, c, h, w), name_seed(f"predrnn_action.{tag}.frames"))
+        actions = seeded_randn((B, Ttot, PRED_ACTION_KW["action_size"]), name_seed(f"predrnn_action.{tag}.actions"))
+        model = PR("cpu", **PRED_ACTION_KW, **extra)
+        fill_state_dict_(model, name_seed("predrnn_action." + tag))
+        model.eval()
+        pred, ml = model(frames, pred_frames=P, actions=actions)
+        _, loss = _loss_provider(c).get_losses(pred, frames[:, Ttot - P:])
+        loss = loss + ml["ST-LSTM decouple loss"]
+        model.zero_grad()
+        loss.backward()
+        _, gflat = _flat_sorted({k: p.grad for k, p in model.named_parameters()})
+        arrays = dict(pred=_np(pred), decouple=_np(ml["ST-LSTM decouple loss"]), loss=_np(loss), grads_flat=gflat,
+                      n_params=np.array(sum(p.numel() for p in model.parameters())))
+        arrays.update(_sd_meta(model))
+        _save(f"predrnn_action_{tag}", **arrays)
+
+
 def gen_ef_trajgru():
     """EF_TrajGRU tiny model (ef_traj_gru.py + ef_blocks.py): forward, loss and every parameter gradient."""
     from vp_suite.models import MODEL_CLASSES
@@ -407,7 +433,7 @@ def gen_predrnn():
 
 
 GENERATORS = {"hzzone": gen_hzzone, "ndrplz": gen_ndrplz, "stlstm": gen_stlstm, "decouple": gen_decouple,
-              "ef": gen_ef, "predrnn": gen_predrnn, "phy_ssc": gen_phydnet_ssc, "acstlstm": gen_acstlstm, "trajgru": gen_trajgru, "ef_trajgru": gen_ef_trajgru}
+              "ef": gen_ef, "predrnn": gen_predrnn, "phy_ssc": gen_phydnet_ssc, "acstlstm": gen_acstlstm, "trajgru": gen_trajgru, "ef_trajgru": gen_ef_trajgru, "predrnn_action": gen_predrnn_action}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

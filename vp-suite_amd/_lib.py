@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd",
     "vpx_conv2d_ex_bwd_workspace_bytes", "vpx_conv2d_ex_bwd",
     "vpx_conv2d_nhwc_fwd_ex", "vpx_leaky_bwd_workspace_bytes", "vpx_leaky_bwd", "vpx_axpy",
+    "vpx_acst_gates_fwd", "vpx_acst_gates_bwd", "vpx_st_out_fwd", "vpx_st_out_bwd",
     "vpx_trajgru_warp_fwd", "vpx_trajgru_warp_bwd", "vpx_trajgru_gates_fwd", "vpx_trajgru_gates_bwd",
     "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
     "vpx_mse_loss_workspace_bytes", "vpx_mse_loss", "vpx_adam_step",
@@ -130,6 +131,14 @@ def lib():
         L.vpx_leaky_bwd.argtypes = [vp, vp, fl, vp, vp, ll, ci, vp, sz, vp]
         L.vpx_axpy.restype = ci
         L.vpx_axpy.argtypes = [vp, vp, ll, vp]
+        L.vpx_acst_gates_fwd.restype = ci
+        L.vpx_acst_gates_fwd.argtypes = [vp] * 13 + [ll, ci, fl, vp]
+        L.vpx_acst_gates_bwd.restype = ci
+        L.vpx_acst_gates_bwd.argtypes = [vp] * 17 + [ll, ci, vp]
+        L.vpx_st_out_fwd.restype = ci
+        L.vpx_st_out_fwd.argtypes = [vp] * 6 + [ll, vp]
+        L.vpx_st_out_bwd.restype = ci
+        L.vpx_st_out_bwd.argtypes = [vp] * 5 + [ll, vp]
         L.vpx_trajgru_warp_fwd.restype = ci
         L.vpx_trajgru_warp_fwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
         L.vpx_trajgru_warp_bwd.restype = ci

@@ -6,10 +6,11 @@ same return tuple `(h_new, c_new, m_new, delta_c, delta_m)`. The five convolutio
 fused implicit-GEMM launches (csrc/stlstm_api.hip); with layer_norm=True the convolutions are normalised one by one
 (csrc/stlstm_ln_api.hip, csrc/layernorm.hip).
 
-`ActionConditionalSpatioTemporalLSTMCell` (:86-169) is provided as a composite: its six convolutions (with bias) run on
-the library's implicit-GEMM kernel (`ops.conv2d_same`, forward and backward), the `conv_h(h) * conv_a(a)` product, the
-optional LayerNorms and the gate arithmetic are ATen pointwise ops — the product of two contractions cannot be folded
-into one GEMM epilogue, and this variant is not on any BASELINE configuration."""
+`ActionConditionalSpatioTemporalLSTMCell` (:86-169): its six biased convolutions run on the library's implicit-GEMM kernel
+(`ops.conv2d_same`, forward and backward); the `conv_h(h) * conv_a(a)` product (:144), both gate groups, the state updates
+and the output gate are two HIP kernels with explicit backward (`ops.acst_gates`, `ops.st_out`, csrc/acst.hip) — the
+product of two contractions cannot be folded into one GEMM epilogue, so the convolutions stay separate launches. Only the
+optional LayerNorms (layer_norm=True) still go through `F.layer_norm`."""
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -99,23 +100,12 @@ class ActionConditionalSpatioTemporalLSTMCell(VPModelBlock):
         return y
 
     def forward(self, x_t, h_t, c_t, m_t, a_t):
-        nh = self.num_hidden
+        # four biased convolutions (+ LayerNorm), then ONE gate kernel: conv_h(h) * conv_a(a) (predrnn.py:144), both gate
+        # groups, c / m updates, o_pre and mem = (c_new | m_new); conv_o / conv_last on mem; one output-gate kernel
         x_concat, h_concat = self._conv(self.conv_x, x_t), self._conv(self.conv_h, h_t)
         a_concat, m_concat = self._conv(self.conv_a, a_t), self._conv(self.conv_m, m_t)
-        i_x, f_x, g_x, i_x_prime, f_x_prime, g_x_prime, o_x = torch.split(x_concat, nh, dim=1)
-        i_h, f_h, g_h, o_h = torch.split(h_concat * a_concat, nh, dim=1)   # predrnn.py:144
-        i_m, f_m, g_m = torch.split(m_concat, nh, dim=1)
-        i_t = torch.sigmoid(i_x + i_h)
-        f_t = torch.sigmoid(f_x + f_h + self._forget_bias)
-        g_t = torch.tanh(g_x + g_h)
-        delta_c = i_t * g_t
-        c_new = f_t * c_t + delta_c
-        i_t_prime = torch.sigmoid(i_x_prime + i_m)
-        f_t_prime = torch.sigmoid(f_x_prime + f_m + self._forget_bias)
-        g_t_prime = torch.tanh(g_x_prime + g_m)
-        delta_m = i_t_prime * g_t_prime
-        m_new = f_t_prime * m_t + delta_m
-        mem = torch.cat((c_new, m_new), 1)
-        o_t = torch.sigmoid(o_x + o_h + self._conv(self.conv_o, mem))
-        h_new = o_t * torch.tanh(ops.conv2d_same(mem, self.conv_last.weight, self.conv_last.bias, precision=self.precision))
+        c_new, m_new, delta_c, delta_m, o_pre, mem = ops.acst_gates(x_concat, h_concat, a_concat, m_concat, c_t, m_t,
+                                                                    self._forget_bias)
+        lc = ops.conv2d_same(mem, self.conv_last.weight, self.conv_last.bias, precision=self.precision)
+        h_new = ops.st_out(o_pre, self._conv(self.conv_o, mem), lc)
         return h_new, c_new, m_new, delta_c, delta_m

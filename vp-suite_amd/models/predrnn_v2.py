@@ -1,4 +1,4 @@
-"""PredRNN-V2 ("predrnn-pp") — drop-in for vp_suite/models/predrnn_v2.py:11-365 (non-action-conditional form).
+"""PredRNN-V2 ("predrnn-pp") — drop-in for vp_suite/models/predrnn_v2.py:11-365, incl. the action-conditional form.
 
 Hyper-parameter names/defaults, state_dict keys (`cell_list.{l}.conv_{x,h,m,o}.0.weight`,
 `cell_list.{l}.conv_last.weight`, `conv_last.weight`, `adapter.weight`), the forward contract
@@ -6,7 +6,12 @@ Hyper-parameter names/defaults, state_dict keys (`cell_list.{l}.conv_{x,h,m,o}.0
 scheduled-sampling schedules and the custom train_iter (forward + reversed forward, averaged) follow the reference.
 Every ST-LSTM cell step (4 fused launches), the decoupling-loss tail (K4) and the 1x1 frame head (K5) run in
 libvpx_hip; patchify is a pure permutation and the input blend one elementwise expression.
-The action-conditional variant is outside the hot-path scope (no action dataset in the BASELINE configs)."""
+Action-conditional form (:62-121, 143-149, 178-221): `action_conditional=True` forces `conv_actions_on_input` and
+`reverse_scheduled_sampling` like the reference; frames and the spatially broadcast actions pass two stride-2 5x5
+convolutions each (`conv_input1/2`, `action_conv_input1/2`), the ST-LSTM cells multiply conv_h(h) by conv_a(action)
+(`ActionConditionalSpatioTemporalLSTMCell`) and two stride-2 transposed convolutions (`deconv_output1/2`, optionally with
+the encoder residuals) map the top hidden state back to a patch frame — all of them on the library's convolution
+kernels (vpx_conv2d_ex_fwd/_bwd, output padding resolved from the requested size like `output_size=` does)."""
 import math
 
 import torch
@@ -15,6 +20,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..base import VPModel, _progress
+from ..model_blocks import ActionConditionalSpatioTemporalLSTMCell as ACSTCell
 from ..model_blocks import SpatioTemporalLSTMCell as STCell
 
 
@@ -23,7 +29,7 @@ class PredRNN_V2(VPModel):
     PAPER_REFERENCE = "https://arxiv.org/abs/2103.09504"
     CODE_REFERENCE = "https://github.com/thuml/predrnn-pytorch"
     MATCHES_REFERENCE: str = "Yes"
-    CAN_HANDLE_ACTIONS = False
+    CAN_HANDLE_ACTIONS = True
     NEEDS_COMPLETE_INPUT = True
 
     patch_size = 4
@@ -51,26 +57,51 @@ class PredRNN_V2(VPModel):
 
     def __init__(self, device, **model_kwargs):
         super().__init__(device, **model_kwargs)
-        if self.action_conditional:
-            raise NotImplementedError("action-conditional PredRNN-V2 is outside the scope of this build")
         self.patch_c = self.patch_size * self.patch_size * self.img_c
         self.patch_a = self.action_size
         self.patch_h = self.rnn_h = self.img_h // self.patch_size
         self.patch_w = self.rnn_w = self.img_w // self.patch_size
-        self.conv_actions_on_input = False
-        self.residual_on_action_conv = False
+        if self.action_conditional:  # the action-conditional graph only exists in this form (predrnn_v2.py:64-70)
+            self.conv_actions_on_input = True
+            self.reverse_scheduled_sampling = True
+        else:
+            self.conv_actions_on_input = False
+            self.residual_on_action_conv = False
+        nh, k = self.num_hidden, self.filter_size
+        if self.conv_actions_on_input:
+            if self.rnn_h % 4 or self.rnn_w % 4:
+                raise ValueError(f"action-conditional {self.NAME}: the patch grid {self.rnn_h}x{self.rnn_w} must be divisible by 4 "
+                                 f"(two stride-2 convolutions, predrnn_v2.py:73-75)")
+            self.rnn_h //= 4
+            self.rnn_w //= 4
+
+            def down(c_in, c_out):
+                return nn.Conv2d(c_in, c_out, k, stride=2, padding=k // 2, bias=False)
+
+            def up(c_in, c_out):
+                return nn.ConvTranspose2d(c_in, c_out, k, stride=2, padding=k // 2, bias=False)
+            self.conv_input1, self.conv_input2 = down(self.patch_c, nh[0] // 2), down(nh[0] // 2, nh[0])
+            self.action_conv_input1, self.action_conv_input2 = down(self.patch_a, nh[0] // 2), down(nh[0] // 2, nh[0])
+            top = nh[self.num_layers - 1]
+            self.deconv_output1, self.deconv_output2 = up(top, top // 2), up(top // 2, self.patch_c)
 
         cells = []
         for i in range(self.num_layers):
-            c_in = self.patch_c if i == 0 else self.num_hidden[i - 1]
-            cell = STCell(c_in, self.num_hidden[i], self.rnn_h, self.rnn_w, self.filter_size, self.stride,
-                          self.layer_norm)
+            if i > 0:
+                c_in = nh[i - 1]
+            elif self.action_conditional:
+                c_in = nh[0] if self.conv_actions_on_input else self.patch_c + self.patch_a
+            else:
+                c_in = self.patch_c
+            cell = (ACSTCell if self.action_conditional else STCell)(c_in, nh[i], self.rnn_h, self.rnn_w, k, self.stride,
+                                                                    self.layer_norm)
             cell.precision = self.cell_precision
             cells.append(cell)
         self.cell_list = nn.ModuleList(cells)
-        self.conv_last = nn.Conv2d(self.num_hidden[self.num_layers - 1], self.patch_c, kernel_size=1, stride=1,
-                                   padding=0, bias=False)
-        self.adapter = nn.Conv2d(self.num_hidden[0], self.num_hidden[0], kernel_size=1, stride=1, padding=0, bias=False)
+        if not self.conv_actions_on_input:   # (absent when the deconvolutions produce the frame, predrnn_v2.py:108-114)
+            self.conv_last = nn.Conv2d(nh[self.num_layers - 1], self.patch_c, kernel_size=1, stride=1, padding=0, bias=False)
+        adap = nh[self.num_layers - 1] if self.action_conditional else nh[0]
+        self.adapter = nn.Conv2d(adap, adap, kernel_size=1, stride=1, padding=0, bias=False)
         self.training_iteration = 1
         self.sampling_eta = 1.0
         self.NON_CONFIG_VARS.extend(["training_iteration, sampling_eta"])
@@ -90,14 +121,23 @@ class PredRNN_V2(VPModel):
         train = kwargs.get("train", False)
         dev = x.device
         x_patch = self._reshape_patch(x)
+        a_patch = None
+        if self.action_conditional:
+            actions = kwargs.get("actions", None)
+            if actions is None or actions.dim() != 3 or actions.shape[-1] != self.action_size or not bool(actions.any()):
+                raise ValueError("Given actions are None or of the wrong size!")   # predrnn_v2.py:146-147
+            a_patch = actions.to(dev)[..., None, None].expand(-1, -1, -1, self.patch_h, self.patch_w)
+        prec = self.cell_precision
+        nh, top = self.num_hidden, self.num_layers - 1
 
         def zeros(i):
-            return torch.zeros(b, self.num_hidden[i], self.rnn_h, self.rnn_w, device=dev)
+            return torch.zeros(b, nh[i], self.rnn_h, self.rnn_w, device=dev)
         h_t = [zeros(i) for i in range(self.num_layers)]
         c_t = [zeros(i) for i in range(self.num_layers)]
         memory = zeros(0)
         mask_true = self._scheduled_sampling(b, context_frames, pred_frames, train)
         first_blend = 1 if self.reverse_scheduled_sampling else context_frames
+        k = self.filter_size
         x_gen, next_frames, decouple = None, [], []
         for t in range(total_frames - 1):
             if t < first_blend:
@@ -105,11 +145,27 @@ class PredRNN_V2(VPModel):
             else:
                 mk = mask_true[:, t - first_blend]
                 net = mk * x_patch[:, t] + (1 - mk) * x_gen
+            action = a_patch[:, t] if a_patch is not None else None
+            if self.conv_actions_on_input:   # two stride-2 convolutions on the frame and on the action map (:178-188)
+                shape1 = net.shape[-2:]
+                net = in1 = ops.conv2d_ex(net, self.conv_input1.weight, None, 2, k // 2, False, 0.0, prec)
+                shape2 = net.shape[-2:]
+                net = in2 = ops.conv2d_ex(net, self.conv_input2.weight, None, 2, k // 2, False, 0.0, prec)
+                action = ops.conv2d_ex(action.contiguous(), self.action_conv_input1.weight, None, 2, k // 2, False, 0.0, prec)
+                action = ops.conv2d_ex(action, self.action_conv_input2.weight, None, 2, k // 2, False, 0.0, prec)
             for i in range(self.num_layers):
                 inp = net if i == 0 else h_t[i - 1]
-                h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory)
+                if self.action_conditional:
+                    h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory, action)
+                else:
+                    h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory)
                 decouple.append(self._decouple_term(d_c, d_m))
-            x_gen = ops.conv2d_same(h_t[self.num_layers - 1], self.conv_last.weight, None, self.cell_precision)
+            if self.conv_actions_on_input:   # two stride-2 transposed convolutions back to the patch grid (:212-218)
+                res2, res1 = (in2, in1) if self.residual_on_action_conv else (0, 0)
+                x_gen = ops.conv_transpose2d_to_size(h_t[top] + res2, self.deconv_output1.weight, 2, k // 2, shape2, prec)
+                x_gen = ops.conv_transpose2d_to_size(x_gen + res1, self.deconv_output2.weight, 2, k // 2, shape1, prec)
+            else:
+                x_gen = ops.conv2d_same(h_t[top], self.conv_last.weight, None, prec)
             next_frames.append(x_gen)
         pred = self._reshape_patch_back(torch.stack(next_frames[-pred_frames:], dim=1))
         loss = torch.mean(torch.stack(decouple, dim=0))
@@ -183,7 +239,7 @@ class PredRNN_V2(VPModel):
         return self._std_schedule_sampling(batch_size, context_frames, pred_frames)
 
     def _rng_device(self):
-        return self.conv_last.weight.device
+        return self.adapter.weight.device
 
     def training_loss(self, inp, targets, pred_frames, loss_provider, reversed_pair=None, **fwd_kwargs):
         """Loss of ONE training iteration (predrnn_v2.py:326-352): forward with the training-time sampling mask; with

@@ -286,7 +286,7 @@ class _ConvExFn(torch.autograd.Function):
     run in libvpx_hip; ATen only for kernels smaller than their stride."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, padding, transposed, slope, precision):
+    def forward(ctx, x, w, bias, stride, padding, transposed, slope, precision, out_pad=(0, 0)):
         _require_gpu(x, "conv2d_ex")
         xs = to_channels_last(x)
         N, Ci, H, Wd = xs.shape
@@ -296,7 +296,8 @@ class _ConvExFn(torch.autograd.Function):
             raise ValueError(f"conv2d_ex: weight {tuple(w.shape)} does not match {Ci} input channels")
         wc = w.contiguous()
         bc = None if bias is None else bias.contiguous()
-        d = ConvDesc(N, H, Wd, Ci, Co, kh, kw, int(stride), int(padding), int(bool(transposed)), float(slope), precision, 0, 0)
+        d = ConvDesc(N, H, Wd, Ci, Co, kh, kw, int(stride), int(padding), int(bool(transposed)), float(slope), precision,
+                     int(out_pad[0]), int(out_pad[1]))
         L = _lib.lib()
         ho, wo = ctypes.c_int(0), ctypes.c_int(0)
         check(L.vpx_conv2d_ex_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "vpx_conv2d_ex_out_shape")
@@ -331,7 +332,7 @@ class _ConvExFn(torch.autograd.Function):
             db = torch.empty(d.Co, device=dy.device) if mask[2] else None
             check(L.vpx_conv2d_ex_bwd(ctypes.byref(d), ptr(xs), ptr(wc), ptr(y), ptr(dyc), ptr(dx), ptr(dw), ptr(db), ptr(ws),
                                       ws_bytes, _stream()), "vpx_conv2d_ex_bwd")
-            return dx, dw, db, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None
         # fallback (kernel smaller than the stride, negative slope): ATen's convolution backward = MIOpen NHWC kernels.
         # GLUE_BACKWARD_NATIVE additionally routes it around MIOpen (MIOpen's solver search aborted the process in ~10 % of
         # the runs of a test with exotic shapes on this image, inside miopen find).
@@ -341,12 +342,24 @@ class _ConvExFn(torch.autograd.Function):
         bias_sizes = [int(wc.shape[1] if transposed else wc.shape[0])] if has_bias else None
         with torch.backends.cudnn.flags(enabled=not GLUE_BACKWARD_NATIVE):
             dx, dw, db = torch.ops.aten.convolution_backward(dy, xs, wc, bias_sizes, [stride, stride], [padding, padding],
-                                                             [1, 1], transposed, [0, 0], 1, mask)
-        return dx, dw, (db if has_bias else None), None, None, None, None, None
+                                                             [1, 1], transposed, [d.out_pad_h, d.out_pad_w], 1, mask)
+        return dx, dw, (db if has_bias else None), None, None, None, None, None, None
 
 
-def conv2d_ex(x, w, bias, stride, padding, transposed=False, leaky_slope=0.0, precision="f32"):
-    return _ConvExFn.apply(x, w, bias, stride, padding, transposed, leaky_slope, PRECISIONS[precision])
+def conv2d_ex(x, w, bias, stride, padding, transposed=False, leaky_slope=0.0, precision="f32", output_padding=(0, 0)):
+    """Conv2d / ConvTranspose2d (stride 1 or 2; `output_padding` for transposed layers) + bias + LeakyReLU, differentiable."""
+    return _ConvExFn.apply(x, w, bias, stride, padding, transposed, leaky_slope, PRECISIONS[precision], tuple(output_padding))
+
+
+def conv_transpose2d_to_size(x, w, stride, padding, out_hw, precision="f32"):
+    """nn.ConvTranspose2d(...)(x, output_size=out_hw) without bias (predrnn_v2.py:213-218): the output padding is whatever
+    makes the result exactly out_hw (it must lie in [0, stride))."""
+    kh, kw = int(w.shape[2]), int(w.shape[3])
+    base = ((x.shape[-2] - 1) * stride - 2 * padding + kh, (x.shape[-1] - 1) * stride - 2 * padding + kw)
+    op = (int(out_hw[0]) - base[0], int(out_hw[1]) - base[1])
+    if min(op) < 0 or max(op) >= max(stride, 1):
+        raise ValueError(f"requested output size {tuple(out_hw)} is not reachable (needs output padding {op}, stride {stride})")
+    return conv2d_ex(x, w, None, stride, padding, True, 0.0, precision, op)
 
 
 def glue_supported(kh, kw, stride, padding, transposed) -> bool:
@@ -598,3 +611,74 @@ def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=Non
         raise ValueError("stlstm_step: ln must hold 0 or 8 tensors")
     need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (x, h, c, m, Wx, Wh, Wm, Wo, Wlast) + ln)
     return _STLSTMStepFn.apply(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, PRECISIONS[precision], need_grad, wsholder, *ln)
+
+
+class _ACSTGatesFn(torch.autograd.Function):
+    """(c_new, m_new, delta_c, delta_m, o_pre, mem) from the conv outputs of the (action-conditional) ST-LSTM cell
+    (predrnn.py:143-164): conv_h(h) * conv_a(a) product, both gate groups and the state updates in ONE HIP pass,
+    explicit backward (csrc/acst.hip). `ac` may be None (plain ST-LSTM arithmetic on conv outputs)."""
+
+    @staticmethod
+    def forward(ctx, xc, hc, ac, mc, c, m, forget_bias):
+        _require_gpu(xc, "acst_gates")
+        xs, hs, ms, cs, mm = (to_channels_last(t) for t in (xc, hc, mc, c, m))
+        as_ = None if ac is None else to_channels_last(ac)
+        B, Ch, H, Wd = cs.shape
+        dev = xc.device
+        outs = [new_channels_last((B, Ch, H, Wd), dev) for _ in range(5)]
+        mem = new_channels_last((B, 2 * Ch, H, Wd), dev)
+        need = any(ctx.needs_input_grad)
+        save = torch.empty(B * H * Wd * 6 * Ch, device=dev) if need else None
+        check(_lib.lib().vpx_acst_gates_fwd(ptr(xs), ptr(hs), ptr(as_), ptr(ms), ptr(cs), ptr(mm), *[ptr(o) for o in outs], ptr(mem),
+                                            ptr(save), B * H * Wd, Ch, float(forget_bias), _stream()), "vpx_acst_gates_fwd")
+        if need:
+            ctx.save_for_backward(hs, as_, cs, mm, save)
+        return (*outs, mem)
+
+    @staticmethod
+    def backward(ctx, d_cn, d_mn, d_dc, d_dm, d_opre, d_mem):
+        hs, as_, cs, mm, save = ctx.saved_tensors
+        B, Ch, H, Wd = cs.shape
+        dev = cs.device
+        g = [None if t is None else to_channels_last(t) for t in (d_cn, d_mn, d_dc, d_dm, d_opre, d_mem)]
+        dxc = new_channels_last((B, 7 * Ch, H, Wd), dev)
+        dhc = new_channels_last((B, 4 * Ch, H, Wd), dev)
+        dac = new_channels_last((B, 4 * Ch, H, Wd), dev) if as_ is not None else None
+        dmc = new_channels_last((B, 3 * Ch, H, Wd), dev)
+        dc, dm = new_channels_last((B, Ch, H, Wd), dev), new_channels_last((B, Ch, H, Wd), dev)
+        check(_lib.lib().vpx_acst_gates_bwd(ptr(hs), ptr(as_), ptr(cs), ptr(mm), ptr(save), *[ptr(t) for t in g], ptr(dxc), ptr(dhc),
+                                            ptr(dac), ptr(dmc), ptr(dc), ptr(dm), B * H * Wd, Ch, _stream()), "vpx_acst_gates_bwd")
+        return dxc, dhc, dac, dmc, dc, dm, None
+
+
+def acst_gates(xc, hc, ac, mc, c, m, forget_bias=1.0):
+    return _ACSTGatesFn.apply(xc, hc, ac, mc, c, m, float(forget_bias))
+
+
+class _STOutFn(torch.autograd.Function):
+    """h_new = sigmoid(o_pre + oc) * tanh(lc)  (predrnn.py:166-167), one HIP pass each way."""
+
+    @staticmethod
+    def forward(ctx, o_pre, oc, lc):
+        _require_gpu(o_pre, "st_out")
+        a, b, c = to_channels_last(o_pre), to_channels_last(oc), to_channels_last(lc)
+        h = new_channels_last(tuple(a.shape), a.device)
+        need = any(ctx.needs_input_grad)
+        o_s = torch.empty_like(h) if need else None
+        t_s = torch.empty_like(h) if need else None
+        check(_lib.lib().vpx_st_out_fwd(ptr(a), ptr(b), ptr(c), ptr(h), ptr(o_s), ptr(t_s), a.numel(), _stream()), "vpx_st_out_fwd")
+        if need:
+            ctx.save_for_backward(o_s, t_s)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        o_s, t_s = ctx.saved_tensors
+        g = torch.empty_like(o_s).copy_(dh) if dh.stride() != o_s.stride() else dh
+        d_o, d_lc = torch.empty_like(o_s), torch.empty_like(o_s)
+        check(_lib.lib().vpx_st_out_bwd(ptr(g), ptr(o_s), ptr(t_s), ptr(d_o), ptr(d_lc), o_s.numel(), _stream()), "vpx_st_out_bwd")
+        return d_o, d_o, d_lc
+
+
+def st_out(o_pre, oc, lc):
+    return _STOutFn.apply(o_pre, oc, lc)
