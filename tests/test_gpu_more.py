@@ -41,16 +41,21 @@ def test_ndrplz_sequence_block_vs_golden(vpx, tag):
         blk(x, hidden_state=[None])
 
 
-def test_stlstm_c_abi_nchw(vpx):
-    """vpx_stlstm_step_fwd/_bwd called directly on reference-layout (NCHW) buffers."""
+@pytest.mark.parametrize("tag", ["plain", "ln"])
+def test_stlstm_c_abi_nchw(vpx, tag):
+    """vpx_stlstm_step_fwd/_bwd called directly on reference-layout (NCHW) buffers; "ln" = the LayerNorm variant
+    (predrnn.py:24-40), whose NCHW backward form transposes through the workspace."""
     from golden_util import seeded_state_dict
     L = vpx._lib.lib()
-    tag = "plain"
     Cin, Ch, H, W, k, ln, B = gc.STLSTM_CASES[tag]
     g = load_golden(f"stlstm_{tag}")
     sd = {kk: v.cuda().contiguous() for kk, v in seeded_state_dict(g, name_seed("stlstm." + tag)).items()}
     inp = {n: v.cuda().contiguous() for n, v in gc.stlstm_inputs(tag, Cin, Ch, H, W, B).items()}
-    d = vpx._lib.STLSTMDesc(B, Cin, Ch, H, W, k, 0, vpx._lib.LAYOUT_NCHW, vpx._lib.PREC_F32, vpx._lib.FLAG_SAVE_FOR_BWD)
+    d = vpx._lib.STLSTMDesc(B, Cin, Ch, H, W, k, int(ln), vpx._lib.LAYOUT_NCHW, vpx._lib.PREC_F32, vpx._lib.FLAG_SAVE_FOR_BWD)
+    ln_names = [f"conv_{n}.1.{wb}" for n in "xhmo" for wb in ("weight", "bias")]
+    ln_arr = (ctypes.c_void_p * 8)(*[sd[n].data_ptr() for n in ln_names]) if ln else None
+    dln = [torch.empty_like(sd[n]) for n in ln_names] if ln else []
+    dln_arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in dln]) if ln else None
     ws_bytes, rs_bytes = L.vpx_stlstm_workspace_bytes(ctypes.byref(d)), L.vpx_stlstm_reserve_bytes(ctypes.byref(d))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
     rs = torch.empty(rs_bytes, dtype=torch.uint8, device="cuda")
@@ -58,7 +63,7 @@ def test_stlstm_c_abi_nchw(vpx):
     p = vpx._lib.ptr
     Ws = [sd["conv_x.0.weight"], sd["conv_h.0.weight"], sd["conv_m.0.weight"], sd["conv_o.0.weight"], sd["conv_last.weight"]]
     rc = L.vpx_stlstm_step_fwd(ctypes.byref(d), p(inp["x"]), p(inp["h"]), p(inp["c"]), p(inp["m"]), *[p(w) for w in Ws],
-                               None, *[p(o) for o in outs], p(rs), rs_bytes, p(ws), ws_bytes, None)
+                               ln_arr, *[p(o) for o in outs], p(rs), rs_bytes, p(ws), ws_bytes, None)
     assert rc == 0, L.vpx_last_error()
     for o, n in zip(outs, ("h_new", "c_new", "m_new", "delta_c", "delta_m")):
         assert _relmax(o, g[n]) < 1e-5, n
@@ -66,13 +71,15 @@ def test_stlstm_c_abi_nchw(vpx):
     dins = [torch.empty_like(inp[n]) for n in ("x", "h", "c", "m")]
     dWs = [torch.empty_like(w) for w in Ws]
     rc = L.vpx_stlstm_step_bwd(ctypes.byref(d), p(inp["x"]), p(inp["h"]), p(inp["c"]), p(inp["m"]), p(outs[1]), p(outs[2]),
-                               *[p(w) for w in Ws], None, p(rs), rs_bytes, *[p(t) for t in grads_in],
-                               *[p(t) for t in dins], *[p(t) for t in dWs], None, p(ws), ws_bytes, None)
+                               *[p(w) for w in Ws], ln_arr, p(rs), rs_bytes, *[p(t) for t in grads_in],
+                               *[p(t) for t in dins], *[p(t) for t in dWs], dln_arr, p(ws), ws_bytes, None)
     assert rc == 0, L.vpx_last_error()
     torch.cuda.synchronize()
     for t, n in zip(dins, ("dx", "dh", "dc", "dm")):
         assert _relmax(t, g[n]) < 5e-5, n
     for t, n in zip(dWs, ("conv_x.0.weight", "conv_h.0.weight", "conv_m.0.weight", "conv_o.0.weight", "conv_last.weight")):
+        assert _relmax(t, g["grad." + n]) < 5e-5, n
+    for t, n in zip(dln, ln_names):
         assert _relmax(t, g["grad." + n]) < 5e-5, n
 
 

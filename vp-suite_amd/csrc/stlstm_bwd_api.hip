@@ -129,13 +129,37 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     const int B = d->B, Cin = d->Cin, Ch = d->Ch, H = d->H, Wd = d->W, k = d->k;
     const size_t HW = (size_t)H * Wd;
     const int ldG = 7 * Ch;
+    vpx_stlstm_desc d2;
     if (d->layer_norm) {
         if (!ln) { set_error("vpx_stlstm_step_bwd: layer_norm set but ln is NULL"); return VPX_ERR_ARG; }
-        if (d->layout != VPX_LAYOUT_NHWC) { set_error("vpx_stlstm_step_bwd: the LayerNorm variant's backward takes NHWC buffers only"); return VPX_ERR_UNSUPPORTED; }
         Carver w2{(char*)workspace, 0, workspace_bytes};
         w2.off = (256 - ((uintptr_t)workspace & 255)) & 255;
-        return stlstm_ln_bwd(d, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, ln, reserve, dh_new, dc_new, dm_new, ddelta_c, ddelta_m,
-                             dx, dh, dc, dm, dWx, dWh, dWm, dWo, dWlast, dln, w2, stream);
+        if (d->layout == VPX_LAYOUT_NHWC)
+            return stlstm_ln_bwd(d, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, ln, reserve, dh_new, dc_new, dm_new, ddelta_c, ddelta_m,
+                                 dx, dh, dc, dm, dWx, dWh, dWm, dWo, dWlast, dln, w2, stream);
+        // reference layout (NCHW): activations and incoming gradients are transposed into the workspace, the NHWC routine
+        // runs on the copies, the data gradients are transposed back (the LayerNorm parameters and their gradients keep the
+        // reference's [C,H,W] layout either way)
+        const size_t n_x = (size_t)B * HW * Cin, n_s = (size_t)B * HW * Ch;
+        float* bx = w2.take(n_x);
+        float* bdx = w2.take(n_x);
+        float* st[12];
+        for (auto& p : st) p = w2.take(n_s);
+        const float* in_nchw[9] = {h, c, m, dh_new, dc_new, dm_new, ddelta_c, ddelta_m, nullptr};
+        const float* in_nhwc[9] = {};
+        VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B, Cin, H, Wd, stream));
+        for (int i = 0; i < 8; ++i)
+            if (in_nchw[i]) { VPX_CHECK_HIP(launch_nchw_to_nhwc(in_nchw[i], st[i], B, Ch, H, Wd, stream)); in_nhwc[i] = st[i]; }
+        float* dhn = dh ? st[8] : nullptr; float* dcn2 = dc ? st[9] : nullptr; float* dmn2 = dm ? st[10] : nullptr;
+        d2 = *d; d2.layout = VPX_LAYOUT_NHWC;
+        rc = stlstm_ln_bwd(&d2, bx, in_nhwc[0], in_nhwc[1], in_nhwc[2], Wx, Wh, Wm, Wo, Wlast, ln, reserve, in_nhwc[3], in_nhwc[4],
+                           in_nhwc[5], in_nhwc[6], in_nhwc[7], dx ? bdx : nullptr, dhn, dcn2, dmn2, dWx, dWh, dWm, dWo, dWlast, dln, w2, stream);
+        if (rc != VPX_OK) return rc;
+        if (dx) VPX_CHECK_HIP(launch_nhwc_to_nchw(bdx, dx, B, Cin, H, Wd, stream));
+        if (dh) VPX_CHECK_HIP(launch_nhwc_to_nchw(dhn, dh, B, Ch, H, Wd, stream));
+        if (dc) VPX_CHECK_HIP(launch_nhwc_to_nchw(dcn2, dc, B, Ch, H, Wd, stream));
+        if (dm) VPX_CHECK_HIP(launch_nhwc_to_nchw(dmn2, dm, B, Ch, H, Wd, stream));
+        return VPX_OK;
     }
 
     // VPX_FLAG_WEIGHTS_PACKED: `workspace` is the one a previous backward call of the SAME cell, weights, shape and set of
