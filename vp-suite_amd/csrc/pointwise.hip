@@ -137,7 +137,8 @@ hipError_t launch_axpy(float* y, const float* x, long long n, hipStream_t s) {
 // Same arithmetic as EpiConvLSTM (conv_gemm.hip): peepholes on the previous cell for i,f and on the NEW cell for o
 // (conv_lstm_hzzone.py:62-68). One thread per (pixel, channel); `pre` may alias ea.gates (a thread reads its four
 // values before it writes them).
-__global__ __launch_bounds__(256) void convlstm_pointwise_kernel(const ConvLSTMStepArgs a, const float* pre, int B, long long HW) {
+__global__ __launch_bounds__(256) void convlstm_pointwise_kernel(const ConvLSTMStepArgs a, const float* pre, long long pre_bstride, int B,
+                                                                 long long HW) {
     const long long e = blockIdx.x * 256LL + threadIdx.x;
     const int Ch = a.Ch;
     if (e >= (long long)B * HW * Ch) return;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void convlstm_pointwise_kernel(const ConvLSTMS
     const long long bp = e / Ch;          // b * HW + pix
     const long long pix = bp % HW;
     const int b = (int)(bp / HW);
-    const float* p4 = pre + bp * 4 * Ch + ch;
+    const float* p4 = pre + (size_t)b * pre_bstride + pix * 4 * Ch + ch;   // pre_bstride: elements between batch items
     float ai = p4[a.gate_pos[0] * Ch], af = p4[a.gate_pos[1] * Ch], ag = p4[a.gate_pos[2] * Ch], ao = p4[a.gate_pos[3] * Ch];
     if (a.bias) {
         ai += a.bias[a.gate_pos[0] * Ch + ch]; af += a.bias[a.gate_pos[1] * Ch + ch];
@@ -165,9 +166,11 @@ __global__ __launch_bounds__(256) void convlstm_pointwise_kernel(const ConvLSTMS
     }
 }
 
-hipError_t launch_convlstm_pointwise(const ConvLSTMStepArgs& ea, const float* pre, int B, long long HW, hipStream_t s) {
+hipError_t launch_convlstm_pointwise(const ConvLSTMStepArgs& ea, const float* pre, int B, long long HW, hipStream_t s,
+                                     long long pre_bstride) {
     const long long n = (long long)B * HW * ea.Ch;
-    hipLaunchKernelGGL(convlstm_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ea, pre, B, HW);
+    if (pre_bstride <= 0) pre_bstride = HW * 4 * ea.Ch;
+    hipLaunchKernelGGL(convlstm_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ea, pre, pre_bstride, B, HW);
     return hipGetLastError();
 }
 

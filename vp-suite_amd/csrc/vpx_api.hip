@@ -70,6 +70,9 @@ size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
     // forward: packed weights + cell scratch (+ NCHW staging)
     size_t fwd = align256(convlstm_wpk_bytes(d, L)) + align256(L.n_state * sizeof(float));
     if (L.split) fwd += align256(4 * L.n_state * sizeof(float));  // gate pre-activations of one step
+    if (L.hoist)  // input projection of all steps [B,T,HW,4Ch] + the two weight packs (x columns, h columns)
+        fwd += align256(4 * L.n_out * sizeof(float)) + align256(packed_weight_bytes(L.s_tiles, L.hx_chunks, L.s_ng, d->precision)) +
+               align256(packed_weight_bytes(L.s_tiles, L.hh_chunks, L.s_ng, d->precision));
     if (L.v2)  // packed weights of cell2 + split copies of x, h0 and a two-slot ring of h_t
         fwd += align256(cell2_packed_bytes(L.n_tiles, 3 * ((d->Cin + d->Ch) / 16))) + align256(L.n_x * 4) + 3 * align256(L.n_state * 4);
     if (d->layout == VPX_LAYOUT_NCHW)
@@ -109,6 +112,13 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     float* wpk = ws.take(convlstm_wpk_bytes(d, L) / sizeof(float));
     float* c_scratch = ws.take(L.n_state);
     float* pre_scratch = L.split ? ws.take(4 * L.n_state) : nullptr;
+    const bool hoist = L.hoist && x != nullptr;
+    float *pre_all = nullptr, *wpk_hx = nullptr, *wpk_hh = nullptr;
+    if (hoist) {
+        pre_all = ws.take(4 * L.n_out);
+        wpk_hx = ws.take(packed_weight_bytes(L.s_tiles, L.hx_chunks, L.s_ng, d->precision) / sizeof(float));
+        wpk_hh = ws.take(packed_weight_bytes(L.s_tiles, L.hh_chunks, L.s_ng, d->precision) / sizeof(float));
+    }
     char *wpk2 = nullptr, *x_sp = nullptr, *h0_sp = nullptr, *h_ring[2] = {nullptr, nullptr};
     if (L.v2) {
         wpk2 = (char*)ws.take(cell2_packed_bytes(L.n_tiles, 3 * ((Cin + Ch) / 16)) / sizeof(float));
@@ -182,6 +192,35 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     }
     if (!L.v2) VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
 
+    if (hoist) {
+        // two packs (x columns / h columns of W, reference row order), then W_x * x for all B*T frames in one launch
+        PackDesc px{}, ph{};
+        px.seg[0] = PackSeg{W, ld_o, L.taps, 0, Cin};
+        memcpy(px.stage, L.hx_stage, sizeof(ConvStage) * L.hx_nstage);
+        px.nstage = L.hx_nstage; px.chunks_total = L.hx_chunks; px.prec = d->precision; px.taps = L.taps;
+        fill_plain_pack(px, 4 * Ch, 0, L.s_ng);
+        VPX_CHECK_HIP(launch_pack_weights(px, wpk_hx, stream));
+        ph.seg[0] = PackSeg{W, ld_o, L.taps, Cin, Ch};
+        memcpy(ph.stage, L.hh_stage, sizeof(ConvStage) * L.hh_nstage);
+        ph.nstage = L.hh_nstage; ph.chunks_total = L.hh_chunks; ph.prec = d->precision; ph.taps = L.taps;
+        fill_plain_pack(ph, 4 * Ch, 0, L.s_ng);
+        VPX_CHECK_HIP(launch_pack_weights(ph, wpk_hh, stream));
+        ConvPlan PX{};
+        PX.B = B * T; PX.H = H; PX.W = Wd; PX.kh = d->kh; PX.kw = d->kw;
+        set_plan_tiles(PX, 1);
+        PX.nseg = 1;
+        PX.seg[0] = ConvSeg{xn, (long long)(HW * Cin), Cin, 0};   // x is [B][T][HW][Cin]: B*T dense images
+        PX.nstage = L.hx_nstage;
+        memcpy(PX.stage, L.hx_stage, sizeof(ConvStage) * L.hx_nstage);
+        PX.chunks_total = L.hx_chunks; PX.prec = d->precision;
+        PX.a_bytes = conv_a_bytes(L.hx_stage, L.hx_nstage, d->kh, d->kw, 1);
+        PX.wpk = wpk_hx;
+        PlainEpiArgs pa{};
+        pa.Co = 4 * Ch; pa.split = 4 * Ch; pa.ng = L.s_ng;
+        pa.out0 = pre_all; pa.bstride0 = (long long)(HW * 4 * Ch); pa.ld0 = 4 * Ch;
+        VPX_CHECK_HIP(launch_conv_plain_f32(PX, pa, L.s_tiles, stream));
+    }
+
     float* gates_all = nullptr;
     float* cs_all = nullptr;
     if (save) {
@@ -240,6 +279,30 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             P2.hs_off = Cin / 16;
             // the split copy of h_t feeds step t+1 only: the last step does not need it
             VPX_CHECK_HIP(launch_cell2(P2, ea, (t + 1 < T) ? h_ring[t & 1] : nullptr, (long long)(HW * Ch * 4), stream));
+        } else if (hoist) {
+            // the step contracts only h_{t-1} and accumulates (atomics when K is split) into its slice of the hoisted input
+            // projection; the pointwise kernel reads that slice (batch stride T*HW*4Ch) and writes gates / c / h
+            float* pre_t = pre_all + (size_t)t * HW * 4 * Ch;
+            const long long pre_bs = (long long)((size_t)T * HW * 4 * Ch);
+            if (hprev) {
+                ConvPlan PH{};
+                PH.B = B; PH.H = H; PH.W = Wd; PH.kh = d->kh; PH.kw = d->kw;
+                set_plan_tiles(PH, 1);
+                PH.nseg = 1;
+                PH.seg[0] = ConvSeg{hprev, hprev_bs, Ch, 0};
+                PH.nstage = L.hh_nstage;
+                memcpy(PH.stage, L.hh_stage, sizeof(ConvStage) * L.hh_nstage);
+                PH.chunks_total = L.hh_chunks; PH.prec = d->precision;
+                PH.a_bytes = conv_a_bytes(L.hh_stage, L.hh_nstage, d->kh, d->kw, 1);
+                PH.wpk = wpk_hh;
+                PH.ksplit = L.hh_split;
+                PlainEpiArgs pa{};
+                pa.Co = 4 * Ch; pa.split = 4 * Ch; pa.ng = L.s_ng;
+                pa.out0 = pre_t; pa.bstride0 = pre_bs; pa.ld0 = 4 * Ch;
+                pa.accumulate = 1;
+                VPX_CHECK_HIP(launch_conv_plain_f32(PH, pa, L.s_tiles, stream));
+            }
+            VPX_CHECK_HIP(launch_convlstm_pointwise(ea, pre_t, B, (long long)HW, stream, pre_bs));
         } else if (L.split) {
             // pre-activations of all four gates by a K-split plain convolution (atomic partial sums), then the gates
             float* pre = ea.gates ? ea.gates : pre_scratch;  // with SAVE_FOR_BWD the reserve slot doubles as scratch

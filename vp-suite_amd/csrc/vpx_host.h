@@ -114,6 +114,11 @@ struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     // small maps: the step as a K-split plain convolution into a gate buffer + a pointwise gate kernel (0 = fused launch)
     int split, s_ng, s_tiles, s_nstage, s_chunks;
     ConvStage s_stage[MAX_STAGE];
+    // ... with the input projection hoisted out of the recurrence (split path, T > 1): W_x * x_t for ALL steps is ONE launch
+    // over B*T images into the gate buffers; a step then only contracts h_{t-1} (K = Ch*taps instead of (Cin+Ch)*taps on
+    // the serial path) and accumulates into its slice — which also saves the per-step clear of the gate buffer
+    int hoist, hx_nstage, hx_chunks, hh_nstage, hh_chunks, hh_split;
+    ConvStage hx_stage[MAX_STAGE], hh_stage[MAX_STAGE];
     size_t n_state, n_x, n_out, n_peep;
     // backward
     int d_nstage, d_chunks, d_mw;  // data-gradient conv: K stages over the 4Ch gate axis; rows-per-workgroup variant
@@ -134,6 +139,7 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     L.nstage = build_stages(L.stage, &L.chunks_total, segC, 2, L.taps, pick_stage_channels(segC, 2, d->kh, d->kw, 4, d->precision, L.mw, 1, L.qpc), d->precision, L.qpc);
     if (L.nstage < 0) { set_error("convlstm: too many channel stages (Cin=%d Ch=%d)", d->Cin, d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.split = 0;
+    L.hoist = 0;
     {
         const long long m_tiles = (long long)d->B * ((d->H + TILE_H - 1) / TILE_H) * ((d->W + TILE_W - 1) / TILE_W);
         // the fused launch would leave CUs idle (small batches / maps). Measured on MI355X, bf16x3, (96,96,16x16):
@@ -150,6 +156,18 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
             L.s_nstage = build_stages(L.s_stage, &L.s_chunks, segC, 2, L.taps, cs, d->precision);
             const int ks = L.s_nstage > 0 ? pick_ksplit(m_tiles * tiles, L.s_nstage) : 1;
             if (ks > 1) { L.split = ks; L.s_ng = ng; L.s_tiles = tiles; }
+            L.hoist = 0;
+            static int hoist_on = -1;  // VPX_HOIST=0 disables (experiments)
+            if (hoist_on < 0) { const char* e = getenv("VPX_HOIST"); hoist_on = e ? atoi(e) : 1; }
+            if (L.split && d->T > 1 && hoist_on) {
+                const int sx[1] = {d->Cin}, sh[1] = {d->Ch};
+                L.hx_nstage = build_stages(L.hx_stage, &L.hx_chunks, sx, 1, L.taps, pick_stage_channels(sx, 1, d->kh, d->kw, ng, d->precision), d->precision);
+                L.hh_nstage = build_stages(L.hh_stage, &L.hh_chunks, sh, 1, L.taps, cs, d->precision);
+                if (L.hx_nstage > 0 && L.hh_nstage > 0) {
+                    L.hh_split = pick_ksplit(m_tiles * tiles, L.hh_nstage);
+                    L.hoist = 1;
+                }
+            }
         }
     }
     L.v2 = (!L.split && cell2_applicable(d)) ? 1 : 0;

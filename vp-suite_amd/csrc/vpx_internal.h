@@ -137,7 +137,8 @@ size_t cell2_packed_bytes(int n_tiles, int chunks_total);
 hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s);
 
 // pointwise half of the K-split step: pre-activations pre [B*HW, 4Ch] (reference gate order) -> gates, c, h (pointwise.hip)
-hipError_t launch_convlstm_pointwise(const ConvLSTMStepArgs& ea, const float* pre, int B, long long HW, hipStream_t s);
+hipError_t launch_convlstm_pointwise(const ConvLSTMStepArgs& ea, const float* pre, int B, long long HW, hipStream_t s,
+                                     long long pre_bstride = 0);  // elements between batch items of pre (0 = dense)
 
 // Plain epilogue: y = conv (+bias), channels [0,split) -> out0, [split, Co) -> out1 (either may be null = dropped).
 struct PlainEpiArgs {
