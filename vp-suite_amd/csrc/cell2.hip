@@ -223,6 +223,91 @@ struct Cell2Epi {
             }
         }
     }
+
+    // Vectorised epilogue for tiles that lie inside the image and cover 32 valid channels: the accumulators take a round trip
+    // through this wave's private 16 KiB of LDS ([gate][pixel][32 ch], conflict-free both ways) so that a lane then owns FOUR
+    // consecutive channels of a pixel — every global access is 16 bytes per lane (8 lanes = one pixel's 128-byte channel row)
+    // and the address arithmetic runs once per four elements. Same arithmetic per element as run<>().
+    __device__ __forceinline__ void run_vec(const f32x16 (&acc)[4], char* lds, int b, int y0, int x0, int n_tile, int prow, int lane,
+                                            int H, int W) const {
+        const int j = lane & 31, hh = lane >> 5;
+        const unsigned Ch = (unsigned)a.Ch;
+        float* ldsf = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;     // MFMA row = pixel slot of the sub-tile
+                ldsf[g * 1024 + i * 32 + j] = acc[g][r];
+            }
+        // (LDS operations of one wave execute in order: the reads below see the writes above without a barrier)
+        const int cg = lane & 7, p4 = lane >> 3;
+        const unsigned ch = (unsigned)(n_tile * 32 + cg * 4);
+        f32x4 bi = {0.f, 0.f, 0.f, 0.f}, bf = bi, bg = bi, bo = bi;
+        if (a.bias) {
+            bi = *reinterpret_cast<const f32x4*>(a.bias + a.gate_pos[0] * Ch + ch);
+            bf = *reinterpret_cast<const f32x4*>(a.bias + a.gate_pos[1] * Ch + ch);
+            bg = *reinterpret_cast<const f32x4*>(a.bias + a.gate_pos[2] * Ch + ch);
+            bo = *reinterpret_cast<const f32x4*>(a.bias + a.gate_pos[3] * Ch + ch);
+        }
+        const size_t img = (size_t)b * H * W;
+        const float* const cin_b = a.c_in ? a.c_in + img * Ch : nullptr;
+        float* const cout_b = a.c_out + img * Ch;
+        float* const hout_b = a.h_out + (size_t)b * a.h_bstride;
+        float* const g0 = a.gates ? a.gates + img * 4 * Ch : nullptr;
+        char* const hsp_b = h_sp ? h_sp + (size_t)b * h_sp_bstride : nullptr;
+        const unsigned sp_off = (ch >> 3) * 32 + (ch & 7) * 2;   // hi quad of channels ch..ch+3; the lo quad sits 16 bytes further
+        const int rowpix = (y0 + prow) * W + x0;
+        unsigned eo[4];
+        f32x4 cp[4], wi[4], wf[4], wo[4];
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ip = k * 8 + p4;                               // pixel slot 0..31 of the sub-tile
+            const int pix = rowpix + (ip >> 4) * W + c2_px(ip);
+            eo[k] = __umul24((unsigned)pix, Ch) + ch;
+            cp[k] = cin_b ? *reinterpret_cast<const f32x4*>(cin_b + eo[k]) : zero;
+            wi[k] = a.wci ? *reinterpret_cast<const f32x4*>(a.wci + eo[k]) : zero;
+            wf[k] = a.wci ? *reinterpret_cast<const f32x4*>(a.wcf + eo[k]) : zero;
+            wo[k] = a.wco ? *reinterpret_cast<const f32x4*>(a.wco + eo[k]) : zero;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ip = k * 8 + p4;
+            const f32x4 ai = *reinterpret_cast<const f32x4*>(ldsf + 0 * 1024 + ip * 32 + cg * 4);
+            const f32x4 af = *reinterpret_cast<const f32x4*>(ldsf + 1 * 1024 + ip * 32 + cg * 4);
+            const f32x4 ag = *reinterpret_cast<const f32x4*>(ldsf + 2 * 1024 + ip * 32 + cg * 4);
+            const f32x4 ao = *reinterpret_cast<const f32x4*>(ldsf + 3 * 1024 + ip * 32 + cg * 4);
+            f32x4 i4, f4, g4, o4, cn, hn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c0 = cp[k][e];
+                i4[e] = sigmoid_f(ai[e] + bi[e] + wi[k][e] * c0);
+                f4[e] = sigmoid_f(af[e] + bf[e] + wf[k][e] * c0);
+                g4[e] = tanh_f(ag[e] + bg[e]);
+                cn[e] = f4[e] * c0 + i4[e] * g4[e];
+                o4[e] = sigmoid_f(ao[e] + bo[e] + wo[k][e] * cn[e]);
+                hn[e] = o4[e] * tanh_f(cn[e]);
+            }
+            *reinterpret_cast<f32x4*>(cout_b + eo[k]) = cn;
+            *reinterpret_cast<f32x4*>(hout_b + eo[k]) = hn;
+            if (g0) {
+                const unsigned go = 4u * (eo[k] - ch) + ch;
+                *reinterpret_cast<f32x4*>(g0 + go) = i4;
+                *reinterpret_cast<f32x4*>(g0 + go + Ch) = f4;
+                *reinterpret_cast<f32x4*>(g0 + go + 2 * Ch) = g4;
+                *reinterpret_cast<f32x4*>(g0 + go + 3 * Ch) = o4;
+            }
+            if (hsp_b) {
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c2_split(hn[e], h[e], l[e]);
+                char* dst = hsp_b + 4u * (eo[k] - ch) + sp_off;
+                *reinterpret_cast<uint2*>(dst) = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+                *reinterpret_cast<uint2*>(dst + 16) = uint2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+            }
+        }
+    }
 };
 
 #ifdef VPX_ABLATE
@@ -419,9 +504,12 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
     }
     C2_STAMP(40);
     const bool full = y0 + 32 <= P.H && x0 + 16 <= P.W;
+    const bool vec = full && n_tile * 32 + 32 <= epi.a.Ch && (epi.a.Ch & 3) == 0;
+    if (vec) c2_barrier();   // every wave has read its last fragments: the staging buffers become the epilogue's transposition space
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        if (full) epi.run<true>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, P.H, P.W);
+        if (vec) epi.run_vec(acc[m], smem + wave * 16384, b, y0, x0, n_tile, 4 * wave + 2 * m, lane, P.H, P.W);
+        else if (full) epi.run<true>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, P.H, P.W);
         else epi.run<false>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, P.H, P.W);
         C2_STAMP(41 + m);
     }
