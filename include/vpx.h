@@ -48,7 +48,9 @@ enum { VPX_LAYOUT_NHWC = 0, VPX_LAYOUT_NCHW = 1 };
 enum { VPX_PREC_F32 = 0    /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 operands + fp32 accumulate */,
        VPX_PREC_BF16X3 = 1 /* split bf16 (hi/lo) operands, 3 bf16 MFMAs per product, fp32 accumulate (~fp32 accuracy) */,
        VPX_PREC_BF16 = 2   /* bf16 operands, fp32 accumulate, fp32 state and I/O */ };
-enum { VPX_FLAG_SAVE_FOR_BWD = 1 /* forward fills `reserve` (gate activations + cell states per step) */,
+enum { VPX_FLAG_X_SPLIT = 4 /* ConvLSTM forward: `x` holds the input sequence in the split-bf16 operand format (below) instead of
+                              fp32 — only where vpx_convlstm_takes_split_input() says so; saves the conversion pass */,
+       VPX_FLAG_SAVE_FOR_BWD = 1 /* forward fills `reserve` (gate activations + cell states per step) */,
        VPX_FLAG_WEIGHTS_PACKED = 2 /* ST-LSTM: `workspace` still holds the repacked weights of a previous call with the
                                       SAME weight values and desc (caller keeps one workspace per cell per forward; the
                                       backward has its own workspace and additionally needs the same set of requested
@@ -84,6 +86,11 @@ int vpx_set_option(int option, int value);
 
 /* ---- ConvLSTM over a sequence ------------------------------------------------------------------------------ */
 size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d); /* scratch, contents undefined between calls */
+/* Split-bf16 operand format ("split"): a [N,H,W,C] fp32 NHWC tensor re-encoded, same byte count, as per pixel, per group of 8
+ * channels: 8 hi bf16 (round-to-nearest of the value) then 8 lo bf16 (round-to-nearest of value - hi) — what the bf16x3
+ * kernels multiply. Producers: vpx_conv2d_ex_fwd_split (the stage glue feeding a recurrent block). 1 = this descriptor's
+ * forward consumes x in that form when VPX_FLAG_X_SPLIT is set (second-generation cell kernel, inference), 0 = fp32 only. */
+int vpx_convlstm_takes_split_input(const vpx_convlstm_desc* d);
 size_t vpx_convlstm_reserve_bytes(const vpx_convlstm_desc* d);   /* saved-for-backward, 0 without SAVE_FOR_BWD */
 
 /* x may be NULL (all-zero input: conv_lstm_hzzone.py:54-56), h0/c0 may be NULL (zero state: :40-45), bias may be NULL,
@@ -173,6 +180,10 @@ size_t vpx_conv2d_ex_workspace_bytes(const vpx_conv_desc* d);
 /* y [N,Ho,Wo,Co]. A stride-2 transposed convolution runs as 4 output-phase launches of the same kernel. */
 int vpx_conv2d_ex_fwd(const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The same layer with the output (also) in the split-bf16 operand format (see vpx_convlstm_takes_split_input): y_split
+ * [N,Ho,Wo,Co] split-encoded, Co % 8 == 0; y may be NULL (inference: nobody reads the fp32 copy). */
+int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* y_split,
+                            void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the same layer (the reference gets it from autograd over nn.Conv2d / nn.ConvTranspose2d (+ LeakyReLU),
  * ef_blocks.py:15-49): dy [N,Ho,Wo,Co] is the gradient w.r.t. the layer OUTPUT (after bias and activation); y is that
  * output as vpx_conv2d_ex_fwd produced it — needed (and only read) when d->leaky_slope != 0: the activation derivative is

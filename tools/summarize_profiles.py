@@ -15,7 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
 DST = os.path.join(ROOT, "profiles")
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
-DOMINANT = "EpiConvLSTM"
+DOMINANT = ("EpiConvLSTM", "cell2_kernel")   # fused cell step: first-generation kernel / second generation (cell2.hip)
+
+
+def is_dominant(name):
+    return any(d in name for d in DOMINANT)
 
 
 def one(pattern):
@@ -38,11 +42,11 @@ def pmc_means(d):
     if f:
         for r in csv.DictReader(open(f)):
             name, c, v = r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])
-            if DOMINANT in name:
+            if is_dominant(name):
                 agg[c].append(v)
-            if DOMINANT in name or any(p in name for p in SPLIT_PARTS):
+            if is_dominant(name) or any(p in name for p in SPLIT_PARTS):
                 step_sum[c] += v
-            if DOMINANT in name or "convlstm_pointwise_kernel" in name:
+            if is_dominant(name) or "convlstm_pointwise_kernel" in name:
                 steps[c] += 1
     out = {k: {"launches": len(v), "mean_per_launch": sum(v) / len(v)} for k, v in agg.items()}
     for k in out:
@@ -88,8 +92,8 @@ for tag, name in (("infer_f32", f"bench_infer_{BT}_f32"), ("predrnn_infer", f"be
 counters = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     counters.update(pmc_means(d))
-summary = {"kernel": "conv_gemm_kernel<EpiConvLSTM, bf16x3> averaged over the launches of `bench.py --steps 3` "
-                     f"(convlstm-shi, {BT}, 6 block shapes)",
+summary = {"kernel": "fused ConvLSTM cell step (cell2_kernel on 64x64 / 32x32 maps, conv_gemm_kernel<EpiConvLSTM, bf16x3> on 16x16 maps) "
+                     f"averaged over the launches of `bench.py --steps 3` (convlstm-shi, {BT}, 6 block shapes)",
            "command": "tools/collect_profiles.sh (rocprofv3 --pmc <counter> --kernel-trace, one pass per counter group)",
            "counters": counters}
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
@@ -106,3 +110,42 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "GRBM_GUI_ACTIVE" in counters:
     summary["mfma_pipe_busy_frac"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / elapsed_simd_cycles
 json.dump(summary, open(os.path.join(DST, f"{ROUND}_pmc_bench_infer_{BT}_bf16x3.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:1500])
+
+
+# ---- training step: forward-cell traffic (what bench.py's roofline object describes in train mode too) + a per-kernel table ----
+def per_kernel(d):
+    f = one(f"{d}/*/*counter_collection.csv")
+    tab = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    if f:
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0][:90]
+            a = tab[k][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    return tab
+
+
+tcount = {}
+for d in ("pmc_train_fetch", "pmc_train_write", "pmc_train_sq"):
+    tcount.update(pmc_means(d))
+if "FETCH_SIZE" in tcount and "WRITE_SIZE" in tcount:
+    rd = 2.0 * tcount["FETCH_SIZE"]["mean_per_cell_step"] * 1024
+    wr = tcount["WRITE_SIZE"]["mean_per_cell_step"] * 1024
+    tsum = {"kernel": "forward fused ConvLSTM cell steps inside the TRAINING step (gates and cell states saved for BPTT), "
+                      f"`bench.py --mode train --steps 2` (convlstm-shi, {BT})",
+            "command": "tools/collect_profiles.sh (pmc_train_* passes)",
+            "counters": tcount,
+            "hbm_traffic_bytes_per_launch": {"read": rd, "write": wr, "total": rd + wr,
+                                             "note": "per forward cell step; read = 2 * FETCH_SIZE KiB, write = WRITE_SIZE KiB"}}
+    table = {}
+    for d, cname in (("pmc_train_fetch", "FETCH_SIZE"), ("pmc_train_write", "WRITE_SIZE")):
+        for k, cs in per_kernel(d).items():
+            if cname in cs:
+                tot, n = cs[cname]
+                e = table.setdefault(k, {"launches": n})
+                e["read_MB_per_launch" if cname == "FETCH_SIZE" else "write_MB_per_launch"] = round((2.0 if cname == "FETCH_SIZE" else 1.0) * tot / n * 1024 / 1e6, 2)
+    for k, cs in per_kernel("pmc_train_sq").items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs and cs["GRBM_GUI_ACTIVE"][0] > 0:
+            table.setdefault(k, {})["mfma_pipe_busy_frac"] = round(cs["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (cs["GRBM_GUI_ACTIVE"][0] / 8 * 1024), 4)
+    tsum["per_kernel"] = {k: v for k, v in sorted(table.items(), key=lambda kv: -kv[1].get("read_MB_per_launch", 0) * kv[1].get("launches", 0))[:16]}
+    json.dump(tsum, open(os.path.join(DST, f"{ROUND}_pmc_bench_train_{BT}_bf16x3.json"), "w"), indent=1)
+    print("train pmc summary written")

@@ -16,16 +16,18 @@ LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 FLAG_SAVE_FOR_BWD = 1
 FLAG_WEIGHTS_PACKED = 2
+FLAG_X_SPLIT = 4
 
 OPT_CELL2 = 1
 
 EXPORTED_SYMBOLS = [
     "vpx_version", "vpx_last_error", "vpx_set_deterministic", "vpx_set_option",
-    "vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes", "vpx_convlstm_seq_fwd", "vpx_convlstm_seq_bwd",
+    "vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes", "vpx_convlstm_takes_split_input", "vpx_convlstm_seq_fwd",
+    "vpx_convlstm_seq_bwd",
     "vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes", "vpx_stlstm_step_fwd", "vpx_stlstm_step_bwd",
     "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
     "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_conv2d_bwd_workspace_bytes", "vpx_conv2d_nhwc_bwd",
-    "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd",
+    "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd", "vpx_conv2d_ex_fwd_split",
     "vpx_conv2d_ex_bwd_workspace_bytes", "vpx_conv2d_ex_bwd",
     "vpx_conv2d_nhwc_fwd_ex", "vpx_leaky_bwd_workspace_bytes", "vpx_leaky_bwd", "vpx_axpy",
     "vpx_acst_gates_fwd", "vpx_acst_gates_bwd", "vpx_st_out_fwd", "vpx_st_out_bwd",
@@ -90,6 +92,8 @@ def lib():
         for name in ("vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes"):
             getattr(L, name).restype = sz
             getattr(L, name).argtypes = [ctypes.POINTER(STLSTMDesc)]
+        L.vpx_convlstm_takes_split_input.restype = ctypes.c_int
+        L.vpx_convlstm_takes_split_input.argtypes = [ctypes.POINTER(ConvLSTMDesc)]
         L.vpx_convlstm_seq_fwd.restype = ctypes.c_int
         L.vpx_convlstm_seq_fwd.argtypes = [ctypes.POINTER(ConvLSTMDesc)] + [vp] * 11 + [vp, sz, vp, sz, vp]
         L.vpx_convlstm_seq_bwd.restype = ctypes.c_int
@@ -147,6 +151,8 @@ def lib():
         L.vpx_trajgru_gates_fwd.argtypes = [vp, ll, vp, vp, vp, vp, ci, ci, ci, ci, fl, vp]
         L.vpx_trajgru_gates_bwd.restype = ci
         L.vpx_trajgru_gates_bwd.argtypes = [vp, vp, vp, vp, vp, ll, vp, vp, ci, ci, ci, ci, fl, vp]
+        L.vpx_conv2d_ex_fwd_split.restype = ci
+        L.vpx_conv2d_ex_fwd_split.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 5 + [vp, sz, vp]
         L.vpx_mse_loss_workspace_bytes.restype = sz
         L.vpx_mse_loss_workspace_bytes.argtypes = []
         L.vpx_mse_loss.restype = ctypes.c_int

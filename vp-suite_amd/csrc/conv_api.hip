@@ -182,7 +182,7 @@ static int ex_mw(const vpx_conv_desc* d, int Ht, int Wt, int sd) {
 // one launch: tile space Ht x Wt, kernel taps th x tw, halo origin (oy, ox), input step `sd`
 int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
               const ExGeo& g, int Ht, int Wt, int th, int tw, int sd, int oy, int ox, const int* tapmap, bool flip,
-              int omap, int oys, int oyo, int oxs, int oxo, float* wpk) {
+              int omap, int oys, int oyo, int oxs, int oxo, float* wpk, char* y_split = nullptr) {
     const int prec = d->precision;
     ConvPlan P{};
     int chunks = 0;
@@ -216,12 +216,13 @@ int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const 
     ea.out0 = y; ea.bstride0 = (long long)g.Ho * g.Wo * d->Co; ea.ld0 = d->Co;
     ea.leaky = d->leaky_slope;
     ea.omap = omap; ea.oys = oys; ea.oyo = oyo; ea.oxs = oxs; ea.oxo = oxo; ea.Wmem = g.Wo;
+    ea.sp_out = y_split; ea.sp_bstride = (long long)g.Ho * g.Wo * d->Co * 4;
     VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, pd.n_tiles, stream));
     return VPX_OK;
 }
 
 int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const float* w, const float* bias, float* y, float* wpk,
-               hipStream_t stream);
+               hipStream_t stream, char* y_split = nullptr);
 
 size_t ex_wpk_floats(const vpx_conv_desc* d) {
     // upper bound over the launches this descriptor can produce (full tap set, stride as given)
@@ -271,19 +272,33 @@ int vpx_conv2d_ex_fwd(const vpx_conv_desc* d, const float* x, const float* w, co
     return ex_forward(d, g, x, w, bias, y, wpk, (hipStream_t)stream_);
 }
 
+int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* y_split,
+                            void* workspace, size_t workspace_bytes, void* stream_) {
+    ExGeo g;
+    int rc = ex_check(d, g);
+    if (rc != VPX_OK) return rc;
+    if (!x || !w || !y_split) { set_error("vpx_conv2d_ex_fwd_split: NULL tensor argument"); return VPX_ERR_ARG; }
+    if (d->Co & 7) { set_error("vpx_conv2d_ex_fwd_split: the split format needs Co to be a multiple of 8 (got %d)", d->Co); return VPX_ERR_UNSUPPORTED; }
+    if (!workspace || workspace_bytes < vpx_conv2d_ex_workspace_bytes(d)) { set_error("vpx_conv2d_ex_fwd_split: workspace too small"); return VPX_ERR_WORKSPACE; }
+    Carver ws{(char*)workspace, 0, workspace_bytes};
+    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    float* wpk = ws.take(ex_wpk_floats(d));
+    return ex_forward(d, g, x, w, bias, y, wpk, (hipStream_t)stream_, reinterpret_cast<char*>(y_split));
+}
+
 }  // extern "C"
 
 namespace {
 
 int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const float* w, const float* bias, float* y, float* wpk,
-               hipStream_t stream) {
+               hipStream_t stream, char* y_split) {
     int rc;
     if (!d->transposed)  // y[o] = sum_k x[o*s - pad + k] w[k]
         return ex_launch(stream, d, x, w, bias, y, g, g.Ho, g.Wo, d->kh, d->kw, d->stride, -d->pad, -d->pad, nullptr, false,
-                         0, 1, 0, 1, 0, wpk);
+                         0, 1, 0, 1, 0, wpk, y_split);
     if (d->stride == 1)  // y[o] = sum_k x[o + pad - k] w[k]  ==  correlation with the flipped kernel, origin -(k-1-pad)
         return ex_launch(stream, d, x, w, bias, y, g, g.Ho, g.Wo, d->kh, d->kw, 1, -(d->kh - 1 - d->pad), -(d->kw - 1 - d->pad),
-                         nullptr, true, 0, 1, 0, 1, 0, wpk);
+                         nullptr, true, 0, 1, 0, 1, 0, wpk, y_split);
     // stride 2: output phase (py, px) is a stride-1 correlation of x with the taps k == (p + pad) mod 2 of that axis
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
@@ -302,7 +317,7 @@ int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const flo
                 for (int tx = 0; tx < ntx; ++tx)
                     tapmap[ty * ntx + tx] = (ky0 + 2 * (nty - 1 - ty)) * d->kw + (kx0 + 2 * (ntx - 1 - tx));
             rc = ex_launch(stream, d, x, w, bias, y, g, Ht, Wt, nty, ntx, 1, basey - (nty - 1), basex - (ntx - 1), tapmap, false,
-                           1, 2, py, 2, px, wpk);
+                           1, 2, py, 2, px, wpk, y_split);
             if (rc != VPX_OK) return rc;
         }
     return VPX_OK;

@@ -253,13 +253,16 @@ struct EpiPlain {
             int ld, cc;
             if (co < a.split) { dst = a.out0; bs = a.bstride0; ld = a.ld0; cc = co; }
             else { dst = a.out1; bs = a.bstride1; ld = a.ld1; cc = co - a.split; }
-            if (!dst) continue;
+            if (!dst && !a.sp_out) continue;
+            // split copy: even lanes carry the hi pair (co, co+1), odd lanes the lo pair (co-1, co): one dword store per lane
+            const int coe = co & ~1;
+            const unsigned sp_off = (unsigned)((coe >> 3) * 32 + (coe & 7) * 2 + ((t.j & 1) ? 16 : 0));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int y, x;
                 if (!tile_pixel(t, r, y, x)) continue;
                 const size_t pix = a.omap ? ((size_t)(y * a.oys + a.oyo) * a.Wmem + (x * a.oxs + a.oxo)) : ((size_t)y * t.W + x);
-                float* p = dst + (size_t)t.b * bs + pix * ld + cc;
+                float* p = dst ? dst + (size_t)t.b * bs + pix * ld + cc : nullptr;
                 float v = acc[g][r] + bv;
                 if (a.ksplit > 1) {  // K split over workgroups: partial sums meet in memory (destination pre-zeroed or +=)
                     unsafeAtomicAdd(p, v);
@@ -267,7 +270,16 @@ struct EpiPlain {
                 }
                 if (a.accumulate) v += *p;   // the activation applies to the completed sum (two convolutions into one output)
                 if (a.leaky != 0.0f) v = v > 0.0f ? v : v * a.leaky;
-                *p = v;
+                if (p) *p = v;
+                if (a.sp_out) {
+                    unsigned short h16, l16;
+                    split_bf16(v, h16, l16);
+                    const unsigned hi = h16, lo = l16;
+                    const unsigned nhi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, true);   // lane j ^ 1
+                    const unsigned nlo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, true);
+                    const unsigned word = (t.j & 1) ? (nlo | (lo << 16)) : (hi | (nhi << 16));
+                    *reinterpret_cast<unsigned*>(a.sp_out + (size_t)t.b * a.sp_bstride + pix * ((size_t)a.Co * 4) + sp_off) = word;
+                }
             }
         }
     }

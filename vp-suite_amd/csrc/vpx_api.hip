@@ -64,6 +64,12 @@ static size_t convlstm_wpk_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayou
                    : packed_weight_bytes(L.n_tiles, L.chunks_total, 4, d->precision, L.qpc);
 }
 
+int vpx_convlstm_takes_split_input(const vpx_convlstm_desc* d) {
+    ConvLSTMLayout L;
+    if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
+    return (L.v2 && d->layout == VPX_LAYOUT_NHWC && !(d->flags & VPX_FLAG_SAVE_FOR_BWD)) ? 1 : 0;
+}
+
 size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
     ConvLSTMLayout L;
     if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
@@ -97,6 +103,11 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     const bool peep = Wci || Wcf || Wco;
     if (peep && !(Wci && Wcf && Wco)) { set_error("vpx_convlstm_seq_fwd: peephole tensors must be given together"); return VPX_ERR_ARG; }
     const bool save = (d->flags & VPX_FLAG_SAVE_FOR_BWD) != 0;
+    const bool x_split = (d->flags & VPX_FLAG_X_SPLIT) != 0;
+    if (x_split && !vpx_convlstm_takes_split_input(d)) {
+        set_error("vpx_convlstm_seq_fwd: VPX_FLAG_X_SPLIT given, but this descriptor's forward takes fp32 input (vpx_convlstm_takes_split_input)");
+        return VPX_ERR_ARG;
+    }
     if (save && (!reserve || reserve_bytes < vpx_convlstm_reserve_bytes(d))) {
         set_error("vpx_convlstm_seq_fwd: reserve too small (%zu < %zu)", reserve_bytes, vpx_convlstm_reserve_bytes(d));
         return VPX_ERR_WORKSPACE;
@@ -172,7 +183,8 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         for (int s = 0; s < (Cin + Ch) / 16; ++s) pk.stage_col[s] = 16 * s;  // x stages first, then h: columns of [x | h] in order
         VPX_CHECK_HIP(launch_cell2_pack(pk, wpk2, stream));
         // operands of the steps in split form: the whole input sequence and the initial hidden state, once
-        if (xn) VPX_CHECK_HIP(launch_split_convert(xn, x_sp, (long long)B * T * (long long)HW, Cin, stream));
+        if (xn && x_split) x_sp = const_cast<char*>(reinterpret_cast<const char*>(xn));   // the producer already wrote operands
+        else if (xn) VPX_CHECK_HIP(launch_split_convert(xn, x_sp, (long long)B * T * (long long)HW, Cin, stream));
         if (h0n) VPX_CHECK_HIP(launch_split_convert(h0n, h0_sp, (long long)B * (long long)HW, Ch, stream));
     } else if (L.split) {  // plain layout: output channel n = reference row n of W (gate-major), s_ng * 32 rows per N tile
         memcpy(pd.stage, L.s_stage, sizeof(ConvStage) * L.s_nstage);

@@ -152,6 +152,8 @@ struct PlainEpiArgs {
     float leaky;              // LeakyReLU negative slope applied after the bias (0 = none; 1 would be identity)
     int omap;                 // 1: tile-space pixel (y,x) is stored at (y*oys + oyo, x*oxs + oxo) of a Wmem-wide image
     int oys, oyo, oxs, oxo, Wmem;
+    char* sp_out;             // optional: the output AGAIN in split-bf16 operand format (cell2.hip; [pixel][Co/8][hi 8 | lo 8]) —
+    long long sp_bstride;     //   BYTES between batch items; out0 may then be null (inference: the fp32 copy is never read)
 };
 hipError_t launch_conv_plain_f32(const ConvPlan& plan, const PlainEpiArgs& ea, int n_tiles, hipStream_t s);
 // N tiling of a plain convolution with Co outputs: ng = 1..4 groups of 32 channels per workgroup, chosen to minimise
@@ -214,7 +216,7 @@ inline int gate_bwd_blocks(int HW, int Ch) { return (HW * Ch + 255) / 256; }
 hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s);
 // out[c] = sum_r m[r][c] (* LeakyReLU'(y[r][c]) when y != null, the scaled matrix optionally stored), bit-reproducible;
 // partial_ws: COLSUM_BLOCKS * cols floats of scratch
-constexpr int COLSUM_BLOCKS = 512;
+constexpr int COLSUM_BLOCKS = 4096;   // level-1 blocks: enough 256-thread blocks in flight to stream a GB-sized dy at HBM speed
 hipError_t launch_colsum(const float* m, const float* y, float slope, float* scaled, float* out, float* partial_ws,
                          long long rows, int cols, hipStream_t s);
 

@@ -59,8 +59,16 @@ class ConvLSTM(VPModelBlock):
                     if prefix + n in unexpected_keys:
                         unexpected_keys.remove(prefix + n)
 
+    def takes_split_input(self, batch, seq_len):
+        """True when forward(), in inference, consumes an `ops.SplitActivation` (the stage glue then writes the block's
+        input directly in the kernels' operand format: no fp32 copy, no conversion pass)."""
+        k = self._conv.kernel_size[0]
+        return (not torch.is_grad_enabled()) and ops.convlstm_takes_split(batch, seq_len, self.in_c, self.enc_c, self.state_h,
+                                                                         self.state_w, k, _lib.GATE_IFGO, self.precision)
+
     def forward(self, inputs, states, seq_len):
-        """inputs [B,T,Cin,H,W] or None (zero input every step); states (h, c) or None (zero states)."""
+        """inputs [B,T,Cin,H,W] (or an ops.SplitActivation of that shape) or None (zero input every step); states (h, c) or
+        None (zero states)."""
         if inputs is None and states is None:
             raise ValueError("inputs and states should not be all none")
         if states is None:

@@ -43,7 +43,7 @@ def _stage(spec: "OrderedDict[str, list]") -> nn.Sequential:
     return nn.Sequential(OrderedDict(layers))
 
 
-def _run_stage(subnet: nn.Sequential, x: torch.Tensor, precision: str) -> torch.Tensor:
+def _run_stage(subnet: nn.Sequential, x: torch.Tensor, precision: str, split_last: bool = False):
     """Executes a stage built by _stage() on a channels-last [N,C,H,W] batch. Conv2d / ConvTranspose2d layers (with a
     directly following LeakyReLU fused in) run through libvpx_hip's vpx_conv2d_ex_fwd when the configuration is one it
     implements; every other layer (pool, ReLU, exotic strides) runs as the stock GPU module."""
@@ -62,6 +62,9 @@ def _run_stage(subnet: nn.Sequential, x: torch.Tensor, precision: str) -> torch.
                 if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
                     slope = float(mods[i + 1].negative_slope)
                     i += 1
+                co = m.out_channels
+                if split_last and i + 1 == len(mods) and co % 8 == 0:   # the stage's output goes straight to a recurrent block
+                    return ops.conv2d_ex_split(x, m.weight, m.bias, m.stride[0], m.padding[0], tr, slope, precision)
                 x = ops.conv2d_ex(x, m.weight, m.bias, m.stride[0], m.padding[0], tr, slope, precision)
                 i += 1
                 continue
@@ -70,11 +73,17 @@ def _run_stage(subnet: nn.Sequential, x: torch.Tensor, precision: str) -> torch.
     return x
 
 
-def _apply_framewise(subnet: nn.Module, seq: torch.Tensor, precision: str = "f32") -> torch.Tensor:
-    """Runs a 2-D stage on every frame of [B,T,C,H,W], channels-last in and out (B*T is folded into the batch)."""
+def _apply_framewise(subnet: nn.Module, seq: torch.Tensor, precision: str = "f32", consumer=None):
+    """Runs a 2-D stage on every frame of [B,T,C,H,W], channels-last in and out (B*T is folded into the batch).
+    `consumer`: the recurrent block the result feeds; when it takes split-format input (inference on the second-generation
+    cell kernel) the stage's last convolution writes that format directly and an ops.SplitActivation is returned."""
     b, t = seq.shape[:2]
     flat = ops.to_channels_last(seq).reshape(b * t, *seq.shape[2:])  # a view: NHWC memory folds B,T for free
-    y = _run_stage(subnet, flat.contiguous(memory_format=torch.channels_last), precision)
+    want_split = consumer is not None and hasattr(consumer, "takes_split_input") and consumer.takes_split_input(b, t)
+    y = _run_stage(subnet, flat.contiguous(memory_format=torch.channels_last), precision, want_split)
+    if isinstance(y, tuple):
+        buf, (n, c, h, w) = y
+        return ops.SplitActivation(buf, (b, t, c, h, w))
     y = y.contiguous(memory_format=torch.channels_last)
     return y.view(b, t, *y.shape[1:])
 
@@ -89,7 +98,7 @@ class Encoder(nn.Module):
             setattr(self, f"rnn{index}", rnn)
 
     def forward_by_stage(self, input, subnet, rnn):
-        input = _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"))
+        input = _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"), consumer=rnn)
         return rnn(input, None, seq_len=input.shape[1])
 
     def forward(self, input):
@@ -109,16 +118,17 @@ class Forecaster(nn.Module):
             setattr(self, f"rnn{self.blocks - index}", rnn)
             setattr(self, f"stage{self.blocks - index}", _stage(params))
 
-    def forward_by_stage(self, input, state, pred_frames, subnet, rnn):
+    def forward_by_stage(self, input, state, pred_frames, subnet, rnn, next_rnn=None):
         input, _ = rnn(input, state, pred_frames)
-        return _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"))
+        return _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"), consumer=next_rnn)
 
     def forward(self, hidden_states, pred_frames):
         # like the reference (ef_blocks.py:109-110) the top block is addressed as stage3/rnn3 and gets no input
-        input = self.forward_by_stage(None, hidden_states[-1], pred_frames, self.stage3, self.rnn3)
+        input = self.forward_by_stage(None, hidden_states[-1], pred_frames, self.stage3, self.rnn3,
+                                      getattr(self, f"rnn{self.blocks - 1}", None) if self.blocks > 1 else None)
         for i in range(self.blocks - 1, 0, -1):
             input = self.forward_by_stage(input, hidden_states[i - 1], pred_frames, getattr(self, f"stage{i}"),
-                                          getattr(self, f"rnn{i}"))
+                                          getattr(self, f"rnn{i}"), getattr(self, f"rnn{i - 1}") if i > 1 else None)
         return input
 
 

@@ -104,13 +104,28 @@ def new_channels_last(shape, device, dtype=torch.float32) -> torch.Tensor:
     return torch.empty(*lead, H, W, C, device=device, dtype=dtype).permute(inv)
 
 
+class SplitActivation:
+    """An activation sequence in the library's split-bf16 operand format (include/vpx.h) — what a stage's last convolution
+    hands to the recurrent block in inference so that no fp32 copy is written and no conversion pass runs. Not a tensor:
+    only `ops.convlstm_seq` consumes it. `shape` is the logical [B, T, C, H, W]."""
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape, self.device = buf, tuple(shape), buf.device
+
+
+def convlstm_takes_split(B, T, Cin, Ch, H, W, k, gate_order, precision):
+    """True when convlstm_seq on this problem (inference) consumes a SplitActivation input."""
+    d = ConvLSTMDesc(B, T, Cin, Ch, H, W, k, k, gate_order, _lib.LAYOUT_NHWC, PRECISIONS[precision], 0)
+    return bool(_lib.lib().vpx_convlstm_takes_split_input(ctypes.byref(d)))
+
+
 class _ConvLSTMSeqFn(torch.autograd.Function):
     """out, hT, cT = ConvLSTM over T steps. Replaces the python time loop of conv_lstm_hzzone.py:52-70 /
     conv_lstm_ndrplz.py:112-121 by ONE library call (T fused conv+gate launches on the current stream)."""
 
     @staticmethod
     def forward(ctx, x, h0, c0, W, b, Wci, Wcf, Wco, seq_len, gate_order, precision, in_channels, need_grad):
-        ref = x if x is not None else h0
+        ref = x.buf if isinstance(x, SplitActivation) else (x if x is not None else h0)
         _require_gpu(ref, "convlstm_seq")
         dev = ref.device
         Ch = W.shape[0] // 4
@@ -118,7 +133,13 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
         Cin = int(in_channels)
         if W.shape[1] != Cin + Ch:
             raise ValueError(f"convlstm_seq: weight has {W.shape[1]} input channels, expected {Cin}+{Ch}")
-        if x is not None:
+        x_split = isinstance(x, SplitActivation)
+        if x_split:
+            B, T, cx, H, Wd = x.shape
+            if cx != Cin or T != seq_len or need_grad:
+                raise ValueError("convlstm_seq: a SplitActivation input must match (Cin, seq_len) exactly and is inference-only")
+            x = x.buf
+        elif x is not None:
             B, T, cx, H, Wd = x.shape
             if cx != Cin or T < seq_len:
                 raise ValueError(f"convlstm_seq: input shape {tuple(x.shape)} does not match Cin={Cin}, T>={seq_len}")
@@ -135,7 +156,7 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
         Wc = W.contiguous()
         bc = None if b is None else b.contiguous()
         d = ConvLSTMDesc(B, T, Cin, Ch, H, Wd, kh, kw, gate_order, _lib.LAYOUT_NHWC, precision,
-                         _lib.FLAG_SAVE_FOR_BWD if need_grad else 0)
+                         (_lib.FLAG_SAVE_FOR_BWD if need_grad else 0) | (_lib.FLAG_X_SPLIT if x_split else 0))
         L = _lib.lib()
         ws_bytes = L.vpx_convlstm_workspace_bytes(ctypes.byref(d))
         rs_bytes = L.vpx_convlstm_reserve_bytes(ctypes.byref(d))
@@ -217,7 +238,12 @@ def convlstm_seq(x, h0, c0, W, b, Wci=None, Wcf=None, Wco=None, *, seq_len, in_c
         raise ValueError("convlstm_seq: inputs and states must not both be None")
     # grad mode is always off INSIDE Function.forward, so decide here whether the forward must fill the reserve
     need_grad = torch.is_grad_enabled() and any(
-        t is not None and t.requires_grad for t in (x, h0, c0, W, b, Wci, Wcf, Wco))
+        isinstance(t, torch.Tensor) and t.requires_grad for t in (x, h0, c0, W, b, Wci, Wcf, Wco))
+    if isinstance(x, SplitActivation):   # autograd.Function.apply only takes tensors: call the forward body directly
+        class _Ctx:   # (inference only: nothing is saved)
+            needs_input_grad = (False,) * 13
+        return _ConvLSTMSeqFn.forward(_Ctx(), x, h0, c0, W, b, Wci, Wcf, Wco, int(seq_len), int(gate_order), PRECISIONS[precision],
+                                      int(in_channels), False)
     if x is not None and x.dim() == 5 and x.shape[1] > seq_len:
         x = x[:, :seq_len]  # sliced here, outside the Function: autograd pads dx back to x's shape
     return _ConvLSTMSeqFn.apply(x, h0, c0, W, b, Wci, Wcf, Wco, int(seq_len), int(gate_order), PRECISIONS[precision],
@@ -349,6 +375,29 @@ class _ConvExFn(torch.autograd.Function):
 def conv2d_ex(x, w, bias, stride, padding, transposed=False, leaky_slope=0.0, precision="f32", output_padding=(0, 0)):
     """Conv2d / ConvTranspose2d (stride 1 or 2; `output_padding` for transposed layers) + bias + LeakyReLU, differentiable."""
     return _ConvExFn.apply(x, w, bias, stride, padding, transposed, leaky_slope, PRECISIONS[precision], tuple(output_padding))
+
+
+def conv2d_ex_split(x, w, bias, stride, padding, transposed=False, leaky_slope=0.0, precision="f32"):
+    """conv2d_ex in inference with the output ONLY in the split-bf16 operand format: returns (buffer, (N, Co, Ho, Wo)).
+    The buffer has the byte size of the fp32 NHWC output it replaces."""
+    _require_gpu(x, "conv2d_ex_split")
+    xs = to_channels_last(x)
+    N, Ci, H, Wd = xs.shape
+    kh, kw = int(w.shape[2]), int(w.shape[3])
+    Co = int(w.shape[1] if transposed else w.shape[0])
+    d = ConvDesc(N, H, Wd, Ci, Co, kh, kw, int(stride), int(padding), int(bool(transposed)), float(leaky_slope),
+                 PRECISIONS[precision], 0, 0)
+    L = _lib.lib()
+    ho, wo = ctypes.c_int(0), ctypes.c_int(0)
+    check(L.vpx_conv2d_ex_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "vpx_conv2d_ex_out_shape")
+    ws_bytes = L.vpx_conv2d_ex_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    buf = torch.empty(N * ho.value * wo.value * Co, dtype=torch.float32, device=x.device)
+    wc = w.contiguous()
+    bc = None if bias is None else bias.contiguous()
+    check(L.vpx_conv2d_ex_fwd_split(ctypes.byref(d), ptr(xs), ptr(wc), ptr(bc), None, ptr(buf), ptr(ws), ws_bytes, _stream()),
+          "vpx_conv2d_ex_fwd_split")
+    return buf, (N, Co, ho.value, wo.value)
 
 
 def conv_transpose2d_to_size(x, w, stride, padding, out_hw, precision="f32"):
