@@ -205,7 +205,9 @@ def roofline(spec, ps):
         "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(ach_tflops / peak, 4), "traffic": measured_traffic(spec),
         "algorithmic_bytes_per_launch": round(ps["bytes"] / launches),
-        "kernel": (f"conv_gemm_kernel<EpiConvLSTM, {spec.precision}> (fused ConvLSTM cell step, forward)"
+        "kernel": ((f"cell2_kernel (second-generation fused ConvLSTM cell step: pre-split bf16x3 operands, LDS-DMA staging; "
+                    f"conv_gemm_kernel<EpiConvLSTM> on 16x16 maps and small grids), forward" if spec.precision == "bf16x3" else
+                    f"conv_gemm_kernel<EpiConvLSTM, {spec.precision}> (fused ConvLSTM cell step, forward)")
                    if spec.model == "convlstm-shi" else
                    f"conv_gemm_kernel<EpiSTGate/EpiSTOut/EpiPlain, {spec.precision}> (ST-LSTM cell step, forward)"),
         "note": ("achieved = algorithmic fp32 FLOPs / kernel time. bf16x3 issues 3 bf16 MFMAs per algorithmic "
@@ -319,6 +321,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = "RANK" in os.environ  # under torch.distributed.run always go through RCCL (also at N=1)
+    os.environ.setdefault("NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout: rank 0 prints exactly one JSON line
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
