@@ -88,7 +88,8 @@ static inline int wgrad_target_wgs() {
 }
 
 // Second-generation fused cell (cell2.hip) applies to: bf16x3, 3x3, channel counts in whole 16-channel stages, maps
-// taller than half a 32x16 tile, and a launch of at least one workgroup per CU. VPX_CELL2=0 disables it, =2 forces it
+// taller than half a 32x16 tile, and a launch of at least 128 workgroups (half the CUs: measured crossover, B=16 +11 %, B=32
+// +3 % against a bar of 256; below, the first-generation kernel's 128-pixel tiles fill more CUs). VPX_CELL2=0 disables it, =2 forces it
 // wherever the shape allows (experiments).
 extern int g_cell2_mode;  // vpx_api.hip: -1 = not yet read from the environment
 static inline int cell2_mode() {
@@ -102,7 +103,9 @@ static inline bool cell2_applicable(const vpx_convlstm_desc* d) {
     if (d->H <= 16) return false;
     if (cell2_mode() == 2) return true;
     const long long wgs = (long long)d->B * ((d->H + 31) / 32) * ((d->W + 15) / 16) * ((d->Ch + 31) / 32);
-    return wgs >= 256;
+    static int min_wgs = -1;   // VPX_CELL2_MIN_WGS: experiment override of the bar below
+    if (min_wgs < 0) { const char* e = getenv("VPX_CELL2_MIN_WGS"); min_wgs = e ? atoi(e) : 128; }
+    return wgs >= min_wgs;
 }
 
 struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
