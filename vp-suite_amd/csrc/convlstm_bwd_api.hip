@@ -153,6 +153,16 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         wa.hseq = outn; wa.h_bstride = (long long)((size_t)T * HW * Ch); wa.h_tstride = (long long)(HW * Ch);
         wa.h0 = h0n;
         wa.n_ctiles = wgrad_make_ctiles(wa.ct, WG_MAX_CTILES, xn ? Cin : 0, Ch, Cin);  // no input tensor: its columns stay zero
+        if (L.v2 && d->layout == VPX_LAYOUT_NHWC) {
+            // the forward ran on the second-generation cell: x, h_0 and h_t sit in the reserve in split operand format
+            const char* r = (const char*)reserve + align256((size_t)T * L.n_state * 4 * sizeof(float)) + align256((size_t)T * L.n_state * sizeof(float));
+            wa.a_split = 1;
+            wa.x_sp = xn ? r : nullptr; wa.x_sp_bstride = (long long)((size_t)T * HW * Cin * 4); wa.x_sp_tstride = (long long)(HW * Cin * 4);
+            r += align256(L.n_x * 4);
+            wa.h0_sp = h0n ? r : nullptr;
+            r += align256(L.n_state * 4);
+            wa.h_sp = r; wa.h_sp_bstride = (long long)(HW * Ch * 4); wa.h_sp_tstride = (long long)(L.n_state * 4);
+        }
         wa.slabs = slabs;
         // every launched tile stores all of its slab elements; only the skipped x columns need a clear
         if (!xn) VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, L.slab_floats * sizeof(float), stream));

@@ -632,7 +632,12 @@ __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmc
 
 // DB = false: ONE item buffer (5x5 / 7x7 halo tiles: two do not fit) — every wave stores item i, multiplies it with the
 // loads of item i+1 in flight, two barriers per item; the tap groups still halve the accumulator registers.
-template <int MAXT, int TH, int APRE, bool DB = true>
+// ASP = true (round 2): the ACTIVATION operand arrives pre-split (x / h_t written in operand format by the cell2 forward):
+// its halo tile is copied HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, six 16-byte pieces per thread and item, the XOR
+// swizzle of the 128-byte rows applied through the choice of source piece) — no split VALU work for it (58 % of an item's
+// conversion work), and the 24 registers that held its prefetched vectors go back to the compiler for fragment read-ahead.
+// dG still comes through registers (fp32 from the gate-backward kernel). DB only.
+template <int MAXT, int TH, int APRE, bool DB = true, bool ASP = false>
 __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, const int tap_base) {
     constexpr int NTH = 512;
     constexpr int TA = (MAXT + 1) / 2, TB = MAXT - TA;  // taps of group 0 / group 1
@@ -735,12 +740,67 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
             const bool ok = gy < a.H && gx < a.W && n_col < a.N4;
             gv[u] = *reinterpret_cast<const f32x4*>(ok ? dg + (gy * a.W + gx) * ldG + n_col : wg_zero16);
         }
+        if constexpr (!ASP) {
 #pragma unroll
-        for (int u = 0; u < APRE; ++u) {
-            const int gy = y0 - ph + (hyx[u] >> 16), gx = x0 - pw + (hyx[u] & 0xffff);
-            long long pix = 0;
-            const bool ok = wg_apix(a, gy, gx, pix) && hyx[u] >= 0 && a_ok;
-            av[u] = *reinterpret_cast<const f32x4*>(ok ? src + (int)pix * C + c_col : wg_zero16);
+            for (int u = 0; u < APRE; ++u) {
+                const int gy = y0 - ph + (hyx[u] >> 16), gx = x0 - pw + (hyx[u] & 0xffff);
+                long long pix = 0;
+                const bool ok = wg_apix(a, gy, gx, pix) && hyx[u] >= 0 && a_ok;
+                av[u] = *reinterpret_cast<const f32x4*>(ok ? src + (int)pix * C + c_col : wg_zero16);
+            }
+        }
+    };
+    // ---- ASP: this thread's six 16-byte pieces of the activation halo image (hi plane then lo plane, 8 pieces per position) ----
+    constexpr int NPIECE = ASP ? 6 : 1;
+    int pc_hyx[NPIECE], pc_off[NPIECE];   // halo position (row << 16 | col, -1 = none) / (half << 16) | byte offset inside the half's pixel row
+    if constexpr (ASP) {
+#pragma unroll
+        for (int u = 0; u < NPIECE; ++u) {
+            const int piece = tid + NTH * u;
+            const int plane = piece >= npos * 8 ? 1 : 0;
+            const int qq = piece - plane * npos * 8;
+            const int pos = qq >> 3;
+            const int logical = wg_aswz(pos * 128 + (qq & 7) * 16);   // the swizzle is an involution: physical slot -> logical offset
+            const int sl = (logical & 127) >> 4;                       // logical 16-byte slot = 8 channels of the 64-channel row
+            const int hy = pos / halo_w;
+            const WgradCHalf hf = (sl >> 2) ? ch1 : ch0;
+            const bool ok = piece < 2 * npos * 8 && (sl & 3) * 8 < hf.cn;
+            pc_hyx[u] = ok ? ((hy << 16) | (pos - hy * halo_w)) : -1;
+            pc_off[u] = ((sl >> 2) << 16) | (((hf.c0 + (sl & 3) * 8) >> 3) * 32 + plane * 16);
+        }
+    }
+    auto dma_A = [&](const Item& it, char* buf) {
+        if constexpr (ASP) {
+            const int y0 = it.ty * TH, x0 = it.tx * TILE_W;
+            // per half: base of this (t, b) image in its split tensor and bytes per pixel row; null = the half stages zeros
+            const char* base[2];
+            int prow_b[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const WgradCHalf hf = h ? ch1 : ch0;
+                base[h] = nullptr; prow_b[h] = 0;
+                if (hf.cn == 0) continue;
+                if (hf.seg == 0) { base[h] = a.x_sp + (size_t)it.b * a.x_sp_bstride + (size_t)it.t * a.x_sp_tstride; prow_b[h] = a.Cin * 4; }
+                else {
+                    prow_b[h] = a.Ch * 4;
+                    if (it.t > 0) base[h] = a.h_sp + (size_t)(it.t - 1) * a.h_sp_tstride + (size_t)it.b * a.h_sp_bstride;
+                    else if (a.h0_sp) base[h] = a.h0_sp + (size_t)it.b * a.HW * a.Ch * 4;
+                }
+            }
+            char* dst = buf + A_HI + (wave * 64) * 16;
+#pragma unroll
+            for (int u = 0; u < NPIECE; ++u) {
+                const int h = pc_off[u] >> 16;
+                const int gy = y0 - ph + (pc_hyx[u] >> 16), gx = x0 - pw + (pc_hyx[u] & 0xffff);
+                const bool ok = pc_hyx[u] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && base[h] != nullptr;
+                const char* src = ok ? base[h] + (size_t)(gy * a.W + gx) * prow_b[h] + (pc_off[u] & 0xffff)
+                                     : reinterpret_cast<const char*>(wg_zero16);
+                if (tid + NTH * u < 2 * npos * 8) {
+                    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(dst + u * NTH * 16);
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                                 :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds)) : "memory", "m0");
+                }
+            }
         }
     };
     auto store_item = [&](char* buf) {
@@ -753,14 +813,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
             *reinterpret_cast<uint2*>(buf + off) = hi;
             *reinterpret_cast<uint2*>(buf + G_LO + off) = lo;
         }
+        if constexpr (!ASP) {
 #pragma unroll
-        for (int u = 0; u < APRE; ++u) {
-            if (hyx[u] >= 0) {
-                uint2 hi, lo;
-                wg_split4(av[u], hi, lo);
-                const int off = wg_aswz((prow + 32 * u) * 128 + q4 * 8);
-                *reinterpret_cast<uint2*>(buf + A_HI + off) = hi;
-                *reinterpret_cast<uint2*>(buf + A_LO + off) = lo;
+            for (int u = 0; u < APRE; ++u) {
+                if (hyx[u] >= 0) {
+                    uint2 hi, lo;
+                    wg_split4(av[u], hi, lo);
+                    const int off = wg_aswz((prow + 32 * u) * 128 + q4 * 8);
+                    *reinterpret_cast<uint2*>(buf + A_HI + off) = hi;
+                    *reinterpret_cast<uint2*>(buf + A_LO + off) = lo;
+                }
             }
         }
     };
@@ -769,7 +831,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
     // (consecutive MFMAs accumulate into different tiles), then group 0's extra tap under a scalar branch. Measured
     // alternatives (64ch 64x64 block, B=128: this 4.32 ms): batches of <= 3 taps without unrolling 4.65; a branch-free block
     // of TA taps with a repeated tap in group 1's spare slot 5.24; the odd tap split over k between the groups 5.66; an
-    // explicit sched_barrier-fenced read-ahead pipeline 5.31 — each loses to spills of the prefetched vectors.
+    // explicit sched_barrier-fenced read-ahead pipeline 5.31 — each loses to spills of the prefetched vectors. With pre-split
+    // activations (ASP) two explicit fragment pipelines (two register sets; a rolling single set) were also tried: the compiler
+    // hoists the swizzled addresses of every unrolled k-step, hits 256 VGPRs and spills (36-208 B/lane) — not kept.
     auto tap_batch = [&](const char* buf, const bf16x8& gh, const bf16x8& gl, int arow, auto t0_c, auto nb_c, auto lo_c) {
         constexpr int T0 = decltype(t0_c)::value, NB = decltype(nb_c)::value;
         constexpr bool LO = decltype(lo_c)::value;
@@ -779,6 +843,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
             const int aoff = wg_aswz(arow + tapoff[T0 + j]);
             ah[j] = wg_tr_frag(buf + A_HI + aoff);
             if constexpr (LO) al[j] = wg_tr_frag(buf + A_LO + aoff);
+        }
+        if constexpr (ASP) {
+            // all fragment reads of the batch ahead of its MFMAs (the freed prefetch registers pay for it): without this the
+            // compiler re-uses one register quad for successive lo-plane fragments and waits for each read right before its MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, (LO ? 4 : 2) * NB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, (LO ? 3 : 1) * NB, 0);
         }
         if constexpr (LO) {
 #pragma unroll
@@ -822,8 +892,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
             advance(nxt);
         }
     }
-    if (DB && cur.t < a.T) { load_item(cur); store_item(smem); }
+    if (DB && cur.t < a.T) { dma_A(cur, smem); load_item(cur); store_item(smem); }
     if (DB && nxt.t < a.T) load_item(nxt);
+    if constexpr (ASP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first item's DMA pieces (unknown to the compiler)
     __syncthreads();
     int bsel = 0;
     while (DB && cur.t < a.T) {
@@ -831,6 +902,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
         char* bnxt = smem + (bsel ^ 1) * BUF;
         Item nn = nxt;
         advance(nn);
+        if constexpr (ASP) {
+            // One straight-line order for every wave (the three-phase loop below makes the compiler keep TWO copies of the
+            // accumulator tiles — 160 registers — and serialise every fragment read behind its MFMA): the other buffer was
+            // multiplied in the previous iteration and every wave has passed that iteration's barrier, so its activation image
+            // is overwritten right away by the copy of item i+1 (a whole item to land), dG(i+1) goes from registers to LDS,
+            // the dG loads of item i+2 fly under the multiply of item i.
+            if (nxt.t < a.T) { dma_A(nxt, bnxt); store_item(bnxt); }
+            if (nn.t < a.T) load_item(nn);
+            multiply_g(bcur);
+            // the copy must have landed; the dG loads issued after it may stay in flight (vmcnt is in order)
+            if (nn.t < a.T) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(GPRE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
         // group 0: multiply, then stage; group 1: stage, then multiply — as ONE copy of each (a three-phase loop the
         // compiler must not unroll)
 #ifdef VPX_ABLATE  // timing-only variants (results are wrong): 1 no multiply, 2 no split+store, 4 no global loads, 8 same order in both groups
@@ -847,6 +931,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
                 if (nxt.t < a.T && do_st) store_item(bnxt);
                 if (nn.t < a.T && do_ld) load_item(nn);
             }
+        }
         }
         wg_lds_barrier();  // (not __syncthreads(): its fence would also wait for the global loads just issued)
         cur = nxt; nxt = nn; bsel ^= 1;
@@ -922,6 +1007,10 @@ static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int ta
                 // overhead 2.5x for 5x5): measured slower than the 128-row form below (PredRNN 5x5 step 332 vs 311 ms)
                 if (a.kh <= 3 && a.kw <= 3) {
                     const size_t l2 = 2 * (size_t)(2 * 128 * 128 + 2 * npos * 128);
+                    static int asp_env = -1;  // VPX_WGRAD_ASP=0: convert the activation operand in the kernel as before (experiments)
+                    if (asp_env < 0) { const char* e = getenv("VPX_WGRAD_ASP"); asp_env = e ? atoi(e) : 1; }
+                    if (a.a_split && asp_env && !a.a_sub && !a.use_org && NTAPS == 9 && npos * 16 <= 6 * 512)
+                        return go(&wgrad_tg_kernel<NTAPS, 8, 6, true, true>, grid, 512, l2);
                     return go(&wgrad_tg_kernel<NTAPS, 8, 6>, grid, 512, l2);
                 }
                 static int tg1_env = -1;  // VPX_WGRAD_TG1=0: larger kernels on the 128-row form below

@@ -56,7 +56,10 @@ size_t vpx_convlstm_reserve_bytes(const vpx_convlstm_desc* d) {
     if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
     if (!(d->flags & VPX_FLAG_SAVE_FOR_BWD)) return 0;
     // gates [T][B,H,W,4Ch] + cell states [T][B,H,W,Ch]
-    return align256((size_t)d->T * L.n_state * 4 * sizeof(float)) + align256((size_t)d->T * L.n_state * sizeof(float));
+    size_t b = align256((size_t)d->T * L.n_state * 4 * sizeof(float)) + align256((size_t)d->T * L.n_state * sizeof(float));
+    // second-generation cell: the operands in split format stay for the weight gradient (x all frames, h_0, h_1 .. h_T)
+    if (L.v2) b += align256(L.n_x * 4) + align256(L.n_state * 4) + align256((size_t)d->T * L.n_state * 4);
+    return b;
 }
 
 static size_t convlstm_wpk_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
@@ -130,13 +133,19 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         wpk_hx = ws.take(packed_weight_bytes(L.s_tiles, L.hx_chunks, L.s_ng, d->precision) / sizeof(float));
         wpk_hh = ws.take(packed_weight_bytes(L.s_tiles, L.hh_chunks, L.s_ng, d->precision) / sizeof(float));
     }
-    char *wpk2 = nullptr, *x_sp = nullptr, *h0_sp = nullptr, *h_ring[2] = {nullptr, nullptr};
+    char *wpk2 = nullptr, *x_sp = nullptr, *h0_sp = nullptr, *h_ring[2] = {nullptr, nullptr}, *h_sp_all = nullptr;
     if (L.v2) {
         wpk2 = (char*)ws.take(cell2_packed_bytes(L.n_tiles, 3 * ((Cin + Ch) / 16)) / sizeof(float));
         x_sp = (char*)ws.take(L.n_x);
         h0_sp = (char*)ws.take(L.n_state);
         h_ring[0] = (char*)ws.take(L.n_state);
         h_ring[1] = (char*)ws.take(L.n_state);
+        if (save) {  // keep the split operands for the backward's weight gradient: they live in the reserve instead
+            char* r = (char*)reserve + align256((size_t)T * L.n_state * 4 * sizeof(float)) + align256((size_t)T * L.n_state * sizeof(float));
+            x_sp = r; r += align256(L.n_x * 4);
+            h0_sp = r; r += align256(L.n_state * 4);
+            h_sp_all = r;
+        }
     }
 
     // ---- layout adaptation (reference NCHW -> native NHWC) ----
@@ -283,14 +292,15 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             P2.B = B; P2.H = H; P2.W = Wd; P2.tiles_x = (Wd + 15) / 16; P2.tiles_y = (H + 31) / 32; P2.n_tiles = L.n_tiles;
             P2.chunks_total = 3 * ((Cin + Ch) / 16);
             P2.wpk = wpk2;
-            const char* hprev_sp = (t == 0) ? (h0n ? h0_sp : nullptr) : h_ring[(t - 1) & 1];
+            auto h_slot = [&](int tt) { return h_sp_all ? h_sp_all + (size_t)tt * L.n_state * 4 : h_ring[tt & 1]; };
+            const char* hprev_sp = (t == 0) ? (h0n ? h0_sp : nullptr) : h_slot(t - 1);
             P2.seg[0] = Cell2Seg{xn ? x_sp + (size_t)t * HW * Cin * 4 : nullptr, (long long)((size_t)T * HW * Cin * 4), Cin, 0};
             P2.seg[1] = Cell2Seg{hprev_sp, (long long)(HW * Ch * 4), Ch, 0};
             P2.nx = xn ? Cin / 16 : 0;
             P2.nh = hprev_sp ? Ch / 16 : 0;
             P2.hs_off = Cin / 16;
             // the split copy of h_t feeds step t+1 only: the last step does not need it
-            VPX_CHECK_HIP(launch_cell2(P2, ea, (t + 1 < T) ? h_ring[t & 1] : nullptr, (long long)(HW * Ch * 4), stream));
+            VPX_CHECK_HIP(launch_cell2(P2, ea, (t + 1 < T) ? h_slot(t) : nullptr, (long long)(HW * Ch * 4), stream));
         } else if (hoist) {
             // the step contracts only h_{t-1} and accumulates (atomics when K is split) into its slice of the hoisted input
             // projection; the pointwise kernel reads that slice (batch stride T*HW*4Ch) and writes gates / c / h

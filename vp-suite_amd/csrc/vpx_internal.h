@@ -261,6 +261,12 @@ struct WgradArgs {
     int a_Wfull;              // pixels per row of the full image (the batch stride is x_bstride)
     int use_org, org_y, org_x;  // tap (0,0) reads activation pixel (y + org_y, x + org_x) instead of (y - kh/2, x - kw/2)
     int dbg;                    // timing ablations, -DVPX_ABLATE builds only (VPX_WG_DBG: 1 = no multiply, 2 = stage the first item only)
+    // activation operand pre-split (ConvLSTM block after a cell2 forward): x, h_{t-1} and h_0 again in the split-bf16 operand
+    // format (cell2.hip); the tap-group kernel then stages the halo tile by LDS-DMA instead of load + split + store
+    int a_split;
+    const char* x_sp; long long x_sp_bstride, x_sp_tstride;    // BYTES
+    const char* h_sp; long long h_sp_bstride, h_sp_tstride;    // h_t of step t at h_sp + t * tstride (time-major slots), BYTES
+    const char* h0_sp;                                         // [B][HW][Ch] or null
     int vec_all;                // set by launch_wgrad: every operand allows 16-byte vector loads (bf16 forms: unconditional load issue)
     int grid_x, grid_slices;    // set by launch_wgrad: logical grid (row tile x column tile, K slice) behind the XCD-aware 1-D launch
 };
