@@ -308,6 +308,88 @@ struct Cell2Epi {
             }
         }
     }
+
+    __device__ __forceinline__ void finish(const f32x16 (&acc)[2][4], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
+                                           int /*ngr*/, int H, int W) const {
+        const int j = lane & 31, hh = lane >> 5;
+        const bool full = y0 + 32 <= H && x0 + 16 <= W;
+        const bool vec = full && n_tile * 32 + 32 <= a.Ch && (a.Ch & 3) == 0;
+        if (vec) c2_barrier();   // every wave has read its last fragments: the staging buffers become the epilogue's transposition space
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (vec) run_vec(acc[m], smem + wave * 16384, b, y0, x0, n_tile, 4 * wave + 2 * m, lane, H, W);
+            else if (full) run<true>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, H, W);
+            else run<false>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, H, W);
+        }
+    }
+};
+
+// Plain epilogue of the same main loop ("conv2"): y = conv(src) (+ bias), output channel c of tile n_tile, group g, column j =
+// (n_tile * gpt + g) * 32 + j; channels [0, split) go to out0, [split, Co) to out1 (either may be null = dropped). The
+// accumulators take the same round trip through the wave's 16 KiB of LDS as Cell2Epi::run_vec, so a lane owns four
+// consecutive channels of a pixel and stores 16 bytes. First user: the ConvLSTM data gradient (dG -> dx_t | dh_{t-1}).
+struct Conv2Epi {
+    const float* bias;
+    int Co, split, gpt, accumulate;
+    float* out0; long long bstride0; int ld0, _p0;
+    float* out1; long long bstride1; int ld1, _p1;
+
+    __device__ __forceinline__ void finish(const f32x16 (&acc)[2][4], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
+                                           int ngr, int H, int W) const {
+        c2_barrier();
+        float* ldsf = reinterpret_cast<float*>(smem + wave * 16384);
+        const int j = lane & 31, hh = lane >> 5, cg = lane & 7, p4 = lane >> 3;
+        const bool v4 = ((Co | split | ld0 | ld1) & 3) == 0;
+        float* const o0 = out0 ? out0 + (size_t)b * bstride0 : nullptr;
+        float* const o1 = out1 ? out1 + (size_t)b * bstride1 : nullptr;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int prow = 4 * wave + 2 * m;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (g < ngr)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ldsf[g * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + j] = acc[m][g][r];
+            // (LDS operations of one wave execute in order: no barrier between these writes and the reads below)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g >= ngr) continue;
+                const int c = (n_tile * gpt + g) * 32 + cg * 4;
+                if (c >= Co) continue;
+                const bool first = c < split;
+                float* const ob = first ? o0 : o1;
+                const unsigned ld = (unsigned)(first ? ld0 : ld1);
+                const int cc = first ? c : c - split;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ip = k * 8 + p4;
+                    const int y = y0 + prow + (ip >> 4), x = x0 + c2_px(ip);
+                    f32x4 v = *reinterpret_cast<const f32x4*>(ldsf + g * 1024 + ip * 32 + cg * 4);
+                    if (y >= H || x >= W) continue;
+                    const size_t e = (size_t)__umul24((unsigned)(y * W + x), ld) + cc;
+                    if (v4) {
+                        if (!ob) continue;
+                        if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
+                        if (accumulate) v += *reinterpret_cast<const f32x4*>(ob + e);
+                        *reinterpret_cast<f32x4*>(ob + e) = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int cq = c + q;
+                            if (cq >= Co) continue;
+                            const bool f1 = cq < split;
+                            float* const oq = f1 ? o0 : o1;
+                            if (!oq) continue;
+                            const size_t eq = (size_t)__umul24((unsigned)(y * W + x), (unsigned)(f1 ? ld0 : ld1)) + (f1 ? cq : cq - split);
+                            float val = v[q] + (bias ? bias[cq] : 0.f);
+                            if (accumulate) val += oq[eq];
+                            oq[eq] = val;
+                        }
+                    }
+                }
+            }
+        }
+    }
 };
 
 #ifdef VPX_ABLATE
@@ -326,7 +408,11 @@ struct C2Frags {
     bf16x8 bh[2], bl[2];
 };
 
-__global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const Cell2Epi epi) {
+// Epi = Cell2Epi (the fused ConvLSTM step; every N tile holds four gate groups) or Conv2Epi (a plain convolution over the
+// same main loop: the N tile's four 32-column groups are 128 consecutive output channels, of which the last tile may
+// use fewer — ALLG = false skips the MFMAs of the unused groups under a wave-uniform branch).
+template <class Epi, bool ALLG>
+__global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -345,6 +431,8 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
     const int ty = mt % P.tiles_y;
     const int b = mt / P.tiles_y;
     const int x0 = tx * 16, y0 = ty * 32;
+    int ngr = 4;   // 32-column groups of this N tile that hold outputs
+    if constexpr (!ALLG) { ngr = P.n_groups - n_tile * P.gpt; if (ngr > P.gpt) ngr = P.gpt; }
 
     char* const Abuf = smem;
     char* const Wbuf = smem + 2 * C2_ABUF;
@@ -473,6 +561,7 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
                 }
                 // ---- 6 MFMAs of gate group (dx, g) ----
                 __builtin_amdgcn_s_setprio(1);
+                if (ALLG || g < ngr)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     f32x16 c = acc[m][g];
@@ -503,22 +592,15 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
         }
     }
     C2_STAMP(40);
-    const bool full = y0 + 32 <= P.H && x0 + 16 <= P.W;
-    const bool vec = full && n_tile * 32 + 32 <= epi.a.Ch && (epi.a.Ch & 3) == 0;
-    if (vec) c2_barrier();   // every wave has read its last fragments: the staging buffers become the epilogue's transposition space
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        if (vec) epi.run_vec(acc[m], smem + wave * 16384, b, y0, x0, n_tile, 4 * wave + 2 * m, lane, P.H, P.W);
-        else if (full) epi.run<true>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, P.H, P.W);
-        else epi.run<false>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, P.H, P.W);
-        C2_STAMP(41 + m);
-    }
+    epi.finish(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+    C2_STAMP(42);
 }
 
-hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s) {
+template <class Epi, bool ALLG>
+static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel<Epi, ALLG>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -528,9 +610,64 @@ hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void*
     { const char* e = getenv("VPX_C2_STAMP_BLOCK"); p._p = e ? atoi(e) : -1; }
 #endif
     const long long per_xcd = ((long long)p.grid_m * p.n_tiles + 7) / 8;
-    Cell2Epi epi{ea, reinterpret_cast<char*>(h_sp), h_sp_bstride};
-    hipLaunchKernelGGL(cell2_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), C2_LDS, s, p, epi);
+    hipLaunchKernelGGL((cell2_kernel<Epi, ALLG>), dim3((unsigned)(per_xcd * 8)), dim3(512), C2_LDS, s, p, epi);
     return hipGetLastError();
+}
+
+hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s) {
+    Cell2Epi epi{ea, reinterpret_cast<char*>(h_sp), h_sp_bstride};
+    return launch_cell2_t<Cell2Epi, true>(plan, epi, s);
+}
+
+// ---- conv2: plain 3x3 'same' convolution of ONE split-format source (K = C channels in 16-channel stages) ----
+// weight repack: element (out channel oc, in channel ic, tap) of the source tensor at w[ic * s_ic + (col0 + oc) * s_oc + tap],
+// tap flipped for a data gradient -> the chunk layout of cell2_pack_kernel with n = g * 32 + j <-> oc = (n_tile * gpt + g) * 32 + j
+__global__ void conv2_pack_kernel(const Conv2Pack pk, char* __restrict__ dst) {
+    const long long total = (long long)pk.n_tiles * pk.chunks_total * (C2_WCHUNK / 2);  // bf16 elements
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e & 7);
+        long long r = e >> 3;
+        const int n = (int)(r & 127); r >>= 7;
+        const int khalf = (int)(r & 1); r >>= 1;
+        const int part = (int)(r & 1); r >>= 1;
+        const int q = (int)(r % 3); r /= 3;
+        const int chunk = (int)(r % pk.chunks_total);
+        const int n_tile = (int)(r / pk.chunks_total);
+        const int stage = chunk / 3, dy = chunk - stage * 3;
+        const int g = n >> 5, j = n & 31;
+        const int oc = (n_tile * pk.gpt + g) * 32 + j;
+        float v = 0.0f;
+        if (g < pk.gpt && oc < pk.Co) {
+            const int ic = stage * 16 + khalf * 8 + i;
+            const int tap = pk.flip ? (2 - dy) * 3 + (2 - q) : dy * 3 + q;
+            v = pk.w[(long long)ic * pk.s_ic + (long long)(pk.col0 + oc) * pk.s_oc + tap];
+        }
+        unsigned hi, lo;
+        c2_split(v, hi, lo);
+        reinterpret_cast<unsigned short*>(dst)[e] = (unsigned short)(part ? lo : hi);
+    }
+}
+
+hipError_t launch_conv2_pack(const Conv2Pack& pk, void* dst, hipStream_t s) {
+    const long long total = (long long)pk.n_tiles * pk.chunks_total * (C2_WCHUNK / 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv2_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
+    return hipGetLastError();
+}
+
+hipError_t launch_conv2(const Conv2Args& c, hipStream_t s) {
+    Cell2Plan P{};
+    P.B = c.B; P.H = c.H; P.W = c.W;
+    P.tiles_x = (c.W + 15) / 16; P.tiles_y = (c.H + 31) / 32;
+    P.n_groups = (c.Co + 31) / 32;
+    P.n_tiles = conv2_tiles(c.Co); P.gpt = conv2_gpt(c.Co);
+    P.nx = c.C / 16; P.nh = 0; P.hs_off = 0; P.chunks_total = 3 * P.nx;
+    P.seg[0] = Cell2Seg{c.src_sp, c.src_bstride, c.C, 0};
+    P.seg[1] = Cell2Seg{c.src_sp, 0, c.C, 0};
+    P.wpk = c.wpk;
+    Conv2Epi epi{c.bias, c.Co, c.split, P.gpt, c.accumulate, c.out0, c.bstride0, c.ld0, 0, c.out1, c.bstride1, c.ld1, 0};
+    return launch_cell2_t<Conv2Epi, false>(P, epi, s);
 }
 
 }  // namespace vpx

@@ -42,6 +42,16 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     const int gb_blocks = gate_bwd_blocks((int)HW, Ch);
     float* db_part = ws.take((size_t)T * gb_blocks * N4);
     float* db_part2 = ws.take((size_t)COLSUM_BLOCKS * N4);
+    // forward on the second-generation cell: the gate-backward kernel also writes dG in split operand format and the data
+    // gradient runs on the cell2 main loop with a plain epilogue (conv2); VPX_CONV2_DGRAD=0 keeps the first-generation kernel
+    static int c2d_env = -1;
+    if (c2d_env < 0) { const char* e = getenv("VPX_CONV2_DGRAD"); c2d_env = e ? atoi(e) : 1; }
+    const bool c2d = L.v2 && c2d_env != 0;
+    char* dG_sp_all = nullptr; char* wpk2 = nullptr;
+    if (L.v2) {
+        dG_sp_all = (char*)ws.take((size_t)T * L.n_state * 4);
+        wpk2 = (char*)ws.take(cell2_packed_bytes(conv2_tiles(Ct), 3 * (N4 / 16)) / sizeof(float));
+    }
 
     // ---- layout adaptation ----
     const float *xn = x, *h0n = h0, *c0n = c0, *outn = out, *doutn = dout, *dhTn = dhT, *dcTn = dcT;
@@ -91,7 +101,10 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     const int col_start = need_dx ? 0 : Cin;
     const int n_out = need_dx ? Ct : Ch;
     const int d_tiles = plain_tiles(n_out);
-    {
+    if (c2d) {
+        Conv2Pack pk{W, (long long)L.taps, (long long)Ct * L.taps, n_out, col_start, conv2_tiles(n_out), conv2_gpt(n_out), 3 * (N4 / 16), 1};
+        VPX_CHECK_HIP(launch_conv2_pack(pk, wpk2, stream));
+    } else {
         PackDesc pd{};
         pd.seg[0] = PackSeg{W, (long long)Ct * L.taps, L.taps, 0, N4};
         memcpy(pd.stage, L.d_stage, sizeof(ConvStage) * L.d_nstage);
@@ -116,11 +129,21 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         ga.wci = wci; ga.wcf = wcf; ga.wco = wco;
         ga.dwci = dpeep ? dwci : nullptr; ga.dwcf = dpeep ? dwcf : nullptr; ga.dwco = dpeep ? dwco : nullptr;
         ga.dG = dG_all + (size_t)t * L.n_state * 4;
+        ga.dG_sp = c2d ? dG_sp_all + (size_t)t * L.n_state * 16 : nullptr;
         ga.db_partial = db ? db_part + (size_t)t * gb_blocks * N4 : nullptr;
         VPX_CHECK_HIP(launch_gate_bwd(ga, stream));
 
         float* dh_target = (t > 0) ? dh_buf : dh0n;  // at t = 0 the recurrent gradient is dL/dh0 (if requested)
-        if (need_dx || dh_target) {
+        if ((need_dx || dh_target) && c2d) {
+            Conv2Args ca{};
+            ca.B = B; ca.H = H; ca.W = Wd; ca.C = N4; ca.Co = n_out; ca.split = need_dx ? Cin : 0;
+            ca.src_sp = ga.dG_sp; ca.src_bstride = (long long)(HW * N4 * 4);
+            ca.wpk = wpk2;
+            ca.out0 = need_dx ? dxn + (size_t)t * HW * Cin : nullptr;
+            ca.bstride0 = (long long)((size_t)T * HW * Cin); ca.ld0 = Cin;
+            ca.out1 = dh_target; ca.bstride1 = (long long)(HW * Ch); ca.ld1 = Ch;
+            VPX_CHECK_HIP(launch_conv2(ca, stream));
+        } else if (need_dx || dh_target) {
             ConvPlan P{};
             P.B = B; P.H = H; P.W = Wd; P.kh = d->kh; P.kw = d->kw;
             set_plan_tiles(P, L.d_mw);
@@ -166,8 +189,11 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         wa.slabs = slabs;
         // every launched tile stores all of its slab elements; only the skipped x columns need a clear
         if (!xn) VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, L.slab_floats * sizeof(float), stream));
-        VPX_CHECK_HIP(launch_wgrad(wa, L.n_slices, stream));
-        VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dW, L.n_slices, L.taps, N4, Ct, stream));
+        wa.g_sp = c2d ? dG_sp_all : nullptr;
+        int ns_used = L.n_slices;
+        if (wgrad2_applicable(wa)) VPX_CHECK_HIP(launch_wgrad2(wa, L.n_slices, &ns_used, stream));
+        else VPX_CHECK_HIP(launch_wgrad(wa, L.n_slices, stream));
+        VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dW, ns_used, L.taps, N4, Ct, stream));
     }
     if (db)  // block partials from the gate-backward kernel, summed in a fixed order
         VPX_CHECK_HIP(launch_colsum(db_part, nullptr, 0.f, nullptr, db, db_part2, (long long)T * gb_blocks, N4, stream));

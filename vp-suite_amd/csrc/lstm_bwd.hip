@@ -16,6 +16,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short gb_bf16_bits(float v) {   // round to nearest even, the split of conv_gemm.hip / cell2.hip
+    __bf16 h = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, h);
+}
+
 __global__ __launch_bounds__(256) void convlstm_gate_bwd_kernel(const GateBwdArgs a) {
     __shared__ float db_vals[4][256];  // per-thread bias-gradient sums of this block (only when a.db_partial)
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -47,11 +52,31 @@ __global__ __launch_bounds__(256) void convlstm_gate_bwd_kernel(const GateBwdArg
         float dcp = dcn * f_;
         if (peep) { dcp += dai * wci + daf * wcf; dpi += dai * cp; dpf += daf * cp; }
         a.dc_out[s] = dcp;
-        float* dg = a.dG + ((size_t)b * HW + pix) * 4 * Ch + ch;
-        dg[a.gate_pos[0] * Ch] = dai;
-        dg[a.gate_pos[1] * Ch] = daf;
-        dg[a.gate_pos[2] * Ch] = dag;
-        dg[a.gate_pos[3] * Ch] = dao;
+        if (a.dG) {
+            float* dg = a.dG + ((size_t)b * HW + pix) * 4 * Ch + ch;
+            dg[a.gate_pos[0] * Ch] = dai;
+            dg[a.gate_pos[1] * Ch] = daf;
+            dg[a.gate_pos[2] * Ch] = dag;
+            dg[a.gate_pos[3] * Ch] = dao;
+        }
+        if (a.dG_sp) {
+            // operand format of the data- and weight-gradient kernels: [pixel][4Ch / 8][8 hi bf16 | 8 lo bf16]. Lanes 2k, 2k+1 hold
+            // channels ch, ch+1 (Ch even): the even lane stores the hi pair, the odd lane the lo pair — 4-byte stores, and a
+            // wave's stores of one gate cover a contiguous run of the pixel row
+            char* const row = a.dG_sp + ((size_t)b * HW + pix) * 16 * Ch;
+            const float dv[4] = {dai, daf, dag, dao};
+            const int che = ch & ~1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned short h = gb_bf16_bits(dv[g]);
+                const unsigned hi = h, lo = gb_bf16_bits(dv[g] - __builtin_bit_cast(float, (unsigned)h << 16));
+                const unsigned nhi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                const unsigned nlo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, true);
+                const unsigned n = (unsigned)(a.gate_pos[g] * Ch + che);
+                const unsigned off = (n >> 3) * 32 + (n & 7) * 2 + ((ch & 1) ? 16 : 0);
+                *reinterpret_cast<unsigned*>(row + off) = (ch & 1) ? (nlo | (lo << 16)) : (hi | (nhi << 16));
+            }
+        }
         sb0 += dai; sb1 += daf; sb2 += dag; sb3 += dao;
     }
     if (peep && a.dwci) {  // single owner per (pix, ch): plain accumulate over the time steps

@@ -94,7 +94,7 @@ int run_wgrad(const vpx_stlstm_desc* d, const STBwdLayout& L, const float* dG, i
     const int taps = k * k;
     // K slices: enough for ~1024 workgroups, no more (every slice costs a slab write + a reduce read of the whole dW)
     const int out_tiles = ((N + 63) / 64) * wa.n_ctiles * ((taps + 8) / 9);
-    int ns = (wgrad_target_wgs() + out_tiles - 1) / out_tiles;
+    int ns = wgrad_target_wgs() / out_tiles;   // rounded down: whole rounds of workgroups (see convlstm_layout)
     if (ns > L.n_slices) ns = L.n_slices;
     if (ns < 1) ns = 1;
     // (no slab clear: every workgroup of every slice stores its full tile, so each slab element is written once)

@@ -193,7 +193,9 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
         const int tiles = ((d->W + TILE_W - 1) / TILE_W) * ((d->H + TILE_H - 1) / TILE_H);
         const long long items = (long long)d->T * d->B * tiles;
         const int out_tiles = ((N4 + 63) / 64) * L.n_ctiles * ((L.taps + 8) / 9);
-        long long ns = (wgrad_target_wgs() + out_tiles - 1) / out_tiles;
+        // rounded DOWN: the launch runs one workgroup per CU in rounds of 256, and 1032 workgroups (86 slices x 12 tiles) took
+        // five rounds where 1008 take four (measured: training step 144.8 -> 140.2 ms)
+        long long ns = wgrad_target_wgs() / out_tiles;
         if (ns > items) ns = items;
         if (ns > 256) ns = 256;
         if (ns < 1) ns = 1;
@@ -211,6 +213,8 @@ static inline size_t convlstm_bwd_workspace_bytes(const vpx_convlstm_desc* d, co
     b += align256(L.slab_floats * sizeof(float));
     b += align256((size_t)d->T * gate_bwd_blocks(d->H * d->W, d->Ch) * 4 * d->Ch * sizeof(float));  // bias-gradient partials
     b += align256((size_t)COLSUM_BLOCKS * 4 * d->Ch * sizeof(float));                                // ... and their second level
+    if (L.v2)  // dG of all steps in split operand format + the conv2 weight pack of the data gradient
+        b += align256((size_t)d->T * L.n_state * 16) + align256(cell2_packed_bytes(conv2_tiles(d->Cin + d->Ch), 3 * (4 * d->Ch / 16)));
     if (d->layout == VPX_LAYOUT_NCHW) {
         // staged copies of x, out, dout, dx + states (h0,c0,dhT,dcT,dh0,dc0) + 6 peephole-sized buffers
         b += 2 * align256(L.n_x * 4) + 2 * align256(L.n_out * 4) + 6 * align256(L.n_state * 4) + 6 * align256(L.n_peep * 4);
@@ -285,7 +289,7 @@ static inline int wgrad_slices(int N, int H, int W) {
 // slices actually launched: enough for ~1024 workgroups (each slice costs a slab write + a reduce read of all of dW)
 static inline int wgrad_pick_slices(int cap, int rows, int n_ctiles, int taps) {
     const int out_tiles = ((rows + 63) / 64) * n_ctiles * ((taps + 8) / 9);
-    int ns = (wgrad_target_wgs() + out_tiles - 1) / out_tiles;
+    int ns = wgrad_target_wgs() / out_tiles;   // rounded down: whole rounds of 256 workgroups (see convlstm_layout)
     if (ns > cap) ns = cap;
     return ns < 1 ? 1 : ns;
 }

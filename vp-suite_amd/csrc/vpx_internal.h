@@ -122,6 +122,7 @@ struct Cell2Seg { const char* sp; long long bstride; int C; int _pad; };   // sp
 // arithmetic on these fields (a table walk cost an s_load + s_waitcnt lgkmcnt(0) per copy inside the MFMA loop).
 struct Cell2Plan {
     int B, H, W, tiles_x, tiles_y, n_tiles, nx, nh, hs_off, chunks_total, grid_m, _p;
+    int n_groups, gpt;        // conv2 only: 32-column output groups in total / per N tile (the last tile may hold fewer)
     Cell2Seg seg[2];
     const char* wpk;          // [n_tiles][chunks_total][24576 B]
 };
@@ -135,6 +136,23 @@ hipError_t launch_split_convert(const float* src, void* dst, long long npix, int
 hipError_t launch_cell2_pack(const Cell2Pack& pk, void* dst, hipStream_t s);
 size_t cell2_packed_bytes(int n_tiles, int chunks_total);
 hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s);
+// conv2: the same kernel with a plain epilogue — 3x3 'same' convolution of one split-format source with C channels (C % 16 == 0)
+// into Co fp32 NHWC output channels, [0, split) -> out0, [split, Co) -> out1. N tiling: 128-column tiles, balanced.
+static inline int conv2_tiles(int Co) { return ((Co + 31) / 32 + 3) / 4; }
+static inline int conv2_gpt(int Co) { const int g = (Co + 31) / 32, t = (g + 3) / 4; return (g + t - 1) / t; }
+struct Conv2Pack {
+    const float* w; long long s_oc, s_ic;   // element strides of the output / input channel (the tap index is contiguous)
+    int Co, col0, n_tiles, gpt, chunks_total, flip;
+};
+struct Conv2Args {
+    int B, H, W, C, Co, split, accumulate, _p;
+    const char* src_sp; long long src_bstride;   // split source [B][HW][C], BYTES between batch items
+    const char* wpk; const float* bias;
+    float* out0; long long bstride0; int ld0, _p0;
+    float* out1; long long bstride1; int ld1, _p1;
+};
+hipError_t launch_conv2_pack(const Conv2Pack& pk, void* dst, hipStream_t s);
+hipError_t launch_conv2(const Conv2Args& c, hipStream_t s);
 
 // pointwise half of the K-split step: pre-activations pre [B*HW, 4Ch] (reference gate order) -> gates, c, h (pointwise.hip)
 hipError_t launch_convlstm_pointwise(const ConvLSTMStepArgs& ea, const float* pre, int B, long long HW, hipStream_t s,
@@ -209,7 +227,8 @@ struct GateBwdArgs {
     float* dc_out;            // dc flowing out to step t-1
     const float* wci; const float* wcf; const float* wco;  // peepholes [HW,Ch] or null
     float* dwci; float* dwcf; float* dwco;                  // accumulated (+=) over steps, or null
-    float* dG;                // [B,HW,4Ch] d(pre-activation), reference gate order
+    float* dG;                // [B,HW,4Ch] d(pre-activation), reference gate order (or null when only dG_sp is wanted)
+    char* dG_sp;              // the same tensor in split-bf16 operand format (cell2.hip), or null; needs an even Ch
     float* db_partial;        // [gridDim.x][4Ch] per-block column sums of dG (bias gradient partials), or null
 };
 inline int gate_bwd_blocks(int HW, int Ch) { return (HW * Ch + 255) / 256; }
@@ -267,11 +286,15 @@ struct WgradArgs {
     const char* x_sp; long long x_sp_bstride, x_sp_tstride;    // BYTES
     const char* h_sp; long long h_sp_bstride, h_sp_tstride;    // h_t of step t at h_sp + t * tstride (time-major slots), BYTES
     const char* h0_sp;                                         // [B][HW][Ch] or null
+    const char* g_sp;           // dG again in split format [T][B][HW][N4] (gate-backward kernel), or null: with a_split, selects wgrad2.hip
     int vec_all;                // set by launch_wgrad: every operand allows 16-byte vector loads (bf16 forms: unconditional load issue)
     int grid_x, grid_slices;    // set by launch_wgrad: logical grid (row tile x column tile, K slice) behind the XCD-aware 1-D launch
 };
 hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s);
+// wgrad2.hip: both operands pre-split (3x3, bf16x3); writes slabs [used_slices][9][N4][Ct] like launch_wgrad
+bool wgrad2_applicable(const WgradArgs& a);
+hipError_t launch_wgrad2(const WgradArgs& a, int max_slices, int* used_slices, hipStream_t s);
 // same, but launch tap t lands at tap index tapmap[t] of a dW with real_taps taps per (row, channel); tapmap[t] < 0: dropped
 hipError_t launch_wgrad_reduce_map(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int real_taps,
                                    const int* tapmap, hipStream_t s);

@@ -1,0 +1,296 @@
+// wgrad2.hip — weight gradient of the ConvLSTM block with BOTH operands pre-split (round 2): dW[n][c][tap] =
+// sum over (t, b, pixel) of dG[t,b,pixel][n] * [x_t | h_{t-1}][pixel + tap][c]  (autograd of conv_lstm_hzzone.py:59-61).
+// Same contraction, operand split and slab / K-slice scheme as wgrad_tg_kernel (lstm_bwd.hip); what changed and why:
+//   * dG arrives in split operand format from the gate-backward kernel, the activations from the cell2 forward: every
+//     operand byte goes HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4). No split VALU work, no staging registers.
+//   * a wave owns 64 gate rows x 32 channels x its tap group (wgrad_tg: 32 x 32): the activation fragments of a tap are
+//     read once for two row blocks, 14 fragment reads per 30 MFMAs instead of 12 per 15. The tap-group kernel kept the
+//     LDS read pipe ~80 % busy at full matrix rate (PMC: MFMA busy 36 %); here it is 47 %.
+//   * workgroup tile 128 rows x 64 channels x 9 taps, items of 4 x 16 pixels (two item buffers of 59 KiB), one barrier per item.
+// LDS image of an item: dG planes [row half wn][hi | lo][64 px][64 rows] (128-byte pixel rows, wg_aswz swizzle), then the
+// activation halo planes [hi | lo][6 x 18 positions][64 channels]. Fragments are transposing reads (ds_read_b64_tr_b16).
+#include <stdlib.h>
+
+#include "vpx_internal.h"
+
+namespace vpx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int W2_TH = 4;                          // tile rows per item
+constexpr int W2_NPX = W2_TH * 16;                // 64 pixels = 4 k-steps of 16
+constexpr int W2_HALO_W = 18;
+constexpr int W2_NPOS = (W2_TH + 2) * W2_HALO_W;  // 108 halo positions
+constexpr int W2_GPL = W2_NPX * 128;              // one dG plane: 8 KiB
+constexpr int W2_A0 = 4 * W2_GPL;                 // activation planes start here
+constexpr int W2_APL = W2_NPOS * 128;             // 13824 B
+constexpr int W2_BUF = W2_A0 + 2 * W2_APL;        // 60416 B per item
+constexpr int W2_LDS = 2 * W2_BUF;                // 120832 B
+constexpr int W2_APIECES = 2 * W2_NPOS * 8;       // 1728 16-byte pieces of the activation planes
+
+__device__ const float w2_zero16[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ int w2_swz(const int off) { return off ^ ((off >> 2) & 0x40); }   // 128-byte rows: row bit 1 swaps the 64-byte halves
+
+__device__ __forceinline__ bf16x8 w2_frag(const char* base) {
+    // two transposing reads: pixels +0..3 and +4..7 of this lane half's 8-pixel group (128 bytes per pixel row)
+    typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base));
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base + 512));
+    return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+__device__ __forceinline__ void w2_dma16(const char* g, char* lds_wave_base) {
+    // 64 lanes x 16 B -> lds_wave_base + 16 * lane. Inline asm: see c2_dma16 (cell2.hip) — a compiler-visible LDS-DMA
+    // degrades every later s_waitcnt of the kernel to zero.
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds)) : "memory", "m0");
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
+    constexpr int TA = 5, TB = 4;   // taps of group 0 / group 1
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hh = lane >> 5;
+    const int tg = wave >> 2, wn = (wave >> 1) & 1, wc = wave & 1;
+    // XCD-aware block decode (the rule of wg_block, lstm_bwd.hip): contiguous ranges of (slice, tile) per XCD
+    int bx, slice;
+    {
+        const long long total = (long long)a.grid_x * a.grid_slices;
+        const long long per_xcd = (total + 7) / 8;
+        const unsigned L = blockIdx.x;
+        const long long v = (long long)(L & 7) * per_xcd + (L >> 3);
+        if ((long long)(L >> 3) >= per_xcd || v >= total) return;
+        slice = __builtin_amdgcn_readfirstlane((int)(v / a.grid_x));
+        bx = __builtin_amdgcn_readfirstlane((int)(v - (long long)slice * a.grid_x));
+    }
+    const int n_ct = a.n_ctiles;
+    const int ct_id = __builtin_amdgcn_readfirstlane(bx % n_ct);
+    const WgradCHalf ch0 = a.ct[ct_id].h[0], ch1 = a.ct[ct_id].h[1];
+    const int n0 = __builtin_amdgcn_readfirstlane((bx / n_ct) * 128);
+    const int tap0 = tg ? TA : 0;
+
+    f32x16 acc[2][TA];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][t][r] = 0.0f;
+
+    // fragment addressing (transposing reads; same lane map as wgrad_tg_kernel)
+    const int L16 = lane & 15, q = L16 >> 2, p = L16 & 3, half16 = (lane >> 4) & 1;
+    int g_lane[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) g_lane[nb] = w2_swz(((8 * hh + q) * 64 + nb * 32 + 16 * half16 + 4 * p) * 2);
+    const int a_lane = ((8 * hh + q) * 64 + wc * 32 + 16 * half16 + 4 * p) * 2;
+    int tapoff[TA];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        const int tp = tap0 + t;
+        const int dy = tp / 3, dx = tp - dy * 3;
+        tapoff[t] = (dy * W2_HALO_W + dx) * 128;
+    }
+
+    // ---- item walk: slice, slice + n_slices, ... as a mixed-radix counter (tx, ty, b, t) ----
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + W2_TH - 1) / W2_TH, tiles = tiles_x * tiles_y;
+    const int ns = a.grid_slices;
+    const int d_tx = __builtin_amdgcn_readfirstlane(ns % tiles_x), d_ty = __builtin_amdgcn_readfirstlane((ns / tiles_x) % tiles_y);
+    const int d_b = __builtin_amdgcn_readfirstlane((ns / tiles) % a.B), d_t = __builtin_amdgcn_readfirstlane(ns / (tiles * a.B));
+    struct Item { int tx, ty, b, t; };
+    auto advance = [&](Item& it) {
+        it.tx += d_tx; if (it.tx >= tiles_x) { it.tx -= tiles_x; ++it.ty; }
+        it.ty += d_ty; if (it.ty >= tiles_y) { it.ty -= tiles_y; ++it.b; }
+        it.b += d_b;   if (it.b >= a.B) { it.b -= a.B; ++it.t; }
+        it.t += d_t;
+    };
+    // a tile whose present halves all read h sees nothing at t = 0 without an initial state: start at the first item with t > 0
+    const bool skip_t0 = !a.h0_sp && (ch0.cn == 0 || ch0.seg == 1) && (ch1.cn == 0 || ch1.seg == 1);
+    Item cur;
+    {
+        int w = slice;
+        const int first = skip_t0 ? a.B * tiles : 0;
+        if (w < first) w += (first - w + ns - 1) / ns * ns;
+        const int tile = w % tiles, tb = w / tiles;
+        cur.ty = __builtin_amdgcn_readfirstlane(tile / tiles_x);
+        cur.tx = __builtin_amdgcn_readfirstlane(tile - cur.ty * tiles_x);
+        cur.b = __builtin_amdgcn_readfirstlane(tb % a.B);
+        cur.t = __builtin_amdgcn_readfirstlane(tb / a.B);
+    }
+
+    // ---- this thread's DMA pieces. dG: one 16-byte slot of each of the four planes (same pixel, same slot); the XOR swizzle of
+    //      the image is applied through the CHOICE of source (physical slot -> logical slot, the swizzle is an involution) ----
+    const int g_px = tid >> 3;
+    const int g_sl = (w2_swz(g_px * 128 + (tid & 7) * 16) & 127) >> 4;     // logical slot: rows g_sl*8 .. +7 of the plane's 64
+    const int g_off = ((n0 + g_sl * 8) >> 3) * 32;                         // byte offset inside the dG pixel row (plane u adds (u>>1)*256 + (u&1)*16)
+    const bool g_ok0 = n0 + g_sl * 8 < a.N4, g_ok1 = n0 + 64 + g_sl * 8 < a.N4;
+    const unsigned g_prow = (unsigned)a.N4 * 4u;
+    // activations: pieces tid + 512 u of [hi plane | lo plane], 8 pieces per halo position
+    int pc_hyx[4], pc_off[4];   // (row << 16) | column of the halo position, -1: none; (half << 16) | byte offset inside that half's pixel row
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int piece = tid + 512 * u;
+        const int plane = piece >= W2_NPOS * 8 ? 1 : 0;
+        const int qq = piece - plane * W2_NPOS * 8;
+        const int pos = qq >> 3;
+        const int sl = (w2_swz(pos * 128 + (qq & 7) * 16) & 127) >> 4;     // logical slot = 8 channels of the 64-channel row
+        const int hy = pos / W2_HALO_W;
+        const WgradCHalf hf = (sl >> 2) ? ch1 : ch0;
+        const bool ok = piece < W2_APIECES && (sl & 3) * 8 < hf.cn;
+        pc_hyx[u] = ok ? ((hy << 16) | (pos - hy * W2_HALO_W)) : -1;
+        pc_off[u] = ((sl >> 2) << 16) | (((hf.c0 + (sl & 3) * 8) >> 3) * 32 + plane * 16);
+    }
+    auto dma_item = [&](const Item& it, char* buf) {
+        const int y0 = it.ty * W2_TH, x0 = it.tx * 16;
+        {
+            const int gy = y0 + (g_px >> 4), gx = x0 + (g_px & 15);
+            const bool pix_ok = gy < a.H && gx < a.W;
+            const char* row = a.g_sp + (((size_t)it.t * a.B + it.b) * a.HW + (size_t)(gy * a.W + gx)) * g_prow + g_off;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = pix_ok && ((u >> 1) ? g_ok1 : g_ok0);
+                const char* src = ok ? row + (u >> 1) * 256 + (u & 1) * 16 : reinterpret_cast<const char*>(w2_zero16);
+                w2_dma16(src, buf + u * W2_GPL + wave * 1024);
+            }
+        }
+        // per half: base of this (t, b) image in its split tensor and bytes per pixel row; null = the half stages zeros
+        const char* base[2];
+        int prow_b[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const WgradCHalf hf = h ? ch1 : ch0;
+            base[h] = nullptr; prow_b[h] = 0;
+            if (hf.cn == 0) continue;
+            if (hf.seg == 0) { base[h] = a.x_sp + (size_t)it.b * a.x_sp_bstride + (size_t)it.t * a.x_sp_tstride; prow_b[h] = a.Cin * 4; }
+            else {
+                prow_b[h] = a.Ch * 4;
+                if (it.t > 0) base[h] = a.h_sp + (size_t)(it.t - 1) * a.h_sp_tstride + (size_t)it.b * a.h_sp_bstride;
+                else if (a.h0_sp) base[h] = a.h0_sp + (size_t)it.b * a.HW * a.Ch * 4;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int h = pc_off[u] >> 16;
+            const int gy = y0 - 1 + (pc_hyx[u] >> 16), gx = x0 - 1 + (pc_hyx[u] & 0xffff);
+            const bool ok = pc_hyx[u] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && base[h] != nullptr;
+            const char* src = ok ? base[h] + (size_t)(gy * a.W + gx) * prow_b[h] + (pc_off[u] & 0xffff)
+                                 : reinterpret_cast<const char*>(w2_zero16);
+            if (512 * u + wave * 64 < W2_APIECES)   // (wave-uniform: 1728 = 27 waves' worth of pieces)
+                w2_dma16(src, buf + W2_A0 + (512 * u + wave * 64) * 16);
+        }
+    };
+
+    // ---- one item: 4 k-steps of 16 pixels; per k-step the dG fragments of both row blocks, then the taps in batches ----
+    auto tap_batch = [&](const char* buf, const bf16x8 (&gh)[2], const bf16x8 (&gl)[2], int arow, auto t0_c, auto nb_c) {
+        constexpr int T0 = decltype(t0_c)::value, NB = decltype(nb_c)::value;
+        bf16x8 ah[NB], al[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int aoff = w2_swz(arow + tapoff[T0 + j]);
+            ah[j] = w2_frag(buf + W2_A0 + aoff);
+            al[j] = w2_frag(buf + W2_A0 + W2_APL + aoff);
+        }
+        // the three terms term-major: consecutive MFMAs accumulate into different tiles
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[nb][T0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl[nb], ah[j], acc[nb][T0 + j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[nb][T0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[nb], al[j], acc[nb][T0 + j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[nb][T0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[nb], ah[j], acc[nb][T0 + j], 0, 0, 0);
+    };
+    auto multiply = [&](const char* buf) {
+        const char* gb = buf + wn * 2 * W2_GPL;
+#pragma unroll 1
+        for (int s = 0; s < W2_TH; ++s) {
+            bf16x8 gh[2], gl[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                gh[nb] = w2_frag(gb + g_lane[nb] + s * 2048);
+                gl[nb] = w2_frag(gb + W2_GPL + g_lane[nb] + s * 2048);
+            }
+            const int arow = a_lane + s * W2_HALO_W * 128;
+            tap_batch(buf, gh, gl, arow, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            tap_batch(buf, gh, gl, arow, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+            if (tg == 0) tap_batch(buf, gh, gl, arow, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+        }
+    };
+
+    Item nxt = cur;
+    advance(nxt);
+    if (cur.t < a.T) dma_item(cur, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int bsel = 0;
+    while (cur.t < a.T) {
+        char* bcur = smem + bsel * W2_BUF;
+        char* bnxt = smem + (bsel ^ 1) * W2_BUF;
+        // the other buffer was multiplied in the previous iteration and every wave has passed that iteration's barrier:
+        // item i+1 is copied over it while item i is multiplied (a whole item of MFMA time to land)
+        if (nxt.t < a.T) dma_item(nxt, bnxt);
+        multiply(bcur);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        cur = nxt; advance(nxt); bsel ^= 1;
+    }
+
+    const WgradCHalf oh = wc ? ch1 : ch0;
+    const int col = oh.cglobal + i;
+    const bool col_ok = i < oh.cn;
+    float* slab = a.slabs + (size_t)slice * 9 * a.N4 * a.Ct;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            if (tg == 1 && t >= TB) break;
+            float* st = slab + (size_t)(tap0 + t) * a.N4 * a.Ct;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (n < a.N4 && col_ok) st[(size_t)n * a.Ct + col] = acc[nb][t][r];
+            }
+        }
+}
+
+// Applies when launch_wgrad would pick the pre-split tap-group kernel AND dG is available in split format: 3x3, bf16x3.
+bool wgrad2_applicable(const WgradArgs& a) {
+    static int env = -1;   // VPX_WGRAD2=0: keep wgrad_tg_kernel (experiments)
+    if (env < 0) { const char* e = getenv("VPX_WGRAD2"); env = e ? atoi(e) : 1; }
+    if (!env || !a.a_split || !a.g_sp || a.kh != 3 || a.kw != 3 || a.prec != VPX_PREC_BF16X3) return false;
+    if (a.a_sub || a.use_org || a.blk || (a.n_out && a.n_out != a.N4) || (a.N4 & 7) || (a.Cin & 7) || (a.Ch & 7)) return false;
+    const long long items = (long long)a.T * a.B * ((a.W + 15) / 16) * ((a.H + W2_TH - 1) / W2_TH);
+    return items + 4096 < (1ll << 31);
+}
+
+// slices: whole rounds of 256 one-per-CU workgroups (two rounds by default, VPX_WGRAD2_WGS overrides), at most max_slices
+hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("VPX_WGRAD2_WGS"); target = e ? atoi(e) : 512; }
+    WgradArgs a = a_in;
+    a.grid_x = ((a.N4 + 127) / 128) * a.n_ctiles;
+    int ns = target / a.grid_x;
+    if (ns > max_slices) ns = max_slices;
+    const long long items = (long long)a.T * a.B * ((a.W + 15) / 16) * ((a.H + W2_TH - 1) / W2_TH);
+    if (ns > items) ns = (int)items;
+    if (ns < 1) ns = 1;
+    a.grid_slices = ns;
+    *used_slices = ns;
+    const long long total = (long long)a.grid_x * ns;
+    hipLaunchKernelGGL(wgrad2_kernel, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace vpx
