@@ -39,8 +39,8 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     float* dh_buf = ws.take(L.n_state);
     float* dc_buf = ws.take(L.n_state);
     float* slabs = ws.take(L.slab_floats);
-    const int gb_blocks = gate_bwd_blocks((int)HW, Ch);
-    float* db_part = ws.take((size_t)T * gb_blocks * N4);
+    const int gb_blocks = gate_bwd_blocks((int)HW, Ch) * gate_bwd_slices((int)HW, Ch, B, dWci != nullptr);  // partial rows per step
+    float* db_part = ws.take((size_t)T * GATE_BWD_MAX_SLICES * gate_bwd_blocks((int)HW, Ch) * N4);
     float* db_part2 = ws.take((size_t)COLSUM_BLOCKS * N4);
     // forward on the second-generation cell: the gate-backward kernel also writes dG in split operand format and the data
     // gradient runs on the cell2 main loop with a plain epilogue (conv2); VPX_CONV2_DGRAD=0 keeps the first-generation kernel
@@ -114,6 +114,15 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
     }
 
+    // fp32 dG is only written for consumers that still read it (first-generation data- / weight-gradient kernels)
+    bool wgrad_takes_sp = false;
+    if (c2d && d->layout == VPX_LAYOUT_NHWC) {
+        WgradArgs probe{};
+        probe.T = T; probe.B = B; probe.H = H; probe.W = Wd; probe.kh = d->kh; probe.kw = d->kw; probe.N4 = N4; probe.Cin = Cin; probe.Ch = Ch;
+        probe.prec = d->precision; probe.a_split = 1; probe.g_sp = dG_sp_all;
+        wgrad_takes_sp = wgrad2_applicable(probe);
+    }
+    const bool need_dG_f32 = !c2d || (dW && !wgrad_takes_sp);
     for (int t = T - 1; t >= 0; --t) {
         GateBwdArgs ga{};
         ga.B = B; ga.HW = (int)HW; ga.Ch = Ch;
@@ -128,7 +137,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         ga.dc_out = (t == 0 && dc0n) ? dc0n : dc_buf;
         ga.wci = wci; ga.wcf = wcf; ga.wco = wco;
         ga.dwci = dpeep ? dwci : nullptr; ga.dwcf = dpeep ? dwcf : nullptr; ga.dwco = dpeep ? dwco : nullptr;
-        ga.dG = dG_all + (size_t)t * L.n_state * 4;
+        ga.dG = need_dG_f32 ? dG_all + (size_t)t * L.n_state * 4 : nullptr;
         ga.dG_sp = c2d ? dG_sp_all + (size_t)t * L.n_state * 16 : nullptr;
         ga.db_partial = db ? db_part + (size_t)t * gb_blocks * N4 : nullptr;
         VPX_CHECK_HIP(launch_gate_bwd(ga, stream));

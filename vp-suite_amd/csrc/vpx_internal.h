@@ -232,6 +232,16 @@ struct GateBwdArgs {
     float* db_partial;        // [gridDim.x][4Ch] per-block column sums of dG (bias gradient partials), or null
 };
 inline int gate_bwd_blocks(int HW, int Ch) { return (HW * Ch + 255) / 256; }
+// batch slices (grid.y): the kernel streams ~56 B per element with one element per thread and batch step, so it wants >= 8
+// waves per SIMD in flight (2048 blocks); a (pixel, channel) thread then walks B / slices batch items. 1 with peephole gradients.
+constexpr int GATE_BWD_MAX_SLICES = 8;
+inline int gate_bwd_slices(int HW, int Ch, int B, bool peephole_grads) {
+    if (peephole_grads) return 1;
+    int s = (2048 + gate_bwd_blocks(HW, Ch) - 1) / gate_bwd_blocks(HW, Ch);
+    if (s > GATE_BWD_MAX_SLICES) s = GATE_BWD_MAX_SLICES;
+    if (s > B) s = B;
+    return s < 1 ? 1 : s;
+}
 hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s);
 // out[c] = sum_r m[r][c] (* LeakyReLU'(y[r][c]) when y != null, the scaled matrix optionally stored), bit-reproducible;
 // partial_ws: COLSUM_BLOCKS * cols floats of scratch

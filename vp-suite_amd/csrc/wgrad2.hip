@@ -147,11 +147,11 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
         const int y0 = it.ty * W2_TH, x0 = it.tx * 16;
         {
             const int gy = y0 + (g_px >> 4), gx = x0 + (g_px & 15);
-            const bool pix_ok = gy < a.H && gx < a.W;
+            const bool pix_ok = (gy < a.H) & (gx < a.W);   // (bitwise on purpose, here and below: selects, not divergent branches)
             const char* row = a.g_sp + (((size_t)it.t * a.B + it.b) * a.HW + (size_t)(gy * a.W + gx)) * g_prow + g_off;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const bool ok = pix_ok && ((u >> 1) ? g_ok1 : g_ok0);
+                const bool ok = pix_ok & ((u >> 1) ? g_ok1 : g_ok0);
                 const char* src = ok ? row + (u >> 1) * 256 + (u & 1) * 16 : reinterpret_cast<const char*>(w2_zero16);
                 w2_dma16(src, buf + u * W2_GPL + wave * 1024);
             }
@@ -173,10 +173,12 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int h = pc_off[u] >> 16;
+            const bool h = (pc_off[u] >> 16) != 0;
+            const char* const bs = h ? base[1] : base[0];
+            const int pr = h ? prow_b[1] : prow_b[0];
             const int gy = y0 - 1 + (pc_hyx[u] >> 16), gx = x0 - 1 + (pc_hyx[u] & 0xffff);
-            const bool ok = pc_hyx[u] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && base[h] != nullptr;
-            const char* src = ok ? base[h] + (size_t)(gy * a.W + gx) * prow_b[h] + (pc_off[u] & 0xffff)
+            const bool ok = (pc_hyx[u] >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (bs != nullptr);
+            const char* src = ok ? bs + (size_t)((unsigned)(gy * a.W + gx) * (unsigned long long)(unsigned)pr) + (pc_off[u] & 0xffff)
                                  : reinterpret_cast<const char*>(w2_zero16);
             if (512 * u + wave * 64 < W2_APIECES)   // (wave-uniform: 1728 = 27 waves' worth of pieces)
                 w2_dma16(src, buf + W2_A0 + (512 * u + wave * 64) * 16);
