@@ -21,7 +21,7 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 512)()
 L.vpx_dbg_cell2_stamps.argtypes = [ctypes.c_void_p]
 assert L.vpx_dbg_cell2_stamps(buf) == 0
-names = {0: "start", 1: "prologue issued", 2: "prologue landed+barrier", 40: "loop end", 41: "epilogue sub-tile 0", 42: "epilogue sub-tile 1"}
+names = {0: "start", 1: "prologue issued", 2: "prologue landed+barrier", 40: "loop end", 42: "epilogue done"}
 for w in range(8):
     st = [buf[w * 64 + i] for i in range(64)]
     t0 = st[0]
@@ -33,5 +33,7 @@ for w in range(8):
         a, bb, cc = st[3 + 3 * c], st[4 + 3 * c], st[5 + 3 * c]
         line.append(f"c{c}: run {a - prev} vm {bb - a} bar {cc - bb}")
         prev = cc
-    line.append(f"loop end +{st[40] - t0}; epi0 {st[41] - st[40]} epi1 {st[42] - st[41]}; total {st[42] - t0}")
+    line.append(f"loop end +{st[40] - t0}; epilogue {st[42] - st[40]}; total {st[42] - t0}")
+    e = [st[43 + i] for i in range(5)]
+    line.append(f"epi: loads0+barrier {e[1] - e[0]} put0+loads1 {e[2] - e[1]} math0 {e[3] - e[2]} put1+math1 {e[4] - e[3]}")
     print(" | ".join(line))

@@ -135,6 +135,17 @@ __device__ __forceinline__ void c2_barrier() {
     asm volatile("" ::: "memory");
 }
 
+#ifdef VPX_ABLATE
+// developer build only (make ablate): per-wave s_memtime stamps of ONE workgroup (block id = Cell2Plan::_p), read back with
+// vpx_dbg_cell2_stamps(). Never compiled into the product library.
+__device__ unsigned long long c2_stamps[8 * 64];
+#define C2_STAMP(slot) do { if (stamp_on && lane == 0) c2_stamps[wave * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define C2_EPI_STAMP(slot) do { if (stamp_on && (lane & 63) == 0) c2_stamps[(prow >> 2) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C2_STAMP(slot) do { } while (0)
+#define C2_EPI_STAMP(slot) do { } while (0)
+#endif
+
 // The ConvLSTM epilogue (conv_lstm_hzzone.py:62-68), plus the split copy of h_t for the next step / the weight gradient.
 // Addressing: one 24-bit multiply per pixel (pixel index x Ch), every array is a wave-uniform base + that 32-bit element
 // offset; FULL = the tile lies inside the image (no per-pixel bounds test). The first-generation epilogue spent ~45
@@ -227,11 +238,33 @@ struct Cell2Epi {
     // Vectorised epilogue for tiles that lie inside the image and cover 32 valid channels: the accumulators take a round trip
     // through this wave's private 16 KiB of LDS ([gate][pixel][32 ch], conflict-free both ways) so that a lane then owns FOUR
     // consecutive channels of a pixel — every global access is 16 bytes per lane (8 lanes = one pixel's 128-byte channel row)
-    // and the address arithmetic runs once per four elements. Same arithmetic per element as run<>().
-    __device__ __forceinline__ void run_vec(const f32x16 (&acc)[4], char* lds, int b, int y0, int x0, int n_tile, int prow, int lane,
-                                            int H, int W) const {
-        const int j = lane & 31, hh = lane >> 5;
+    // and the address arithmetic runs once per four elements. Same arithmetic per element as run<>(). Three phases per
+    // sub-tile so that finish() can order them: vec_load (cell state + peepholes, 16 vector loads per lane), vec_put
+    // (accumulators -> LDS), vec_math (LDS -> gates -> c, h, split h).
+    struct VecIn { unsigned eo[4]; f32x4 cp[4], wi[4], wf[4], wo[4]; };
+
+    __device__ __forceinline__ void vec_load(VecIn& v, int b, int y0, int x0, int n_tile, int prow, int lane, int H, int W) const {
         const unsigned Ch = (unsigned)a.Ch;
+        const int cg = lane & 7, p4 = lane >> 3;
+        const unsigned ch = (unsigned)(n_tile * 32 + cg * 4);
+        const size_t img = (size_t)b * H * W;
+        const float* const cin_b = a.c_in ? a.c_in + img * Ch : nullptr;
+        const int rowpix = (y0 + prow) * W + x0;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ip = k * 8 + p4;                               // pixel slot 0..31 of the sub-tile
+            const int pix = rowpix + (ip >> 4) * W + c2_px(ip);
+            v.eo[k] = __umul24((unsigned)pix, Ch) + ch;
+            v.cp[k] = cin_b ? *reinterpret_cast<const f32x4*>(cin_b + v.eo[k]) : zero;
+            v.wi[k] = a.wci ? *reinterpret_cast<const f32x4*>(a.wci + v.eo[k]) : zero;
+            v.wf[k] = a.wci ? *reinterpret_cast<const f32x4*>(a.wcf + v.eo[k]) : zero;
+            v.wo[k] = a.wco ? *reinterpret_cast<const f32x4*>(a.wco + v.eo[k]) : zero;
+        }
+    }
+
+    __device__ __forceinline__ void vec_put(const f32x16 (&acc)[4], char* lds, int lane) const {
+        const int j = lane & 31, hh = lane >> 5;
         float* ldsf = reinterpret_cast<float*>(lds);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -240,7 +273,12 @@ struct Cell2Epi {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * hh;     // MFMA row = pixel slot of the sub-tile
                 ldsf[g * 1024 + i * 32 + j] = acc[g][r];
             }
-        // (LDS operations of one wave execute in order: the reads below see the writes above without a barrier)
+        // (LDS operations of one wave execute in order: vec_math's reads see these writes without a barrier)
+    }
+
+    __device__ __forceinline__ void vec_math(const VecIn& v, const char* lds, int b, int n_tile, int lane, int H, int W) const {
+        const unsigned Ch = (unsigned)a.Ch;
+        const float* ldsf = reinterpret_cast<const float*>(lds);
         const int cg = lane & 7, p4 = lane >> 3;
         const unsigned ch = (unsigned)(n_tile * 32 + cg * 4);
         f32x4 bi = {0.f, 0.f, 0.f, 0.f}, bf = bi, bg = bi, bo = bi;
@@ -251,26 +289,11 @@ struct Cell2Epi {
             bo = *reinterpret_cast<const f32x4*>(a.bias + a.gate_pos[3] * Ch + ch);
         }
         const size_t img = (size_t)b * H * W;
-        const float* const cin_b = a.c_in ? a.c_in + img * Ch : nullptr;
         float* const cout_b = a.c_out + img * Ch;
         float* const hout_b = a.h_out + (size_t)b * a.h_bstride;
         float* const g0 = a.gates ? a.gates + img * 4 * Ch : nullptr;
         char* const hsp_b = h_sp ? h_sp + (size_t)b * h_sp_bstride : nullptr;
         const unsigned sp_off = (ch >> 3) * 32 + (ch & 7) * 2;   // hi quad of channels ch..ch+3; the lo quad sits 16 bytes further
-        const int rowpix = (y0 + prow) * W + x0;
-        unsigned eo[4];
-        f32x4 cp[4], wi[4], wf[4], wo[4];
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ip = k * 8 + p4;                               // pixel slot 0..31 of the sub-tile
-            const int pix = rowpix + (ip >> 4) * W + c2_px(ip);
-            eo[k] = __umul24((unsigned)pix, Ch) + ch;
-            cp[k] = cin_b ? *reinterpret_cast<const f32x4*>(cin_b + eo[k]) : zero;
-            wi[k] = a.wci ? *reinterpret_cast<const f32x4*>(a.wci + eo[k]) : zero;
-            wf[k] = a.wci ? *reinterpret_cast<const f32x4*>(a.wcf + eo[k]) : zero;
-            wo[k] = a.wco ? *reinterpret_cast<const f32x4*>(a.wco + eo[k]) : zero;
-        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int ip = k * 8 + p4;
@@ -281,18 +304,19 @@ struct Cell2Epi {
             f32x4 i4, f4, g4, o4, cn, hn;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float c0 = cp[k][e];
-                i4[e] = sigmoid_f(ai[e] + bi[e] + wi[k][e] * c0);
-                f4[e] = sigmoid_f(af[e] + bf[e] + wf[k][e] * c0);
+                const float c0 = v.cp[k][e];
+                i4[e] = sigmoid_f(ai[e] + bi[e] + v.wi[k][e] * c0);
+                f4[e] = sigmoid_f(af[e] + bf[e] + v.wf[k][e] * c0);
                 g4[e] = tanh_f(ag[e] + bg[e]);
                 cn[e] = f4[e] * c0 + i4[e] * g4[e];
-                o4[e] = sigmoid_f(ao[e] + bo[e] + wo[k][e] * cn[e]);
+                o4[e] = sigmoid_f(ao[e] + bo[e] + v.wo[k][e] * cn[e]);
                 hn[e] = o4[e] * tanh_f(cn[e]);
             }
-            *reinterpret_cast<f32x4*>(cout_b + eo[k]) = cn;
-            *reinterpret_cast<f32x4*>(hout_b + eo[k]) = hn;
+            const unsigned eo = v.eo[k];
+            *reinterpret_cast<f32x4*>(cout_b + eo) = cn;
+            *reinterpret_cast<f32x4*>(hout_b + eo) = hn;
             if (g0) {
-                const unsigned go = 4u * (eo[k] - ch) + ch;
+                const unsigned go = 4u * (eo - ch) + ch;
                 *reinterpret_cast<f32x4*>(g0 + go) = i4;
                 *reinterpret_cast<f32x4*>(g0 + go + Ch) = f4;
                 *reinterpret_cast<f32x4*>(g0 + go + 2 * Ch) = g4;
@@ -302,7 +326,7 @@ struct Cell2Epi {
                 unsigned h[4], l[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) c2_split(hn[e], h[e], l[e]);
-                char* dst = hsp_b + 4u * (eo[k] - ch) + sp_off;
+                char* dst = hsp_b + 4u * (eo - ch) + sp_off;
                 *reinterpret_cast<uint2*>(dst) = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
                 *reinterpret_cast<uint2*>(dst + 16) = uint2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
             }
@@ -310,17 +334,37 @@ struct Cell2Epi {
     }
 
     __device__ __forceinline__ void finish(const f32x16 (&acc)[2][4], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
-                                           int /*ngr*/, int H, int W) const {
+                                           int /*ngr*/, int H, int W, bool stamp_on = false) const {
         const int j = lane & 31, hh = lane >> 5;
         const bool full = y0 + 32 <= H && x0 + 16 <= W;
         const bool vec = full && n_tile * 32 + 32 <= a.Ch && (a.Ch & 3) == 0;
-        if (vec) c2_barrier();   // every wave has read its last fragments: the staging buffers become the epilogue's transposition space
+        if (vec) {
+            // Order matters (in-kernel stamps, 158 k-cycle tile: the epilogue took 17-21 k, of which 2.7 + 4.2 k were the two
+            // sub-tiles' waits for their state / peephole loads): sub-tile 0's loads go out BEFORE the barrier and the LDS
+            // round trip, sub-tile 1's before sub-tile 0's arithmetic — their latency runs under work that does not need them.
+            const int prow = 4 * wave;   // (also the stamp row of C2_EPI_STAMP)
+            char* const lds = smem + wave * 16384;
+            VecIn v0, v1;
+            C2_EPI_STAMP(43);
+            vec_load(v0, b, y0, x0, n_tile, prow, lane, H, W);
+            c2_barrier();   // every wave has read its last fragments: the staging buffers become the epilogue's transposition space
+            C2_EPI_STAMP(44);
+            vec_put(acc[0], lds, lane);
+            vec_load(v1, b, y0, x0, n_tile, prow + 2, lane, H, W);
+            C2_EPI_STAMP(45);
+            vec_math(v0, lds, b, n_tile, lane, H, W);
+            C2_EPI_STAMP(46);
+            vec_put(acc[1], lds, lane);
+            vec_math(v1, lds, b, n_tile, lane, H, W);
+            C2_EPI_STAMP(47);
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            if (vec) run_vec(acc[m], smem + wave * 16384, b, y0, x0, n_tile, 4 * wave + 2 * m, lane, H, W);
-            else if (full) run<true>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, H, W);
+            if (full) run<true>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, H, W);
             else run<false>(acc[m], b, y0, x0, n_tile, 4 * wave + 2 * m, j, hh, H, W);
         }
+        (void)stamp_on;
     }
 };
 
@@ -335,7 +379,7 @@ struct Conv2Epi {
     float* out1; long long bstride1; int ld1, _p1;
 
     __device__ __forceinline__ void finish(const f32x16 (&acc)[2][4], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
-                                           int ngr, int H, int W) const {
+                                           int ngr, int H, int W, bool = false) const {
         c2_barrier();
         float* ldsf = reinterpret_cast<float*>(smem + wave * 16384);
         const int j = lane & 31, hh = lane >> 5, cg = lane & 7, p4 = lane >> 3;
@@ -392,14 +436,6 @@ struct Conv2Epi {
     }
 };
 
-#ifdef VPX_ABLATE
-// developer build only (make ablate): per-wave s_memtime stamps of ONE workgroup (block id = Cell2Plan::_p), read back with
-// vpx_dbg_cell2_stamps(). Never compiled into the product library.
-__device__ unsigned long long c2_stamps[8 * 64];
-#define C2_STAMP(slot) do { if (stamp_on && lane == 0) c2_stamps[wave * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define C2_STAMP(slot) do { } while (0)
-#endif
 
 // Fragment registers of the MFMA loop: three activation sets (one per tap column dx, so the set of dx = 0 can be refilled
 // for the next chunk while dx = 2 is still being multiplied) and two weight sets (even / odd gate group).
@@ -592,7 +628,11 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
         }
     }
     C2_STAMP(40);
+#ifdef VPX_ABLATE
+    epi.finish(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W, stamp_on);
+#else
     epi.finish(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+#endif
     C2_STAMP(42);
 }
 
