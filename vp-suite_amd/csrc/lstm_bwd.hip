@@ -1107,7 +1107,7 @@ hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s) {
 // dW[n][c][tap] (OIHW, ld = Ct*taps) = sum_s slab[s][tap][n][c]
 struct TapMap { int real_taps; int map[16]; };  // real_taps = 0: identity (launch taps == tensor taps)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dW, int n_slices, int taps,
-                                    int N4, int Ct, const TapMap tm) {
+                                    int N4, int Ct, const TapMap tm, int tail_col0, int tail_slices) {
     const long long total = (long long)N4 * Ct * taps;
     const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (e >= total) return;
@@ -1120,14 +1120,23 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
     if (tm.real_taps) { real_taps = tm.real_taps; dst_tap = tm.map[tap]; if (dst_tap < 0) return; }
     float acc = 0.f;
     const size_t slab_sz = (size_t)taps * N4 * Ct;
-    for (int s = 0; s < n_slices; ++s) acc += slabs[(size_t)s * slab_sz + e];
+    const int ns = c >= tail_col0 ? tail_slices : n_slices;   // wgrad2: the half-empty last column tile runs on fewer slices
+    for (int s = 0; s < ns; ++s) acc += slabs[(size_t)s * slab_sz + e];
     dW[((size_t)n * Ct + c) * real_taps + dst_tap] = acc;
 }
 
 hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s) {
     const long long total = (long long)N4 * Ct * taps;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
-                       taps, N4, Ct, TapMap{});
+                       taps, N4, Ct, TapMap{}, Ct, n_slices);
+    return hipGetLastError();
+}
+
+hipError_t launch_wgrad_reduce_tail(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int tail_col0, int tail_slices,
+                                    hipStream_t s) {
+    const long long total = (long long)N4 * Ct * taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
+                       taps, N4, Ct, TapMap{}, tail_col0, tail_slices);
     return hipGetLastError();
 }
 
@@ -1139,7 +1148,7 @@ hipError_t launch_wgrad_reduce_map(const float* slabs, float* dW, int n_slices, 
     for (int i = 0; i < taps; ++i) tm.map[i] = tapmap[i];
     const long long total = (long long)N4 * Ct * taps;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
-                       taps, N4, Ct, tm);
+                       taps, N4, Ct, tm, Ct, n_slices);
     return hipGetLastError();
 }
 

@@ -200,6 +200,11 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
         if (ns > 256) ns = 256;
         if (ns < 1) ns = 1;
         L.n_slices = (int)ns;
+        if (L.v2) {   // wgrad2.hip: 128-row tiles (half the tiles per slice) and, with a half-empty last column tile, up to 2x the slices
+            const long long ns2 = 1024 / (((N4 + 127) / 128) * L.n_ctiles);
+            if (ns2 > L.n_slices) L.n_slices = (int)(ns2 < items ? ns2 : items);
+            if (L.n_slices < 2) L.n_slices = 2;
+        }
         L.slab_floats = (size_t)L.n_slices * L.taps * N4 * Ct;
     }
     return VPX_OK;

@@ -299,12 +299,16 @@ struct WgradArgs {
     const char* g_sp;           // dG again in split format [T][B][HW][N4] (gate-backward kernel), or null: with a_split, selects wgrad2.hip
     int vec_all;                // set by launch_wgrad: every operand allows 16-byte vector loads (bf16 forms: unconditional load issue)
     int grid_x, grid_slices;    // set by launch_wgrad: logical grid (row tile x column tile, K slice) behind the XCD-aware 1-D launch
+    int w2_nh, w2_ns_half;      // set by launch_wgrad2: row tiles of a half-empty last column tile (0 = none) and their slice count
 };
 hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s);
 // wgrad2.hip: both operands pre-split (3x3, bf16x3); writes slabs [used_slices][9][N4][Ct] like launch_wgrad
 bool wgrad2_applicable(const WgradArgs& a);
-hipError_t launch_wgrad2(const WgradArgs& a, int max_slices, int* used_slices, hipStream_t s);
+// columns >= *tail_col0 (the half-empty last column tile, if any) were written to the first *tail_slices slabs only
+hipError_t launch_wgrad2(const WgradArgs& a, int max_slices, int* used_slices, int* tail_col0, int* tail_slices, hipStream_t s);
+hipError_t launch_wgrad_reduce_tail(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int tail_col0, int tail_slices,
+                                    hipStream_t s);
 // same, but launch tap t lands at tap index tapmap[t] of a dW with real_taps taps per (row, channel); tapmap[t] < 0: dropped
 hipError_t launch_wgrad_reduce_map(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int real_taps,
                                    const int* tapmap, hipStream_t s);

@@ -56,16 +56,26 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hh = lane >> 5;
     const int tg = wave >> 2, wn = (wave >> 1) & 1, wc = wave & 1;
-    // XCD-aware block decode (the rule of wg_block, lstm_bwd.hip): contiguous ranges of (slice, tile) per XCD
-    int bx, slice;
+    // XCD-aware block decode (the rule of wg_block, lstm_bwd.hip): contiguous ranges of the logical sequence per XCD. The
+    // sequence lists the FULL column tiles of every slice first (grid_slices slices), then the half-empty last column tile
+    // (w2_nh row tiles of it per slice) on FEWER slices (w2_ns_half): its items are cheaper (k-steps split over the wave pair,
+    // below), so each of its workgroups takes more of them and every workgroup of the launch runs equally long.
+    int bx, slice, ns;
     {
-        const long long total = (long long)a.grid_x * a.grid_slices;
+        const int nf = a.grid_x - a.w2_nh;                       // full tiles per slice
+        const long long n_full = (long long)nf * a.grid_slices;
+        const long long total = n_full + (long long)a.w2_nh * a.w2_ns_half;
         const long long per_xcd = (total + 7) / 8;
         const unsigned L = blockIdx.x;
         const long long v = (long long)(L & 7) * per_xcd + (L >> 3);
         if ((long long)(L >> 3) >= per_xcd || v >= total) return;
-        slice = __builtin_amdgcn_readfirstlane((int)(v / a.grid_x));
-        bx = __builtin_amdgcn_readfirstlane((int)(v - (long long)slice * a.grid_x));
+        int fi;
+        if (v < n_full) { slice = (int)(v / nf); fi = (int)(v - (long long)slice * nf); ns = a.grid_slices; }
+        else { const long long u = v - n_full; slice = (int)(u / a.w2_nh); fi = -1 - (int)(u - (long long)slice * a.w2_nh); ns = a.w2_ns_half; }
+        const int n_ctf = a.w2_nh ? a.n_ctiles - 1 : a.n_ctiles; // column tiles with both halves in use
+        // bx = row tile * n_ctiles + column tile, as before
+        bx = fi >= 0 ? (fi / n_ctf) * a.n_ctiles + fi % n_ctf : (-1 - fi) * a.n_ctiles + (a.n_ctiles - 1);
+        slice = __builtin_amdgcn_readfirstlane(slice); bx = __builtin_amdgcn_readfirstlane(bx); ns = __builtin_amdgcn_readfirstlane(ns);
     }
     const int n_ct = a.n_ctiles;
     const int ct_id = __builtin_amdgcn_readfirstlane(bx % n_ct);
@@ -86,7 +96,12 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
     int g_lane[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) g_lane[nb] = w2_swz(((8 * hh + q) * 64 + nb * 32 + 16 * half16 + 4 * p) * 2);
-    const int a_lane = ((8 * hh + q) * 64 + wc * 32 + 16 * half16 + 4 * p) * 2;
+    // A column tile whose second 32-channel half is empty (80 = 16 + 32 + 32 channels -> the last tile holds one half) would leave
+    // the wc = 1 waves multiplying zeros: there, both waves of a pair take the SAME channels and split the k-steps of every item
+    // between them (wc = 0: rows 0-1, wc = 1: rows 2-3 of the 4 x 16 item); the pair's accumulators meet in LDS after the loop.
+    const bool ksplit = ch1.cn == 0;
+    const int s_lo = ksplit ? 2 * wc : 0, s_hi = ksplit ? 2 * wc + 2 : W2_TH;
+    const int a_lane = ((8 * hh + q) * 64 + (ksplit ? 0 : wc) * 32 + 16 * half16 + 4 * p) * 2;
     int tapoff[TA];
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
@@ -97,7 +112,6 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
 
     // ---- item walk: slice, slice + n_slices, ... as a mixed-radix counter (tx, ty, b, t) ----
     const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + W2_TH - 1) / W2_TH, tiles = tiles_x * tiles_y;
-    const int ns = a.grid_slices;
     const int d_tx = __builtin_amdgcn_readfirstlane(ns % tiles_x), d_ty = __builtin_amdgcn_readfirstlane((ns / tiles_x) % tiles_y);
     const int d_b = __builtin_amdgcn_readfirstlane((ns / tiles) % a.B), d_t = __builtin_amdgcn_readfirstlane(ns / (tiles * a.B));
     struct Item { int tx, ty, b, t; };
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
     auto multiply = [&](const char* buf) {
         const char* gb = buf + wn * 2 * W2_GPL;
 #pragma unroll 1
-        for (int s = 0; s < W2_TH; ++s) {
+        for (int s = s_lo; s < s_hi; ++s) {
             bf16x8 gh[2], gl[2];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
@@ -243,6 +257,28 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
         cur = nxt; advance(nxt); bsel ^= 1;
     }
 
+    if (ksplit) {
+        // pair reduction (once per workgroup): the wc = 1 wave of each (tap group, row half) pair parks its accumulators in LDS,
+        // the wc = 0 wave adds them; one row block (5 tiles x 16 registers x 64 lanes = 20 KiB per pair) at a time
+        float* red = reinterpret_cast<float*>(smem) + (wave >> 1) * (TA * 16 * 64);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            __syncthreads();
+            if (wc == 1) {
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[nb][t][r];
+            }
+            __syncthreads();
+            if (wc == 0) {
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nb][t][r] += red[(t * 16 + r) * 64 + lane];
+            }
+        }
+    }
     const WgradCHalf oh = wc ? ch1 : ch0;
     const int col = oh.cglobal + i;
     const bool col_ok = i < oh.cn;
@@ -272,7 +308,7 @@ bool wgrad2_applicable(const WgradArgs& a) {
 }
 
 // slices: whole rounds of 256 one-per-CU workgroups (two rounds by default, VPX_WGRAD2_WGS overrides), at most max_slices
-hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices, hipStream_t s) {
+hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices, int* tail_col0, int* tail_slices, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
@@ -282,15 +318,26 @@ hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices
     static int target = -1;
     if (target < 0) { const char* e = getenv("VPX_WGRAD2_WGS"); target = e ? atoi(e) : 512; }
     WgradArgs a = a_in;
-    a.grid_x = ((a.N4 + 127) / 128) * a.n_ctiles;
-    int ns = target / a.grid_x;
+    const int rows = (a.N4 + 127) / 128;
+    a.grid_x = rows * a.n_ctiles;
+    const bool half_tail = a.ct[a.n_ctiles - 1].h[1].cn == 0;
+    a.w2_nh = half_tail ? rows : 0;
+    const int nf = a.grid_x - a.w2_nh;
+    // Full tiles take ns slices, the half-empty tail tiles 5/8 ns: an item of a tail tile costs 0.62 of a full one (measured: the
+    // MFMA work halves, the copy and the barrier do not), so with 8/5 of the items its workgroups run as long as the others —
+    // ns * nf + 5/8 ns * nh workgroups of equal length, at most `target`.
+    int ns = half_tail ? (8 * target) / (8 * nf + 5 * a.w2_nh) : target / nf;
     if (ns > max_slices) ns = max_slices;
     const long long items = (long long)a.T * a.B * ((a.W + 15) / 16) * ((a.H + W2_TH - 1) / W2_TH);
     if (ns > items) ns = (int)items;
+    if (half_tail && ns >= 8) ns &= ~7;
     if (ns < 1) ns = 1;
     a.grid_slices = ns;
+    a.w2_ns_half = half_tail ? (ns >= 8 ? ns / 8 * 5 : ns) : 0;
     *used_slices = ns;
-    const long long total = (long long)a.grid_x * ns;
+    *tail_col0 = half_tail ? a.ct[a.n_ctiles - 1].h[0].cglobal : a.Ct;
+    *tail_slices = half_tail ? a.w2_ns_half : ns;
+    const long long total = (long long)nf * ns + (long long)a.w2_nh * a.w2_ns_half;
     hipLaunchKernelGGL(wgrad2_kernel, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
     return hipGetLastError();
 }
