@@ -143,6 +143,7 @@ def test_conv2d_ex_vs_torch(vpx):
         (False, 1, 16, 3, 1, 1, 20, 24), (False, 64, 64, 3, 2, 1, 32, 32), (False, 12, 20, 3, 2, 1, 17, 23),
         (False, 16, 1, 1, 1, 0, 16, 16), (True, 96, 96, 4, 2, 1, 8, 8), (True, 10, 14, 4, 2, 1, 7, 9),
         (True, 64, 16, 3, 1, 1, 16, 16), (True, 6, 5, 5, 2, 2, 6, 7), (False, 8, 8, 4, 2, 1, 12, 12),
+        (False, 3, 16, 3, 1, 1, 19, 21), (False, 16, 3, 1, 1, 0, 18, 20),   # few-channel layers: wgrad_small_kernel (with 1->16, 16->1 above)
     ]
     _conv2d_ex_cases(vpx, cases, F)   # backward: vpx_conv2d_ex_bwd (adjoint layer + strided MFMA weight gradient)
     # the ATen fallback wiring (used when the kernel is smaller than the stride), on ATen's native kernels: MIOpen's

@@ -442,7 +442,10 @@ int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, co
         ExGeo ga{d->H, d->W};
         if ((rc = ex_forward(&a, ga, dy, w, nullptr, dx, wpk, stream)) != VPX_OK) return rc;
     }
-    if (dw) {
+    if (dw && !d->transposed && wgrad_small_applicable(d->Co, d->Ci, d->kh, d->kw, d->stride, d->pad) &&
+        (size_t)WGRAD_SMALL_BLOCKS * d->Co * d->Ci * d->kh * d->kw <= ex_bwd_slab_floats(d, g)) {
+        VPX_CHECK_HIP(launch_wgrad_small(dy, x, d->N, d->H, d->W, d->Co, d->Ci, d->kh, d->pad, slabs, dw, stream));
+    } else if (dw) {
         if (!d->transposed)  // dW[co][ci][ky][kx] = sum dy[b,oy,ox,co] x[b, s*oy + ky - p, s*ox + kx - p, ci]
             rc = strided_wgrad(stream, d->precision, d->N, g.Ho, g.Wo, dy, d->Co, d->H, d->W, x, d->Ci, d->kh, d->kw, d->stride, d->pad, slabs, dw);
         else                 // dW[ci][co][ky][kx] = sum x[b,i,j,ci] dy[b, s*i + ky - p, s*j + kx - p, co]

@@ -187,6 +187,83 @@ hipError_t launch_colsum(const float* m, const float* y, float slope, float* sca
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the EF glue's few-channel layers (1 -> 16 and 16 -> 1 around the image; stride 1): Co*C*k*k <= 144 sums over
+// every pixel of the batch — no matrix shape worth an MFMA tile (the MFMA kernels ran them at 15-25x their HBM time: 64-wide
+// tiles for 1 or 16 useful rows / columns). Here: one thread per pixel (grid stride), all sums of its output-channel group in
+// registers, fp32 FMA; wave reduction by shuffles, block partials, then colsum_l2_kernel — fixed order, bit-reproducible.
+template <int COB, int C, int K>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const float* __restrict__ dy, const float* __restrict__ x, int N, int H, int W,
+                                                          int CO, int pad, float* __restrict__ partial) {
+    constexpr int KK = K * K, ACC = COB * C * KK;
+    float acc[ACC];
+#pragma unroll
+    for (int a = 0; a < ACC; ++a) acc[a] = 0.f;
+    const long long npix = (long long)N * H * W;
+    const int co0 = blockIdx.y * COB;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+        const int xx = (int)(p % W);
+        const long long r = p / W;
+        const int yy = (int)(r % H);
+        const long long img = (r / H) * H;   // row index of the image's first row
+        float g[COB];
+#pragma unroll
+        for (int i = 0; i < COB; ++i) g[i] = dy[p * CO + co0 + i];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int iy = yy + ky - pad, ix = xx + kx - pad;
+                const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const float* src = x + ((img + iy) * W + ix) * C;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float v = in ? src[c] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < COB; ++i) acc[(i * C + c) * KK + ky * K + kx] += g[i] * v;
+                }
+            }
+    }
+    __shared__ float red[4][ACC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < ACC; ++a) {
+        float v = acc[a];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wave][a] = v;
+    }
+    __syncthreads();
+    const int cols = CO * C * KK;
+    for (int a = threadIdx.x; a < ACC; a += 256)
+        partial[(size_t)blockIdx.x * cols + co0 * C * KK + a] = (red[0][a] + red[1][a]) + (red[2][a] + red[3][a]);
+}
+
+bool wgrad_small_applicable(int Co, int C, int kh, int kw, int stride, int pad) {
+    static int env = -1;   // VPX_WGRAD_SMALL=0: MFMA kernels for these layers too (experiments)
+    if (env < 0) { const char* e = getenv("VPX_WGRAD_SMALL"); env = e ? atoi(e) : 1; }
+    if (!env || stride != 1 || kh != kw) return false;
+    if (kh == 3 && pad == 1) return (C == 1 && Co % 16 == 0 && Co <= 64) || (C == 3 && Co % 4 == 0 && Co <= 64);
+    if (kh == 1 && pad == 0) return C == 16 && (Co == 1 || Co == 3);
+    return false;
+}
+
+// dw[Co][C][k][k] = sum over (n, y, x) dy[n,y,x,co] * x[n, y + ky - pad, x + kx - pad, c]; partial_ws: WGRAD_SMALL_BLOCKS * Co*C*k*k floats
+hipError_t launch_wgrad_small(const float* dy, const float* x, int N, int H, int W, int Co, int C, int k, int pad, float* partial_ws,
+                              float* dw, hipStream_t s) {
+    const long long npix = (long long)N * H * W;
+    int blocks = WGRAD_SMALL_BLOCKS;
+    if ((npix + 255) / 256 < blocks) blocks = (int)((npix + 255) / 256);
+    const int cols = Co * C * k * k;
+    if (k == 3 && C == 1) hipLaunchKernelGGL((wgrad_small_kernel<16, 1, 3>), dim3(blocks, Co / 16), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
+    else if (k == 3 && C == 3) hipLaunchKernelGGL((wgrad_small_kernel<4, 3, 3>), dim3(blocks, Co / 4), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
+    else if (k == 1 && Co == 1) hipLaunchKernelGGL((wgrad_small_kernel<1, 16, 1>), dim3(blocks, 1), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
+    else if (k == 1 && Co == 3) hipLaunchKernelGGL((wgrad_small_kernel<3, 16, 1>), dim3(blocks, 1), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
+    else return hipErrorInvalidValue;
+    hipLaunchKernelGGL(colsum_l2_kernel, dim3((cols + 15) / 16), dim3(256), 0, s, partial_ws, dw, blocks, cols);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // weight gradient. Work item = (t, b, spatial tile); slice `s` (see wg_block) owns items slice, slice + n_slices, ...
 // LDS: dG tile [128 px][64 rows] (32 KiB) + activation halo tile [halo positions][64 ch].
 // Each wave owns a 32 (rows) x 32 (channels) output block for up to WG_MAXT taps: acc[tap] += dG^T (px-contracted) A_tap.

@@ -303,6 +303,11 @@ struct WgradArgs {
 };
 hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s);
+// few-channel stride-1 layers of the EF glue (1|3 -> Co 3x3 'same', 16 -> 1|3 1x1): direct fp32 sums, no MFMA (lstm_bwd.hip)
+constexpr int WGRAD_SMALL_BLOCKS = 2048;
+bool wgrad_small_applicable(int Co, int C, int kh, int kw, int stride, int pad);
+hipError_t launch_wgrad_small(const float* dy, const float* x, int N, int H, int W, int Co, int C, int k, int pad, float* partial_ws,
+                              float* dw, hipStream_t s);
 // wgrad2.hip: both operands pre-split (3x3, bf16x3); writes slabs [used_slices][9][N4][Ct] like launch_wgrad
 bool wgrad2_applicable(const WgradArgs& a);
 // columns >= *tail_col0 (the half-empty last column tile, if any) were written to the first *tail_slices slabs only
