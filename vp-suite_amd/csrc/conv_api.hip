@@ -293,6 +293,12 @@ namespace {
 int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const float* w, const float* bias, float* y, float* wpk,
                hipStream_t stream, char* y_split) {
     int rc;
+    if (const int kind = conv_small_kind(d)) {   // few-channel layers: streaming kernels (conv_small.hip)
+        if (kind != 2 || !y_split) {
+            VPX_CHECK_HIP(launch_conv_small(d, kind, x, w, bias, y, y_split, stream));
+            return VPX_OK;
+        }
+    }
     if (!d->transposed)  // y[o] = sum_k x[o*s - pad + k] w[k]
         return ex_launch(stream, d, x, w, bias, y, g, g.Ho, g.Wo, d->kh, d->kw, d->stride, -d->pad, -d->pad, nullptr, false,
                          0, 1, 0, 1, 0, wpk, y_split);

@@ -303,6 +303,10 @@ struct WgradArgs {
 };
 hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s);
+// conv_small.hip: the same layers' forward (and the 1x1 adjoint) as streaming kernels; kind from conv_small_kind (0 = not one)
+int conv_small_kind(const vpx_conv_desc* d);
+hipError_t launch_conv_small(const vpx_conv_desc* d, int kind, const float* x, const float* w, const float* bias, float* y, char* y_sp,
+                             hipStream_t s);
 // few-channel stride-1 layers of the EF glue (1|3 -> Co 3x3 'same', 16 -> 1|3 1x1): direct fp32 sums, no MFMA (lstm_bwd.hip)
 constexpr int WGRAD_SMALL_BLOCKS = 2048;
 bool wgrad_small_applicable(int Co, int C, int kh, int kw, int stride, int pad);
