@@ -82,6 +82,9 @@ int vpx_set_deterministic(int on);
  *   VPX_OPT_CELL2        0 = the first-generation fused cell kernel everywhere; 1 (default) = the second-generation kernel
  *                        (pre-split operands, LDS-DMA staging) where it applies and fills the chip; 2 = wherever it applies */
 #define VPX_OPT_CELL2 1
+/*   VPX_OPT_CELL3        small grids (small batch and / or 16x16 - 32x32 maps): 1 (default) = the sliced fused step (8-channel
+ *                        slices, weights resident in LDS, no atomics) where it applies; 0 = K-split convolution + gate kernel */
+#define VPX_OPT_CELL3 2
 int vpx_set_option(int option, int value);
 
 /* ---- ConvLSTM over a sequence ------------------------------------------------------------------------------ */

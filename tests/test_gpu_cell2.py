@@ -116,3 +116,49 @@ def test_set_option_contract(vpx):
     prev = L.vpx_set_option(vpx._lib.OPT_CELL2, 0)
     assert L.vpx_set_option(vpx._lib.OPT_CELL2, prev) == 0
     assert L.vpx_set_option(12345, 1) < 0 and b"unknown option" in L.vpx_last_error()
+
+
+# ---- the small-grid sliced step (csrc/cell3.hip): 16x16-pixel tiles x 8-channel slices, weights resident in LDS ----
+CASES3 = {  # eligible shapes: channels in 16s (<= 96), maps in whole 16x16 tiles, a grid below 256 first-generation workgroups
+    "enc2_b4": (64, 96, 32, 32, 4, 3, True, False, True, 0),
+    "enc3_states": (96, 96, 16, 16, 3, 3, True, True, True, 0),
+    "fore1_noinput": (96, 96, 16, 16, 4, 3, False, True, True, 0),
+    "ifog_nopeep_small": (32, 48, 32, 16, 2, 4, True, True, False, 1),
+    "t1_single_step": (16, 64, 32, 32, 2, 1, True, True, True, 0),
+}
+CASES.update(CASES3)
+
+
+@pytest.fixture
+def cell3_switch(vpx):
+    L = vpx._lib.lib()
+    prev = L.vpx_set_option(vpx._lib.OPT_CELL3, 1)
+
+    def set_mode(v):
+        L.vpx_set_option(vpx._lib.OPT_CELL3, v)
+    yield set_mode
+    L.vpx_set_option(vpx._lib.OPT_CELL3, prev)
+
+
+@pytest.mark.parametrize("tag", list(CASES3))
+def test_cell3_matches_split_path_and_oracle_and_is_reproducible(vpx, cell3_switch, tag):
+    cell3_switch(0)
+    o1, h1, c1, _ = _run(vpx, tag, grads=False)      # K-split convolution + pointwise gate kernel (or the fused first generation)
+    cell3_switch(1)
+    o2, h2, c2, _ = _run(vpx, tag, grads=False)
+    assert _relmax(o2, o1) < 2e-6 and _relmax(c2, c1) < 2e-6 and _relmax(h2, h1) < 2e-6
+    ro, rh, rc, _ = _oracle(tag)
+    assert _relmax(o2, ro) < 2e-5 and _relmax(c2, rc) < 2e-5 and _relmax(h2, rh) < 2e-5
+    o3, h3, c3, _ = _run(vpx, tag, grads=False)      # no atomics on this path: bit-identical from run to run
+    assert torch.equal(o2, o3) and torch.equal(c2, c3)
+
+
+@pytest.mark.parametrize("tag", ["enc2_b4", "enc3_states", "ifog_nopeep_small"])
+def test_cell3_training_path_vs_oracle(vpx, cell3_switch, tag):
+    """cell3 fills the saved-for-backward reserve (gates, cell states); BPTT on top of it against autograd."""
+    cell3_switch(1)
+    out, hT, cT, g = _run(vpx, tag, grads=True)
+    ro, rh, rc, rg = _oracle(tag)
+    assert _relmax(out, ro) < 2e-5
+    for k in rg:
+        assert _relmax(g[k], rg[k]) < 5e-5, k

@@ -19,6 +19,7 @@ FLAG_WEIGHTS_PACKED = 2
 FLAG_X_SPLIT = 4
 
 OPT_CELL2 = 1
+OPT_CELL3 = 2
 
 EXPORTED_SYMBOLS = [
     "vpx_version", "vpx_last_error", "vpx_set_deterministic", "vpx_set_option",

@@ -18,6 +18,7 @@ void set_error(const char* fmt, ...) {
 }
 
 int g_deterministic = 0;
+int g_cell3_mode = -1;
 int g_cell2_mode = -1;
 
 }  // namespace vpx
@@ -33,6 +34,11 @@ int vpx_set_option(int option, int value) {
     if (option == VPX_OPT_CELL2) {
         const int prev = cell2_mode();
         vpx::g_cell2_mode = value < 0 ? 0 : (value > 2 ? 2 : value);
+        return prev;
+    }
+    if (option == VPX_OPT_CELL3) {
+        const int prev = cell3_mode();
+        vpx::g_cell3_mode = value ? 1 : 0;
         return prev;
     }
     set_error("vpx_set_option: unknown option %d", option);
@@ -82,6 +88,9 @@ size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
     if (L.hoist)  // input projection of all steps [B,T,HW,4Ch] + the two weight packs (x columns, h columns)
         fwd += align256(4 * L.n_out * sizeof(float)) + align256(packed_weight_bytes(L.s_tiles, L.hx_chunks, L.s_ng, d->precision)) +
                align256(packed_weight_bytes(L.s_tiles, L.hh_chunks, L.s_ng, d->precision));
+    if (L.v3)  // input projection of all steps + its weight pack + the slice-major recurrent weights + split h0 and a two-slot ring of h_t
+        fwd += align256(4 * L.n_out * sizeof(float)) + align256(packed_weight_bytes(L.s_tiles, L.hx_chunks, L.s_ng, d->precision)) +
+               align256(cell3_packed_bytes(d->Ch)) + 3 * align256(L.n_state * 4);
     if (L.v2)  // packed weights of cell2 + split copies of x, h0 and a two-slot ring of h_t
         fwd += align256(cell2_packed_bytes(L.n_tiles, 3 * ((d->Cin + d->Ch) / 16))) + align256(L.n_x * 4) + 3 * align256(L.n_state * 4);
     if (d->layout == VPX_LAYOUT_NCHW)
@@ -132,6 +141,15 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         pre_all = ws.take(4 * L.n_out);
         wpk_hx = ws.take(packed_weight_bytes(L.s_tiles, L.hx_chunks, L.s_ng, d->precision) / sizeof(float));
         wpk_hh = ws.take(packed_weight_bytes(L.s_tiles, L.hh_chunks, L.s_ng, d->precision) / sizeof(float));
+    }
+    char *wpk3 = nullptr, *h0_sp3 = nullptr, *h_ring3[2] = {nullptr, nullptr};
+    if (L.v3) {
+        pre_all = ws.take(4 * L.n_out);
+        wpk_hx = ws.take(packed_weight_bytes(L.s_tiles, L.hx_chunks, L.s_ng, d->precision) / sizeof(float));
+        wpk3 = (char*)ws.take(cell3_packed_bytes(Ch) / sizeof(float));
+        h0_sp3 = (char*)ws.take(L.n_state);
+        h_ring3[0] = (char*)ws.take(L.n_state);
+        h_ring3[1] = (char*)ws.take(L.n_state);
     }
     char *wpk2 = nullptr, *x_sp = nullptr, *h0_sp = nullptr, *h_ring[2] = {nullptr, nullptr}, *h_sp_all = nullptr;
     if (L.v2) {
@@ -211,9 +229,15 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         pd.tile_stride = 32;
         pd.nch = Ch;
     }
-    if (!L.v2) VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+    if (!L.v2 && !L.v3) VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+    if (L.v3) {
+        Cell3Pack pk{W, Cin, Ch, Cin + Ch, Ch / 8, 9 * Ch / 16, {gp[0], gp[1], gp[2], gp[3]}};
+        VPX_CHECK_HIP(launch_cell3_pack(pk, wpk3, stream));
+        if (h0n) VPX_CHECK_HIP(launch_split_convert(h0n, h0_sp3, (long long)B * (long long)HW, Ch, stream));
+    }
 
-    if (hoist) {
+    const bool hoist_x = hoist || (L.v3 && xn != nullptr);
+    if (hoist_x) {
         // two packs (x columns / h columns of W, reference row order), then W_x * x for all B*T frames in one launch
         PackDesc px{}, ph{};
         px.seg[0] = PackSeg{W, ld_o, L.taps, 0, Cin};
@@ -221,11 +245,13 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         px.nstage = L.hx_nstage; px.chunks_total = L.hx_chunks; px.prec = d->precision; px.taps = L.taps;
         fill_plain_pack(px, 4 * Ch, 0, L.s_ng);
         VPX_CHECK_HIP(launch_pack_weights(px, wpk_hx, stream));
-        ph.seg[0] = PackSeg{W, ld_o, L.taps, Cin, Ch};
-        memcpy(ph.stage, L.hh_stage, sizeof(ConvStage) * L.hh_nstage);
-        ph.nstage = L.hh_nstage; ph.chunks_total = L.hh_chunks; ph.prec = d->precision; ph.taps = L.taps;
-        fill_plain_pack(ph, 4 * Ch, 0, L.s_ng);
-        VPX_CHECK_HIP(launch_pack_weights(ph, wpk_hh, stream));
+        if (hoist) {
+            ph.seg[0] = PackSeg{W, ld_o, L.taps, Cin, Ch};
+            memcpy(ph.stage, L.hh_stage, sizeof(ConvStage) * L.hh_nstage);
+            ph.nstage = L.hh_nstage; ph.chunks_total = L.hh_chunks; ph.prec = d->precision; ph.taps = L.taps;
+            fill_plain_pack(ph, 4 * Ch, 0, L.s_ng);
+            VPX_CHECK_HIP(launch_pack_weights(ph, wpk_hh, stream));
+        }
         ConvPlan PX{};
         PX.B = B * T; PX.H = H; PX.W = Wd; PX.kh = d->kh; PX.kw = d->kw;
         set_plan_tiles(PX, 1);
@@ -287,7 +313,19 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         ea.wci = wci; ea.wcf = wcf; ea.wco = wco;
         ea.h_out = outn + (size_t)t * HW * Ch;
         ea.h_bstride = (long long)((size_t)T * HW * Ch);
-        if (L.v2) {
+        if (L.v3) {
+            Cell3Args c3{};
+            c3.B = B; c3.H = H; c3.W = Wd;
+            c3.h_sp = (t == 0) ? (h0n ? h0_sp3 : nullptr) : h_ring3[(t - 1) & 1];
+            c3.h_bstride = (long long)(HW * Ch * 4);
+            c3.wpk = wpk3;
+            c3.pre = xn ? pre_all + (size_t)t * HW * 4 * Ch : nullptr;
+            c3.pre_bstride = (long long)((size_t)T * HW * 4 * Ch);
+            c3.h_sp_out = (t + 1 < T) ? h_ring3[t & 1] : nullptr;
+            c3.h_sp_out_bstride = (long long)(HW * Ch * 4);
+            c3.ea = ea;
+            VPX_CHECK_HIP(launch_cell3(c3, stream));
+        } else if (L.v2) {
             Cell2Plan P2{};
             P2.B = B; P2.H = H; P2.W = Wd; P2.tiles_x = (Wd + 15) / 16; P2.tiles_y = (H + 31) / 32; P2.n_tiles = L.n_tiles;
             P2.chunks_total = 3 * ((Cin + Ch) / 16);

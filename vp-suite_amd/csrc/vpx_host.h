@@ -111,6 +111,7 @@ static inline bool cell2_applicable(const vpx_convlstm_desc* d) {
 struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     int taps, n_tiles, nstage, chunks_total;
     int v2;                        // 1: the forward steps run on cell2_kernel (pre-split operands)
+    int v3;                        // 1: small grid, the forward steps run on cell3_kernel (8-channel slices, hoisted input projection)
     int mw;                        // forward cell kernel: 32-pixel row tiles per wave
     int qpc, d_qpc;                // k-steps per weight chunk of the forward cell / data-gradient launches (2 or 3)
     ConvStage stage[MAX_STAGE];
@@ -143,13 +144,17 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     if (L.nstage < 0) { set_error("convlstm: too many channel stages (Cin=%d Ch=%d)", d->Cin, d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.split = 0;
     L.hoist = 0;
+    L.v3 = 0;
     {
         const long long m_tiles = (long long)d->B * ((d->H + TILE_H - 1) / TILE_H) * ((d->W + TILE_W - 1) / TILE_W);
         // the fused launch would leave CUs idle (small batches / maps). Measured on MI355X, bf16x3, (96,96,16x16):
         // B=4 (24 workgroups fused) 20 -> 39 TF with the split; B=32 (192 workgroups) 155 -> 164 TF with 2 splits
         static int bar = -1;  // VPX_SPLIT_BAR: experiment override of the workgroup-count bar below
         if (bar < 0) { const char* e = getenv("VPX_SPLIT_BAR"); bar = e ? atoi(e) : 256; }
-        if (m_tiles * L.n_tiles < bar) {
+        static int bar3 = -1;  // VPX_CELL3_BAR: workgroup count of the fused launch below which cell3.hip takes the step (where it applies)
+        if (bar3 < 0) { const char* e = getenv("VPX_CELL3_BAR"); bar3 = e ? atoi(e) : 256; }
+        const bool want3 = m_tiles * L.n_tiles < bar3 && cell3_applicable(d);
+        if (m_tiles * L.n_tiles < bar || want3) {
             const int ng = plain_groups(4 * d->Ch);
             const int tiles = plain_tiles_ng(4 * d->Ch, ng);
             // grids this small never have more than ~1 workgroup per CU, so LDS residency is no argument for small stages:
@@ -157,7 +162,7 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
             int cs = pick_stage_channels(segC, 2, d->kh, d->kw, ng, d->precision);
             if (cs < 32) cs = 32;
             L.s_nstage = build_stages(L.s_stage, &L.s_chunks, segC, 2, L.taps, cs, d->precision);
-            const int ks = L.s_nstage > 0 ? pick_ksplit(m_tiles * tiles, L.s_nstage) : 1;
+            const int ks = (L.s_nstage > 0 && m_tiles * L.n_tiles < bar) ? pick_ksplit(m_tiles * tiles, L.s_nstage) : 1;
             if (ks > 1) { L.split = ks; L.s_ng = ng; L.s_tiles = tiles; }
             L.hoist = 0;
             static int hoist_on = -1;  // VPX_HOIST=0 disables (experiments)
@@ -171,9 +176,15 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
                     L.hoist = 1;
                 }
             }
+            // third form (cell3.hip): no K split, no atomics — preferred wherever its shape limits allow
+            if (want3) {
+                const int sx[1] = {d->Cin};
+                L.hx_nstage = build_stages(L.hx_stage, &L.hx_chunks, sx, 1, L.taps, pick_stage_channels(sx, 1, d->kh, d->kw, ng, d->precision), d->precision);
+                if (L.hx_nstage > 0) { L.v3 = 1; L.split = 0; L.hoist = 0; L.s_ng = ng; L.s_tiles = tiles; }
+            }
         }
     }
-    L.v2 = (!L.split && cell2_applicable(d)) ? 1 : 0;
+    L.v2 = (!L.split && !L.v3 && cell2_applicable(d)) ? 1 : 0;
     L.n_state = (size_t)d->B * d->H * d->W * d->Ch;
     L.n_x = (size_t)d->B * d->T * d->H * d->W * d->Cin;
     L.n_out = (size_t)d->B * d->T * d->H * d->W * d->Ch;

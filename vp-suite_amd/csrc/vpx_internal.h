@@ -154,6 +154,24 @@ struct Conv2Args {
 hipError_t launch_conv2_pack(const Conv2Pack& pk, void* dst, hipStream_t s);
 hipError_t launch_conv2(const Conv2Args& c, hipStream_t s);
 
+// ---- small-grid fused cell (cell3.hip): 16x16-pixel tiles x 8-channel slices, the slice's recurrent weights resident in LDS,
+//      the input projection hoisted (enters through `pre`) ----
+struct Cell3Pack { const float* w; int Cin, Ch, Ct, n_slices, nk; int gate_pos[4]; };
+struct Cell3Args {
+    int B, H, W, tiles_x, tiles_y, n_slices, nk, _p;
+    const char* h_sp; long long h_bstride;       // h_{t-1}, split format [B][HW][Ch], BYTES between batch items; null = zero state
+    const char* wpk;                              // cell3_pack_kernel output
+    const float* pre; long long pre_bstride;      // W_x * x_t of this step [b][HW][4Ch] (reference gate order), ELEMENTS between batch items; or null
+    char* h_sp_out; long long h_sp_out_bstride;   // split h_t for the next step (or null), BYTES
+    ConvLSTMStepArgs ea;
+};
+extern int g_cell3_mode;   // vpx_api.hip: -1 = not yet read from the environment (VPX_CELL3), else 0 / 1 (vpx_set_option)
+int cell3_mode();
+bool cell3_applicable(const vpx_convlstm_desc* d);
+size_t cell3_packed_bytes(int Ch);
+hipError_t launch_cell3_pack(const Cell3Pack& pk, void* dst, hipStream_t s);
+hipError_t launch_cell3(const Cell3Args& args, hipStream_t s);
+
 // pointwise half of the K-split step: pre-activations pre [B*HW, 4Ch] (reference gate order) -> gates, c, h (pointwise.hip)
 hipError_t launch_convlstm_pointwise(const ConvLSTMStepArgs& ea, const float* pre, int B, long long HW, hipStream_t s,
                                      long long pre_bstride = 0);  // elements between batch items of pre (0 = dense)
