@@ -161,8 +161,16 @@ __global__ __launch_bounds__(256) void colsum_l2_kernel(const float* __restrict_
     const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
     float sum = 0.f;
-    if (c < cols)
-        for (int r = g; r < nrows; r += 16) sum += partial[(size_t)r * cols + c];
+    if (c < cols) {   // four independent partial sums per thread (rows g + 16k, k mod 4), fixed combination order
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        int r = g;
+        for (; r + 48 < nrows; r += 64) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k] += partial[(size_t)(r + 16 * k) * cols + c];
+        }
+        for (int k = 0; r < nrows; r += 16, ++k) p[k] += partial[(size_t)r * cols + c];
+        sum = (p[0] + p[1]) + (p[2] + p[3]);
+    }
     comb[g][cx] = sum;
     __syncthreads();
     if (g == 0 && c < cols) {
@@ -1198,7 +1206,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
     float acc = 0.f;
     const size_t slab_sz = (size_t)taps * N4 * Ct;
     const int ns = c >= tail_col0 ? tail_slices : n_slices;   // wgrad2: the half-empty last column tile runs on fewer slices
-    for (int s = 0; s < ns; ++s) acc += slabs[(size_t)s * slab_sz + e];
+    // eight independent partial sums (slab s -> sum s % 8), combined in a fixed order: the serial chain kept one load in flight
+    // per thread (62 us on average for 30-150 MB of slabs; bit-reproducible either way)
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* src = slabs + e;
+    int s = 0;
+    for (; s + 8 <= ns; s += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] += src[(size_t)(s + k) * slab_sz];
+    }
+    for (int k = 0; s < ns; ++s, ++k) p[k] += src[(size_t)s * slab_sz];
+    acc = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     dW[((size_t)n * Ct + c) * real_taps + dst_tap] = acc;
 }
 
