@@ -142,8 +142,14 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
     const int g_off = ((n0 + g_sl * 8) >> 3) * 32;                         // byte offset inside the dG pixel row (plane u adds (u>>1)*256 + (u&1)*16)
     const bool g_ok0 = n0 + g_sl * 8 < a.N4, g_ok1 = n0 + 64 + g_sl * 8 < a.N4;
     const unsigned g_prow = (unsigned)a.N4 * 4u;
+    // Addresses = a per-item SCALAR base (image of (t, b) + the tile's origin) + a per-thread 32-bit offset fixed for the whole
+    // launch: a copy costs two adds and a select per piece (the first version redid a 64-bit multiply chain per piece and item,
+    // ~250 vector instructions per item and wave next to its 120 MFMAs).
+    const unsigned g_toff = (unsigned)((g_px >> 4) * a.W + (g_px & 15)) * g_prow + (unsigned)g_off;
     // activations: pieces tid + 512 u of [hi plane | lo plane], 8 pieces per halo position
-    int pc_hyx[4], pc_off[4];   // (row << 16) | column of the halo position, -1: none; (half << 16) | byte offset inside that half's pixel row
+    int pc_hyx[4];        // (row << 16) | column of the halo position, -1: none
+    unsigned pc_toff[4];  // (hy * W + hx) * bytes-per-pixel of its half + the byte offset of its 8 channels (hi or lo)
+    bool pc_h1[4];        // the piece belongs to the tile's second half
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int piece = tid + 512 * u;
@@ -151,18 +157,21 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
         const int qq = piece - plane * W2_NPOS * 8;
         const int pos = qq >> 3;
         const int sl = (w2_swz(pos * 128 + (qq & 7) * 16) & 127) >> 4;     // logical slot = 8 channels of the 64-channel row
-        const int hy = pos / W2_HALO_W;
+        const int hy = pos / W2_HALO_W, hx = pos - hy * W2_HALO_W;
         const WgradCHalf hf = (sl >> 2) ? ch1 : ch0;
         const bool ok = piece < W2_APIECES && (sl & 3) * 8 < hf.cn;
-        pc_hyx[u] = ok ? ((hy << 16) | (pos - hy * W2_HALO_W)) : -1;
-        pc_off[u] = ((sl >> 2) << 16) | (((hf.c0 + (sl & 3) * 8) >> 3) * 32 + plane * 16);
+        const unsigned prow_h = (unsigned)(hf.seg == 0 ? a.Cin : a.Ch) * 4u;
+        pc_hyx[u] = ok ? ((hy << 16) | hx) : -1;
+        pc_toff[u] = (unsigned)(hy * a.W + hx) * prow_h + (unsigned)(((hf.c0 + (sl & 3) * 8) >> 3) * 32 + plane * 16);
+        pc_h1[u] = (sl >> 2) != 0;
     }
+    const unsigned prow0 = (unsigned)(ch0.seg == 0 ? a.Cin : a.Ch) * 4u, prow1 = (unsigned)(ch1.seg == 0 ? a.Cin : a.Ch) * 4u;
     auto dma_item = [&](const Item& it, char* buf) {
         const int y0 = it.ty * W2_TH, x0 = it.tx * 16;
         {
-            const int gy = y0 + (g_px >> 4), gx = x0 + (g_px & 15);
-            const bool pix_ok = (gy < a.H) & (gx < a.W);   // (bitwise on purpose, here and below: selects, not divergent branches)
-            const char* row = a.g_sp + (((size_t)it.t * a.B + it.b) * a.HW + (size_t)(gy * a.W + gx)) * g_prow + g_off;
+            const bool pix_ok = (y0 + (g_px >> 4) < a.H) & (x0 + (g_px & 15) < a.W);   // (bitwise on purpose, here and below: selects, not divergent branches)
+            const char* const gbase = a.g_sp + (((size_t)it.t * a.B + it.b) * a.HW + (size_t)(y0 * a.W + x0)) * g_prow;   // scalar
+            const char* row = gbase + g_toff;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool ok = pix_ok & ((u >> 1) ? g_ok1 : g_ok0);
@@ -170,30 +179,27 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
                 w2_dma16(src, buf + u * W2_GPL + wave * 1024);
             }
         }
-        // per half: base of this (t, b) image in its split tensor and bytes per pixel row; null = the half stages zeros
+        // per half (scalar): the (t, b) image of its split tensor shifted to the halo origin (y0 - 1, x0 - 1) — only dereferenced
+        // for positions inside the image; null = the half stages zeros (unused half, or no hidden state at t = 0)
         const char* base[2];
-        int prow_b[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const WgradCHalf hf = h ? ch1 : ch0;
-            base[h] = nullptr; prow_b[h] = 0;
+            base[h] = nullptr;
             if (hf.cn == 0) continue;
-            if (hf.seg == 0) { base[h] = a.x_sp + (size_t)it.b * a.x_sp_bstride + (size_t)it.t * a.x_sp_tstride; prow_b[h] = a.Cin * 4; }
-            else {
-                prow_b[h] = a.Ch * 4;
-                if (it.t > 0) base[h] = a.h_sp + (size_t)(it.t - 1) * a.h_sp_tstride + (size_t)it.b * a.h_sp_bstride;
-                else if (a.h0_sp) base[h] = a.h0_sp + (size_t)it.b * a.HW * a.Ch * 4;
-            }
+            if (hf.seg == 0) base[h] = a.x_sp + (size_t)it.b * a.x_sp_bstride + (size_t)it.t * a.x_sp_tstride;
+            else if (it.t > 0) base[h] = a.h_sp + (size_t)(it.t - 1) * a.h_sp_tstride + (size_t)it.b * a.h_sp_bstride;
+            else if (a.h0_sp) base[h] = a.h0_sp + (size_t)it.b * a.HW * a.Ch * 4;
         }
+        const long long org = (long long)(y0 - 1) * a.W + (x0 - 1);
+        const bool ok0 = base[0] != nullptr, ok1 = base[1] != nullptr;
+        const char* const ab0 = ok0 ? base[0] + org * (long long)prow0 : nullptr;
+        const char* const ab1 = ok1 ? base[1] + org * (long long)prow1 : nullptr;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bool h = (pc_off[u] >> 16) != 0;
-            const char* const bs = h ? base[1] : base[0];
-            const int pr = h ? prow_b[1] : prow_b[0];
             const int gy = y0 - 1 + (pc_hyx[u] >> 16), gx = x0 - 1 + (pc_hyx[u] & 0xffff);
-            const bool ok = (pc_hyx[u] >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (bs != nullptr);
-            const char* src = ok ? bs + (size_t)((unsigned)(gy * a.W + gx) * (unsigned long long)(unsigned)pr) + (pc_off[u] & 0xffff)
-                                 : reinterpret_cast<const char*>(w2_zero16);
+            const bool ok = (pc_hyx[u] >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (pc_h1[u] ? ok1 : ok0);
+            const char* src = ok ? (pc_h1[u] ? ab1 : ab0) + pc_toff[u] : reinterpret_cast<const char*>(w2_zero16);
             if (512 * u + wave * 64 < W2_APIECES)   // (wave-uniform: 1728 = 27 waves' worth of pieces)
                 w2_dma16(src, buf + W2_A0 + (512 * u + wave * 64) * 16);
         }
