@@ -251,3 +251,29 @@ def test_backward_weight_pack_reuse_matches_repacking(vpx, monkeypatch):
             o.step()
     for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert (p1 - p2).abs().max() < 1e-6, n1
+
+
+@pytest.mark.gpu
+def test_layernorm_cell_pack_reuse_follows_parameter_updates(vpx):
+    """The LayerNorm ST-LSTM keeps its five weight packs and the transposed LayerNorm parameters in the cell's workspace while
+    (data_ptr, _version) of all of them are unchanged (VPX_FLAG_WEIGHTS_PACKED): an in-place update of a LayerNorm weight or
+    of a convolution weight must be seen by the next call."""
+    import copy
+    from vp_suite_amd.model_blocks import SpatioTemporalLSTMCell
+    Cin, Ch, H, W, k, ln, B = gc.STLSTM_CASES["ln"]
+    cell = SpatioTemporalLSTMCell(Cin, Ch, H, W, k, 1, ln)
+    fill_state_dict_(cell, name_seed("stlstm.ln"))
+    cell = cell.cuda()
+    inp = {n: v.cuda() for n, v in gc.stlstm_inputs("ln", Cin, Ch, H, W, B).items()}
+    args = (inp["x"], inp["h"], inp["c"], inp["m"])
+    with torch.no_grad():
+        o1 = cell(*args)
+        o1b = cell(*args)                      # packs and transposed parameters re-used
+        assert _relmax(o1b[0], o1[0]) < 1e-6
+        cell.conv_h[1].weight.mul_(1.5)        # LayerNorm gamma of conv_h, in place
+        cell.conv_x[0].weight.mul_(0.5)        # a convolution weight, in place
+        o2 = cell(*args)
+        fresh = copy.deepcopy(cell)            # pickled state drops the workspace: packs from scratch
+        o3 = fresh(*args)
+    assert _relmax(o2[0], o3[0]) < 1e-6 and _relmax(o2[1], o3[1]) < 1e-6
+    assert _relmax(o2[0], o1[0]) > 1e-3

@@ -51,7 +51,7 @@ size_t stlstm_ln_workspace_bytes(const vpx_stlstm_desc* d) {
     const size_t per_sample = align256(s.HW * d->Ch * 4);
     size_t fwd = 19 * plane + 30 * per_sample;
     size_t bwd = 28 * plane + 60 * per_sample + align256(s.slab_floats * 4);
-    size_t b = (fwd > bwd ? fwd : bwd) + align256(s.wpk_max * 4) + align256((size_t)d->B * 64 * 2 * 8) + align256((size_t)d->B * 2 * 4);
+    size_t b = (fwd > bwd ? fwd : bwd) + 5 * align256(s.wpk_max * 4) + align256((size_t)d->B * 64 * 2 * 8) + align256((size_t)d->B * 2 * 4);
     if (d->layout == VPX_LAYOUT_NCHW) b += 2 * align256(s.n_x * 4) + 14 * plane;
     return b + 64 * 256;  // alignment slack of the individual carves
 }
@@ -72,13 +72,13 @@ static LNReserve carve_reserve(void* reserve, const STLN& s) {
 }
 
 // transposes the 8 LN parameter tensors ([C,H,W] -> [HW,C]); order x_g,x_b,h_g,h_b,m_g,m_b,o_g,o_b
-static int ln_params_nhwc(const float* const* ln, float* dst[8], Carver& ws, const STLN& s, hipStream_t stream) {
+static int ln_params_nhwc(const float* const* ln, float* dst[8], Carver& ws, const STLN& s, hipStream_t stream, bool cached = false) {
     const int mult[4] = {7, 4, 3, 1};
     for (int i = 0; i < 8; ++i) {
         const int C = mult[i / 2] * s.Ch;
         dst[i] = ws.take(s.HW * C);
         if (!ln[i]) { set_error("stlstm (layer_norm): LayerNorm parameter %d is NULL", i); return VPX_ERR_ARG; }
-        VPX_CHECK_HIP(launch_nchw_to_nhwc(ln[i], dst[i], 1, C, s.H, s.W, stream));
+        if (!cached) VPX_CHECK_HIP(launch_nchw_to_nhwc(ln[i], dst[i], 1, C, s.H, s.W, stream));
     }
     return VPX_OK;
 }
@@ -93,7 +93,14 @@ int stlstm_ln_fwd(const vpx_stlstm_desc* d, const float* x, const float* h, cons
     const bool save = (d->flags & VPX_FLAG_SAVE_FOR_BWD) != 0;
     LNReserve R{};
     if (save) R = carve_reserve(reserve, s);
-    float* wpk = ws.take(s.wpk_max);
+    // VPX_FLAG_WEIGHTS_PACKED: the caller kept this workspace since a call with the same weights, LayerNorm parameters and desc —
+    // the five weight packs (one region each) and the transposed LayerNorm parameters are still in it (first carves: fixed offsets)
+    const bool packed = (d->flags & VPX_FLAG_WEIGHTS_PACKED) != 0;
+    float* wpk5[5];
+    for (auto& p : wpk5) p = ws.take(s.wpk_max);
+    float* lnp[8];
+    int rc;
+    if ((rc = ln_params_nhwc(ln, lnp, ws, s, stream, packed))) return rc;
     double* partial = (double*)ws.take((size_t)B * 64 * 2 * 2);
     float* st_tmp = ws.take((size_t)8 * B);
     float* xc = ws.take(7 * s.n_state);
@@ -103,17 +110,14 @@ int stlstm_ln_fwd(const vpx_stlstm_desc* d, const float* x, const float* h, cons
     float* oc = ws.take(s.n_state);
     float* lc = ws.take(s.n_state);
     float* mem_ws = ws.take(2 * s.n_state);
-    float* lnp[8];
-    int rc;
-    if ((rc = ln_params_nhwc(ln, lnp, ws, s, stream))) return rc;
     float* mem = save ? R.mem : mem_ws;
     const long long n1 = (long long)s.HW * Ch;
     // conv_x / conv_h / conv_m, each followed by its own LayerNorm (predrnn.py:58-60 with :24-36)
-    if ((rc = plain_conv(stream, prec, g, x, Cin, Cin, Wx, (long long)Cin * k * k, k * k, k, k, 7 * Ch, false, nullptr, xc, 7 * Ch, false, wpk))) return rc;
+    if ((rc = plain_conv(stream, prec, g, x, Cin, Cin, Wx, (long long)Cin * k * k, k * k, k, k, 7 * Ch, false, nullptr, xc, 7 * Ch, false, wpk5[0], 0.0f, packed))) return rc;
     VPX_CHECK_HIP(launch_layernorm_fwd(xc, lnp[0], lnp[1], xc, save ? R.xhat_x : nullptr, save ? R.st_x : st_tmp, partial, B, 7 * n1, stream));
-    if ((rc = plain_conv(stream, prec, g, h, Ch, Ch, Wh, (long long)Ch * k * k, k * k, k, k, 4 * Ch, false, nullptr, hc, 4 * Ch, false, wpk))) return rc;
+    if ((rc = plain_conv(stream, prec, g, h, Ch, Ch, Wh, (long long)Ch * k * k, k * k, k, k, 4 * Ch, false, nullptr, hc, 4 * Ch, false, wpk5[1], 0.0f, packed))) return rc;
     VPX_CHECK_HIP(launch_layernorm_fwd(hc, lnp[2], lnp[3], hc, save ? R.xhat_h : nullptr, save ? R.st_h : st_tmp + 2 * B, partial, B, 4 * n1, stream));
-    if ((rc = plain_conv(stream, prec, g, m, Ch, Ch, Wm, (long long)Ch * k * k, k * k, k, k, 3 * Ch, false, nullptr, mc, 3 * Ch, false, wpk))) return rc;
+    if ((rc = plain_conv(stream, prec, g, m, Ch, Ch, Wm, (long long)Ch * k * k, k * k, k, k, 3 * Ch, false, nullptr, mc, 3 * Ch, false, wpk5[2], 0.0f, packed))) return rc;
     VPX_CHECK_HIP(launch_layernorm_fwd(mc, lnp[4], lnp[5], mc, save ? R.xhat_m : nullptr, save ? R.st_m : st_tmp + 4 * B, partial, B, 3 * n1, stream));
     STLNGateArgs ga{};
     ga.npix = (long long)B * s.HW; ga.Ch = Ch; ga.xc = xc; ga.hc = hc; ga.mc = mc; ga.c = c; ga.m = m;
@@ -121,9 +125,9 @@ int stlstm_ln_fwd(const vpx_stlstm_desc* d, const float* x, const float* h, cons
     ga.gates_c = save ? R.gates_c : nullptr; ga.gates_m = save ? R.gates_m : nullptr;
     VPX_CHECK_HIP(launch_st_ln_gates(ga, stream));
     // conv_o(mem) + LayerNorm, conv_last(mem)   (predrnn.py:80-81)
-    if ((rc = plain_conv(stream, prec, g, mem, 2 * Ch, 2 * Ch, Wo, (long long)2 * Ch * k * k, k * k, k, k, Ch, false, nullptr, oc, Ch, false, wpk))) return rc;
+    if ((rc = plain_conv(stream, prec, g, mem, 2 * Ch, 2 * Ch, Wo, (long long)2 * Ch * k * k, k * k, k, k, Ch, false, nullptr, oc, Ch, false, wpk5[3], 0.0f, packed))) return rc;
     VPX_CHECK_HIP(launch_layernorm_fwd(oc, lnp[6], lnp[7], oc, save ? R.xhat_o : nullptr, save ? R.st_o : st_tmp + 6 * B, partial, B, n1, stream));
-    if ((rc = plain_conv(stream, prec, g, mem, 2 * Ch, 2 * Ch, Wlast, (long long)2 * Ch, 1, 1, 1, Ch, false, nullptr, lc, Ch, false, wpk))) return rc;
+    if ((rc = plain_conv(stream, prec, g, mem, 2 * Ch, 2 * Ch, Wlast, (long long)2 * Ch, 1, 1, 1, Ch, false, nullptr, lc, Ch, false, wpk5[4], 0.0f, packed))) return rc;
     VPX_CHECK_HIP(launch_st_ln_out(o_pre, oc, lc, h_new, save ? R.o : nullptr, save ? R.tl : nullptr, (long long)s.n_state, stream));
     return VPX_OK;
 }

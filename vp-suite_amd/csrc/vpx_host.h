@@ -244,7 +244,7 @@ struct ConvGeo { int N, H, W; };
 // y (+)= conv(src; w) with Co outputs; `transposed`: contraction over w's O axis (data gradient). Returns packed floats used.
 static inline int plain_conv(hipStream_t stream, int prec, ConvGeo g, const float* src, int C, int ld, const float* w, long long ld_o,
                int ld_i, int kh, int kw, int Co, bool transposed, const float* bias, float* out, int out_ld,
-               bool accumulate, float* wpk, float leaky = 0.0f) {
+               bool accumulate, float* wpk, float leaky = 0.0f, bool weights_packed = false) {
     ConvPlan P{};
     int chunks = 0;
     const int segC[1] = {C};
@@ -259,7 +259,7 @@ static inline int plain_conv(hipStream_t stream, int prec, ConvGeo g, const floa
     pd.nstage = P.nstage; pd.chunks_total = chunks; pd.prec = prec; pd.taps = kh * kw;
     fill_plain_pack(pd, Co, 0, ng);
     pd.transposed = transposed ? 1 : 0; pd.flip = transposed ? 1 : 0;
-    VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+    if (!weights_packed) VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));   // (else: wpk still holds this layer's pack of an earlier call)
     P.B = g.N; P.H = g.H; P.W = g.W; P.kh = kh; P.kw = kw;
     set_plan_tiles(P, 1);
     P.nseg = 1;

@@ -576,8 +576,9 @@ class _STLSTMStepFn(torch.autograd.Function):
         if ws_bytes == 0:
             check(-4 if b"not implemented" in L.vpx_last_error() else -1, "vpx_stlstm_workspace_bytes")
         rs_bytes = L.vpx_stlstm_reserve_bytes(ctypes.byref(d))
-        key = (B, Cin, Ch, H, Wd, k, precision, flags, _det_state, tuple((w.data_ptr(), w._version) for w in W5))
-        if wsholder is not None and not use_ln:
+        key = (B, Cin, Ch, H, Wd, k, precision, flags, _det_state, tuple((w.data_ptr(), w._version) for w in W5),
+               tuple((t.data_ptr(), t._version) for t in lnc))
+        if wsholder is not None:
             ws, packed = wsholder.get(ws_bytes, dev, key)
         else:
             ws, packed = torch.empty(ws_bytes, dtype=torch.uint8, device=dev), False
