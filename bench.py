@@ -206,7 +206,8 @@ def roofline(spec, ps):
         "frac": round(ach_tflops / peak, 4), "traffic": measured_traffic(spec),
         "algorithmic_bytes_per_launch": round(ps["bytes"] / launches),
         "kernel": ((f"cell2_kernel (second-generation fused ConvLSTM cell step: pre-split bf16x3 operands, LDS-DMA staging; "
-                    f"conv_gemm_kernel<EpiConvLSTM> on 16x16 maps and small grids), forward" if spec.precision == "bf16x3" else
+                    f"conv_gemm_kernel<EpiConvLSTM> on 16x16 maps at large batch; cell3_kernel — 8-channel slices, hoisted input "
+                    f"projection — on grids below 256 workgroups), forward" if spec.precision == "bf16x3" else
                     f"conv_gemm_kernel<EpiConvLSTM, {spec.precision}> (fused ConvLSTM cell step, forward)")
                    if spec.model == "convlstm-shi" else
                    f"conv_gemm_kernel<EpiSTGate/EpiSTOut/EpiPlain, {spec.precision}> (ST-LSTM cell step, forward)"),
