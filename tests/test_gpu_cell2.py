@@ -162,3 +162,37 @@ def test_cell3_training_path_vs_oracle(vpx, cell3_switch, tag):
     assert _relmax(out, ro) < 2e-5
     for k in rg:
         assert _relmax(g[k], rg[k]) < 5e-5, k
+
+
+@pytest.mark.parametrize("tag,force2", [("enc2_b4", 0), ("fore1_states", 2)])
+def test_c_abi_nchw_layout_on_operand_format_kernels(vpx, cell2_switch, cell3_switch, tag, force2):
+    """The raw C ABI on reference-layout (NCHW) buffers, bf16x3, at shapes the small-grid kernel (cell3) resp. the second-generation
+    kernel (cell2 forward, conv2 data gradient) take: forward + backward against the oracle's autograd."""
+    import ctypes
+    L = vpx._lib.lib()
+    cell3_switch(1)
+    cell2_switch(force2 if force2 else 1)
+    Cin, Ch, H, W, B, T, with_x, with_state, peep, order = CASES[tag]
+    inp = {k: (None if v is None else v.cuda().contiguous()) for k, v in _inputs(tag).items()}
+    d = vpx._lib.ConvLSTMDesc(B, T, Cin, Ch, H, W, 3, 3, order, vpx._lib.LAYOUT_NCHW, vpx._lib.PREC_BF16X3, vpx._lib.FLAG_SAVE_FOR_BWD)
+    ws_bytes, rs_bytes = L.vpx_convlstm_workspace_bytes(ctypes.byref(d)), L.vpx_convlstm_reserve_bytes(ctypes.byref(d))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    rs = torch.empty(rs_bytes, dtype=torch.uint8, device="cuda")
+    out = torch.empty(B, T, Ch, H, W, device="cuda")
+    hT, cT = torch.empty(B, Ch, H, W, device="cuda"), torch.empty(B, Ch, H, W, device="cuda")
+    p = vpx._lib.ptr
+    rc = L.vpx_convlstm_seq_fwd(ctypes.byref(d), p(inp["x"]), p(inp["h0"]), p(inp["c0"]), p(inp["W"]), p(inp["b"]), p(inp["Wci"]),
+                                p(inp["Wcf"]), p(inp["Wco"]), p(out), p(hT), p(cT), p(rs), rs_bytes, p(ws), ws_bytes, None)
+    assert rc == 0, L.vpx_last_error()
+    names = [("dx", "x"), ("dh0", "h0"), ("dc0", "c0"), ("dW", "W"), ("db", "b"), ("dWci", "Wci"), ("dWcf", "Wcf"), ("dWco", "Wco")]
+    G = {n: (torch.empty_like(inp[m]) if inp[m] is not None else None) for n, m in names}
+    rc = L.vpx_convlstm_seq_bwd(ctypes.byref(d), p(inp["x"]), p(inp["h0"]), p(inp["c0"]), p(inp["W"]), p(inp["Wci"]), p(inp["Wcf"]),
+                                p(inp["Wco"]), p(out), p(rs), rs_bytes, p(inp["g_out"]), None, p(inp["g_cT"]), *[p(G[n]) for n, _ in names],
+                                p(ws), ws_bytes, None)
+    assert rc == 0, L.vpx_last_error()
+    torch.cuda.synchronize()
+    ro, rh, rc_, rg = _oracle(tag)
+    assert _relmax(out, ro) < 2e-5 and _relmax(cT, rc_) < 2e-5 and _relmax(hT, rh) < 2e-5
+    for n, m in names:
+        if G[n] is not None and m in rg:
+            assert _relmax(G[n], rg[m]) < 5e-5, n
