@@ -52,6 +52,14 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         dG_sp_all = (char*)ws.take((size_t)T * L.n_state * 4);
         wpk2 = (char*)ws.take(cell2_packed_bytes(conv2_tiles(Ct), 3 * (N4 / 16)) / sizeof(float));
     }
+    const bool wsp = wgrad2_wsp(d, L) && dW != nullptr;   // forward on another kernel, weight gradient on wgrad2 all the same
+    char *xsp_w = nullptr, *hsp_w = nullptr, *h0sp_w = nullptr;
+    if (wgrad2_wsp(d, L)) {
+        dG_sp_all = (char*)ws.take((size_t)T * L.n_state * 4);
+        xsp_w = (char*)ws.take(L.n_x);
+        hsp_w = (char*)ws.take(L.n_out);
+        h0sp_w = (char*)ws.take(L.n_state);
+    }
 
     // ---- layout adaptation ----
     const float *xn = x, *h0n = h0, *c0n = c0, *outn = out, *doutn = dout, *dhTn = dhT, *dcTn = dcT;
@@ -138,7 +146,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         ga.wci = wci; ga.wcf = wcf; ga.wco = wco;
         ga.dwci = dpeep ? dwci : nullptr; ga.dwcf = dpeep ? dwcf : nullptr; ga.dwco = dpeep ? dwco : nullptr;
         ga.dG = need_dG_f32 ? dG_all + (size_t)t * L.n_state * 4 : nullptr;
-        ga.dG_sp = c2d ? dG_sp_all + (size_t)t * L.n_state * 16 : nullptr;
+        ga.dG_sp = (c2d || wsp) ? dG_sp_all + (size_t)t * L.n_state * 16 : nullptr;
         ga.db_partial = db ? db_part + (size_t)t * gb_blocks * N4 : nullptr;
         VPX_CHECK_HIP(launch_gate_bwd(ga, stream));
 
@@ -195,10 +203,19 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
             r += align256(L.n_state * 4);
             wa.h_sp = r; wa.h_sp_bstride = (long long)(HW * Ch * 4); wa.h_sp_tstride = (long long)(L.n_state * 4);
         }
+        if (wsp) {   // operands in split form, laid out like x / out ([B][T][HW][C]); conversions are one pass each over small tensors
+            if (xn) VPX_CHECK_HIP(launch_split_convert(xn, xsp_w, (long long)B * T * (long long)HW, Cin, stream));
+            VPX_CHECK_HIP(launch_split_convert(outn, hsp_w, (long long)B * T * (long long)HW, Ch, stream));
+            if (h0n) VPX_CHECK_HIP(launch_split_convert(h0n, h0sp_w, (long long)B * (long long)HW, Ch, stream));
+            wa.a_split = 1;
+            wa.x_sp = xn ? xsp_w : nullptr; wa.x_sp_bstride = (long long)((size_t)T * HW * Cin * 4); wa.x_sp_tstride = (long long)(HW * Cin * 4);
+            wa.h0_sp = h0n ? h0sp_w : nullptr;
+            wa.h_sp = hsp_w; wa.h_sp_bstride = (long long)((size_t)T * HW * Ch * 4); wa.h_sp_tstride = (long long)(HW * Ch * 4);
+        }
         wa.slabs = slabs;
         // every launched tile stores all of its slab elements; only the skipped x columns need a clear
         if (!xn) VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, L.slab_floats * sizeof(float), stream));
-        wa.g_sp = c2d ? dG_sp_all : nullptr;
+        wa.g_sp = (c2d || wsp) ? dG_sp_all : nullptr;
         int ns_used = L.n_slices, tail_col0 = Ct, tail_slices = L.n_slices;
         if (wgrad2_applicable(wa)) VPX_CHECK_HIP(launch_wgrad2(wa, L.n_slices, &ns_used, &tail_col0, &tail_slices, stream));
         else VPX_CHECK_HIP(launch_wgrad(wa, L.n_slices, stream));

@@ -134,6 +134,15 @@ struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     size_t slab_floats;
 };
 
+// Blocks whose FORWARD did not run on the operand-format kernel (16x16 maps, small grids) still take the wgrad2 weight gradient:
+// the backward converts x, the output sequence and h0 to the split format itself (small tensors there) and the gate-backward
+// kernel writes dG in both forms. VPX_WGRAD2_WSP=0 disables.
+static inline bool wgrad2_wsp(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("VPX_WGRAD2_WSP"); env = e ? atoi(e) : 1; }
+    return env && !L.v2 && d->precision == VPX_PREC_BF16X3 && d->kh == 3 && d->kw == 3 && (d->Cin & 7) == 0 && (d->Ch & 7) == 0;
+}
+
 static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L) {
     L.taps = d->kh * d->kw;
     L.n_tiles = (d->Ch + 31) / 32;
@@ -211,7 +220,7 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
         if (ns > 256) ns = 256;
         if (ns < 1) ns = 1;
         L.n_slices = (int)ns;
-        if (L.v2) {   // wgrad2.hip: 128-row tiles (half the tiles per slice) and, with a half-empty last column tile, up to 2x the slices
+        if (L.v2 || wgrad2_wsp(d, L)) {   // wgrad2.hip: 128-row tiles (half the tiles per slice) and, with a half-empty last column tile, up to 2x the slices
             const long long ns2 = 1024 / (((N4 + 127) / 128) * L.n_ctiles);
             if (ns2 > L.n_slices) L.n_slices = (int)(ns2 < items ? ns2 : items);
             if (L.n_slices < 2) L.n_slices = 2;
@@ -231,6 +240,8 @@ static inline size_t convlstm_bwd_workspace_bytes(const vpx_convlstm_desc* d, co
     b += align256((size_t)COLSUM_BLOCKS * 4 * d->Ch * sizeof(float));                                // ... and their second level
     if (L.v2)  // dG of all steps in split operand format + the conv2 weight pack of the data gradient
         b += align256((size_t)d->T * L.n_state * 16) + align256(cell2_packed_bytes(conv2_tiles(d->Cin + d->Ch), 3 * (4 * d->Ch / 16)));
+    if (wgrad2_wsp(d, L))  // split dG of all steps + split copies of x, the output sequence and h0
+        b += align256((size_t)d->T * L.n_state * 16) + align256(L.n_x * 4) + align256(L.n_out * 4) + align256(L.n_state * 4);
     if (d->layout == VPX_LAYOUT_NCHW) {
         // staged copies of x, out, dout, dx + states (h0,c0,dhT,dcT,dh0,dc0) + 6 peephole-sized buffers
         b += 2 * align256(L.n_x * 4) + 2 * align256(L.n_out * 4) + 6 * align256(L.n_state * 4) + 6 * align256(L.n_peep * 4);
