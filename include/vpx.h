@@ -51,8 +51,8 @@ enum { VPX_PREC_F32 = 0    /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 operands 
 enum { VPX_FLAG_X_SPLIT = 4 /* ConvLSTM forward: `x` holds the input sequence in the split-bf16 operand format (below) instead of
                               fp32 — only where vpx_convlstm_takes_split_input() says so; saves the conversion pass */,
        VPX_FLAG_SAVE_FOR_BWD = 1 /* forward fills `reserve` (gate activations + cell states per step) */,
-       VPX_FLAG_WEIGHTS_PACKED = 2 /* ST-LSTM: `workspace` still holds the repacked weights of a previous call with the
-                                      SAME weight values and desc (caller keeps one workspace per cell per forward; the
+       VPX_FLAG_WEIGHTS_PACKED = 2 /* ST-LSTM: `workspace` still holds the repacked weights (LayerNorm variant, forward: and the
+                                      transposed LayerNorm parameters) of a previous call with the SAME values and desc (caller keeps one workspace per cell per forward; the
                                       backward has its own workspace and additionally needs the same set of requested
                                       data gradients dx / dh / dm as the call that packed) */ };
 
