@@ -38,6 +38,26 @@ def test_workspace_queries_run_without_gpu(vpx):
     assert b"odd" in L.vpx_last_error()
 
 
+def test_workspace_queries_follow_the_kernel_selection(vpx):
+    """The size queries (pure host logic, no GPU) reflect which kernel a descriptor gets: the second-generation cell keeps split
+    copies of its operands in the reserve and takes split input; the small-grid kernel needs the hoisted input projection of
+    all steps in the workspace and takes fp32 input; the backward of either carries dG of all steps in split format too."""
+    L = vpx._lib.lib()
+    BF16X3, SAVE = vpx._lib.PREC_BF16X3, vpx._lib.FLAG_SAVE_FOR_BWD
+    def desc(B, T, Cin, Ch, H, W, flags):
+        return vpx._lib.ConvLSTMDesc(B, T, Cin, Ch, H, W, 3, 3, 0, vpx._lib.LAYOUT_NHWC, BF16X3, flags)
+    big, small = desc(128, 10, 64, 64, 64, 64, 0), desc(4, 10, 64, 96, 32, 32, 0)
+    assert L.vpx_convlstm_takes_split_input(ctypes.byref(big)) == 1       # cell2: 2048 workgroups
+    assert L.vpx_convlstm_takes_split_input(ctypes.byref(small)) == 0     # cell3: small grid
+    n_state, n_x = 128 * 64 * 64 * 64, 128 * 10 * 64 * 64 * 64
+    rs = L.vpx_convlstm_reserve_bytes(ctypes.byref(desc(128, 10, 64, 64, 64, 64, SAVE)))
+    assert rs >= 10 * n_state * 5 * 4 + n_x * 4 + n_state * 4 + 10 * n_state * 4   # gates + c, then x, h0, h_1..h_T split
+    ws_small = L.vpx_convlstm_workspace_bytes(ctypes.byref(small))
+    assert ws_small >= 4 * (4 * 10 * 32 * 32 * 96) * 4                    # W_x * x of all steps: [B,T,HW,4Ch] fp32
+    ws_fwd, ws_bwd = L.vpx_convlstm_workspace_bytes(ctypes.byref(big)), L.vpx_convlstm_workspace_bytes(ctypes.byref(desc(128, 10, 64, 64, 64, 64, SAVE)))
+    assert ws_bwd >= ws_fwd and ws_bwd >= 2 * 10 * n_state * 16          # dG of all steps, fp32 and split
+
+
 def test_conv_desc_layout_and_shape_calculus(vpx):
     """The ctypes mirror of vpx_conv_desc matches the C struct (every field influences the C side's answer), and the
     output-shape rules are those of nn.Conv2d / nn.ConvTranspose2d (ef_blocks.py:15-49 builds exactly these layers)."""
