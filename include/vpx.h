@@ -85,6 +85,11 @@ int vpx_set_deterministic(int on);
 /*   VPX_OPT_CELL3        small grids (small batch and / or 16x16 - 32x32 maps): 1 (default) = the sliced fused step (8-channel
  *                        slices, weights resident in LDS, no atomics) where it applies; 0 = K-split convolution + gate kernel */
 #define VPX_OPT_CELL3 2
+/*   VPX_OPT_MFMA_SHAPE   bf16 MFMA shape of the second-generation kernels' main loop (fused cell step, its data gradient): 0 =
+ *                        v_mfma_f32_32x32x16_bf16, 1 = v_mfma_f32_16x16x32_bf16 (K = 32 steps pair two taps of a 16-channel
+ *                        stage; same wave tile, same LDS traffic, the chip holds a higher clock on it). Same products, same
+ *                        operand split: results differ in fp32 summation order only */
+#define VPX_OPT_MFMA_SHAPE 3
 int vpx_set_option(int option, int value);
 
 /* ---- ConvLSTM over a sequence ------------------------------------------------------------------------------ */

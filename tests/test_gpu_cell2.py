@@ -196,3 +196,54 @@ def test_c_abi_nchw_layout_on_operand_format_kernels(vpx, cell2_switch, cell3_sw
     for n, m in names:
         if G[n] is not None and m in rg:
             assert _relmax(G[n], rg[m]) < 5e-5, n
+
+
+# ---- the 16x16x32 MFMA form of the second-generation main loop (cell2_kernel_q: fused step and conv2 data gradient) ----
+CASESQ = {  # full 32x16 tiles and whole 32-channel tiles for the fused step; the K = 32 steps pair taps over the PRESENT stages
+    "q_enc1_oddx": (16, 64, 64, 32, 2, 3, True, False, True, 0),      # x-only pack at t = 0 (S = 1), odd x|h boundary (S = 5)
+    "q_odd_total_states": (48, 64, 32, 32, 2, 2, True, True, True, 0),  # S = 7: the last period has no odd stage
+    "q_enc2": (64, 96, 32, 32, 2, 3, True, False, True, 0),
+    "q_fore3_noinput": (96, 96, 32, 32, 2, 3, False, True, True, 0),   # h-only pack
+    "q_ifog_nopeep": (32, 32, 32, 48, 2, 3, True, True, False, 1),
+    "q_t1_nostate": (32, 64, 32, 16, 3, 1, True, False, True, 0),      # a single step, x only
+}
+CASES.update(CASESQ)
+
+
+@pytest.fixture
+def shape_switch(vpx):
+    L = vpx._lib.lib()
+    prev = L.vpx_set_option(vpx._lib.OPT_MFMA_SHAPE, 0)
+
+    def set_mode(v):
+        L.vpx_set_option(vpx._lib.OPT_MFMA_SHAPE, v)
+    yield set_mode
+    L.vpx_set_option(vpx._lib.OPT_MFMA_SHAPE, prev)
+
+
+@pytest.mark.parametrize("tag", list(CASESQ))
+def test_mfma_16x16x32_form_matches_32x32x16_form_and_oracle(vpx, cell2_switch, shape_switch, tag):
+    cell2_switch(2)
+    shape_switch(0)
+    o1, h1, c1, _ = _run(vpx, tag, grads=False)
+    shape_switch(1)
+    o2, h2, c2, _ = _run(vpx, tag, grads=False)
+    assert _relmax(o2, o1) < 2e-6 and _relmax(c2, c1) < 2e-6 and _relmax(h2, h1) < 2e-6   # same products, other summation order
+    assert not torch.equal(o2, o1)    # ... and it really is another kernel
+    ro, rh, rc, _ = _oracle(tag)
+    assert _relmax(o2, ro) < 2e-5 and _relmax(c2, rc) < 2e-5 and _relmax(h2, rh) < 2e-5
+    o3, _, c3, _ = _run(vpx, tag, grads=False)
+    assert torch.equal(o2, o3) and torch.equal(c2, c3)   # no atomics: bit-identical run to run
+
+
+@pytest.mark.parametrize("tag", ["q_enc1_oddx", "q_odd_total_states", "q_ifog_nopeep", "enc1_ragged", "fore1_states"])
+def test_mfma_16x16x32_training_path_vs_oracle(vpx, cell2_switch, shape_switch, tag):
+    """Forward on the q-form cell where it applies (enc1_ragged: ragged map, so only the data gradient takes the q form —
+    its epilogue handles partial tiles), conv2 data gradient on the q form: every gradient against autograd."""
+    cell2_switch(2)
+    shape_switch(1)
+    out, hT, cT, g = _run(vpx, tag, grads=True)
+    ro, rh, rc, rg = _oracle(tag)
+    assert _relmax(out, ro) < 2e-5
+    for k in rg:
+        assert _relmax(g[k], rg[k]) < 5e-5, k

@@ -37,6 +37,10 @@ constexpr int C2_ABUF = 4 * C2_PLANE;           // 40960 B
 constexpr int C2_WCHUNK = 3 * 2 * 2 * 128 * 16; // 24576 B
 constexpr int C2_LDS = 2 * C2_ABUF + 3 * C2_WCHUNK;  // 155648 B <= 160 KiB
 
+// 16x16x32 form ("q form", cell2_kernel_q below): same activation stage image; one weight chunk = one K = 32 step
+constexpr int CQ_WCHUNK = 2 * 4 * 128 * 16;     // 16384 B: [part][k group = tap half * 2 + channel half][n = gate*32 + j][16 B]
+constexpr int CQ_LDS = 2 * C2_ABUF + 3 * CQ_WCHUNK;  // 131072 B (the epilogue's transposition space needs 8 x 16 KiB as well)
+
 __device__ const float c2_zero16[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};  // source of out-of-image pieces
 
 __device__ __forceinline__ unsigned short c2_bf16_bits(float v) {
@@ -76,6 +80,37 @@ hipError_t launch_split_convert(const float* src, void* dst, long long npix, int
 
 // ---------------------------------------------------------------------------------------------------------------
 // weight repack: reference OIHW [4Ch, Cin+Ch, 3, 3] -> [n_tile][chunk = stage*3 + dy][q = dx][part][khalf][n][8 bf16]
+// step p (0..8) of a two-stage period, lane half tsel (k groups 0,1 | 2,3): which stage of the period (0 even, 1 odd) and tap
+__host__ __device__ constexpr int cq_stage_of(int p, int tsel) { return p < 4 ? 0 : (p == 4 ? tsel : 1); }
+__host__ __device__ constexpr int cq_tap_of(int p, int tsel) { return p < 4 ? 2 * p + tsel : (p == 4 ? (tsel ? 0 : 8) : 2 * (p - 5) + 1 + tsel); }
+
+// q form: [n_tile][step q][part][k group][n][8 bf16] over the present stage sequence pk.stage_col[0 .. S-1]
+__global__ void cell2_pack_q_kernel(const Cell2Pack pk, char* __restrict__ dst) {
+    const long long total = (long long)pk.n_tiles * pk.chunks_total * (CQ_WCHUNK / 2);  // bf16 elements
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e & 7);
+        long long r = e >> 3;
+        const int n = (int)(r & 127); r >>= 7;
+        const int kg = (int)(r & 3); r >>= 2;
+        const int part = (int)(r & 1); r >>= 1;
+        const int q = (int)(r % pk.chunks_total);
+        const int n_tile = (int)(r / pk.chunks_total);
+        const int p = q % 9, tsel = kg >> 1, khalf = kg & 1;
+        const int stage = 2 * (q / 9) + cq_stage_of(p, tsel), tap = cq_tap_of(p, tsel);
+        const int g = n >> 5, j = n & 31;
+        const int ch = n_tile * 32 + j;
+        float v = 0.0f;
+        if (ch < pk.Ch && stage < pk.S) {
+            const int row = pk.gate_pos[g] * pk.Ch + ch;
+            const int col = pk.stage_col[stage] + khalf * 8 + i;   // column in [x | h]
+            v = pk.w[((long long)row * pk.Ct + col) * 9 + tap];
+        }
+        unsigned hi, lo;
+        c2_split(v, hi, lo);
+        reinterpret_cast<unsigned short*>(dst)[e] = (unsigned short)(part ? lo : hi);
+    }
+}
+
 __global__ void cell2_pack_kernel(const Cell2Pack pk, char* __restrict__ dst) {
     const long long total = (long long)pk.n_tiles * pk.chunks_total * (C2_WCHUNK / 2);  // bf16 elements
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -103,14 +138,16 @@ __global__ void cell2_pack_kernel(const Cell2Pack pk, char* __restrict__ dst) {
 }
 
 hipError_t launch_cell2_pack(const Cell2Pack& pk, void* dst, hipStream_t s) {
-    const long long total = (long long)pk.n_tiles * pk.chunks_total * (C2_WCHUNK / 2);
+    const long long total = (long long)pk.n_tiles * pk.chunks_total * ((pk.qform ? CQ_WCHUNK : C2_WCHUNK) / 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(cell2_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
+    if (pk.qform) hipLaunchKernelGGL(cell2_pack_q_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
+    else hipLaunchKernelGGL(cell2_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
     return hipGetLastError();
 }
 
 size_t cell2_packed_bytes(int n_tiles, int chunks_total) { return (size_t)n_tiles * chunks_total * C2_WCHUNK; }
+size_t cell2_packed_bytes_q(int n_tiles, int S) { return (size_t)n_tiles * cell2_qchunks(S) * CQ_WCHUNK; }
 
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void c2_dma16(const char* g, char* lds_wave_base) {
@@ -120,9 +157,12 @@ __device__ __forceinline__ void c2_dma16(const char* g, char* lds_wave_base) {
     // — the MFMA loop then waited for the fragments it had just requested (72 % matrix-pipe use by a lone wave, measured).
     // Hidden in asm, the loop's ds_reads get counted waits; the DMA's own completion is waited for by hand (C2_WAIT_VM)
     // at the sync points, and compiler-made vmcnt waits (epilogue loads) only become stricter by the extra queue entries.
+    // M0 is an INPUT operand bound to the physical register ("{m0}"): the compiler emits the s_mov to m0 itself and knows
+    // about it — nothing reserved is clobbered behind its back. The s_nop covers the "SALU writes M0 -> LDS-DMA" wait state,
+    // which the hazard recognizer cannot see through the asm.
     const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds)) : "memory", "m0");
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(g), "{m0}"(__builtin_amdgcn_readfirstlane(lds)) : "memory");
 }
 
 __device__ __forceinline__ int c2_px(int i) { return (i & 16) ? ((i + 14) & 15) : (i & 15); }
@@ -243,6 +283,7 @@ struct Cell2Epi {
     // (accumulators -> LDS), vec_math (LDS -> gates -> c, h, split h).
     struct VecIn { unsigned eo[4]; f32x4 cp[4], wi[4], wf[4], wo[4]; };
 
+    template <bool ROT = true>   // ROT: the 32x32x16 loop's pixel map (odd row rotated, c2_px); else pixel slot ip = row * 16 + column
     __device__ __forceinline__ void vec_load(VecIn& v, int b, int y0, int x0, int n_tile, int prow, int lane, int H, int W) const {
         const unsigned Ch = (unsigned)a.Ch;
         const int cg = lane & 7, p4 = lane >> 3;
@@ -254,7 +295,7 @@ struct Cell2Epi {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int ip = k * 8 + p4;                               // pixel slot 0..31 of the sub-tile
-            const int pix = rowpix + (ip >> 4) * W + c2_px(ip);
+            const int pix = rowpix + (ip >> 4) * W + (ROT ? c2_px(ip) : (ip & 15));
             v.eo[k] = __umul24((unsigned)pix, Ch) + ch;
             v.cp[k] = cin_b ? *reinterpret_cast<const f32x4*>(cin_b + v.eo[k]) : zero;
             v.wi[k] = a.wci ? *reinterpret_cast<const f32x4*>(a.wci + v.eo[k]) : zero;
@@ -333,6 +374,35 @@ struct Cell2Epi {
         }
     }
 
+    // 16x16x32 accumulators: acc[m][nt] = tile row m (16 pixels) x column tile nt (gate nt >> 1, channels (nt & 1) * 16 ..); a
+    // lane holds column lane & 15 of pixels 4 * (lane >> 4) .. + 3. Rows 2*mp, 2*mp + 1 fill the same [gate][pixel 32][32 ch] image.
+    __device__ __forceinline__ void vec_put16(const f32x4 (&acc)[4][8], int mp, char* lds, int lane) const {
+        const int c16 = lane & 15, q4 = lane >> 4;
+        float* ldsf = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ldsf[(nt >> 1) * 1024 + (mm * 16 + 4 * q4 + r) * 32 + (nt & 1) * 16 + c16] = acc[2 * mp + mm][nt][r];
+    }
+
+    // (the q form is only selected for tiles inside the image and whole 32-channel tiles: cell2_q_applicable)
+    __device__ __forceinline__ void finish16(const f32x4 (&acc)[4][8], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
+                                             int /*ngr*/, int H, int W) const {
+        const int prow = 4 * wave;
+        char* const lds = smem + wave * 16384;
+        VecIn v0, v1;
+        vec_load<false>(v0, b, y0, x0, n_tile, prow, lane, H, W);
+        c2_barrier();   // every wave has read its last fragments: the staging buffers become the epilogue's transposition space
+        vec_put16(acc, 0, lds, lane);
+        vec_load<false>(v1, b, y0, x0, n_tile, prow + 2, lane, H, W);
+        vec_math(v0, lds, b, n_tile, lane, H, W);
+        vec_put16(acc, 1, lds, lane);
+        vec_math(v1, lds, b, n_tile, lane, H, W);
+    }
+
     __device__ __forceinline__ void finish(const f32x16 (&acc)[2][4], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
                                            int /*ngr*/, int H, int W, bool stamp_on = false) const {
         const int j = lane & 31, hh = lane >> 5;
@@ -378,60 +448,85 @@ struct Conv2Epi {
     float* out0; long long bstride0; int ld0, _p0;
     float* out1; long long bstride1; int ld1, _p1;
 
-    __device__ __forceinline__ void finish(const f32x16 (&acc)[2][4], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
-                                           int ngr, int H, int W, bool = false) const {
-        c2_barrier();
-        float* ldsf = reinterpret_cast<float*>(smem + wave * 16384);
-        const int j = lane & 31, hh = lane >> 5, cg = lane & 7, p4 = lane >> 3;
+    // stores one 32-pixel sub-tile (tile rows prow, prow + 1) from the wave's [group][pixel 32][32 ch] LDS image
+    template <bool ROT>
+    __device__ __forceinline__ void store_sub(const float* ldsf, int lane, int b, int y0, int x0, int n_tile, int ngr, int prow, int H, int W) const {
+        const int cg = lane & 7, p4 = lane >> 3;
         const bool v4 = ((Co | split | ld0 | ld1) & 3) == 0;
         float* const o0 = out0 ? out0 + (size_t)b * bstride0 : nullptr;
         float* const o1 = out1 ? out1 + (size_t)b * bstride1 : nullptr;
 #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g >= ngr) continue;
+            const int c = (n_tile * gpt + g) * 32 + cg * 4;
+            if (c >= Co) continue;
+            const bool first = c < split;
+            float* const ob = first ? o0 : o1;
+            const unsigned ld = (unsigned)(first ? ld0 : ld1);
+            const int cc = first ? c : c - split;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ip = k * 8 + p4;
+                const int y = y0 + prow + (ip >> 4), x = x0 + (ROT ? c2_px(ip) : (ip & 15));
+                f32x4 v = *reinterpret_cast<const f32x4*>(ldsf + g * 1024 + ip * 32 + cg * 4);
+                if (y >= H || x >= W) continue;
+                const size_t e = (size_t)__umul24((unsigned)(y * W + x), ld) + cc;
+                if (v4) {
+                    if (!ob) continue;
+                    if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
+                    if (accumulate) v += *reinterpret_cast<const f32x4*>(ob + e);
+                    *reinterpret_cast<f32x4*>(ob + e) = v;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cq = c + q;
+                        if (cq >= Co) continue;
+                        const bool f1 = cq < split;
+                        float* const oq = f1 ? o0 : o1;
+                        if (!oq) continue;
+                        const size_t eq = (size_t)__umul24((unsigned)(y * W + x), (unsigned)(f1 ? ld0 : ld1)) + (f1 ? cq : cq - split);
+                        float val = v[q] + (bias ? bias[cq] : 0.f);
+                        if (accumulate) val += oq[eq];
+                        oq[eq] = val;
+                    }
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void finish(const f32x16 (&acc)[2][4], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
+                                           int ngr, int H, int W, bool = false) const {
+        c2_barrier();
+        float* ldsf = reinterpret_cast<float*>(smem + wave * 16384);
+        const int j = lane & 31, hh = lane >> 5;
+#pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const int prow = 4 * wave + 2 * m;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (g < ngr)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ldsf[g * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + j] = acc[m][g][r];
             // (LDS operations of one wave execute in order: no barrier between these writes and the reads below)
+            store_sub<true>(ldsf, lane, b, y0, x0, n_tile, ngr, 4 * wave + 2 * m, H, W);
+        }
+    }
+
+    __device__ __forceinline__ void finish16(const f32x4 (&acc)[4][8], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
+                                             int ngr, int H, int W) const {
+        c2_barrier();
+        float* ldsf = reinterpret_cast<float*>(smem + wave * 16384);
+        const int c16 = lane & 15, q4 = lane >> 4;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g >= ngr) continue;
-                const int c = (n_tile * gpt + g) * 32 + cg * 4;
-                if (c >= Co) continue;
-                const bool first = c < split;
-                float* const ob = first ? o0 : o1;
-                const unsigned ld = (unsigned)(first ? ld0 : ld1);
-                const int cc = first ? c : c - split;
+        for (int mp = 0; mp < 2; ++mp) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int ip = k * 8 + p4;
-                    const int y = y0 + prow + (ip >> 4), x = x0 + c2_px(ip);
-                    f32x4 v = *reinterpret_cast<const f32x4*>(ldsf + g * 1024 + ip * 32 + cg * 4);
-                    if (y >= H || x >= W) continue;
-                    const size_t e = (size_t)__umul24((unsigned)(y * W + x), ld) + cc;
-                    if (v4) {
-                        if (!ob) continue;
-                        if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
-                        if (accumulate) v += *reinterpret_cast<const f32x4*>(ob + e);
-                        *reinterpret_cast<f32x4*>(ob + e) = v;
-                    } else {
+            for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int cq = c + q;
-                            if (cq >= Co) continue;
-                            const bool f1 = cq < split;
-                            float* const oq = f1 ? o0 : o1;
-                            if (!oq) continue;
-                            const size_t eq = (size_t)__umul24((unsigned)(y * W + x), (unsigned)(f1 ? ld0 : ld1)) + (f1 ? cq : cq - split);
-                            float val = v[q] + (bias ? bias[cq] : 0.f);
-                            if (accumulate) val += oq[eq];
-                            oq[eq] = val;
-                        }
-                    }
-                }
-            }
+                for (int nt = 0; nt < 8; ++nt)
+                    if ((nt >> 1) < ngr)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            ldsf[(nt >> 1) * 1024 + (mm * 16 + 4 * q4 + r) * 32 + (nt & 1) * 16 + c16] = acc[2 * mp + mm][nt][r];
+            store_sub<false>(ldsf, lane, b, y0, x0, n_tile, ngr, 4 * wave + 2 * mp, H, W);
         }
     }
 };
@@ -636,16 +731,188 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
     C2_STAMP(42);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same main loop on v_mfma_f32_16x16x32_bf16 ("q form"). Same workgroup tile (32x16 pixels x 128 columns), same wave tile
+// (4 tile rows x 128 columns = 32 accumulator tiles of 16x16: 128 registers), same activation stage image, same fragment bytes
+// read from LDS per MFMA cycle — but the chip holds a higher clock on this MFMA shape (MI355X_MICROARCH.md, DVFS give-back (7):
+// 1.12-1.14x the FLOP/s at equal cycles per FLOP), and the clock, not issue, bounds the 32x32x16 loop (1.81 GHz measured).
+//   K = 32 step: k groups (lane >> 4) 0,1 = channel halves of tap tA, 2,3 = channel halves of tap tB of ONE 16-channel stage
+//   (cell2_pack_q_kernel has the schedule); the lane's fragment address is base_kind(lane) + immediate, base kinds = the three
+//   slot distances tB - tA that occur (1, 16, and the cross step's "other buffer").
+//   M tile = one tile row (16 pixels): no column rotation needed, fragment reads are conflict-free as they stand.
+//   Weight ring: three 16 KiB chunks (one step each); sync point S_q before the 6th of the 8 column tiles of step q: wait for
+//   the own pieces of chunk q+1 -> barrier -> copy of chunk q+2 (its slot was last read in step q-1), and at steps 0 / 5 of a
+//   period the copy of the period's odd stage / the next period's even stage (buffers last read in steps 8 / 4).
+//   Fragments: one activation set (4 rows x hi/lo), refilled for step q+1 row by row behind the last column tile's MFMAs;
+//   two weight sets (column tile nt + 1 is read before the MFMAs of nt).
+struct CQFrags { bf16x8 ah[4], al[4], bh[2], bl[2]; };
+
+__host__ __device__ constexpr int cq_slot(int tap) { return (tap / 3) * C2_HALO_W + tap % 3; }
+__host__ __device__ constexpr int cq_kind(int p) { return p == 4 ? 2 : ((p == 1 || p == 7) ? 1 : 0); }   // slot distance tB - tA: 1 | 16 | other buffer
+__host__ __device__ constexpr int cq_aoff(int p) { return (p >= 5 ? C2_ABUF : 0) + cq_slot(cq_tap_of(p, 0)) * 16; }
+
+template <class Epi, bool ALLG>
+__global__ __launch_bounds__(512, 2) void cell2_kernel_q(const Cell2Plan P, const Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+
+    const unsigned L = blockIdx.x;
+    const long long total = (long long)P.grid_m * P.n_tiles;
+    const long long per_xcd = (total + 7) / 8;
+    const long long sidx = (long long)(L & 7) * per_xcd + (L >> 3);
+    if ((long long)(L >> 3) >= per_xcd || sidx >= total) return;
+    int mt = (int)(sidx / P.n_tiles);
+    const int n_tile = (int)(sidx - (long long)mt * P.n_tiles);
+    const int tx = mt % P.tiles_x;
+    mt /= P.tiles_x;
+    const int ty = mt % P.tiles_y;
+    const int b = mt / P.tiles_y;
+    const int x0 = tx * 16, y0 = ty * 32;
+    int ngr = 4;
+    if constexpr (!ALLG) { ngr = P.n_groups - n_tile * P.gpt; if (ngr > P.gpt) ngr = P.gpt; }
+
+    char* const Abuf = smem;
+    char* const Wbuf = smem + 2 * C2_ABUF;
+
+    int pixoff[5], choff[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int piece = tid + 512 * u;
+        const int plane = piece / C2_PLANE_POS, pos = piece - plane * C2_PLANE_POS;
+        const int hy = pos / C2_HALO_W, hx = pos - hy * C2_HALO_W;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = pos < C2_NPOS && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+        pixoff[u] = ok ? gy * P.W + gx : -1;
+        choff[u] = (plane & 1) * 32 + (plane >> 1) * 16;
+    }
+    const int dma_off = (wave * 64) * 16;
+    const char* const wtile = P.wpk + (size_t)n_tile * P.chunks_total * CQ_WCHUNK + tid * 16;
+
+    const int nx = P.nx, S = P.nx + P.nh, Q = (9 * S + 1) / 2;
+    const char* const xb = P.seg[0].sp + (size_t)b * P.seg[0].bstride;
+    const char* const hb = P.seg[1].sp + (size_t)b * P.seg[1].bstride;
+    const unsigned xrow = (unsigned)P.seg[0].C * 4u, hrow = (unsigned)P.seg[1].C * 4u;
+    auto issue_A1 = [&](int s, int buf, int u) {
+        const bool isx = s < nx;
+        const char* base = isx ? xb + s * 64 : hb + (s - nx) * 64;
+        const unsigned prow = isx ? xrow : hrow;
+        const char* src = pixoff[u] >= 0 ? base + (size_t)((unsigned)pixoff[u] * (unsigned long long)prow) + choff[u]
+                                         : reinterpret_cast<const char*>(c2_zero16);
+        c2_dma16(src, Abuf + buf * C2_ABUF + dma_off + u * 8192);
+    };
+    auto issue_W1 = [&](int chunk, int slot, int u) {
+        c2_dma16(wtile + (size_t)chunk * CQ_WCHUNK + u * 8192, Wbuf + slot * CQ_WCHUNK + dma_off + u * 8192);
+    };
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][nt][r] = 0.0f;
+
+    // lane bases into the activation buffers (tap (0,0), tile row 4 * wave, buffer 0, hi plane): k group = tap half * 2 + channel half
+    const int a_lane = (kg & 1) * C2_PLANE + ((4 * wave) * C2_HALO_W + r16) * 16;
+    const int base1 = a_lane + (kg >> 1) * 16;                        // tB one slot right of tA
+    const int base16 = a_lane + (kg >> 1) * 256;                      // tB = (dy + 1, dx - 2): 16 slots further
+    const int baseX = a_lane + (kg >> 1) * (C2_ABUF - cq_slot(8) * 16);  // cross step: tap 0 of the odd stage (buffer 1)
+    const int w_lane = kg * 2048 + r16 * 16;
+    CQFrags F;
+    auto load_A1 = [&](int p, int m, int bx) {   // activation fragments (hi, lo) of tile row m for period step p
+        const int base = cq_kind(p) == 0 ? base1 : (cq_kind(p) == 1 ? base16 : bx);
+        const char* a = smem + base + cq_aoff(p) + m * (C2_HALO_W * 16);
+        F.ah[m] = *reinterpret_cast<const bf16x8*>(a);
+        F.al[m] = *reinterpret_cast<const bf16x8*>(a + 2 * C2_PLANE);
+    };
+    auto load_B = [&](int slot, int nt) {        // weight fragments (hi, lo) of column tile nt -> set nt & 1
+        const char* w = Wbuf + slot * CQ_WCHUNK + w_lane + nt * 256;
+        F.bh[nt & 1] = *reinterpret_cast<const bf16x8*>(w);
+        F.bl[nt & 1] = *reinterpret_cast<const bf16x8*>(w + 8192);
+    };
+
+    if (S > 0) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) issue_A1(0, 0, u);
+        issue_W1(0, 0, 0); issue_W1(0, 0, 1);
+        if (Q > 1) { issue_W1(1, 1, 0); issue_W1(1, 1, 1); C2_WAIT_VM(2); }
+        else C2_WAIT_VM(0);
+        c2_barrier();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) load_A1(0, m, a_lane);
+        load_B(0, 0);
+    }
+    for (int s0 = 0; s0 < S; s0 += 2) {
+        const bool odd = s0 + 1 < S;         // the period's odd stage exists
+        const bool more = s0 + 2 < S;        // another period follows
+        const int q0 = (s0 >> 1) * 9;
+        const int bx = odd ? baseX : a_lane;  // without an odd stage the cross step's second half multiplies zero weights: read valid data
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            if (p < 5 || odd) {
+                const int q = q0 + p;
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    if (nt == 5) {
+                        // ---- sync point S_q ----
+                        if ((p == 1 && odd) || (p == 6 && more)) C2_WAIT_VM(5); else C2_WAIT_VM(0);   // the stage copy issued one step ago may still fly
+                        c2_barrier();
+                    }
+                    // ---- weight fragments of the next column tile ----
+                    //      (after the last step these reads, like the row refills below, fetch bytes nobody uses: cheaper than a branch)
+                    if (nt < 7) load_B(p % 3, nt + 1);
+                    else load_B((p + 1) % 3, 0);
+                    // ---- 12 MFMAs of column tile nt ----
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        if (ALLG || nt < 2 * ngr) {
+                            f32x4 c = acc[m][nt];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.al[m], F.bh[nt & 1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bl[nt & 1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bh[nt & 1], c, 0, 0, 0);
+                            acc[m][nt] = c;
+                        }
+                        // the last column tile frees row m's fragments: refill them for the next step
+                        if (nt == 7) load_A1(p == 8 ? 0 : p + 1, m, bx);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                    // ---- this sync point's copies, behind the MFMAs of column tiles 5..7: the weight chunk first, then the stage ----
+                    if (nt == 5 && q + 2 < Q) { issue_W1(q + 2, (p + 2) % 3, 0); issue_W1(q + 2, (p + 2) % 3, 1); }
+                    if (p == 0 && odd) {
+                        if (nt == 6) { issue_A1(s0 + 1, 1, 0); issue_A1(s0 + 1, 1, 1); }
+                        if (nt == 7) { issue_A1(s0 + 1, 1, 2); issue_A1(s0 + 1, 1, 3); issue_A1(s0 + 1, 1, 4); }
+                    }
+                    if (p == 5 && more) {
+                        if (nt == 6) { issue_A1(s0 + 2, 0, 0); issue_A1(s0 + 2, 0, 1); }
+                        if (nt == 7) { issue_A1(s0 + 2, 0, 2); issue_A1(s0 + 2, 0, 3); issue_A1(s0 + 2, 0, 4); }
+                    }
+                }
+            }
+        }
+    }
+    epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+}
+
 template <class Epi, bool ALLG>
 static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel<Epi, ALLG>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG>), hipFuncAttributeMaxDynamicSharedMemorySize, CQ_LDS);
+        if (e != hipSuccess) return e;
         attr_set = true;
     }
     Cell2Plan p = plan;
     p.grid_m = plan.B * plan.tiles_x * plan.tiles_y;
+    if (plan.qform) {
+        const long long per_xcd_q = ((long long)p.grid_m * p.n_tiles + 7) / 8;
+        hipLaunchKernelGGL((cell2_kernel_q<Epi, ALLG>), dim3((unsigned)(per_xcd_q * 8)), dim3(512), CQ_LDS, s, p, epi);
+        return hipGetLastError();
+    }
 #ifdef VPX_ABLATE
     { const char* e = getenv("VPX_C2_STAMP_BLOCK"); p._p = e ? atoi(e) : -1; }
 #endif
@@ -688,11 +955,43 @@ __global__ void conv2_pack_kernel(const Conv2Pack pk, char* __restrict__ dst) {
     }
 }
 
+// q form of the same pack: [n_tile][step q][part][k group][n][8 bf16], steps as in cell2_pack_q_kernel over the C / 16 stages
+__global__ void conv2_pack_q_kernel(const Conv2Pack pk, int S, char* __restrict__ dst) {
+    const long long total = (long long)pk.n_tiles * pk.chunks_total * (CQ_WCHUNK / 2);  // bf16 elements
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e & 7);
+        long long r = e >> 3;
+        const int n = (int)(r & 127); r >>= 7;
+        const int kg = (int)(r & 3); r >>= 2;
+        const int part = (int)(r & 1); r >>= 1;
+        const int q = (int)(r % pk.chunks_total);
+        const int n_tile = (int)(r / pk.chunks_total);
+        const int p = q % 9, tsel = kg >> 1, khalf = kg & 1;
+        const int stage = 2 * (q / 9) + cq_stage_of(p, tsel), t = cq_tap_of(p, tsel);
+        const int g = n >> 5, j = n & 31;
+        const int oc = (n_tile * pk.gpt + g) * 32 + j;
+        float v = 0.0f;
+        if (g < pk.gpt && oc < pk.Co && stage < S) {
+            const int ic = stage * 16 + khalf * 8 + i;
+            const int tap = pk.flip ? 8 - t : t;
+            v = pk.w[(long long)ic * pk.s_ic + (long long)(pk.col0 + oc) * pk.s_oc + tap];
+        }
+        unsigned hi, lo;
+        c2_split(v, hi, lo);
+        reinterpret_cast<unsigned short*>(dst)[e] = (unsigned short)(part ? lo : hi);
+    }
+}
+
 hipError_t launch_conv2_pack(const Conv2Pack& pk, void* dst, hipStream_t s) {
-    const long long total = (long long)pk.n_tiles * pk.chunks_total * (C2_WCHUNK / 2);
+    const long long total = (long long)pk.n_tiles * pk.chunks_total * ((pk.qform ? CQ_WCHUNK : C2_WCHUNK) / 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(conv2_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
+    if (pk.qform) {
+        const int S = (2 * pk.chunks_total) / 9;   // chunks_total = cell2_qchunks(S)
+        hipLaunchKernelGGL(conv2_pack_q_kernel, dim3(blocks), dim3(256), 0, s, pk, S, reinterpret_cast<char*>(dst));
+    } else {
+        hipLaunchKernelGGL(conv2_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
+    }
     return hipGetLastError();
 }
 
@@ -702,7 +1001,8 @@ hipError_t launch_conv2(const Conv2Args& c, hipStream_t s) {
     P.tiles_x = (c.W + 15) / 16; P.tiles_y = (c.H + 31) / 32;
     P.n_groups = (c.Co + 31) / 32;
     P.n_tiles = conv2_tiles(c.Co); P.gpt = conv2_gpt(c.Co);
-    P.nx = c.C / 16; P.nh = 0; P.hs_off = 0; P.chunks_total = 3 * P.nx;
+    P.nx = c.C / 16; P.nh = 0; P.hs_off = 0; P.chunks_total = c.qform ? cell2_qchunks(P.nx) : 3 * P.nx;
+    P.qform = c.qform;
     P.seg[0] = Cell2Seg{c.src_sp, c.src_bstride, c.C, 0};
     P.seg[1] = Cell2Seg{c.src_sp, 0, c.C, 0};
     P.wpk = c.wpk;

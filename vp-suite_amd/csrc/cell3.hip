@@ -35,8 +35,8 @@ __device__ const float c3_zero16[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.
 
 __device__ __forceinline__ void c3_dma16(const char* g, char* lds_wave_base) {   // see c2_dma16 (cell2.hip) for the why of the asm
     const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds)) : "memory", "m0");
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(g), "{m0}"(__builtin_amdgcn_readfirstlane(lds)) : "memory");
 }
 __device__ __forceinline__ int c3_px(int i) { return (i & 16) ? ((i + 14) & 15) : (i & 15); }   // column rotation of the odd row (bank spread, as c2_px)
 __device__ __forceinline__ unsigned short c3_bf16_bits(float v) {

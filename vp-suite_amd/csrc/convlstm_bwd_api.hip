@@ -50,7 +50,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     char* dG_sp_all = nullptr; char* wpk2 = nullptr;
     if (L.v2) {
         dG_sp_all = (char*)ws.take((size_t)T * L.n_state * 4);
-        wpk2 = (char*)ws.take(cell2_packed_bytes(conv2_tiles(Ct), 3 * (N4 / 16)) / sizeof(float));
+        wpk2 = (char*)ws.take((cell2_packed_bytes(conv2_tiles(Ct), 3 * (N4 / 16)) + 16384 * conv2_tiles(Ct)) / sizeof(float));
     }
     const bool wsp = wgrad2_wsp(d, L) && dW != nullptr;   // forward on another kernel, weight gradient on wgrad2 all the same
     char *xsp_w = nullptr, *hsp_w = nullptr, *h0sp_w = nullptr;
@@ -109,8 +109,10 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     const int col_start = need_dx ? 0 : Cin;
     const int n_out = need_dx ? Ct : Ch;
     const int d_tiles = plain_tiles(n_out);
+    const int qform = mfma_shape() == 1 ? 1 : 0;   // conv2's epilogue handles ragged tiles in both forms
     if (c2d) {
-        Conv2Pack pk{W, (long long)L.taps, (long long)Ct * L.taps, n_out, col_start, conv2_tiles(n_out), conv2_gpt(n_out), 3 * (N4 / 16), 1};
+        Conv2Pack pk{W, (long long)L.taps, (long long)Ct * L.taps, n_out, col_start, conv2_tiles(n_out), conv2_gpt(n_out),
+                     qform ? cell2_qchunks(N4 / 16) : 3 * (N4 / 16), 1, qform, 0};
         VPX_CHECK_HIP(launch_conv2_pack(pk, wpk2, stream));
     } else {
         PackDesc pd{};
@@ -155,7 +157,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
             Conv2Args ca{};
             ca.B = B; ca.H = H; ca.W = Wd; ca.C = N4; ca.Co = n_out; ca.split = need_dx ? Cin : 0;
             ca.src_sp = ga.dG_sp; ca.src_bstride = (long long)(HW * N4 * 4);
-            ca.wpk = wpk2;
+            ca.wpk = wpk2; ca.qform = qform;
             ca.out0 = need_dx ? dxn + (size_t)t * HW * Cin : nullptr;
             ca.bstride0 = (long long)((size_t)T * HW * Cin); ca.ld0 = Cin;
             ca.out1 = dh_target; ca.bstride1 = (long long)(HW * Ch); ca.ld1 = Ch;

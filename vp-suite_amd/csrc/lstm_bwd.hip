@@ -922,8 +922,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_tg_kernel(const WgradArgs a, con
                                      : reinterpret_cast<const char*>(wg_zero16);
                 if (tid + NTH * u < 2 * npos * 8) {
                     const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(dst + u * NTH * 16);
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                                 :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds)) : "memory", "m0");
+                    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                                 :: "v"(src), "{m0}"(__builtin_amdgcn_readfirstlane(lds)) : "memory");
                 }
             }
         }

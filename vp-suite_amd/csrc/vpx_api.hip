@@ -20,6 +20,11 @@ void set_error(const char* fmt, ...) {
 int g_deterministic = 0;
 int g_cell3_mode = -1;
 int g_cell2_mode = -1;
+int g_mfma_shape = -1;
+int mfma_shape() {
+    if (g_mfma_shape < 0) { const char* e = getenv("VPX_MFMA_SHAPE"); g_mfma_shape = e ? (atoi(e) ? 1 : 0) : VPX_MFMA_SHAPE_DEFAULT; }
+    return g_mfma_shape;
+}
 
 }  // namespace vpx
 
@@ -34,6 +39,11 @@ int vpx_set_option(int option, int value) {
     if (option == VPX_OPT_CELL2) {
         const int prev = cell2_mode();
         vpx::g_cell2_mode = value < 0 ? 0 : (value > 2 ? 2 : value);
+        return prev;
+    }
+    if (option == VPX_OPT_MFMA_SHAPE) {
+        const int prev = mfma_shape();
+        vpx::g_mfma_shape = value ? 1 : 0;
         return prev;
     }
     if (option == VPX_OPT_CELL3) {
@@ -68,6 +78,13 @@ size_t vpx_convlstm_reserve_bytes(const vpx_convlstm_desc* d) {
     return b;
 }
 
+// one cell2 weight pack: an upper bound over both MFMA forms (the q form rounds an odd stage count up by half a stage)
+static size_t cell2_wpk_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
+    const int S = (d->Cin + d->Ch) / 16;
+    const size_t a = cell2_packed_bytes(L.n_tiles, 3 * S), b = cell2_packed_bytes_q(L.n_tiles, S);
+    return a > b ? a : b;
+}
+
 static size_t convlstm_wpk_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
     return L.split ? packed_weight_bytes(L.s_tiles, L.s_chunks, L.s_ng, d->precision)
                    : packed_weight_bytes(L.n_tiles, L.chunks_total, 4, d->precision, L.qpc);
@@ -91,8 +108,8 @@ size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
     if (L.v3)  // input projection of all steps + its weight pack + the slice-major recurrent weights + split h0 and a two-slot ring of h_t
         fwd += align256(4 * L.n_out * sizeof(float)) + align256(packed_weight_bytes(L.s_tiles, L.hx_chunks, L.s_ng, d->precision)) +
                align256(cell3_packed_bytes(d->Ch)) + 3 * align256(L.n_state * 4);
-    if (L.v2)  // packed weights of cell2 + split copies of x, h0 and a two-slot ring of h_t
-        fwd += align256(cell2_packed_bytes(L.n_tiles, 3 * ((d->Cin + d->Ch) / 16))) + align256(L.n_x * 4) + 3 * align256(L.n_state * 4);
+    if (L.v2)  // packed weights of cell2 (q form: up to two packs, one per set of present operands) + split copies of x, h0 and a two-slot ring of h_t
+        fwd += 2 * align256(cell2_wpk_bytes(d, L)) + align256(L.n_x * 4) + 3 * align256(L.n_state * 4);
     if (d->layout == VPX_LAYOUT_NCHW)
         fwd += align256(L.n_x * 4) + align256(L.n_out * 4) + 4 * align256(L.n_state * 4) + 3 * align256(L.n_peep * 4);
     // backward (only with SAVE_FOR_BWD): packed dgrad weights + dG for all steps + dh/dc carries + wgrad K-slice slabs
@@ -151,9 +168,10 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         h_ring3[0] = (char*)ws.take(L.n_state);
         h_ring3[1] = (char*)ws.take(L.n_state);
     }
-    char *wpk2 = nullptr, *x_sp = nullptr, *h0_sp = nullptr, *h_ring[2] = {nullptr, nullptr}, *h_sp_all = nullptr;
+    char *wpk2 = nullptr, *wpk2b = nullptr, *x_sp = nullptr, *h0_sp = nullptr, *h_ring[2] = {nullptr, nullptr}, *h_sp_all = nullptr;
     if (L.v2) {
-        wpk2 = (char*)ws.take(cell2_packed_bytes(L.n_tiles, 3 * ((Cin + Ch) / 16)) / sizeof(float));
+        wpk2 = (char*)ws.take(cell2_wpk_bytes(d, L) / sizeof(float));
+        wpk2b = (char*)ws.take(cell2_wpk_bytes(d, L) / sizeof(float));
         x_sp = (char*)ws.take(L.n_x);
         h0_sp = (char*)ws.take(L.n_state);
         h_ring[0] = (char*)ws.take(L.n_state);
@@ -203,12 +221,31 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     pd.taps = L.taps;
     pd.transposed = 0;
     pd.flip = 0;
+    // q form (16x16x32 MFMAs): the K = 32 steps pair taps over the sequence of PRESENT stages, so steps with different operand
+    // sets (t = 0 without an initial state: x only; no input tensor: h only) read different packs — at most two per call
+    const int qform = (L.v2 && cell2_q_applicable(d)) ? 1 : 0;
+    const int combo0 = (xn ? 1 : 0) | (h0n ? 2 : 0), combo1 = (xn ? 1 : 0) | 2;   // operand sets of step 0 / of steps t >= 1
+    auto pack_of = [&](int combo) -> char* { return combo == combo1 ? wpk2 : wpk2b; };
     if (L.v2) {
         Cell2Pack pk{};
-        pk.w = W; pk.Ch = Ch; pk.Ct = Cin + Ch; pk.n_tiles = L.n_tiles; pk.chunks_total = 3 * ((Cin + Ch) / 16);
+        pk.w = W; pk.Ch = Ch; pk.Ct = Cin + Ch; pk.n_tiles = L.n_tiles;
         memcpy(pk.gate_pos, gp, sizeof(gp));
-        for (int s = 0; s < (Cin + Ch) / 16; ++s) pk.stage_col[s] = 16 * s;  // x stages first, then h: columns of [x | h] in order
-        VPX_CHECK_HIP(launch_cell2_pack(pk, wpk2, stream));
+        if (!qform) {
+            pk.chunks_total = 3 * ((Cin + Ch) / 16);
+            for (int s = 0; s < (Cin + Ch) / 16; ++s) pk.stage_col[s] = 16 * s;  // x stages first, then h: columns of [x | h] in order
+            VPX_CHECK_HIP(launch_cell2_pack(pk, wpk2, stream));
+        } else {
+            for (int pass = 0; pass < 2; ++pass) {
+                const int combo = pass ? combo0 : combo1;
+                // combo1 serves steps t >= 1 (and step 0 when it has the same operands); combo0 only when it differs and is not empty
+                if (pass == 0 ? (T < 2 && combo0 != combo1) : (combo0 == combo1 || combo0 == 0)) continue;
+                pk.qform = 1; pk.S = 0;
+                if (combo & 1) for (int s = 0; s < Cin / 16; ++s) pk.stage_col[pk.S++] = 16 * s;
+                if (combo & 2) for (int s = 0; s < Ch / 16; ++s) pk.stage_col[pk.S++] = Cin + 16 * s;
+                pk.chunks_total = cell2_qchunks(pk.S);
+                VPX_CHECK_HIP(launch_cell2_pack(pk, pack_of(combo), stream));
+            }
+        }
         // operands of the steps in split form: the whole input sequence and the initial hidden state, once
         if (xn && x_split) x_sp = const_cast<char*>(reinterpret_cast<const char*>(xn));   // the producer already wrote operands
         else if (xn) VPX_CHECK_HIP(launch_split_convert(xn, x_sp, (long long)B * T * (long long)HW, Cin, stream));
@@ -330,6 +367,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             P2.B = B; P2.H = H; P2.W = Wd; P2.tiles_x = (Wd + 15) / 16; P2.tiles_y = (H + 31) / 32; P2.n_tiles = L.n_tiles;
             P2.chunks_total = 3 * ((Cin + Ch) / 16);
             P2.wpk = wpk2;
+            P2.qform = qform;
             auto h_slot = [&](int tt) { return h_sp_all ? h_sp_all + (size_t)tt * L.n_state * 4 : h_ring[tt & 1]; };
             const char* hprev_sp = (t == 0) ? (h0n ? h0_sp : nullptr) : h_slot(t - 1);
             P2.seg[0] = Cell2Seg{xn ? x_sp + (size_t)t * HW * Cin * 4 : nullptr, (long long)((size_t)T * HW * Cin * 4), Cin, 0};
@@ -337,6 +375,10 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             P2.nx = xn ? Cin / 16 : 0;
             P2.nh = hprev_sp ? Ch / 16 : 0;
             P2.hs_off = Cin / 16;
+            if (qform) {   // the pack of this step's operand set
+                P2.chunks_total = cell2_qchunks(P2.nx + P2.nh);
+                P2.wpk = pack_of((P2.nx ? 1 : 0) | (P2.nh ? 2 : 0));
+            }
             // the split copy of h_t feeds step t+1 only: the last step does not need it
             VPX_CHECK_HIP(launch_cell2(P2, ea, (t + 1 < T) ? h_slot(t) : nullptr, (long long)(HW * Ch * 4), stream));
         } else if (hoist) {

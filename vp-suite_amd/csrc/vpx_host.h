@@ -108,6 +108,13 @@ static inline bool cell2_applicable(const vpx_convlstm_desc* d) {
     return wgs >= min_wgs;
 }
 
+// 16x16x32 form of the second-generation kernels (vpx_set_option(VPX_OPT_MFMA_SHAPE)): the fused cell's q-form epilogue is the
+// vectorised one only — tiles inside the image, whole 32-channel tiles
+#define VPX_MFMA_SHAPE_DEFAULT 1   // measured (tools/ab_shape.py, B=128, one process, interleaved): 1.05-1.11x per fused step, every block shape
+static inline bool cell2_q_applicable(const vpx_convlstm_desc* d) {
+    return mfma_shape() == 1 && (d->H & 31) == 0 && (d->W & 15) == 0 && (d->Ch & 31) == 0;
+}
+
 struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     int taps, n_tiles, nstage, chunks_total;
     int v2;                        // 1: the forward steps run on cell2_kernel (pre-split operands)
@@ -162,8 +169,9 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
         if (bar < 0) { const char* e = getenv("VPX_SPLIT_BAR"); bar = e ? atoi(e) : 256; }
         static int bar3 = -1;  // VPX_CELL3_BAR: workgroup count of the fused launch below which cell3.hip takes the step (where it applies)
         if (bar3 < 0) { const char* e = getenv("VPX_CELL3_BAR"); bar3 = e ? atoi(e) : 256; }
-        const bool want3 = m_tiles * L.n_tiles < bar3 && cell3_applicable(d);
-        if (m_tiles * L.n_tiles < bar || want3) {
+        const bool force2 = cell2_mode() == 2 && cell2_applicable(d);   // "wherever the shape allows": also on small grids (tests, A/B)
+        const bool want3 = !force2 && m_tiles * L.n_tiles < bar3 && cell3_applicable(d);
+        if (!force2 && (m_tiles * L.n_tiles < bar || want3)) {
             const int ng = plain_groups(4 * d->Ch);
             const int tiles = plain_tiles_ng(4 * d->Ch, ng);
             // grids this small never have more than ~1 workgroup per CU, so LDS residency is no argument for small stages:
@@ -239,7 +247,7 @@ static inline size_t convlstm_bwd_workspace_bytes(const vpx_convlstm_desc* d, co
     b += align256((size_t)d->T * GATE_BWD_MAX_SLICES * gate_bwd_blocks(d->H * d->W, d->Ch) * 4 * d->Ch * sizeof(float));  // bias-gradient partials
     b += align256((size_t)COLSUM_BLOCKS * 4 * d->Ch * sizeof(float));                                // ... and their second level
     if (L.v2)  // dG of all steps in split operand format + the conv2 weight pack of the data gradient
-        b += align256((size_t)d->T * L.n_state * 16) + align256(cell2_packed_bytes(conv2_tiles(d->Cin + d->Ch), 3 * (4 * d->Ch / 16)));
+        b += align256((size_t)d->T * L.n_state * 16) + align256(cell2_packed_bytes(conv2_tiles(d->Cin + d->Ch), 3 * (4 * d->Ch / 16)) + 16384 * conv2_tiles(d->Cin + d->Ch));
     if (wgrad2_wsp(d, L))  // split dG of all steps + split copies of x, the output sequence and h0
         b += align256((size_t)d->T * L.n_state * 16) + align256(L.n_x * 4) + align256(L.n_out * 4) + align256(L.n_state * 4);
     if (d->layout == VPX_LAYOUT_NCHW) {

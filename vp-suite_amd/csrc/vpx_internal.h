@@ -122,19 +122,30 @@ struct Cell2Seg { const char* sp; long long bstride; int C; int _pad; };   // sp
 // arithmetic on these fields (a table walk cost an s_load + s_waitcnt lgkmcnt(0) per copy inside the MFMA loop).
 struct Cell2Plan {
     int B, H, W, tiles_x, tiles_y, n_tiles, nx, nh, hs_off, chunks_total, grid_m, _p;
+    int qform, _q;            // 1: the 16x16x32 main loop (cell2_kernel_q); wpk / chunks_total then describe K = 32 chunks (below)
     int n_groups, gpt;        // conv2 only: 32-column output groups in total / per N tile (the last tile may hold fewer)
     Cell2Seg seg[2];
     const char* wpk;          // [n_tiles][chunks_total][24576 B]
 };
+// 16x16x32 form ("q form"): the K = 32 steps pair two taps of a 16-channel stage over the PRESENT stage sequence s = 0 .. S-1
+// (x stages, then h stages) in periods of two stages = 9 steps: even stage taps (0,1) (2,3) (4,5) (6,7), the cross step
+// (tap 8 of the even stage | tap 0 of the odd stage), odd stage taps (1,2) (3,4) (5,6) (7,8); an odd S ends with (tap 8 | zero
+// weights). One weight chunk = one step = [part][k group 0..3 = tap half * 2 + channel half][n][8 bf16] = 16 KiB; the pack
+// therefore depends on which operands are present (an absent x or h changes the pairing).
+static inline int cell2_qchunks(int S) { return (9 * S + 1) / 2; }
 struct Cell2Pack {
     const float* w;           // reference OIHW [4Ch, Ct, 3, 3]
     int Ch, Ct, n_tiles, chunks_total;
+    int qform, S;             // q form: S present stages, chunks_total = cell2_qchunks(S), stage_col[] lists the present stages
     int gate_pos[4];
     int stage_col[MAX_STAGE]; // column in [x | h] of the first channel of packed stage s (chunks 3s .. 3s+2)
 };
 hipError_t launch_split_convert(const float* src, void* dst, long long npix, int C, hipStream_t s);  // fp32 NHWC -> split format
 hipError_t launch_cell2_pack(const Cell2Pack& pk, void* dst, hipStream_t s);
-size_t cell2_packed_bytes(int n_tiles, int chunks_total);
+size_t cell2_packed_bytes(int n_tiles, int chunks_total);   // 32x32x16 form: chunks of 24 KiB (3 per stage)
+size_t cell2_packed_bytes_q(int n_tiles, int S);             // q form: cell2_qchunks(S) chunks of 16 KiB
+extern int g_mfma_shape;   // vpx_api.hip: -1 = not yet read from the environment (VPX_MFMA_SHAPE), else 0 / 1 (vpx_set_option)
+int mfma_shape();
 hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s);
 // conv2: the same kernel with a plain epilogue — 3x3 'same' convolution of one split-format source with C channels (C % 16 == 0)
 // into Co fp32 NHWC output channels, [0, split) -> out0, [split, Co) -> out1. N tiling: 128-column tiles, balanced.
@@ -143,9 +154,10 @@ static inline int conv2_gpt(int Co) { const int g = (Co + 31) / 32, t = (g + 3) 
 struct Conv2Pack {
     const float* w; long long s_oc, s_ic;   // element strides of the output / input channel (the tap index is contiguous)
     int Co, col0, n_tiles, gpt, chunks_total, flip;
+    int qform, _p;                          // 1: K = 32 chunks (chunks_total = cell2_qchunks(C / 16))
 };
 struct Conv2Args {
-    int B, H, W, C, Co, split, accumulate, _p;
+    int B, H, W, C, Co, split, accumulate, qform;
     const char* src_sp; long long src_bstride;   // split source [B][HW][C], BYTES between batch items
     const char* wpk; const float* bias;
     float* out0; long long bstride0; int ld0, _p0;

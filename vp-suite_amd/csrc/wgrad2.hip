@@ -46,8 +46,8 @@ __device__ __forceinline__ void w2_dma16(const char* g, char* lds_wave_base) {
     // 64 lanes x 16 B -> lds_wave_base + 16 * lane. Inline asm: see c2_dma16 (cell2.hip) — a compiler-visible LDS-DMA
     // degrades every later s_waitcnt of the kernel to zero.
     const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(g), "s"(__builtin_amdgcn_readfirstlane(lds)) : "memory", "m0");
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(g), "{m0}"(__builtin_amdgcn_readfirstlane(lds)) : "memory");
 }
 
 __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
