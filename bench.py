@@ -90,11 +90,16 @@ class Spec:
     """One measured configuration."""
 
     def __init__(self, name, model="convlstm-shi", mode="infer", batch=128, precision="bf16x3", img=64, channels=1,
-                 context=10, pred=10, layers=None):
+                 context=10, pred=10, layers=None, cell=None):
         self.name, self.model, self.mode, self.batch, self.precision = name, model, mode, batch, precision
         self.img, self.channels, self.context, self.pred, self.layers = img, channels, context, pred, layers
+        self.cell = cell   # (Cin, Ch, H, W): ONE ConvLSTM block alone (kernel micro-bench, SURVEY.md §8d), T = context steps
 
     def workload(self):
+        if self.cell:
+            cin, ch, h, w = self.cell
+            return (f"one ConvLSTM block (conv_lstm_hzzone.py:38-70) alone: Cin={cin}, Ch={ch}, {h}x{w} map, 3x3, peepholes, "
+                    f"T={self.context} steps, zero initial state, random input sequence and weights")
         deep = f", num_layers={self.layers}" if self.layers else ""
         return (f"{self.model} (default hyper-parameters{deep}) on MovingMNIST-shaped synthetic frames "
                 f"{self.channels}x{self.img}x{self.img}, {self.context}->{self.pred}, random-init weights")
@@ -106,6 +111,17 @@ class Runner:
         from vp_suite_amd.models import MODEL_CLASSES
         self.spec, self.dev, self.rank, self.world, self.use_dist = spec, dev, rank, world, use_dist
         torch.manual_seed(0)  # identical random-init weights on every rank
+        if spec.cell:
+            from vp_suite_amd import ops
+            cin, ch, h, w = spec.cell
+            self.model = None
+            self.cell_w = torch.randn(4 * ch, cin + ch, 3, 3, device=dev) / math.sqrt(9.0 * (cin + ch))
+            self.cell_b = torch.randn(4 * ch, device=dev) * 0.1
+            self.cell_peep = [torch.randn(1, ch, h, w, device=dev) * 0.1 for _ in range(3)]
+            torch.manual_seed(42 + rank)
+            self.x = ops.to_channels_last(torch.rand(spec.batch, spec.context, cin, h, w, device=dev))
+            self.semantics = "ops.convlstm_seq (= model_blocks.ConvLSTM.forward) under no_grad: T fused cell-step launches per call"
+            return
         kw = dict(img_shape=(spec.channels, spec.img, spec.img), action_size=0, tensor_value_range=[0.0, 1.0],
                   cell_precision=spec.precision)
         if spec.layers:
@@ -130,6 +146,12 @@ class Runner:
 
     def step(self):
         import torch
+        if self.spec.cell:
+            from vp_suite_amd import ops
+            with torch.no_grad():
+                ops.convlstm_seq(self.x, None, None, self.cell_w, self.cell_b, *self.cell_peep, seq_len=self.spec.context,
+                                 in_channels=self.spec.cell[0], precision=self.spec.precision)
+            return
         if self.spec.mode == "train":
             self.trainer.step(self.x, self.target, self.spec.pred)
         else:
@@ -182,6 +204,14 @@ def measured_traffic(spec):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with
     tools/collect_profiles.sh on this exact workload: separate --pmc FETCH_SIZE / WRITE_SIZE passes, read = 2 x FETCH_SIZE
     per the gfx950 correction); None when no committed pass matches the configuration."""
+    if spec.cell:
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                       if f.endswith(f"_pmc_cell_{spec.cell[0]}x{spec.cell[1]}x{spec.cell[2]}_b{spec.batch}.json"))
+        if not cands:
+            return None
+        with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
+            t = json.load(fh).get("hbm_traffic_bytes_per_launch")
+        return None if t is None else round(t["total"])
     if not (spec.img == 64 and spec.channels == 1 and spec.context == 10 and spec.pred == 10):
         return None
     tag = {"convlstm-shi": ""}.get(spec.model)
@@ -232,13 +262,20 @@ def run_extra(spec, dev, rank, world, use_dist, seconds):
     r = Runner(spec, dev, rank, world, use_dist)
     steps = r.calibrated_steps(seconds)
     elapsed, ps = r.timed(steps, 1)
+    units = spec.context if spec.cell else spec.pred   # a cell entry counts cell steps of one sample, a model entry predicted frames
     out = {"name": spec.name, "workload": spec.workload(), "mode": spec.mode, "semantics": r.semantics,
            "dtype": spec.precision, "per_gpu_batch": spec.batch, "global_batch": spec.batch * world, "n_gpus": world,
            "steps": steps, "timed_region_s": round(elapsed, 3), "ms_per_step": round(elapsed / steps * 1e3, 4),
-           "value": round(world * spec.batch * spec.pred * steps / elapsed, 2), "unit": "frames/s",
+           "value": round(world * spec.batch * units * steps / elapsed, 2),
+           "unit": "cell steps x samples/s" if spec.cell else "frames/s",
            "roofline": roofline(spec, ps)}
-    for k in ("note", "hbm_view", "vs_fp32_matrix_peak"):
+    for k in ("note", "vs_fp32_matrix_peak") + (() if spec.cell else ("hbm_view",)):
         out["roofline"].pop(k, None)
+    if spec.cell:
+        out["roofline"]["hbm_view"]["note"] = (
+            "north-star 'fraction of HBM roofline' on the fused cell: algorithmic bytes (SURVEY.md §8d) / kernel time / 8 TB/s. "
+            "Structural ceiling at 1e-4 parity: the cell is MFMA-bound (2.416 GFLOP vs 5.24 MB per unit at 64x64x64ch), bf16x3 "
+            "spends 3 MFMAs per product, so frac <= 5.24 MB / (2.416 GFLOP / 833 TF) / 8 TB/s = 0.23 at roofline.frac = 1")
     del r
     torch.cuda.empty_cache()
     return out
@@ -253,7 +290,7 @@ def cpu_baseline(model, spec, seconds):
     all_cores = torch.get_num_threads()
     b = 4
     x = torch.rand(b, spec.context, spec.channels, spec.img, spec.img)
-    best = None
+    best, scan = None, {}
     # PyTorch's default (all host cores) over-subscribes this small problem; report the best of a short thread scan
     for threads in sorted({all_cores, min(all_cores, 32), min(all_cores, 16)}, reverse=True):
         torch.set_num_threads(threads)
@@ -267,11 +304,13 @@ def cpu_baseline(model, spec, seconds):
                 if el > seconds / 3 or n >= 50:
                     break
         fps = n * b * spec.pred / el
+        scan[str(threads)] = round(fps, 2)
         if best is None or fps > best[0]:
             best = (fps, threads, n, el)
     torch.set_num_threads(all_cores)
     fps, threads, n, el = best
     return {"value": round(fps, 2), "unit": "predicted frames/s", "cores": threads, "kind": "port",
+            "all_cores": {"cores": all_cores, "value": scan[str(all_cores)]}, "thread_scan": scan,
             "sample": f"oracle/torch_ref.ef_convlstm_forward (PyTorch-CPU restatement of the reference path), "
                       f"batch {b}, {spec.context}->{spec.pred}, {spec.channels}x{spec.img}x{spec.img}, "
                       f"{n} iterations in {el:.1f} s on {threads} of {all_cores} host threads (the best point of a 3-point "
@@ -282,7 +321,7 @@ def cpu_baseline(model, spec, seconds):
 def extras_for(world):
     if world == 1:
         return [
-            Spec("headline_sustained"),
+            Spec("infer_b128"),   # the headline configuration timed for >= --extras-seconds (the same name in the N > 1 list)
             Spec("infer_b4", batch=4),
             Spec("infer_b32", batch=32),
             Spec("train_b32", mode="train", batch=32),
@@ -291,10 +330,26 @@ def extras_for(world):
             Spec("predrnn_infer_b128", model="predrnn-pp"),
             Spec("c4_infer_b4_128x128x3_10to20", batch=4, img=128, channels=3, pred=20),
             Spec("c4_train_b4_128x128x3_10to20", mode="train", batch=4, img=128, channels=3, pred=20),
+            # the cell the north-star states its target on (K1 at (Cin,Ch,H,W) = (64,64,64,64), B in {4,32,128}) ...
+            Spec("cell_64x64x64_b128", cell=(64, 64, 64, 64), batch=128),
+            Spec("cell_64x64x64_b32", cell=(64, 64, 64, 64), batch=32),
+            Spec("cell_64x64x64_b4", cell=(64, 64, 64, 64), batch=4),
+            # ... and the six block shapes of convlstm-shi at the default batch
+            Spec("cell_enc1_16x64x64_b128", cell=(16, 64, 64, 64), batch=128),
+            Spec("cell_enc2_64x96x32_b128", cell=(64, 96, 32, 32), batch=128),
+            Spec("cell_enc3_96x96x16_b128", cell=(96, 96, 16, 16), batch=128),
+            Spec("cell_fore2_96x96x32_b128", cell=(96, 96, 32, 32), batch=128),
+            Spec("cell_fore1_96x64x64_b128", cell=(96, 64, 64, 64), batch=128),
+            # PredRNN-V2 (BASELINE configs[2]) training iteration, and the deep long-horizon shape of configs[4]
+            Spec("predrnn_train_b128", model="predrnn-pp", mode="train", batch=128),
+            Spec("predrnn_train_b32", model="predrnn-pp", mode="train", batch=32),
+            Spec("c5_infer_b4_128x128x3_10to30_L4", model="predrnn-pp", batch=4, img=128, channels=3, pred=30, layers=4),
+            Spec("c5_train_b2_128x128x3_10to30_L4", model="predrnn-pp", mode="train", batch=2, img=128, channels=3, pred=30, layers=4),
         ]
     # N > 1: the entries in which ranks exchange gradients (the north-star's DP-scaling figure), at the default batch and
     # at BASELINE configs[3]'s 4 samples per GPU
     return [
+        Spec("infer_b128"),   # the headline again, sustained: shared with the N = 1 line (no collective in this mode)
         Spec("train_b128", mode="train", batch=128),
         Spec("c4_train_b4_128x128x3_10to20", mode="train", batch=4, img=128, channels=3, pred=20),
         Spec("c4_infer_b4_128x128x3_10to20", batch=4, img=128, channels=3, pred=20),

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX: kernel-trace of the cell kernel under chosen ablation bits -> average kernel duration per variant
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-export VPX_LIB=$PWD/gpurun_ablate.so PREC=${PREC:-bf16x3}
+export VPX_LIB=$PWD/build/libvpx_ablate.so PREC=${PREC:-bf16x3}
 OUT=gpurun_out/abl; rm -rf $OUT; mkdir -p $OUT
 for d in ${BITS:-0 15 47}; do
   export VPX_DBG=$d

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX: MFMA-busy and clock of the cell kernel under a timing ablation (VPX_DBG bits, ablation library)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-export VPX_LIB=$PWD/gpurun_ablate.so PREC=bf16x3
+export VPX_LIB=$PWD/build/libvpx_ablate.so PREC=bf16x3
 OUT=gpurun_out/pmc_abl; rm -rf $OUT; mkdir -p $OUT
 for d in ${BITS:-0 206}; do
   export VPX_DBG=$d

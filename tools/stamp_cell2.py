@@ -1,4 +1,4 @@
-"""Developer tool (ablate build only: make -C vp-suite_amd/csrc ablate; VPX_LIB=gpurun_ablate.so): per-wave s_memtime stamps
+"""Developer tool (ablate build only: make -C vp-suite_amd/csrc ablate; VPX_LIB=build/libvpx_ablate.so): per-wave s_memtime stamps
 of one cell2 workgroup on the headline cell -> where a tile's cycles go (prologue / sync waits / barriers / epilogue)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -219,7 +219,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         if (!xn) VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, L.slab_floats * sizeof(float), stream));
         wa.g_sp = (c2d || wsp) ? dG_sp_all : nullptr;
         int ns_used = L.n_slices, tail_col0 = Ct, tail_slices = L.n_slices;
-        if (wgrad2_applicable(wa)) VPX_CHECK_HIP(launch_wgrad2(wa, L.n_slices, &ns_used, &tail_col0, &tail_slices, stream));
+        if (L.n_slices2 > 0 && wgrad2_applicable(wa)) VPX_CHECK_HIP(launch_wgrad2(wa, L.n_slices2, &ns_used, &tail_col0, &tail_slices, stream));
         else VPX_CHECK_HIP(launch_wgrad(wa, L.n_slices, stream));
         VPX_CHECK_HIP(launch_wgrad_reduce_tail(slabs, dW, ns_used, L.taps, N4, Ct, tail_col0, tail_slices, stream));
     }

@@ -137,7 +137,8 @@ struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
     int d_tiles_full, d_tiles_h;   // N tiles when producing [dx | dh] resp. only dh
     int n_ctiles;                  // weight-gradient: 64-channel slices of [x | h]
     WgradCTile ct[WG_MAX_CTILES];
-    int n_slices;                  // weight-gradient K slices
+    int n_slices;                  // weight-gradient K slices (first-generation kernels)
+    int n_slices2;                 // ... of wgrad2.hip where it can take the launch (0 = never)
     size_t slab_floats;
 };
 
@@ -228,12 +229,17 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
         if (ns > 256) ns = 256;
         if (ns < 1) ns = 1;
         L.n_slices = (int)ns;
-        if (L.v2 || wgrad2_wsp(d, L)) {   // wgrad2.hip: 128-row tiles (half the tiles per slice) and, with a half-empty last column tile, up to 2x the slices
-            const long long ns2 = 1024 / (((N4 + 127) / 128) * L.n_ctiles);
-            if (ns2 > L.n_slices) L.n_slices = (int)(ns2 < items ? ns2 : items);
-            if (L.n_slices < 2) L.n_slices = 2;
+        // wgrad2.hip (128-row tiles, its own slice rule): the slab space covers whichever kernel takes the launch; the
+        // first-generation count above stays what launch_wgrad is handed when it does
+        L.n_slices2 = 0;
+        if (L.v2 || wgrad2_wsp(d, L)) {
+            const bool half_tail = L.ct[L.n_ctiles - 1].h[1].cn == 0;
+            long long ns2 = wgrad2_slices(wgrad2_target_wgs(), (N4 + 127) / 128, L.n_ctiles, half_tail);
+            if (ns2 > items) ns2 = items;
+            if (ns2 < 1) ns2 = 1;
+            L.n_slices2 = (int)ns2;
         }
-        L.slab_floats = (size_t)L.n_slices * L.taps * N4 * Ct;
+        L.slab_floats = (size_t)(L.n_slices > L.n_slices2 ? L.n_slices : L.n_slices2) * L.taps * N4 * Ct;
     }
     return VPX_OK;
 }

@@ -344,6 +344,14 @@ hipError_t launch_wgrad_small(const float* dy, const float* x, int N, int H, int
                               float* dw, hipStream_t s);
 // wgrad2.hip: both operands pre-split (3x3, bf16x3); writes slabs [used_slices][9][N4][Ct] like launch_wgrad
 bool wgrad2_applicable(const WgradArgs& a);
+int wgrad2_target_wgs();   // workgroups a wgrad2 launch aims at (512 = two rounds of one-per-CU workgroups; VPX_WGRAD2_WGS overrides)
+// K slices of a wgrad2 launch over `rows128` row tiles x n_ctiles column tiles (the last one half-empty or not), before the caps
+// by the caller's slab space and the item count. One rule for the launch (launch_wgrad2) and the slab sizing (convlstm_layout).
+static inline int wgrad2_slices(int target, int rows128, int n_ctiles, bool half_tail) {
+    const int nh = half_tail ? rows128 : 0, nf = rows128 * n_ctiles - nh;
+    if (nf <= 0) return target / (rows128 > 0 ? rows128 : 1);
+    return half_tail ? (8 * target) / (8 * nf + 5 * nh) : target / nf;
+}
 // columns >= *tail_col0 (the half-empty last column tile, if any) were written to the first *tail_slices slabs only
 hipError_t launch_wgrad2(const WgradArgs& a, int max_slices, int* used_slices, int* tail_col0, int* tail_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce_tail(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int tail_col0, int tail_slices,

@@ -313,6 +313,12 @@ bool wgrad2_applicable(const WgradArgs& a) {
     return items + 4096 < (1ll << 31);
 }
 
+int wgrad2_target_wgs() {
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("VPX_WGRAD2_WGS"); target = e ? atoi(e) : 512; }
+    return target;
+}
+
 // slices: whole rounds of 256 one-per-CU workgroups (two rounds by default, VPX_WGRAD2_WGS overrides), at most max_slices
 hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices, int* tail_col0, int* tail_slices, hipStream_t s) {
     static bool attr_set = false;
@@ -321,8 +327,7 @@ hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("VPX_WGRAD2_WGS"); target = e ? atoi(e) : 512; }
+    const int target = wgrad2_target_wgs();
     WgradArgs a = a_in;
     const int rows = (a.N4 + 127) / 128;
     a.grid_x = rows * a.n_ctiles;
@@ -332,7 +337,7 @@ hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices
     // Full tiles take ns slices, the half-empty tail tiles 5/8 ns: an item of a tail tile costs 0.62 of a full one (measured: the
     // MFMA work halves, the copy and the barrier do not), so with 8/5 of the items its workgroups run as long as the others —
     // ns * nf + 5/8 ns * nh workgroups of equal length, at most `target`.
-    int ns = half_tail ? (8 * target) / (8 * nf + 5 * a.w2_nh) : target / nf;
+    int ns = wgrad2_slices(target, rows, a.n_ctiles, half_tail);
     if (ns > max_slices) ns = max_slices;
     const long long items = (long long)a.T * a.B * ((a.W + 15) / 16) * ((a.H + W2_TH - 1) / W2_TH);
     if (ns > items) ns = (int)items;

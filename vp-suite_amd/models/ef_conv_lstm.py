@@ -68,6 +68,9 @@ def _run_stage(subnet: nn.Sequential, x: torch.Tensor, precision: str, split_las
                 x = ops.conv2d_ex(x, m.weight, m.bias, m.stride[0], m.padding[0], tr, slope, precision)
                 i += 1
                 continue
+        if is_conv and x.is_cuda:
+            ops._warn_once(f"glue_stock_{type(m).__name__}_{tuple(m.kernel_size)}_{tuple(m.stride)}",
+                           f"EF stage glue: {m} is outside vpx_conv2d_ex (ops.glue_supported); it runs as the stock torch module")
         x = m(x)
         i += 1
     return x

@@ -124,8 +124,10 @@ class PredRNN_V2(VPModel):
         a_patch = None
         if self.action_conditional:
             actions = kwargs.get("actions", None)
-            if actions is None or actions.dim() != 3 or actions.shape[-1] != self.action_size or not bool(actions.any()):
-                raise ValueError("Given actions are None or of the wrong size!")   # predrnn_v2.py:146-147
+            # predrnn_v2.py:141-147 raises for the missing-actions placeholder ([b, T] zeros, never equal to a [b, T, a] tensor) and
+            # for a wrong last dimension; an all-zero [b, T, a] batch (a robot at rest) is valid there and here. No device sync.
+            if actions is None or actions.dim() != 3 or actions.shape[-1] != self.action_size:
+                raise ValueError("Given actions are None or of the wrong size!")
             a_patch = actions.to(dev)[..., None, None].expand(-1, -1, -1, self.patch_h, self.patch_w)
         prec = self.cell_precision
         nh, top = self.num_hidden, self.num_layers - 1

@@ -27,6 +27,16 @@ class KernelProfile:
 
 PROFILE = None  # set to a KernelProfile() to collect
 
+_warned = set()
+
+
+def _warn_once(key, msg):
+    """A path that leaves the library is never taken silently: one RuntimeWarning per process and reason."""
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
 
 def _require_gpu(t: torch.Tensor, what: str):
     _sync_determinism()
@@ -359,6 +369,8 @@ class _ConvExFn(torch.autograd.Function):
             check(L.vpx_conv2d_ex_bwd(ctypes.byref(d), ptr(xs), ptr(wc), ptr(y), ptr(dyc), ptr(dx), ptr(dw), ptr(db), ptr(ws),
                                       ws_bytes, _stream()), "vpx_conv2d_ex_bwd")
             return dx, dw, db, None, None, None, None, None, None
+        _warn_once("glue_bwd_aten", f"conv2d_ex backward: layer (k={d.kh}x{d.kw}, stride={stride}, transposed={bool(transposed)}, "
+                   f"slope={slope}) is outside the library's glue backward; its gradients come from ATen (convolution_backward)")
         # fallback (kernel smaller than the stride, negative slope): ATen's convolution backward = MIOpen NHWC kernels.
         # GLUE_BACKWARD_NATIVE additionally routes it around MIOpen (MIOpen's solver search aborted the process in ~10 % of
         # the runs of a test with exotic shapes on this image, inside miopen find).
