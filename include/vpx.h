@@ -192,6 +192,16 @@ int vpx_conv2d_ex_fwd(const vpx_conv_desc* d, const float* x, const float* w, co
  * [N,Ho,Wo,Co] split-encoded, Co % 8 == 0; y may be NULL (inference: nobody reads the fp32 copy). */
 int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* y_split,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* The same layer on SPLIT-format input (x_split: [N,H,W,Ci] split-encoded; image n at (n / x_nT) * x_bstride + (n % x_nT) *
+ * x_tstride bytes, x_bstride = 0: dense, x_nT <= 1: plain batch), on the schedule-driven K = 32 kernel (csrc/convq.hip): bf16x3,
+ * Ci % 16 == 0, stride 1 or 2, taps within one pixel of the (sub-)image grid (3x3 pad 1, 4x4 stride 2 pad 1, plain or transposed)
+ * — vpx_conv2d_ex_takes_split says whether a descriptor qualifies. y (fp32) and y_split may each be NULL, not both.
+ * weights_packed: the workspace still holds this layer's packed weights (same values, same descriptor). */
+int vpx_conv2d_ex_takes_split(const vpx_conv_desc* d);
+size_t vpx_conv2d_ex_split_workspace_bytes(const vpx_conv_desc* d);
+int vpx_conv2d_ex_fwd_from_split(const vpx_conv_desc* d, const void* x_split, long long x_bstride, long long x_tstride, int x_nT,
+                                 const float* w, const float* bias, float* y, void* y_split, int weights_packed, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 /* Backward of the same layer (the reference gets it from autograd over nn.Conv2d / nn.ConvTranspose2d (+ LeakyReLU),
  * ef_blocks.py:15-49): dy [N,Ho,Wo,Co] is the gradient w.r.t. the layer OUTPUT (after bias and activation); y is that
  * output as vpx_conv2d_ex_fwd produced it — needed (and only read) when d->leaky_slope != 0: the activation derivative is

@@ -1,0 +1,54 @@
+"""The schedule-driven K = 32 convolution (csrc/convq.hip) behind vpx_conv2d_ex_fwd_from_split: the EF stage-glue layers of
+convlstm-shi (ef_blocks.py:15-49, ef_conv_lstm.py:36-65) and their adjoint shapes on split-format input, against
+torch.nn.functional convolutions in fp32 on the same GPU (the oracle's op for these layers) at the glue's tolerance."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import name_seed, seeded_rand, seeded_randn
+
+pytestmark = pytest.mark.gpu
+
+
+def _relmax(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+CASES = {  # tag: (N, Ci, Co, H, W, k, stride, pad, transposed, slope)
+    "deconv2_t2k4": (3, 96, 96, 32, 32, 4, 2, 1, True, 0.2),
+    "deconv1_t2k4_small": (2, 96, 96, 16, 16, 4, 2, 1, True, 0.2),
+    "conv3_s2k3": (3, 96, 96, 32, 32, 3, 2, 1, False, 0.2),
+    "conv2_s2k3_co64": (2, 64, 64, 64, 64, 3, 2, 1, False, 0.2),
+    "deconv3_t1k3_co16": (2, 64, 16, 64, 64, 3, 1, 1, True, 0.2),
+    "plain_k3_co96": (2, 32, 96, 40, 24, 3, 1, 1, False, 0.0),
+    "adj_t2k3": (2, 64, 64, 16, 16, 3, 2, 1, True, 0.0),
+    "adj_s2k4": (2, 96, 96, 32, 32, 4, 2, 1, False, 0.0),
+    "ragged_s2k3": (2, 32, 48, 37, 21, 3, 2, 1, False, 0.2),
+    "ragged_t2k4": (1, 16, 40, 19, 9, 4, 2, 1, True, 0.0),
+    "one_stage_k3": (1, 16, 32, 32, 16, 3, 1, 1, False, 0.0),
+}
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_glue_layer_on_split_input_vs_torch(vpx, tag):
+    N, Ci, Co, H, W, k, s, p, tr, slope = CASES[tag]
+    x = seeded_rand((N, Ci, H, W), name_seed(f"convq.{tag}.x")).cuda() - 0.3
+    wshape = (Ci, Co, k, k) if tr else (Co, Ci, k, k)
+    w = (seeded_randn(wshape, name_seed(f"convq.{tag}.w"), 1.0 / np.sqrt(Ci * k * k))).cuda()
+    b = seeded_randn((Co,), name_seed(f"convq.{tag}.b"), 0.1).cuda()
+    assert vpx.ops.conv2d_ex_takes_split(N, H, W, Ci, Co, k, k, s, p, tr)
+    xbuf, _ = vpx.ops.split_convert(x)
+    want_split = Co % 8 == 0
+    y, ybuf, shp = vpx.ops.conv2d_ex_from_split(xbuf, (N, Ci, H, W), w, b, s, p, tr, slope, "bf16x3", out_split=want_split)
+    ref = F.conv_transpose2d(x, w, b, stride=s, padding=p) if tr else F.conv2d(x, w, b, stride=s, padding=p)
+    if slope:
+        ref = F.leaky_relu(ref, slope)
+    assert tuple(y.shape) == tuple(ref.shape) == shp
+    assert _relmax(y, ref) < 2e-5, tag
+    if want_split:   # the split copy decodes to the fp32 output (hi + lo, to bf16x2 precision)
+        sb, _ = vpx.ops.split_convert(y)
+        assert torch.equal(sb.view(torch.int32), ybuf.view(torch.int32))
+    # second call: packed weights re-used from the layer's workspace
+    y2, _, _ = vpx.ops.conv2d_ex_from_split(xbuf, (N, Ci, H, W), w, b, s, p, tr, slope, "bf16x3")
+    assert torch.equal(y, y2)

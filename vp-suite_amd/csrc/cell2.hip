@@ -21,37 +21,9 @@
 //   weight chunk (one tap row = 3 k-steps of 16): [q = dx][part][khalf][n = gate*32 + j][16 B]       24 KiB, x3 ring
 #include <stdlib.h>
 
-#include "vpx_internal.h"
+#include "cell2_dev.h"
 
 namespace vpx {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int C2_HALO_W = 18;                   // 16 + 3 - 1
-constexpr int C2_NPOS = 34 * C2_HALO_W;         // 612 halo positions of a 32x16 tile
-constexpr int C2_PLANE_POS = 640;               // padded so that 4 planes are exactly 5 pieces per thread (512 threads)
-constexpr int C2_PLANE = C2_PLANE_POS * 16;
-constexpr int C2_ABUF = 4 * C2_PLANE;           // 40960 B
-constexpr int C2_WCHUNK = 3 * 2 * 2 * 128 * 16; // 24576 B
-constexpr int C2_LDS = 2 * C2_ABUF + 3 * C2_WCHUNK;  // 155648 B <= 160 KiB
-
-// 16x16x32 form ("q form", cell2_kernel_q below): same activation stage image; one weight chunk = one K = 32 step
-constexpr int CQ_WCHUNK = 2 * 4 * 128 * 16;     // 16384 B: [part][k group = tap half * 2 + channel half][n = gate*32 + j][16 B]
-constexpr int CQ_LDS = 2 * C2_ABUF + 3 * CQ_WCHUNK;  // 131072 B (the epilogue's transposition space needs 8 x 16 KiB as well)
-
-__device__ const float c2_zero16[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};  // source of out-of-image pieces
-
-__device__ __forceinline__ unsigned short c2_bf16_bits(float v) {
-    __bf16 h = (__bf16)v;  // v_cvt_pk_bf16_f32: round to nearest even (same split as conv_gemm.hip's split_bf16)
-    return __builtin_bit_cast(unsigned short, h);
-}
-__device__ __forceinline__ void c2_split(float v, unsigned& hi, unsigned& lo) {
-    const unsigned short h = c2_bf16_bits(v);
-    hi = h;
-    lo = c2_bf16_bits(v - __builtin_bit_cast(float, (unsigned)h << 16));
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // fp32 NHWC [npix][C] -> split format. One thread per (pixel, 8-channel group). HBM-bound, 8 B per element.
@@ -150,31 +122,6 @@ size_t cell2_packed_bytes(int n_tiles, int chunks_total) { return (size_t)n_tile
 size_t cell2_packed_bytes_q(int n_tiles, int S) { return (size_t)n_tiles * cell2_qchunks(S) * CQ_WCHUNK; }
 
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void c2_dma16(const char* g, char* lds_wave_base) {
-    // 64 lanes x 16 B: lane l's bytes land at lds_wave_base + 16*l (M0 = wave-uniform base).
-    // Inline asm on purpose: while a compiler-visible LDS-DMA (__builtin_amdgcn_global_load_lds) is pending, hipcc's
-    // waitcnt pass treats it as an access to BOTH memory and LDS and degrades every later wait to lgkmcnt(0) / vmcnt(0)
-    // — the MFMA loop then waited for the fragments it had just requested (72 % matrix-pipe use by a lone wave, measured).
-    // Hidden in asm, the loop's ds_reads get counted waits; the DMA's own completion is waited for by hand (C2_WAIT_VM)
-    // at the sync points, and compiler-made vmcnt waits (epilogue loads) only become stricter by the extra queue entries.
-    // M0 is an INPUT operand bound to the physical register ("{m0}"): the compiler emits the s_mov to m0 itself and knows
-    // about it — nothing reserved is clobbered behind its back. The s_nop covers the "SALU writes M0 -> LDS-DMA" wait state,
-    // which the hazard recognizer cannot see through the asm.
-    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
-    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                 :: "v"(g), "{m0}"(__builtin_amdgcn_readfirstlane(lds)) : "memory");
-}
-
-__device__ __forceinline__ int c2_px(int i) { return (i & 16) ? ((i + 14) & 15) : (i & 15); }
-
-#define C2_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-
-__device__ __forceinline__ void c2_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 #ifdef VPX_ABLATE
 // developer build only (make ablate): per-wave s_memtime stamps of ONE workgroup (block id = Cell2Plan::_p), read back with
 // vpx_dbg_cell2_stamps(). Never compiled into the product library.

@@ -223,6 +223,9 @@ int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const 
 
 int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const float* w, const float* bias, float* y, float* wpk,
                hipStream_t stream, char* y_split = nullptr);
+bool exq_problem(const vpx_conv_desc* d, const ExGeo& g, ConvQProblem& pr);
+int ex_forward_q(const vpx_conv_desc* d, const ExGeo& g, const char* x_sp, long long x_bstride, long long x_tstride, int x_nT,
+                 const float* w, const float* bias, float* y, char* y_sp, char* wpk, bool weights_packed, hipStream_t stream);
 
 size_t ex_wpk_floats(const vpx_conv_desc* d) {
     // upper bound over the launches this descriptor can produce (full tap set, stride as given)
@@ -286,6 +289,38 @@ int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float*
     return ex_forward(d, g, x, w, bias, y, wpk, (hipStream_t)stream_, reinterpret_cast<char*>(y_split));
 }
 
+int vpx_conv2d_ex_takes_split(const vpx_conv_desc* d) {
+    ExGeo g;
+    static thread_local ConvQProblem pr;
+    if (ex_check(d, g) != VPX_OK || !exq_problem(d, g, pr)) return 0;
+    return convq_wpk_bytes(pr) > 0 ? 1 : 0;
+}
+
+size_t vpx_conv2d_ex_split_workspace_bytes(const vpx_conv_desc* d) {
+    ExGeo g;
+    static thread_local ConvQProblem pr;
+    if (ex_check(d, g) != VPX_OK || !exq_problem(d, g, pr)) return 0;
+    const size_t b = convq_wpk_bytes(pr);
+    return b ? align256(b) + 512 : 0;
+}
+
+int vpx_conv2d_ex_fwd_from_split(const vpx_conv_desc* d, const void* x_split, long long x_bstride, long long x_tstride, int x_nT,
+                                 const float* w, const float* bias, float* y, void* y_split, int weights_packed, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
+    ExGeo g;
+    int rc = ex_check(d, g);
+    if (rc != VPX_OK) return rc;
+    if (!x_split || !w || (!y && !y_split)) { set_error("vpx_conv2d_ex_fwd_from_split: NULL tensor argument"); return VPX_ERR_ARG; }
+    if (y_split && (d->Co & 7)) { set_error("vpx_conv2d_ex_fwd_from_split: the split format needs Co to be a multiple of 8 (got %d)", d->Co); return VPX_ERR_UNSUPPORTED; }
+    const size_t need = vpx_conv2d_ex_split_workspace_bytes(d);
+    if (!need) { set_error("vpx_conv2d_ex_fwd_from_split: layer not implemented on split input (vpx_conv2d_ex_takes_split)"); return VPX_ERR_UNSUPPORTED; }
+    if (!workspace || workspace_bytes < need) { set_error("vpx_conv2d_ex_fwd_from_split: workspace too small"); return VPX_ERR_WORKSPACE; }
+    char* wpk = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    if (x_bstride == 0) x_bstride = (long long)d->H * d->W * d->Ci * 4;
+    return ex_forward_q(d, g, reinterpret_cast<const char*>(x_split), x_bstride, x_tstride, x_nT, w, bias, y, reinterpret_cast<char*>(y_split),
+                        wpk, weights_packed != 0, (hipStream_t)stream_);
+}
+
 }  // extern "C"
 
 namespace {
@@ -327,6 +362,96 @@ int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const flo
             if (rc != VPX_OK) return rc;
         }
     return VPX_OK;
+}
+
+// ---- the same layers on SPLIT-format input through the schedule-driven K = 32 kernel (convq.hip) -----------------------
+// Terms of a layer (see convq.hip): a convolution with stride s reads the s x s sub-images x[s*i + sy, s*j + sx] of its input,
+// tap ky of row residue sy = (ky - pad) mod s lands at da = (ky - pad - sy) / s; a transposed convolution computes output phase
+// (py, px) = (oy mod s, ox mod s) as a stride-1 correlation over x with the taps ky = (py + pad) mod s (+ s, ...) at
+// da = -(ky - py - pad) / s. Sub-positions with a single tap get a zero-weight filler so that their stages span a whole step.
+bool exq_problem(const vpx_conv_desc* d, const ExGeo& g, ConvQProblem& pr) {
+    memset(&pr, 0, sizeof(pr));
+    if (d->precision != VPX_PREC_BF16X3 || (d->Ci & 15) || d->Ci < 16 || d->Ci / 16 > 60) return false;
+    const int s = d->stride, p = d->pad;
+    const int nst = d->Ci / 16;
+    const int row = d->W * d->Ci * 4, pix = d->Ci * 4;
+    pr.N = d->N; pr.halo = 2;
+    pr.Co = d->Co; pr.col0 = 0;
+    const int taps = d->kh * d->kw;
+    if (taps > 25) return false;
+    auto fmod_ = [](int a, int b) { return ((a % b) + b) % b; };
+    if (!d->transposed) {
+        pr.s_oc = (long long)d->Ci * taps; pr.s_ic = taps;
+        pr.H = g.Ho; pr.W = g.Wo;
+        pr.nseg = s * s; pr.ngs = 1; pr.phases = 0;
+        if (pr.nseg > 4) return false;
+        ConvQGroupSet& gs = pr.gs[0];
+        gs.nt0 = 0; gs.ntn = 8; gs.nterm = 0;
+        int per_seg[4] = {0, 0, 0, 0};
+        for (int sy = 0; sy < s; ++sy)
+            for (int sx = 0; sx < s; ++sx) {
+                const int si = sy * s + sx;
+                CQSeg& sg = pr.seg[si];
+                sg.sp = nullptr; sg.nT = 1;
+                sg.rowpitch = s * row; sg.colpitch = s * pix; sg.org = (sy * d->W + sx) * pix;
+                sg.Hs = (d->H - sy + s - 1) / s; sg.Ws = (d->W - sx + s - 1) / s;
+                sg.nstage = nst; sg.c0 = 0; pr.seg_wc0[si] = 0;
+            }
+        for (int ky = 0; ky < d->kh; ++ky)
+            for (int kx = 0; kx < d->kw; ++kx) {
+                const int sy = fmod_(ky - p, s), sx = fmod_(kx - p, s);
+                const int da = (ky - p - sy) / s, db = (kx - p - sx) / s;
+                if (da < -1 || da > 1 || db < -1 || db > 1 || gs.nterm >= 30) return false;
+                gs.term[gs.nterm++] = ConvQTerm{sy * s + sx, da, db, ky * d->kw + kx};
+                ++per_seg[sy * s + sx];
+            }
+        for (int si = 0; si < pr.nseg; ++si) {
+            if (per_seg[si] == 0) return false;   // a sub-image nobody reads (kernel smaller than the stride)
+            if (per_seg[si] == 1 && s > 1) {      // filler: the same tap again with zero weights
+                for (int k = 0; k < gs.nterm; ++k)
+                    if (gs.term[k].seg == si) { ConvQTerm f = gs.term[k]; f.wtap = -1; gs.term[gs.nterm++] = f; break; }
+            }
+        }
+        pr.periodic = s == 1 ? 1 : 0;
+    } else {
+        pr.s_oc = taps; pr.s_ic = (long long)d->Co * taps;
+        pr.nseg = 1;
+        CQSeg& sg = pr.seg[0];
+        sg.sp = nullptr; sg.nT = 1; sg.rowpitch = row; sg.colpitch = pix; sg.org = 0; sg.Hs = d->H; sg.Ws = d->W; sg.nstage = nst; sg.c0 = 0;
+        pr.seg_wc0[0] = 0;
+        pr.H = (g.Ho + s - 1) / s; pr.W = (g.Wo + s - 1) / s;
+        pr.phases = s == 2 ? 1 : 0;
+        pr.ngs = s * s;
+        for (int py = 0; py < s; ++py)
+            for (int px = 0; px < s; ++px) {
+                ConvQGroupSet& gs = pr.gs[py * s + px];
+                gs.nt0 = s == 2 ? 2 * (py * 2 + px) : 0; gs.ntn = s == 2 ? 2 : 8; gs.nterm = 0;
+                for (int ky = fmod_(py + p, s); ky < d->kh; ky += s)
+                    for (int kx = fmod_(px + p, s); kx < d->kw; kx += s) {
+                        const int da = -(ky - py - p) / s, db = -(kx - px - p) / s;
+                        if (da < -1 || da > 1 || db < -1 || db > 1 || gs.nterm >= 30) return false;
+                        gs.term[gs.nterm++] = ConvQTerm{0, da, db, ky * d->kw + kx};
+                    }
+                if (gs.nterm == 0) return false;
+            }
+        pr.periodic = s == 1 ? 1 : 0;
+    }
+    return true;
+}
+
+int ex_forward_q(const vpx_conv_desc* d, const ExGeo& g, const char* x_sp, long long x_bstride, long long x_tstride, int x_nT,
+                 const float* w, const float* bias, float* y, char* y_sp, char* wpk, bool weights_packed, hipStream_t stream) {
+    static thread_local ConvQProblem pr;
+    if (!exq_problem(d, g, pr)) { set_error("vpx_conv2d_ex_fwd_from_split: layer not implemented on split input"); return VPX_ERR_UNSUPPORTED; }
+    for (int i = 0; i < pr.nseg; ++i) { pr.seg[i].sp = x_sp; pr.seg[i].bstride = x_bstride; pr.seg[i].tstride = x_tstride; pr.seg[i].nT = x_nT > 0 ? x_nT : 1; }
+    pr.w = w;
+    ConvQEpiArgs ea{};
+    ea.bias = bias; ea.leaky = d->leaky_slope; ea.Co = d->Co; ea.split = d->Co;
+    const int s = d->transposed ? d->stride : 1;
+    ea.oys = s; ea.oxs = s; ea.oyo = 0; ea.oxo = 0; ea.Hmem = g.Ho; ea.Wmem = g.Wo;
+    ea.out0 = y; ea.bstride0 = (long long)g.Ho * g.Wo * d->Co; ea.ld0 = d->Co;
+    ea.sp_out = y_sp; ea.sp_bstride = (long long)g.Ho * g.Wo * d->Co * 4;
+    return convq_run(pr, ea, wpk, weights_packed, stream);
 }
 
 constexpr long long GLUE_SLAB_FLOATS = 4ll << 20;  // K-slice slab budget of the glue weight gradients (16 MB)

@@ -1,0 +1,636 @@
+// convq.hip — a schedule-driven convolution on the second-generation main loop (split-bf16 operands, all staging by LDS-DMA,
+// v_mfma_f32_16x16x32_bf16): the EF stage glue of convlstm-shi (ef_blocks.py:15-49, layer table ef_conv_lstm.py:36-65) — stride-2
+// convolutions, stride-2 transposed convolutions, the stride-1 transposed 3x3 — and their adjoints (data gradients).
+//
+// Everything such a layer needs is a list of TERMS: "tap (da, db) of source sub-image s contributes to output group g with
+// weight tap w". A stride-2 convolution reads the four sub-images x[2i + sy, 2j + sx] of its input (addressed in place:
+// the LDS-DMA source address carries the pixel stride), each with its own taps; a stride-2 transposed convolution computes its
+// four output phases as four column groups of ONE N tile over the same input halo tile (like the four gates of the cell).
+// The host pairs the taps of each 16-channel stage into K = 32 steps (any two taps of a stage, or the last tap of one stage with
+// the first of the next: a lane's fragment address is base(lane) + (lane half ? offB : offA)), lays the steps out in weight
+// chunks of 128 columns x 32 k and hands the kernel a table of at most 64 steps that covers all stages (or two / four stages,
+// repeated, when every stage has the same taps: 3x3 and 5x5 'same' convolutions). The kernel keeps the table in one VGPR pair
+// (lane i = step i, v_readlane: no memory access inside the loop) and runs cell2_kernel_q's pipeline: two activation stage
+// buffers, a ring of three weight chunks, one sync point per chunk (counted vmcnt -> barrier -> next copies, spread behind the
+// MFMAs), fragments of the next column tile / step read ahead of the MFMAs.
+#include <stdlib.h>
+#include <string.h>
+
+#include "cell2_dev.h"
+#include "vpx_host.h"
+
+namespace vpx {
+
+// ---- schedule entry (64 bits) --------------------------------------------------------------------------------------
+// [0,17) offA  [17,34) offB  [34,42) mask of 16-column tiles  [42,45) bcol0  [45] first step of a chunk  [46] stage copy at this
+// chunk's sync  [47] ... issued BEFORE the weight chunk  [48] late: this step's activation fragments are read after its sync
+// [49,56) stage to copy (relative to the pass)  [56,63) stage of tap A (relative)
+static inline unsigned long long cq_entry(unsigned offA, unsigned offB, unsigned mask, unsigned bcol0, unsigned newchunk, unsigned issue,
+                                          unsigned afirst, unsigned late, unsigned istage, unsigned stA) {
+    return (unsigned long long)offA | ((unsigned long long)offB << 17) | ((unsigned long long)mask << 34) | ((unsigned long long)bcol0 << 42) |
+           ((unsigned long long)newchunk << 45) | ((unsigned long long)issue << 46) | ((unsigned long long)afirst << 47) |
+           ((unsigned long long)late << 48) | ((unsigned long long)istage << 49) | ((unsigned long long)stA << 56);
+}
+struct CQDec { int offA, offB, mask, bcol0, newchunk, issue, afirst, late, istage, stA; };
+__host__ __device__ __forceinline__ CQDec cq_decode(unsigned lo, unsigned hi) {
+    CQDec d;
+    d.offA = (int)(lo & 0x1ffff);
+    d.offB = (int)((lo >> 17) | ((hi & 3u) << 15));
+    d.mask = (int)((hi >> 2) & 0xff);
+    d.bcol0 = (int)((hi >> 10) & 7);
+    d.newchunk = (int)((hi >> 13) & 1);
+    d.issue = (int)((hi >> 14) & 1);
+    d.afirst = (int)((hi >> 15) & 1);
+    d.late = (int)((hi >> 16) & 1);
+    d.istage = (int)((hi >> 17) & 0x7f);
+    d.stA = (int)((hi >> 24) & 0x7f);
+    return d;
+}
+
+// ---- epilogue: bias, LeakyReLU, two fp32 destinations split by channel or one destination (also) in split operand format,
+//      optional output-phase mapping (group g of the N tile = output phase (g >> 1, g & 1) of a stride-2 transposed convolution)
+struct ConvQEpi {
+    ConvQEpiArgs a;
+
+    __device__ __forceinline__ void store_sub(const float* ldsf, int lane, int b, int y0, int x0, int n_tile, int ngr, int prow, int H, int W) const {
+        const int cg = lane & 7, p4 = lane >> 3;
+        const bool v4 = ((a.Co | a.split | a.ld0 | a.ld1) & 3) == 0;
+        float* const o0 = a.out0 ? a.out0 + (size_t)b * a.bstride0 : nullptr;
+        float* const o1 = a.out1 ? a.out1 + (size_t)b * a.bstride1 : nullptr;
+        char* const sp = a.sp_out ? a.sp_out + (size_t)b * a.sp_bstride : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g >= ngr) continue;
+            const int c = (a.phases ? n_tile : n_tile * a.gpt + g) * 32 + cg * 4;
+            if (c >= a.Co) continue;
+            const int py = a.phases ? (g >> 1) : 0, px = a.phases ? (g & 1) : 0;
+            const bool first = c < a.split;
+            float* const ob = first ? o0 : o1;
+            const unsigned ld = (unsigned)(first ? a.ld0 : a.ld1);
+            const int cc = first ? c : c - a.split;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ip = k * 8 + p4;
+                const int y = y0 + prow + (ip >> 4), x = x0 + (ip & 15);
+                f32x4 v = *reinterpret_cast<const f32x4*>(ldsf + g * 1024 + ip * 32 + cg * 4);
+                const int my = y * a.oys + a.oyo + py, mx = x * a.oxs + a.oxo + px;
+                if (y >= H || x >= W || my >= a.Hmem || mx >= a.Wmem) continue;
+                const unsigned mp = (unsigned)(my * a.Wmem + mx);
+                if (v4) {
+                    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + c);
+                    if (a.accumulate && ob) v += *reinterpret_cast<const f32x4*>(ob + (size_t)mp * ld + cc);
+                    if (a.leaky != 0.0f) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.0f ? v[q] : v[q] * a.leaky;
+                    }
+                    if (ob) *reinterpret_cast<f32x4*>(ob + (size_t)mp * ld + cc) = v;
+                    if (sp && first) {
+                        unsigned h[4], l[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) c2_split(v[q], h[q], l[q]);
+                        char* dst = sp + (size_t)mp * ((unsigned)a.Co * 4u) + (unsigned)((c >> 3) * 32 + (c & 7) * 2);
+                        *reinterpret_cast<uint2*>(dst) = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+                        *reinterpret_cast<uint2*>(dst + 16) = uint2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cq = c + q;
+                        if (cq >= a.Co) continue;
+                        const bool f1 = cq < a.split;
+                        float* const oq = f1 ? o0 : o1;
+                        if (!oq) continue;
+                        const size_t eq = (size_t)mp * (unsigned)(f1 ? a.ld0 : a.ld1) + (f1 ? cq : cq - a.split);
+                        float val = v[q] + (a.bias ? a.bias[cq] : 0.f);
+                        if (a.accumulate) val += oq[eq];
+                        if (a.leaky != 0.0f) val = val > 0.0f ? val : val * a.leaky;
+                        oq[eq] = val;
+                    }
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void finish16(const f32x4 (&acc)[4][8], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
+                                             int ngr, int H, int W) const {
+        c2_barrier();
+        float* ldsf = reinterpret_cast<float*>(smem + wave * 16384);
+        const int c16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt)
+                    if ((nt >> 1) < ngr)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            ldsf[(nt >> 1) * 1024 + (mm * 16 + 4 * q4 + r) * 32 + (nt & 1) * 16 + c16] = acc[2 * mp + mm][nt][r];
+            store_sub(ldsf, lane, b, y0, x0, n_tile, ngr, 4 * wave + 2 * mp, H, W);
+        }
+    }
+};
+
+// ---- the kernel ----------------------------------------------------------------------------------------------------
+template <int HALO>
+__global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const ConvQEpi epi) {
+    constexpr int HW_ = 16 + HALO;                 // halo tile width
+    constexpr int NPOS = (32 + HALO) * HW_;        // halo positions of a 32x16 tile
+    constexpr int PPOS = HALO == 2 ? 640 : 768;    // padded: 4 planes = NP pieces per thread
+    constexpr int PLANE = PPOS * 16, ABUF = 4 * PLANE, NP = 4 * PPOS / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+
+    const unsigned L = blockIdx.x;
+    const long long total = (long long)P.grid_m * P.n_tiles;
+    const long long per_xcd = (total + 7) / 8;
+    const long long sidx = (long long)(L & 7) * per_xcd + (L >> 3);
+    if ((long long)(L >> 3) >= per_xcd || sidx >= total) return;
+    int mt = (int)(sidx / P.n_tiles);
+    const int n_tile = (int)(sidx - (long long)mt * P.n_tiles);
+    const int tx = mt % P.tiles_x;
+    mt /= P.tiles_x;
+    const int ty = mt % P.tiles_y;
+    const int b = mt / P.tiles_y;
+    const int x0 = tx * 16, y0 = ty * 32;
+    int ngr = P.n_groups - n_tile * P.gpt;   // 32-column groups of this N tile that hold outputs
+    if (ngr > P.gpt) ngr = P.gpt;
+    const int tmask = (1 << (2 * ngr)) - 1;  // column tiles of those groups: the MFMAs of the others are skipped
+
+    char* const Abuf = smem;
+    char* const Wbuf = smem + 2 * ABUF;
+
+    // the schedule: lane i keeps entry i
+    const unsigned long long my_entry = P.sched[lane];
+    const int e_lo = (int)(unsigned)my_entry, e_hi = (int)(unsigned)(my_entry >> 32);
+
+    int php[NP], choff[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int piece = tid + 512 * u;
+        const int plane = piece / PPOS, pos = piece - plane * PPOS;
+        const int hy = pos / HW_, hx = pos - hy * HW_;
+        php[u] = pos < NPOS ? ((hy << 8) | hx) : -1;
+        choff[u] = (plane & 1) * 32 + (plane >> 1) * 16;   // plane = part*2 + khalf; pixel row: [group][hi 16 B | lo 16 B]
+    }
+    const int dma_off = (wave * 64) * 16;
+    const char* const wtile = P.wpk + (size_t)n_tile * P.nchunk_total * CQ_WCHUNK + tid * 16;
+    const int S = P.S;
+
+    // source of a stage (scalars): segment lookup + the image's base; stages >= S read zeros
+    struct Src { const char* base; int rowp, colp, Hs, Ws; };
+    auto stage_src = [&](int s) -> Src {
+        int first = 0, si = 0;
+        bool go = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (go && i + 1 < P.nseg && s >= first + P.seg[i].nstage) { first += P.seg[i].nstage; si = i + 1; }
+            else go = false;
+        }
+        const CQSeg sg = P.seg[si];
+        const int bb = b / sg.nT, tt = b - bb * sg.nT;
+        Src r;
+        r.base = s < S ? sg.sp + (size_t)bb * sg.bstride + (size_t)tt * sg.tstride + sg.org + (size_t)(sg.c0 + 16 * (s - first)) * 4 : nullptr;
+        r.rowp = sg.rowpitch; r.colp = sg.colpitch; r.Hs = sg.Hs; r.Ws = sg.Ws;
+        return r;
+    };
+    auto issue_A1 = [&](const Src& sc, int buf, int u) {
+        const int hy = php[u] >> 8, hx = php[u] & 255;
+        const int gy = y0 + P.oy + hy, gx = x0 + P.ox + hx;
+        const bool ok = (sc.base != nullptr) & (php[u] >= 0) & ((unsigned)gy < (unsigned)sc.Hs) & ((unsigned)gx < (unsigned)sc.Ws);
+        const char* src = ok ? sc.base + (size_t)((unsigned)(gy * sc.rowp) + (unsigned)(gx * sc.colp)) + choff[u]
+                             : reinterpret_cast<const char*>(c2_zero16);
+        c2_dma16(src, Abuf + buf * ABUF + dma_off + u * 8192);
+    };
+    auto issue_W1 = [&](int chunk, int slot, int u) {
+        c2_dma16(wtile + (size_t)chunk * CQ_WCHUNK + u * 8192, Wbuf + slot * CQ_WCHUNK + dma_off + u * 8192);
+    };
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][nt][r] = 0.0f;
+
+    // lane bases: activation fragments (buffer 0, halo position (0,0), tile row 4 * wave, hi plane); weight fragments
+    const int a_lane = (kg & 1) * PLANE + ((4 * wave) * HW_ + r16) * 16;
+    const int w_lane = kg * 2048 + r16 * 16;
+    const bool tselB = (kg >> 1) != 0;
+    bf16x8 ah[4], al[4], bh[2], bl[2], bnh, bnl;
+    auto load_A1 = [&](int va, int m) {
+        const char* a = smem + va + m * (HW_ * 16);
+        ah[m] = *reinterpret_cast<const bf16x8*>(a);
+        al[m] = *reinterpret_cast<const bf16x8*>(a + 2 * PLANE);
+    };
+
+    if (S > 0 && P.nsub > 0) {
+        // ---- prologue: stage 0 (and stage 1 where the schedule expects it to be under way), chunks 0 and 1 ----
+        Src aq_src = stage_src(0);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) issue_A1(aq_src, 0, u);
+        if (P.pro_stage1) {
+            const Src s1 = stage_src(1);
+#pragma unroll
+            for (int u = 0; u < NP; ++u) issue_A1(s1, 1, u);
+        }
+        issue_W1(0, 0, 0); issue_W1(0, 0, 1);
+        if (P.nchunk_total > 1) { issue_W1(1, 1, 0); issue_W1(1, 1, 1); }
+        C2_WAIT_VM(0);
+        c2_barrier();
+
+        int idx = 0, base = 0, c = -1;
+        bool a_pending = false;                 // a stage copy issued AFTER the last weight chunk may still fly at the next sync
+        int wq = -1, wq_slot = 0;               // weight chunk still to issue for this sync (-1: none)
+        int aq = 0, aq_buf = 0; bool aq_first = false;   // stage-copy pieces still to issue: aq = next piece + 1 (0: none)
+        CQDec cur = cq_decode((unsigned)__builtin_amdgcn_readlane(e_lo, 0), (unsigned)__builtin_amdgcn_readlane(e_hi, 0));
+        cur.mask &= tmask;
+        {
+            const int va = a_lane + (tselB ? cur.offB : cur.offA);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) load_A1(va, m);
+            const char* w = Wbuf + w_lane + (cur.bcol0 + __builtin_ctz(cur.mask | 0x100)) * 256;
+            bnh = *reinterpret_cast<const bf16x8*>(w);
+            bnl = *reinterpret_cast<const bf16x8*>(w + 8192);
+        }
+        // at most two copy pieces per call: the sync's weight chunk and stage copy trickle out behind the MFMAs of the column tiles
+        // (a burst right after the barrier keeps all eight waves off the matrix pipe while the LDS-DMA instructions issue)
+        auto issue_slot = [&]() {
+            if (wq >= 0 && !(aq_first && aq > 0)) { issue_W1(wq, wq_slot, 0); issue_W1(wq, wq_slot, 1); wq = -1; return; }
+            if (aq == 1) { issue_A1(aq_src, aq_buf, 0); issue_A1(aq_src, aq_buf, 1); aq = 3; }
+            else if (aq == 3) { issue_A1(aq_src, aq_buf, 2); issue_A1(aq_src, aq_buf, 3); aq = 5; }
+            else if (aq == 5) { issue_A1(aq_src, aq_buf, 4); if (NP > 5) issue_A1(aq_src, aq_buf, NP - 1); aq = 0; }
+        };
+        while (true) {
+            if (cur.newchunk) {
+                // ---- sync point of chunk c (first: everything the previous sync queued has been issued) ----
+                while (wq >= 0 || aq > 0) issue_slot();
+                ++c;
+                if (c > 0) {
+                    if (a_pending) { if (NP == 5) C2_WAIT_VM(5); else C2_WAIT_VM(6); } else C2_WAIT_VM(0);
+                    c2_barrier();
+                }
+                a_pending = false;
+                if (c + 2 < P.nchunk_total) { wq = c + 2; wq_slot = (c + 2) % 3; }
+                if (cur.issue) {
+                    const int st = base + cur.istage;
+                    if (st <= S) {       // st == S: zero fill (a cross step may read that buffer against zero weights)
+                        aq_src = stage_src(st);
+                        aq = 1; aq_buf = st & 1; aq_first = cur.afirst != 0;
+                        a_pending = !aq_first;
+                    }
+                }
+                if (cur.late) {          // a stage that landed with this very sync: its fragments could not be read ahead
+                    const int va = a_lane + (tselB ? cur.offB : cur.offA);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) load_A1(va, m);
+                }
+            }
+            const int slot = c % 3;
+            // next entry (the schedule wraps around with the stage base advanced)
+            int nidx = idx + 1, nbase = base;
+            if (nidx == P.nsub) { nidx = 0; nbase = base + P.SP; }
+            CQDec nxt = cq_decode((unsigned)__builtin_amdgcn_readlane(e_lo, nidx), (unsigned)__builtin_amdgcn_readlane(e_hi, nidx));
+            nxt.mask &= tmask;
+            const bool more = nbase + nxt.stA < S;
+            const int n_va = a_lane + (tselB ? nxt.offB : nxt.offA);
+            const int n_slot = nxt.newchunk ? (c + 1) % 3 : slot;
+            const char* const n_w = Wbuf + n_slot * CQ_WCHUNK + w_lane + (nxt.bcol0 + __builtin_ctz(nxt.mask | 0x100)) * 256;
+            const char* const wb = Wbuf + slot * CQ_WCHUNK + w_lane + cur.bcol0 * 256;
+            const bool n_ahead = !nxt.late;
+            const int mask = cur.mask;
+            // the first column tile's weight fragments were read ahead into the spare set
+            if (__builtin_ctz(mask | 0x100) & 1) { bh[1] = bnh; bl[1] = bnl; } else { bh[0] = bnh; bl[0] = bnl; }
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                if (!((mask >> nt) & 1)) continue;
+                const bool last = (mask >> (nt + 1)) == 0;
+                if (!last) {
+                    bh[(nt + 1) & 1] = *reinterpret_cast<const bf16x8*>(wb + (nt + 1) * 256);
+                    bl[(nt + 1) & 1] = *reinterpret_cast<const bf16x8*>(wb + (nt + 1) * 256 + 8192);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        f32x4 cc = acc[m][nt];
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[nt & 1], cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[nt & 1], cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[nt & 1], cc, 0, 0, 0);
+                        acc[m][nt] = cc;
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                } else {
+                    // last column tile of the step: the next step's first weight fragments, and its activation rows as they free up
+                    bnh = *reinterpret_cast<const bf16x8*>(n_w);
+                    bnl = *reinterpret_cast<const bf16x8*>(n_w + 8192);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        f32x4 cc = acc[m][nt];
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[nt & 1], cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[nt & 1], cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[nt & 1], cc, 0, 0, 0);
+                        acc[m][nt] = cc;
+                        if (n_ahead) load_A1(n_va, m);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                if (wq >= 0 || aq > 0) issue_slot();
+            }
+            if (!more) break;
+            idx = nidx; base = nbase; cur = nxt;
+        }
+        while (wq >= 0 || aq > 0) issue_slot();   // (nothing the outputs depend on: keeps the queue accounting simple)
+        C2_WAIT_VM(0);                            // no copy may land in the epilogue's transposition space
+    }
+    epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+}
+
+// ---- weight pack: [n_tile][chunk][part][k group][n][8 bf16]; the table says, per chunk of a pass and 16-column tile, which
+//      (stage, weight tap) the two lane halves multiply ----
+struct ConvQPackArgs {
+    const float* w; long long s_oc, s_ic;
+    int Co, col0, n_tiles, gpt, phases, colw;   // colw: columns of one step (128 unless several steps sit side by side in a chunk)
+    int S, SP, nchunk_pass, nchunk_total;
+    int nseg; int seg_nstage[4], seg_wc0[4];
+    signed char tab[64][8][4];   // [chunk of a pass][16-column tile][stage A (relative), weight tap A, stage B, weight tap B]; tap < 0: zeros
+};
+
+__global__ void convq_pack_kernel(const ConvQPackArgs pk, char* __restrict__ dst) {
+    const long long total = (long long)pk.n_tiles * pk.nchunk_total * (CQ_WCHUNK / 2);  // bf16 elements
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e & 7);
+        long long r = e >> 3;
+        const int n = (int)(r & 127); r >>= 7;
+        const int kg = (int)(r & 3); r >>= 2;
+        const int part = (int)(r & 1); r >>= 1;
+        const int q = (int)(r % pk.nchunk_total);
+        const int n_tile = (int)(r / pk.nchunk_total);
+        const int tsel = kg >> 1, khalf = kg & 1;
+        const int pass = q / pk.nchunk_pass, cq = q - pass * pk.nchunk_pass;
+        const signed char* t = pk.tab[cq][n >> 4];
+        const int stage = pass * pk.SP + t[2 * tsel], tap = t[2 * tsel + 1];
+        float v = 0.0f;
+        if (tap >= 0 && stage < pk.S) {
+            const int nn = n % pk.colw;   // column inside its step
+            const int g = nn >> 5, j = nn & 31;
+            const int oc = pk.phases ? n_tile * 32 + j : (n_tile * pk.gpt + g) * 32 + j;
+            if (oc < pk.Co && (pk.phases || g < pk.gpt)) {
+                int first = 0, si = 0;
+                bool go = true;
+                for (int k = 0; k < 3; ++k) {
+                    if (go && k + 1 < pk.nseg && stage >= first + pk.seg_nstage[k]) { first += pk.seg_nstage[k]; si = k + 1; }
+                    else go = false;
+                }
+                const int ic = pk.seg_wc0[si] + 16 * (stage - first) + khalf * 8 + i;
+                v = pk.w[(long long)ic * pk.s_ic + (long long)(pk.col0 + oc) * pk.s_oc + tap];
+            }
+        }
+        unsigned hi, lo;
+        c2_split(v, hi, lo);
+        reinterpret_cast<unsigned short*>(dst)[e] = (unsigned short)(part ? lo : hi);
+    }
+}
+
+// ---- host: schedule construction ----------------------------------------------------------------------------------
+namespace {
+
+struct QTap { int stage, off, wtap; };       // off: byte offset of the tap inside its stage buffer (without the buffer's own offset)
+struct QSub { int chunk, nt0, ntn, bcol0; QTap a, b; bool has_b; };
+
+struct QBuild {
+    ConvQPlan P;
+    ConvQPackArgs pk;
+    int halo;
+};
+
+int seg_of_stage(const ConvQProblem& pr, int s) {
+    int first = 0;
+    for (int i = 0; i < pr.nseg; ++i) { if (s < first + pr.seg[i].nstage) return i; first += pr.seg[i].nstage; }
+    return pr.nseg - 1;
+}
+
+int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
+    if (pr.halo != 2 && pr.halo != 4) { set_error("convq: halo %d", pr.halo); return VPX_ERR_ARG; }
+    const int HW_ = 16 + pr.halo, PPOS = pr.halo == 2 ? 640 : 768, ABUF = 4 * PPOS * 16, org = pr.halo / 2;
+    int S = 0;
+    for (int i = 0; i < pr.nseg; ++i) S += pr.seg[i].nstage;
+    if (S < 1 || pr.nseg < 1 || pr.nseg > 4 || pr.ngs < 1 || pr.ngs > 4) { set_error("convq: bad problem (S=%d nseg=%d ngs=%d)", S, pr.nseg, pr.ngs); return VPX_ERR_ARG; }
+    const bool periodic = pr.periodic != 0;
+    if (periodic && pr.ngs != 1) { set_error("convq: a periodic schedule takes one group set"); return VPX_ERR_ARG; }
+    const int n_tiles = pr.phases ? (pr.Co + 31) / 32 : ((pr.Co + 31) / 32 + 3) / 4;
+    const int n_groups = pr.phases ? 4 * n_tiles : (pr.Co + 31) / 32;   // (phases: every N tile holds the four phases of its 32 channels)
+    const int gpt = pr.phases ? 4 : (n_groups + n_tiles - 1) / n_tiles;
+    // steps that use few column tiles sit side by side in one weight chunk (Co <= 64 with a single N tile)
+    int cpack = 1, ntn_plain = 8;
+    if (!pr.phases) {
+        if (pr.ngs != 1) { set_error("convq: several group sets need the phase mapping"); return VPX_ERR_ARG; }
+        const int cols = pr.Co < gpt * 32 ? pr.Co : gpt * 32;
+        ntn_plain = (cols + 15) / 16;
+        if (n_tiles == 1 && max_cpack > 1 && (ntn_plain == 1 || ntn_plain == 2 || ntn_plain == 4)) cpack = 8 / ntn_plain;
+        if (cpack > max_cpack) cpack = max_cpack;
+    }
+    int SP = periodic ? 2 : S;
+    if (periodic && ((2 * pr.gs[0].nterm) & 1)) SP = 4;   // (never: 2 * n is even; kept for clarity of the rule below)
+    if (periodic) {
+        int pairs = SP * pr.gs[0].nterm / 2;
+        while (cpack > 1 && pairs % cpack) cpack >>= 1;
+    }
+    const int NSV = periodic ? 3 * SP : S;   // stages laid out (periodic: three passes, the middle one is the steady state)
+
+    // sub-steps, chunk by chunk
+    static thread_local QSub subs[4096];
+    int nsub = 0, nchunk = 0;
+    auto tap_of = [&](int stage, const ConvQTerm& t) {
+        QTap q; q.stage = stage; q.off = ((t.da + org) * HW_ + (t.db + org)) * 16; q.wtap = t.wtap; return q;
+    };
+    if (pr.ngs == 1) {
+        // one group set: the taps of all stages in one line, paired in order (the last tap of a stage with the first of the next)
+        static thread_local QTap line[8192];
+        int n = 0;
+        const ConvQGroupSet& gs = pr.gs[0];
+        for (int s = 0; s < NSV; ++s)
+            for (int k = 0; k < gs.nterm; ++k) {
+                if (!periodic && gs.term[k].seg != seg_of_stage(pr, s)) continue;
+                if (n >= 8192) { set_error("convq: too many taps"); return VPX_ERR_UNSUPPORTED; }
+                line[n++] = tap_of(s, gs.term[k]);
+            }
+        const int pairs = (n + 1) / 2;
+        nchunk = (pairs + cpack - 1) / cpack;
+        for (int p = 0; p < pairs; ++p) {
+            if (nsub >= 4096) { set_error("convq: schedule too long"); return VPX_ERR_UNSUPPORTED; }
+            QSub& q = subs[nsub++];
+            q.chunk = p / cpack; q.nt0 = 0; q.ntn = ntn_plain; q.bcol0 = (p % cpack) * ntn_plain;
+            q.a = line[2 * p]; q.has_b = 2 * p + 1 < n; q.b = q.has_b ? line[2 * p + 1] : line[2 * p];
+        }
+    } else {
+        // several group sets (output phases): stage by stage, each set pairs its own taps of that stage; a chunk holds the k-th pair of every set
+        for (int s = 0; s < NSV; ++s) {
+            int maxp = 0;
+            for (int g = 0; g < pr.ngs; ++g) {
+                int cnt = 0;
+                for (int k = 0; k < pr.gs[g].nterm; ++k) if (pr.gs[g].term[k].seg == seg_of_stage(pr, s)) ++cnt;
+                if ((cnt + 1) / 2 > maxp) maxp = (cnt + 1) / 2;
+            }
+            for (int p = 0; p < maxp; ++p) {
+                for (int g = 0; g < pr.ngs; ++g) {
+                    QTap tp[2]; int cnt = 0, seen = 0;
+                    for (int k = 0; k < pr.gs[g].nterm; ++k) {
+                        if (pr.gs[g].term[k].seg != seg_of_stage(pr, s)) continue;
+                        if (seen >= 2 * p && seen < 2 * p + 2) tp[cnt++] = tap_of(s, pr.gs[g].term[k]);
+                        ++seen;
+                    }
+                    if (!cnt) continue;
+                    if (nsub >= 4096) { set_error("convq: schedule too long"); return VPX_ERR_UNSUPPORTED; }
+                    QSub& q = subs[nsub++];
+                    q.chunk = nchunk + p; q.nt0 = pr.gs[g].nt0; q.ntn = pr.gs[g].ntn; q.bcol0 = 0;
+                    q.a = tp[0]; q.has_b = cnt > 1; q.b = q.has_b ? tp[1] : tp[0];
+                }
+            }
+            nchunk += maxp;
+        }
+    }
+    if (nchunk < 1) { set_error("convq: empty schedule"); return VPX_ERR_ARG; }
+
+    // per stage: first / last chunk that reads it; then the sync at which its copy is issued (stage t >= 1; stage 0: prologue)
+    static thread_local int fu[8192], lu[8192], ev_stage[8192], ev_first[8192], late_chunk[8192];
+    if (NSV > 8192 || nchunk > 8192) { set_error("convq: problem too large"); return VPX_ERR_UNSUPPORTED; }
+    for (int s = 0; s < NSV; ++s) { fu[s] = 1 << 30; lu[s] = -1; }
+    for (int i = 0; i < nsub; ++i)
+        for (int h = 0; h < 2; ++h) {
+            const int st = h ? subs[i].b.stage : subs[i].a.stage;
+            if (subs[i].chunk < fu[st]) fu[st] = subs[i].chunk;
+            if (subs[i].chunk > lu[st]) lu[st] = subs[i].chunk;
+        }
+    for (int k = 0; k < nchunk; ++k) { ev_stage[k] = -1; ev_first[k] = 0; late_chunk[k] = 0; }
+    for (int t = 1; t < NSV; ++t) {
+        if (lu[t] < 0) continue;   // a stage nobody reads (cannot happen with well-formed terms)
+        const int lo = t >= 2 ? lu[t - 2] + 1 : 0;
+        // copy issued at sync ci after the weight chunk: landed for reads after sync ci + 2; before it: after sync ci + 1. Reads of
+        // chunk fu's first step are issued at the end of chunk fu - 1 — unless that step is marked late (read after its own sync).
+        int ci = -1, afirst = 0, late = 0;
+        for (int mode = 0; mode < 3 && ci < 0; ++mode) {
+            const int hi = fu[t] - (mode == 0 ? 3 : (mode == 1 ? 2 : 1));
+            for (int k = lo; k <= hi; ++k)
+                if (k >= 0 && ev_stage[k] < 0) { ci = k; afirst = mode >= 1; late = mode == 2; break; }
+        }
+        if (ci < 0) {
+            if (cpack > 1) return convq_build(pr, out, 1);   // short stages: one step per weight chunk gives every stage its chunk boundaries
+            set_error("convq: stage %d cannot be double-buffered (first use chunk %d, buffer free from chunk %d)", t, fu[t], lo);
+            return VPX_ERR_UNSUPPORTED;
+        }
+        ev_stage[ci] = t; ev_first[ci] = afirst;
+        if (late) late_chunk[fu[t]] = 1;
+    }
+
+    // extract the pass the kernel repeats
+    const int nchunk_pass = periodic ? nchunk / 3 : nchunk;
+    if (periodic && nchunk % 3) { set_error("convq: periodic schedule does not divide into passes"); return VPX_ERR_UNSUPPORTED; }
+    const int c0 = periodic ? nchunk_pass : 0, s0 = periodic ? SP : 0;
+    if (nchunk_pass > 64) { set_error("convq: %d weight chunks per pass (max 64)", nchunk_pass); return VPX_ERR_UNSUPPORTED; }
+    QBuild& B = out;
+    memset(&B.P, 0, sizeof(B.P));
+    memset(&B.pk, 0, sizeof(B.pk));
+    for (int k = 0; k < 64; ++k) for (int t = 0; t < 8; ++t) { B.pk.tab[k][t][0] = 0; B.pk.tab[k][t][1] = -1; B.pk.tab[k][t][2] = 0; B.pk.tab[k][t][3] = -1; }
+    int ne = 0, prev_chunk = -1;
+    bool rel1 = false, relSP1 = false;
+    for (int i = 0; i < nsub; ++i) {
+        const QSub& q = subs[i];
+        if (q.chunk < c0 || q.chunk >= c0 + nchunk_pass) continue;
+        if (ne >= 64) { set_error("convq: more than 64 steps per pass"); return VPX_ERR_UNSUPPORTED; }
+        const int ck = q.chunk - c0;
+        const bool newchunk = q.chunk != prev_chunk;
+        prev_chunk = q.chunk;
+        const int stA = q.a.stage - s0, stB = q.b.stage - s0;
+        if (stA < 0 || stB < 0 || stA > 127 || stB > 127) { set_error("convq: stage index out of range"); return VPX_ERR_UNSUPPORTED; }
+        const unsigned offA = (unsigned)((q.a.stage & 1) * ABUF + q.a.off), offB = (unsigned)((q.b.stage & 1) * ABUF + q.b.off);
+        unsigned issue = 0, afirst = 0, istage = 0, late = 0;
+        if (newchunk) {
+            if (ev_stage[q.chunk] >= 0) {
+                issue = 1; afirst = (unsigned)ev_first[q.chunk]; istage = (unsigned)(ev_stage[q.chunk] - s0);
+                if (istage == 1) rel1 = true;
+                if ((int)istage == SP + 1) relSP1 = true;
+                if (istage > 127) { set_error("convq: stage index out of range"); return VPX_ERR_UNSUPPORTED; }
+            }
+            late = (unsigned)late_chunk[q.chunk];
+        }
+        const unsigned mask = ((1u << q.ntn) - 1u) << q.nt0;
+        B.P.sched[ne++] = cq_entry(offA, offB, mask, (unsigned)q.bcol0, newchunk ? 1u : 0u, issue, afirst, late, istage, (unsigned)stA);
+        for (int t = 0; t < q.ntn; ++t) {
+            signed char* row = B.pk.tab[ck][q.bcol0 + q.nt0 + t];
+            row[0] = (signed char)stA; row[1] = (signed char)q.a.wtap;
+            row[2] = (signed char)stB; row[3] = (signed char)(q.has_b ? q.b.wtap : -1);
+        }
+    }
+    // total chunks over the S real stages
+    int nchunk_total;
+    if (periodic) {
+        const int n_taps = S * pr.gs[0].nterm, pairs = (n_taps + 1) / 2;
+        nchunk_total = (pairs + cpack - 1) / cpack;
+    } else {
+        nchunk_total = nchunk;
+    }
+    ConvQPlan& P = B.P;
+    P.B = pr.N; P.H = pr.H; P.W = pr.W;
+    P.tiles_x = (pr.W + 15) / 16; P.tiles_y = (pr.H + 31) / 32; P.n_tiles = n_tiles; P.grid_m = pr.N * P.tiles_x * P.tiles_y;
+    P.n_groups = n_groups; P.gpt = gpt;
+    P.S = S; P.SP = SP; P.nsub = ne; P.nchunk_total = nchunk_total;
+    P.pro_stage1 = (periodic && relSP1 && !rel1) ? 1 : 0;
+    P.oy = -org; P.ox = -org; P.nseg = pr.nseg;
+    for (int i = 0; i < pr.nseg; ++i) P.seg[i] = pr.seg[i];
+    ConvQPackArgs& pk = B.pk;
+    pk.w = pr.w; pk.s_oc = pr.s_oc; pk.s_ic = pr.s_ic;
+    pk.Co = pr.Co; pk.col0 = pr.col0; pk.n_tiles = n_tiles; pk.gpt = gpt; pk.phases = pr.phases;
+    pk.colw = cpack > 1 ? 128 / cpack : 128;
+    pk.S = S; pk.SP = SP; pk.nchunk_pass = nchunk_pass; pk.nchunk_total = nchunk_total;
+    pk.nseg = pr.nseg;
+    for (int i = 0; i < pr.nseg; ++i) { pk.seg_nstage[i] = pr.seg[i].nstage; pk.seg_wc0[i] = pr.seg_wc0[i]; }
+    B.halo = pr.halo;
+    return VPX_OK;
+}
+
+template <int HALO>
+hipError_t launch_convq_t(const ConvQPlan& P, const ConvQEpi& epi, hipStream_t s) {
+    constexpr int LDS = 2 * 4 * (HALO == 2 ? 640 : 768) * 16 + 3 * CQ_WCHUNK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convq_kernel<HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long long per_xcd = ((long long)P.grid_m * P.n_tiles + 7) / 8;
+    hipLaunchKernelGGL((convq_kernel<HALO>), dim3((unsigned)(per_xcd * 8)), dim3(512), LDS, s, P, epi);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t convq_wpk_bytes(const ConvQProblem& pr) {
+    static thread_local QBuild b;
+    if (convq_build(pr, b) != VPX_OK) return 0;
+    return (size_t)b.P.n_tiles * b.P.nchunk_total * CQ_WCHUNK;
+}
+
+int convq_run(const ConvQProblem& pr, const ConvQEpiArgs& ea_in, char* wpk, bool weights_packed, hipStream_t s) {
+    static thread_local QBuild b;
+    int rc = convq_build(pr, b);
+    if (rc != VPX_OK) return rc;
+    if (!weights_packed) {
+        const long long total = (long long)b.pk.n_tiles * b.pk.nchunk_total * (CQ_WCHUNK / 2);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(convq_pack_kernel, dim3(blocks), dim3(256), 0, s, b.pk, wpk);
+        VPX_CHECK_HIP(hipGetLastError());
+    }
+    b.P.wpk = wpk;
+    ConvQEpi epi{ea_in};
+    epi.a.gpt = b.P.gpt;
+    epi.a.phases = pr.phases;
+    if (b.halo == 2) VPX_CHECK_HIP(launch_convq_t<2>(b.P, epi, s));
+    else VPX_CHECK_HIP(launch_convq_t<4>(b.P, epi, s));
+    return VPX_OK;
+}
+
+}  // namespace vpx

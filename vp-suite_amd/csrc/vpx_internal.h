@@ -166,6 +166,49 @@ struct Conv2Args {
 hipError_t launch_conv2_pack(const Conv2Pack& pk, void* dst, hipStream_t s);
 hipError_t launch_conv2(const Conv2Args& c, hipStream_t s);
 
+// ---- schedule-driven K = 32 convolution on split operands (convq.hip): EF stage glue and its adjoints ----
+struct CQSeg {                 // one activation source: a (sub-)image of a split-format tensor
+    const char* sp;            // tensor base
+    long long bstride, tstride; int nT, _p0;   // image n = (n / nT) * bstride + (n % nT) * tstride  (BYTES; nT = 1: plain batch)
+    int rowpitch, colpitch;    // bytes between consecutive tile-space rows / columns (a stride-2 sub-image: twice the tensor's)
+    int org;                   // byte offset of the sub-image's pixel (0, 0) (sub-position (sy, sx) of a stride-2 source)
+    int Hs, Ws;                // its extent: tile-space positions outside [0, Hs) x [0, Ws) read zeros
+    int nstage, c0;            // 16-channel stages taken from it, first channel (multiple of 8)
+    int _p1;
+};
+struct ConvQPlan {
+    int B, H, W, tiles_x, tiles_y, n_tiles, grid_m;
+    int n_groups, gpt;         // 32-column output groups in total / per N tile
+    int S, SP, nsub, nchunk_total, pro_stage1;   // stages; stages per pass of the schedule; its entries; weight chunks; copy stage 1 in the prologue
+    int oy, ox, nseg;
+    CQSeg seg[4];
+    const char* wpk;           // [n_tile][chunk][16 KiB]
+    unsigned long long sched[64];
+};
+struct ConvQEpiArgs {          // bias, LeakyReLU, destinations (see ConvQEpi, convq.hip)
+    const float* bias;
+    float leaky;
+    int Co, split, gpt, phases, accumulate;
+    int oys, oxs, oyo, oxo, Hmem, Wmem;
+    float* out0; long long bstride0; int ld0, _p0;
+    float* out1; long long bstride1; int ld1, _p1;
+    char* sp_out; long long sp_bstride;
+};
+// host-side description of the layer: terms = (source segment, tap, weight tap) per set of output column tiles
+struct ConvQTerm { int seg, da, db, wtap; };   // wtap < 0: a zero-weight filler tap (keeps a short stage long enough to double-buffer)
+struct ConvQGroupSet { int nt0, ntn, nterm; ConvQTerm term[32]; };   // 16-column tiles [nt0, nt0 + ntn) of the N tile
+struct ConvQProblem {
+    int N, H, W, halo;         // images, tile-space extent, 2 (taps in [-1,1]^2) or 4 ([-2,2]^2)
+    int nseg; CQSeg seg[4]; int seg_wc0[4];   // + the weight tensor's input channel of each segment's first stage
+    int ngs; ConvQGroupSet gs[4];
+    int periodic;              // 1: one group set whose terms apply to every stage (term.seg ignored): the schedule covers 2 or 4 stages and repeats
+    const float* w; long long s_oc, s_ic;     // weight element (oc, ic, tap) at w[ic * s_ic + (col0 + oc) * s_oc + tap]
+    int Co, col0, phases;      // phases: group g of an N tile = output phase g of the SAME 32 channels (stride-2 transposed convolution)
+};
+size_t convq_wpk_bytes(const ConvQProblem& pr);
+// packs the weights into wpk (unless they still are there from a previous call) and launches; VPX_OK or an error code (set_error)
+int convq_run(const ConvQProblem& pr, const ConvQEpiArgs& ea, char* wpk, bool weights_packed, hipStream_t s);
+
 // ---- small-grid fused cell (cell3.hip): 16x16-pixel tiles x 8-channel slices, the slice's recurrent weights resident in LDS,
 //      the input projection hoisted (enters through `pre`) ----
 struct Cell3Pack { const float* w; int Cin, Ch, Ct, n_slices, nk; int gate_pos[4]; };

@@ -412,6 +412,72 @@ def conv2d_ex_split(x, w, bias, stride, padding, transposed=False, leaky_slope=0
     return buf, (N, Co, ho.value, wo.value)
 
 
+def split_convert(x):
+    """fp32 [..., C, H, W] tensor -> SplitActivation-style buffer in the split-bf16 operand format (tests / tools; the models'
+    producers write the format themselves). Returns (buffer, logical shape)."""
+    _require_gpu(x, "split_convert")
+    xs = to_channels_last(x)
+    C = xs.shape[-3]
+    if C % 8:
+        raise ValueError("split_convert: the channel count must be a multiple of 8")
+    # fp32 hi/lo split on the GPU with torch ops (same rounding as the kernels: round-to-nearest-even to bf16, twice)
+    flat = xs.permute(*range(xs.dim() - 3), xs.dim() - 2, xs.dim() - 1, xs.dim() - 3).contiguous()   # [..., H, W, C]
+    hi = flat.to(torch.bfloat16)
+    lo = (flat - hi.to(torch.float32)).to(torch.bfloat16)
+    g = flat.shape[:-1] + (C // 8, 8)
+    buf = torch.stack([hi.reshape(g), lo.reshape(g)], dim=-2).contiguous()   # [..., C/8, 2, 8] bf16
+    return buf.view(torch.float32).reshape(-1), tuple(x.shape)
+
+
+_convq_ws = {}
+
+
+def conv2d_ex_takes_split(N, H, W, Ci, Co, kh, kw, stride, padding, transposed, precision="bf16x3"):
+    d = ConvDesc(N, H, W, Ci, Co, kh, kw, int(stride), int(padding), int(bool(transposed)), 0.0, PRECISIONS[precision], 0, 0)
+    return bool(_lib.lib().vpx_conv2d_ex_takes_split(ctypes.byref(d)))
+
+
+def conv2d_ex_from_split(xbuf, xshape, w, bias, stride, padding, transposed=False, leaky_slope=0.0, precision="bf16x3",
+                         out_split=False, out_fp32=True):
+    """The stage-glue layer on an input that already is in the split-bf16 operand format (inference): xbuf / xshape =
+    (buffer, (N, Ci, H, W)). Returns (y or None, ybuf or None, (N, Co, Ho, Wo)). The packed weights stay in a per-layer
+    workspace while the weight tensor is unchanged (keyed on the tensor object, its version and address)."""
+    import weakref
+    N, Ci, H, Wd = xshape
+    kh, kw = int(w.shape[2]), int(w.shape[3])
+    Co = int(w.shape[1] if transposed else w.shape[0])
+    d = ConvDesc(N, H, Wd, Ci, Co, kh, kw, int(stride), int(padding), int(bool(transposed)), float(leaky_slope),
+                 PRECISIONS[precision], 0, 0)
+    L = _lib.lib()
+    ho, wo = ctypes.c_int(0), ctypes.c_int(0)
+    check(L.vpx_conv2d_ex_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "vpx_conv2d_ex_out_shape")
+    ws_bytes = L.vpx_conv2d_ex_split_workspace_bytes(ctypes.byref(d))
+    if ws_bytes == 0:
+        raise _lib.VpxError("conv2d_ex_from_split: layer not implemented on split input: " + L.vpx_last_error().decode())
+    key = (id(w), N, H, Wd, int(stride), int(padding), bool(transposed), precision)
+    ent = _convq_ws.get(key)
+    packed = 0
+    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == w.data_ptr() and ent[3].numel() >= ws_bytes:
+        ws, packed = ent[3], 1
+    else:
+        if len(_convq_ws) > 64:
+            _convq_ws.clear()
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xbuf.device)
+        try:
+            _convq_ws[key] = (weakref.ref(w), w._version, w.data_ptr(), ws)
+        except TypeError:
+            pass
+    wc = w.contiguous()
+    if wc.data_ptr() != w.data_ptr():
+        packed = 0
+    bc = None if bias is None else bias.contiguous()
+    y = new_channels_last((N, Co, ho.value, wo.value), xbuf.device) if out_fp32 else None
+    ybuf = torch.empty(N * ho.value * wo.value * Co, dtype=torch.float32, device=xbuf.device) if out_split else None
+    check(L.vpx_conv2d_ex_fwd_from_split(ctypes.byref(d), ptr(xbuf), 0, 0, 1, ptr(wc), ptr(bc), ptr(y), ptr(ybuf), packed, ptr(ws),
+                                         ws_bytes, _stream()), "vpx_conv2d_ex_fwd_from_split")
+    return y, ybuf, (N, Co, ho.value, wo.value)
+
+
 def conv_transpose2d_to_size(x, w, stride, padding, out_hw, precision="f32"):
     """nn.ConvTranspose2d(...)(x, output_size=out_hw) without bias (predrnn_v2.py:213-218): the output padding is whatever
     makes the result exactly out_hw (it must lie in [0, stride))."""
