@@ -132,12 +132,18 @@ struct ConvQEpi {
 };
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------
-template <int HALO>
+// NTS = 16-column tiles per step (8: a step fills the whole N tile; 4 / 2 / 1: 2 / 4 / 8 steps sit side by side in one weight
+// chunk — few output channels). PHASE: the (up to) four steps of a chunk accumulate into DIFFERENT accumulator tiles (output
+// phases of a stride-2 transposed convolution, NTS = 2); otherwise every step accumulates into tiles [0, NTS).
+// The loop body is one weight chunk = 8 column tiles with static tile / register indices; what is read at run time per step
+// is only where its two taps sit (offA / offB) and whether it exists.
+template <int NTS, bool PHASE, int HALO>
 __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const ConvQEpi epi) {
     constexpr int HW_ = 16 + HALO;                 // halo tile width
     constexpr int NPOS = (32 + HALO) * HW_;        // halo positions of a 32x16 tile
     constexpr int PPOS = HALO == 2 ? 640 : 768;    // padded: 4 planes = NP pieces per thread
     constexpr int PLANE = PPOS * 16, ABUF = 4 * PLANE, NP = 4 * PPOS / 512;
+    constexpr int NSUB = 8 / NTS;                  // steps per chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
     const int x0 = tx * 16, y0 = ty * 32;
     int ngr = P.n_groups - n_tile * P.gpt;   // 32-column groups of this N tile that hold outputs
     if (ngr > P.gpt) ngr = P.gpt;
-    const int tmask = (1 << (2 * ngr)) - 1;  // column tiles of those groups: the MFMAs of the others are skipped
+    const int tmask = (1 << (2 * ngr)) - 1;  // accumulator tiles of those groups: the MFMAs of the others are skipped
 
     char* const Abuf = smem;
     char* const Wbuf = smem + 2 * ABUF;
@@ -165,22 +171,33 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
     // the schedule: lane i keeps entry i
     const unsigned long long my_entry = P.sched[lane];
     const int e_lo = (int)(unsigned)my_entry, e_hi = (int)(unsigned)(my_entry >> 32);
+    auto entry = [&](int i) { return cq_decode((unsigned)__builtin_amdgcn_readlane(e_lo, i), (unsigned)__builtin_amdgcn_readlane(e_hi, i)); };
+    const int e_off = (int)P.offs[lane];   // (offA / 16) | on << 15 | (offB / 16) << 16
 
-    int php[NP], choff[NP];
+    // this thread's pieces of a stage copy: byte offset from the tile's halo origin in the source (sub-)image + the piece's
+    // 16 bytes inside the stage's 64-byte channel block, and per segment whether the position lies inside its (sub-)image
+    // (all segments of a layer share the row / column pitch; their extents differ by a pixel at most: odd-sized stride-2 inputs)
+    int pofs[NP], pval[NP];
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
         const int piece = tid + 512 * u;
         const int plane = piece / PPOS, pos = piece - plane * PPOS;
         const int hy = pos / HW_, hx = pos - hy * HW_;
-        php[u] = pos < NPOS ? ((hy << 8) | hx) : -1;
-        choff[u] = (plane & 1) * 32 + (plane >> 1) * 16;   // plane = part*2 + khalf; pixel row: [group][hi 16 B | lo 16 B]
+        const int gy = y0 + P.oy + hy, gx = x0 + P.ox + hx;
+        pofs[u] = hy * P.seg[0].rowpitch + hx * P.seg[0].colpitch + (plane & 1) * 32 + (plane >> 1) * 16;   // plane = part*2 + khalf
+        int v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < P.nseg && pos < NPOS && (unsigned)gy < (unsigned)P.seg[i].Hs && (unsigned)gx < (unsigned)P.seg[i].Ws) v |= 1 << i;
+        pval[u] = v;
     }
     const int dma_off = (wave * 64) * 16;
     const char* const wtile = P.wpk + (size_t)n_tile * P.nchunk_total * CQ_WCHUNK + tid * 16;
     const int S = P.S;
+    const long long tile_org = (long long)(y0 + P.oy) * P.seg[0].rowpitch + (long long)(x0 + P.ox) * P.seg[0].colpitch;
 
-    // source of a stage (scalars): segment lookup + the image's base; stages >= S read zeros
-    struct Src { const char* base; int rowp, colp, Hs, Ws; };
+    // source of a stage (scalars): segment lookup + the image's base shifted to the tile's halo origin; stages >= S read zeros
+    struct Src { const char* base; int seg; };
     auto stage_src = [&](int s) -> Src {
         int first = 0, si = 0;
         bool go = true;
@@ -192,16 +209,13 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
         const CQSeg sg = P.seg[si];
         const int bb = b / sg.nT, tt = b - bb * sg.nT;
         Src r;
-        r.base = s < S ? sg.sp + (size_t)bb * sg.bstride + (size_t)tt * sg.tstride + sg.org + (size_t)(sg.c0 + 16 * (s - first)) * 4 : nullptr;
-        r.rowp = sg.rowpitch; r.colp = sg.colpitch; r.Hs = sg.Hs; r.Ws = sg.Ws;
+        r.base = s < S ? sg.sp + (size_t)bb * sg.bstride + (size_t)tt * sg.tstride + sg.org + (size_t)(sg.c0 + 16 * (s - first)) * 4 + tile_org : nullptr;
+        r.seg = si;
         return r;
     };
     auto issue_A1 = [&](const Src& sc, int buf, int u) {
-        const int hy = php[u] >> 8, hx = php[u] & 255;
-        const int gy = y0 + P.oy + hy, gx = x0 + P.ox + hx;
-        const bool ok = (sc.base != nullptr) & (php[u] >= 0) & ((unsigned)gy < (unsigned)sc.Hs) & ((unsigned)gx < (unsigned)sc.Ws);
-        const char* src = ok ? sc.base + (size_t)((unsigned)(gy * sc.rowp) + (unsigned)(gx * sc.colp)) + choff[u]
-                             : reinterpret_cast<const char*>(c2_zero16);
+        const bool ok = (sc.base != nullptr) & (((pval[u] >> sc.seg) & 1) != 0);
+        const char* src = ok ? sc.base + pofs[u] : reinterpret_cast<const char*>(c2_zero16);
         c2_dma16(src, Abuf + buf * ABUF + dma_off + u * 8192);
     };
     auto issue_W1 = [&](int chunk, int slot, int u) {
@@ -219,19 +233,29 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
     // lane bases: activation fragments (buffer 0, halo position (0,0), tile row 4 * wave, hi plane); weight fragments
     const int a_lane = (kg & 1) * PLANE + ((4 * wave) * HW_ + r16) * 16;
     const int w_lane = kg * 2048 + r16 * 16;
-    const bool tselB = (kg >> 1) != 0;
-    bf16x8 ah[4], al[4], bh[2], bl[2], bnh, bnl;
+    const int tsel_shift = (kg >> 1) ? 16 : 0;   // which half of a packed offset pair this lane's k group reads
+    // fragment address of a step for this lane: a_lane + 16 * (its half of the step's packed offsets)
+    auto step_va = [&](int packed) { return a_lane + ((int)(((unsigned)packed >> tsel_shift) & 0x1fffu) << 4); };
+    bf16x8 ah[4], al[4], bh[2], bl[2];
     auto load_A1 = [&](int va, int m) {
         const char* a = smem + va + m * (HW_ * 16);
         ah[m] = *reinterpret_cast<const bf16x8*>(a);
         al[m] = *reinterpret_cast<const bf16x8*>(a + 2 * PLANE);
     };
+    auto load_B = [&](int slot, int t) {   // weight fragments of chunk tile t -> set t & 1
+        const char* w = Wbuf + slot * CQ_WCHUNK + w_lane + t * 256;
+        bh[t & 1] = *reinterpret_cast<const bf16x8*>(w);
+        bl[t & 1] = *reinterpret_cast<const bf16x8*>(w + 8192);
+    };
 
     if (S > 0 && P.nsub > 0) {
         // ---- prologue: stage 0 (and stage 1 where the schedule expects it to be under way), chunks 0 and 1 ----
         Src aq_src = stage_src(0);
+        if (P.dbg & 32) return;
+        if (!(P.dbg & 16)) {
 #pragma unroll
         for (int u = 0; u < NP; ++u) issue_A1(aq_src, 0, u);
+        }
         if (P.pro_stage1) {
             const Src s1 = stage_src(1);
 #pragma unroll
@@ -241,111 +265,100 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
         if (P.nchunk_total > 1) { issue_W1(1, 1, 0); issue_W1(1, 1, 1); }
         C2_WAIT_VM(0);
         c2_barrier();
+        if (P.dbg & 64) return;
 
-        int idx = 0, base = 0, c = -1;
+        int idx = 0, base = 0, c = 0;
         bool a_pending = false;                 // a stage copy issued AFTER the last weight chunk may still fly at the next sync
-        int wq = -1, wq_slot = 0;               // weight chunk still to issue for this sync (-1: none)
-        int aq = 0, aq_buf = 0; bool aq_first = false;   // stage-copy pieces still to issue: aq = next piece + 1 (0: none)
-        CQDec cur = cq_decode((unsigned)__builtin_amdgcn_readlane(e_lo, 0), (unsigned)__builtin_amdgcn_readlane(e_hi, 0));
-        cur.mask &= tmask;
+        CQDec cur = entry(0);                   // first step of the chunk (carries the chunk's events)
+        int cur_off = __builtin_amdgcn_readlane(e_off, 0);
         {
-            const int va = a_lane + (tselB ? cur.offB : cur.offA);
+            const int va = step_va(cur_off);
 #pragma unroll
             for (int m = 0; m < 4; ++m) load_A1(va, m);
-            const char* w = Wbuf + w_lane + (cur.bcol0 + __builtin_ctz(cur.mask | 0x100)) * 256;
-            bnh = *reinterpret_cast<const bf16x8*>(w);
-            bnl = *reinterpret_cast<const bf16x8*>(w + 8192);
+            load_B(0, 0);
         }
-        // at most two copy pieces per call: the sync's weight chunk and stage copy trickle out behind the MFMAs of the column tiles
-        // (a burst right after the barrier keeps all eight waves off the matrix pipe while the LDS-DMA instructions issue)
-        auto issue_slot = [&]() {
-            if (wq >= 0 && !(aq_first && aq > 0)) { issue_W1(wq, wq_slot, 0); issue_W1(wq, wq_slot, 1); wq = -1; return; }
-            if (aq == 1) { issue_A1(aq_src, aq_buf, 0); issue_A1(aq_src, aq_buf, 1); aq = 3; }
-            else if (aq == 3) { issue_A1(aq_src, aq_buf, 2); issue_A1(aq_src, aq_buf, 3); aq = 5; }
-            else if (aq == 5) { issue_A1(aq_src, aq_buf, 4); if (NP > 5) issue_A1(aq_src, aq_buf, NP - 1); aq = 0; }
-        };
         while (true) {
-            if (cur.newchunk) {
-                // ---- sync point of chunk c (first: everything the previous sync queued has been issued) ----
-                while (wq >= 0 || aq > 0) issue_slot();
-                ++c;
-                if (c > 0) {
-                    if (a_pending) { if (NP == 5) C2_WAIT_VM(5); else C2_WAIT_VM(6); } else C2_WAIT_VM(0);
-                    c2_barrier();
-                }
-                a_pending = false;
-                if (c + 2 < P.nchunk_total) { wq = c + 2; wq_slot = (c + 2) % 3; }
-                if (cur.issue) {
-                    const int st = base + cur.istage;
-                    if (st <= S) {       // st == S: zero fill (a cross step may read that buffer against zero weights)
-                        aq_src = stage_src(st);
-                        aq = 1; aq_buf = st & 1; aq_first = cur.afirst != 0;
-                        a_pending = !aq_first;
-                    }
-                }
-                if (cur.late) {          // a stage that landed with this very sync: its fragments could not be read ahead
-                    const int va = a_lane + (tselB ? cur.offB : cur.offA);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) load_A1(va, m);
+            // ---- sync point of chunk c ----
+            if (c > 0) {
+                if (a_pending) { if (NP == 5) C2_WAIT_VM(5); else C2_WAIT_VM(6); } else C2_WAIT_VM(0);
+                c2_barrier();
+            }
+            const int slot = c % 3, nslot = (c + 1) % 3;
+            const int wq = (c + 2 < P.nchunk_total && !(P.dbg & 4)) ? c + 2 : -1, wq_slot = (c + 2) % 3;
+            bool aq = false, aq_first = false; int aq_buf = 0;
+            if (cur.issue && !(P.dbg & 2)) {
+                const int st = base + cur.istage;
+                if (st <= S) {           // st == S: zero fill (a cross step may read that buffer against zero weights)
+                    aq_src = stage_src(st);
+                    aq = true; aq_buf = st & 1; aq_first = cur.afirst != 0;
                 }
             }
-            const int slot = c % 3;
-            // next entry (the schedule wraps around with the stage base advanced)
-            int nidx = idx + 1, nbase = base;
-            if (nidx == P.nsub) { nidx = 0; nbase = base + P.SP; }
-            CQDec nxt = cq_decode((unsigned)__builtin_amdgcn_readlane(e_lo, nidx), (unsigned)__builtin_amdgcn_readlane(e_hi, nidx));
-            nxt.mask &= tmask;
-            const bool more = nbase + nxt.stA < S;
-            const int n_va = a_lane + (tselB ? nxt.offB : nxt.offA);
-            const int n_slot = nxt.newchunk ? (c + 1) % 3 : slot;
-            const char* const n_w = Wbuf + n_slot * CQ_WCHUNK + w_lane + (nxt.bcol0 + __builtin_ctz(nxt.mask | 0x100)) * 256;
-            const char* const wb = Wbuf + slot * CQ_WCHUNK + w_lane + cur.bcol0 * 256;
-            const bool n_ahead = !nxt.late;
-            const int mask = cur.mask;
-            // the first column tile's weight fragments were read ahead into the spare set
-            if (__builtin_ctz(mask | 0x100) & 1) { bh[1] = bnh; bl[1] = bnl; } else { bh[0] = bnh; bl[0] = bnl; }
+            a_pending = aq && !aq_first;
+            if (cur.late) {              // a stage that landed with this very sync: its fragments could not be read ahead
+                const int va = step_va(cur_off);
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                if (!((mask >> nt) & 1)) continue;
-                const bool last = (mask >> (nt + 1)) == 0;
-                if (!last) {
-                    bh[(nt + 1) & 1] = *reinterpret_cast<const bf16x8*>(wb + (nt + 1) * 256);
-                    bl[(nt + 1) & 1] = *reinterpret_cast<const bf16x8*>(wb + (nt + 1) * 256 + 8192);
-                    __builtin_amdgcn_s_setprio(1);
+                for (int m = 0; m < 4; ++m) load_A1(va, m);
+            }
+            // next chunk's first entry (the schedule wraps around with the stage base advanced)
+            int nidx = idx + NSUB, nbase = base;
+            if (nidx >= P.nsub) { nidx = 0; nbase = base + P.SP; }
+            const CQDec nxt = entry(nidx);
+            const int nxt_off = __builtin_amdgcn_readlane(e_off, nidx);
+            const bool more = nbase + nxt.stA < S && c + 1 < P.nchunk_total;
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        f32x4 cc = acc[m][nt];
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[nt & 1], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[nt & 1], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[nt & 1], cc, 0, 0, 0);
-                        acc[m][nt] = cc;
+            for (int j = 0; j < NSUB; ++j) {
+                // step j of the chunk; the step after it (for the read-ahead of its activation rows)
+                const int oj = j == 0 ? cur_off : __builtin_amdgcn_readlane(e_off, idx + j);
+                const int on_ = j + 1 < NSUB ? __builtin_amdgcn_readlane(e_off, idx + j + 1) : nxt_off;
+                const int n_va = step_va(on_);
+                const bool on = (oj & 0x8000) != 0;
+#pragma unroll
+                for (int k = 0; k < NTS; ++k) {
+                    const int t = j * NTS + k;           // tile inside the weight chunk
+                    const int at = PHASE ? t : k;        // accumulator tile
+                    if (t < 7) load_B(slot, t + 1); else load_B(nslot, 0);
+                    const bool go = on && ((tmask >> at) & 1) && !(P.dbg & 1);
+                    if (go) {
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            f32x4 cc = acc[m][at];
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[t & 1], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[t & 1], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[t & 1], cc, 0, 0, 0);
+                            acc[m][at] = cc;
+                            if (k == NTS - 1) load_A1(n_va, m);   // the step's last tile frees row m: the next step's fragments
+                        }
+                        __builtin_amdgcn_s_setprio(0);
+                    } else if (k == NTS - 1) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) load_A1(n_va, m);
                     }
-                    __builtin_amdgcn_s_setprio(0);
-                } else {
-                    // last column tile of the step: the next step's first weight fragments, and its activation rows as they free up
-                    bnh = *reinterpret_cast<const bf16x8*>(n_w);
-                    bnl = *reinterpret_cast<const bf16x8*>(n_w + 8192);
-                    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        f32x4 cc = acc[m][nt];
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[nt & 1], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[nt & 1], cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[nt & 1], cc, 0, 0, 0);
-                        acc[m][nt] = cc;
-                        if (n_ahead) load_A1(n_va, m);
+                    // ---- this sync's copies, behind the MFMAs of tiles 0..3: weight chunk, then the stage (or the stage first) ----
+                    if (t == 0) {
+                        if (aq && aq_first) { issue_A1(aq_src, aq_buf, 0); issue_A1(aq_src, aq_buf, 1); }
+                        else if (wq >= 0) { issue_W1(wq, wq_slot, 0); issue_W1(wq, wq_slot, 1); }
                     }
-                    __builtin_amdgcn_s_setprio(0);
+                    if (t == 1 && aq) {
+                        if (aq_first) { issue_A1(aq_src, aq_buf, 2); issue_A1(aq_src, aq_buf, 3); }
+                        else { issue_A1(aq_src, aq_buf, 0); issue_A1(aq_src, aq_buf, 1); }
+                    }
+                    if (t == 2 && aq) {
+                        if (aq_first) { issue_A1(aq_src, aq_buf, 4); if (NP > 5) issue_A1(aq_src, aq_buf, NP - 1); }
+                        else { issue_A1(aq_src, aq_buf, 2); issue_A1(aq_src, aq_buf, 3); }
+                    }
+                    if (t == 3) {
+                        if (aq && !aq_first) { issue_A1(aq_src, aq_buf, 4); if (NP > 5) issue_A1(aq_src, aq_buf, NP - 1); }
+                        if (aq && aq_first && wq >= 0) { issue_W1(wq, wq_slot, 0); issue_W1(wq, wq_slot, 1); }
+                    }
                 }
-                if (wq >= 0 || aq > 0) issue_slot();
             }
             if (!more) break;
-            idx = nidx; base = nbase; cur = nxt;
+            idx = nidx; base = nbase; cur = nxt; cur_off = nxt_off; ++c;
         }
-        while (wq >= 0 || aq > 0) issue_slot();   // (nothing the outputs depend on: keeps the queue accounting simple)
         C2_WAIT_VM(0);                            // no copy may land in the epilogue's transposition space
     }
-    epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+    if (!(P.dbg & 8)) epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
 }
 
 // ---- weight pack: [n_tile][chunk][part][k group][n][8 bf16]; the table says, per chunk of a pass and 16-column tile, which
@@ -398,12 +411,12 @@ __global__ void convq_pack_kernel(const ConvQPackArgs pk, char* __restrict__ dst
 namespace {
 
 struct QTap { int stage, off, wtap; };       // off: byte offset of the tap inside its stage buffer (without the buffer's own offset)
-struct QSub { int chunk, nt0, ntn, bcol0; QTap a, b; bool has_b; };
+struct QSub { int chunk, pos; QTap a, b; bool has_b; };   // pos: which of the chunk's 8 / NTS steps
 
 struct QBuild {
     ConvQPlan P;
     ConvQPackArgs pk;
-    int halo;
+    int halo, NTS;
 };
 
 int seg_of_stage(const ConvQProblem& pr, int s) {
@@ -418,42 +431,44 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
     int S = 0;
     for (int i = 0; i < pr.nseg; ++i) S += pr.seg[i].nstage;
     if (S < 1 || pr.nseg < 1 || pr.nseg > 4 || pr.ngs < 1 || pr.ngs > 4) { set_error("convq: bad problem (S=%d nseg=%d ngs=%d)", S, pr.nseg, pr.ngs); return VPX_ERR_ARG; }
-    const bool periodic = pr.periodic != 0;
-    if (periodic && pr.ngs != 1) { set_error("convq: a periodic schedule takes one group set"); return VPX_ERR_ARG; }
+    for (int i = 1; i < pr.nseg; ++i)
+        if (pr.seg[i].rowpitch != pr.seg[0].rowpitch || pr.seg[i].colpitch != pr.seg[0].colpitch) { set_error("convq: segments must share their pixel pitches"); return VPX_ERR_ARG; }
+    if (pr.phases ? pr.ngs > 4 : pr.ngs != 1) { set_error("convq: several group sets need the phase mapping"); return VPX_ERR_ARG; }
     const int n_tiles = pr.phases ? (pr.Co + 31) / 32 : ((pr.Co + 31) / 32 + 3) / 4;
     const int n_groups = pr.phases ? 4 * n_tiles : (pr.Co + 31) / 32;   // (phases: every N tile holds the four phases of its 32 channels)
     const int gpt = pr.phases ? 4 : (n_groups + n_tiles - 1) / n_tiles;
-    // steps that use few column tiles sit side by side in one weight chunk (Co <= 64 with a single N tile)
-    int cpack = 1, ntn_plain = 8;
-    if (!pr.phases) {
-        if (pr.ngs != 1) { set_error("convq: several group sets need the phase mapping"); return VPX_ERR_ARG; }
-        const int cols = pr.Co < gpt * 32 ? pr.Co : gpt * 32;
-        ntn_plain = (cols + 15) / 16;
-        if (n_tiles == 1 && max_cpack > 1 && (ntn_plain == 1 || ntn_plain == 2 || ntn_plain == 4)) cpack = 8 / ntn_plain;
-        if (cpack > max_cpack) cpack = max_cpack;
+    // NTS = 16-column tiles of a step, rounded up to 1 / 2 / 4 / 8: 8 / NTS steps share one weight chunk (phases: the four phases'
+    // steps; else consecutive steps of a layer with few output channels)
+    int NTS = 8;
+    if (pr.phases) NTS = 2;
+    else if (n_tiles == 1) {
+        const int ntn = ((pr.Co < 128 ? pr.Co : 128) + 15) / 16;
+        NTS = ntn <= 1 ? 1 : (ntn <= 2 ? 2 : (ntn <= 4 ? 4 : 8));
+        if (8 / NTS > max_cpack) NTS = 8 / max_cpack;
     }
-    int SP = periodic ? 2 : S;
-    if (periodic && ((2 * pr.gs[0].nterm) & 1)) SP = 4;   // (never: 2 * n is even; kept for clarity of the rule below)
-    if (periodic) {
-        int pairs = SP * pr.gs[0].nterm / 2;
-        while (cpack > 1 && pairs % cpack) cpack >>= 1;
-    }
+    const int cpack = pr.phases ? 1 : 8 / NTS, NSUB = 8 / NTS;
+    const bool all_stages = pr.periodic != 0;   // the one group set's terms apply to every stage
+    const int nterm0 = pr.gs[0].nterm;
+    // a short K loop is laid out in full; a long one with identical stages as a pass over two stages that repeats
+    bool periodic = all_stages;
+    if (periodic && (((S * nterm0 + 1) / 2 + cpack - 1) / cpack) * NSUB <= 64) periodic = false;
+    if (periodic && cpack > 1) return convq_build(pr, out, 1);   // (a pass of 2 stages does not divide into side-by-side steps)
+    const int SP = periodic ? 2 : S;
     const int NSV = periodic ? 3 * SP : S;   // stages laid out (periodic: three passes, the middle one is the steady state)
 
-    // sub-steps, chunk by chunk
     static thread_local QSub subs[4096];
     int nsub = 0, nchunk = 0;
     auto tap_of = [&](int stage, const ConvQTerm& t) {
         QTap q; q.stage = stage; q.off = ((t.da + org) * HW_ + (t.db + org)) * 16; q.wtap = t.wtap; return q;
     };
-    if (pr.ngs == 1) {
+    if (!pr.phases) {
         // one group set: the taps of all stages in one line, paired in order (the last tap of a stage with the first of the next)
         static thread_local QTap line[8192];
         int n = 0;
         const ConvQGroupSet& gs = pr.gs[0];
         for (int s = 0; s < NSV; ++s)
             for (int k = 0; k < gs.nterm; ++k) {
-                if (!periodic && gs.term[k].seg != seg_of_stage(pr, s)) continue;
+                if (!all_stages && gs.term[k].seg != seg_of_stage(pr, s)) continue;
                 if (n >= 8192) { set_error("convq: too many taps"); return VPX_ERR_UNSUPPORTED; }
                 line[n++] = tap_of(s, gs.term[k]);
             }
@@ -462,11 +477,11 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
         for (int p = 0; p < pairs; ++p) {
             if (nsub >= 4096) { set_error("convq: schedule too long"); return VPX_ERR_UNSUPPORTED; }
             QSub& q = subs[nsub++];
-            q.chunk = p / cpack; q.nt0 = 0; q.ntn = ntn_plain; q.bcol0 = (p % cpack) * ntn_plain;
+            q.chunk = p / cpack; q.pos = p % cpack;
             q.a = line[2 * p]; q.has_b = 2 * p + 1 < n; q.b = q.has_b ? line[2 * p + 1] : line[2 * p];
         }
     } else {
-        // several group sets (output phases): stage by stage, each set pairs its own taps of that stage; a chunk holds the k-th pair of every set
+        // output phases: stage by stage, each phase pairs its own taps of that stage; a chunk holds the k-th pair of every phase
         for (int s = 0; s < NSV; ++s) {
             int maxp = 0;
             for (int g = 0; g < pr.ngs; ++g) {
@@ -485,7 +500,7 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
                     if (!cnt) continue;
                     if (nsub >= 4096) { set_error("convq: schedule too long"); return VPX_ERR_UNSUPPORTED; }
                     QSub& q = subs[nsub++];
-                    q.chunk = nchunk + p; q.nt0 = pr.gs[g].nt0; q.ntn = pr.gs[g].ntn; q.bcol0 = 0;
+                    q.chunk = nchunk + p; q.pos = pr.gs[g].nt0 / 2;
                     q.a = tp[0]; q.has_b = cnt > 1; q.b = q.has_b ? tp[1] : tp[0];
                 }
             }
@@ -509,12 +524,18 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
         if (lu[t] < 0) continue;   // a stage nobody reads (cannot happen with well-formed terms)
         const int lo = t >= 2 ? lu[t - 2] + 1 : 0;
         // copy issued at sync ci after the weight chunk: landed for reads after sync ci + 2; before it: after sync ci + 1. Reads of
-        // chunk fu's first step are issued at the end of chunk fu - 1 — unless that step is marked late (read after its own sync).
+        // chunk fu's first step are issued at the end of chunk fu - 1 — unless that chunk is marked late (read after its own sync).
+        // Order of preference: (0) after the chunk, read ahead; (1) after the chunk, first chunk late — the copy still has two
+        // chunks of time; (2) before the chunk (must land within ONE chunk: the sync may stall); (3) before the chunk and late.
         int ci = -1, afirst = 0, late = 0;
-        for (int mode = 0; mode < 3 && ci < 0; ++mode) {
-            const int hi = fu[t] - (mode == 0 ? 3 : (mode == 1 ? 2 : 1));
+        static const int m_hi[4] = {3, 2, 2, 1}, m_af[4] = {0, 0, 1, 1}, m_late[4] = {0, 1, 0, 1};
+        static int mode_mask = -1;   // VPX_CONVQ_MODES: bit m allows mode m (experiments)
+        if (mode_mask < 0) { const char* e = getenv("VPX_CONVQ_MODES"); mode_mask = e ? atoi(e) : 15; }
+        for (int mode = 0; mode < 4 && ci < 0; ++mode) {
+            if (!((mode_mask >> mode) & 1)) continue;
+            const int hi = fu[t] - m_hi[mode];
             for (int k = lo; k <= hi; ++k)
-                if (k >= 0 && ev_stage[k] < 0) { ci = k; afirst = mode >= 1; late = mode == 2; break; }
+                if (k >= 0 && ev_stage[k] < 0) { ci = k; afirst = m_af[mode]; late = m_late[mode]; break; }
         }
         if (ci < 0) {
             if (cpack > 1) return convq_build(pr, out, 1);   // short stages: one step per weight chunk gives every stage its chunk boundaries
@@ -525,41 +546,52 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
         if (late) late_chunk[fu[t]] = 1;
     }
 
-    // extract the pass the kernel repeats
+    // extract the pass the kernel repeats: NSUB entries per chunk (missing steps: mask 0)
     const int nchunk_pass = periodic ? nchunk / 3 : nchunk;
     if (periodic && nchunk % 3) { set_error("convq: periodic schedule does not divide into passes"); return VPX_ERR_UNSUPPORTED; }
     const int c0 = periodic ? nchunk_pass : 0, s0 = periodic ? SP : 0;
-    if (nchunk_pass > 64) { set_error("convq: %d weight chunks per pass (max 64)", nchunk_pass); return VPX_ERR_UNSUPPORTED; }
+    if (nchunk_pass * NSUB > 64) {
+        if (cpack > 1) return convq_build(pr, out, cpack / 2);
+        set_error("convq: %d steps per pass (max 64)", nchunk_pass * NSUB);
+        return VPX_ERR_UNSUPPORTED;
+    }
     QBuild& B = out;
     memset(&B.P, 0, sizeof(B.P));
     memset(&B.pk, 0, sizeof(B.pk));
     for (int k = 0; k < 64; ++k) for (int t = 0; t < 8; ++t) { B.pk.tab[k][t][0] = 0; B.pk.tab[k][t][1] = -1; B.pk.tab[k][t][2] = 0; B.pk.tab[k][t][3] = -1; }
-    int ne = 0, prev_chunk = -1;
     bool rel1 = false, relSP1 = false;
+    // default entries: no step; a chunk's first entry still carries its events and a stage index for the termination test
+    static thread_local int first_stage[8192];
+    for (int k = 0; k < nchunk; ++k) first_stage[k] = 1 << 30;
+    for (int i = 0; i < nsub; ++i) if (subs[i].a.stage < first_stage[subs[i].chunk]) first_stage[subs[i].chunk] = subs[i].a.stage;
+    for (int ck = 0; ck < nchunk_pass; ++ck) {
+        unsigned issue = 0, afirst = 0, istage = 0;
+        const int gc = c0 + ck;
+        if (ev_stage[gc] >= 0) {
+            issue = 1; afirst = (unsigned)ev_first[gc]; istage = (unsigned)(ev_stage[gc] - s0);
+            if (istage == 1) rel1 = true;
+            if ((int)istage == SP + 1) relSP1 = true;
+            if (istage > 127) { set_error("convq: stage index out of range"); return VPX_ERR_UNSUPPORTED; }
+        }
+        const int fs = first_stage[gc] - s0;
+        if (fs < 0 || fs > 127) { set_error("convq: stage index out of range"); return VPX_ERR_UNSUPPORTED; }
+        for (int j = 0; j < NSUB; ++j)
+            B.P.sched[ck * NSUB + j] = cq_entry(0, 0, 0, 0, j == 0, j == 0 ? issue : 0, j == 0 ? afirst : 0,
+                                                j == 0 ? (unsigned)late_chunk[gc] : 0, j == 0 ? istage : 0, (unsigned)fs);
+    }
     for (int i = 0; i < nsub; ++i) {
         const QSub& q = subs[i];
         if (q.chunk < c0 || q.chunk >= c0 + nchunk_pass) continue;
-        if (ne >= 64) { set_error("convq: more than 64 steps per pass"); return VPX_ERR_UNSUPPORTED; }
         const int ck = q.chunk - c0;
-        const bool newchunk = q.chunk != prev_chunk;
-        prev_chunk = q.chunk;
         const int stA = q.a.stage - s0, stB = q.b.stage - s0;
         if (stA < 0 || stB < 0 || stA > 127 || stB > 127) { set_error("convq: stage index out of range"); return VPX_ERR_UNSUPPORTED; }
         const unsigned offA = (unsigned)((q.a.stage & 1) * ABUF + q.a.off), offB = (unsigned)((q.b.stage & 1) * ABUF + q.b.off);
-        unsigned issue = 0, afirst = 0, istage = 0, late = 0;
-        if (newchunk) {
-            if (ev_stage[q.chunk] >= 0) {
-                issue = 1; afirst = (unsigned)ev_first[q.chunk]; istage = (unsigned)(ev_stage[q.chunk] - s0);
-                if (istage == 1) rel1 = true;
-                if ((int)istage == SP + 1) relSP1 = true;
-                if (istage > 127) { set_error("convq: stage index out of range"); return VPX_ERR_UNSUPPORTED; }
-            }
-            late = (unsigned)late_chunk[q.chunk];
-        }
-        const unsigned mask = ((1u << q.ntn) - 1u) << q.nt0;
-        B.P.sched[ne++] = cq_entry(offA, offB, mask, (unsigned)q.bcol0, newchunk ? 1u : 0u, issue, afirst, late, istage, (unsigned)stA);
-        for (int t = 0; t < q.ntn; ++t) {
-            signed char* row = B.pk.tab[ck][q.bcol0 + q.nt0 + t];
+        unsigned long long& e = B.P.sched[ck * NSUB + q.pos];
+        const CQDec d = cq_decode((unsigned)e, (unsigned)(e >> 32));
+        e = cq_entry(offA, offB, 0xff, 0, (unsigned)d.newchunk, (unsigned)d.issue, (unsigned)d.afirst, (unsigned)d.late, (unsigned)d.istage, (unsigned)d.stA);
+        B.P.offs[ck * NSUB + q.pos] = (offA >> 4) | 0x8000u | ((offB >> 4) << 16);
+        for (int t = 0; t < NTS; ++t) {
+            signed char* row = B.pk.tab[ck][q.pos * NTS + t];
             row[0] = (signed char)stA; row[1] = (signed char)q.a.wtap;
             row[2] = (signed char)stB; row[3] = (signed char)(q.has_b ? q.b.wtap : -1);
         }
@@ -567,7 +599,7 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
     // total chunks over the S real stages
     int nchunk_total;
     if (periodic) {
-        const int n_taps = S * pr.gs[0].nterm, pairs = (n_taps + 1) / 2;
+        const int pairs = (S * nterm0 + 1) / 2;
         nchunk_total = (pairs + cpack - 1) / cpack;
     } else {
         nchunk_total = nchunk;
@@ -576,32 +608,32 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
     P.B = pr.N; P.H = pr.H; P.W = pr.W;
     P.tiles_x = (pr.W + 15) / 16; P.tiles_y = (pr.H + 31) / 32; P.n_tiles = n_tiles; P.grid_m = pr.N * P.tiles_x * P.tiles_y;
     P.n_groups = n_groups; P.gpt = gpt;
-    P.S = S; P.SP = SP; P.nsub = ne; P.nchunk_total = nchunk_total;
+    P.S = S; P.SP = SP; P.nsub = nchunk_pass * NSUB; P.nchunk_total = nchunk_total;
     P.pro_stage1 = (periodic && relSP1 && !rel1) ? 1 : 0;
     P.oy = -org; P.ox = -org; P.nseg = pr.nseg;
     for (int i = 0; i < pr.nseg; ++i) P.seg[i] = pr.seg[i];
     ConvQPackArgs& pk = B.pk;
     pk.w = pr.w; pk.s_oc = pr.s_oc; pk.s_ic = pr.s_ic;
     pk.Co = pr.Co; pk.col0 = pr.col0; pk.n_tiles = n_tiles; pk.gpt = gpt; pk.phases = pr.phases;
-    pk.colw = cpack > 1 ? 128 / cpack : 128;
+    pk.colw = pr.phases ? 128 : 16 * NTS;
     pk.S = S; pk.SP = SP; pk.nchunk_pass = nchunk_pass; pk.nchunk_total = nchunk_total;
     pk.nseg = pr.nseg;
     for (int i = 0; i < pr.nseg; ++i) { pk.seg_nstage[i] = pr.seg[i].nstage; pk.seg_wc0[i] = pr.seg_wc0[i]; }
-    B.halo = pr.halo;
+    B.halo = pr.halo; B.NTS = NTS;
     return VPX_OK;
 }
 
-template <int HALO>
+template <int NTS, bool PHASE, int HALO>
 hipError_t launch_convq_t(const ConvQPlan& P, const ConvQEpi& epi, hipStream_t s) {
     constexpr int LDS = 2 * 4 * (HALO == 2 ? 640 : 768) * 16 + 3 * CQ_WCHUNK;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convq_kernel<HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convq_kernel<NTS, PHASE, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const long long per_xcd = ((long long)P.grid_m * P.n_tiles + 7) / 8;
-    hipLaunchKernelGGL((convq_kernel<HALO>), dim3((unsigned)(per_xcd * 8)), dim3(512), LDS, s, P, epi);
+    hipLaunchKernelGGL((convq_kernel<NTS, PHASE, HALO>), dim3((unsigned)(per_xcd * 8)), dim3(512), LDS, s, P, epi);
     return hipGetLastError();
 }
 
@@ -625,11 +657,18 @@ int convq_run(const ConvQProblem& pr, const ConvQEpiArgs& ea_in, char* wpk, bool
         VPX_CHECK_HIP(hipGetLastError());
     }
     b.P.wpk = wpk;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VPX_CQ_DBG"); dbg = e ? atoi(e) : 0; } b.P.dbg = dbg; }
     ConvQEpi epi{ea_in};
     epi.a.gpt = b.P.gpt;
     epi.a.phases = pr.phases;
-    if (b.halo == 2) VPX_CHECK_HIP(launch_convq_t<2>(b.P, epi, s));
-    else VPX_CHECK_HIP(launch_convq_t<4>(b.P, epi, s));
+    hipError_t e;
+    if (b.halo == 4) e = launch_convq_t<8, false, 4>(b.P, epi, s);
+    else if (pr.phases) e = launch_convq_t<2, true, 2>(b.P, epi, s);
+    else if (b.NTS == 8) e = launch_convq_t<8, false, 2>(b.P, epi, s);
+    else if (b.NTS == 4) e = launch_convq_t<4, false, 2>(b.P, epi, s);
+    else if (b.NTS == 2) e = launch_convq_t<2, false, 2>(b.P, epi, s);
+    else e = launch_convq_t<1, false, 2>(b.P, epi, s);
+    VPX_CHECK_HIP(e);
     return VPX_OK;
 }
 

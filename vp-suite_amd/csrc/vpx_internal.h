@@ -181,9 +181,11 @@ struct ConvQPlan {
     int n_groups, gpt;         // 32-column output groups in total / per N tile
     int S, SP, nsub, nchunk_total, pro_stage1;   // stages; stages per pass of the schedule; its entries; weight chunks; copy stage 1 in the prologue
     int oy, ox, nseg;
+    int dbg, _pd;              // timing ablations (VPX_CQ_DBG, experiments): 1 no MFMAs, 2 no stage copies, 4 no weight copies, 8 no epilogue
     CQSeg seg[4];
     const char* wpk;           // [n_tile][chunk][16 KiB]
-    unsigned long long sched[64];
+    unsigned long long sched[64];   // per step; only a chunk's FIRST entry is decoded in full (its events)
+    unsigned offs[64];         // per step: (offA / 16) | on << 15 | (offB / 16) << 16 — all the inner loop reads
 };
 struct ConvQEpiArgs {          // bias, LeakyReLU, destinations (see ConvQEpi, convq.hip)
     const float* bias;
