@@ -51,7 +51,10 @@ enum { VPX_PREC_F32 = 0    /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 operands 
 enum { VPX_FLAG_X_SPLIT = 4 /* ConvLSTM forward: `x` holds the input sequence in the split-bf16 operand format (below) instead of
                               fp32 — only where vpx_convlstm_takes_split_input() says so; saves the conversion pass */,
        VPX_FLAG_SAVE_FOR_BWD = 1 /* forward fills `reserve` (gate activations + cell states per step) */,
-       VPX_FLAG_WEIGHTS_PACKED = 2 /* ST-LSTM: `workspace` still holds the repacked weights (LayerNorm variant, forward: and the
+       VPX_FLAG_WEIGHTS_PACKED = 2 /* ConvLSTM forward: `workspace` still holds the weight packs of a previous forward call with the SAME
+                                      descriptor (flags aside), weight values and set of present operands (x / h0 NULL or not) — the caller
+                                      keeps one workspace per block; saves the repack launches of a small-batch inference step.
+                                      ST-LSTM: `workspace` still holds the repacked weights (LayerNorm variant, forward: and the
                                       transposed LayerNorm parameters) of a previous call with the SAME values and desc (caller keeps one workspace per cell per forward; the
                                       backward has its own workspace and additionally needs the same set of requested
                                       data gradients dx / dh / dm as the call that packed) */ };
@@ -91,6 +94,9 @@ int vpx_set_deterministic(int on);
  *                        operand split: results differ in fp32 summation order only */
 #define VPX_OPT_MFMA_SHAPE 3
 int vpx_set_option(int option, int value);
+/* A counter that advances with every vpx_set_option / vpx_set_deterministic call: callers that cache anything kernel-selection
+ * dependent (a workspace with weight packs, VPX_FLAG_WEIGHTS_PACKED) key it on this value. */
+int vpx_option_epoch(void);
 
 /* ---- ConvLSTM over a sequence ------------------------------------------------------------------------------ */
 size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d); /* scratch, contents undefined between calls */

@@ -15,19 +15,28 @@ pytestmark = pytest.mark.gpu
 
 
 class _FakeWorld:
-    """Sum-all-reduce over the replicas living in this process: every replica deposits its bucket, the reduction
-    happens when the last one arrived, then every bucket holds the sum (what ncclAllReduce(SUM) leaves)."""
+    """Sum-all-reduce over the replicas living in this process: every replica deposits its buckets in launch order, the k-th
+    reduction happens when every replica's k-th bucket has arrived, then all of them hold the sum (what ncclAllReduce(SUM)
+    leaves). One callable per rank (`for_rank`), as every rank has its own communicator."""
 
     def __init__(self, n):
-        self.n, self.pending = n, []
+        self.n, self.queues, self.done = n, [[] for _ in range(n)], 0
 
-    def all_reduce(self, t):
-        self.pending.append(t)
-        if len(self.pending) == self.n:
-            total = torch.stack(self.pending).sum(dim=0)
-            for p in self.pending:
-                p.copy_(total)
-            self.pending = []
+    def for_rank(self, r):
+        def all_reduce(t):
+            self.queues[r].append(t)
+            while all(len(q) > self.done for q in self.queues):
+                parts = [q[self.done] for q in self.queues]
+                assert len({p.numel() for p in parts}) == 1   # the ranks cut and launch their buckets alike
+                total = torch.stack(parts).sum(dim=0)
+                for p in parts:
+                    p.copy_(total)
+                self.done += 1
+        return all_reduce
+
+    def reset(self):
+        assert all(len(q) == self.done for q in self.queues)
+        self.queues, self.done = [[] for _ in range(self.n)], 0
 
     def broadcast(self, t, src):
         pass  # replicas are built from identical seeds
@@ -38,8 +47,8 @@ def _flat(m):
     return torch.cat([named[k].detach().reshape(-1) for k in sorted(named)]).cpu().numpy()
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
-def test_fused_dp_world2_equals_global_batch_update(vpx, precision):
+@pytest.mark.parametrize("precision,bucketed", [("f32", True), ("bf16x3", True), ("bf16x3", False)])
+def test_fused_dp_world2_equals_global_batch_update(vpx, precision, bucketed):
     from vp_suite_amd.train import DataParallelTrainer
     kw = dict(gc.EF_TINY_KW, cell_precision=precision)
     B, T, P = 4, 3, 2
@@ -50,22 +59,31 @@ def test_fused_dp_world2_equals_global_batch_update(vpx, precision):
     tr_ref = DataParallelTrainer(ref, lr=1e-3, world_size=1)
     world = _FakeWorld(2)
     reps = [_ef(vpx, "tiny", kw) for _ in range(2)]
-    trs = [DataParallelTrainer(m, lr=1e-3, world_size=2, all_reduce=world.all_reduce, broadcast=world.broadcast)
-           for m in reps]
+    trs = [DataParallelTrainer(m, lr=1e-3, world_size=2, all_reduce=world.for_rank(r), broadcast=world.broadcast, bucketed=bucketed)
+           for r, m in enumerate(reps)]
     assert all(t.fused and t.collectives for t in trs)
+    # per-block buckets: the 6 recurrent blocks and the 6 stages of convlstm-shi, contiguous and complete
+    assert [b[3] for b in trs[0].buckets] == [f"{half}.{kind}{i}" for half, order in (("encoder", (1, 2, 3)), ("forecaster", (3, 2, 1)))
+                                               for i in order for kind in (("stage", "rnn") if half == "encoder" else ("rnn", "stage"))]
+    assert sum(b[1] for b in trs[0].buckets) == trs[0].flat_grad.numel()
     for step in range(3):
         tr_ref.step(frames[:, :T], frames[:, T:], P)
-        # ranks run concurrently in reality; here: both backward passes, then the exchange, then both updates
+        # ranks run concurrently in reality; here: both backward passes (bucketed: each block's bucket is deposited from inside
+        # the backward pass, the sums complete during rank 1's), then the rest of the exchange, then both updates
         for r, t in enumerate(trs):
             t.backward_shard(frames[2 * r:2 * r + 2, :T], frames[2 * r:2 * r + 2, T:], P)
-        shard_sum = trs[0].flat_grad + trs[1].flat_grad
+        if not bucketed:
+            shard_sum = trs[0].flat_grad + trs[1].flat_grad
         for t in trs:
             t.reduce_gradients()
-        assert torch.equal(trs[0].flat_grad, shard_sum) and torch.equal(trs[1].flat_grad, shard_sum)
+        world.reset()
+        if not bucketed:
+            assert torch.equal(trs[0].flat_grad, shard_sum)
+        assert torch.equal(trs[0].flat_grad, trs[1].flat_grad)
         assert trs[0].optimizer.grad_scale == 0.5
         # mean over the global batch = (sum of shard means) / 2: the summed bucket is 2x the global-batch gradient
         g_ref = tr_ref.flat_grad
-        err = float((shard_sum * 0.5 - g_ref).abs().max() / g_ref.abs().max())
+        err = float((trs[0].flat_grad * 0.5 - g_ref).abs().max() / g_ref.abs().max())
         assert err < (2e-5 if precision == "f32" else 1e-4), (step, err)
         for t in trs:
             t.optimizer.step()
@@ -74,6 +92,27 @@ def test_fused_dp_world2_equals_global_batch_update(vpx, precision):
         # Adam's first steps move every weight by ~lr regardless of gradient scale; compare absolutely (lr = 1e-3)
         assert np.abs(_flat(m) - want).max() < 2e-5
     assert np.array_equal(_flat(reps[0]), _flat(reps[1]))
+
+
+@pytest.mark.timeout(600)
+def test_bench_launcher_path_runs_rccl_world1():
+    """`bench.py --gpus 1` under a launcher (RANK set): one rank per GPU through RCCL, spawned as a CHILD `torch.distributed.run`
+    before anything in the parent touches the GPU. Asserts the line's backend / n_gpus and that gradients went through RCCL
+    (train mode, bucketed all-reduce on a world of one)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(bench.free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch", "8", "--mode", "train", "--no-extras", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["backend"] == "nccl (RCCL)" and line["config"]["mode"] == "train"
+    assert line["value"] > 0 and line["steps"] == 2
 
 
 def test_trainer_runs_predrnn_training_semantics(vpx):

@@ -23,7 +23,7 @@ OPT_CELL3 = 2
 OPT_MFMA_SHAPE = 3   # 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_f32_16x16x32_bf16 in the second-generation kernels' main loop
 
 EXPORTED_SYMBOLS = [
-    "vpx_version", "vpx_last_error", "vpx_set_deterministic", "vpx_set_option",
+    "vpx_version", "vpx_last_error", "vpx_set_deterministic", "vpx_set_option", "vpx_option_epoch",
     "vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes", "vpx_convlstm_takes_split_input", "vpx_convlstm_seq_fwd",
     "vpx_convlstm_seq_bwd",
     "vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes", "vpx_stlstm_step_fwd", "vpx_stlstm_step_bwd",
@@ -87,6 +87,8 @@ def lib():
         L.vpx_last_error.restype = ctypes.c_char_p
         L.vpx_set_deterministic.restype = ctypes.c_int
         L.vpx_set_deterministic.argtypes = [ctypes.c_int]
+        L.vpx_option_epoch.restype = ctypes.c_int
+        L.vpx_option_epoch.argtypes = []
         L.vpx_set_option.restype = ctypes.c_int
         L.vpx_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
         for name in ("vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes"):

@@ -33,9 +33,12 @@ using namespace vpx;
 extern "C" {
 
 int vpx_version(void) { return VPX_VERSION; }
-int vpx_set_deterministic(int on) { const int prev = vpx::g_deterministic; vpx::g_deterministic = on ? 1 : 0; return prev; }
+static int g_option_epoch = 0;
+int vpx_option_epoch(void) { return g_option_epoch; }
+int vpx_set_deterministic(int on) { const int prev = vpx::g_deterministic; vpx::g_deterministic = on ? 1 : 0; ++g_option_epoch; return prev; }
 const char* vpx_last_error(void) { return g_err; }
 int vpx_set_option(int option, int value) {
+    ++g_option_epoch;
     if (option == VPX_OPT_CELL2) {
         const int prev = cell2_mode();
         vpx::g_cell2_mode = value < 0 ? 0 : (value > 2 ? 2 : value);
@@ -133,6 +136,8 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     if (peep && !(Wci && Wcf && Wco)) { set_error("vpx_convlstm_seq_fwd: peephole tensors must be given together"); return VPX_ERR_ARG; }
     const bool save = (d->flags & VPX_FLAG_SAVE_FOR_BWD) != 0;
     const bool x_split = (d->flags & VPX_FLAG_X_SPLIT) != 0;
+    // the caller's workspace still holds every weight pack of an earlier call with the same descriptor, weights and operand set
+    const bool wp = (d->flags & VPX_FLAG_WEIGHTS_PACKED) != 0;
     if (x_split && !vpx_convlstm_takes_split_input(d)) {
         set_error("vpx_convlstm_seq_fwd: VPX_FLAG_X_SPLIT given, but this descriptor's forward takes fp32 input (vpx_convlstm_takes_split_input)");
         return VPX_ERR_ARG;
@@ -233,7 +238,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         if (!qform) {
             pk.chunks_total = 3 * ((Cin + Ch) / 16);
             for (int s = 0; s < (Cin + Ch) / 16; ++s) pk.stage_col[s] = 16 * s;  // x stages first, then h: columns of [x | h] in order
-            VPX_CHECK_HIP(launch_cell2_pack(pk, wpk2, stream));
+            if (!wp) VPX_CHECK_HIP(launch_cell2_pack(pk, wpk2, stream));
         } else {
             for (int pass = 0; pass < 2; ++pass) {
                 const int combo = pass ? combo0 : combo1;
@@ -243,7 +248,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
                 if (combo & 1) for (int s = 0; s < Cin / 16; ++s) pk.stage_col[pk.S++] = 16 * s;
                 if (combo & 2) for (int s = 0; s < Ch / 16; ++s) pk.stage_col[pk.S++] = Cin + 16 * s;
                 pk.chunks_total = cell2_qchunks(pk.S);
-                VPX_CHECK_HIP(launch_cell2_pack(pk, pack_of(combo), stream));
+                if (!wp) VPX_CHECK_HIP(launch_cell2_pack(pk, pack_of(combo), stream));
             }
         }
         // operands of the steps in split form: the whole input sequence and the initial hidden state, once
@@ -266,10 +271,10 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         pd.tile_stride = 32;
         pd.nch = Ch;
     }
-    if (!L.v2 && !L.v3) VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+    if (!L.v2 && !L.v3 && !wp) VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
     if (L.v3) {
         Cell3Pack pk{W, Cin, Ch, Cin + Ch, Ch / 8, 9 * Ch / 16, {gp[0], gp[1], gp[2], gp[3]}};
-        VPX_CHECK_HIP(launch_cell3_pack(pk, wpk3, stream));
+        if (!wp) VPX_CHECK_HIP(launch_cell3_pack(pk, wpk3, stream));
         if (h0n) VPX_CHECK_HIP(launch_split_convert(h0n, h0_sp3, (long long)B * (long long)HW, Ch, stream));
     }
 
@@ -281,13 +286,13 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         memcpy(px.stage, L.hx_stage, sizeof(ConvStage) * L.hx_nstage);
         px.nstage = L.hx_nstage; px.chunks_total = L.hx_chunks; px.prec = d->precision; px.taps = L.taps;
         fill_plain_pack(px, 4 * Ch, 0, L.s_ng);
-        VPX_CHECK_HIP(launch_pack_weights(px, wpk_hx, stream));
+        if (!wp) VPX_CHECK_HIP(launch_pack_weights(px, wpk_hx, stream));
         if (hoist) {
             ph.seg[0] = PackSeg{W, ld_o, L.taps, Cin, Ch};
             memcpy(ph.stage, L.hh_stage, sizeof(ConvStage) * L.hh_nstage);
             ph.nstage = L.hh_nstage; ph.chunks_total = L.hh_chunks; ph.prec = d->precision; ph.taps = L.taps;
             fill_plain_pack(ph, 4 * Ch, 0, L.s_ng);
-            VPX_CHECK_HIP(launch_pack_weights(ph, wpk_hh, stream));
+            if (!wp) VPX_CHECK_HIP(launch_pack_weights(ph, wpk_hh, stream));
         }
         ConvPlan PX{};
         PX.B = B * T; PX.H = H; PX.W = Wd; PX.kh = d->kh; PX.kw = d->kw;

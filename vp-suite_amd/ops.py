@@ -98,6 +98,8 @@ def _cached_channels_last(p: torch.Tensor) -> torch.Tensor:
 
 def clear_layout_cache():
     _cl_cache.clear()
+    _clstm_ws.clear()
+    _convq_ws.clear()
 
 
 def is_channels_last(t: torch.Tensor) -> bool:
@@ -127,6 +129,15 @@ def convlstm_takes_split(B, T, Cin, Ch, H, W, k, gate_order, precision):
     """True when convlstm_seq on this problem (inference) consumes a SplitActivation input."""
     d = ConvLSTMDesc(B, T, Cin, Ch, H, W, k, k, gate_order, _lib.LAYOUT_NHWC, PRECISIONS[precision], 0)
     return bool(_lib.lib().vpx_convlstm_takes_split_input(ctypes.byref(d)))
+
+
+_clstm_ws = {}
+_CLSTM_WS_CACHE_LIMIT = 1 << 30   # bytes: larger workspaces (large batches) are not kept alive — there the repack is noise
+
+
+def _kernel_options():
+    """Epoch of the library's kernel-selection switches (they change which packs a workspace holds)."""
+    return _lib.lib().vpx_option_epoch()
 
 
 class _ConvLSTMSeqFn(torch.autograd.Function):
@@ -172,7 +183,28 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
         rs_bytes = L.vpx_convlstm_reserve_bytes(ctypes.byref(d))
         if ws_bytes == 0:
             check(-1 if "not implemented" not in L.vpx_last_error().decode() else -4, "vpx_convlstm_workspace_bytes")
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ws = None
+        if not need_grad and ws_bytes <= _CLSTM_WS_CACHE_LIMIT:
+            # inference: the block keeps its workspace, and with it the weight packs, while the weight tensor is unchanged
+            # (identity by weak reference + version + address; kernel selection switches are part of the key)
+            key = (id(W), B, T, Cin, Ch, H, Wd, kh, kw, gate_order, precision, x is None, h0 is None, x_split,
+                   torch.are_deterministic_algorithms_enabled(), _kernel_options())
+            ent = _clstm_ws.get(key)
+            if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == Wc.data_ptr() and ent[3].numel() == ws_bytes \
+                    and ent[3].device == dev:
+                ws = ent[3]
+                d.flags |= _lib.FLAG_WEIGHTS_PACKED
+            else:
+                import weakref
+                if len(_clstm_ws) > 64:
+                    _clstm_ws.clear()
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                try:
+                    _clstm_ws[key] = (weakref.ref(W), W._version, Wc.data_ptr(), ws)
+                except TypeError:
+                    pass
+        if ws is None:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         reserve = torch.empty(max(rs_bytes, 1), dtype=torch.uint8, device=dev)
         out = new_channels_last((B, T, Ch, H, Wd), dev)
         hT = out[:, T - 1]  # h_T IS the last slice of the output slab: a view, no copy

@@ -8,9 +8,13 @@ SURVEY.md §2.1), restating the training semantics of the reference around it:
             (through the model's `training_loss` hook, so the trainer runs each model's own train_iter semantics)
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for tests). The only
-exchange is ONE all-reduce of ONE flat fp32 gradient bucket per step: every parameter's .grad is a view into the
-bucket, so there is no gather/scatter copy around the collective. Because the loss is a batch mean, all-reduce(sum)/W
-of the per-shard gradients equals the single-process gradient of the global batch."""
+exchange is the all-reduce of the fp32 gradients: every parameter's .grad is a view into ONE flat buffer, so there is no
+gather/scatter copy around the collective. The buffer is cut into per-block buckets (encoder.stage1, encoder.rnn1, ...,
+contiguous ranges in parameter order); a bucket's all-reduce is launched asynchronously the moment the backward pass has
+produced the last gradient of the block (autograd post-accumulate hooks) and runs on RCCL's stream under the BPTT of the
+blocks still to come; the last wait sits in front of the optimizer step (`bucketed=False`: one all-reduce of the whole
+buffer after the backward pass). Because the loss is a batch mean, all-reduce(sum)/W of the per-shard gradients equals
+the single-process gradient of the global batch."""
 import torch
 import torch.distributed as dist
 
@@ -142,13 +146,15 @@ class DataParallelTrainer:
     replace it to execute the world>1 arithmetic (sum of shard gradients, 1/W folded into the update) on one device."""
 
     def __init__(self, model, lr: float = 1e-4, world_size: int = None, losses_and_scales=None, device=None,
-                 force_collectives: bool = False, all_reduce=None, broadcast=None):
+                 force_collectives: bool = False, all_reduce=None, broadcast=None, bucketed: bool = True):
         self.model = model
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = device if device is not None else self.params[0].device
         self.loss_provider = PredictionLossProvider({"device": dev, "losses_and_scales": losses_and_scales or {"mse": 1.0}})
-        self._all_reduce = all_reduce if all_reduce is not None else (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        # returns None (done) or a handle with .wait(): the default launches asynchronously
+        self._all_reduce = all_reduce if all_reduce is not None else \
+            (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
         self._broadcast = broadcast if broadcast is not None else (lambda t, src: dist.broadcast(t, src=src))
         # one flat gradient bucket; parameter grads are views into it
         total = sum(p.numel() for p in self.params)
@@ -158,6 +164,27 @@ class DataParallelTrainer:
         _link_views(self.params, self.flat_grad, "grad")
         self.collectives = self.world > 1 or (force_collectives and dist.is_initialized())
         self.fused = torch.device(dev).type == "cuda"
+        # per-block gradient buckets: contiguous ranges of the flat buffer, one per top-level block of the model
+        self.bucketed = bool(bucketed)
+        self.buckets = []          # [offset, numel, n_params, name]
+        self._bucket_of = {}       # id(param) -> bucket index
+        names = {id(p): n for n, p in model.named_parameters()}
+        off = 0
+        for p in self.params:
+            parts = names.get(id(p), "").split(".")
+            key = ".".join(parts[:max(1, min(2, len(parts) - 1))])   # "encoder.rnn1._conv.weight" -> "encoder.rnn1"; "conv.weight" -> "conv"
+            if not self.buckets or self.buckets[-1][3] != key:
+                self.buckets.append([off, 0, 0, key])
+            self.buckets[-1][1] += p.numel()
+            self.buckets[-1][2] += 1
+            self._bucket_of[id(p)] = len(self.buckets) - 1
+            off += p.numel()
+        self._pending = []         # gradients still missing per bucket (this step)
+        self._handles = []
+        self._launched = []
+        if self.collectives and self.bucketed:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._grad_ready)
         if self.fused:
             # parameters become views of ONE flat bucket as well, so the update is one kernel over (param, grad, m, v)
             self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
@@ -184,10 +211,29 @@ class DataParallelTrainer:
                 total = total + value
         return total
 
+    def _launch_bucket(self, i):
+        off, n = self.buckets[i][0], self.buckets[i][1]
+        h = self._all_reduce(self.flat_grad[off:off + n])
+        self._launched[i] = True
+        if h is not None:
+            self._handles.append(h)
+
+    def _grad_ready(self, p):
+        """Post-accumulate hook: p's gradient of this step is final. The block's bucket goes out with its last one."""
+        if not self._pending:
+            return
+        i = self._bucket_of[id(p)]
+        self._pending[i] -= 1
+        if self._pending[i] == 0 and not self._launched[i]:
+            self._launch_bucket(i)
+
     def backward_shard(self, x, target, pred_frames: int, **fwd_kwargs):
         """Forward + loss + backward on this rank's shard; leaves the shard's gradient in `flat_grad`. Models with their
         own training semantics (PredRNN-V2: scheduled sampling, reversed pass) provide `training_loss`."""
         self.flat_grad.zero_()
+        self._pending = [b[2] for b in self.buckets] if (self.collectives and self.bucketed) else []
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
         hook = getattr(self.model, "training_loss", None)
         if hook is not None:
             total = hook(x, target, pred_frames, self.loss_provider, **fwd_kwargs)
@@ -199,7 +245,18 @@ class DataParallelTrainer:
 
     def reduce_gradients(self):
         if self.collectives:
-            self._all_reduce(self.flat_grad)
+            if self.bucketed:
+                # buckets whose hooks did not all fire (a parameter without a gradient this step) go out now
+                for i in range(len(self.buckets)):
+                    if not self._launched[i]:
+                        self._launch_bucket(i)
+            else:
+                h = self._all_reduce(self.flat_grad)
+                if h is not None:
+                    self._handles.append(h)
+            for h in self._handles:
+                h.wait()
+            self._handles, self._pending = [], []
             if self.world > 1:
                 if self.fused:
                     self.optimizer.grad_scale = 1.0 / self.world  # folded into the update kernel
