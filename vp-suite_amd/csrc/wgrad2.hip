@@ -32,13 +32,19 @@ constexpr int W2_APIECES = 2 * W2_NPOS * 8;       // 1728 16-byte pieces of the 
 
 __device__ const float w2_zero16[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
 
-__device__ __forceinline__ int w2_swz(const int off) { return off ^ ((off >> 2) & 0x40); }   // 128-byte rows: row bit 1 swaps the 64-byte halves
+// 128-byte rows. 32x32x16 form: row bit 1 swaps the 64-byte halves (a 32-lane half reads 4 consecutive rows at two column blocks).
+// 16x16x32 form (QF): row bit 2 additionally swaps the 32-byte quarters — there a 32-lane half reads EIGHT consecutive rows at one
+// 16-column block (32 bytes), and (row bit 0 -> the 128-byte row parity, bit 1, bit 2) then spread them over the 8 x 8 banks.
+template <bool QF>
+__device__ __forceinline__ int w2_swz(const int off) { return QF ? (off ^ ((off >> 2) & 0x40) ^ ((off >> 4) & 0x20)) : (off ^ ((off >> 2) & 0x40)); }
 
+template <int STEP2 = 512>
 __device__ __forceinline__ bf16x8 w2_frag(const char* base) {
-    // two transposing reads: pixels +0..3 and +4..7 of this lane half's 8-pixel group (128 bytes per pixel row)
+    // two transposing reads: pixels +0..3 and +4..7 of this lane half's 8-pixel group (128 bytes per pixel row); 16x16x32 form:
+    // pixels +0..3 and +8..11 (STEP2 = 1024) — any k <-> pixel map works as long as both operands use the same one
     typedef bf16x4 __attribute__((address_space(3))) * lds_v4;
     const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base));
-    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base + 512));
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4)(base + STEP2));
     return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
@@ -50,6 +56,12 @@ __device__ __forceinline__ void w2_dma16(const char* g, char* lds_wave_base) {
                  :: "v"(g), "{m0}"(__builtin_amdgcn_readfirstlane(lds)) : "memory");
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// QF: the same kernel on v_mfma_f32_16x16x32_bf16 (vpx_set_option(VPX_OPT_MFMA_SHAPE, 1)): a K = 32 step is two tile rows of the
+// item, a wave's 64 gate rows x 32 channels x tap group are 4 x 2 accumulator tiles of 16x16 per tap (the same 160 registers),
+// the same fragment bytes per MFMA cycle.
+template <bool QF>
 __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
     constexpr int TA = 5, TB = 4;   // taps of group 0 / group 1
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,25 +95,38 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
     const int n0 = __builtin_amdgcn_readfirstlane((bx / n_ct) * 128);
     const int tap0 = tg ? TA : 0;
 
-    f32x16 acc[2][TA];
+    f32x16 acc[QF ? 1 : 2][QF ? 1 : TA];     // 32x32x16 form: [row block of 32][tap]
+    f32x4 accq[QF ? 4 : 1][2][QF ? TA : 1];  // 16x16x32 form: [row tile of 16][channel tile of 16][tap]
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < (QF ? 1 : 2); ++nb)
 #pragma unroll
-        for (int t = 0; t < TA; ++t)
+        for (int t = 0; t < (QF ? 1 : TA); ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][t][r] = 0.0f;
+#pragma unroll
+    for (int rt = 0; rt < (QF ? 4 : 1); ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int t = 0; t < (QF ? TA : 1); ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accq[rt][ct][t][r] = 0.0f;
 
     // fragment addressing (transposing reads; same lane map as wgrad_tg_kernel)
     const int L16 = lane & 15, q = L16 >> 2, p = L16 & 3, half16 = (lane >> 4) & 1;
+    const int kgq = lane >> 4;   // QF: k group = tile row of the K = 32 pair (kgq >> 1) and which 4 + 4 of its pixels (kgq & 1)
     int g_lane[2];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) g_lane[nb] = w2_swz(((8 * hh + q) * 64 + nb * 32 + 16 * half16 + 4 * p) * 2);
+    for (int nb = 0; nb < 2; ++nb) g_lane[nb] = w2_swz<false>(((8 * hh + q) * 64 + nb * 32 + 16 * half16 + 4 * p) * 2);
+    // QF: rows 16 * (kgq >> 1) + 4 * (kgq & 1) + q (+ 8 in the second read), row tile rt at columns rt * 16: + (rt * 32) under the XOR
+    const int g_laneq = w2_swz<true>(((16 * (kgq >> 1) + 4 * (kgq & 1) + q) * 64 + 4 * p) * 2);
     // A column tile whose second 32-channel half is empty (80 = 16 + 32 + 32 channels -> the last tile holds one half) would leave
     // the wc = 1 waves multiplying zeros: there, both waves of a pair take the SAME channels and split the k-steps of every item
     // between them (wc = 0: rows 0-1, wc = 1: rows 2-3 of the 4 x 16 item); the pair's accumulators meet in LDS after the loop.
     const bool ksplit = ch1.cn == 0;
     const int s_lo = ksplit ? 2 * wc : 0, s_hi = ksplit ? 2 * wc + 2 : W2_TH;
-    const int a_lane = ((8 * hh + q) * 64 + (ksplit ? 0 : wc) * 32 + 16 * half16 + 4 * p) * 2;
+    const int a_lane = QF ? (((kgq >> 1) * W2_HALO_W + 4 * (kgq & 1) + q) * 64 + (ksplit ? 0 : wc) * 32 + 4 * p) * 2
+                          : ((8 * hh + q) * 64 + (ksplit ? 0 : wc) * 32 + 16 * half16 + 4 * p) * 2;
     int tapoff[TA];
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
@@ -138,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
     // ---- this thread's DMA pieces. dG: one 16-byte slot of each of the four planes (same pixel, same slot); the XOR swizzle of
     //      the image is applied through the CHOICE of source (physical slot -> logical slot, the swizzle is an involution) ----
     const int g_px = tid >> 3;
-    const int g_sl = (w2_swz(g_px * 128 + (tid & 7) * 16) & 127) >> 4;     // logical slot: rows g_sl*8 .. +7 of the plane's 64
+    const int g_sl = (w2_swz<QF>(g_px * 128 + (tid & 7) * 16) & 127) >> 4;     // logical slot: rows g_sl*8 .. +7 of the plane's 64
     const int g_off = ((n0 + g_sl * 8) >> 3) * 32;                         // byte offset inside the dG pixel row (plane u adds (u>>1)*256 + (u&1)*16)
     const bool g_ok0 = n0 + g_sl * 8 < a.N4, g_ok1 = n0 + 64 + g_sl * 8 < a.N4;
     const unsigned g_prow = (unsigned)a.N4 * 4u;
@@ -156,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
         const int plane = piece >= W2_NPOS * 8 ? 1 : 0;
         const int qq = piece - plane * W2_NPOS * 8;
         const int pos = qq >> 3;
-        const int sl = (w2_swz(pos * 128 + (qq & 7) * 16) & 127) >> 4;     // logical slot = 8 channels of the 64-channel row
+        const int sl = (w2_swz<QF>(pos * 128 + (qq & 7) * 16) & 127) >> 4;     // logical slot = 8 channels of the 64-channel row
         const int hy = pos / W2_HALO_W, hx = pos - hy * W2_HALO_W;
         const WgradCHalf hf = (sl >> 2) ? ch1 : ch0;
         const bool ok = piece < W2_APIECES && (sl & 3) * 8 < hf.cn;
@@ -211,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
         bf16x8 ah[NB], al[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int aoff = w2_swz(arow + tapoff[T0 + j]);
+            const int aoff = w2_swz<false>(arow + tapoff[T0 + j]);
             ah[j] = w2_frag(buf + W2_A0 + aoff);
             al[j] = w2_frag(buf + W2_A0 + W2_APL + aoff);
         }
@@ -231,6 +256,42 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
     };
     auto multiply = [&](const char* buf) {
         const char* gb = buf + wn * 2 * W2_GPL;
+        if constexpr (QF) {
+            // K = 32 steps: tile rows (0,1) and (2,3) of the item; ksplit: one step per wave of the pair
+#pragma unroll 1
+            for (int s2 = (ksplit ? wc : 0); s2 < (ksplit ? wc + 1 : 2); ++s2) {
+                bf16x8 gh[4], gl[4];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    gh[rt] = w2_frag<1024>(gb + (g_laneq ^ (rt * 32)) + s2 * 4096);
+                    gl[rt] = w2_frag<1024>(gb + W2_GPL + (g_laneq ^ (rt * 32)) + s2 * 4096);
+                }
+                const int arow = a_lane + s2 * 2 * W2_HALO_W * 128;
+#pragma unroll
+                for (int t = 0; t < TA; ++t) {
+                    if (t == TA - 1 && tg != 0) break;
+                    bf16x8 ah[2], al[2];
+                    const int aoff = w2_swz<true>(arow + tapoff[t]);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        ah[ct] = w2_frag<1024>(buf + W2_A0 + (aoff ^ (ct * 32)));
+                        al[ct] = w2_frag<1024>(buf + W2_A0 + W2_APL + (aoff ^ (ct * 32)));
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) accq[rt][ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl[rt], ah[ct], accq[rt][ct][t], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) accq[rt][ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[rt], al[ct], accq[rt][ct][t], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) accq[rt][ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[rt], ah[ct], accq[rt][ct][t], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll 1
         for (int s = s_lo; s < s_hi; ++s) {
             bf16x8 gh[2], gl[2];
@@ -243,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
             tap_batch(buf, gh, gl, arow, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
             tap_batch(buf, gh, gl, arow, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
             if (tg == 0) tap_batch(buf, gh, gl, arow, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+        }
         }
     };
 
@@ -271,24 +333,66 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
         for (int nb = 0; nb < 2; ++nb) {
             __syncthreads();
             if (wc == 1) {
+                if constexpr (QF) {
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                            for (int t = 0; t < TA; ++t)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) red[(((rr * 2 + ct) * TA + t) * 4 + r) * 64 + lane] = accq[2 * nb + rr][ct][t][r];
+                } else {
 #pragma unroll
                 for (int t = 0; t < TA; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[nb][t][r];
+                }
             }
             __syncthreads();
             if (wc == 0) {
+                if constexpr (QF) {
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                            for (int t = 0; t < TA; ++t)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) accq[2 * nb + rr][ct][t][r] += red[(((rr * 2 + ct) * TA + t) * 4 + r) * 64 + lane];
+                } else {
 #pragma unroll
                 for (int t = 0; t < TA; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[nb][t][r] += red[(t * 16 + r) * 64 + lane];
+                }
             }
         }
     }
     const WgradCHalf oh = wc ? ch1 : ch0;
+    float* slab = a.slabs + (size_t)slice * 9 * a.N4 * a.Ct;
+    if constexpr (QF) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int cw = ct * 16 + (lane & 15);
+                const int col = oh.cglobal + cw;
+                const bool col_ok = cw < oh.cn;
+#pragma unroll
+                for (int t = 0; t < TA; ++t) {
+                    if (tg == 1 && t >= TB) break;
+                    float* st = slab + (size_t)(tap0 + t) * a.N4 * a.Ct;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + wn * 64 + rt * 16 + 4 * (lane >> 4) + r;
+                        if (n < a.N4 && col_ok) st[(size_t)n * a.Ct + col] = accq[rt][ct][t][r];
+                    }
+                }
+            }
+    } else {
     const int col = oh.cglobal + i;
     const bool col_ok = i < oh.cn;
-    float* slab = a.slabs + (size_t)slice * 9 * a.N4 * a.Ct;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -301,6 +405,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
                 if (n < a.N4 && col_ok) st[(size_t)n * a.Ct + col] = acc[nb][t][r];
             }
         }
+    }
 }
 
 // Applies when launch_wgrad would pick the pre-split tap-group kernel AND dG is available in split format: 3x3, bf16x3.
@@ -323,7 +428,9 @@ int wgrad2_target_wgs() {
 hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices, int* tail_col0, int* tail_slices, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -349,7 +456,8 @@ hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices
     *tail_col0 = half_tail ? a.ct[a.n_ctiles - 1].h[0].cglobal : a.Ct;
     *tail_slices = half_tail ? a.w2_ns_half : ns;
     const long long total = (long long)nf * ns + (long long)a.w2_nh * a.w2_ns_half;
-    hipLaunchKernelGGL(wgrad2_kernel, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
+    if (mfma_shape() == 1) hipLaunchKernelGGL(wgrad2_kernel<true>, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
+    else hipLaunchKernelGGL(wgrad2_kernel<false>, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
     return hipGetLastError();
 }
 
