@@ -160,3 +160,71 @@ def test_block_backward_at_batch128(vpx, Cin, Ch, HW, precision):
         ((ro * g_out[s:s + 1].cpu()).sum() + 0.5 * (rc * rc).sum()).backward()
         assert _relmax(out[s:s + 1], ro) < 2e-5
         assert _relmax(grads[0][s:s + 1], lv[0].grad) < 5e-5
+
+
+def test_c1_literal_batch4_full_model_vs_oracle(vpx):
+    """BASELINE configs[0]/[1] at their literal batch: convlstm-shi, 1x64x64, 10 -> 10, FOUR samples — every recurrent block on
+    the small-grid kernel (cell3), the glue at 40 frames per launch, weight packs re-used on the second call."""
+    from oracle import torch_ref as tr
+    m = _model("convlstm-shi", "ef.c1b4", img_shape=(1, 64, 64), cell_precision="bf16x3")
+    x = seeded_rand((4, 10, 1, 64, 64), name_seed("ef.c1b4.x"))
+    with torch.no_grad():
+        pred, _ = m(x.cuda(), pred_frames=10)
+        pred2, _ = m(x.cuda(), pred_frames=10)      # workspace + weight packs of the first call re-used (VPX_FLAG_WEIGHTS_PACKED)
+        ref = tr.ef_convlstm_forward(_cpu_sd(m), x, 10)
+    assert pred.shape == (4, 10, 1, 64, 64)
+    assert _relmax(pred, ref) < 1e-4
+    assert torch.equal(pred, pred2)                 # no atomics on this path: bit-identical
+    # changing a weight in place bumps its version: the cached packs must not be used again
+    with torch.no_grad():
+        m.encoder.rnn1._conv.weight.mul_(1.5)
+        pred3, _ = m(x.cuda(), pred_frames=10)
+        ref3 = tr.ef_convlstm_forward(_cpu_sd(m), x[:1], 10)
+    assert _relmax(pred3[:1], ref3) < 1e-4 and not torch.equal(pred3, pred)
+
+
+@pytest.mark.parametrize("Cin", [16, 128])
+def test_stlstm_step_backward_at_batch128(vpx, Cin):
+    """ST-LSTM step (PredRNN default shapes: 16 | 128 -> 128 channels, 16x16 maps, 5x5) forward + backward at B = 128 — the
+    training bench's kernel forms (dual gate launch, K-split data gradients, one-buffer tap-group weight gradients with their
+    batch-dependent K slices). Outputs and dx/dh/dc/dm of single samples against the oracle's autograd; batch-summed weight
+    gradients against the sum over sixteen B = 8 calls (which test_gpu_stlstm.py pins to the reference fixtures)."""
+    from oracle import torch_ref as tr
+    Ch, H, W, k, B = 128, 16, 16, 5, 128
+    tag = f"st128.{Cin}"
+    names = ("x", "h", "c", "m")
+    inp = {n: (seeded_randn((B, Cin if n == "x" else Ch, H, W), name_seed(f"{tag}.{n}"), 0.5)).cuda() for n in names}
+    shapes = {"Wx": (7 * Ch, Cin, k, k), "Wh": (4 * Ch, Ch, k, k), "Wm": (3 * Ch, Ch, k, k), "Wo": (Ch, 2 * Ch, k, k), "Wlast": (Ch, 2 * Ch, 1, 1)}
+    Ws = {n: seeded_randn(s, name_seed(f"{tag}.{n}"), 1.0 / np.sqrt(s[1] * s[2] * s[3])).cuda() for n, s in shapes.items()}
+    gout = [seeded_randn((B, Ch, H, W), name_seed(f"{tag}.g{i}")).cuda() for i in range(5)]
+
+    def run(sl):
+        a = [inp[n][sl].clone().requires_grad_(True) for n in names]
+        w = [Ws[n].clone().requires_grad_(True) for n in shapes]
+        outs = vpx.ops.stlstm_step(*a, *w, precision="bf16x3")
+        sum((o * g[sl]).sum() for o, g in zip(outs, gout)).backward()
+        return [o.detach() for o in outs], [t.grad for t in a], [t.grad for t in w]
+
+    outs, dact, dw = run(slice(0, B))
+    acc = None
+    for c0 in range(0, B, 8):
+        o8, a8, w8 = run(slice(c0, c0 + 8))
+        for o, o_ in zip(outs, o8):
+            assert _relmax(o[c0:c0 + 8], o_) < 1e-5
+        for g, g_ in zip(dact, a8):
+            assert _relmax(g[c0:c0 + 8], g_) < 5e-5
+        acc = w8 if acc is None else [x + y for x, y in zip(acc, w8)]
+    for n, got, want in zip(shapes, dw, acc):
+        assert _relmax(got, want) < 5e-5, n
+    # anchor on the oracle: one sample, outputs and activation gradients
+    s = 77
+    sd = {"conv_x.0.weight": Ws["Wx"], "conv_h.0.weight": Ws["Wh"], "conv_m.0.weight": Ws["Wm"], "conv_o.0.weight": Ws["Wo"],
+          "conv_last.weight": Ws["Wlast"]}
+    sd = {kk: v.detach().cpu() for kk, v in sd.items()}
+    a = [inp[n][s:s + 1].detach().cpu().clone().requires_grad_(True) for n in names]
+    ref = tr.stlstm_cell(*a, sd, "", False)
+    sum((o * g[s:s + 1].cpu()).sum() for o, g in zip(ref, gout)).backward()
+    for o, r in zip(outs, ref):
+        assert _relmax(o[s:s + 1], r) < 2e-5
+    for g, t in zip(dact, a):
+        assert _relmax(g[s:s + 1], t.grad) < 5e-5
