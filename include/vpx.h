@@ -78,7 +78,8 @@ const char* vpx_last_error(void);
 /* Run-to-run bit reproducibility (the counterpart of torch.use_deterministic_algorithms, which the reference inherits
  * from PyTorch). Default 0: convolutions on small feature maps split their contraction over workgroups and combine
  * partial sums with floating-point atomics (results equal up to fp32 summation order, ~1e-7 relative). 1: no atomics
- * anywhere (slower on 16x16 / 32x32 maps). Process-wide; returns the previous setting. */
+ * anywhere (slower on 16x16 / 32x32 maps; TrajGRU's warp backward switches to integer atomics, whose sum is order-independent:
+ * vpx_trajgru_warp_bwd_det). Process-wide; returns the previous setting. */
 int vpx_set_deterministic(int on);
 /* Kernel-selection switches for A/B measurements and parity tests inside one process (results never depend on them beyond
  * fp32 summation order). Returns the previous value, or a negative error code for an unknown option.
@@ -236,13 +237,19 @@ int vpx_axpy(float* y, const float* x, long long n, void* stream);
 /* ---- TrajGRU step pieces (vp_suite/model_blocks/traj_gru.py:148-162, 190-203), NHWC -------------------------------- *
  * warp: warped[b,p, l*C + c] = bilinear sample of h[b,:,:,c] at pixel p displaced by -flows[b,p,2l..2l+1] with the
  *       reference's normalisation (divide by W-1 / H-1, grid_sample align_corners=False, zero padding); C % 4 == 0.
- *       backward: dh += scatter (float atomics; dh may be NULL), dflows written (may be NULL).
+ *       backward: dh += scatter (float atomics; dh may be NULL), dflows written (may be NULL). The float scatter is the one
+ *       place where summation order depends on timing; under vpx_set_deterministic(1) this entry refuses a non-NULL dh and
+ *       vpx_trajgru_warp_bwd_det takes its place: the same scatter in 2^40-scaled 64-bit integers (associative, hence
+ *       bit-reproducible; resolution 9e-13, range +-8.4e6 per element), converted and added onto dh by a second kernel.
  * gates: r = s(i0+h0), u = s(i1+h1), m = act(i2 + r*h2), next = u*prev + (1-u)*m; i2h (a [HW,3C] slice per batch item,
  *       batch stride in elements) may be NULL; act 0 = LeakyReLU(slope) (slope 0 = ReLU), 1 = sigmoid; save [B,HW,3C]
  *       receives (r, u, m) for the backward, which writes di2h (may be NULL), dh2h and dprev = u * dnext. */
 int vpx_trajgru_warp_fwd(const float* h, const float* flows, float* warped, int B, int H, int W, int C, int L, void* stream);
 int vpx_trajgru_warp_bwd(const float* h, const float* flows, const float* dwarped, float* dh, float* dflows, int B, int H, int W,
                          int C, int L, void* stream);
+size_t vpx_trajgru_warp_bwd_det_workspace_bytes(int B, int H, int W, int C);
+int vpx_trajgru_warp_bwd_det(const float* h, const float* flows, const float* dwarped, float* dh, float* dflows, int B, int H, int W,
+                             int C, int L, void* workspace, size_t workspace_bytes, void* stream);
 int vpx_trajgru_gates_fwd(const float* i2h, long long i2h_bstride, const float* h2h, const float* prev, float* next, float* save,
                           int B, int HW, int C, int act, float slope, void* stream);
 int vpx_trajgru_gates_bwd(const float* dnext, const float* h2h, const float* prev, const float* save, float* di2h,

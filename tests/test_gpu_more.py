@@ -370,6 +370,37 @@ def test_trajgru_block_vs_golden(vpx, tag):
 
 
 @pytest.mark.gpu
+def test_trajgru_backward_is_bit_reproducible_on_request(vpx):
+    """torch.use_deterministic_algorithms(True): the warp backward scatters 2^40-scaled integers (vpx_trajgru_warp_bwd_det) — two
+    runs give bit-identical gradients, equal to the float-atomic path within its summation noise."""
+    from vp_suite_amd.model_blocks import TrajGRU
+    in_c, enc_c, H, W, L, B, T, mode = gc.TRAJGRU_CASES["full"]
+    blk = TrajGRU("cuda", in_c, enc_c, H, W, L=L)
+    fill_state_dict_(blk, name_seed("trajgru.full"))
+    blk = blk.cuda()
+    x0 = seeded_rand((B, T, in_c, H, W), name_seed("trajgru.full.x")).cuda()
+    gout = seeded_randn((B, T, enc_c, H, W), name_seed("trajgru.full.g")).cuda()
+
+    def run():
+        for p_ in blk.parameters():
+            p_.grad = None
+        x = x0.clone().requires_grad_(True)
+        out, _ = blk(x, None, T)
+        (out * gout).sum().backward()
+        return [x.grad.clone()] + [p_.grad.clone() for p_ in blk.parameters()]
+
+    ref = run()
+    torch.use_deterministic_algorithms(True)
+    try:
+        a, b = run(), run()
+    finally:
+        torch.use_deterministic_algorithms(False)
+    for u, v_, r in zip(a, b, ref):
+        assert torch.equal(u, v_)
+        assert _relmax(u, r) < 2e-5
+
+
+@pytest.mark.gpu
 def test_small_grids_fused_and_split_paths_agree(vpx):
     """On nearly-empty grids the ConvLSTM step runs as a K-split convolution + pointwise gates (atomics); with
     torch.use_deterministic_algorithms(True) the same shapes take the fused launch. Both must meet the oracle, the

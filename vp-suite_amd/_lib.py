@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "vpx_conv2d_ex_bwd_workspace_bytes", "vpx_conv2d_ex_bwd",
     "vpx_conv2d_nhwc_fwd_ex", "vpx_leaky_bwd_workspace_bytes", "vpx_leaky_bwd", "vpx_axpy",
     "vpx_acst_gates_fwd", "vpx_acst_gates_bwd", "vpx_st_out_fwd", "vpx_st_out_bwd",
-    "vpx_trajgru_warp_fwd", "vpx_trajgru_warp_bwd", "vpx_trajgru_gates_fwd", "vpx_trajgru_gates_bwd",
+    "vpx_trajgru_warp_fwd", "vpx_trajgru_warp_bwd", "vpx_trajgru_warp_bwd_det_workspace_bytes", "vpx_trajgru_warp_bwd_det", "vpx_trajgru_gates_fwd", "vpx_trajgru_gates_bwd",
     "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
     "vpx_mse_loss_workspace_bytes", "vpx_mse_loss", "vpx_adam_step",
 ]
@@ -152,6 +152,10 @@ def lib():
         L.vpx_trajgru_warp_fwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
         L.vpx_trajgru_warp_bwd.restype = ci
         L.vpx_trajgru_warp_bwd.argtypes = [vp] * 5 + [ci] * 5 + [vp]
+        L.vpx_trajgru_warp_bwd_det_workspace_bytes.restype = sz
+        L.vpx_trajgru_warp_bwd_det_workspace_bytes.argtypes = [ci] * 4
+        L.vpx_trajgru_warp_bwd_det.restype = ci
+        L.vpx_trajgru_warp_bwd_det.argtypes = [vp] * 5 + [ci] * 5 + [vp, sz, vp]
         L.vpx_trajgru_gates_fwd.restype = ci
         L.vpx_trajgru_gates_fwd.argtypes = [vp, ll, vp, vp, vp, vp, ci, ci, ci, ci, fl, vp]
         L.vpx_trajgru_gates_bwd.restype = ci

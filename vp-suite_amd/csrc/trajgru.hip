@@ -58,9 +58,22 @@ __global__ __launch_bounds__(256) void trajgru_warp_fwd_kernel(const WarpGeo g, 
 // backward: one thread per (b, pixel, l) walks the channels: dh (+)= scatter of d_warped with the bilinear weights (float
 // atomics: the scatter targets are data dependent — like torch's grid_sample backward the sum order is not reproducible),
 // d_flow = -(d sample / d coordinate) summed over the channels (the warp uses pixel - flow)
+// FIXED (vpx_set_deterministic(1) / vpx_trajgru_warp_bwd_det): the scatter adds 2^40-scaled 64-bit integers instead of floats —
+// integer addition is associative, so the sum no longer depends on the order in which the atomics arrive (bit-reproducible);
+// resolution 9e-13, range +-8.4e6 per element. trajgru_fixed_to_float_kernel then adds the converted sums onto dh.
+constexpr double WARP_FIXED_SCALE = 1099511627776.0;   // 2^40
+__device__ __forceinline__ void warp_fixed_add(long long* acc, size_t i, float v) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc) + i, (unsigned long long)__double2ll_rn((double)v * WARP_FIXED_SCALE));
+}
+__global__ __launch_bounds__(256) void trajgru_fixed_to_float_kernel(const long long* __restrict__ acc, float* __restrict__ dh, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dh[i] += (float)((double)acc[i] * (1.0 / WARP_FIXED_SCALE));
+}
+
+template <bool FIXED>
 __global__ __launch_bounds__(256) void trajgru_warp_bwd_kernel(const WarpGeo g, const float* __restrict__ h, const float* __restrict__ flows,
                                                                const float* __restrict__ dwarped, float* __restrict__ dh,
-                                                               float* __restrict__ dflows) {
+                                                               float* __restrict__ dflows, long long* __restrict__ acc) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)g.B * g.H * g.W * g.L;
     if (idx >= total) return;
@@ -75,6 +88,7 @@ __global__ __launch_bounds__(256) void trajgru_warp_bwd_kernel(const WarpGeo g, 
     warp_coords(g, x, y, flows[fo], flows[fo + 1], x0, y0, ax, ay);
     const float* hb = h + (size_t)b * g.H * g.W * g.C;
     float* dhb = dh ? dh + (size_t)b * g.H * g.W * g.C : nullptr;
+    long long* accb = acc ? acc + (size_t)b * g.H * g.W * g.C : nullptr;
     const float* dw = dwarped + ((size_t)b * g.H * g.W + pix) * ((size_t)g.L * g.C) + (size_t)l * g.C;
     bool ok[2][2];
     size_t off[2][2];
@@ -93,7 +107,14 @@ __global__ __launch_bounds__(256) void trajgru_warp_bwd_kernel(const WarpGeo g, 
         const float v10 = ok[1][0] ? hb[off[1][0] + c] : 0.f, v11 = ok[1][1] ? hb[off[1][1] + c] : 0.f;
         gx += d * ((1.0f - ay) * (v01 - v00) + ay * (v11 - v10));
         gy += d * ((1.0f - ax) * (v10 - v00) + ax * (v11 - v01));
-        if (dhb) {
+        if (FIXED) {
+            if (accb) {
+                if (ok[0][0]) warp_fixed_add(accb, off[0][0] + c, d * (1.0f - ax) * (1.0f - ay));
+                if (ok[0][1]) warp_fixed_add(accb, off[0][1] + c, d * ax * (1.0f - ay));
+                if (ok[1][0]) warp_fixed_add(accb, off[1][0] + c, d * (1.0f - ax) * ay);
+                if (ok[1][1]) warp_fixed_add(accb, off[1][1] + c, d * ax * ay);
+            }
+        } else if (dhb) {
             if (ok[0][0]) unsafeAtomicAdd(dhb + off[0][0] + c, d * (1.0f - ax) * (1.0f - ay));
             if (ok[0][1]) unsafeAtomicAdd(dhb + off[0][1] + c, d * ax * (1.0f - ay));
             if (ok[1][0]) unsafeAtomicAdd(dhb + off[1][0] + c, d * (1.0f - ax) * ay);
@@ -204,10 +225,43 @@ int vpx_trajgru_warp_bwd(const float* h, const float* flows, const float* dwarpe
     int rc = warp_geo(g, B, H, W, C, L, "vpx_trajgru_warp_bwd");
     if (rc != VPX_OK) return rc;
     if (!h || !flows || !dwarped) { set_error("vpx_trajgru_warp_bwd: NULL tensor argument"); return VPX_ERR_ARG; }
+    if (vpx::g_deterministic && dh) {
+        set_error("vpx_trajgru_warp_bwd: deterministic mode is on — call vpx_trajgru_warp_bwd_det (it needs a workspace for the fixed-point sums)");
+        return VPX_ERR_UNSUPPORTED;
+    }
     const long long total = (long long)B * H * W * L;
-    hipLaunchKernelGGL(trajgru_warp_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, h, flows,
-                       dwarped, dh, dflows);
+    hipLaunchKernelGGL(trajgru_warp_bwd_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, h, flows,
+                       dwarped, dh, dflows, (long long*)nullptr);
     VPX_CHECK_HIP(hipGetLastError());
+    return VPX_OK;
+}
+
+size_t vpx_trajgru_warp_bwd_det_workspace_bytes(int B, int H, int W, int C) {
+    if (B < 1 || H < 1 || W < 1 || C < 1) return 0;
+    return (size_t)B * H * W * C * sizeof(long long) + 256;
+}
+
+int vpx_trajgru_warp_bwd_det(const float* h, const float* flows, const float* dwarped, float* dh, float* dflows, int B, int H, int W,
+                             int C, int L, void* workspace, size_t workspace_bytes, void* stream_) {
+    WarpGeo g;
+    int rc = warp_geo(g, B, H, W, C, L, "vpx_trajgru_warp_bwd_det");
+    if (rc != VPX_OK) return rc;
+    if (!h || !flows || !dwarped) { set_error("vpx_trajgru_warp_bwd_det: NULL tensor argument"); return VPX_ERR_ARG; }
+    if (dh && (!workspace || workspace_bytes < vpx_trajgru_warp_bwd_det_workspace_bytes(B, H, W, C))) {
+        set_error("vpx_trajgru_warp_bwd_det: workspace too small");
+        return VPX_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    long long* acc = dh ? reinterpret_cast<long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255) : nullptr;
+    const long long n = (long long)B * H * W * C, total = (long long)B * H * W * L;
+    if (acc) VPX_CHECK_HIP(hipMemsetAsync(acc, 0, (size_t)n * sizeof(long long), stream));
+    hipLaunchKernelGGL(trajgru_warp_bwd_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, g, h, flows, dwarped, dh,
+                       dflows, acc);
+    VPX_CHECK_HIP(hipGetLastError());
+    if (acc) {
+        hipLaunchKernelGGL(trajgru_fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc, dh, n);
+        VPX_CHECK_HIP(hipGetLastError());
+    }
     return VPX_OK;
 }
 

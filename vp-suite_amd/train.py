@@ -50,7 +50,14 @@ def _link_views(params, flat, attr):
 class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam(params, lr) (vpsuite.py:353) as ONE HIP kernel over flat buckets: `params` are views into
     `flat_param`, their .grad views into `flat_grad`. A torch Optimizer (param_groups / state_dict / zero_grad), so LR
-    schedulers such as ReduceLROnPlateau (vpsuite.py:354) drive it unchanged. One parameter group only."""
+    schedulers such as ReduceLROnPlateau (vpsuite.py:354) drive it unchanged. One parameter group only.
+
+    One deliberate difference from torch.optim.Adam: EVERY parameter of the bucket is stepped in every iteration with the
+    bucket-wide step count. torch skips a parameter whose .grad is None; here such a parameter is re-linked to a zeroed slice
+    of the gradient bucket and takes a zero-gradient Adam step (its moments decay, remaining momentum still moves it, weight
+    decay applies). All parameters of the shipped models receive a gradient in every iteration, so the trajectories coincide
+    (tests/test_gpu_models.py pins them against torch.optim.Adam); a model with a branch that is unused in some iterations
+    should freeze that branch (requires_grad = False) or use torch.optim.Adam."""
 
     def __init__(self, params, flat_param, flat_grad, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         params = list(params)

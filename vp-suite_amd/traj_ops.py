@@ -137,6 +137,8 @@ class _TrajGRUSeqFn(torch.autograd.Function):
         t_w = {n: torch.empty_like(v) for n, v in g.items()}
         t_b = {n: torch.empty_like(v) for n, v in gb.items()}
         lws = torch.empty(Lc.vpx_leaky_bwd_workspace_bytes(F), dtype=torch.uint8, device=dev)
+        det = torch.are_deterministic_algorithms_enabled()
+        det_ws = torch.empty(Lc.vpx_trajgru_warp_bwd_det_workspace_bytes(B, H, W, C), dtype=torch.uint8, device=dev) if det else None
         for t in range(T - 1, -1, -1):
             prev = h_init if t == 0 else hs[t - 1]
             if dout_tm is not None:
@@ -148,8 +150,12 @@ class _TrajGRUSeqFn(torch.autograd.Function):
             check(Lc.vpx_trajgru_warp_fwd(ptr(prev), ptr(flows[t]), ptr(warped), B, H, W, C, L, _stream()), "vpx_trajgru_warp_fwd")
             lib.conv_bwd(warped, ret_w, dh2h, dwarped, t_w["ret_w"], t_b["ret_b"], B, H, W, L * C, 3 * C, 1)
             lib.axpy(g["ret_w"], t_w["ret_w"]); lib.axpy(gb["ret_b"], t_b["ret_b"])
-            check(Lc.vpx_trajgru_warp_bwd(ptr(prev), ptr(flows[t]), ptr(dwarped), ptr(dprev), ptr(dflows), B, H, W, C, L, _stream()),
-                  "vpx_trajgru_warp_bwd")
+            if det:   # integer (order-independent) scatter: bit-reproducible under torch.use_deterministic_algorithms(True)
+                check(Lc.vpx_trajgru_warp_bwd_det(ptr(prev), ptr(flows[t]), ptr(dwarped), ptr(dprev), ptr(dflows), B, H, W, C, L,
+                                                  ptr(det_ws), det_ws.numel(), _stream()), "vpx_trajgru_warp_bwd_det")
+            else:
+                check(Lc.vpx_trajgru_warp_bwd(ptr(prev), ptr(flows[t]), ptr(dwarped), ptr(dprev), ptr(dflows), B, H, W, C, L, _stream()),
+                      "vpx_trajgru_warp_bwd")
             lib.conv_bwd(f1[t], fl_w, dflows, df1, t_w["fl_w"], t_b["fl_b"], B, H, W, F, 2 * L, 5)
             lib.axpy(g["fl_w"], t_w["fl_w"]); lib.axpy(gb["fl_b"], t_b["fl_b"])
             check(Lc.vpx_leaky_bwd(ptr(df1), ptr(f1[t]), slope, ptr(df1s), ptr(t_b["f_b"]), B * HW, F, ptr(lws), lws.numel(), _stream()),
