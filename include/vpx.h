@@ -271,6 +271,16 @@ int vpx_st_out_fwd(const float* o_pre, const float* oc, const float* lc, float* 
                    void* stream);
 int vpx_st_out_bwd(const float* dh, const float* o, const float* tl, float* d_o, float* d_lc, long long n, void* stream);
 
+/* ---- LayerNorm([C,H,W]) per sample on NHWC tensors (predrnn.py:27-40, 105-135; eps = 1e-5) ---------------------------------- *
+ * x, y, xhat: [B][n = H*W*C]; gamma, beta (and dgamma, dbeta): [H*W][C], i.e. the reference's [C,H,W] parameters channels-last;
+ * stats [B][2] = (mean, 1/std) and xhat (optional in the forward: NULL skips the store) feed the backward. Sums run in double over
+ * fixed chunks (bit-reproducible); dgamma / dbeta are OVERWRITTEN. */
+size_t vpx_layernorm_workspace_bytes(int B);
+int vpx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* xhat, float* stats, int B, long long n,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int vpx_layernorm_bwd(const float* dy, const float* xhat, const float* stats, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                      int B, int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- layout adaptors: src [N,C,H,W] <-> dst [N,H,W,C] -------------------------------------------------------- */
 int vpx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, void* stream);
 int vpx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, void* stream);

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "vpx_acst_gates_fwd", "vpx_acst_gates_bwd", "vpx_st_out_fwd", "vpx_st_out_bwd",
     "vpx_trajgru_warp_fwd", "vpx_trajgru_warp_bwd", "vpx_trajgru_warp_bwd_det_workspace_bytes", "vpx_trajgru_warp_bwd_det", "vpx_trajgru_gates_fwd", "vpx_trajgru_gates_bwd",
     "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
+    "vpx_layernorm_workspace_bytes", "vpx_layernorm_fwd", "vpx_layernorm_bwd",
     "vpx_mse_loss_workspace_bytes", "vpx_mse_loss", "vpx_adam_step",
 ]
 
@@ -168,6 +169,12 @@ def lib():
         L.vpx_conv2d_ex_split_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
         L.vpx_conv2d_ex_fwd_from_split.restype = ci
         L.vpx_conv2d_ex_fwd_from_split.argtypes = [ctypes.POINTER(ConvDesc), vp, ll, ll, ci, vp, vp, vp, vp, ci, vp, sz, vp]
+        L.vpx_layernorm_workspace_bytes.restype = sz
+        L.vpx_layernorm_workspace_bytes.argtypes = [ci]
+        L.vpx_layernorm_fwd.restype = ci
+        L.vpx_layernorm_fwd.argtypes = [vp] * 6 + [ci, ll, vp, sz, vp]
+        L.vpx_layernorm_bwd.restype = ci
+        L.vpx_layernorm_bwd.argtypes = [vp] * 7 + [ci, ci, ci, vp, sz, vp]
         L.vpx_mse_loss_workspace_bytes.restype = sz
         L.vpx_mse_loss_workspace_bytes.argtypes = []
         L.vpx_mse_loss.restype = ctypes.c_int

@@ -3,7 +3,7 @@
 // is normalised on its own before the gates add them.
 // All tensors NHWC: a sample is one contiguous run of n = HW*C floats; gamma/beta are [HW, C] (transposed once per call
 // from the reference's [C,H,W]).
-#include "vpx_internal.h"
+#include "vpx_host.h"
 
 namespace vpx {
 
@@ -216,3 +216,37 @@ hipError_t launch_st_ln_out(const float* o_pre, const float* oc, const float* lc
 }
 
 }  // namespace vpx
+
+
+// ---- standalone LayerNorm([C,H,W]) over NHWC samples (the action-conditional ST-LSTM cell normalises each of its biased
+//      convolutions on its own: predrnn.py:102-136) -----------------------------------------------------------------------
+extern "C" {
+
+size_t vpx_layernorm_workspace_bytes(int B) {
+    if (B < 1) return 0;
+    return vpx::align256((size_t)B * vpx::LN_CHUNKS * 2 * sizeof(double)) + vpx::align256((size_t)B * 2 * sizeof(float)) + 256;
+}
+
+int vpx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* xhat, float* stats, int B, long long n,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace vpx;
+    if (!x || !gamma || !beta || !y || !stats || B < 1 || n < 1) { set_error("vpx_layernorm_fwd: bad argument"); return VPX_ERR_ARG; }
+    if (!workspace || workspace_bytes < vpx_layernorm_workspace_bytes(B)) { set_error("vpx_layernorm_fwd: workspace too small"); return VPX_ERR_WORKSPACE; }
+    double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    VPX_CHECK_HIP(launch_layernorm_fwd(x, gamma, beta, y, xhat, stats, partial, B, n, (hipStream_t)stream));
+    return VPX_OK;
+}
+
+int vpx_layernorm_bwd(const float* dy, const float* xhat, const float* stats, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                      int B, int HW, int C, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace vpx;
+    if (!dy || !xhat || !stats || !gamma || !dx || !dgamma || !dbeta || B < 1 || HW < 1 || C < 1) { set_error("vpx_layernorm_bwd: bad argument"); return VPX_ERR_ARG; }
+    if (!workspace || workspace_bytes < vpx_layernorm_workspace_bytes(B)) { set_error("vpx_layernorm_bwd: workspace too small"); return VPX_ERR_WORKSPACE; }
+    char* w = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    double* partial = reinterpret_cast<double*>(w);
+    float* sums = reinterpret_cast<float*>(w + align256((size_t)B * LN_CHUNKS * 2 * sizeof(double)));
+    VPX_CHECK_HIP(launch_layernorm_bwd(dy, C, 0, nullptr, xhat, stats, gamma, B, HW, C, partial, sums, dx, dgamma, dbeta, (hipStream_t)stream));
+    return VPX_OK;
+}
+
+}  // extern "C"

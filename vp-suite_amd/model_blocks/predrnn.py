@@ -96,7 +96,7 @@ class ActionConditionalSpatioTemporalLSTMCell(VPModelBlock):
     def _conv(self, seq, t):
         y = ops.conv2d_same(t, seq[0].weight, seq[0].bias, precision=self.precision)
         if self.layer_norm:
-            y = F.layer_norm(y, seq[1].normalized_shape, seq[1].weight, seq[1].bias, seq[1].eps)
+            y = ops.layer_norm_chw(y, seq[1].weight, seq[1].bias, seq[1].eps)   # library LayerNorm kernels (csrc/layernorm.hip)
         return y
 
     def forward(self, x_t, h_t, c_t, m_t, a_t):

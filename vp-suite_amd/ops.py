@@ -773,6 +773,56 @@ def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=Non
     return _STLSTMStepFn.apply(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, PRECISIONS[precision], need_grad, wsholder, *ln)
 
 
+class _LayerNormCHWFn(torch.autograd.Function):
+    """nn.LayerNorm([C,H,W]) on a [B,C,H,W] tensor (channels-last memory) through the library's LayerNorm kernels (double-precision
+    statistics over fixed chunks, explicit backward) — the action-conditional ST-LSTM cell's per-convolution normalisation
+    (predrnn.py:105-135)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_gpu(x, "layer_norm_chw")
+        xs = to_channels_last(x)
+        B, C, H, Wd = xs.shape
+        g = _cached_channels_last(weight[None]) if weight.dim() == 3 else to_channels_last(weight)
+        b = _cached_channels_last(bias[None]) if bias.dim() == 3 else to_channels_last(bias)
+        L = _lib.lib()
+        ws_bytes = L.vpx_layernorm_workspace_bytes(B)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        y = new_channels_last((B, C, H, Wd), x.device)
+        need = any(ctx.needs_input_grad)
+        xhat = new_channels_last((B, C, H, Wd), x.device) if need else None
+        stats = torch.empty(B, 2, device=x.device)
+        check(L.vpx_layernorm_fwd(ptr(xs), ptr(g), ptr(b), ptr(y), ptr(xhat), ptr(stats), B, C * H * Wd, ptr(ws), ws_bytes, _stream()),
+              "vpx_layernorm_fwd")
+        if need:
+            ctx.save_for_backward(xhat, stats, g)
+            ctx.wshape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        _sync_determinism()
+        xhat, stats, g = ctx.saved_tensors
+        B, C, H, Wd = xhat.shape
+        dys = to_channels_last(dy)
+        L = _lib.lib()
+        ws_bytes = L.vpx_layernorm_workspace_bytes(B)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+        dx = new_channels_last((B, C, H, Wd), dy.device)
+        dg = new_channels_last((1, C, H, Wd), dy.device)
+        db = new_channels_last((1, C, H, Wd), dy.device)
+        check(L.vpx_layernorm_bwd(ptr(dys), ptr(xhat), ptr(stats), ptr(g), ptr(dx), ptr(dg), ptr(db), B, H * Wd, C, ptr(ws), ws_bytes,
+                                  _stream()), "vpx_layernorm_bwd")
+        return dx, dg.reshape(ctx.wshape), db.reshape(ctx.wshape)
+
+
+def layer_norm_chw(x, weight, bias, eps=1e-5):
+    """F.layer_norm(x, [C,H,W], weight, bias, eps) for a [B,C,H,W] tensor, on the library's kernels (eps is fixed at 1e-5)."""
+    if abs(float(eps) - 1e-5) > 1e-12:
+        raise ValueError("layer_norm_chw: the library's LayerNorm kernels use eps = 1e-5 (nn.LayerNorm's default)")
+    return _LayerNormCHWFn.apply(x, weight, bias)
+
+
 class _ACSTGatesFn(torch.autograd.Function):
     """(c_new, m_new, delta_c, delta_m, o_pre, mem) from the conv outputs of the (action-conditional) ST-LSTM cell
     (predrnn.py:143-164): conv_h(h) * conv_a(a) product, both gate groups and the state updates in ONE HIP pass,
