@@ -48,7 +48,11 @@ enum { VPX_LAYOUT_NHWC = 0, VPX_LAYOUT_NCHW = 1 };
 enum { VPX_PREC_F32 = 0    /* exact fp32: v_mfma_f32_32x32x2_f32, fp32 operands + fp32 accumulate */,
        VPX_PREC_BF16X3 = 1 /* split bf16 (hi/lo) operands, 3 bf16 MFMAs per product, fp32 accumulate (~fp32 accuracy) */,
        VPX_PREC_BF16 = 2   /* bf16 operands, fp32 accumulate, fp32 state and I/O */ };
-enum { VPX_FLAG_X_SPLIT = 4 /* ConvLSTM forward: `x` holds the input sequence in the split-bf16 operand format (below) instead of
+enum { VPX_FLAG_OUT_SPLIT = 8 /* ConvLSTM forward (inference): `out` receives the output sequence in the split-bf16 operand format
+                                 ([B][T][H*W][Ch] split-encoded, the byte size of the fp32 tensor it replaces) and NO fp32 copy is written
+                                 — for a consumer that reads the operand format (vpx_conv2d_ex_fwd_from_split); hT, if not NULL, is
+                                 still fp32. Only where vpx_convlstm_writes_split_output() says so, and not with SAVE_FOR_BWD */,
+       VPX_FLAG_X_SPLIT = 4 /* ConvLSTM forward: `x` holds the input sequence in the split-bf16 operand format (below) instead of
                               fp32 — only where vpx_convlstm_takes_split_input() says so; saves the conversion pass */,
        VPX_FLAG_SAVE_FOR_BWD = 1 /* forward fills `reserve` (gate activations + cell states per step) */,
        VPX_FLAG_WEIGHTS_PACKED = 2 /* ConvLSTM forward: `workspace` still holds the weight packs of a previous forward call with the SAME
@@ -106,6 +110,7 @@ size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d); /* scratch, con
  * kernels multiply. Producers: vpx_conv2d_ex_fwd_split (the stage glue feeding a recurrent block). 1 = this descriptor's
  * forward consumes x in that form when VPX_FLAG_X_SPLIT is set (second-generation cell kernel, inference), 0 = fp32 only. */
 int vpx_convlstm_takes_split_input(const vpx_convlstm_desc* d);
+int vpx_convlstm_writes_split_output(const vpx_convlstm_desc* d);   /* 1 = VPX_FLAG_OUT_SPLIT is available for this descriptor */
 size_t vpx_convlstm_reserve_bytes(const vpx_convlstm_desc* d);   /* saved-for-backward, 0 without SAVE_FOR_BWD */
 
 /* x may be NULL (all-zero input: conv_lstm_hzzone.py:54-56), h0/c0 may be NULL (zero state: :40-45), bias may be NULL,

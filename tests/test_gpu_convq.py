@@ -52,3 +52,26 @@ def test_glue_layer_on_split_input_vs_torch(vpx, tag):
     # second call: packed weights re-used from the layer's workspace
     y2, _, _ = vpx.ops.conv2d_ex_from_split(xbuf, (N, Ci, H, W), w, b, s, p, tr, slope, "bf16x3")
     assert torch.equal(y, y2)
+
+
+def test_convlstm_block_hands_its_output_over_in_operand_format(vpx):
+    """VPX_FLAG_OUT_SPLIT: the second-generation cell writes its output sequence ONLY in the split-bf16 operand format ([B][T][HW][Ch]);
+    decoded, it equals the fp32 sequence of a normal call bit for bit (same kernel, same arithmetic), h_T / c_T come out in fp32."""
+    Cin, Ch, H, W, B, T = 64, 96, 32, 32, 32, 3
+    x = seeded_rand((B, T, Cin, H, W), name_seed("osplit.x")).cuda()
+    Wt = seeded_randn((4 * Ch, Cin + Ch, 3, 3), name_seed("osplit.W"), 1.0 / np.sqrt((Cin + Ch) * 9.0)).cuda()
+    b = seeded_randn((4 * Ch,), name_seed("osplit.b"), 0.1).cuda()
+    peep = [seeded_randn((1, Ch, H, W), name_seed(f"osplit.p{i}"), 0.1).cuda() for i in range(3)]
+    assert vpx.ops.convlstm_writes_split(B, T, Cin, Ch, H, W, 3, 0, "bf16x3")
+    with torch.no_grad():
+        out, hT, cT = vpx.ops.convlstm_seq(x, None, None, Wt, b, *peep, seq_len=T, in_channels=Cin, precision="bf16x3")
+        sp, hT2, cT2 = vpx.ops.convlstm_seq(x, None, None, Wt, b, *peep, seq_len=T, in_channels=Cin, precision="bf16x3", out_split=True)
+    assert isinstance(sp, vpx.ops.SplitActivation) and sp.shape == (B, T, Ch, H, W)
+    assert torch.equal(hT2, hT) and torch.equal(cT2, cT)
+    want, _ = vpx.ops.split_convert(out)          # [B, T, H, W, C/8, 2, 8] bf16 of the fp32 sequence
+    assert torch.equal(sp.buf.view(torch.int32), want.view(torch.int32))
+    # small grids take other kernels: no split output there, and asking for it is an error
+    assert not vpx.ops.convlstm_writes_split(2, T, Cin, Ch, 16, 16, 3, 0, "bf16x3")
+    with pytest.raises(Exception):
+        vpx.ops.convlstm_seq(x[:2, :, :, :16, :16], None, None, Wt, b, *[p[..., :16, :16] for p in peep], seq_len=T, in_channels=Cin,
+                             precision="bf16x3", out_split=True)

@@ -17,6 +17,7 @@ PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 FLAG_SAVE_FOR_BWD = 1
 FLAG_WEIGHTS_PACKED = 2
 FLAG_X_SPLIT = 4
+FLAG_OUT_SPLIT = 8
 
 OPT_CELL2 = 1
 OPT_CELL3 = 2
@@ -24,7 +25,7 @@ OPT_MFMA_SHAPE = 3   # 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_f32_16x16x32_bf16 
 
 EXPORTED_SYMBOLS = [
     "vpx_version", "vpx_last_error", "vpx_set_deterministic", "vpx_set_option", "vpx_option_epoch",
-    "vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes", "vpx_convlstm_takes_split_input", "vpx_convlstm_seq_fwd",
+    "vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes", "vpx_convlstm_takes_split_input", "vpx_convlstm_writes_split_output", "vpx_convlstm_seq_fwd",
     "vpx_convlstm_seq_bwd",
     "vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes", "vpx_stlstm_step_fwd", "vpx_stlstm_step_bwd",
     "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
@@ -100,6 +101,8 @@ def lib():
             getattr(L, name).argtypes = [ctypes.POINTER(STLSTMDesc)]
         L.vpx_convlstm_takes_split_input.restype = ctypes.c_int
         L.vpx_convlstm_takes_split_input.argtypes = [ctypes.POINTER(ConvLSTMDesc)]
+        L.vpx_convlstm_writes_split_output.restype = ctypes.c_int
+        L.vpx_convlstm_writes_split_output.argtypes = [ctypes.POINTER(ConvLSTMDesc)]
         L.vpx_convlstm_seq_fwd.restype = ctypes.c_int
         L.vpx_convlstm_seq_fwd.argtypes = [ctypes.POINTER(ConvLSTMDesc)] + [vp] * 11 + [vp, sz, vp, sz, vp]
         L.vpx_convlstm_seq_bwd.restype = ctypes.c_int

@@ -159,7 +159,7 @@ struct Cell2Epi {
         const size_t img = (size_t)b * H * W;                       // wave-uniform
         const float* const cin_b = a.c_in ? a.c_in + img * Ch : nullptr;
         float* const cout_b = a.c_out + img * Ch;
-        float* const hout_b = a.h_out + (size_t)b * a.h_bstride;
+        float* const hout_b = a.h_out ? a.h_out + (size_t)b * a.h_bstride : nullptr;
         float* const g0 = a.gates ? a.gates + img * 4 * Ch : nullptr;
         char* const hsp_b = h_sp ? h_sp + (size_t)b * h_sp_bstride : nullptr;
         const int che = ch & ~1;
@@ -201,7 +201,7 @@ struct Cell2Epi {
                 const float o_ = sigmoid_f(ao);
                 const float hn = o_ * tanh_f(cn);
                 cout_b[eo[u]] = cn;
-                hout_b[eo[u]] = hn;
+                if (a.h_out) hout_b[eo[u]] = hn;
                 if (g0) {
                     const unsigned go = 4u * po[u] + (unsigned)ch;
                     g0[go] = i_;
@@ -278,7 +278,7 @@ struct Cell2Epi {
         }
         const size_t img = (size_t)b * H * W;
         float* const cout_b = a.c_out + img * Ch;
-        float* const hout_b = a.h_out + (size_t)b * a.h_bstride;
+        float* const hout_b = a.h_out ? a.h_out + (size_t)b * a.h_bstride : nullptr;
         float* const g0 = a.gates ? a.gates + img * 4 * Ch : nullptr;
         char* const hsp_b = h_sp ? h_sp + (size_t)b * h_sp_bstride : nullptr;
         const unsigned sp_off = (ch >> 3) * 32 + (ch & 7) * 2;   // hi quad of channels ch..ch+3; the lo quad sits 16 bytes further
@@ -302,7 +302,7 @@ struct Cell2Epi {
             }
             const unsigned eo = v.eo[k];
             *reinterpret_cast<f32x4*>(cout_b + eo) = cn;
-            *reinterpret_cast<f32x4*>(hout_b + eo) = hn;
+            if (a.h_out) *reinterpret_cast<f32x4*>(hout_b + eo) = hn;   // (null: the consumer reads the split copy below — VPX_FLAG_OUT_SPLIT)
             if (g0) {
                 const unsigned go = 4u * (eo - ch) + ch;
                 *reinterpret_cast<f32x4*>(g0 + go) = i4;

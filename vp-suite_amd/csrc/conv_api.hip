@@ -182,7 +182,7 @@ static int ex_mw(const vpx_conv_desc* d, int Ht, int Wt, int sd) {
 // one launch: tile space Ht x Wt, kernel taps th x tw, halo origin (oy, ox), input step `sd`
 int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
               const ExGeo& g, int Ht, int Wt, int th, int tw, int sd, int oy, int ox, const int* tapmap, bool flip,
-              int omap, int oys, int oyo, int oxs, int oxo, float* wpk, char* y_split = nullptr) {
+              int omap, int oys, int oyo, int oxs, int oxo, float* wpk, char* y_split = nullptr, bool x_split = false) {
     const int prec = d->precision;
     ConvPlan P{};
     int chunks = 0;
@@ -207,7 +207,7 @@ int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const 
     set_plan_tiles(P, mw);
     P.stride = sd; P.use_org = 1; P.org_y = oy; P.org_x = ox; P.Hin = d->H; P.Win = d->W;
     P.nseg = 1;
-    P.seg[0] = ConvSeg{x, (long long)d->H * d->W * d->Ci, d->Ci, d->Ci};
+    P.seg[0] = ConvSeg{x, (long long)d->H * d->W * d->Ci, d->Ci, d->Ci, x_split ? 1 : 0, 0};
     P.chunks_total = chunks;
     P.a_bytes = conv_a_bytes(P.stage, P.nstage, th, tw, mw, sd);
     P.wpk = wpk;
@@ -222,7 +222,7 @@ int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const 
 }
 
 int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const float* w, const float* bias, float* y, float* wpk,
-               hipStream_t stream, char* y_split = nullptr);
+               hipStream_t stream, char* y_split = nullptr, bool x_split = false);
 bool exq_problem(const vpx_conv_desc* d, const ExGeo& g, ConvQProblem& pr);
 int ex_forward_q(const vpx_conv_desc* d, const ExGeo& g, const char* x_sp, long long x_bstride, long long x_tstride, int x_nT,
                  const float* w, const float* bias, float* y, char* y_sp, char* wpk, bool weights_packed, hipStream_t stream);
@@ -289,19 +289,36 @@ int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float*
     return ex_forward(d, g, x, w, bias, y, wpk, (hipStream_t)stream_, reinterpret_cast<char*>(y_split));
 }
 
+// Which kernel takes a layer on split input (measured at the bench shapes, tools/ab_glue.py): the schedule-driven K = 32 kernel
+// where its 32-row tiles fill (tile space >= 32 rows) and the layer has >= 64 output channels (stride-2 convolution 64 -> 64 at
+// 64x64: 0.73 -> 0.64 ms, stride-2 transposed 4x4 at 32x32: 1.8 -> 1.7 ms per 1280 frames); else the first-generation kernel,
+// which stages the split tensor without its hi / lo conversion. VPX_CONVQ=0 / 2: never / wherever it applies.
+static bool exq_preferred(const vpx_conv_desc* d, const ExGeo& g, ConvQProblem& pr) {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("VPX_CONVQ"); mode = e ? atoi(e) : 1; }
+    if (mode == 0 || !exq_problem(d, g, pr) || convq_wpk_bytes(pr) == 0) return false;
+    if (mode == 2) return true;
+    return pr.H >= 32 && d->Co >= 64;
+}
+static bool ex_split_gen1_ok(const vpx_conv_desc* d) {
+    return d->precision != VPX_PREC_F32 && (d->Ci & 7) == 0;
+}
+
 int vpx_conv2d_ex_takes_split(const vpx_conv_desc* d) {
     ExGeo g;
     static thread_local ConvQProblem pr;
-    if (ex_check(d, g) != VPX_OK || !exq_problem(d, g, pr)) return 0;
-    return convq_wpk_bytes(pr) > 0 ? 1 : 0;
+    if (ex_check(d, g) != VPX_OK) return 0;
+    return (exq_preferred(d, g, pr) || ex_split_gen1_ok(d)) ? 1 : 0;
 }
 
 size_t vpx_conv2d_ex_split_workspace_bytes(const vpx_conv_desc* d) {
     ExGeo g;
     static thread_local ConvQProblem pr;
-    if (ex_check(d, g) != VPX_OK || !exq_problem(d, g, pr)) return 0;
-    const size_t b = convq_wpk_bytes(pr);
-    return b ? align256(b) + 512 : 0;
+    if (ex_check(d, g) != VPX_OK) return 0;
+    size_t b = 0;
+    if (exq_preferred(d, g, pr)) b = align256(convq_wpk_bytes(pr)) + 512;
+    if (ex_split_gen1_ok(d)) { const size_t b1 = align256(ex_wpk_floats(d) * 4) + 512; if (b1 > b) b = b1; }
+    return b;
 }
 
 int vpx_conv2d_ex_fwd_from_split(const vpx_conv_desc* d, const void* x_split, long long x_bstride, long long x_tstride, int x_nT,
@@ -316,9 +333,15 @@ int vpx_conv2d_ex_fwd_from_split(const vpx_conv_desc* d, const void* x_split, lo
     if (!need) { set_error("vpx_conv2d_ex_fwd_from_split: layer not implemented on split input (vpx_conv2d_ex_takes_split)"); return VPX_ERR_UNSUPPORTED; }
     if (!workspace || workspace_bytes < need) { set_error("vpx_conv2d_ex_fwd_from_split: workspace too small"); return VPX_ERR_WORKSPACE; }
     char* wpk = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    if (x_bstride == 0) x_bstride = (long long)d->H * d->W * d->Ci * 4;
-    return ex_forward_q(d, g, reinterpret_cast<const char*>(x_split), x_bstride, x_tstride, x_nT, w, bias, y, reinterpret_cast<char*>(y_split),
-                        wpk, weights_packed != 0, (hipStream_t)stream_);
+    const long long dense = (long long)d->H * d->W * d->Ci * 4;
+    if (x_bstride == 0) x_bstride = dense;
+    static thread_local ConvQProblem pr;
+    if (exq_preferred(d, g, pr))
+        return ex_forward_q(d, g, reinterpret_cast<const char*>(x_split), x_bstride, x_tstride, x_nT, w, bias, y, reinterpret_cast<char*>(y_split),
+                            wpk, weights_packed != 0, (hipStream_t)stream_);
+    if (x_nT > 1 || x_bstride != dense) { set_error("vpx_conv2d_ex_fwd_from_split: this layer needs a dense batch of split images"); return VPX_ERR_UNSUPPORTED; }
+    return ex_forward(d, g, reinterpret_cast<const float*>(x_split), w, bias, y, reinterpret_cast<float*>(wpk), (hipStream_t)stream_,
+                      reinterpret_cast<char*>(y_split), true);
 }
 
 }  // extern "C"
@@ -326,9 +349,10 @@ int vpx_conv2d_ex_fwd_from_split(const vpx_conv_desc* d, const void* x_split, lo
 namespace {
 
 int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const float* w, const float* bias, float* y, float* wpk,
-               hipStream_t stream, char* y_split) {
+               hipStream_t stream, char* y_split, bool x_split) {
     int rc;
-    if (const int kind = conv_small_kind(d)) {   // few-channel layers: streaming kernels (conv_small.hip)
+    const int small_kind = x_split ? 0 : conv_small_kind(d);   // (the streaming kernels read fp32)
+    if (const int kind = small_kind) {   // few-channel layers: streaming kernels (conv_small.hip)
         if (kind != 2 || !y_split) {
             VPX_CHECK_HIP(launch_conv_small(d, kind, x, w, bias, y, y_split, stream));
             return VPX_OK;
@@ -336,10 +360,10 @@ int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const flo
     }
     if (!d->transposed)  // y[o] = sum_k x[o*s - pad + k] w[k]
         return ex_launch(stream, d, x, w, bias, y, g, g.Ho, g.Wo, d->kh, d->kw, d->stride, -d->pad, -d->pad, nullptr, false,
-                         0, 1, 0, 1, 0, wpk, y_split);
+                         0, 1, 0, 1, 0, wpk, y_split, x_split);
     if (d->stride == 1)  // y[o] = sum_k x[o + pad - k] w[k]  ==  correlation with the flipped kernel, origin -(k-1-pad)
         return ex_launch(stream, d, x, w, bias, y, g, g.Ho, g.Wo, d->kh, d->kw, 1, -(d->kh - 1 - d->pad), -(d->kw - 1 - d->pad),
-                         nullptr, true, 0, 1, 0, 1, 0, wpk, y_split);
+                         nullptr, true, 0, 1, 0, 1, 0, wpk, y_split, x_split);
     // stride 2: output phase (py, px) is a stride-1 correlation of x with the taps k == (p + pad) mod 2 of that axis
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
@@ -358,7 +382,7 @@ int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const flo
                 for (int tx = 0; tx < ntx; ++tx)
                     tapmap[ty * ntx + tx] = (ky0 + 2 * (nty - 1 - ty)) * d->kw + (kx0 + 2 * (ntx - 1 - tx));
             rc = ex_launch(stream, d, x, w, bias, y, g, Ht, Wt, nty, ntx, 1, basey - (nty - 1), basex - (ntx - 1), tapmap, false,
-                           1, 2, py, 2, px, wpk, y_split);
+                           1, 2, py, 2, px, wpk, y_split, x_split);
             if (rc != VPX_OK) return rc;
         }
     return VPX_OK;

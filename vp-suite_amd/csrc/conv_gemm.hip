@@ -293,11 +293,24 @@ struct EpiPlain {
 // cn lo-bf16; a weight row is one chunk of one output channel: KC fp32, or KC hi followed by KC lo.
 // ---------------------------------------------------------------------------------------------------------------
 
+// 4 channels c .. c+3 (c % 4 == 0) of a pixel row: fp32 tensor -> the values; split-format tensor -> 8 bytes of hi halves + 8 of lo
+__device__ __forceinline__ f32x4 stage_load(const float* pixel_row, int c, const bool split) {
+    if (!split) return *reinterpret_cast<const f32x4*>(pixel_row + c);
+    const char* p = reinterpret_cast<const char*>(pixel_row) + (c >> 3) * 32 + (c & 7) * 2;
+    const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + 16);
+    return __builtin_bit_cast(f32x4, uint4{h.x, h.y, l.x, l.y});
+}
+
 // one 4-channel vector of the activation halo tile -> LDS (fp32 as is; bf16 modes: hi half-row, then lo half-row)
+// (split source: `val` already holds the 4 hi halves in its first 8 bytes and the 4 lo halves in the last 8)
 template <int MODE>
-__device__ __forceinline__ void stage_store(char* dst, int lo_off, const f32x4 val) {
+__device__ __forceinline__ void stage_store(char* dst, int lo_off, const f32x4 val, const bool split = false) {
     if constexpr (MODE == 0) {
         *reinterpret_cast<f32x4*>(dst) = val;
+    } else if (split) {
+        const uint4 u = __builtin_bit_cast(uint4, val);
+        *reinterpret_cast<uint2*>(dst) = uint2{u.x, u.y};
+        *reinterpret_cast<uint2*>(dst + lo_off) = uint2{u.z, u.w};
     } else {
         unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
         split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);
@@ -443,15 +456,15 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
                     int hy = pos / halo_w, hx = pos - hy * halo_w;
                     const int c = st.c0 + c4 * 4;
                     const bool c_ok = c < sg.C && !DBGBIT(2);
-                    const float* srcc = src + c;
+                    const bool spl = MODE != 0 && sg.split != 0;
                     char* dstc = A_lds + (MODE == 0 ? c4 * 16 : c4 * 8);
                     if (DBGBIT(16)) {
                     for (; pos < npos; pos += dpos) {
                         const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
                         f32x4 val = {0.f, 0.f, 0.f, 0.f};
                         if (c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win)
-                            val = *reinterpret_cast<const f32x4*>(srcc + ((size_t)gy * Win + gx) * ld);
-                        stage_store<MODE>(dstc + pos * arow, st.cn * 2, val);
+                            val = stage_load(src + ((size_t)gy * Win + gx) * ld, c, spl);
+                        stage_store<MODE>(dstc + pos * arow, st.cn * 2, val, spl);
                         hx += dhx; hy += dhy;
                         if (hx >= halo_w) { hx -= halo_w; ++hy; }
                     }
@@ -466,13 +479,13 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
                             const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
                             val[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                             if (pos + u * dpos < npos && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win)
-                                val[u] = *reinterpret_cast<const f32x4*>(srcc + ((size_t)gy * Win + gx) * ld);
+                                val[u] = stage_load(src + ((size_t)gy * Win + gx) * ld, c, spl);
                             hx += dhx; hy += dhy;
                             if (hx >= halo_w) { hx -= halo_w; ++hy; }
                         }
 #pragma unroll
                         for (int u = 0; u < AU; ++u)
-                            if (pos + u * dpos < npos) stage_store<MODE>(dstc + (pos + u * dpos) * arow, st.cn * 2, val[u]);
+                            if (pos + u * dpos < npos) stage_store<MODE>(dstc + (pos + u * dpos) * arow, st.cn * 2, val[u], spl);
                     }
                     }
                 } else {
@@ -483,10 +496,13 @@ __device__ __forceinline__ void conv_body(const ConvPlan& P, const Epi& epi, con
                         const int gy = y0 * sd - ph + hy, gx = x0 * sd - pw + hx;
                         const int c = st.c0 + c4 * 4;
                         f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                        const bool spl = MODE != 0 && sg.split != 0;
                         if (gy >= 0 && gy < Hin && gx >= 0 && gx < Win && c < sg.C && !DBGBIT(2))
-                            val = *reinterpret_cast<const f32x4*>(src + ((size_t)gy * Win + gx) * ld + c);
+                            val = stage_load(src + ((size_t)gy * Win + gx) * ld, c, spl);
                         if constexpr (MODE == 0) {
                             *reinterpret_cast<f32x4*>(A_lds + pos * arow + c4 * 16) = val;
+                        } else if (spl) {
+                            stage_store<MODE>(A_lds + pos * arow + c4 * 8, st.cn * 2, val, true);
                         } else {
                             unsigned short h0, h1, h2, h3, l0, l1, l2, l3;
                             split_bf16(val[0], h0, l0); split_bf16(val[1], h1, l1);

@@ -99,6 +99,10 @@ int vpx_convlstm_takes_split_input(const vpx_convlstm_desc* d) {
     return (L.v2 && d->layout == VPX_LAYOUT_NHWC && !(d->flags & VPX_FLAG_SAVE_FOR_BWD)) ? 1 : 0;
 }
 
+int vpx_convlstm_writes_split_output(const vpx_convlstm_desc* d) {   // the second-generation cell writes h_t in operand format anyway
+    return vpx_convlstm_takes_split_input(d);
+}
+
 size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
     ConvLSTMLayout L;
     if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
@@ -138,6 +142,11 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     const bool x_split = (d->flags & VPX_FLAG_X_SPLIT) != 0;
     // the caller's workspace still holds every weight pack of an earlier call with the same descriptor, weights and operand set
     const bool wp = (d->flags & VPX_FLAG_WEIGHTS_PACKED) != 0;
+    const bool out_split = (d->flags & VPX_FLAG_OUT_SPLIT) != 0;
+    if (out_split && !vpx_convlstm_writes_split_output(d)) {
+        set_error("vpx_convlstm_seq_fwd: VPX_FLAG_OUT_SPLIT given, but this descriptor's forward writes fp32 only (vpx_convlstm_writes_split_output)");
+        return VPX_ERR_ARG;
+    }
     if (x_split && !vpx_convlstm_takes_split_input(d)) {
         set_error("vpx_convlstm_seq_fwd: VPX_FLAG_X_SPLIT given, but this descriptor's forward takes fp32 input (vpx_convlstm_takes_split_input)");
         return VPX_ERR_ARG;
@@ -373,10 +382,19 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             P2.chunks_total = 3 * ((Cin + Ch) / 16);
             P2.wpk = wpk2;
             P2.qform = qform;
-            auto h_slot = [&](int tt) { return h_sp_all ? h_sp_all + (size_t)tt * L.n_state * 4 : h_ring[tt & 1]; };
+            // h_t in operand format: the reserve (training), the caller's `out` buffer laid out [B][T][HW][Ch] (OUT_SPLIT), or a two-slot ring
+            const long long hsp_bs = out_split ? (long long)((size_t)T * HW * Ch * 4) : (long long)(HW * Ch * 4);
+            auto h_slot = [&](int tt) -> char* {
+                if (out_split) return reinterpret_cast<char*>(outn) + (size_t)tt * HW * Ch * 4;
+                return h_sp_all ? h_sp_all + (size_t)tt * L.n_state * 4 : h_ring[tt & 1];
+            };
+            if (out_split) {   // no fp32 sequence; the last step still hands h_T out in fp32 where the caller wants it
+                ea.h_out = (t == T - 1) ? hTn : nullptr;
+                ea.h_bstride = (long long)(HW * Ch);
+            }
             const char* hprev_sp = (t == 0) ? (h0n ? h0_sp : nullptr) : h_slot(t - 1);
             P2.seg[0] = Cell2Seg{xn ? x_sp + (size_t)t * HW * Cin * 4 : nullptr, (long long)((size_t)T * HW * Cin * 4), Cin, 0};
-            P2.seg[1] = Cell2Seg{hprev_sp, (long long)(HW * Ch * 4), Ch, 0};
+            P2.seg[1] = Cell2Seg{hprev_sp, (t == 0) ? (long long)(HW * Ch * 4) : hsp_bs, Ch, 0};
             P2.nx = xn ? Cin / 16 : 0;
             P2.nh = hprev_sp ? Ch / 16 : 0;
             P2.hs_off = Cin / 16;
@@ -385,7 +403,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
                 P2.wpk = pack_of((P2.nx ? 1 : 0) | (P2.nh ? 2 : 0));
             }
             // the split copy of h_t feeds step t+1 only: the last step does not need it
-            VPX_CHECK_HIP(launch_cell2(P2, ea, (t + 1 < T) ? h_slot(t) : nullptr, (long long)(HW * Ch * 4), stream));
+            VPX_CHECK_HIP(launch_cell2(P2, ea, (t + 1 < T || out_split) ? h_slot(t) : nullptr, hsp_bs, stream));
         } else if (hoist) {
             // the step contracts only h_{t-1} and accumulates (atomics when K is split) into its slice of the hoisted input
             // projection; the pointwise kernel reads that slice (batch stride T*HW*4Ch) and writes gates / c / h
@@ -429,7 +447,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     // ---- final states ----
     if (cTn && save)
         VPX_CHECK_HIP(hipMemcpyAsync(cTn, cs_all + (size_t)(T - 1) * L.n_state, L.n_state * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    if (hTn)
+    if (hTn && !out_split)
         VPX_CHECK_HIP(hipMemcpy2DAsync(hTn, HW * Ch * sizeof(float), outn + (size_t)(T - 1) * HW * Ch,
                                        (size_t)T * HW * Ch * sizeof(float), HW * Ch * sizeof(float), B,
                                        hipMemcpyDeviceToDevice, stream));

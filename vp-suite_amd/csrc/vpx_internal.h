@@ -30,6 +30,7 @@ struct ConvSeg {          // one activation source, NHWC [B][H][W][C] with arbit
     long long bstride;    // elements between consecutive batch items
     int C;                // channels taken from each pixel row
     int ld;               // elements between consecutive pixels (0 = C): lets a segment be a channel slice of a wider tensor
+    int split, _p;        // 1: the tensor is in the split-bf16 operand format (same strides in 4-byte units; bf16 modes, C % 8 == 0): staged without conversion
 };
 
 struct ConvStage {        // one K-stage: channels [c0, c0+cn) of segment `seg`, all taps

@@ -66,9 +66,16 @@ class ConvLSTM(VPModelBlock):
         return (not torch.is_grad_enabled()) and ops.convlstm_takes_split(batch, seq_len, self.in_c, self.enc_c, self.state_h,
                                                                          self.state_w, k, _lib.GATE_IFGO, self.precision)
 
-    def forward(self, inputs, states, seq_len):
+    def writes_split_output(self, batch, seq_len):
+        """True when forward(..., out_split=True), in inference, can hand its output sequence out as an `ops.SplitActivation`
+        (no fp32 copy is written; for consumers that read the operand format)."""
+        k = self._conv.kernel_size[0]
+        return (not torch.is_grad_enabled()) and ops.convlstm_writes_split(batch, seq_len, self.in_c, self.enc_c, self.state_h,
+                                                                           self.state_w, k, _lib.GATE_IFGO, self.precision)
+
+    def forward(self, inputs, states, seq_len, out_split=False):
         """inputs [B,T,Cin,H,W] (or an ops.SplitActivation of that shape) or None (zero input every step); states (h, c) or
-        None (zero states)."""
+        None (zero states). out_split: see writes_split_output (not part of the reference's signature; default off)."""
         if inputs is None and states is None:
             raise ValueError("inputs and states should not be all none")
         if states is None:
@@ -78,5 +85,5 @@ class ConvLSTM(VPModelBlock):
             h0, c0 = states
         out, hT, cT = ops.convlstm_seq(inputs, h0, c0, self._conv.weight, self._conv.bias, self.Wci, self.Wcf, self.Wco,
                                        seq_len=seq_len, in_channels=self.in_c, gate_order=_lib.GATE_IFGO,
-                                       precision=self.precision)
+                                       precision=self.precision, out_split=out_split)
         return out, (hT, cT)

@@ -43,32 +43,65 @@ def _stage(spec: "OrderedDict[str, list]") -> nn.Sequential:
     return nn.Sequential(OrderedDict(layers))
 
 
-def _run_stage(subnet: nn.Sequential, x: torch.Tensor, precision: str, split_last: bool = False):
-    """Executes a stage built by _stage() on a channels-last [N,C,H,W] batch. Conv2d / ConvTranspose2d layers (with a
-    directly following LeakyReLU fused in) run through libvpx_hip's vpx_conv2d_ex_fwd when the configuration is one it
-    implements; every other layer (pool, ReLU, exotic strides) runs as the stock GPU module."""
+def _conv_cfg(m):
+    """(kh, kw, stride, pad, transposed) of a Conv2d / ConvTranspose2d the library's glue entry points can take, else None."""
+    if not isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        return None
+    tr = isinstance(m, nn.ConvTranspose2d)
+    kh, kw = m.kernel_size
+    simple = (m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.dilation == (1, 1)
+              and m.groups == 1 and (not tr or m.output_padding == (0, 0)))
+    if simple and ops.glue_supported(kh, kw, m.stride[0], m.padding[0], tr):
+        return kh, kw, m.stride[0], m.padding[0], tr
+    return None
+
+
+def _stage_takes_split(subnet: nn.Sequential, n, c, h, w, precision):
+    """True when the stage's first layer can read its input in the split-bf16 operand format (inference): the producing
+    recurrent block then writes that format only."""
+    mods = list(subnet.children())
+    cfg = _conv_cfg(mods[0]) if mods else None
+    if cfg is None or precision != "bf16x3" or torch.is_grad_enabled():
+        return False
+    kh, kw, stride, pad, tr = cfg
+    co = mods[0].out_channels
+    return ops.conv2d_ex_takes_split(n, h, w, c, co, kh, kw, stride, pad, tr, precision)
+
+
+def _run_stage(subnet: nn.Sequential, x, precision: str, split_last: bool = False):
+    """Executes a stage built by _stage() on a channels-last [N,C,H,W] batch — or on (buffer, (N,C,H,W)) in the split-bf16 operand
+    format, which the stage's first convolution then reads directly. Conv2d / ConvTranspose2d layers (with a directly following
+    LeakyReLU fused in) run through libvpx_hip's glue entry points when the configuration is one they implement; every other
+    layer (pool, ReLU, exotic strides) runs as the stock GPU module."""
     mods = list(subnet.children())
     i = 0
     while i < len(mods):
         m = mods[i]
-        is_conv = isinstance(m, (nn.Conv2d, nn.ConvTranspose2d))
-        if is_conv and x.is_cuda:
-            tr = isinstance(m, nn.ConvTranspose2d)
-            kh, kw = m.kernel_size
-            simple = (m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.dilation == (1, 1)
-                      and m.groups == 1 and (not tr or m.output_padding == (0, 0)))
-            if simple and ops.glue_supported(kh, kw, m.stride[0], m.padding[0], tr):
-                slope = 0.0
-                if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
-                    slope = float(mods[i + 1].negative_slope)
-                    i += 1
-                co = m.out_channels
-                if split_last and i + 1 == len(mods) and co % 8 == 0:   # the stage's output goes straight to a recurrent block
-                    return ops.conv2d_ex_split(x, m.weight, m.bias, m.stride[0], m.padding[0], tr, slope, precision)
-                x = ops.conv2d_ex(x, m.weight, m.bias, m.stride[0], m.padding[0], tr, slope, precision)
+        cfg = _conv_cfg(m)
+        x_split = isinstance(x, tuple)
+        if cfg is not None and (x_split or x.is_cuda):
+            kh, kw, stride, pad, tr = cfg
+            slope = 0.0
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+                slope = float(mods[i + 1].negative_slope)
                 i += 1
-                continue
-        if is_conv and x.is_cuda:
+            co = m.out_channels
+            last_to_split = split_last and i + 1 == len(mods) and co % 8 == 0   # the stage's output goes straight to a recurrent block
+            if x_split:
+                y, ybuf, shp = ops.conv2d_ex_from_split(x[0], x[1], m.weight, m.bias, stride, pad, tr, slope, precision,
+                                                        out_split=last_to_split, out_fp32=not last_to_split)
+                if last_to_split:
+                    return ybuf, shp
+                x = y
+            elif last_to_split:
+                return ops.conv2d_ex_split(x, m.weight, m.bias, stride, pad, tr, slope, precision)
+            else:
+                x = ops.conv2d_ex(x, m.weight, m.bias, stride, pad, tr, slope, precision)
+            i += 1
+            continue
+        if isinstance(x, tuple):
+            raise RuntimeError(f"EF stage glue: {m} cannot read a split-format input (stage was offered one by mistake)")
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and x.is_cuda:
             ops._warn_once(f"glue_stock_{type(m).__name__}_{tuple(m.kernel_size)}_{tuple(m.stride)}",
                            f"EF stage glue: {m} is outside vpx_conv2d_ex (ops.glue_supported); it runs as the stock torch module")
         x = m(x)
@@ -76,19 +109,37 @@ def _run_stage(subnet: nn.Sequential, x: torch.Tensor, precision: str, split_las
     return x
 
 
-def _apply_framewise(subnet: nn.Module, seq: torch.Tensor, precision: str = "f32", consumer=None):
-    """Runs a 2-D stage on every frame of [B,T,C,H,W], channels-last in and out (B*T is folded into the batch).
+def _apply_framewise(subnet: nn.Module, seq, precision: str = "f32", consumer=None):
+    """Runs a 2-D stage on every frame of [B,T,C,H,W] (a tensor, or an ops.SplitActivation handed over by the producing block),
+    channels-last in and out (B*T is folded into the batch).
     `consumer`: the recurrent block the result feeds; when it takes split-format input (inference on the second-generation
     cell kernel) the stage's last convolution writes that format directly and an ops.SplitActivation is returned."""
     b, t = seq.shape[:2]
-    flat = ops.to_channels_last(seq).reshape(b * t, *seq.shape[2:])  # a view: NHWC memory folds B,T for free
     want_split = consumer is not None and hasattr(consumer, "takes_split_input") and consumer.takes_split_input(b, t)
-    y = _run_stage(subnet, flat.contiguous(memory_format=torch.channels_last), precision, want_split)
+    if isinstance(seq, ops.SplitActivation):
+        _, _, c, h, w = seq.shape
+        y = _run_stage(subnet, (seq.buf, (b * t, c, h, w)), precision, want_split)
+    else:
+        flat = ops.to_channels_last(seq).reshape(b * t, *seq.shape[2:])  # a view: NHWC memory folds B,T for free
+        y = _run_stage(subnet, flat.contiguous(memory_format=torch.channels_last), precision, want_split)
     if isinstance(y, tuple):
         buf, (n, c, h, w) = y
         return ops.SplitActivation(buf, (b, t, c, h, w))
     y = y.contiguous(memory_format=torch.channels_last)
     return y.view(b, t, *y.shape[1:])
+
+
+SPLIT_HANDOVER = True   #: inference: recurrent blocks hand their output sequences to the stage glue in operand format only (A/B switch)
+
+
+def _block_out_split(rnn, next_stage, batch, seq_len):
+    """Should this recurrent block hand its output sequence out in operand format only? Yes when it can (inference, second-generation
+    cell kernel) and its consumer — the next stage's first convolution, or nobody — does not need the fp32 copy."""
+    if not SPLIT_HANDOVER or not hasattr(rnn, "writes_split_output") or not rnn.writes_split_output(batch, seq_len):
+        return False
+    if next_stage is None:
+        return True
+    return _stage_takes_split(next_stage, batch * seq_len, rnn.enc_c, rnn.state_h, rnn.state_w, getattr(rnn, "precision", "f32"))
 
 
 class Encoder(nn.Module):
@@ -100,14 +151,18 @@ class Encoder(nn.Module):
             setattr(self, f"stage{index}", _stage(params))
             setattr(self, f"rnn{index}", rnn)
 
-    def forward_by_stage(self, input, subnet, rnn):
+    def forward_by_stage(self, input, subnet, rnn, next_stage=None, last=False):
         input = _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"), consumer=rnn)
-        return rnn(input, None, seq_len=input.shape[1])
+        b, t = input.shape[:2]
+        if (last or next_stage is not None) and _block_out_split(rnn, next_stage, b, t):
+            return rnn(input, None, seq_len=t, out_split=True)
+        return rnn(input, None, seq_len=t)
 
     def forward(self, input):
         hidden_states = []
         for i in range(1, self.blocks + 1):
-            input, state = self.forward_by_stage(input, getattr(self, f"stage{i}"), getattr(self, f"rnn{i}"))
+            nxt = getattr(self, f"stage{i + 1}") if i < self.blocks else None   # the last block's sequence has no reader (states only)
+            input, state = self.forward_by_stage(input, getattr(self, f"stage{i}"), getattr(self, f"rnn{i}"), nxt, last=i == self.blocks)
             hidden_states.append(state)
         return tuple(hidden_states)
 
@@ -122,7 +177,11 @@ class Forecaster(nn.Module):
             setattr(self, f"stage{self.blocks - index}", _stage(params))
 
     def forward_by_stage(self, input, state, pred_frames, subnet, rnn, next_rnn=None):
-        input, _ = rnn(input, state, pred_frames)
+        b = state[0].shape[0]
+        if _block_out_split(rnn, subnet, b, pred_frames):
+            input, _ = rnn(input, state, pred_frames, out_split=True)
+        else:
+            input, _ = rnn(input, state, pred_frames)
         return _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"), consumer=next_rnn)
 
     def forward(self, hidden_states, pred_frames):

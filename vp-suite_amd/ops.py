@@ -145,7 +145,7 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
     conv_lstm_ndrplz.py:112-121 by ONE library call (T fused conv+gate launches on the current stream)."""
 
     @staticmethod
-    def forward(ctx, x, h0, c0, W, b, Wci, Wcf, Wco, seq_len, gate_order, precision, in_channels, need_grad):
+    def forward(ctx, x, h0, c0, W, b, Wci, Wcf, Wco, seq_len, gate_order, precision, in_channels, need_grad, out_split=False):
         ref = x.buf if isinstance(x, SplitActivation) else (x if x is not None else h0)
         _require_gpu(ref, "convlstm_seq")
         dev = ref.device
@@ -176,8 +176,11 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
         wco = _cached_channels_last(Wco) if peep else None
         Wc = W.contiguous()
         bc = None if b is None else b.contiguous()
+        if out_split and need_grad:
+            raise ValueError("convlstm_seq: out_split is inference-only")
         d = ConvLSTMDesc(B, T, Cin, Ch, H, Wd, kh, kw, gate_order, _lib.LAYOUT_NHWC, precision,
-                         (_lib.FLAG_SAVE_FOR_BWD if need_grad else 0) | (_lib.FLAG_X_SPLIT if x_split else 0))
+                         (_lib.FLAG_SAVE_FOR_BWD if need_grad else 0) | (_lib.FLAG_X_SPLIT if x_split else 0) |
+                         (_lib.FLAG_OUT_SPLIT if out_split else 0))
         L = _lib.lib()
         ws_bytes = L.vpx_convlstm_workspace_bytes(ctypes.byref(d))
         rs_bytes = L.vpx_convlstm_reserve_bytes(ctypes.byref(d))
@@ -187,7 +190,7 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
         if not need_grad and ws_bytes <= _CLSTM_WS_CACHE_LIMIT:
             # inference: the block keeps its workspace, and with it the weight packs, while the weight tensor is unchanged
             # (identity by weak reference + version + address; kernel selection switches are part of the key)
-            key = (id(W), B, T, Cin, Ch, H, Wd, kh, kw, gate_order, precision, x is None, h0 is None, x_split,
+            key = (id(W), B, T, Cin, Ch, H, Wd, kh, kw, gate_order, precision, x is None, h0 is None, x_split, out_split,
                    torch.are_deterministic_algorithms_enabled(), _kernel_options())
             ent = _clstm_ws.get(key)
             if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == Wc.data_ptr() and ent[3].numel() == ws_bytes \
@@ -206,15 +209,19 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
         if ws is None:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         reserve = torch.empty(max(rs_bytes, 1), dtype=torch.uint8, device=dev)
-        out = new_channels_last((B, T, Ch, H, Wd), dev)
-        hT = out[:, T - 1]  # h_T IS the last slice of the output slab: a view, no copy
+        if out_split:   # the sequence in operand format (no fp32 copy exists); h_T separately in fp32
+            out = torch.empty(B * T * H * Wd * Ch, dtype=torch.float32, device=dev)
+            hT = new_channels_last((B, Ch, H, Wd), dev)
+        else:
+            out = new_channels_last((B, T, Ch, H, Wd), dev)
+            hT = out[:, T - 1]  # h_T IS the last slice of the output slab: a view, no copy
         cT = new_channels_last((B, Ch, H, Wd), dev)
         if PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         rc = L.vpx_convlstm_seq_fwd(ctypes.byref(d), ptr(x), ptr(h0c), ptr(c0c), ptr(Wc), ptr(bc), ptr(wci), ptr(wcf),
-                                    ptr(wco), ptr(out), None, ptr(cT), ptr(reserve), rs_bytes, ptr(ws), ws_bytes,
-                                    _stream())
+                                    ptr(wco), ptr(out), ptr(hT) if out_split else None, ptr(cT), ptr(reserve), rs_bytes, ptr(ws),
+                                    ws_bytes, _stream())
         check(rc, "vpx_convlstm_seq_fwd")
         if PROFILE is not None:
             ev1.record()
@@ -226,6 +233,8 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
             ctx.desc = d
             ctx.has_bias = b is not None
             ctx.rs_bytes = rs_bytes
+        if out_split:
+            return SplitActivation(out, (B, T, Ch, H, Wd)), hT, cT
         return out, hT, cT
 
     @staticmethod
@@ -273,19 +282,32 @@ def convlstm_algorithmic_work(B, T, Cin, Ch, H, W, kh, kw, has_h0=True, peephole
     return flops, nbytes
 
 
+def convlstm_writes_split(B, T, Cin, Ch, H, W, k, gate_order, precision):
+    """True when convlstm_seq on this problem (inference) can hand its output sequence out as a SplitActivation (out_split=True)."""
+    d = ConvLSTMDesc(B, T, Cin, Ch, H, W, k, k, gate_order, _lib.LAYOUT_NHWC, PRECISIONS[precision], 0)
+    return bool(_lib.lib().vpx_convlstm_writes_split_output(ctypes.byref(d)))
+
+
 def convlstm_seq(x, h0, c0, W, b, Wci=None, Wcf=None, Wco=None, *, seq_len, in_channels, gate_order=_lib.GATE_IFGO,
-                 precision="f32"):
-    """x: [B,T,Cin,H,W] or None; h0/c0: [B,Ch,H,W] or None (not both x and h0 None). Returns (out [B,T,Ch,H,W], hT, cT)."""
+                 precision="f32", out_split=False):
+    """x: [B,T,Cin,H,W] or None; h0/c0: [B,Ch,H,W] or None (not both x and h0 None). Returns (out [B,T,Ch,H,W], hT, cT);
+    out_split (inference, where convlstm_writes_split says so): `out` is a SplitActivation — the sequence in the library's operand
+    format for a consumer that reads it (conv2d_ex_from_split); no fp32 copy of it is written."""
     if x is None and h0 is None:
         raise ValueError("convlstm_seq: inputs and states must not both be None")
     # grad mode is always off INSIDE Function.forward, so decide here whether the forward must fill the reserve
     need_grad = torch.is_grad_enabled() and any(
         isinstance(t, torch.Tensor) and t.requires_grad for t in (x, h0, c0, W, b, Wci, Wcf, Wco))
-    if isinstance(x, SplitActivation):   # autograd.Function.apply only takes tensors: call the forward body directly
+    if isinstance(x, SplitActivation) or out_split:   # autograd.Function.apply only takes / returns tensors: call the forward body directly
+        if need_grad:
+            raise ValueError("convlstm_seq: split-format input / output is inference-only")
+
         class _Ctx:   # (inference only: nothing is saved)
             needs_input_grad = (False,) * 13
+        if x is not None and not isinstance(x, SplitActivation) and x.dim() == 5 and x.shape[1] > seq_len:
+            x = x[:, :seq_len]
         return _ConvLSTMSeqFn.forward(_Ctx(), x, h0, c0, W, b, Wci, Wcf, Wco, int(seq_len), int(gate_order), PRECISIONS[precision],
-                                      int(in_channels), False)
+                                      int(in_channels), False, bool(out_split))
     if x is not None and x.dim() == 5 and x.shape[1] > seq_len:
         x = x[:, :seq_len]  # sliced here, outside the Function: autograd pads dx back to x's shape
     return _ConvLSTMSeqFn.apply(x, h0, c0, W, b, Wci, Wcf, Wco, int(seq_len), int(gate_order), PRECISIONS[precision],
