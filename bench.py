@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--context", type=int, default=10)
     ap.add_argument("--pred", type=int, default=10)
     ap.add_argument("--layers", type=int, default=None, help="predrnn-pp: num_layers (default 3; BASELINE configs[4] 'deep' = 4)")
+    ap.add_argument("--cell", type=str, default=None,
+                    help="Cin,Ch,H,W: time ONE ConvLSTM block alone (kernel micro-bench, SURVEY.md §8d) instead of the model")
+    ap.add_argument("--name", type=str, default=None, help="name of the configuration (selects the committed PMC summary for roofline.traffic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true")
@@ -204,14 +207,15 @@ def measured_traffic(spec):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/, collected with
     tools/collect_profiles.sh on this exact workload: separate --pmc FETCH_SIZE / WRITE_SIZE passes, read = 2 x FETCH_SIZE
     per the gfx950 correction); None when no committed pass matches the configuration."""
-    if spec.cell:
-        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
-                       if f.endswith(f"_pmc_cell_{spec.cell[0]}x{spec.cell[1]}x{spec.cell[2]}_b{spec.batch}.json"))
-        if not cands:
-            return None
+    # a PMC summary committed under this configuration's name (tools/prof_extra.sh + tools/summarize_extra.py) ...
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(f"_pmc_{spec.name}.json"))
+    if cands:
         with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
             t = json.load(fh).get("hbm_traffic_bytes_per_launch")
         return None if t is None else round(t["total"])
+    if spec.cell:
+        return None
+    # ... or the headline collection's (tools/collect_profiles.sh) for the 64x64 10->10 convlstm-shi configurations
     if not (spec.img == 64 and spec.channels == 1 and spec.context == 10 and spec.pred == 10):
         return None
     tag = {"convlstm-shi": ""}.get(spec.model)
@@ -386,14 +390,15 @@ def main():
 
     import vp_suite_amd  # noqa: F401
 
-    spec = Spec("headline", model=args.model, mode=args.mode, batch=args.batch, precision=args.precision, img=args.img,
-                channels=args.channels, context=args.context, pred=args.pred, layers=args.layers)
+    spec = Spec(args.name or "headline", model=args.model, mode=args.mode, batch=args.batch, precision=args.precision, img=args.img,
+                channels=args.channels, context=args.context, pred=args.pred, layers=args.layers,
+                cell=tuple(int(v) for v in args.cell.split(",")) if args.cell else None)
     runner = Runner(spec, dev, rank, world, use_dist)
     elapsed, ps = runner.timed(args.steps, args.warmup)
 
     out = None
     if rank == 0:
-        frames_total = world * spec.batch * spec.pred * args.steps
+        frames_total = world * spec.batch * (spec.context if spec.cell else spec.pred) * args.steps
         out = {
             "metric": "predicted frames/sec (whole node), MovingMNIST 64x64 10->10",
             "value": round(frames_total / elapsed, 2),

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_extra/<tag>/ (tools/prof_extra.sh) -> profiles/<round>_extra_<name>_kernel_stats.csv, ..._under_rocprof.json and
+profiles/<round>_pmc_<name>.json: per-kernel HBM bytes (read = 2 * FETCH_SIZE KiB: gfx950 wide-read correction; write = WRITE_SIZE
+KiB) and MFMA-busy share, plus hbm_traffic_bytes_per_launch = bytes of the fused-cell kernels per step / the cell launches bench.py
+counts per step (what `roofline.traffic` of the `extras` entry <name> reports).
+usage: tools/summarize_extra.py <round> <tag> <name>"""
+import collections, csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND, TAG, NAME = sys.argv[1], sys.argv[2], sys.argv[3]
+SRC = os.path.join(ROOT, "gpurun_out", "prof_extra", TAG)
+DST = os.path.join(ROOT, "profiles")
+CELL = ("cell2_kernel", "cell3_kernel", "EpiConvLSTM", "convlstm_pointwise_kernel", "conv_gemm_dual_kernel", "EpiSTOut", "EpiSTGate",
+        "st_ln_", "st_gates", "st_out")
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(SRC, pattern))
+    return max(f, key=os.path.getmtime) if f else None
+
+
+def is_cell(k):
+    return any(c in k for c in CELL) and "Conv2Epi" not in k
+
+
+f = one("trace/*/*kernel_stats.csv")
+if f:
+    shutil.copy(f, os.path.join(DST, f"{ROUND}_extra_{NAME}_kernel_stats.csv"))
+line = None
+log = os.path.join(SRC, "bench.log")
+if os.path.exists(log):
+    lines = [l for l in open(log) if l.startswith("{")]
+    if lines:
+        line = json.loads(lines[-1])
+        open(os.path.join(DST, f"{ROUND}_extra_{NAME}_under_rocprof.json"), "w").write(lines[-1])
+tab = collections.defaultdict(dict)
+steps_in_pmc = 3 + 1   # tools/prof_extra.sh: --steps 3 --warmup 1
+for d, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", "SQ_VALU_MFMA_BUSY_CYCLES"), ("pmc_sq", "GRBM_GUI_ACTIVE")):
+    f = one(f"{d}/*/*counter_collection.csv")
+    if not f:
+        continue
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != cname:
+            continue
+        k = r["Kernel_Name"].split("(")[0][:100]
+        e = tab[k].setdefault(cname, [0.0, 0])
+        e[0] += float(r["Counter_Value"]); e[1] += 1
+out = {"configuration": NAME, "command": f"tools/prof_extra.sh {TAG} ... (separate --pmc passes over bench.py --steps 3 --warmup 1)", "per_kernel": {}}
+cell_bytes = 0.0
+for k, cs in tab.items():
+    e = {}
+    if "FETCH_SIZE" in cs:
+        e["launches"] = cs["FETCH_SIZE"][1]
+        e["read_MB_per_launch"] = round(2.0 * cs["FETCH_SIZE"][0] / cs["FETCH_SIZE"][1] * 1024 / 1e6, 3)
+    if "WRITE_SIZE" in cs:
+        e["write_MB_per_launch"] = round(cs["WRITE_SIZE"][0] / cs["WRITE_SIZE"][1] * 1024 / 1e6, 3)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs and cs["GRBM_GUI_ACTIVE"][0] > 0:
+        e["mfma_pipe_busy_frac"] = round(cs["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (cs["GRBM_GUI_ACTIVE"][0] / 8 * 1024), 4)
+    if is_cell(k):
+        cell_bytes += 2.0 * cs.get("FETCH_SIZE", [0, 1])[0] * 1024 + cs.get("WRITE_SIZE", [0, 1])[0] * 1024
+    out["per_kernel"][k] = e
+out["per_kernel"] = dict(sorted(out["per_kernel"].items(), key=lambda kv: -(kv[1].get("read_MB_per_launch", 0) + kv[1].get("write_MB_per_launch", 0)) * kv[1].get("launches", 0))[:20])
+if line is not None and cell_bytes > 0:
+    per_step_launches = line["roofline"]["launches"] / line["steps"]
+    out["hbm_traffic_bytes_per_launch"] = {"total": cell_bytes / steps_in_pmc / per_step_launches,
+                                           "note": "HBM bytes of the fused-cell kernels per step / cell launches per step as bench.py counts them"}
+    out["algorithmic_bytes_per_launch"] = line["roofline"].get("algorithmic_bytes_per_launch")
+json.dump(out, open(os.path.join(DST, f"{ROUND}_pmc_{NAME}.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}, indent=1))
