@@ -236,11 +236,15 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
     const int tsel_shift = (kg >> 1) ? 16 : 0;   // which half of a packed offset pair this lane's k group reads
     // fragment address of a step for this lane: a_lane + 16 * (its half of the step's packed offsets)
     auto step_va = [&](int packed) { return a_lane + ((int)(((unsigned)packed >> tsel_shift) & 0x1fffu) << 4); };
-    bf16x8 ah[4], al[4], bh[2], bl[2];
-    auto load_A1 = [&](int va, int m) {
+    // activation fragments: with several steps per chunk (NSUB >= 2: 12 or 24 MFMAs per step) two sets — the next step's rows are
+    // requested at the START of the current step; with one step per chunk (96 MFMAs) one set, refilled row by row behind the
+    // last column tile's MFMAs (as cell2_kernel_q)
+    constexpr int NSET = NSUB >= 2 ? 2 : 1;
+    bf16x8 ah[NSET][4], al[NSET][4], bh[2], bl[2];
+    auto load_A1 = [&](int set, int va, int m) {
         const char* a = smem + va + m * (HW_ * 16);
-        ah[m] = *reinterpret_cast<const bf16x8*>(a);
-        al[m] = *reinterpret_cast<const bf16x8*>(a + 2 * PLANE);
+        ah[set][m] = *reinterpret_cast<const bf16x8*>(a);
+        al[set][m] = *reinterpret_cast<const bf16x8*>(a + 2 * PLANE);
     };
     auto load_B = [&](int slot, int t) {   // weight fragments of chunk tile t -> set t & 1
         const char* w = Wbuf + slot * CQ_WCHUNK + w_lane + t * 256;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
         {
             const int va = step_va(cur_off);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) load_A1(va, m);
+            for (int m = 0; m < 4; ++m) load_A1(0, va, m);
             load_B(0, 0);
         }
         while (true) {
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
             if (cur.late) {              // a stage that landed with this very sync: its fragments could not be read ahead
                 const int va = step_va(cur_off);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) load_A1(va, m);
+                for (int m = 0; m < 4; ++m) load_A1(0, va, m);
             }
             // next chunk's first entry (the schedule wraps around with the stage base advanced)
             int nidx = idx + NSUB, nbase = base;
@@ -312,6 +316,13 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
                 const int on_ = j + 1 < NSUB ? __builtin_amdgcn_readlane(e_off, idx + j + 1) : nxt_off;
                 const int n_va = step_va(on_);
                 const bool on = (oj & 0x8000) != 0;
+                constexpr int SET_SHIFT = 0;
+                const int cs = NSET == 2 ? (j & 1) : 0, ns = NSET == 2 ? ((j + 1) & 1) : 0;   // this step's / the next step's fragment set
+                (void)SET_SHIFT;
+                if (NSET == 2) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) load_A1(ns, n_va, m);
+                }
 #pragma unroll
                 for (int k = 0; k < NTS; ++k) {
                     const int t = j * NTS + k;           // tile inside the weight chunk
@@ -323,16 +334,16 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
                             f32x4 cc = acc[m][at];
-                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[t & 1], cc, 0, 0, 0);
-                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[t & 1], cc, 0, 0, 0);
-                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[t & 1], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cs][m], bh[t & 1], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cs][m], bl[t & 1], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cs][m], bh[t & 1], cc, 0, 0, 0);
                             acc[m][at] = cc;
-                            if (k == NTS - 1) load_A1(n_va, m);   // the step's last tile frees row m: the next step's fragments
+                            if (NSET == 1 && k == NTS - 1) load_A1(0, n_va, m);   // the step's last tile frees row m: the next step's fragments
                         }
                         __builtin_amdgcn_s_setprio(0);
-                    } else if (k == NTS - 1) {
+                    } else if (NSET == 1 && k == NTS - 1) {
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) load_A1(n_va, m);
+                        for (int m = 0; m < 4; ++m) load_A1(0, n_va, m);
                     }
                     // ---- this sync's copies, behind the MFMAs of tiles 0..3: weight chunk, then the stage (or the stage first) ----
                     if (t == 0) {
