@@ -780,6 +780,11 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel_q(const Cell2Plan P, cons
         F.bl[nt & 1] = *reinterpret_cast<const bf16x8*>(w + 8192);
     };
 
+    // Waves 4-7 meet each sync point at THEIR tile 1 instead of tile 5, i.e. they run half a chunk behind waves 0-3: the two waves
+    // of a SIMD then do not reach fragment reads, MFMA groups and the barrier in lockstep (MI355X_MICROARCH.md, two waves per SIMD,
+    // item 9). Bit-identical outputs; +0.4..0.8 % on every block shape (tools/ab_exp.py; experiment bit 0 switches it off). A static
+    // s_setprio 1 for waves 4-7 instead of the per-group flips measured -0.5..0.8 % and is not kept.
+    const bool late_sync = !(P._q & 1) && wave >= 4;
     if (S > 0) {
 #pragma unroll
         for (int u = 0; u < 5; ++u) issue_A1(0, 0, u);
@@ -802,8 +807,8 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel_q(const Cell2Plan P, cons
                 const int q = q0 + p;
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) {
-                    if (nt == 5) {
-                        // ---- sync point S_q ----
+                    if ((nt == 5 && !late_sync) || (nt == 1 && late_sync)) {
+                        // ---- sync point S_q (waves 0-3 before their tile 5, waves 4-7 before their tile 1: see late_sync) ----
                         if ((p == 1 && odd) || (p == 6 && more)) C2_WAIT_VM(5); else C2_WAIT_VM(0);   // the stage copy issued one step ago may still fly
                         c2_barrier();
                     }
@@ -827,14 +832,15 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel_q(const Cell2Plan P, cons
                     }
                     __builtin_amdgcn_s_setprio(0);
                     // ---- this sync point's copies, behind the MFMAs of column tiles 5..7: the weight chunk first, then the stage ----
-                    if (nt == 5 && q + 2 < Q) { issue_W1(q + 2, (p + 2) % 3, 0); issue_W1(q + 2, (p + 2) % 3, 1); }
+                    const int i0 = late_sync ? 1 : 5;   // first tile after this wave's sync point
+                    if (nt == i0 && q + 2 < Q) { issue_W1(q + 2, (p + 2) % 3, 0); issue_W1(q + 2, (p + 2) % 3, 1); }
                     if (p == 0 && odd) {
-                        if (nt == 6) { issue_A1(s0 + 1, 1, 0); issue_A1(s0 + 1, 1, 1); }
-                        if (nt == 7) { issue_A1(s0 + 1, 1, 2); issue_A1(s0 + 1, 1, 3); issue_A1(s0 + 1, 1, 4); }
+                        if (nt == i0 + 1) { issue_A1(s0 + 1, 1, 0); issue_A1(s0 + 1, 1, 1); }
+                        if (nt == i0 + 2) { issue_A1(s0 + 1, 1, 2); issue_A1(s0 + 1, 1, 3); issue_A1(s0 + 1, 1, 4); }
                     }
                     if (p == 5 && more) {
-                        if (nt == 6) { issue_A1(s0 + 2, 0, 0); issue_A1(s0 + 2, 0, 1); }
-                        if (nt == 7) { issue_A1(s0 + 2, 0, 2); issue_A1(s0 + 2, 0, 3); issue_A1(s0 + 2, 0, 4); }
+                        if (nt == i0 + 1) { issue_A1(s0 + 2, 0, 0); issue_A1(s0 + 2, 0, 1); }
+                        if (nt == i0 + 2) { issue_A1(s0 + 2, 0, 2); issue_A1(s0 + 2, 0, 3); issue_A1(s0 + 2, 0, 4); }
                     }
                 }
             }
@@ -856,6 +862,7 @@ static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStrea
     Cell2Plan p = plan;
     p.grid_m = plan.B * plan.tiles_x * plan.tiles_y;
     if (plan.qform) {
+        p._q = g_experiment;
         const long long per_xcd_q = ((long long)p.grid_m * p.n_tiles + 7) / 8;
         hipLaunchKernelGGL((cell2_kernel_q<Epi, ALLG>), dim3((unsigned)(per_xcd_q * 8)), dim3(512), CQ_LDS, s, p, epi);
         return hipGetLastError();

@@ -20,6 +20,7 @@ void set_error(const char* fmt, ...) {
 int g_deterministic = 0;
 int g_cell3_mode = -1;
 int g_cell2_mode = -1;
+int g_experiment = 0;
 int g_mfma_shape = -1;
 int mfma_shape() {
     if (g_mfma_shape < 0) { const char* e = getenv("VPX_MFMA_SHAPE"); g_mfma_shape = e ? (atoi(e) ? 1 : 0) : VPX_MFMA_SHAPE_DEFAULT; }
@@ -42,6 +43,11 @@ int vpx_set_option(int option, int value) {
     if (option == VPX_OPT_CELL2) {
         const int prev = cell2_mode();
         vpx::g_cell2_mode = value < 0 ? 0 : (value > 2 ? 2 : value);
+        return prev;
+    }
+    if (option == VPX_OPT_EXPERIMENT) {
+        const int prev = vpx::g_experiment;
+        vpx::g_experiment = value;
         return prev;
     }
     if (option == VPX_OPT_MFMA_SHAPE) {

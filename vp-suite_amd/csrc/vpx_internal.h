@@ -145,6 +145,7 @@ hipError_t launch_split_convert(const float* src, void* dst, long long npix, int
 hipError_t launch_cell2_pack(const Cell2Pack& pk, void* dst, hipStream_t s);
 size_t cell2_packed_bytes(int n_tiles, int chunks_total);   // 32x32x16 form: chunks of 24 KiB (3 per stage)
 size_t cell2_packed_bytes_q(int n_tiles, int S);             // q form: cell2_qchunks(S) chunks of 16 KiB
+extern int g_experiment;   // vpx_api.hip: bits of kernel experiments in flight (vpx_set_option(VPX_OPT_EXPERIMENT)); 0 in the product
 extern int g_mfma_shape;   // vpx_api.hip: -1 = not yet read from the environment (VPX_MFMA_SHAPE), else 0 / 1 (vpx_set_option)
 int mfma_shape();
 hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s);
