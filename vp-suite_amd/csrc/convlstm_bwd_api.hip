@@ -39,9 +39,14 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     float* dh_buf = ws.take(L.n_state);
     float* dc_buf = ws.take(L.n_state);
     float* slabs = ws.take(L.slab_floats);
-    const int gb_blocks = gate_bwd_blocks((int)HW, Ch) * gate_bwd_slices((int)HW, Ch, B, dWci != nullptr);  // partial rows per step
+    // peephole gradients: a sum over the batch. With several batch slices every slice accumulates (over the time steps, single
+    // owner per element) into its own partial tensor; launch_peep_reduce adds them in a fixed order after the loop
+    const int gb_slices = gate_bwd_slices((int)HW, Ch, B, false);
+    const int gb_blocks = gate_bwd_blocks((int)HW, Ch) * gb_slices;  // partial rows per step
     float* db_part = ws.take((size_t)T * GATE_BWD_MAX_SLICES * gate_bwd_blocks((int)HW, Ch) * N4);
     float* db_part2 = ws.take((size_t)COLSUM_BLOCKS * N4);
+    float* peep_part[3];
+    for (auto& pp_ : peep_part) pp_ = ws.take((size_t)GATE_BWD_MAX_SLICES * L.n_peep);
     // forward on the second-generation cell: the gate-backward kernel also writes dG in split operand format and the data
     // gradient runs on the cell2 main loop with a plain epilogue (conv2); VPX_CONV2_DGRAD=0 keeps the first-generation kernel
     static int c2d_env = -1;
@@ -98,7 +103,10 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     int gp[4];
     gate_positions(d->gate_order, gp);
 
-    if (dpeep) {
+    const bool peep_sliced = dpeep && gb_slices > 1;
+    if (peep_sliced) {
+        for (auto pp_ : peep_part) VPX_CHECK_HIP(hipMemsetAsync(pp_, 0, (size_t)gb_slices * L.n_peep * sizeof(float), stream));
+    } else if (dpeep) {
         VPX_CHECK_HIP(hipMemsetAsync(dwci, 0, L.n_peep * sizeof(float), stream));
         VPX_CHECK_HIP(hipMemsetAsync(dwcf, 0, L.n_peep * sizeof(float), stream));
         VPX_CHECK_HIP(hipMemsetAsync(dwco, 0, L.n_peep * sizeof(float), stream));
@@ -147,6 +155,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         ga.dc_out = (t == 0 && dc0n) ? dc0n : dc_buf;
         ga.wci = wci; ga.wcf = wcf; ga.wco = wco;
         ga.dwci = dpeep ? dwci : nullptr; ga.dwcf = dpeep ? dwcf : nullptr; ga.dwco = dpeep ? dwco : nullptr;
+        if (peep_sliced) { ga.dwci = peep_part[0]; ga.dwcf = peep_part[1]; ga.dwco = peep_part[2]; ga.peep_slice_stride = (long long)L.n_peep; }
         ga.dG = need_dG_f32 ? dG_all + (size_t)t * L.n_state * 4 : nullptr;
         ga.dG_sp = (c2d || wsp) ? dG_sp_all + (size_t)t * L.n_state * 16 : nullptr;
         ga.db_partial = db ? db_part + (size_t)t * gb_blocks * N4 : nullptr;
@@ -183,6 +192,8 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         }
     }
     if (dxn && !xn) { set_error("vpx_convlstm_seq_bwd: dx requested but x is NULL"); return VPX_ERR_ARG; }
+    if (peep_sliced)
+        VPX_CHECK_HIP(launch_peep_reduce(peep_part[0], peep_part[1], peep_part[2], dwci, dwcf, dwco, gb_slices, (long long)L.n_peep, stream));
 
     // ---- weight gradient over all (t, b) images ----
     if (dW) {

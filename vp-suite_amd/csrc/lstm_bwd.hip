@@ -82,10 +82,11 @@ __global__ __launch_bounds__(256) void convlstm_gate_bwd_kernel(const GateBwdArg
         }
         sb0 += dai; sb1 += daf; sb2 += dag; sb3 += dao;
     }
-    if (peep && a.dwci) {  // single owner per (pix, ch): plain accumulate over the time steps
-        a.dwci[pc] += dpi;
-        a.dwcf[pc] += dpf;
-        a.dwco[pc] += dpo;
+    if (peep && a.dwci) {  // single owner per (slice, pix, ch): plain accumulate over the time steps
+        const size_t po = (size_t)blockIdx.y * (size_t)a.peep_slice_stride + pc;
+        a.dwci[po] += dpi;
+        a.dwcf[po] += dpf;
+        a.dwco[po] += dpo;
     }
     }  // active
     if (a.db_partial) {
@@ -105,7 +106,26 @@ __global__ __launch_bounds__(256) void convlstm_gate_bwd_kernel(const GateBwdArg
 }
 
 hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(convlstm_gate_bwd_kernel, dim3(gate_bwd_blocks(a.HW, a.Ch), gate_bwd_slices(a.HW, a.Ch, a.B, a.dwci != nullptr)), dim3(256), 0, s, a);
+    const bool one_owner = a.dwci != nullptr && a.peep_slice_stride == 0;
+    hipLaunchKernelGGL(convlstm_gate_bwd_kernel, dim3(gate_bwd_blocks(a.HW, a.Ch), gate_bwd_slices(a.HW, a.Ch, a.B, one_owner)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void peep_reduce_kernel(const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ p2,
+                                                          float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2, int slices,
+                                                          long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* p = blockIdx.y == 0 ? p0 : (blockIdx.y == 1 ? p1 : p2);
+    float* d = blockIdx.y == 0 ? d0 : (blockIdx.y == 1 ? d1 : d2);
+    float acc = 0.f;
+    for (int s = 0; s < slices; ++s) acc += p[(size_t)s * n + i];   // fixed order: bit-reproducible
+    d[i] = acc;
+}
+
+hipError_t launch_peep_reduce(const float* p0, const float* p1, const float* p2, float* d0, float* d1, float* d2, int slices, long long n,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(peep_reduce_kernel, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, s, p0, p1, p2, d0, d1, d2, slices, n);
     return hipGetLastError();
 }
 

@@ -252,6 +252,7 @@ static inline size_t convlstm_bwd_workspace_bytes(const vpx_convlstm_desc* d, co
     b += align256(L.slab_floats * sizeof(float));
     b += align256((size_t)d->T * GATE_BWD_MAX_SLICES * gate_bwd_blocks(d->H * d->W, d->Ch) * 4 * d->Ch * sizeof(float));  // bias-gradient partials
     b += align256((size_t)COLSUM_BLOCKS * 4 * d->Ch * sizeof(float));                                // ... and their second level
+    b += 3 * align256((size_t)GATE_BWD_MAX_SLICES * L.n_peep * sizeof(float));                       // per-batch-slice peephole-gradient partials
     if (L.v2)  // dG of all steps in split operand format + the conv2 weight pack of the data gradient
         b += align256((size_t)d->T * L.n_state * 16) + align256(cell2_packed_bytes(conv2_tiles(d->Cin + d->Ch), 3 * (4 * d->Ch / 16)) + 16384 * conv2_tiles(d->Cin + d->Ch));
     if (wgrad2_wsp(d, L))  // split dG of all steps + split copies of x, the output sequence and h0

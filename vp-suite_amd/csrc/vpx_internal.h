@@ -304,13 +304,16 @@ struct GateBwdArgs {
     float* dc_out;            // dc flowing out to step t-1
     const float* wci; const float* wcf; const float* wco;  // peepholes [HW,Ch] or null
     float* dwci; float* dwcf; float* dwco;                  // accumulated (+=) over steps, or null
+    long long peep_slice_stride;                            // > 0: batch slice y accumulates into dwc*[y * stride + ..] (per-slice partials,
+                                                            //      summed by launch_peep_reduce after the time loop); 0: one slice, in place
     float* dG;                // [B,HW,4Ch] d(pre-activation), reference gate order (or null when only dG_sp is wanted)
     char* dG_sp;              // the same tensor in split-bf16 operand format (cell2.hip), or null; needs an even Ch
     float* db_partial;        // [gridDim.x][4Ch] per-block column sums of dG (bias gradient partials), or null
 };
 inline int gate_bwd_blocks(int HW, int Ch) { return (HW * Ch + 255) / 256; }
 // batch slices (grid.y): the kernel streams ~56 B per element with one element per thread and batch step, so it wants >= 8
-// waves per SIMD in flight (2048 blocks); a (pixel, channel) thread then walks B / slices batch items. 1 with peephole gradients.
+// waves per SIMD in flight (2048 blocks); a (pixel, channel) thread then walks B / slices batch items. Peephole gradients (a sum
+// over the batch with one owner per element) keep one slice unless the caller provides per-slice partial buffers (peep_slice_stride).
 constexpr int GATE_BWD_MAX_SLICES = 8;
 inline int gate_bwd_slices(int HW, int Ch, int B, bool peephole_grads) {
     if (peephole_grads) return 1;
@@ -320,6 +323,9 @@ inline int gate_bwd_slices(int HW, int Ch, int B, bool peephole_grads) {
     return s < 1 ? 1 : s;
 }
 hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s);
+// dw[i] = sum over slices of part[slice * n + i], fixed order; the three peephole tensors in one launch (part / dw: 3 pointers each)
+hipError_t launch_peep_reduce(const float* p0, const float* p1, const float* p2, float* d0, float* d1, float* d2, int slices, long long n,
+                              hipStream_t s);
 // out[c] = sum_r m[r][c] (* LeakyReLU'(y[r][c]) when y != null, the scaled matrix optionally stored), bit-reproducible;
 // partial_ws: COLSUM_BLOCKS * cols floats of scratch
 constexpr int COLSUM_BLOCKS = 4096;   // level-1 blocks: enough 256-thread blocks in flight to stream a GB-sized dy at HBM speed
