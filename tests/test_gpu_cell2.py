@@ -247,3 +247,46 @@ def test_mfma_16x16x32_training_path_vs_oracle(vpx, cell2_switch, shape_switch, 
     assert _relmax(out, ro) < 2e-5
     for k in rg:
         assert _relmax(g[k], rg[k]) < 5e-5, k
+
+
+# ---- the half tile (cell2_kernel_q<.., 4>: 16x16-pixel tiles, two workgroups per CU, weight ring of two chunks in halves) ----
+@pytest.fixture
+def experiment_switch(vpx):
+    L = vpx._lib.lib()
+    prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, 0)
+
+    def set_mode(v):
+        L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, v)
+    yield set_mode
+    L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, prev)
+
+
+@pytest.mark.parametrize("tag", list(CASESQ))
+def test_half_tile_bit_identical_to_full_tile(vpx, cell2_switch, shape_switch, experiment_switch, tag):
+    """Same products in the same order per output element: the two tile forms must agree bit for bit."""
+    cell2_switch(2)
+    shape_switch(1)
+    experiment_switch(4)
+    o1, h1, c1, _ = _run(vpx, tag, grads=False)
+    experiment_switch(2)
+    o2, h2, c2, _ = _run(vpx, tag, grads=False)
+    assert torch.equal(o2, o1) and torch.equal(c2, c1) and torch.equal(h2, h1)
+    ro, rh, rc, _ = _oracle(tag)
+    assert _relmax(o2, ro) < 2e-5 and _relmax(c2, rc) < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["q_enc1_oddx", "q_odd_total_states", "q_ifog_nopeep", "enc1_ragged", "fore1_states"])
+def test_half_tile_training_path(vpx, cell2_switch, shape_switch, experiment_switch, tag):
+    cell2_switch(2)
+    shape_switch(1)
+    experiment_switch(4)
+    out1, _, _, g1 = _run(vpx, tag, grads=True)
+    experiment_switch(2)
+    out2, _, _, g2 = _run(vpx, tag, grads=True)
+    assert torch.equal(out1, out2)
+    for k in g1:
+        if g1[k] is not None:
+            assert torch.equal(g1[k], g2[k]), k
+    _, _, _, rg = _oracle(tag)
+    for k in rg:
+        assert _relmax(g2[k], rg[k]) < 5e-5, k

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import vp_suite_amd as v
 dev = torch.device("cuda:0")
+if os.environ.get("EXP"):
+    v._lib.lib().vpx_set_option(v._lib.OPT_EXPERIMENT, int(os.environ["EXP"]))
 B, T = int(os.environ.get("BB", 32)), 4
 Cin, Ch, H, W = 64, 64, 64, 64
 x = v.ops.to_channels_last(torch.rand(B, T, Cin, H, W, device=dev))

@@ -20,6 +20,7 @@
 //   activation stage (16 channels): [plane = part*2 + khalf][pos (34x18 halo, padded to 640)][16 B]   40 KiB, x2 buffers
 //   weight chunk (one tap row = 3 k-steps of 16): [q = dx][part][khalf][n = gate*32 + j][16 B]       24 KiB, x3 ring
 #include <stdlib.h>
+#include <type_traits>
 
 #include "cell2_dev.h"
 
@@ -56,15 +57,17 @@ hipError_t launch_split_convert(const float* src, void* dst, long long npix, int
 __host__ __device__ constexpr int cq_stage_of(int p, int tsel) { return p < 4 ? 0 : (p == 4 ? tsel : 1); }
 __host__ __device__ constexpr int cq_tap_of(int p, int tsel) { return p < 4 ? 2 * p + tsel : (p == 4 ? (tsel ? 0 : 8) : 2 * (p - 5) + 1 + tsel); }
 
-// q form: [n_tile][step q][part][k group][n][8 bf16] over the present stage sequence pk.stage_col[0 .. S-1]
+// q form: [n_tile][step q][half = n >> 6][part][k group][n & 63][8 bf16] over the present stage sequence pk.stage_col[0 .. S-1]
+// (a chunk is two 8 KiB halves, one per four column tiles: the half-tile kernel's weight ring turns over in halves)
 __global__ void cell2_pack_q_kernel(const Cell2Pack pk, char* __restrict__ dst) {
     const long long total = (long long)pk.n_tiles * pk.chunks_total * (CQ_WCHUNK / 2);  // bf16 elements
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int i = (int)(e & 7);
         long long r = e >> 3;
-        const int n = (int)(r & 127); r >>= 7;
+        int n = (int)(r & 63); r >>= 6;
         const int kg = (int)(r & 3); r >>= 2;
         const int part = (int)(r & 1); r >>= 1;
+        n += (int)(r & 1) * 64; r >>= 1;                         // half chunk: column tiles 0-3 | 4-7
         const int q = (int)(r % pk.chunks_total);
         const int n_tile = (int)(r / pk.chunks_total);
         const int p = q % 9, tsel = kg >> 1, khalf = kg & 1;
@@ -696,10 +699,16 @@ struct CQFrags { bf16x8 ah[4], al[4], bh[2], bl[2]; };
 
 __host__ __device__ constexpr int cq_slot(int tap) { return (tap / 3) * C2_HALO_W + tap % 3; }
 __host__ __device__ constexpr int cq_kind(int p) { return p == 4 ? 2 : ((p == 1 || p == 7) ? 1 : 0); }   // slot distance tB - tA: 1 | 16 | other buffer
-__host__ __device__ constexpr int cq_aoff(int p) { return (p >= 5 ? C2_ABUF : 0) + cq_slot(cq_tap_of(p, 0)) * 16; }
+__host__ __device__ constexpr int cq_aoff(int p, int abuf) { return (p >= 5 ? abuf : 0) + cq_slot(cq_tap_of(p, 0)) * 16; }
 
-template <class Epi, bool ALLG>
-__global__ __launch_bounds__(512, 2) void cell2_kernel_q(const Cell2Plan P, const Epi epi) {
+// NW = 8: the 32x16 tile, one workgroup per CU. NW = 4: the half tile (16x16 pixels), two workgroups per CU — the epilogue of
+// one (transcendental-bound: ~18 k of a 158 k-cycle tile at NW = 8) and its prologue run under the other's MFMAs. Its weight
+// ring holds TWO chunks and turns over in halves (a chunk = [half][...]: column tiles 0-3 | 4-7): sync point X_q sits before
+// the weight read of column tile 4 of step q; after its barrier every wave has read tiles 0-3 of chunk q and all of chunk q-1, so
+// half 1 of chunk q+1 and half 0 of chunk q+2 are requested there, each with a whole step to land (as in the ring of three).
+template <class Epi, bool ALLG, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, const Epi epi) {
+    using G = CQGeom<NW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -711,26 +720,32 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel_q(const Cell2Plan P, cons
     const long long sidx = (long long)(L & 7) * per_xcd + (L >> 3);
     if ((long long)(L >> 3) >= per_xcd || sidx >= total) return;
     int mt = (int)(sidx / P.n_tiles);
-    const int n_tile = (int)(sidx - (long long)mt * P.n_tiles);
+    int n_tile_ = (int)(sidx - (long long)mt * P.n_tiles);
+    if ((P._q & 8) && per_xcd % P.n_tiles == 0) {   // diagnostic: the N tiles of a pixel tile half a launch apart (no L2 sharing possible)
+        const long long per_n = per_xcd / P.n_tiles, i = L >> 3;
+        n_tile_ = (int)(i / per_n);
+        mt = (int)(((long long)(L & 7) * per_xcd) / P.n_tiles + i % per_n);
+    }
+    const int n_tile = n_tile_;
     const int tx = mt % P.tiles_x;
     mt /= P.tiles_x;
     const int ty = mt % P.tiles_y;
     const int b = mt / P.tiles_y;
-    const int x0 = tx * 16, y0 = ty * 32;
+    const int x0 = tx * 16, y0 = ty * G::TH;
     int ngr = 4;
     if constexpr (!ALLG) { ngr = P.n_groups - n_tile * P.gpt; if (ngr > P.gpt) ngr = P.gpt; }
 
     char* const Abuf = smem;
-    char* const Wbuf = smem + 2 * C2_ABUF;
+    char* const Wbuf = smem + 2 * G::ABUF;
 
-    int pixoff[5], choff[5];
+    int pixoff[G::NPIECE], choff[G::NPIECE];
 #pragma unroll
-    for (int u = 0; u < 5; ++u) {
-        const int piece = tid + 512 * u;
-        const int plane = piece / C2_PLANE_POS, pos = piece - plane * C2_PLANE_POS;
+    for (int u = 0; u < G::NPIECE; ++u) {
+        const int piece = tid + G::NT * u;
+        const int plane = piece / G::PLANE_POS, pos = piece - plane * G::PLANE_POS;
         const int hy = pos / C2_HALO_W, hx = pos - hy * C2_HALO_W;
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = pos < C2_NPOS && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+        const bool ok = pos < G::NPOS && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
         pixoff[u] = ok ? gy * P.W + gx : -1;
         choff[u] = (plane & 1) * 32 + (plane >> 1) * 16;
     }
@@ -747,10 +762,13 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel_q(const Cell2Plan P, cons
         const unsigned prow = isx ? xrow : hrow;
         const char* src = pixoff[u] >= 0 ? base + (size_t)((unsigned)pixoff[u] * (unsigned long long)prow) + choff[u]
                                          : reinterpret_cast<const char*>(c2_zero16);
-        c2_dma16(src, Abuf + buf * C2_ABUF + dma_off + u * 8192);
+        c2_dma16(src, Abuf + buf * G::ABUF + dma_off + u * (G::NT * 16));
     };
-    auto issue_W1 = [&](int chunk, int slot, int u) {
-        c2_dma16(wtile + (size_t)chunk * CQ_WCHUNK + u * 8192, Wbuf + slot * CQ_WCHUNK + dma_off + u * 8192);
+    auto issue_Wh = [&](int chunk, int slot, int half) {   // one 8 KiB half of a weight chunk
+#pragma unroll
+        for (int w = 0; w < G::WPIECE; ++w)
+            c2_dma16(wtile + (size_t)chunk * CQ_WCHUNK + half * 8192 + w * (G::NT * 16),
+                     Wbuf + slot * CQ_WCHUNK + half * 8192 + w * (G::NT * 16) + dma_off);
     };
 
     f32x4 acc[4][8];
@@ -762,35 +780,41 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel_q(const Cell2Plan P, cons
             for (int r = 0; r < 4; ++r) acc[m][nt][r] = 0.0f;
 
     // lane bases into the activation buffers (tap (0,0), tile row 4 * wave, buffer 0, hi plane): k group = tap half * 2 + channel half
-    const int a_lane = (kg & 1) * C2_PLANE + ((4 * wave) * C2_HALO_W + r16) * 16;
+    const int a_lane = (kg & 1) * G::PLANE + ((4 * wave) * C2_HALO_W + r16) * 16;
     const int base1 = a_lane + (kg >> 1) * 16;                        // tB one slot right of tA
     const int base16 = a_lane + (kg >> 1) * 256;                      // tB = (dy + 1, dx - 2): 16 slots further
-    const int baseX = a_lane + (kg >> 1) * (C2_ABUF - cq_slot(8) * 16);  // cross step: tap 0 of the odd stage (buffer 1)
-    const int w_lane = kg * 2048 + r16 * 16;
+    const int baseX = a_lane + (kg >> 1) * (G::ABUF - cq_slot(8) * 16);  // cross step: tap 0 of the odd stage (buffer 1)
+    // weight fragments: lane base of ring slot 0 (wb0) and, NW = 4, of slot 1 (wb1); with two slots and nine steps per period
+    // the slot of period step p alternates between periods: the two bases swap at each period end
+    int wb0 = 2 * G::ABUF + kg * 1024 + r16 * 16, wb1 = wb0 + CQ_WCHUNK;
     CQFrags F;
     auto load_A1 = [&](int p, int m, int bx) {   // activation fragments (hi, lo) of tile row m for period step p
         const int base = cq_kind(p) == 0 ? base1 : (cq_kind(p) == 1 ? base16 : bx);
-        const char* a = smem + base + cq_aoff(p) + m * (C2_HALO_W * 16);
+        const char* a = smem + base + cq_aoff(p, G::ABUF) + m * (C2_HALO_W * 16);
         F.ah[m] = *reinterpret_cast<const bf16x8*>(a);
-        F.al[m] = *reinterpret_cast<const bf16x8*>(a + 2 * C2_PLANE);
+        F.al[m] = *reinterpret_cast<const bf16x8*>(a + 2 * G::PLANE);
     };
-    auto load_B = [&](int slot, int nt) {        // weight fragments (hi, lo) of column tile nt -> set nt & 1
-        const char* w = Wbuf + slot * CQ_WCHUNK + w_lane + nt * 256;
+    auto load_B = [&](int p, int nt) {           // weight fragments (hi, lo) of column tile nt of period step p -> set nt & 1
+        const int base = NW == 8 ? wb0 + (p % 3) * CQ_WCHUNK : ((p & 1) ? wb1 : wb0);
+        const char* w = smem + base + (nt >> 2) * 8192 + (nt & 3) * 256;
         F.bh[nt & 1] = *reinterpret_cast<const bf16x8*>(w);
-        F.bl[nt & 1] = *reinterpret_cast<const bf16x8*>(w + 8192);
+        F.bl[nt & 1] = *reinterpret_cast<const bf16x8*>(w + 4096);
     };
 
-    // Waves 4-7 meet each sync point at THEIR tile 1 instead of tile 5, i.e. they run half a chunk behind waves 0-3: the two waves
-    // of a SIMD then do not reach fragment reads, MFMA groups and the barrier in lockstep (MI355X_MICROARCH.md, two waves per SIMD,
-    // item 9). Bit-identical outputs; +0.4..0.8 % on every block shape (tools/ab_exp.py; experiment bit 0 switches it off). A static
-    // s_setprio 1 for waves 4-7 instead of the per-group flips measured -0.5..0.8 % and is not kept.
-    const bool late_sync = !(P._q & 1) && wave >= 4;
+    // NW = 8: waves 4-7 meet each sync point at THEIR tile 1 instead of tile 5, i.e. they run half a chunk behind waves 0-3: the two
+    // waves of a SIMD then do not reach fragment reads, MFMA groups and the barrier in lockstep (MI355X_MICROARCH.md, two waves per
+    // SIMD, item 9). Bit-identical outputs; +0.4..0.8 % on every block shape (tools/ab_exp.py; experiment bit 0 switches it off). A
+    // static s_setprio 1 for waves 4-7 instead of the per-group flips measured -0.5..0.8 % and is not kept.
+    const bool late_sync = NW == 8 && !(P._q & 1) && wave >= 4;
     if (S > 0) {
 #pragma unroll
-        for (int u = 0; u < 5; ++u) issue_A1(0, 0, u);
-        issue_W1(0, 0, 0); issue_W1(0, 0, 1);
-        if (Q > 1) { issue_W1(1, 1, 0); issue_W1(1, 1, 1); C2_WAIT_VM(2); }
-        else C2_WAIT_VM(0);
+        for (int u = 0; u < G::NPIECE; ++u) issue_A1(0, 0, u);
+        issue_Wh(0, 0, 0); issue_Wh(0, 0, 1);
+        if (Q > 1) {   // NW = 8: all of chunk 1; NW = 4: its first half — two copies per thread either way
+            issue_Wh(1, 1, 0);
+            if constexpr (NW == 8) issue_Wh(1, 1, 1);
+            C2_WAIT_VM(2);
+        } else C2_WAIT_VM(0);
         c2_barrier();
 #pragma unroll
         for (int m = 0; m < 4; ++m) load_A1(0, m, a_lane);
@@ -800,6 +824,7 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel_q(const Cell2Plan P, cons
         const bool odd = s0 + 1 < S;         // the period's odd stage exists
         const bool more = s0 + 2 < S;        // another period follows
         const int q0 = (s0 >> 1) * 9;
+        const int par = (s0 >> 1) & 1;       // NW = 4: ring slot of period step 0
         const int bx = odd ? baseX : a_lane;  // without an odd stage the cross step's second half multiplies zero weights: read valid data
 #pragma unroll
         for (int p = 0; p < 9; ++p) {
@@ -807,15 +832,25 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel_q(const Cell2Plan P, cons
                 const int q = q0 + p;
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) {
-                    if ((nt == 5 && !late_sync) || (nt == 1 && late_sync)) {
-                        // ---- sync point S_q (waves 0-3 before their tile 5, waves 4-7 before their tile 1: see late_sync) ----
-                        if ((p == 1 && odd) || (p == 6 && more)) C2_WAIT_VM(5); else C2_WAIT_VM(0);   // the stage copy issued one step ago may still fly
-                        c2_barrier();
+                    const bool stage_flies = (p == 1 && odd) || (p == 6 && more);   // the stage copy issued one step ago may still fly
+                    if constexpr (NW == 8) {
+                        if ((nt == 5 && !late_sync) || (nt == 1 && late_sync)) {
+                            // ---- sync point S_q (waves 0-3 before their tile 5, waves 4-7 before their tile 1: see late_sync) ----
+                            if (stage_flies) C2_WAIT_VM(5); else C2_WAIT_VM(0);
+                            c2_barrier();
+                        }
+                    } else {
+                        if (nt == 3) {
+                            // ---- sync point X_q: the fragments of tiles 0-3 are in registers (lgkmcnt) before their half chunk is given away ----
+                            if (stage_flies) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                            c2_barrier();
+                        }
                     }
                     // ---- weight fragments of the next column tile ----
                     //      (after the last step these reads, like the row refills below, fetch bytes nobody uses: cheaper than a branch)
-                    if (nt < 7) load_B(p % 3, nt + 1);
-                    else load_B((p + 1) % 3, 0);
+                    if (nt < 7) load_B(p, nt + 1);
+                    else load_B(p + 1, 0);
                     // ---- 12 MFMAs of column tile nt ----
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -831,22 +866,45 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel_q(const Cell2Plan P, cons
                         if (nt == 7) load_A1(p == 8 ? 0 : p + 1, m, bx);
                     }
                     __builtin_amdgcn_s_setprio(0);
-                    // ---- this sync point's copies, behind the MFMAs of column tiles 5..7: the weight chunk first, then the stage ----
-                    const int i0 = late_sync ? 1 : 5;   // first tile after this wave's sync point
-                    if (nt == i0 && q + 2 < Q) { issue_W1(q + 2, (p + 2) % 3, 0); issue_W1(q + 2, (p + 2) % 3, 1); }
-                    if (p == 0 && odd) {
-                        if (nt == i0 + 1) { issue_A1(s0 + 1, 1, 0); issue_A1(s0 + 1, 1, 1); }
-                        if (nt == i0 + 2) { issue_A1(s0 + 1, 1, 2); issue_A1(s0 + 1, 1, 3); issue_A1(s0 + 1, 1, 4); }
-                    }
-                    if (p == 5 && more) {
-                        if (nt == i0 + 1) { issue_A1(s0 + 2, 0, 0); issue_A1(s0 + 2, 0, 1); }
-                        if (nt == i0 + 2) { issue_A1(s0 + 2, 0, 2); issue_A1(s0 + 2, 0, 3); issue_A1(s0 + 2, 0, 4); }
+                    // ---- this sync point's copies, behind the MFMAs of the following column tiles: the weights first, then the stage ----
+                    if constexpr (NW == 8) {
+                        const int i0 = late_sync ? 1 : 5;   // first tile after this wave's sync point
+                        if (nt == i0 && q + 2 < Q) { issue_Wh(q + 2, (p + 2) % 3, 0); issue_Wh(q + 2, (p + 2) % 3, 1); }
+                        if (p == 0 && odd) {
+                            if (nt == i0 + 1) { issue_A1(s0 + 1, 1, 0); issue_A1(s0 + 1, 1, 1); }
+                            if (nt == i0 + 2) { issue_A1(s0 + 1, 1, 2); issue_A1(s0 + 1, 1, 3); issue_A1(s0 + 1, 1, 4); }
+                        }
+                        if (p == 5 && more) {
+                            if (nt == i0 + 1) { issue_A1(s0 + 2, 0, 0); issue_A1(s0 + 2, 0, 1); }
+                            if (nt == i0 + 2) { issue_A1(s0 + 2, 0, 2); issue_A1(s0 + 2, 0, 3); issue_A1(s0 + 2, 0, 4); }
+                        }
+                    } else {
+                        if (nt == 3) {
+                            const int sl = (p & 1) ^ par;   // ring slot of chunk q (and q + 2)
+                            if (q + 1 < Q) issue_Wh(q + 1, sl ^ 1, 1);
+                            if (q + 2 < Q) issue_Wh(q + 2, sl, 0);
+                        }
+                        if ((p == 0 && odd) || (p == 5 && more)) {
+                            const int st = p == 0 ? s0 + 1 : s0 + 2, bf = p == 0 ? 1 : 0;
+                            if (nt == 4) { issue_A1(st, bf, 0); issue_A1(st, bf, 1); issue_A1(st, bf, 2); }
+                            if (nt == 5) { issue_A1(st, bf, 3); issue_A1(st, bf, 4); issue_A1(st, bf, 5); }
+                        }
                     }
                 }
             }
         }
+        if constexpr (NW == 4) { const int t = wb0; wb0 = wb1; wb1 = t; }
     }
     epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+}
+
+// Half tile (cell2_kernel_q<.., 4>: 16x16-pixel tiles, two workgroups per CU) or the 32x16 tile? Measured (tools/ab_exp.py,
+// B=128, five block shapes): the half tile is +1.5..7 % per forward step and +1.3..3 % per block forward + backward (one shape
+// -0.5 %) — 14 % fewer cycles, of which the chip takes 10 % back as clock (1.96 -> 1.77 GHz: MFMA busy 60 -> 69 %, power-bound).
+// VPX_OPT_EXPERIMENT bit 2 forces the full tile (A/B runs, tests).
+static bool cell2_half_tile(const Cell2Plan& p, bool ragged_ok) {
+    if (!ragged_ok && (p.H & 15) != 0) return false;   // the fused step's vector epilogue wants tiles inside the image
+    return !(g_experiment & 4);
 }
 
 template <class Epi, bool ALLG>
@@ -855,7 +913,9 @@ static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStrea
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel<Epi, ALLG>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG>), hipFuncAttributeMaxDynamicSharedMemorySize, CQ_LDS);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, CQGeom<8>::LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, CQGeom<4>::LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -863,8 +923,15 @@ static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStrea
     p.grid_m = plan.B * plan.tiles_x * plan.tiles_y;
     if (plan.qform) {
         p._q = g_experiment;
+        if (cell2_half_tile(p, std::is_same<Epi, Conv2Epi>::value)) {
+            p.tiles_y = (p.H + 15) / 16;
+            p.grid_m = p.B * p.tiles_x * p.tiles_y;
+            const long long per_xcd_h = ((long long)p.grid_m * p.n_tiles + 7) / 8;
+            hipLaunchKernelGGL((cell2_kernel_q<Epi, ALLG, 4>), dim3((unsigned)(per_xcd_h * 8)), dim3(256), CQGeom<4>::LDS, s, p, epi);
+            return hipGetLastError();
+        }
         const long long per_xcd_q = ((long long)p.grid_m * p.n_tiles + 7) / 8;
-        hipLaunchKernelGGL((cell2_kernel_q<Epi, ALLG>), dim3((unsigned)(per_xcd_q * 8)), dim3(512), CQ_LDS, s, p, epi);
+        hipLaunchKernelGGL((cell2_kernel_q<Epi, ALLG, 8>), dim3((unsigned)(per_xcd_q * 8)), dim3(512), CQGeom<8>::LDS, s, p, epi);
         return hipGetLastError();
     }
 #ifdef VPX_ABLATE
@@ -909,15 +976,16 @@ __global__ void conv2_pack_kernel(const Conv2Pack pk, char* __restrict__ dst) {
     }
 }
 
-// q form of the same pack: [n_tile][step q][part][k group][n][8 bf16], steps as in cell2_pack_q_kernel over the C / 16 stages
+// q form of the same pack: [n_tile][step q][half][part][k group][n & 63][8 bf16], steps as in cell2_pack_q_kernel over the C / 16 stages
 __global__ void conv2_pack_q_kernel(const Conv2Pack pk, int S, char* __restrict__ dst) {
     const long long total = (long long)pk.n_tiles * pk.chunks_total * (CQ_WCHUNK / 2);  // bf16 elements
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int i = (int)(e & 7);
         long long r = e >> 3;
-        const int n = (int)(r & 127); r >>= 7;
+        int n = (int)(r & 63); r >>= 6;
         const int kg = (int)(r & 3); r >>= 2;
         const int part = (int)(r & 1); r >>= 1;
+        n += (int)(r & 1) * 64; r >>= 1;                         // half chunk: column tiles 0-3 | 4-7
         const int q = (int)(r % pk.chunks_total);
         const int n_tile = (int)(r / pk.chunks_total);
         const int p = q % 9, tsel = kg >> 1, khalf = kg & 1;

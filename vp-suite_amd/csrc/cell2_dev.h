@@ -18,8 +18,26 @@ constexpr int C2_WCHUNK = 3 * 2 * 2 * 128 * 16; // 24576 B
 constexpr int C2_LDS = 2 * C2_ABUF + 3 * C2_WCHUNK;  // 155648 B <= 160 KiB
 
 // 16x16x32 form ("q form", cell2_kernel_q below): same activation stage image; one weight chunk = one K = 32 step
-constexpr int CQ_WCHUNK = 2 * 4 * 128 * 16;     // 16384 B: [part][k group = tap half * 2 + channel half][n = gate*32 + j][16 B]
+constexpr int CQ_WCHUNK = 2 * 2 * 4 * 64 * 16;  // 16384 B: [half = n >> 6][part][k group = tap half * 2 + channel half][n & 63][16 B], n = gate*32 + j
 constexpr int CQ_LDS = 2 * C2_ABUF + 3 * CQ_WCHUNK;  // 131072 B (the epilogue's transposition space needs 8 x 16 KiB as well)
+
+// Geometry of the q-form workgroup tile: NW waves own 4 * NW tile rows of 16 pixels.
+//   NW = 8: the 32x16 tile, one workgroup per CU, three whole weight chunks in the ring.
+//   NW = 4: the "half tile" (16x16 pixels, 256 threads, 80 KiB of LDS): TWO workgroups per CU, so that one's epilogue and
+//           prologue run under the other's MFMAs; the weight ring holds two chunks and turns over in halves.
+template <int NW>
+struct CQGeom {
+    static constexpr int NT = 64 * NW;                          // threads
+    static constexpr int TH = 4 * NW;                           // tile rows
+    static constexpr int NPOS = (TH + 2) * C2_HALO_W;           // halo positions (612 | 324)
+    static constexpr int PLANE_POS = NW == 8 ? 640 : 384;       // padded: 4 planes = NPIECE pieces per thread exactly
+    static constexpr int PLANE = PLANE_POS * 16;
+    static constexpr int ABUF = 4 * PLANE;                      // 40960 | 24576 B
+    static constexpr int NPIECE = 4 * PLANE_POS / NT;           // stage-copy DMAs per thread: 5 | 6
+    static constexpr int WSLOTS = NW == 8 ? 3 : 2;
+    static constexpr int WPIECE = CQ_WCHUNK / 2 / (NT * 16);    // DMAs per thread and half chunk: 1 | 2
+    static constexpr int LDS = 2 * ABUF + WSLOTS * CQ_WCHUNK;   // 131072 | 81920 B (the epilogue needs NW x 16 KiB)
+};
 
 __device__ const float c2_zero16[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};  // source of out-of-image pieces
 
