@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prewarm", type=float, default=0.5,
+                    help="seconds of untimed steps before the W warmup steps (brings an idle GPU out of its low-power state); 0 = none")
     ap.add_argument("--batch", type=int, default=128,
                     help="per-GPU batch. 128 fills the chip on every block of the model; the reference's default training "
                          "batch_size is 32 (defaults.py:37-64); both, and batch 4, are reported in `extras`")
@@ -189,6 +191,29 @@ class Runner:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, prof.summary()
+
+    def prewarm(self, seconds):
+        """Untimed steps for about `seconds` of wall time BEFORE the W warmup steps: an idle MI355X sits in a low-power state
+        (rocm-smi: sclk ~100 MHz) and a short run — B=4: 23 steps of 2 ms — can end inside the clock ramp (measured: the first
+        process on an idle box 4.2 ms per step, the next two 2.12). Same step count on every rank. Returns the steps run."""
+        import torch
+        import torch.distributed as dist
+        if seconds <= 0:
+            return 0
+        self.step()
+        self.barrier()
+        t0 = time.perf_counter()
+        self.step()
+        self.barrier()
+        n = min(2000, int(math.ceil(seconds / max(time.perf_counter() - t0, 1e-6))))
+        if self.use_dist:
+            t = torch.tensor([n], device=self.dev, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n = int(t.item())
+        for _ in range(n):
+            self.step()
+        self.barrier()
+        return n + 2
 
     def calibrated_steps(self, seconds):
         """Step count for a timed region of at least `seconds` (same count on every rank)."""
@@ -394,6 +419,7 @@ def main():
                 channels=args.channels, context=args.context, pred=args.pred, layers=args.layers,
                 cell=tuple(int(v) for v in args.cell.split(",")) if args.cell else None)
     runner = Runner(spec, dev, rank, world, use_dist)
+    prewarm_steps = runner.prewarm(args.prewarm)
     elapsed, ps = runner.timed(args.steps, args.warmup)
 
     out = None
@@ -414,7 +440,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": spec.workload(), "mode": spec.mode, "semantics": runner.semantics,
                        "per_gpu_batch": spec.batch, "global_batch": spec.batch * world, "parallelism": f"dp{world}",
-                       "ranks": world, "backend": ("nccl (RCCL)" if use_dist else "single process")},
+                       "ranks": world, "backend": ("nccl (RCCL)" if use_dist else "single process"),
+                       "prewarm": {"seconds": args.prewarm, "steps": prewarm_steps,
+                                   "what": "untimed steps before the W warmup steps: clock ramp out of the idle power state"}},
             "roofline": roofline(spec, ps),
         }
     cpu_model = runner.model if (world == 1 and not args.no_cpu_baseline and spec.model == "convlstm-shi") else None

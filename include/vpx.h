@@ -209,9 +209,13 @@ int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float*
 /* The same layer on SPLIT-format input (x_split: [N,H,W,Ci] split-encoded; image n at (n / x_nT) * x_bstride + (n % x_nT) *
  * x_tstride bytes, x_bstride = 0: dense, x_nT <= 1: plain batch), on the schedule-driven K = 32 kernel (csrc/convq.hip): bf16x3,
  * Ci % 16 == 0, stride 1 or 2, taps within one pixel of the (sub-)image grid (3x3 pad 1, 4x4 stride 2 pad 1, plain or transposed)
- * — vpx_conv2d_ex_takes_split says whether a descriptor qualifies. y (fp32) and y_split may each be NULL, not both.
+ * — vpx_conv2d_ex_takes_split says whether a descriptor qualifies (0 no; 1 yes; 2 yes, and on the schedule-driven K = 32 kernel,
+ *   which is worth a vpx_split_convert of an fp32 input for stride-2 transposed layers). y (fp32) and y_split may each be NULL, not both.
  * weights_packed: the workspace still holds this layer's packed weights (same values, same descriptor). */
 int vpx_conv2d_ex_takes_split(const vpx_conv_desc* d);
+/* fp32 channels-last pixels [n_pixels][C] -> the split-bf16 operand format (per pixel and 8 channels: 8 hi bf16, 8 lo bf16; the
+ * same n_pixels * C * 4 bytes), C % 8 == 0: what the recurrent blocks and vpx_conv2d_ex_fwd_split write themselves. */
+int vpx_split_convert(const float* x, void* x_split, long long n_pixels, int C, void* stream);
 size_t vpx_conv2d_ex_split_workspace_bytes(const vpx_conv_desc* d);
 int vpx_conv2d_ex_fwd_from_split(const vpx_conv_desc* d, const void* x_split, long long x_bstride, long long x_tstride, int x_nT,
                                  const float* w, const float* bias, float* y, void* y_split, int weights_packed, void* workspace,

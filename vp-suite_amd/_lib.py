@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
     "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_conv2d_bwd_workspace_bytes", "vpx_conv2d_nhwc_bwd",
     "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd", "vpx_conv2d_ex_fwd_split",
-    "vpx_conv2d_ex_takes_split", "vpx_conv2d_ex_split_workspace_bytes", "vpx_conv2d_ex_fwd_from_split",
+    "vpx_conv2d_ex_takes_split", "vpx_split_convert", "vpx_conv2d_ex_split_workspace_bytes", "vpx_conv2d_ex_fwd_from_split",
     "vpx_conv2d_ex_bwd_workspace_bytes", "vpx_conv2d_ex_bwd",
     "vpx_conv2d_nhwc_fwd_ex", "vpx_leaky_bwd_workspace_bytes", "vpx_leaky_bwd", "vpx_axpy",
     "vpx_acst_gates_fwd", "vpx_acst_gates_bwd", "vpx_st_out_fwd", "vpx_st_out_bwd",
@@ -169,6 +169,8 @@ def lib():
         L.vpx_conv2d_ex_fwd_split.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 5 + [vp, sz, vp]
         L.vpx_conv2d_ex_takes_split.restype = ci
         L.vpx_conv2d_ex_takes_split.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.vpx_split_convert.restype = ci
+        L.vpx_split_convert.argtypes = [vp, vp, ll, ci, vp]
         L.vpx_conv2d_ex_split_workspace_bytes.restype = sz
         L.vpx_conv2d_ex_split_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
         L.vpx_conv2d_ex_fwd_from_split.restype = ci

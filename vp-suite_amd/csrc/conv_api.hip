@@ -289,16 +289,20 @@ int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float*
     return ex_forward(d, g, x, w, bias, y, wpk, (hipStream_t)stream_, reinterpret_cast<char*>(y_split));
 }
 
-// Which kernel takes a layer on split input (measured at the bench shapes, tools/ab_glue.py): the schedule-driven K = 32 kernel
-// where its 32-row tiles fill (tile space >= 32 rows) and the layer has >= 64 output channels (stride-2 convolution 64 -> 64 at
-// 64x64: 0.73 -> 0.64 ms, stride-2 transposed 4x4 at 32x32: 1.8 -> 1.7 ms per 1280 frames); else the first-generation kernel,
-// which stages the split tensor without its hi / lo conversion. VPX_CONVQ=0 / 2: never / wherever it applies.
+// Which kernel takes a layer on split input (measured, tools/ab_glue.py, ms per 1280 frames, first generation on split input ->
+// convq on half tiles): layers with >= 64 output channels — stride-2 convolutions 64 -> 64 at 64x64 0.72 -> 0.60 and 96 -> 96 at
+// 32x32 0.32 -> 0.25, stride-2 transposed 4x4 96 -> 96 at 16x16 0.48 -> 0.38 and at 32x32 1.79 -> 1.47 (at 40 frames 0.12 -> 0.04 /
+// 0.15 -> 0.06: the phase form is one launch) — but plain convolutions only on grids of >= 256 workgroups (40 frames: 0.045 -> 0.049).
+// 64 -> 16 3x3 stays on the first-generation kernel (0.92 vs 1.22). VPX_CONVQ=0 / 2: never / wherever it applies.
 static bool exq_preferred(const vpx_conv_desc* d, const ExGeo& g, ConvQProblem& pr) {
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("VPX_CONVQ"); mode = e ? atoi(e) : 1; }
     if (mode == 0 || !exq_problem(d, g, pr) || convq_wpk_bytes(pr) == 0) return false;
     if (mode == 2) return true;
-    return pr.H >= 32 && d->Co >= 64;
+    if (d->Co < 64) return false;
+    if (pr.phases) return true;
+    const long long wgs = (long long)pr.N * ((pr.W + 15) / 16) * ((pr.H + 15) / 16) * (((d->Co + 31) / 32 + 3) / 4);
+    return wgs >= 256;
 }
 static bool ex_split_gen1_ok(const vpx_conv_desc* d) {
     return d->precision != VPX_PREC_F32 && (d->Ci & 7) == 0;
@@ -308,7 +312,8 @@ int vpx_conv2d_ex_takes_split(const vpx_conv_desc* d) {
     ExGeo g;
     static thread_local ConvQProblem pr;
     if (ex_check(d, g) != VPX_OK) return 0;
-    return (exq_preferred(d, g, pr) || ex_split_gen1_ok(d)) ? 1 : 0;
+    if (exq_preferred(d, g, pr)) return 2;
+    return ex_split_gen1_ok(d) ? 1 : 0;
 }
 
 size_t vpx_conv2d_ex_split_workspace_bytes(const vpx_conv_desc* d) {

@@ -137,13 +137,23 @@ struct ConvQEpi {
 // phases of a stride-2 transposed convolution, NTS = 2); otherwise every step accumulates into tiles [0, NTS).
 // The loop body is one weight chunk = 8 column tiles with static tile / register indices; what is read at run time per step
 // is only where its two taps sit (offA / offB) and whether it exists.
-template <int NTS, bool PHASE, int HALO>
-__global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const ConvQEpi epi) {
+// NW = 8: 32x16-pixel tile, one workgroup per CU, ring of three weight chunks. NW = 4: the half tile (16x16 pixels, 256 threads,
+// 80 KiB of LDS) — two workgroups per CU, so that one's stage-copy waits and its epilogue run under the other's MFMAs; ring of TWO
+// weight chunks: chunk c+1 is requested at the sync of chunk c and awaited at the sync of chunk c+1 (its first column tile's
+// fragments are read after that sync instead of ahead of it).
+constexpr int convq_ppos(int halo, int nw) { return nw == 8 ? (halo == 2 ? 640 : 768) : (halo == 2 ? 384 : 448); }
+
+template <int NTS, bool PHASE, int HALO, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, const ConvQEpi epi) {
     constexpr int HW_ = 16 + HALO;                 // halo tile width
-    constexpr int NPOS = (32 + HALO) * HW_;        // halo positions of a 32x16 tile
-    constexpr int PPOS = HALO == 2 ? 640 : 768;    // padded: 4 planes = NP pieces per thread
-    constexpr int PLANE = PPOS * 16, ABUF = 4 * PLANE, NP = 4 * PPOS / 512;
+    constexpr int NT = 64 * NW, TH = 4 * NW;       // threads, tile rows
+    constexpr int NPOS = (TH + HALO) * HW_;        // halo positions of the tile
+    constexpr int PPOS = convq_ppos(HALO, NW);     // padded: 4 planes = NP pieces per thread
+    constexpr int PLANE = PPOS * 16, ABUF = 4 * PLANE, NP = 4 * PPOS / NT;
     constexpr int NSUB = 8 / NTS;                  // steps per chunk
+    constexpr int WSLOTS = NW == 8 ? 3 : 2;
+    constexpr int WP = CQ_WCHUNK / (NT * 16);      // weight-chunk DMAs per thread: 2 | 4
+    static_assert(NP == 5 || NP == 6, "stage copy: 5 or 6 pieces per thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
     mt /= P.tiles_x;
     const int ty = mt % P.tiles_y;
     const int b = mt / P.tiles_y;
-    const int x0 = tx * 16, y0 = ty * 32;
+    const int x0 = tx * 16, y0 = ty * TH;
     int ngr = P.n_groups - n_tile * P.gpt;   // 32-column groups of this N tile that hold outputs
     if (ngr > P.gpt) ngr = P.gpt;
     const int tmask = (1 << (2 * ngr)) - 1;  // accumulator tiles of those groups: the MFMAs of the others are skipped
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
     int pofs[NP], pval[NP];
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
-        const int piece = tid + 512 * u;
+        const int piece = tid + NT * u;
         const int plane = piece / PPOS, pos = piece - plane * PPOS;
         const int hy = pos / HW_, hx = pos - hy * HW_;
         const int gy = y0 + P.oy + hy, gx = x0 + P.ox + hx;
@@ -216,10 +226,12 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
     auto issue_A1 = [&](const Src& sc, int buf, int u) {
         const bool ok = (sc.base != nullptr) & (((pval[u] >> sc.seg) & 1) != 0);
         const char* src = ok ? sc.base + pofs[u] : reinterpret_cast<const char*>(c2_zero16);
-        c2_dma16(src, Abuf + buf * ABUF + dma_off + u * 8192);
+        c2_dma16(src, Abuf + buf * ABUF + dma_off + u * (NT * 16));
     };
-    auto issue_W1 = [&](int chunk, int slot, int u) {
-        c2_dma16(wtile + (size_t)chunk * CQ_WCHUNK + u * 8192, Wbuf + slot * CQ_WCHUNK + dma_off + u * 8192);
+    auto issue_W1 = [&](int chunk, int slot, int u) {   // half u of a weight chunk
+#pragma unroll
+        for (int w = 0; w < WP / 2; ++w)
+            c2_dma16(wtile + (size_t)chunk * CQ_WCHUNK + u * 8192 + w * (NT * 16), Wbuf + slot * CQ_WCHUNK + dma_off + u * 8192 + w * (NT * 16));
     };
 
     f32x4 acc[4][8];
@@ -286,9 +298,12 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
             if (c > 0) {
                 if (a_pending) { if (NP == 5) C2_WAIT_VM(5); else C2_WAIT_VM(6); } else C2_WAIT_VM(0);
                 c2_barrier();
+                if (WSLOTS == 2) load_B(c & 1, 0);   // ring of two: this chunk landed with this sync
             }
-            const int slot = c % 3, nslot = (c + 1) % 3;
-            const int wq = (c + 2 < P.nchunk_total && !(P.dbg & 4)) ? c + 2 : -1, wq_slot = (c + 2) % 3;
+            const int slot = c % WSLOTS, nslot = (c + 1) % WSLOTS;
+            // ring of three: chunk c+2 into the slot chunk c-1 has left; ring of two: chunk c+1 (chunk 1 went out with the prologue)
+            const int wq_c = WSLOTS == 3 ? c + 2 : (c > 0 ? c + 1 : 1 << 30);
+            const int wq = (wq_c < P.nchunk_total && !(P.dbg & 4)) ? wq_c : -1, wq_slot = wq_c % WSLOTS;
             bool aq = false, aq_first = false; int aq_buf = 0;
             if (cur.issue && !(P.dbg & 2)) {
                 const int st = base + cur.istage;
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void convq_kernel(const ConvQPlan P, const 
                 for (int k = 0; k < NTS; ++k) {
                     const int t = j * NTS + k;           // tile inside the weight chunk
                     const int at = PHASE ? t : k;        // accumulator tile
-                    if (t < 7) load_B(slot, t + 1); else load_B(nslot, 0);
+                    if (t < 7) load_B(slot, t + 1); else if (WSLOTS == 3) load_B(nslot, 0);
                     const bool go = on && ((tmask >> at) & 1) && !(P.dbg & 1);
                     if (go) {
                         __builtin_amdgcn_s_setprio(1);
@@ -427,8 +442,15 @@ struct QSub { int chunk, pos; QTap a, b; bool has_b; };   // pos: which of the c
 struct QBuild {
     ConvQPlan P;
     ConvQPackArgs pk;
-    int halo, NTS;
+    int halo, NTS, nw;
 };
+
+// waves per workgroup: 4 = the half tile (two workgroups per CU), 3x3-halo layers only; VPX_CONVQ_NW=8 keeps the 32x16 tile
+int convq_pick_nw(const ConvQProblem& pr) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("VPX_CONVQ_NW"); env = e ? atoi(e) : 4; }
+    return (pr.halo == 2 && env == 4) ? 4 : 8;
+}
 
 int seg_of_stage(const ConvQProblem& pr, int s) {
     int first = 0;
@@ -436,9 +458,10 @@ int seg_of_stage(const ConvQProblem& pr, int s) {
     return pr.nseg - 1;
 }
 
-int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
+int convq_build_impl(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
     if (pr.halo != 2 && pr.halo != 4) { set_error("convq: halo %d", pr.halo); return VPX_ERR_ARG; }
-    const int HW_ = 16 + pr.halo, PPOS = pr.halo == 2 ? 640 : 768, ABUF = 4 * PPOS * 16, org = pr.halo / 2;
+    const int nw = convq_pick_nw(pr);
+    const int HW_ = 16 + pr.halo, PPOS = convq_ppos(pr.halo, nw), ABUF = 4 * PPOS * 16, org = pr.halo / 2;
     int S = 0;
     for (int i = 0; i < pr.nseg; ++i) S += pr.seg[i].nstage;
     if (S < 1 || pr.nseg < 1 || pr.nseg > 4 || pr.ngs < 1 || pr.ngs > 4) { set_error("convq: bad problem (S=%d nseg=%d ngs=%d)", S, pr.nseg, pr.ngs); return VPX_ERR_ARG; }
@@ -463,7 +486,7 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
     // a short K loop is laid out in full; a long one with identical stages as a pass over two stages that repeats
     bool periodic = all_stages;
     if (periodic && (((S * nterm0 + 1) / 2 + cpack - 1) / cpack) * NSUB <= 64) periodic = false;
-    if (periodic && cpack > 1) return convq_build(pr, out, 1);   // (a pass of 2 stages does not divide into side-by-side steps)
+    if (periodic && cpack > 1) return convq_build_impl(pr, out, 1);   // (a pass of 2 stages does not divide into side-by-side steps)
     const int SP = periodic ? 2 : S;
     const int NSV = periodic ? 3 * SP : S;   // stages laid out (periodic: three passes, the middle one is the steady state)
 
@@ -549,7 +572,7 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
                 if (k >= 0 && ev_stage[k] < 0) { ci = k; afirst = m_af[mode]; late = m_late[mode]; break; }
         }
         if (ci < 0) {
-            if (cpack > 1) return convq_build(pr, out, 1);   // short stages: one step per weight chunk gives every stage its chunk boundaries
+            if (cpack > 1) return convq_build_impl(pr, out, 1);   // short stages: one step per weight chunk gives every stage its chunk boundaries
             set_error("convq: stage %d cannot be double-buffered (first use chunk %d, buffer free from chunk %d)", t, fu[t], lo);
             return VPX_ERR_UNSUPPORTED;
         }
@@ -562,7 +585,7 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
     if (periodic && nchunk % 3) { set_error("convq: periodic schedule does not divide into passes"); return VPX_ERR_UNSUPPORTED; }
     const int c0 = periodic ? nchunk_pass : 0, s0 = periodic ? SP : 0;
     if (nchunk_pass * NSUB > 64) {
-        if (cpack > 1) return convq_build(pr, out, cpack / 2);
+        if (cpack > 1) return convq_build_impl(pr, out, cpack / 2);
         set_error("convq: %d steps per pass (max 64)", nchunk_pass * NSUB);
         return VPX_ERR_UNSUPPORTED;
     }
@@ -617,7 +640,7 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
     }
     ConvQPlan& P = B.P;
     P.B = pr.N; P.H = pr.H; P.W = pr.W;
-    P.tiles_x = (pr.W + 15) / 16; P.tiles_y = (pr.H + 31) / 32; P.n_tiles = n_tiles; P.grid_m = pr.N * P.tiles_x * P.tiles_y;
+    P.tiles_x = (pr.W + 15) / 16; P.tiles_y = (pr.H + 4 * nw - 1) / (4 * nw); P.n_tiles = n_tiles; P.grid_m = pr.N * P.tiles_x * P.tiles_y;
     P.n_groups = n_groups; P.gpt = gpt;
     P.S = S; P.SP = SP; P.nsub = nchunk_pass * NSUB; P.nchunk_total = nchunk_total;
     P.pro_stage1 = (periodic && relSP1 && !rel1) ? 1 : 0;
@@ -630,22 +653,59 @@ int convq_build(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
     pk.S = S; pk.SP = SP; pk.nchunk_pass = nchunk_pass; pk.nchunk_total = nchunk_total;
     pk.nseg = pr.nseg;
     for (int i = 0; i < pr.nseg; ++i) { pk.seg_nstage[i] = pr.seg[i].nstage; pk.seg_wc0[i] = pr.seg_wc0[i]; }
-    B.halo = pr.halo; B.NTS = NTS;
+    B.halo = pr.halo; B.NTS = NTS; B.nw = nw;
     return VPX_OK;
 }
 
-template <int NTS, bool PHASE, int HALO>
+// The schedule depends on the layer's geometry only, not on its tensors: a forward pass asks for the same few layers every step
+// (three times per call: kernel choice, workspace size, launch), and at small batches the step is host-bound — keep the last builds.
+int convq_build(const ConvQProblem& pr, QBuild& out) {
+    struct Entry { ConvQProblem key; QBuild val; int rc; bool used; };
+    constexpr int NCACHE = 16;
+    static thread_local Entry* cache = nullptr;
+    static thread_local int next = 0;
+    if (!cache) { cache = new Entry[NCACHE]; for (int i = 0; i < NCACHE; ++i) cache[i].used = false; }
+    static thread_local ConvQProblem key;
+    key = pr;
+    key.w = nullptr;
+    for (int i = 0; i < 4; ++i) { key.seg[i].sp = nullptr; key.seg[i].bstride = 0; key.seg[i].tstride = 0; key.seg[i].nT = 0; }
+    for (int i = pr.nseg; i < 4; ++i) { memset(&key.seg[i], 0, sizeof(CQSeg)); key.seg_wc0[i] = 0; }
+    for (int g = 0; g < 4; ++g) {
+        if (g >= pr.ngs) { memset(&key.gs[g], 0, sizeof(ConvQGroupSet)); continue; }
+        for (int k = pr.gs[g].nterm; k < 32; ++k) memset(&key.gs[g].term[k], 0, sizeof(ConvQTerm));
+    }
+    for (int i = 0; i < NCACHE; ++i) {
+        if (!cache[i].used || memcmp(&cache[i].key, &key, sizeof(ConvQProblem)) != 0) continue;
+        if (cache[i].rc != VPX_OK) return convq_build_impl(pr, out);   // (sets the error text again)
+        out = cache[i].val;
+        for (int k = 0; k < pr.nseg; ++k) out.P.seg[k] = pr.seg[k];
+        out.pk.w = pr.w;
+        return VPX_OK;
+    }
+    const int rc = convq_build_impl(pr, out);
+    Entry& e = cache[next];
+    next = (next + 1) % NCACHE;
+    e.key = key; e.rc = rc; e.used = true;
+    if (rc == VPX_OK) e.val = out;
+    return rc;
+}
+
+template <int NTS, bool PHASE, int HALO, int NW>
 hipError_t launch_convq_t(const ConvQPlan& P, const ConvQEpi& epi, hipStream_t s) {
-    constexpr int LDS = 2 * 4 * (HALO == 2 ? 640 : 768) * 16 + 3 * CQ_WCHUNK;
+    constexpr int LDS = 2 * 4 * convq_ppos(HALO, NW) * 16 + (NW == 8 ? 3 : 2) * CQ_WCHUNK;   // 128 | 80 KiB (3x3 halo)
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convq_kernel<NTS, PHASE, HALO>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convq_kernel<NTS, PHASE, HALO, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const long long per_xcd = ((long long)P.grid_m * P.n_tiles + 7) / 8;
-    hipLaunchKernelGGL((convq_kernel<NTS, PHASE, HALO>), dim3((unsigned)(per_xcd * 8)), dim3(512), LDS, s, P, epi);
+    hipLaunchKernelGGL((convq_kernel<NTS, PHASE, HALO, NW>), dim3((unsigned)(per_xcd * 8)), dim3(64 * NW), LDS, s, P, epi);
     return hipGetLastError();
+}
+template <int NTS, bool PHASE>
+hipError_t launch_convq_h2(const ConvQPlan& P, const ConvQEpi& epi, int nw, hipStream_t s) {
+    return nw == 4 ? launch_convq_t<NTS, PHASE, 2, 4>(P, epi, s) : launch_convq_t<NTS, PHASE, 2, 8>(P, epi, s);
 }
 
 }  // namespace
@@ -673,12 +733,12 @@ int convq_run(const ConvQProblem& pr, const ConvQEpiArgs& ea_in, char* wpk, bool
     epi.a.gpt = b.P.gpt;
     epi.a.phases = pr.phases;
     hipError_t e;
-    if (b.halo == 4) e = launch_convq_t<8, false, 4>(b.P, epi, s);
-    else if (pr.phases) e = launch_convq_t<2, true, 2>(b.P, epi, s);
-    else if (b.NTS == 8) e = launch_convq_t<8, false, 2>(b.P, epi, s);
-    else if (b.NTS == 4) e = launch_convq_t<4, false, 2>(b.P, epi, s);
-    else if (b.NTS == 2) e = launch_convq_t<2, false, 2>(b.P, epi, s);
-    else e = launch_convq_t<1, false, 2>(b.P, epi, s);
+    if (b.halo == 4) e = launch_convq_t<8, false, 4, 8>(b.P, epi, s);
+    else if (pr.phases) e = launch_convq_h2<2, true>(b.P, epi, b.nw, s);
+    else if (b.NTS == 8) e = launch_convq_h2<8, false>(b.P, epi, b.nw, s);
+    else if (b.NTS == 4) e = launch_convq_h2<4, false>(b.P, epi, b.nw, s);
+    else if (b.NTS == 2) e = launch_convq_h2<2, false>(b.P, epi, b.nw, s);
+    else e = launch_convq_h2<1, false>(b.P, epi, b.nw, s);
     VPX_CHECK_HIP(e);
     return VPX_OK;
 }

@@ -105,6 +105,12 @@ int vpx_convlstm_takes_split_input(const vpx_convlstm_desc* d) {
     return (L.v2 && d->layout == VPX_LAYOUT_NHWC && !(d->flags & VPX_FLAG_SAVE_FOR_BWD)) ? 1 : 0;
 }
 
+int vpx_split_convert(const float* x, void* x_split, long long n_pixels, int C, void* stream) {
+    if (!x || !x_split || n_pixels < 0 || C < 8 || (C & 7)) { set_error("vpx_split_convert: NULL tensor or channel count %d not a multiple of 8", C); return VPX_ERR_ARG; }
+    VPX_CHECK_HIP(launch_split_convert(x, x_split, n_pixels, C, (hipStream_t)stream));
+    return VPX_OK;
+}
+
 int vpx_convlstm_writes_split_output(const vpx_convlstm_desc* d) {   // the second-generation cell writes h_t in operand format anyway
     return vpx_convlstm_takes_split_input(d);
 }

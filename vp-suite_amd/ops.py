@@ -474,6 +474,11 @@ def split_convert(x):
     C = xs.shape[-3]
     if C % 8:
         raise ValueError("split_convert: the channel count must be a multiple of 8")
+    if xs.dim() == 4 and xs.dtype == torch.float32 and xs.is_contiguous(memory_format=torch.channels_last):
+        buf = torch.empty(xs.numel(), device=xs.device, dtype=torch.float32)
+        n, _, h, w = xs.shape
+        check(_lib.lib().vpx_split_convert(ptr(xs), ptr(buf), n * h * w, C, _stream()), "vpx_split_convert")
+        return buf, tuple(x.shape)
     # fp32 hi/lo split on the GPU with torch ops (same rounding as the kernels: round-to-nearest-even to bf16, twice)
     flat = xs.permute(*range(xs.dim() - 3), xs.dim() - 2, xs.dim() - 1, xs.dim() - 3).contiguous()   # [..., H, W, C]
     hi = flat.to(torch.bfloat16)
@@ -489,6 +494,13 @@ _convq_ws = {}
 def conv2d_ex_takes_split(N, H, W, Ci, Co, kh, kw, stride, padding, transposed, precision="bf16x3"):
     d = ConvDesc(N, H, W, Ci, Co, kh, kw, int(stride), int(padding), int(bool(transposed)), 0.0, PRECISIONS[precision], 0, 0)
     return bool(_lib.lib().vpx_conv2d_ex_takes_split(ctypes.byref(d)))
+
+
+def conv2d_ex_prefers_split(N, H, W, Ci, Co, kh, kw, stride, padding, transposed, precision="bf16x3"):
+    """True when the layer runs on the schedule-driven K = 32 kernel (convq) given split input — for stride-2 transposed layers
+    that is worth converting an fp32 input first (all four output phases in one launch)."""
+    d = ConvDesc(N, H, W, Ci, Co, kh, kw, int(stride), int(padding), int(bool(transposed)), 0.0, PRECISIONS[precision], 0, 0)
+    return _lib.lib().vpx_conv2d_ex_takes_split(ctypes.byref(d)) == 2
 
 
 def conv2d_ex_from_split(xbuf, xshape, w, bias, stride, padding, transposed=False, leaky_slope=0.0, precision="bf16x3",
