@@ -238,17 +238,23 @@ def test_backward_weight_pack_reuse_matches_repacking(vpx, monkeypatch):
     m1 = MODEL_CLASSES["predrnn-pp"]("cuda", **kw).to("cuda")
     m2 = copy.deepcopy(m1)
     frames = torch.rand(2, 6, 1, 16, 16, device="cuda")
-    for m, env in ((m1, None), (m2, "1")):
-        if env is None:
-            monkeypatch.delenv("VPX_NO_BWD_HOLDER", raising=False)
-        else:
-            monkeypatch.setenv("VPX_NO_BWD_HOLDER", env)
-        o = torch.optim.Adam(m.parameters(), lr=1e-2)
-        for _ in range(2):
-            o.zero_grad()
-            pred, losses = m(frames, pred_frames=3, train=False)
-            (((pred - frames[:, 3:]) ** 2).mean() + sum(losses.values())).backward()
-            o.step()
+    # deterministic mode (no K-split atomics): both models then see bit-identical gradients — Adam turns a last-bit difference
+    # of a near-zero gradient into a full lr-sized step (the test was flaky without it, 1 run in 6)
+    torch.use_deterministic_algorithms(True)
+    try:
+        for m, env in ((m1, None), (m2, "1")):
+            if env is None:
+                monkeypatch.delenv("VPX_NO_BWD_HOLDER", raising=False)
+            else:
+                monkeypatch.setenv("VPX_NO_BWD_HOLDER", env)
+            o = torch.optim.Adam(m.parameters(), lr=1e-2)
+            for _ in range(2):
+                o.zero_grad()
+                pred, losses = m(frames, pred_frames=3, train=False)
+                (((pred - frames[:, 3:]) ** 2).mean() + sum(losses.values())).backward()
+                o.step()
+    finally:
+        torch.use_deterministic_algorithms(False)
     for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert (p1 - p2).abs().max() < 1e-6, n1
 

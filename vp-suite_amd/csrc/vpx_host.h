@@ -104,7 +104,9 @@ static inline bool cell2_applicable(const vpx_convlstm_desc* d) {
     if (cell2_mode() == 2) return true;
     const long long wgs = (long long)d->B * ((d->H + 31) / 32) * ((d->W + 15) / 16) * ((d->Ch + 31) / 32);
     static int min_wgs = -1;   // VPX_CELL2_MIN_WGS: experiment override of the bar below
-    if (min_wgs < 0) { const char* e = getenv("VPX_CELL2_MIN_WGS"); min_wgs = e ? atoi(e) : 128; }
+    // 64 (= 128 half tiles of four waves, cell2_kernel_q<.., 4>): the B=4 steps of the 64x64 blocks, whose first-generation launch
+    // has exactly 256 workgroups, run 48 -> 38 us there (B=4 step 2.13 -> 1.93 ms; B=4 at 3x128x128 6.71 -> 5.89 ms)
+    if (min_wgs < 0) { const char* e = getenv("VPX_CELL2_MIN_WGS"); min_wgs = e ? atoi(e) : 64; }
     return wgs >= min_wgs;
 }
 
