@@ -54,6 +54,37 @@ def test_glue_layer_on_split_input_vs_torch(vpx, tag):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("tag", ["deconv2_t2k4", "conv3_s2k3", "conv2_s2k3_co64", "deconv3_t1k3_co16", "ragged_s2k3", "ragged_t2k4"])
+def test_half_tile_and_full_tile_agree_bit_for_bit(vpx, tag):
+    """convq on 16x16-pixel tiles (two workgroups per CU, ring of two weight chunks: the default) and on 32x16 tiles (VPX_OPT_EXPERIMENT
+    bit 4): the same products in the same order per output element."""
+    N, Ci, Co, H, W, k, s, p, tr, slope = CASES[tag]
+    x = seeded_rand((N, Ci, H, W), name_seed(f"convq.{tag}.x")).cuda() - 0.3
+    wshape = (Ci, Co, k, k) if tr else (Co, Ci, k, k)
+    w = (seeded_randn(wshape, name_seed(f"convq.{tag}.w"), 1.0 / np.sqrt(Ci * k * k))).cuda()
+    b = seeded_randn((Co,), name_seed(f"convq.{tag}.b"), 0.1).cuda()
+    xbuf, _ = vpx.ops.split_convert(x)
+    L = vpx._lib.lib()
+    prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, 0)
+    try:
+        y4, _, _ = vpx.ops.conv2d_ex_from_split(xbuf, (N, Ci, H, W), w, b, s, p, tr, slope, "bf16x3")
+        L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, 16)
+        y8, _, _ = vpx.ops.conv2d_ex_from_split(xbuf, (N, Ci, H, W), w, b, s, p, tr, slope, "bf16x3")
+    finally:
+        L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, prev)
+    assert torch.equal(y4, y8)
+
+
+def test_split_convert_entry_point_matches_the_torch_restatement(vpx):
+    """vpx_split_convert (fp32 channels-last -> operand format) against the same two roundings written with torch ops."""
+    x = seeded_randn((3, 40, 19, 23), name_seed("split_convert.x"), 2.0).cuda()
+    a, shp = vpx.ops.split_convert(x)
+    b, _ = vpx.ops.split_convert(x, native=False)
+    assert shp == (3, 40, 19, 23) and torch.equal(a.view(torch.int32), b.view(torch.int32))
+    with pytest.raises(ValueError):
+        vpx.ops.split_convert(torch.zeros(1, 12, 4, 4, device="cuda"))
+
+
 def test_convlstm_block_hands_its_output_over_in_operand_format(vpx):
     """VPX_FLAG_OUT_SPLIT: the second-generation cell writes its output sequence ONLY in the split-bf16 operand format ([B][T][HW][Ch]);
     decoded, it equals the fp32 sequence of a normal call bit for bit (same kernel, same arithmetic), h_T / c_T come out in fp32."""

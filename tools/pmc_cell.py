@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 if os.environ.get("EXP"):
     v._lib.lib().vpx_set_option(v._lib.OPT_EXPERIMENT, int(os.environ["EXP"]))
 B, T = int(os.environ.get("BB", 32)), 4
-Cin, Ch, H, W = 64, 64, 64, 64
+Cin, Ch, H, W = [int(t) for t in os.environ.get('SHAPE', '64,64,64,64').split(',')]
 x = v.ops.to_channels_last(torch.rand(B, T, Cin, H, W, device=dev))
 Wt = torch.randn(4 * Ch, Cin + Ch, 3, 3, device=dev) * 0.03
 b = torch.zeros(4 * Ch, device=dev)

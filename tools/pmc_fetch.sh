@@ -7,7 +7,7 @@ for e in "$@"; do
   rm -rf $OUT; mkdir -p $OUT
   export EXP=$e
   i=0
-  for line in "FETCH_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+  for line in "FETCH_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" ${EXTRA_PASS:+"$EXTRA_PASS"}; do
     i=$((i+1))
     rocprofv3 --pmc $line --kernel-trace --output-format csv -d $OUT/p$i -- python3 tools/pmc_cell.py > $OUT/p$i.log 2>&1 || echo "pass $i failed"
   done

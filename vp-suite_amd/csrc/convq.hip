@@ -445,10 +445,11 @@ struct QBuild {
     int halo, NTS, nw;
 };
 
-// waves per workgroup: 4 = the half tile (two workgroups per CU), 3x3-halo layers only; VPX_CONVQ_NW=8 keeps the 32x16 tile
+// waves per workgroup: 4 = the half tile (two workgroups per CU), 3x3-halo layers only; VPX_CONVQ_NW=8 / experiment bit 4 keep the 32x16 tile
 int convq_pick_nw(const ConvQProblem& pr) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("VPX_CONVQ_NW"); env = e ? atoi(e) : 4; }
+    if (g_experiment & 16) return 8;   // VPX_OPT_EXPERIMENT bit 4: the 32x16 tile (A/B runs, tests)
     return (pr.halo == 2 && env == 4) ? 4 : 8;
 }
 
@@ -660,7 +661,7 @@ int convq_build_impl(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
 // The schedule depends on the layer's geometry only, not on its tensors: a forward pass asks for the same few layers every step
 // (three times per call: kernel choice, workspace size, launch), and at small batches the step is host-bound — keep the last builds.
 int convq_build(const ConvQProblem& pr, QBuild& out) {
-    struct Entry { ConvQProblem key; QBuild val; int rc; bool used; };
+    struct Entry { ConvQProblem key; QBuild val; int rc, nw; bool used; };
     constexpr int NCACHE = 16;
     static thread_local Entry* cache = nullptr;
     static thread_local int next = 0;
@@ -674,8 +675,9 @@ int convq_build(const ConvQProblem& pr, QBuild& out) {
         if (g >= pr.ngs) { memset(&key.gs[g], 0, sizeof(ConvQGroupSet)); continue; }
         for (int k = pr.gs[g].nterm; k < 32; ++k) memset(&key.gs[g].term[k], 0, sizeof(ConvQTerm));
     }
+    const int nw = convq_pick_nw(pr);   // (an experiment switch may change the tile form between calls)
     for (int i = 0; i < NCACHE; ++i) {
-        if (!cache[i].used || memcmp(&cache[i].key, &key, sizeof(ConvQProblem)) != 0) continue;
+        if (!cache[i].used || cache[i].nw != nw || memcmp(&cache[i].key, &key, sizeof(ConvQProblem)) != 0) continue;
         if (cache[i].rc != VPX_OK) return convq_build_impl(pr, out);   // (sets the error text again)
         out = cache[i].val;
         for (int k = 0; k < pr.nseg; ++k) out.P.seg[k] = pr.seg[k];
@@ -685,7 +687,7 @@ int convq_build(const ConvQProblem& pr, QBuild& out) {
     const int rc = convq_build_impl(pr, out);
     Entry& e = cache[next];
     next = (next + 1) % NCACHE;
-    e.key = key; e.rc = rc; e.used = true;
+    e.key = key; e.rc = rc; e.nw = nw; e.used = true;
     if (rc == VPX_OK) e.val = out;
     return rc;
 }

@@ -466,15 +466,16 @@ def conv2d_ex_split(x, w, bias, stride, padding, transposed=False, leaky_slope=0
     return buf, (N, Co, ho.value, wo.value)
 
 
-def split_convert(x):
-    """fp32 [..., C, H, W] tensor -> SplitActivation-style buffer in the split-bf16 operand format (tests / tools; the models'
-    producers write the format themselves). Returns (buffer, logical shape)."""
+def split_convert(x, native=True):
+    """fp32 [..., C, H, W] tensor -> SplitActivation-style buffer in the split-bf16 operand format (vpx_split_convert for a
+    channels-last 4-D batch; otherwise — and with native=False, the tests' cross-check — the same rounding with torch ops).
+    Returns (buffer, logical shape)."""
     _require_gpu(x, "split_convert")
     xs = to_channels_last(x)
     C = xs.shape[-3]
     if C % 8:
         raise ValueError("split_convert: the channel count must be a multiple of 8")
-    if xs.dim() == 4 and xs.dtype == torch.float32 and xs.is_contiguous(memory_format=torch.channels_last):
+    if native and xs.dim() == 4 and xs.dtype == torch.float32 and xs.is_contiguous(memory_format=torch.channels_last):
         buf = torch.empty(xs.numel(), device=xs.device, dtype=torch.float32)
         n, _, h, w = xs.shape
         check(_lib.lib().vpx_split_convert(ptr(xs), ptr(buf), n * h * w, C, _stream()), "vpx_split_convert")
