@@ -206,6 +206,8 @@ CASESQ = {  # full 32x16 tiles and whole 32-channel tiles for the fused step; th
     "q_fore3_noinput": (96, 96, 32, 32, 2, 3, False, True, True, 0),   # h-only pack
     "q_ifog_nopeep": (32, 32, 32, 48, 2, 3, True, True, False, 1),
     "q_t1_nostate": (32, 64, 32, 16, 3, 1, True, False, True, 0),      # a single step, x only
+    "q_h16_enc3": (96, 96, 16, 16, 3, 2, True, False, True, 0),        # 16-row maps: the half tile only (one tile = one image)
+    "q_h48": (32, 32, 48, 32, 2, 2, True, True, True, 0),              # H % 32 == 16: half tiles inside the image, 32-row tiles not
 }
 CASES.update(CASESQ)
 

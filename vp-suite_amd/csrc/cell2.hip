@@ -721,10 +721,18 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
     if ((long long)(L >> 3) >= per_xcd || sidx >= total) return;
     int mt = (int)(sidx / P.n_tiles);
     int n_tile_ = (int)(sidx - (long long)mt * P.n_tiles);
-    if ((P._q & 8) && per_xcd % P.n_tiles == 0) {   // diagnostic: the N tiles of a pixel tile half a launch apart (no L2 sharing possible)
-        const long long per_n = per_xcd / P.n_tiles, i = L >> 3;
-        n_tile_ = (int)(i / per_n);
-        mt = (int)(((long long)(L & 7) * per_xcd) / P.n_tiles + i % per_n);
+    if ((P._q & 8) && per_xcd % P.n_tiles == 0) {   // diagnostic: the N tiles of a pixel tile D dispatch positions apart inside the XCD
+        const long long i = L >> 3;
+        const int D = (P._q >> 8) & 0xfff;
+        if (D == 0) {                                // half a launch apart (no L2 sharing possible)
+            const long long per_n = per_xcd / P.n_tiles;
+            n_tile_ = (int)(i / per_n);
+            mt = (int)(((long long)(L & 7) * per_xcd) / P.n_tiles + i % per_n);
+        } else if (per_xcd % ((long long)D * P.n_tiles) == 0) {
+            const long long blk = i / ((long long)D * P.n_tiles), r = i % ((long long)D * P.n_tiles);
+            n_tile_ = (int)(r / D);
+            mt = (int)(((long long)(L & 7) * per_xcd) / P.n_tiles + blk * D + r % D);
+        }
     }
     const int n_tile = n_tile_;
     const int tx = mt % P.tiles_x;
@@ -904,6 +912,7 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
 // VPX_OPT_EXPERIMENT bit 2 forces the full tile (A/B runs, tests).
 static bool cell2_half_tile(const Cell2Plan& p, bool ragged_ok) {
     if (!ragged_ok && (p.H & 15) != 0) return false;   // the fused step's vector epilogue wants tiles inside the image
+    if (!ragged_ok && (p.H & 31) != 0) return true;    // ... and 32-row tiles would not be
     return !(g_experiment & 4);
 }
 

@@ -100,7 +100,11 @@ static inline bool cell2_applicable(const vpx_convlstm_desc* d) {
     if (cell2_mode() == 0) return false;
     if (d->precision != VPX_PREC_BF16X3 || d->kh != 3 || d->kw != 3) return false;
     if ((d->Cin & 15) || (d->Ch & 15) || (d->Cin + d->Ch) / 16 > MAX_STAGE) return false;
-    if (d->H <= 16) return false;
+    // 16-row maps: on the half tile (q form) only. Measured at B=128, (96,96,16x16): 128 -> 106 us per step against the
+    // first-generation kernel (384 workgroups of four waves); VPX_CELL2_H16=0 keeps them there
+    static int h16 = -1;
+    if (h16 < 0) { const char* e = getenv("VPX_CELL2_H16"); h16 = e ? atoi(e) : 1; }
+    if (d->H < 16 || (d->H == 16 && !(h16 && mfma_shape() == 1 && (d->W & 15) == 0 && (d->Ch & 31) == 0))) return false;
     if (cell2_mode() == 2) return true;
     const long long wgs = (long long)d->B * ((d->H + 31) / 32) * ((d->W + 15) / 16) * ((d->Ch + 31) / 32);
     static int min_wgs = -1;   // VPX_CELL2_MIN_WGS: experiment override of the bar below
@@ -114,7 +118,7 @@ static inline bool cell2_applicable(const vpx_convlstm_desc* d) {
 // vectorised one only — tiles inside the image, whole 32-channel tiles
 #define VPX_MFMA_SHAPE_DEFAULT 1   // measured (tools/ab_shape.py, B=128, one process, interleaved): 1.05-1.11x per fused step, every block shape
 static inline bool cell2_q_applicable(const vpx_convlstm_desc* d) {
-    return mfma_shape() == 1 && (d->H & 31) == 0 && (d->W & 15) == 0 && (d->Ch & 31) == 0;
+    return mfma_shape() == 1 && (d->H & 15) == 0 && (d->W & 15) == 0 && (d->Ch & 31) == 0;   // (H % 32 == 16: the half tile only)
 }
 
 struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
