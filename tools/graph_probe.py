@@ -7,11 +7,10 @@ from vp_suite_amd.models import MODEL_CLASSES
 B = int(os.environ.get("BB", 4))
 dev = "cuda"
 torch.manual_seed(0)
-m = MODEL_CLASSES["convlstm-shi"](dev, img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0]).to(dev).eval()
-m.cell_precision = "bf16x3"
+m = MODEL_CLASSES["convlstm-shi"](dev, img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0], cell_precision="bf16x3").to(dev).eval()
 x = torch.rand(B, 10, 1, 64, 64, device=dev)
 with torch.no_grad():
-    for _ in range(3):
+    for _ in range(300):
         ref, _ = m(x, pred_frames=10)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

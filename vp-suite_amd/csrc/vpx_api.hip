@@ -115,6 +115,34 @@ int vpx_convlstm_writes_split_output(const vpx_convlstm_desc* d) {   // the seco
     return vpx_convlstm_takes_split_input(d);
 }
 
+}  // extern "C"
+
+// The hoisted input projection W_x (*) x_t of all B*T frames (small-grid paths) as ONE launch of the schedule-driven K = 32 kernel
+// (convq.hip): a plain 3x3 'same' convolution whose output channel is the reference row of W (gate-major), on operand-format input.
+// 40 frames 64 -> 4x96 channels at 32x32: 84 -> ~25 us against the first-generation launch. VPX_HOIST_Q=0 keeps the latter.
+static bool hoist_q_problem(const vpx_convlstm_desc* d, ConvQProblem& pr) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("VPX_HOIST_Q"); on = e ? atoi(e) : 1; }
+    memset(&pr, 0, sizeof(pr));
+    if (!on || d->precision != VPX_PREC_BF16X3 || d->kh != 3 || d->kw != 3 || (d->Cin & 15) || d->Cin < 16 || d->layout != VPX_LAYOUT_NHWC) return false;
+    pr.N = d->B * d->T; pr.H = d->H; pr.W = d->W; pr.halo = 2;
+    pr.nseg = 1;
+    CQSeg& sg = pr.seg[0];
+    sg.nT = 1; sg.bstride = (long long)d->H * d->W * d->Cin * 4;
+    sg.rowpitch = d->W * d->Cin * 4; sg.colpitch = d->Cin * 4; sg.org = 0; sg.Hs = d->H; sg.Ws = d->W; sg.nstage = d->Cin / 16; sg.c0 = 0;
+    pr.ngs = 1;
+    ConvQGroupSet& gs = pr.gs[0];
+    gs.nt0 = 0; gs.ntn = 8; gs.nterm = 0;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) gs.term[gs.nterm++] = ConvQTerm{0, ky - 1, kx - 1, ky * 3 + kx};
+    pr.periodic = 1;
+    pr.s_oc = (long long)(d->Cin + d->Ch) * 9; pr.s_ic = 9;
+    pr.Co = 4 * d->Ch; pr.col0 = 0; pr.phases = 0;
+    return convq_wpk_bytes(pr) != 0;
+}
+
+extern "C" {
+
 size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
     ConvLSTMLayout L;
     if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
@@ -129,6 +157,10 @@ size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d) {
                align256(cell3_packed_bytes(d->Ch)) + 3 * align256(L.n_state * 4);
     if (L.v2)  // packed weights of cell2 (q form: up to two packs, one per set of present operands) + split copies of x, h0 and a two-slot ring of h_t
         fwd += 2 * align256(cell2_wpk_bytes(d, L)) + align256(L.n_x * 4) + 3 * align256(L.n_state * 4);
+    if (L.hoist || L.v3) {  // the hoisted projection on convq: its weight pack + x in operand format
+        static thread_local ConvQProblem hq;
+        if (hoist_q_problem(d, hq)) fwd += align256(convq_wpk_bytes(hq)) + align256(L.n_x * 4);
+    }
     if (d->layout == VPX_LAYOUT_NCHW)
         fwd += align256(L.n_x * 4) + align256(L.n_out * 4) + 4 * align256(L.n_state * 4) + 3 * align256(L.n_peep * 4);
     // backward (only with SAVE_FOR_BWD): packed dgrad weights + dG for all steps + dh/dc carries + wgrad K-slice slabs
@@ -193,6 +225,13 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         h0_sp3 = (char*)ws.take(L.n_state);
         h_ring3[0] = (char*)ws.take(L.n_state);
         h_ring3[1] = (char*)ws.take(L.n_state);
+    }
+    static thread_local ConvQProblem hq;
+    char *wpk_hq = nullptr, *x_sp_hq = nullptr;
+    const bool hoist_q = (L.hoist || L.v3) && hoist_q_problem(d, hq);
+    if (hoist_q) {
+        wpk_hq = (char*)ws.take(align256(convq_wpk_bytes(hq)) / sizeof(float));
+        x_sp_hq = (char*)ws.take(L.n_x);
     }
     char *wpk2 = nullptr, *wpk2b = nullptr, *x_sp = nullptr, *h0_sp = nullptr, *h_ring[2] = {nullptr, nullptr}, *h_sp_all = nullptr;
     if (L.v2) {
@@ -307,7 +346,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         memcpy(px.stage, L.hx_stage, sizeof(ConvStage) * L.hx_nstage);
         px.nstage = L.hx_nstage; px.chunks_total = L.hx_chunks; px.prec = d->precision; px.taps = L.taps;
         fill_plain_pack(px, 4 * Ch, 0, L.s_ng);
-        if (!wp) VPX_CHECK_HIP(launch_pack_weights(px, wpk_hx, stream));
+        if (!wp && !hoist_q) VPX_CHECK_HIP(launch_pack_weights(px, wpk_hx, stream));
         if (hoist) {
             ph.seg[0] = PackSeg{W, ld_o, L.taps, Cin, Ch};
             memcpy(ph.stage, L.hh_stage, sizeof(ConvStage) * L.hh_nstage);
@@ -315,6 +354,17 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             fill_plain_pack(ph, 4 * Ch, 0, L.s_ng);
             if (!wp) VPX_CHECK_HIP(launch_pack_weights(ph, wpk_hh, stream));
         }
+        if (hoist_q) {
+            const char* xs = reinterpret_cast<const char*>(xn);
+            if (!x_split) { VPX_CHECK_HIP(launch_split_convert(xn, x_sp_hq, (long long)B * T * (long long)HW, Cin, stream)); xs = x_sp_hq; }
+            hq.seg[0].sp = xs;
+            hq.w = W;
+            ConvQEpiArgs ea{};
+            ea.Co = 4 * Ch; ea.split = 4 * Ch;
+            ea.oys = 1; ea.oxs = 1; ea.Hmem = H; ea.Wmem = Wd;
+            ea.out0 = pre_all; ea.bstride0 = (long long)(HW * 4 * Ch); ea.ld0 = 4 * Ch;
+            if ((rc = convq_run(hq, ea, wpk_hq, wp, stream)) != VPX_OK) return rc;
+        } else {
         ConvPlan PX{};
         PX.B = B * T; PX.H = H; PX.W = Wd; PX.kh = d->kh; PX.kw = d->kw;
         set_plan_tiles(PX, 1);
@@ -329,6 +379,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         pa.Co = 4 * Ch; pa.split = 4 * Ch; pa.ng = L.s_ng;
         pa.out0 = pre_all; pa.bstride0 = (long long)(HW * 4 * Ch); pa.ld0 = 4 * Ch;
         VPX_CHECK_HIP(launch_conv_plain_f32(PX, pa, L.s_tiles, stream));
+        }
     }
 
     float* gates_all = nullptr;
