@@ -264,9 +264,9 @@ def roofline(spec, ps):
         "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(ach_tflops / peak, 4), "traffic": measured_traffic(spec),
         "algorithmic_bytes_per_launch": round(ps["bytes"] / launches),
-        "kernel": ((f"cell2_kernel (second-generation fused ConvLSTM cell step: pre-split bf16x3 operands, LDS-DMA staging; "
-                    f"conv_gemm_kernel<EpiConvLSTM> on 16x16 maps at large batch; cell3_kernel — 8-channel slices, hoisted input "
-                    f"projection — on grids below 256 workgroups), forward" if spec.precision == "bf16x3" else
+        "kernel": ((f"cell2_kernel_q<Cell2Epi, true, 4> (second-generation fused ConvLSTM cell step: pre-split bf16x3 operands, "
+                    f"LDS-DMA staging, v_mfma_f32_16x16x32_bf16, 16x16-pixel tiles at two workgroups per CU; cell3_kernel — 8-channel "
+                    f"slices, hoisted input projection — on grids below 256 workgroups), forward" if spec.precision == "bf16x3" else
                     f"conv_gemm_kernel<EpiConvLSTM, {spec.precision}> (fused ConvLSTM cell step, forward)")
                    if spec.model == "convlstm-shi" else
                    f"conv_gemm_kernel<EpiSTGate/EpiSTOut/EpiPlain, {spec.precision}> (ST-LSTM cell step, forward)"),

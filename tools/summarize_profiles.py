@@ -93,7 +93,7 @@ for tag, name in (("infer_f32", f"bench_infer_{BT}_f32"), ("predrnn_infer", f"be
 counters = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     counters.update(pmc_means(d))
-summary = {"kernel": "fused ConvLSTM cell step (cell2_kernel on 64x64 / 32x32 maps, conv_gemm_kernel<EpiConvLSTM, bf16x3> on 16x16 maps) "
+summary = {"kernel": "fused ConvLSTM cell step (cell2_kernel_q<Cell2Epi, true, 4>: every block shape of convlstm-shi at this batch) "
                      f"averaged over the launches of `bench.py --steps 3` (convlstm-shi, {BT}, 6 block shapes)",
            "command": "tools/collect_profiles.sh (rocprofv3 --pmc <counter> --kernel-trace, one pass per counter group)",
            "counters": counters}
