@@ -365,20 +365,20 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             ea.out0 = pre_all; ea.bstride0 = (long long)(HW * 4 * Ch); ea.ld0 = 4 * Ch;
             if ((rc = convq_run(hq, ea, wpk_hq, wp, stream)) != VPX_OK) return rc;
         } else {
-        ConvPlan PX{};
-        PX.B = B * T; PX.H = H; PX.W = Wd; PX.kh = d->kh; PX.kw = d->kw;
-        set_plan_tiles(PX, 1);
-        PX.nseg = 1;
-        PX.seg[0] = ConvSeg{xn, (long long)(HW * Cin), Cin, 0};   // x is [B][T][HW][Cin]: B*T dense images
-        PX.nstage = L.hx_nstage;
-        memcpy(PX.stage, L.hx_stage, sizeof(ConvStage) * L.hx_nstage);
-        PX.chunks_total = L.hx_chunks; PX.prec = d->precision;
-        PX.a_bytes = conv_a_bytes(L.hx_stage, L.hx_nstage, d->kh, d->kw, 1);
-        PX.wpk = wpk_hx;
-        PlainEpiArgs pa{};
-        pa.Co = 4 * Ch; pa.split = 4 * Ch; pa.ng = L.s_ng;
-        pa.out0 = pre_all; pa.bstride0 = (long long)(HW * 4 * Ch); pa.ld0 = 4 * Ch;
-        VPX_CHECK_HIP(launch_conv_plain_f32(PX, pa, L.s_tiles, stream));
+            ConvPlan PX{};
+            PX.B = B * T; PX.H = H; PX.W = Wd; PX.kh = d->kh; PX.kw = d->kw;
+            set_plan_tiles(PX, 1);
+            PX.nseg = 1;
+            PX.seg[0] = ConvSeg{xn, (long long)(HW * Cin), Cin, 0};   // x is [B][T][HW][Cin]: B*T dense images
+            PX.nstage = L.hx_nstage;
+            memcpy(PX.stage, L.hx_stage, sizeof(ConvStage) * L.hx_nstage);
+            PX.chunks_total = L.hx_chunks; PX.prec = d->precision;
+            PX.a_bytes = conv_a_bytes(L.hx_stage, L.hx_nstage, d->kh, d->kw, 1);
+            PX.wpk = wpk_hx;
+            PlainEpiArgs pa{};
+            pa.Co = 4 * Ch; pa.split = 4 * Ch; pa.ng = L.s_ng;
+            pa.out0 = pre_all; pa.bstride0 = (long long)(HW * 4 * Ch); pa.ld0 = 4 * Ch;
+            VPX_CHECK_HIP(launch_conv_plain_f32(PX, pa, L.s_tiles, stream));
         }
     }
 
