@@ -52,7 +52,10 @@ __host__ __device__ __forceinline__ CQDec cq_decode(unsigned lo, unsigned hi) {
 struct ConvQEpi {
     ConvQEpiArgs a;
 
-    __device__ __forceinline__ void store_sub(const float* ldsf, int lane, int b, int y0, int x0, int n_tile, int ngr, int prow, int H, int W) const {
+    // phase_of_wave >= 0 (half-tile phase form, see convq_kernel): the wave holds ONE output phase for all 16 tile rows — LDS group g
+    // is then the row group (rows 4 * g + prow ..) and every group belongs to phase `phase_of_wave`; else group g = phase / channel group
+    __device__ __forceinline__ void store_sub(const float* ldsf, int lane, int b, int y0, int x0, int n_tile, int ngr, int prow, int H, int W,
+                                              int phase_of_wave = -1) const {
         const int cg = lane & 7, p4 = lane >> 3;
         const bool v4 = ((a.Co | a.split | a.ld0 | a.ld1) & 3) == 0;
         float* const o0 = a.out0 ? a.out0 + (size_t)b * a.bstride0 : nullptr;
@@ -63,7 +66,9 @@ struct ConvQEpi {
             if (g >= ngr) continue;
             const int c = (a.phases ? n_tile : n_tile * a.gpt + g) * 32 + cg * 4;
             if (c >= a.Co) continue;
-            const int py = a.phases ? (g >> 1) : 0, px = a.phases ? (g & 1) : 0;
+            const int ph = phase_of_wave >= 0 ? phase_of_wave : g;
+            const int py = a.phases ? (ph >> 1) : 0, px = a.phases ? (ph & 1) : 0;
+            const int rbase = phase_of_wave >= 0 ? 4 * g + prow : prow;
             const bool first = c < a.split;
             float* const ob = first ? o0 : o1;
             const unsigned ld = (unsigned)(first ? a.ld0 : a.ld1);
@@ -71,7 +76,7 @@ struct ConvQEpi {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int ip = k * 8 + p4;
-                const int y = y0 + prow + (ip >> 4), x = x0 + (ip & 15);
+                const int y = y0 + rbase + (ip >> 4), x = x0 + (ip & 15);
                 f32x4 v = *reinterpret_cast<const f32x4*>(ldsf + g * 1024 + ip * 32 + cg * 4);
                 const int my = y * a.oys + a.oyo + py, mx = x * a.oxs + a.oxo + px;
                 if (y >= H || x >= W || my >= a.Hmem || mx >= a.Wmem) continue;
@@ -111,6 +116,7 @@ struct ConvQEpi {
         }
     }
 
+    template <bool REMAP = false>
     __device__ __forceinline__ void finish16(const f32x4 (&acc)[4][8], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
                                              int ngr, int H, int W) const {
         c2_barrier();
@@ -126,7 +132,8 @@ struct ConvQEpi {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             ldsf[(nt >> 1) * 1024 + (mm * 16 + 4 * q4 + r) * 32 + (nt & 1) * 16 + c16] = acc[2 * mp + mm][nt][r];
-            store_sub(ldsf, lane, b, y0, x0, n_tile, ngr, 4 * wave + 2 * mp, H, W);
+            if (REMAP) store_sub(ldsf, lane, b, y0, x0, n_tile, ngr, 2 * mp, H, W, wave);
+            else store_sub(ldsf, lane, b, y0, x0, n_tile, ngr, 4 * wave + 2 * mp, H, W);
         }
     }
 };
@@ -154,6 +161,10 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
     constexpr int WSLOTS = NW == 8 ? 3 : 2;
     constexpr int WP = CQ_WCHUNK / (NT * 16);      // weight-chunk DMAs per thread: 2 | 4
     static_assert(NP == 5 || NP == 6, "stage copy: 5 or 6 pieces per thread");
+    // Half-tile phase form: wave w owns output phase w for ALL 16 tile rows (its step of every chunk) instead of four rows of all
+    // four phases. A chunk then costs a wave 4 weight-fragment reads instead of 16 (its two column tiles serve the four row groups):
+    // 36 instead of 48 ds_read_b128 per 96 MFMAs — the phase form is LDS-read-bound. Same products, same order.
+    constexpr bool REMAP = PHASE && NW == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -243,8 +254,8 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
             for (int r = 0; r < 4; ++r) acc[m][nt][r] = 0.0f;
 
     // lane bases: activation fragments (buffer 0, halo position (0,0), tile row 4 * wave, hi plane); weight fragments
-    const int a_lane = (kg & 1) * PLANE + ((4 * wave) * HW_ + r16) * 16;
-    const int w_lane = kg * 2048 + r16 * 16;
+    const int a_lane = (kg & 1) * PLANE + ((REMAP ? 0 : 4 * wave) * HW_ + r16) * 16;
+    const int w_lane = kg * 2048 + r16 * 16 + (REMAP ? wave * 512 : 0);   // REMAP: the wave's two column tiles (its phase)
     const int tsel_shift = (kg >> 1) ? 16 : 0;   // which half of a packed offset pair this lane's k group reads
     // fragment address of a step for this lane: a_lane + 16 * (its half of the step's packed offsets)
     auto step_va = [&](int packed) { return a_lane + ((int)(((unsigned)packed >> tsel_shift) & 0x1fffu) << 4); };
@@ -286,12 +297,13 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
         int idx = 0, base = 0, c = 0;
         bool a_pending = false;                 // a stage copy issued AFTER the last weight chunk may still fly at the next sync
         CQDec cur = entry(0);                   // first step of the chunk (carries the chunk's events)
-        int cur_off = __builtin_amdgcn_readlane(e_off, 0);
+        int cur_off = __builtin_amdgcn_readlane(e_off, REMAP ? wave : 0);   // REMAP: the offsets of this wave's own step of the chunk
         {
             const int va = step_va(cur_off);
 #pragma unroll
             for (int m = 0; m < 4; ++m) load_A1(0, va, m);
             load_B(0, 0);
+            if (REMAP) load_B(0, 1);
         }
         while (true) {
             // ---- sync point of chunk c ----
@@ -299,6 +311,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
                 if (a_pending) { if (NP == 5) C2_WAIT_VM(5); else C2_WAIT_VM(6); } else C2_WAIT_VM(0);
                 c2_barrier();
                 if (WSLOTS == 2) load_B(c & 1, 0);   // ring of two: this chunk landed with this sync
+                if (REMAP) load_B(c & 1, 1);
             }
             const int slot = c % WSLOTS, nslot = (c + 1) % WSLOTS;
             // ring of three: chunk c+2 into the slot chunk c-1 has left; ring of two: chunk c+1 (chunk 1 went out with the prologue)
@@ -322,14 +335,15 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
             int nidx = idx + NSUB, nbase = base;
             if (nidx >= P.nsub) { nidx = 0; nbase = base + P.SP; }
             const CQDec nxt = entry(nidx);
-            const int nxt_off = __builtin_amdgcn_readlane(e_off, nidx);
+            const int nxt_off = __builtin_amdgcn_readlane(e_off, REMAP ? nidx + wave : nidx);
             const bool more = nbase + nxt.stA < S && c + 1 < P.nchunk_total;
 #pragma unroll
             for (int j = 0; j < NSUB; ++j) {
                 // step j of the chunk; the step after it (for the read-ahead of its activation rows)
-                const int oj = j == 0 ? cur_off : __builtin_amdgcn_readlane(e_off, idx + j);
-                const int on_ = j + 1 < NSUB ? __builtin_amdgcn_readlane(e_off, idx + j + 1) : nxt_off;
-                const int n_va = step_va(on_);
+                // REMAP: j is the row group; the step is the wave's own throughout the chunk
+                const int oj = (REMAP || j == 0) ? cur_off : __builtin_amdgcn_readlane(e_off, idx + j);
+                const int on_ = j + 1 < NSUB ? (REMAP ? cur_off : __builtin_amdgcn_readlane(e_off, idx + j + 1)) : nxt_off;
+                const int n_va = step_va(on_) + (REMAP && j + 1 < NSUB ? (j + 1) * 4 * HW_ * 16 : 0);
                 const bool on = (oj & 0x8000) != 0;
                 constexpr int SET_SHIFT = 0;
                 const int cs = NSET == 2 ? (j & 1) : 0, ns = NSET == 2 ? ((j + 1) & 1) : 0;   // this step's / the next step's fragment set
@@ -340,18 +354,19 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
                 }
 #pragma unroll
                 for (int k = 0; k < NTS; ++k) {
-                    const int t = j * NTS + k;           // tile inside the weight chunk
+                    const int t = j * NTS + k;           // tile inside the weight chunk (REMAP: position in time only)
                     const int at = PHASE ? t : k;        // accumulator tile
-                    if (t < 7) load_B(slot, t + 1); else if (WSLOTS == 3) load_B(nslot, 0);
-                    const bool go = on && ((tmask >> at) & 1) && !(P.dbg & 1);
+                    const int bt = REMAP ? k : t;        // weight-fragment set
+                    if (!REMAP) { if (t < 7) load_B(slot, t + 1); else if (WSLOTS == 3) load_B(nslot, 0); }
+                    const bool go = on && ((tmask >> (REMAP ? 2 * wave + k : at)) & 1) && !(P.dbg & 1);
                     if (go) {
                         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
                             f32x4 cc = acc[m][at];
-                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cs][m], bh[t & 1], cc, 0, 0, 0);
-                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cs][m], bl[t & 1], cc, 0, 0, 0);
-                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cs][m], bh[t & 1], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cs][m], bh[bt & 1], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cs][m], bl[bt & 1], cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cs][m], bh[bt & 1], cc, 0, 0, 0);
                             acc[m][at] = cc;
                             if (NSET == 1 && k == NTS - 1) load_A1(0, n_va, m);   // the step's last tile frees row m: the next step's fragments
                         }
@@ -384,7 +399,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
         }
         C2_WAIT_VM(0);                            // no copy may land in the epilogue's transposition space
     }
-    if (!(P.dbg & 8)) epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+    if (!(P.dbg & 8)) epi.template finish16<REMAP>(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
 }
 
 // ---- weight pack: [n_tile][chunk][part][k group][n][8 bf16]; the table says, per chunk of a pass and 16-column tile, which
