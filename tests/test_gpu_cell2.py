@@ -292,3 +292,18 @@ def test_half_tile_training_path(vpx, cell2_switch, shape_switch, experiment_swi
     _, _, _, rg = _oracle(tag)
     for k in rg:
         assert _relmax(g2[k], rg[k]) < 5e-5, k
+
+
+@pytest.mark.parametrize("tag", ["enc2_b4", "enc3_states", "t1_single_step"])
+def test_hoisted_projection_on_convq_matches_first_generation_launch(vpx, cell3_switch, experiment_switch, tag):
+    """Small-grid path (cell3): W_x * x_t of all frames as one convq launch (default) against the first-generation launch
+    (VPX_OPT_EXPERIMENT bit 5): same bf16x3 products, other summation order."""
+    cell3_switch(1)
+    experiment_switch(32)
+    o1, h1, c1, _ = _run(vpx, tag, grads=False)
+    experiment_switch(0)
+    o2, h2, c2, _ = _run(vpx, tag, grads=False)
+    assert _relmax(o2, o1) < 2e-6 and _relmax(c2, c1) < 2e-6
+    assert not torch.equal(o2, o1)
+    ro, rh, rc, _ = _oracle(tag)
+    assert _relmax(o2, ro) < 2e-5 and _relmax(c2, rc) < 2e-5

@@ -124,6 +124,7 @@ static bool hoist_q_problem(const vpx_convlstm_desc* d, ConvQProblem& pr) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("VPX_HOIST_Q"); on = e ? atoi(e) : 1; }
     memset(&pr, 0, sizeof(pr));
+    if (g_experiment & 32) return false;   // VPX_OPT_EXPERIMENT bit 5: the first-generation launch (tests, A/B)
     if (!on || d->precision != VPX_PREC_BF16X3 || d->kh != 3 || d->kw != 3 || (d->Cin & 15) || d->Cin < 16 || d->layout != VPX_LAYOUT_NHWC) return false;
     pr.N = d->B * d->T; pr.H = d->H; pr.W = d->W; pr.halo = 2;
     pr.nseg = 1;
