@@ -73,6 +73,75 @@ __global__ __launch_bounds__(256) void conv_few_to_many_kernel(const float* __re
     }
 }
 
+// few -> 16 channels (the first layer of both EF encoders): one thread per PIXEL and all 16 channels — a quarter of the input loads
+// and address arithmetic of the kernel above, every weight read an LDS broadcast, 16-byte stores (64 contiguous bytes per lane).
+// 1 -> 16 3x3 at 64x64, 1280 frames, operand-format output: 0.143 -> see DESIGN.md 3.5.
+template <int CI, int K>
+__global__ __launch_bounds__(256) void conv_few_to_16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             char* __restrict__ y_sp, long long npix, int H, int W, int pad, float leaky, int tr) {
+    constexpr int KK = K * K, CO = 16;
+    __shared__ __attribute__((aligned(16))) float wl[KK * CI * CO];   // [tap][ci][co]
+    for (int e = threadIdx.x; e < KK * CI * CO; e += 256) {
+        const int co = e % CO, r = e / CO, ci = r % CI, tap = r / CI;
+        wl[e] = tr ? w[(ci * CO + co) * KK + tap] : w[(co * CI + ci) * KK + tap];
+    }
+    __syncthreads();
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const int xx = (int)(p % W);
+    const long long r = p / W;
+    const int yy = (int)(r % H);
+    const long long row0 = (r / H) * H;
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = bias ? *reinterpret_cast<const f32x4*>(bias + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int iy = yy + ky - pad, ix = xx + kx - pad;
+            const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float* src = x + ((row0 + iy) * W + ix) * CI;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) {
+                const float v = in ? src[ci] : 0.f;
+                const float* wr = wl + ((ky * K + kx) * CI + ci) * CO;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += v * *reinterpret_cast<const f32x4*>(wr + q * 4);
+            }
+        }
+    if (leaky != 0.0f) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q][e] = acc[q][e] > 0.f ? acc[q][e] : acc[q][e] * leaky;
+    }
+    if (y) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(y + p * CO + q * 4) = acc[q];
+    }
+    if (y_sp) {   // [pixel][group of 8 channels][8 hi | 8 lo]
+        unsigned h[16], l[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned short hb = cs_bf16_bits(acc[q][e]);
+                h[q * 4 + e] = hb;
+                l[q * 4 + e] = cs_bf16_bits(acc[q][e] - __builtin_bit_cast(float, (unsigned)hb << 16));
+            }
+        char* dst = y_sp + p * CO * 4;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            *reinterpret_cast<uint4*>(dst + g * 32) = uint4{h[g * 8] | (h[g * 8 + 1] << 16), h[g * 8 + 2] | (h[g * 8 + 3] << 16),
+                                                            h[g * 8 + 4] | (h[g * 8 + 5] << 16), h[g * 8 + 6] | (h[g * 8 + 7] << 16)};
+            *reinterpret_cast<uint4*>(dst + g * 32 + 16) = uint4{l[g * 8] | (l[g * 8 + 1] << 16), l[g * 8 + 2] | (l[g * 8 + 3] << 16),
+                                                                 l[g * 8 + 4] | (l[g * 8 + 5] << 16), l[g * 8 + 6] | (l[g * 8 + 7] << 16)};
+        }
+    }
+}
+
 // many -> few (1x1): y[p][co] = act(bias[co] + sum_ci x[p][ci] * w[co][ci]), CO = 1 or 3; one thread per pixel, 16-byte loads
 template <int CO>
 __global__ __launch_bounds__(256) void conv_many_to_few_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -123,9 +192,17 @@ hipError_t launch_conv_small(const vpx_conv_desc* d, int kind, const float* x, c
         else hipLaunchKernelGGL(conv_many_to_few_kernel<3>, grid, dim3(256), 0, s, x, w, bias, y, npix, d->Ci, d->leaky_slope);
         return hipGetLastError();
     }
+    const int tr = kind == 3;
+    if (d->Co == 16) {   // one thread per pixel
+        const dim3 g16((unsigned)((npix + 255) / 256));
+        if (kind == 1 && d->Ci == 1) hipLaunchKernelGGL((conv_few_to_16_kernel<1, 3>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 1, d->leaky_slope, 0);
+        else if (kind == 1) hipLaunchKernelGGL((conv_few_to_16_kernel<3, 3>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 1, d->leaky_slope, 0);
+        else if (d->Ci == 1) hipLaunchKernelGGL((conv_few_to_16_kernel<1, 1>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 0, d->leaky_slope, tr);
+        else hipLaunchKernelGGL((conv_few_to_16_kernel<3, 1>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 0, d->leaky_slope, tr);
+        return hipGetLastError();
+    }
     const long long threads = npix * (d->Co / 4);
     const dim3 grid((unsigned)((threads + 255) / 256));
-    const int tr = kind == 3;
     if (kind == 1 && d->Ci == 1) hipLaunchKernelGGL((conv_few_to_many_kernel<1, 3>), grid, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, d->Co, 1, d->leaky_slope, 0);
     else if (kind == 1) hipLaunchKernelGGL((conv_few_to_many_kernel<3, 3>), grid, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, d->Co, 1, d->leaky_slope, 0);
     else if (d->Ci == 1) hipLaunchKernelGGL((conv_few_to_many_kernel<1, 1>), grid, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, d->Co, 0, d->leaky_slope, tr);
