@@ -284,7 +284,6 @@ struct Cell2Epi {
         float* const hout_b = a.h_out ? a.h_out + (size_t)b * a.h_bstride : nullptr;
         float* const g0 = a.gates ? a.gates + img * 4 * Ch : nullptr;
         char* const hsp_b = h_sp ? h_sp + (size_t)b * h_sp_bstride : nullptr;
-        const unsigned sp_off = (ch >> 3) * 32 + (ch & 7) * 2;   // hi quad of channels ch..ch+3; the lo quad sits 16 bytes further
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int ip = k * 8 + p4;
@@ -317,9 +316,16 @@ struct Cell2Epi {
                 unsigned h[4], l[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) c2_split(hn[e], h[e], l[e]);
-                char* dst = hsp_b + 4u * (eo - ch) + sp_off;
-                *reinterpret_cast<uint2*>(dst) = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-                *reinterpret_cast<uint2*>(dst + 16) = uint2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+                // the lane pair (cg even, cg odd) holds one 8-channel group = 32 bytes [8 hi | 8 lo]: the even lane stores the 16 hi
+                // bytes, the odd lane the 16 lo bytes — it keeps its own half of that quantity and receives the partner's (quad_perm
+                // [1,0,3,2]); one 16-byte store per lane and whole 32-byte sectors per instruction instead of two 8-byte stores
+                const bool odd = (cg & 1) != 0;
+                const unsigned h0 = h[0] | (h[1] << 16), h1 = h[2] | (h[3] << 16), l0 = l[0] | (l[1] << 16), l1 = l[2] | (l[3] << 16);
+                const unsigned s0 = odd ? h0 : l0, s1 = odd ? h1 : l1;             // what the partner stores of mine
+                const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, true);
+                const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, true);
+                char* dst = hsp_b + 4u * (eo - ch) + (ch >> 3) * 32 + (odd ? 16 : 0);   // the group's hi or lo half
+                *reinterpret_cast<uint4*>(dst) = odd ? uint4{r0, r1, l0, l1} : uint4{h0, h1, r0, r1};
             }
         }
     }
@@ -340,17 +346,26 @@ struct Cell2Epi {
 
     // (the q form is only selected for tiles inside the image and whole 32-channel tiles: cell2_q_applicable)
     __device__ __forceinline__ void finish16(const f32x4 (&acc)[4][8], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
-                                             int /*ngr*/, int H, int W) const {
+                                             int /*ngr*/, int H, int W, bool stamp_on = false) const {
         const int prow = 4 * wave;
         char* const lds = smem + wave * 16384;
         VecIn v0, v1;
+        C2_EPI_STAMP(43);
         vec_load<false>(v0, b, y0, x0, n_tile, prow, lane, H, W);
+        C2_EPI_STAMP(44);
         c2_barrier();   // every wave has read its last fragments: the staging buffers become the epilogue's transposition space
+        C2_EPI_STAMP(45);
         vec_put16(acc, 0, lds, lane);
+        C2_EPI_STAMP(46);
         vec_load<false>(v1, b, y0, x0, n_tile, prow + 2, lane, H, W);
+        C2_EPI_STAMP(47);
         vec_math(v0, lds, b, n_tile, lane, H, W);
+        C2_EPI_STAMP(48);
         vec_put16(acc, 1, lds, lane);
+        C2_EPI_STAMP(49);
         vec_math(v1, lds, b, n_tile, lane, H, W);
+        C2_EPI_STAMP(50);
+        (void)stamp_on;
     }
 
     __device__ __forceinline__ void finish(const f32x16 (&acc)[2][4], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
@@ -779,6 +794,10 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
                      Wbuf + slot * CQ_WCHUNK + half * 8192 + w * (G::NT * 16) + dma_off);
     };
 
+#ifdef VPX_ABLATE
+    const bool stamp_on = (int)L == P._p;
+#endif
+    C2_STAMP(0);
     f32x4 acc[4][8];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -823,7 +842,9 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
             if constexpr (NW == 8) issue_Wh(1, 1, 1);
             C2_WAIT_VM(2);
         } else C2_WAIT_VM(0);
+        C2_STAMP(1);
         c2_barrier();
+        C2_STAMP(2);
 #pragma unroll
         for (int m = 0; m < 4; ++m) load_A1(0, m, a_lane);
         load_B(0, 0);
@@ -903,7 +924,17 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
         }
         if constexpr (NW == 4) { const int t = wb0; wb0 = wb1; wb1 = t; }
     }
+    C2_STAMP(40);
+#ifdef VPX_ABLATE
+    if constexpr (std::is_same<Epi, Cell2Epi>::value) epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W, stamp_on);
+    else
+#endif
     epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+    C2_STAMP(41);
+#ifdef VPX_ABLATE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // how long the epilogue's stores take to complete
+#endif
+    C2_STAMP(42);
 }
 
 // Half tile (cell2_kernel_q<.., 4>: 16x16-pixel tiles, two workgroups per CU) or the 32x16 tile? Measured (tools/ab_exp.py,
@@ -932,6 +963,9 @@ static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStrea
     p.grid_m = plan.B * plan.tiles_x * plan.tiles_y;
     if (plan.qform) {
         p._q = g_experiment;
+#ifdef VPX_ABLATE
+        { const char* e = getenv("VPX_C2_STAMP_BLOCK"); p._p = e ? atoi(e) : -1; }
+#endif
         if (cell2_half_tile(p, std::is_same<Epi, Conv2Epi>::value)) {
             p.tiles_y = (p.H + 15) / 16;
             p.grid_m = p.B * p.tiles_x * p.tiles_y;
