@@ -113,6 +113,9 @@ def test_bench_launcher_path_runs_rccl_world1():
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["backend"] == "nccl (RCCL)" and line["config"]["mode"] == "train"
     assert line["value"] > 0 and line["steps"] == 2
+    # the measurement contract's extra objects: roofline of the dominant kernel (live HIP-event timing) and the prewarm record
+    assert line["roofline"]["bound"] == "mfma" and 0.0 < line["roofline"]["frac"] < 1.0 and line["roofline"]["achieved"] > 0
+    assert line["config"]["prewarm"]["steps"] >= 2 and line["config"]["workload"].startswith("convlstm-shi")
 
 
 def test_trainer_runs_predrnn_training_semantics(vpx):
