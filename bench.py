@@ -393,6 +393,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL on this host driver); before the HIP runtime starts
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
