@@ -237,22 +237,22 @@ def measured_traffic(spec):
     if cands:
         with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
             t = json.load(fh).get("hbm_traffic_bytes_per_launch")
-        return None if t is None else round(t["total"])
+        return (None, None) if t is None else (round(t["total"]), "profiles/" + cands[-1])
     if spec.cell:
-        return None
+        return None, None
     # ... or the headline collection's (tools/collect_profiles.sh) for the 64x64 10->10 convlstm-shi configurations
     if not (spec.img == 64 and spec.channels == 1 and spec.context == 10 and spec.pred == 10):
-        return None
+        return None, None
     tag = {"convlstm-shi": ""}.get(spec.model)
     if tag is None:
-        return None
+        return None, None
     cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
                    if f.endswith(f"_pmc_bench_{spec.mode}_b{spec.batch}_{spec.precision}.json"))
     if not cands:
-        return None
+        return None, None
     with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
         t = json.load(fh).get("hbm_traffic_bytes_per_launch")
-    return None if t is None else round(t["total"])
+    return (None, None) if t is None else (round(t["total"]), "profiles/" + cands[-1])
 
 
 def roofline(spec, ps):
@@ -260,9 +260,10 @@ def roofline(spec, ps):
     ach_gbs = ps["bytes"] / (ps["ms"] * 1e-3) / 1e9 if ps["ms"] > 0 else 0.0
     peak = PEAK_TFLOPS[spec.precision]
     launches = max(ps["launches"], 1)
+    traffic, traffic_source = measured_traffic(spec)   # NOT measured in this run: the committed PMC pass of the same configuration
     return {
         "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-        "frac": round(ach_tflops / peak, 4), "traffic": measured_traffic(spec),
+        "frac": round(ach_tflops / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": round(ps["bytes"] / launches),
         "kernel": ((f"cell2_kernel_q<Cell2Epi, true, 4> (second-generation fused ConvLSTM cell step: pre-split bf16x3 operands, "
                     f"LDS-DMA staging, v_mfma_f32_16x16x32_bf16, 16x16-pixel tiles at two workgroups per CU; cell3_kernel — 8-channel "
@@ -345,6 +346,61 @@ def cpu_baseline(model, spec, seconds):
                       f"{n} iterations in {el:.1f} s on {threads} of {all_cores} host threads (the best point of a 3-point "
                       f"thread scan {{all, 32, 16}}, not all cores: the batch-4 problem over-subscribes them; "
                       f"~{seconds:.0f} s of CPU work in total)"}
+
+
+# The driver keeps a bounded tail of stdout and parses the LAST line: r02's 10.5 KB line parsed, r03's 27 KB line did not
+# (BENCH_r03.json: "parsed": null). The final stdout line is therefore the compact form below (< LINE_BUDGET bytes); the full
+# record (long kernel / workload / semantics / note strings of every entry) goes to bench_extras.json.
+LINE_BUDGET = 6144
+ROOFLINE_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch",
+                 "launches", "avg_launch_us", "frac_of_bf16_dense_peak")
+
+
+def compact_roofline(rf):
+    out = {k: rf[k] for k in ROOFLINE_KEEP if k in rf}
+    hv = rf.get("hbm_view")
+    if hv:
+        out["hbm_view"] = {"achieved_GBps": hv["achieved_GBps"], "peak_GBps": hv["peak_GBps"], "frac": hv["frac"]}
+    return out
+
+
+def compact_extra(e):
+    if "error" in e:
+        return {"name": e["name"], "error": e["error"][:120]}
+    rf = e.get("roofline", {})
+    out = {"name": e["name"], "dtype": e["dtype"], "ms_per_step": e["ms_per_step"], "value": e["value"],
+           "unit": "cellsteps/s" if e["unit"].startswith("cell") else e["unit"], "frac": rf.get("frac"),
+           "traffic": rf.get("traffic")}
+    if rf.get("hbm_view"):
+        out["hbm_frac"] = rf["hbm_view"]["frac"]
+    return out
+
+
+def compact_line(full):
+    """The ONE stdout line: headline + roofline + cpu_baseline + per-extra {name, dtype, ms_per_step, value, unit, frac,
+    hbm_frac, traffic}; everything long lives in the sidecar file named by `extras_file`."""
+    out = {k: v for k, v in full.items() if k not in ("roofline", "cpu_baseline", "extras", "config")}
+    cfg = dict(full["config"])
+    cfg.pop("semantics", None)
+    if isinstance(cfg.get("prewarm"), dict):
+        cfg["prewarm"] = {k: cfg["prewarm"][k] for k in ("seconds", "steps") if k in cfg["prewarm"]}
+    out["config"] = cfg
+    out["roofline"] = compact_roofline(full["roofline"])
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "all_cores", "sample") if k in cb}
+        out["cpu_baseline"]["sample"] = cb["sample"][:200]
+    if "extras" in full:
+        out["extras"] = [compact_extra(e) for e in full["extras"]]
+        out["extras_file"] = "bench_extras.json"
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= LINE_BUDGET:   # never let the extras cost the headline: drop them from the line, they stay in the sidecar
+        out["extras"] = [{"name": e["name"], "value": e.get("value"), "frac": e.get("frac")} for e in out.get("extras", [])]
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) >= LINE_BUDGET:
+        out.pop("extras", None)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
 
 
 def extras_for(world):
@@ -465,7 +521,15 @@ def main():
             out["extras"] = extras
         if cpu_model is not None:
             out["cpu_baseline"] = cpu_baseline(cpu_model, spec, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        full = json.dumps(out)
+        try:   # the full record: sidecar file next to bench.py (gpurun_out/ too when it exists)
+            for d in [ROOT] + ([os.path.join(ROOT, "gpurun_out")] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else []):
+                with open(os.path.join(d, "bench_extras.json"), "w") as fh:
+                    fh.write(full + "\n")
+        except OSError as exc:
+            print(f"[bench] could not write bench_extras.json: {exc}", file=sys.stderr)
+        # nothing long on either stream: the driver's capture of this run is bounded (head or tail, unknown)
+        print(compact_line(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

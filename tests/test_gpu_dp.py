@@ -110,8 +110,12 @@ def test_bench_launcher_path_runs_rccl_world1():
            "--batch", "8", "--mode", "train", "--no-extras", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    last = out.stdout.splitlines()[-1]
+    # the driver parses the LAST stdout line out of a bounded capture: it must be the JSON line, and short (BENCH_r03: parsed null)
+    assert last.startswith("{") and len(last) < bench.LINE_BUDGET and len(out.stdout) < 2 * bench.LINE_BUDGET, len(out.stdout)
+    line = json.loads(last)
     assert line["n_gpus"] == 1 and line["config"]["backend"] == "nccl (RCCL)" and line["config"]["mode"] == "train"
+    assert "traffic_source" in line["roofline"]
     assert line["value"] > 0 and line["steps"] == 2
     # the measurement contract's extra objects: roofline of the dominant kernel (live HIP-event timing) and the prewarm record
     assert line["roofline"]["bound"] == "mfma" and 0.0 < line["roofline"]["frac"] < 1.0 and line["roofline"]["achieved"] > 0

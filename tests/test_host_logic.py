@@ -245,6 +245,61 @@ def test_bench_spawns_ranks_before_touching_the_gpu(vpx, monkeypatch):
     assert any(s.mode == "train" for s in bench.extras_for(8))
 
 
+def test_bench_final_line_fits_the_driver_capture(vpx):
+    """The LAST stdout line of bench.py is what the driver parses, from a bounded capture (BENCH_r03.json: a 27 KB line gave
+    "parsed": null; r02's 10.5 KB line parsed). With every extra present the compact line must stay below bench.LINE_BUDGET,
+    round-trip through json, and still carry the contract's keys, `roofline` and `cpu_baseline`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ps = {"flops": 156.27e9 * 1200, "bytes": 321452715 * 1200, "ms": 388.0, "launches": 1200}
+    head = bench.Spec("headline")
+    full = {"metric": "predicted frames/sec (whole node), MovingMNIST 64x64 10->10", "value": 53211.12, "unit": "frames/s",
+            "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 24.0512, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16x3", "data": "synthetic",
+            "config": {"workload": head.workload(), "mode": "infer", "semantics": "VPModel.forward under no_grad" * 4,
+                       "per_gpu_batch": 128, "global_batch": 128, "parallelism": "dp1", "ranks": 1, "backend": "single process",
+                       "prewarm": {"seconds": 0.5, "steps": 23, "what": "x" * 100}},
+            "roofline": bench.roofline(head, ps), "extras": [],
+            "cpu_baseline": {"value": 173.69, "unit": "predicted frames/s", "cores": 16, "kind": "port",
+                             "all_cores": {"cores": 128, "value": 18.96}, "thread_scan": {"128": 18.96, "32": 120.1, "16": 173.69},
+                             "sample": "oracle/torch_ref.ef_convlstm_forward " + "y" * 400}}
+    for es in bench.extras_for(1):
+        rf = bench.roofline(es, ps)
+        full["extras"].append({"name": es.name, "workload": es.workload(), "mode": es.mode, "semantics": "s" * 200,
+                               "dtype": es.precision, "per_gpu_batch": es.batch, "global_batch": es.batch, "n_gpus": 1,
+                               "steps": 128, "timed_region_s": 3.004, "ms_per_step": 23.4712, "value": 54538.11,
+                               "unit": "cell steps x samples/s" if es.cell else "frames/s", "roofline": rf})
+    full["extras"].append({"name": "broken", "error": "RuntimeError: " + "z" * 500})
+    assert len(json.dumps(full)) > 20000          # the record that broke the r03 parse
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line) < bench.LINE_BUDGET <= 8192, len(line)
+    got = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in got, k
+    assert got["value"] == full["value"] and got["config"]["workload"] == head.workload()
+    rf = got["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
+        assert k in rf, k
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3)
+    # traffic is a citation of a committed PMC pass, never presented as live: its source file is named next to it
+    assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
+    if rf["traffic_source"]:
+        assert os.path.exists(os.path.join(ROOT, rf["traffic_source"]))
+    cb = got["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 16 and len(cb["sample"]) <= 200
+    names = [e["name"] for e in got["extras"]]
+    assert names == [e["name"] for e in full["extras"]] and got["extras_file"] == "bench_extras.json"
+    e0 = got["extras"][0]
+    assert set(e0) <= {"name", "dtype", "ms_per_step", "value", "unit", "frac", "hbm_frac", "traffic"} and e0["frac"] is not None
+    # degenerate case: far too many extras still yields a parseable headline under the budget
+    full["extras"] = full["extras"] * 8
+    line = bench.compact_line(full)
+    assert len(line) < bench.LINE_BUDGET and json.loads(line)["roofline"]["frac"] == rf["frac"]
+
+
 def test_ef_trajgru_registry_and_state_dict_contract(vpx):
     """"trajgru" is registered under the reference's key; parameter names / shapes / order equal the reference's."""
     from vp_suite_amd.models import MODEL_CLASSES
