@@ -63,6 +63,117 @@ def _worker(rank, world, port, frames, ret, bucketed):
     dist.destroy_process_group()
 
 
+def _validate_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import vp_suite_amd  # noqa: F401
+    from vp_suite_amd.train import DataParallelTrainer
+    torch.manual_seed(5)
+    model = _TinyPredictor()
+    tr = DataParallelTrainer(model, lr=1e-2, world_size=world, device="cpu", seed=42)
+    # per-rank random stream (scheduled-sampling masks of the shard): seed + rank, different on every rank
+    draw = torch.rand(4)
+    torch.manual_seed(42 + rank)
+    assert torch.equal(draw, torch.rand(4))
+    # rank-dependent validation data: the metric the scheduler sees must be the mean over ranks, identical everywhere
+    g = torch.Generator().manual_seed(900 + rank)
+    batches = [(torch.rand(2, 3, 1, 8, 8, generator=g), torch.rand(2, 2, 1, 8, 8, generator=g) * (1 + 3 * rank)) for _ in range(2)]
+    local = torch.stack([tr.loss_provider.get_losses(model(x, pred_frames=2)[0], y)[0]["mse"] for x, y in batches]).mean().detach()
+    vals, lrs = [], []
+    for it in range(8):   # patience 5: the 7th non-improving call cuts the learning rate - on every rank at once
+        v = tr.validate(batches, 2)
+        vals.append(float(v))
+        lrs.append(tr.optimizer.param_groups[0]["lr"])
+    both = [torch.zeros(1 + 8 + 8, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(both, torch.tensor([float(local)] + vals + lrs, dtype=torch.float64))
+    if rank == 0:
+        ret["local"] = [float(b[0]) for b in both]
+        ret["vals"] = [b[1:9].tolist() for b in both]
+        ret["lrs"] = [b[9:].tolist() for b in both]
+    dist.destroy_process_group()
+
+
+def test_validate_reduces_the_metric_before_the_scheduler_reads_it():
+    """validate() used the asynchronous all-reduce without waiting: each rank stepped ReduceLROnPlateau on
+    its own local_v / W and the replicas' learning rates drifted apart."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_validate_worker, args=(2, port, ret), nprocs=2, join=True)
+    l0, l1 = ret["local"]
+    assert abs(l0 - l1) > 1e-3 * abs(l0)                      # the shards really differ
+    assert ret["vals"][0] == ret["vals"][1] and ret["lrs"][0] == ret["lrs"][1]
+    assert ret["vals"][0][0] == pytest.approx((l0 + l1) / 2, rel=1e-6)
+    assert ret["lrs"][0][0] == pytest.approx(1e-2) and ret["lrs"][0][-1] == pytest.approx(2e-3)   # cut once, together
+
+
+def _real_buckets_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import vp_suite_amd  # noqa: F401
+    from vp_suite_amd.models import MODEL_CLASSES
+    from vp_suite_amd.train import DataParallelTrainer
+    torch.manual_seed(rank)
+    model = MODEL_CLASSES["convlstm-shi"]("cpu", img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0])
+    tr = DataParallelTrainer(model, lr=1e-3, world_size=world, device="cpu")
+    names = [n for n, _ in model.named_parameters()]
+    params = [p for _, p in model.named_parameters()]
+    launches = []
+    inner = tr._all_reduce
+    tr._all_reduce = lambda t: (launches.append((t.storage_offset(), t.numel())), inner(t))[1]
+    # The kernels have no CPU path; the harness does not care what produced the loss. A stand-in loss touches every
+    # parameter with a rank-dependent coefficient; rank 1 builds its graph in a scrambled order and leaves one whole
+    # block (forecaster.rnn2) and one single tensor without a gradient, so its hooks fire in another order than rank 0's.
+    order = list(range(len(params)))
+    skip = set()
+    if rank == 1:
+        order = order[::2] + order[1::2][::-1]
+        skip = {i for i, n in enumerate(names) if n.startswith("forecaster.rnn2.")} | {names.index("encoder.rnn1.Wci")}
+
+    def fake_loss(x, target, pred_frames, loss_provider, **kw):
+        return sum((rank + 1.0) * (i % 7 + 1) * params[i].sum() for i in order if i not in skip)
+    model.training_loss = fake_loss
+    for _ in range(2):
+        tr.step(None, None, 1)
+    grads = tr.flat_grad.clone()
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    got = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(got, flat)
+    all_l = [None] * world
+    dist.all_gather_object(all_l, launches)
+    if rank == 0:
+        ret["buckets"] = [(b[3], b[0], b[1], b[2]) for b in tr.buckets]
+        ret["launches"] = all_l
+        ret["params_equal"] = bool(torch.equal(got[0], got[1]))
+        # expected reduced gradient: sum over ranks of coefficient (constant per tensor), rank 1 skipping some
+        want = torch.cat([torch.full((p.numel(),), (i % 7 + 1) * (1.0 + (0.0 if i in
+                          {j for j, n in enumerate(names) if n.startswith("forecaster.rnn2.")} | {names.index("encoder.rnn1.Wci")}
+                          else 2.0))) for i, p in enumerate(params)])
+        ret["grad_ok"] = bool(torch.equal(grads, want / world))   # CPU path: the mean is taken in the bucket (HIP: inside Adam)
+    tr.close()
+    assert not tr._hooks
+    dist.destroy_process_group()
+
+
+def test_real_bucket_table_launches_in_one_order_on_every_rank():
+    """The 12-bucket table of the real EF_ConvLSTM (names, offsets, launch order) at world 2, with hooks firing in a different
+    order and one block without gradients on one rank (a rank-dependent order hangs or corrupts RCCL)."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_real_buckets_worker, args=(2, port, ret), nprocs=2, join=True)
+    b = ret["buckets"]
+    assert [x[0] for x in b] == ["encoder.stage1", "encoder.rnn1", "encoder.stage2", "encoder.rnn2", "encoder.stage3", "encoder.rnn3",
+                                 "forecaster.rnn3", "forecaster.stage3", "forecaster.rnn2", "forecaster.stage2", "forecaster.rnn1",
+                                 "forecaster.stage1"]
+    assert b[0][1] == 0 and all(b[i][1] + b[i][2] == b[i + 1][1] for i in range(11)) and b[-1][1] + b[-1][2] == 5833249
+    assert sum(x[3] for x in b) == 44
+    l0, l1 = ret["launches"]
+    assert l0 == l1 and len(l0) == 24
+    per_step = [(x[1], x[2]) for x in reversed(b)]            # strictly descending bucket index, every step
+    assert l0[:12] == per_step and l0[12:] == per_step
+    assert ret["grad_ok"]
+    assert ret["params_equal"]
+
+
 @pytest.mark.parametrize("bucketed", [True, False])
 def test_dp_matches_single_process(bucketed):
     import vp_suite_amd  # noqa: F401
@@ -85,9 +196,10 @@ def test_dp_matches_single_process(bucketed):
     names = [n for n, _ in ret["buckets"]]
     assert names == ["conv", "head", "unused"]
     total = sum(n for _, n in ret["buckets"])
-    if bucketed:   # three steps x one launch per block, in the order the backward pass finishes them (head's gradients come first)
+    if bucketed:   # three steps x one launch per block, strictly in descending block order (the backward pass's order)
         assert len(ret["launches"]) == 9 and sum(ret["launches"]) == 3 * total
-        assert ret["launches"][0] == dict(ret["buckets"])["head"] and ret["launches"][2] == dict(ret["buckets"])["unused"]
+        bk = dict(ret["buckets"])
+        assert ret["launches"][:3] == [bk["unused"], bk["head"], bk["conv"]]
     else:
         assert ret["launches"] == [total] * 3
     assert torch.allclose(ret["params"], want, rtol=1e-5, atol=1e-7), float((ret["params"] - want).abs().max())

@@ -10,10 +10,13 @@ SURVEY.md §2.1), restating the training semantics of the reference around it:
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for tests). The only
 exchange is the all-reduce of the fp32 gradients: every parameter's .grad is a view into ONE flat buffer, so there is no
 gather/scatter copy around the collective. The buffer is cut into per-block buckets (encoder.stage1, encoder.rnn1, ...,
-contiguous ranges in parameter order); a bucket's all-reduce is launched asynchronously the moment the backward pass has
-produced the last gradient of the block (autograd post-accumulate hooks) and runs on RCCL's stream under the BPTT of the
-blocks still to come; the last wait sits in front of the optimizer step (`bucketed=False`: one all-reduce of the whole
-buffer after the backward pass). Because the loss is a batch mean, all-reduce(sum)/W of the per-shard gradients equals
+contiguous ranges in parameter order); a bucket's all-reduce is launched asynchronously from the backward pass (autograd
+post-accumulate hooks) and runs on RCCL's stream under the BPTT of the blocks still to come. Launch order is FIXED —
+strictly descending bucket index, the order in which the backward pass finishes the blocks: bucket i goes out once its own
+gradients are complete AND every bucket above it has gone out, so every rank enqueues the same collectives in the same order
+whatever order its hooks fire in (a rank-dependent order would hang or mix up RCCL messages); what is still missing at the
+end of the backward pass goes out in the same descending order. The last wait sits in front of the optimizer step
+(`bucketed=False`: one all-reduce of the whole buffer after the backward pass). Because the loss is a batch mean, all-reduce(sum)/W of the per-shard gradients equals
 the single-process gradient of the global batch."""
 import torch
 import torch.distributed as dist
@@ -153,8 +156,10 @@ class DataParallelTrainer:
     replace it to execute the world>1 arithmetic (sum of shard gradients, 1/W folded into the update) on one device."""
 
     def __init__(self, model, lr: float = 1e-4, world_size: int = None, losses_and_scales=None, device=None,
-                 force_collectives: bool = False, all_reduce=None, broadcast=None, bucketed: bool = True):
+                 force_collectives: bool = False, all_reduce=None, broadcast=None, bucketed: bool = True,
+                 seed: int = None, rank: int = None):
         self.model = model
+        self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.params = [p for p in model.parameters() if p.requires_grad]
         dev = device if device is not None else self.params[0].device
@@ -189,9 +194,11 @@ class DataParallelTrainer:
         self._pending = []         # gradients still missing per bucket (this step)
         self._handles = []
         self._launched = []
+        self._next = -1            # the bucket whose turn it is (descending); -1 = nothing outstanding
+        self._hooks = []           # RemovableHandles: close() takes the hooks off the model again
         if self.collectives and self.bucketed:
             for p in self.params:
-                p.register_post_accumulate_grad_hook(self._grad_ready)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._grad_ready))
         if self.fused:
             # parameters become views of ONE flat bucket as well, so the update is one kernel over (param, grad, m, v)
             self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
@@ -201,6 +208,16 @@ class DataParallelTrainer:
         self.optimizer = FlatAdam(self.params, self.flat_param, self.flat_grad, lr=lr) if self.fused \
             else torch.optim.Adam(self.params, lr=lr)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, patience=5, factor=0.2, min_lr=1e-6)
+        if seed is not None:
+            self.seed_rank_rng(seed)
+
+    def seed_rank_rng(self, seed: int):
+        """Per-rank random stream = seed + rank: the replicas hold identical parameters (broadcast) but must draw DIFFERENT
+        scheduled-sampling masks for their shards (predrnn_v2.py:252-317 draws them from the global generator), as the
+        single-process run draws independent rows for every sample of the global batch."""
+        torch.manual_seed(int(seed) + self.rank)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(int(seed) + self.rank)
 
     def broadcast_parameters(self, src: int = 0):
         with torch.no_grad():
@@ -218,6 +235,18 @@ class DataParallelTrainer:
                 total = total + value
         return total
 
+    def close(self):
+        """Takes the gradient hooks off the model (a discarded trainer must not launch collectives from a later backward)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self._pending, self._next = [], [], -1
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _launch_bucket(self, i):
         off, n = self.buckets[i][0], self.buckets[i][1]
         h = self._all_reduce(self.flat_grad[off:off + n])
@@ -225,14 +254,19 @@ class DataParallelTrainer:
         if h is not None:
             self._handles.append(h)
 
+    def _launch_ready(self, force: bool = False):
+        """Launches buckets in strictly descending index order: `_next` goes out when complete (or `force`), then the one
+        below it, ... — never a lower bucket before a higher one, so the sequence of collectives is rank-independent."""
+        while self._next >= 0 and (force or self._pending[self._next] <= 0):
+            self._launch_bucket(self._next)
+            self._next -= 1
+
     def _grad_ready(self, p):
-        """Post-accumulate hook: p's gradient of this step is final. The block's bucket goes out with its last one."""
+        """Post-accumulate hook: p's gradient of this step is final."""
         if not self._pending:
             return
-        i = self._bucket_of[id(p)]
-        self._pending[i] -= 1
-        if self._pending[i] == 0 and not self._launched[i]:
-            self._launch_bucket(i)
+        self._pending[self._bucket_of[id(p)]] -= 1
+        self._launch_ready()
 
     def backward_shard(self, x, target, pred_frames: int, **fwd_kwargs):
         """Forward + loss + backward on this rank's shard; leaves the shard's gradient in `flat_grad`. Models with their
@@ -241,6 +275,7 @@ class DataParallelTrainer:
         self._pending = [b[2] for b in self.buckets] if (self.collectives and self.bucketed) else []
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self._next = len(self.buckets) - 1 if self._pending else -1
         hook = getattr(self.model, "training_loss", None)
         if hook is not None:
             total = hook(x, target, pred_frames, self.loss_provider, **fwd_kwargs)
@@ -253,17 +288,20 @@ class DataParallelTrainer:
     def reduce_gradients(self):
         if self.collectives:
             if self.bucketed:
-                # buckets whose hooks did not all fire (a parameter without a gradient this step) go out now
-                for i in range(len(self.buckets)):
-                    if not self._launched[i]:
-                        self._launch_bucket(i)
+                # buckets whose hooks did not all fire (a parameter without a gradient this step) go out now, same order
+                if len(self._launched) != len(self.buckets):
+                    self._launched = [False] * len(self.buckets)
+                if self._next < 0 and not all(self._launched):
+                    self._next = len(self.buckets) - 1   # reduce_gradients without backward_shard: everything, descending
+                    self._pending = [0] * len(self.buckets)
+                self._launch_ready(force=True)
             else:
                 h = self._all_reduce(self.flat_grad)
                 if h is not None:
                     self._handles.append(h)
             for h in self._handles:
                 h.wait()
-            self._handles, self._pending = [], []
+            self._handles, self._pending, self._next = [], [], -1
             if self.world > 1:
                 if self.fused:
                     self.optimizer.grad_scale = 1.0 / self.world  # folded into the update kernel
@@ -285,7 +323,10 @@ class DataParallelTrainer:
         self.model.train()
         v = torch.stack(vals).mean()
         if self.world > 1:
-            self._all_reduce(v)
+            v = v.clone()
+            h = self._all_reduce(v)   # asynchronous by default: the sum must have landed before it is divided and read
+            if h is not None:
+                h.wait()
             v = v / self.world
         self.scheduler.step(v.item())
         return v
