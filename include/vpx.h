@@ -158,12 +158,15 @@ int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, const float* h
                         float* dWlast, float* const* dln, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- decoupling-loss term: mean_{b,ch} |cos(normalize(A*dc), normalize(A*dm))| over H*W ---------------------- */
-/* delta_c/delta_m [B,H,W,Ch] (NHWC) ; adapter [Ch,Ch] ; value / dvalue: 1 float on device */
+/* delta_c/delta_m [B,H,W,Ch] (NHWC) ; adapter [Ch,Ch] ; value / dvalue: 1 float on device.
+ * precision (vpx_precision): arithmetic of the tail's three 1x1 contractions (adapter, its adjoint, its weight gradient) —
+ * the caller passes the model's own operand mode, so a VPX_PREC_F32 model gets exact fp32 here too (round 3 ran this tail in
+ * bf16x3 for every caller). The normalisation / cosine / mean are fp32 with double partial sums in every mode. */
 size_t vpx_decouple_workspace_bytes(int B, int Ch, int H, int W);
 int vpx_decouple_fwd(const float* delta_c, const float* delta_m, const float* adapter, float* value, int B, int Ch,
-                     int H, int W, void* workspace, size_t workspace_bytes, void* stream);
+                     int H, int W, int precision, void* workspace, size_t workspace_bytes, void* stream);
 int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* adapter, const float* dvalue,
-                     float* d_delta_c, float* d_delta_m, float* d_adapter, int B, int Ch, int H, int W,
+                     float* d_delta_c, float* d_delta_m, float* d_adapter, int B, int Ch, int H, int W, int precision,
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- training tail (the caller side of the path: base_model.py:168-176, vpsuite.py:353) ------------------------- */

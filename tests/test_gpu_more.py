@@ -146,13 +146,12 @@ def test_conv2d_ex_vs_torch(vpx):
         (False, 3, 16, 3, 1, 1, 19, 21), (False, 16, 3, 1, 1, 0, 18, 20),   # few-channel layers: wgrad_small_kernel (with 1->16, 16->1 above)
     ]
     _conv2d_ex_cases(vpx, cases, F)   # backward: vpx_conv2d_ex_bwd (adjoint layer + strided MFMA weight gradient)
-    # the ATen fallback wiring (used when the kernel is smaller than the stride), on ATen's native kernels: MIOpen's
-    # solver search aborted ~10 % of full-suite runs on these exotic shapes
-    vpx.ops.GLUE_BACKWARD_HIP, vpx.ops.GLUE_BACKWARD_NATIVE = False, True
-    try:
-        _conv2d_ex_cases(vpx, cases[:3], F)
-    finally:
-        vpx.ops.GLUE_BACKWARD_HIP, vpx.ops.GLUE_BACKWARD_NATIVE = True, False
+    # a layer outside the library's glue backward (kernel smaller than its stride) raises instead of falling back to ATen
+    x = torch.rand(1, 4, 8, 8, device="cuda", requires_grad=True)
+    w = torch.rand(4, 4, 1, 1, device="cuda", requires_grad=True)
+    y = vpx.ops.conv2d_ex(x, w, None, 2, 0, False, 0.2, "f32")
+    with pytest.raises(vpx.ops.VpxError, match="unsupported"):
+        y.sum().backward()
 
 
 def _conv2d_ex_cases(vpx, cases, F):

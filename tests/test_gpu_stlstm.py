@@ -154,14 +154,19 @@ def test_decouple_and_conv2d_vs_golden_and_autograd(vpx):
     from golden_util import seeded_randn
     g = load_golden("decouple_tiny")
     B, Ch, H, W = [int(v) for v in g["shape"]]
-    A = seeded_randn((Ch, Ch, 1, 1), name_seed("decouple.adapter"), 1.0 / np.sqrt(Ch)).cuda().requires_grad_(True)
-    dc = seeded_randn((B, Ch, H, W), name_seed("decouple.dc")).cuda().requires_grad_(True)
-    dm = seeded_randn((B, Ch, H, W), name_seed("decouple.dm")).cuda().requires_grad_(True)
-    v = vpx.ops.decouple_term(dc, dm, A)
-    assert abs(float(v) - float(g["value"])) < 1e-6
-    v.backward()
-    assert _relmax(dc.grad, g["d_dc"]) < GRTOL and _relmax(dm.grad, g["d_dm"]) < GRTOL
-    assert _relmax(A.grad, g["d_adapter"]) < GRTOL
+    values = {}
+    for prec in ("f32", "bf16x3"):   # the tail runs in the arithmetic the caller names (the model's operand mode), f32 by default
+        A = seeded_randn((Ch, Ch, 1, 1), name_seed("decouple.adapter"), 1.0 / np.sqrt(Ch)).cuda().requires_grad_(True)
+        dc = seeded_randn((B, Ch, H, W), name_seed("decouple.dc")).cuda().requires_grad_(True)
+        dm = seeded_randn((B, Ch, H, W), name_seed("decouple.dm")).cuda().requires_grad_(True)
+        v = vpx.ops.decouple_term(dc, dm, A, prec) if prec != "f32" else vpx.ops.decouple_term(dc, dm, A)
+        values[prec] = float(v)
+        assert abs(float(v) - float(g["value"])) < 1e-6
+        v.backward()
+        assert _relmax(dc.grad, g["d_dc"]) < GRTOL and _relmax(dm.grad, g["d_dm"]) < GRTOL
+        assert _relmax(A.grad, g["d_adapter"]) < GRTOL
+    with pytest.raises(KeyError):
+        vpx.ops.decouple_term(dc, dm, A, "fp64")
     for prec, tol in (("f32", 2e-5), ("bf16x3", 1e-4)):
         for (Ci, Co, k, Hh, Ww) in [(128, 16, 1, 16, 16), (24, 40, 3, 9, 21)]:
             x = seeded_randn((3, Ci, Hh, Ww), name_seed(f"c2g.x{Ci}{k}"))

@@ -245,6 +245,32 @@ def test_bench_spawns_ranks_before_touching_the_gpu(vpx, monkeypatch):
     assert any(s.mode == "train" for s in bench.extras_for(8))
 
 
+def test_workspace_cache_is_bounded_and_drops_stale_entries(vpx):
+    """ops._WorkspaceCache (inference workspaces + weight packs): LRU under a byte budget; entries whose weight died, changed
+    version or belong to an older kernel-option epoch are dropped on insert (up to 64 x 1 GiB could stay pinned)."""
+    C = vpx.ops._WorkspaceCache(budget_bytes=1000)
+    w1, w2 = torch.zeros(4), torch.zeros(4)
+    a = torch.empty(400, dtype=torch.uint8)
+    C.put(("k1",), w1, w1.data_ptr(), a, 0)
+    assert C.get(("k1",), w1, w1.data_ptr(), 400, a.device) is a
+    assert C.get(("k1",), w1, w1.data_ptr(), 300, a.device) is None and len(C) == 0      # size mismatch drops it
+    C.put(("k1",), w1, w1.data_ptr(), a, 0)
+    C.put(("k2",), w2, w2.data_ptr(), torch.empty(400, dtype=torch.uint8), 0)
+    C.get(("k1",), w1, w1.data_ptr(), 400, a.device)                                        # k1 most recent
+    C.put(("k3",), w2, w2.data_ptr(), torch.empty(400, dtype=torch.uint8), 0)               # budget: evicts k2 (LRU)
+    assert list(C.ents) == [("k1",), ("k3",)] and C.bytes == 800
+    w1.add_(1)                                                                              # version bump: k1 is stale
+    assert C.get(("k1",), w1, w1.data_ptr(), 400, a.device) is None and C.bytes == 400
+    C.put(("k4",), w1, w1.data_ptr(), torch.empty(100, dtype=torch.uint8), 1)               # new option epoch: k3 (epoch 0) goes
+    assert list(C.ents) == [("k4",)] and C.bytes == 100
+    del w1
+    C.put(("k5",), w2, w2.data_ptr(), torch.empty(100, dtype=torch.uint8), 1)               # dead weakref: k4 goes
+    assert list(C.ents) == [("k5",)]
+    # LayerNorm parameters ([C,H,W]) hit the layout cache on the parameter object itself
+    p = torch.nn.Parameter(torch.rand(3, 4, 5))
+    assert vpx.ops._cached_channels_last(p) is vpx.ops._cached_channels_last(p)
+
+
 def test_bench_final_line_fits_the_driver_capture(vpx):
     """The LAST stdout line of bench.py is what the driver parses, from a bounded capture (BENCH_r03.json: a 27 KB line gave
     "parsed": null; r02's 10.5 KB line parsed). With every extra present the compact line must stay below bench.LINE_BUDGET,

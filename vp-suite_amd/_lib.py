@@ -115,9 +115,9 @@ def lib():
         L.vpx_decouple_workspace_bytes.restype = sz
         L.vpx_decouple_workspace_bytes.argtypes = [ctypes.c_int] * 4
         L.vpx_decouple_fwd.restype = ctypes.c_int
-        L.vpx_decouple_fwd.argtypes = [vp] * 4 + [ctypes.c_int] * 4 + [vp, sz, vp]
+        L.vpx_decouple_fwd.argtypes = [vp] * 4 + [ctypes.c_int] * 5 + [vp, sz, vp]
         L.vpx_decouple_bwd.restype = ctypes.c_int
-        L.vpx_decouple_bwd.argtypes = [vp] * 7 + [ctypes.c_int] * 4 + [vp, sz, vp]
+        L.vpx_decouple_bwd.argtypes = [vp] * 7 + [ctypes.c_int] * 5 + [vp, sz, vp]
         L.vpx_conv2d_workspace_bytes.restype = sz
         L.vpx_conv2d_workspace_bytes.argtypes = [ctypes.c_int] * 4
         L.vpx_conv2d_nhwc_fwd.restype = ctypes.c_int

@@ -58,27 +58,21 @@ int vpx_conv2d_nhwc_fwd_ex(const float* x, const float* w, const float* bias, fl
 
 /* ---- decoupling-loss tail ---------------------------------------------------------------------------------- */
 }  // extern "C"
-// Arithmetic of the tail's three 1x1 contractions (adapter forward, its adjoint, its weight gradient). Default bf16x3: fp32-level
-// accuracy (4e-6; the loss value and its gradients hold the goldens' 1e-4 / 5e-5 bars) at a third of the exact-fp32 MFMA cycles —
-// the fp32 forms cost PredRNN's training step 34 of 493 ms (wgrad_kernel<1> 18.6, conv_gemm_kernel<EpiPlain<4>, f32> 15).
-// VPX_DECOUPLE_PREC=0 restores exact fp32.
-static int decouple_prec() {
-    static int p = -1;
-    if (p < 0) { const char* e = getenv("VPX_DECOUPLE_PREC"); p = e ? atoi(e) : VPX_PREC_BF16X3; if (p < VPX_PREC_F32 || p > VPX_PREC_BF16) p = VPX_PREC_BF16X3; }
-    return p;
-}
+// Arithmetic of the tail's three 1x1 contractions (adapter forward, its adjoint, its weight gradient) = the caller's `precision`
+// argument (the model's operand mode). bf16x3: fp32-level accuracy (4e-6; the loss value and its gradients hold the goldens'
+// 1e-4 / 5e-5 bars) at a third of the exact-fp32 MFMA cycles — the fp32 forms cost PredRNN's bf16x3 training step 34 of 493 ms.
 // The adapter (1x1, Ch -> Ch; transposed = its adjoint) applied to the c and the m operand. When both the sources and the
 // destinations are adjacent in memory ([2, B, HW, Ch]: the cell step hands out delta_c | delta_m as one block, the
 // workspace slots are adjacent) the pair is ONE convolution over 2B images — these launches are latency-bound (K = Ch).
-static int decouple_adapter_pair(hipStream_t stream, ConvGeo g, const float* sc, const float* sm, const float* adapter,
+static int decouple_adapter_pair(hipStream_t stream, int prec, ConvGeo g, const float* sc, const float* sm, const float* adapter,
                                  float* oc, float* om, size_t n, int Ch, bool transposed, float* wpk) {
     int rc;
     if (sm == sc + n && om == oc + n) {
         const ConvGeo g2{2 * g.N, g.H, g.W};
-        return plain_conv(stream, decouple_prec(), g2, sc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, transposed, nullptr, oc, Ch, false, wpk);
+        return plain_conv(stream, prec, g2, sc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, transposed, nullptr, oc, Ch, false, wpk);
     }
-    if ((rc = plain_conv(stream, decouple_prec(), g, sc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, transposed, nullptr, oc, Ch, false, wpk))) return rc;
-    return plain_conv(stream, decouple_prec(), g, sm, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, transposed, nullptr, om, Ch, false, wpk);
+    if ((rc = plain_conv(stream, prec, g, sc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, transposed, nullptr, oc, Ch, false, wpk))) return rc;
+    return plain_conv(stream, prec, g, sm, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, transposed, nullptr, om, Ch, false, wpk);
 }
 extern "C" {
 size_t vpx_decouple_workspace_bytes(int B, int Ch, int H, int W) {
@@ -88,9 +82,14 @@ size_t vpx_decouple_workspace_bytes(int B, int Ch, int H, int W) {
            align256((size_t)wgrad_slices(B, H, W) * Ch * Ch * 4) + align256((size_t)Ch * Ch * 4) + 1024;
 }
 
+static bool decouple_prec_ok(int prec, const char* who) {
+    if (prec == VPX_PREC_F32 || prec == VPX_PREC_BF16X3 || prec == VPX_PREC_BF16) return true;
+    set_error(std::string(who) + ": unknown precision"); return false;
+}
 int vpx_decouple_fwd(const float* delta_c, const float* delta_m, const float* adapter, float* value, int B, int Ch,
-                     int H, int W, void* workspace, size_t workspace_bytes, void* stream_) {
+                     int H, int W, int prec, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!delta_c || !delta_m || !adapter || !value || B < 1 || Ch < 1 || H < 1 || W < 1) { set_error("vpx_decouple_fwd: bad argument"); return VPX_ERR_ARG; }
+    if (!decouple_prec_ok(prec, "vpx_decouple_fwd")) return VPX_ERR_ARG;
     if (!workspace || workspace_bytes < vpx_decouple_workspace_bytes(B, Ch, H, W)) { set_error("vpx_decouple_fwd: workspace too small"); return VPX_ERR_WORKSPACE; }
     hipStream_t stream = (hipStream_t)stream_;
     const size_t n = (size_t)B * H * W * Ch;
@@ -103,16 +102,17 @@ int vpx_decouple_fwd(const float* delta_c, const float* delta_m, const float* ad
     float* wpk = ws.take(plain_conv_wpk_floats(Ch, Ch, 1, 1));
     const ConvGeo g{B, H, W};
     int rc;
-    if ((rc = decouple_adapter_pair(stream, g, delta_c, delta_m, adapter, yc, ym, n, Ch, false, wpk))) return rc;
+    if ((rc = decouple_adapter_pair(stream, prec, g, delta_c, delta_m, adapter, yc, ym, n, Ch, false, wpk))) return rc;
     VPX_CHECK_HIP(launch_decouple_stats(yc, ym, stats, B, H * W, Ch, stream));
     VPX_CHECK_HIP(launch_decouple_mean(stats, value, B * Ch, stream));
     return VPX_OK;
 }
 
 int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* adapter, const float* dvalue,
-                     float* d_delta_c, float* d_delta_m, float* d_adapter, int B, int Ch, int H, int W,
+                     float* d_delta_c, float* d_delta_m, float* d_adapter, int B, int Ch, int H, int W, int prec,
                      void* workspace, size_t workspace_bytes, void* stream_) {
     if (!delta_c || !delta_m || !adapter || !dvalue || B < 1 || Ch < 1 || H < 1 || W < 1) { set_error("vpx_decouple_bwd: bad argument"); return VPX_ERR_ARG; }
+    if (!decouple_prec_ok(prec, "vpx_decouple_bwd")) return VPX_ERR_ARG;
     if (!workspace || workspace_bytes < vpx_decouple_workspace_bytes(B, Ch, H, W)) { set_error("vpx_decouple_bwd: workspace too small"); return VPX_ERR_WORKSPACE; }
     hipStream_t stream = (hipStream_t)stream_;
     const size_t n = (size_t)B * H * W * Ch;
@@ -129,22 +129,22 @@ int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* ad
     const ConvGeo g{B, H, W};
     int rc;
     // recompute the adapter outputs (cheaper than keeping them alive between forward and backward)
-    if ((rc = decouple_adapter_pair(stream, g, delta_c, delta_m, adapter, yc, ym, n, Ch, false, wpk))) return rc;
+    if ((rc = decouple_adapter_pair(stream, prec, g, delta_c, delta_m, adapter, yc, ym, n, Ch, false, wpk))) return rc;
     VPX_CHECK_HIP(launch_decouple_stats(yc, ym, stats, B, H * W, Ch, stream));
     VPX_CHECK_HIP(launch_decouple_bwd_pointwise(yc, ym, stats, dvalue, dyc, dym, B, H * W, Ch, stream));
     if (d_delta_c && d_delta_m) {
-        if ((rc = decouple_adapter_pair(stream, g, dyc, dym, adapter, d_delta_c, d_delta_m, n, Ch, true, wpk))) return rc;
+        if ((rc = decouple_adapter_pair(stream, prec, g, dyc, dym, adapter, d_delta_c, d_delta_m, n, Ch, true, wpk))) return rc;
     } else {
-        if (d_delta_c && (rc = plain_conv(stream, decouple_prec(), g, dyc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_c, Ch, false, wpk))) return rc;
-        if (d_delta_m && (rc = plain_conv(stream, decouple_prec(), g, dym, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_m, Ch, false, wpk))) return rc;
+        if (d_delta_c && (rc = plain_conv(stream, prec, g, dyc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_c, Ch, false, wpk))) return rc;
+        if (d_delta_m && (rc = plain_conv(stream, prec, g, dym, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, true, nullptr, d_delta_m, Ch, false, wpk))) return rc;
     }
     if (d_adapter) {
         if (dym == dyc + n && (((uintptr_t)delta_c ^ (uintptr_t)delta_m) & 15) == 0) {
             // both pairs in ONE launch (the c and m halves are two "time steps"): one weight gradient + reduce instead of two + an add
-            if ((rc = plain_wgrad(stream, decouple_prec(), g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter, delta_m))) return rc;
+            if ((rc = plain_wgrad(stream, prec, g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter, delta_m))) return rc;
         } else {
-            if ((rc = plain_wgrad(stream, decouple_prec(), g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter))) return rc;
-            if ((rc = plain_wgrad(stream, decouple_prec(), g, dym, Ch, delta_m, Ch, 1, 1, slabs, dA2))) return rc;
+            if ((rc = plain_wgrad(stream, prec, g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter))) return rc;
+            if ((rc = plain_wgrad(stream, prec, g, dym, Ch, delta_m, Ch, 1, 1, slabs, dA2))) return rc;
             VPX_CHECK_HIP(launch_axpy(d_adapter, dA2, (long long)Ch * Ch, stream));
         }
     }

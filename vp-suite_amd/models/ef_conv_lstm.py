@@ -107,10 +107,11 @@ def _run_stage(subnet: nn.Sequential, x, precision: str, split_last: bool = Fals
             continue
         if isinstance(x, tuple):
             raise RuntimeError(f"EF stage glue: {m} cannot read a split-format input (stage was offered one by mistake)")
-        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and x.is_cuda:
-            ops._warn_once(f"glue_stock_{type(m).__name__}_{tuple(m.kernel_size)}_{tuple(m.stride)}",
-                           f"EF stage glue: {m} is outside vpx_conv2d_ex (ops.glue_supported); it runs as the stock torch module")
-        x = m(x)
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            # no stock-torch convolution in the product path: a glue layer the library does not implement fails loudly
+            raise ops.VpxError(f"EF stage glue: {m} is outside vpx_conv2d_ex (ops.glue_supported: stride 1 or 2, kernel <= 7, square "
+                               f"stride / padding, no dilation / groups / output_padding): unsupported")
+        x = m(x)   # activations / Identity only
         i += 1
     return x
 

@@ -111,7 +111,7 @@ class PredRNN_V2(VPModel):
 
     def _decouple_term(self, delta_c, delta_m):
         # adapter 1x1 conv + normalize + |cosine| + mean, fused in libvpx_hip (vpx_decouple_fwd/_bwd)
-        return ops.decouple_term(delta_c, delta_m, self.adapter.weight)
+        return ops.decouple_term(delta_c, delta_m, self.adapter.weight, self.cell_precision)
 
     def forward(self, x, pred_frames: int = 1, **kwargs):
         b, total_frames = x.shape[:2]

@@ -9,6 +9,7 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, ConvLSTMDesc, STLSTMDesc, check, ptr
 
+VpxError = _lib.VpxError
 PRECISIONS = {"f32": _lib.PREC_F32, "bf16x3": _lib.PREC_BF16X3, "bf16": _lib.PREC_BF16}
 
 
@@ -26,17 +27,6 @@ class KernelProfile:
 
 
 PROFILE = None  # set to a KernelProfile() to collect
-
-_warned = set()
-
-
-def _warn_once(key, msg):
-    """A path that leaves the library is never taken silently: one RuntimeWarning per process and reason."""
-    if key not in _warned:
-        _warned.add(key)
-        import warnings
-        warnings.warn(msg, RuntimeWarning, stacklevel=3)
-
 
 def _require_gpu(t: torch.Tensor, what: str):
     _sync_determinism()
@@ -72,6 +62,56 @@ def to_channels_last(t: torch.Tensor) -> torch.Tensor:
     return t.permute(perm).contiguous().permute(inv)
 
 
+class _WorkspaceCache:
+    """Workspaces (and with them packed weights) kept between inference calls while the owning weight tensor is unchanged.
+    LRU with a byte budget; an entry whose weight tensor died, changed version or moved, or whose kernel-option epoch is
+    stale, is dropped on the next insert — a ragged last batch, a varying horizon or an A/B option toggle cannot pin
+    HBM beyond the budget."""
+
+    def __init__(self, budget_bytes=4 << 30):
+        import collections
+        self.budget, self.bytes, self.ents = budget_bytes, 0, collections.OrderedDict()
+
+    def get(self, key, w, addr, need_bytes, dev, exact=True):
+        ent = self.ents.get(key)
+        if ent is None:
+            return None
+        ref, version, a, ws, _ = ent
+        ok = ref() is w and version == w._version and a == addr and ws.device == dev and \
+            (ws.numel() == need_bytes if exact else ws.numel() >= need_bytes)
+        if not ok:
+            self._drop(key)
+            return None
+        self.ents.move_to_end(key)
+        return ws
+
+    def put(self, key, w, addr, ws, epoch):
+        import weakref
+        self._drop(key)
+        for k in [k for k, (ref, version, a, _, ep) in self.ents.items()
+                  if ref() is None or ref()._version != version or ref().data_ptr() != a or ep != epoch]:
+            self._drop(k)
+        while self.ents and self.bytes + ws.numel() > self.budget:
+            self._drop(next(iter(self.ents)))
+        try:
+            self.ents[key] = (weakref.ref(w), w._version, addr, ws, epoch)
+            self.bytes += ws.numel()
+        except TypeError:
+            pass
+
+    def _drop(self, key):
+        ent = self.ents.pop(key, None)
+        if ent is not None:
+            self.bytes -= ent[3].numel()
+
+    def clear(self):
+        self.ents.clear()
+        self.bytes = 0
+
+    def __len__(self):
+        return len(self.ents)
+
+
 _cl_cache = {}
 
 
@@ -86,8 +126,12 @@ def _cached_channels_last(p: torch.Tensor) -> torch.Tensor:
         ref, version, addr, cl = ent
         if ref() is p and version == p._version and addr == p.data_ptr():
             return cl
-    if len(_cl_cache) > 256:
-        _cl_cache.clear()
+    if len(_cl_cache) > 256:   # drop what died or went stale first; only a cache full of live entries is cleared
+        for k in [k for k, (ref, version, addr, _) in _cl_cache.items()
+                  if ref() is None or ref()._version != version or ref().data_ptr() != addr]:
+            del _cl_cache[k]
+        if len(_cl_cache) > 256:
+            _cl_cache.clear()
     cl = to_channels_last(p.detach())
     try:
         _cl_cache[id(p)] = (weakref.ref(p), p._version, p.data_ptr(), cl)
@@ -131,7 +175,7 @@ def convlstm_takes_split(B, T, Cin, Ch, H, W, k, gate_order, precision):
     return bool(_lib.lib().vpx_convlstm_takes_split_input(ctypes.byref(d)))
 
 
-_clstm_ws = {}
+_clstm_ws = _WorkspaceCache()
 _CLSTM_WS_CACHE_LIMIT = 1 << 30   # bytes: larger workspaces (large batches) are not kept alive — there the repack is noise
 
 
@@ -192,20 +236,12 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
             # (identity by weak reference + version + address; kernel selection switches are part of the key)
             key = (id(W), B, T, Cin, Ch, H, Wd, kh, kw, gate_order, precision, x is None, h0 is None, x_split, out_split,
                    torch.are_deterministic_algorithms_enabled(), _kernel_options())
-            ent = _clstm_ws.get(key)
-            if ent is not None and ent[0]() is W and ent[1] == W._version and ent[2] == Wc.data_ptr() and ent[3].numel() == ws_bytes \
-                    and ent[3].device == dev:
-                ws = ent[3]
+            ws = _clstm_ws.get(key, W, Wc.data_ptr(), ws_bytes, dev)
+            if ws is not None:
                 d.flags |= _lib.FLAG_WEIGHTS_PACKED
             else:
-                import weakref
-                if len(_clstm_ws) > 64:
-                    _clstm_ws.clear()
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-                try:
-                    _clstm_ws[key] = (weakref.ref(W), W._version, Wc.data_ptr(), ws)
-                except TypeError:
-                    pass
+                _clstm_ws.put(key, W, Wc.data_ptr(), ws, _kernel_options())
         if ws is None:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         reserve = torch.empty(max(rs_bytes, 1), dtype=torch.uint8, device=dev)
@@ -366,14 +402,12 @@ def conv2d_same(x, w, bias=None, precision="f32"):
     return _Conv2dSameFn.apply(x, w, bias, PRECISIONS[precision])
 
 
-GLUE_BACKWARD_HIP = True       #: backward of the glue convolutions through vpx_conv2d_ex_bwd (False: ATen / MIOpen)
-GLUE_BACKWARD_NATIVE = False   #: ATen fallback only: avoid MIOpen (slow; for robustness experiments)
 
 
 class _ConvExFn(torch.autograd.Function):
     """Conv2d / ConvTranspose2d (stride 1 or 2) + bias + LeakyReLU in ONE library launch (4 for a stride-2 transposed
     conv) — the EF stage glue of ef_blocks.py:15-49. Forward and backward (LeakyReLU', bias / data / weight gradients)
-    run in libvpx_hip; ATen only for kernels smaller than their stride."""
+    run in libvpx_hip; a layer outside the library (kernel smaller than its stride, negative slope) raises VpxError."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, padding, transposed, slope, precision, out_pad=(0, 0)):
@@ -408,7 +442,7 @@ class _ConvExFn(torch.autograd.Function):
         stride, padding, transposed, slope, has_bias = ctx.cfg
         mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]]
         d = ctx.desc
-        if GLUE_BACKWARD_HIP and d.kh >= d.stride and d.kw >= d.stride and slope >= 0.0:
+        if d.kh >= d.stride and d.kw >= d.stride and slope >= 0.0:
             # library path: LeakyReLU' + bias gradient in one pass over dy, dx = the adjoint layer on the implicit-GEMM kernel,
             # dw on the MFMA weight-gradient kernel
             L = _lib.lib()
@@ -423,19 +457,9 @@ class _ConvExFn(torch.autograd.Function):
             check(L.vpx_conv2d_ex_bwd(ctypes.byref(d), ptr(xs), ptr(wc), ptr(y), ptr(dyc), ptr(dx), ptr(dw), ptr(db), ptr(ws),
                                       ws_bytes, _stream()), "vpx_conv2d_ex_bwd")
             return dx, dw, db, None, None, None, None, None, None
-        _warn_once("glue_bwd_aten", f"conv2d_ex backward: layer (k={d.kh}x{d.kw}, stride={stride}, transposed={bool(transposed)}, "
-                   f"slope={slope}) is outside the library's glue backward; its gradients come from ATen (convolution_backward)")
-        # fallback (kernel smaller than the stride, negative slope): ATen's convolution backward = MIOpen NHWC kernels.
-        # GLUE_BACKWARD_NATIVE additionally routes it around MIOpen (MIOpen's solver search aborted the process in ~10 % of
-        # the runs of a test with exotic shapes on this image, inside miopen find).
-        if slope != 0.0:  # LeakyReLU' from the sign of the output (same sign as the pre-activation for slope > 0)
-            dy = torch.ops.aten.leaky_relu_backward(dy, y, slope, True) if slope > 0.0 else \
-                dy * torch.where(y > 0, torch.ones((), device=y.device), torch.full((), slope, device=y.device))
-        bias_sizes = [int(wc.shape[1] if transposed else wc.shape[0])] if has_bias else None
-        with torch.backends.cudnn.flags(enabled=not GLUE_BACKWARD_NATIVE):
-            dx, dw, db = torch.ops.aten.convolution_backward(dy, xs, wc, bias_sizes, [stride, stride], [padding, padding],
-                                                             [1, 1], transposed, [d.out_pad_h, d.out_pad_w], 1, mask)
-        return dx, dw, (db if has_bias else None), None, None, None, None, None, None
+        # No second backend in the product path: a layer the library's glue backward does not implement fails loudly.
+        raise _lib.VpxError(f"conv2d_ex backward: layer (k={d.kh}x{d.kw}, stride={stride}, transposed={bool(transposed)}, slope={slope}) "
+                       f"is outside vpx_conv2d_ex_bwd (needs kernel >= stride and a non-negative LeakyReLU slope): unsupported")
 
 
 def conv2d_ex(x, w, bias, stride, padding, transposed=False, leaky_slope=0.0, precision="f32", output_padding=(0, 0)):
@@ -489,7 +513,7 @@ def split_convert(x, native=True):
     return buf.view(torch.float32).reshape(-1), tuple(x.shape)
 
 
-_convq_ws = {}
+_convq_ws = _WorkspaceCache()
 
 
 def conv2d_ex_takes_split(N, H, W, Ci, Co, kh, kw, stride, padding, transposed, precision="bf16x3"):
@@ -521,19 +545,15 @@ def conv2d_ex_from_split(xbuf, xshape, w, bias, stride, padding, transposed=Fals
     ws_bytes = L.vpx_conv2d_ex_split_workspace_bytes(ctypes.byref(d))
     if ws_bytes == 0:
         raise _lib.VpxError("conv2d_ex_from_split: layer not implemented on split input: " + L.vpx_last_error().decode())
-    key = (id(w), N, H, Wd, int(stride), int(padding), bool(transposed), precision)
-    ent = _convq_ws.get(key)
+    key = (id(w), N, H, Wd, int(stride), int(padding), bool(transposed), precision,
+           torch.are_deterministic_algorithms_enabled(), _kernel_options())
     packed = 0
-    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == w.data_ptr() and ent[3].numel() >= ws_bytes:
-        ws, packed = ent[3], 1
+    ws = _convq_ws.get(key, w, w.data_ptr(), ws_bytes, xbuf.device, exact=False)
+    if ws is not None:
+        packed = 1
     else:
-        if len(_convq_ws) > 64:
-            _convq_ws.clear()
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xbuf.device)
-        try:
-            _convq_ws[key] = (weakref.ref(w), w._version, w.data_ptr(), ws)
-        except TypeError:
-            pass
+        _convq_ws.put(key, w, w.data_ptr(), ws, _kernel_options())
     wc = w.contiguous()
     if wc.data_ptr() != w.data_ptr():
         packed = 0
@@ -571,7 +591,7 @@ class _DecoupleFn(torch.autograd.Function):
     """mean_{b,ch} |cos(normalize(A*delta_c), normalize(A*delta_m))| over H*W  (predrnn_v2.py:197-198, 209-211)."""
 
     @staticmethod
-    def forward(ctx, delta_c, delta_m, adapter_w):
+    def forward(ctx, delta_c, delta_m, adapter_w, precision):
         _require_gpu(delta_c, "decouple_term")
         dc, dm = to_channels_last(delta_c), to_channels_last(delta_m)
         B, Ch, H, Wd = dc.shape
@@ -580,9 +600,10 @@ class _DecoupleFn(torch.autograd.Function):
         ws_bytes = L.vpx_decouple_workspace_bytes(B, Ch, H, Wd)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dc.device)
         value = torch.empty((), device=dc.device)
-        rc = L.vpx_decouple_fwd(ptr(dc), ptr(dm), ptr(A), ptr(value), B, Ch, H, Wd, ptr(ws), ws_bytes, _stream())
+        rc = L.vpx_decouple_fwd(ptr(dc), ptr(dm), ptr(A), ptr(value), B, Ch, H, Wd, precision, ptr(ws), ws_bytes, _stream())
         check(rc, "vpx_decouple_fwd")
         ctx.save_for_backward(dc, dm, A)
+        ctx.precision = precision
         ctx.wshape = tuple(adapter_w.shape)
         return value
 
@@ -604,13 +625,14 @@ class _DecoupleFn(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dc.device)
         dv = dvalue.contiguous().reshape(1)
         rc = L.vpx_decouple_bwd(ptr(dc), ptr(dm), ptr(A), ptr(dv), ptr(g_dc), ptr(g_dm), ptr(g_A), B, Ch, H, Wd,
-                                ptr(ws), ws_bytes, _stream())
+                                ctx.precision, ptr(ws), ws_bytes, _stream())
         check(rc, "vpx_decouple_bwd")
-        return g_dc, g_dm, (None if g_A is None else g_A.reshape(ctx.wshape))
+        return g_dc, g_dm, (None if g_A is None else g_A.reshape(ctx.wshape)), None
 
 
-def decouple_term(delta_c, delta_m, adapter_w):
-    return _DecoupleFn.apply(delta_c, delta_m, adapter_w)
+def decouple_term(delta_c, delta_m, adapter_w, precision="f32"):
+    """`precision`: arithmetic of the adapter contractions — pass the model's operand mode (default: exact fp32)."""
+    return _DecoupleFn.apply(delta_c, delta_m, adapter_w, PRECISIONS[precision])
 
 
 def _is_dense(t: torch.Tensor) -> bool:
@@ -818,8 +840,9 @@ class _LayerNormCHWFn(torch.autograd.Function):
         _require_gpu(x, "layer_norm_chw")
         xs = to_channels_last(x)
         B, C, H, Wd = xs.shape
-        g = _cached_channels_last(weight[None]) if weight.dim() == 3 else to_channels_last(weight)
-        b = _cached_channels_last(bias[None]) if bias.dim() == 3 else to_channels_last(bias)
+        # keyed on the parameter itself (a `weight[None]` temporary is a new object every call and can never hit)
+        g = _cached_channels_last(weight)
+        b = _cached_channels_last(bias)
         L = _lib.lib()
         ws_bytes = L.vpx_layernorm_workspace_bytes(B)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
