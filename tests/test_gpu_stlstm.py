@@ -149,6 +149,40 @@ def test_predrnn_full_size_vs_golden(vpx):
     assert abs(float(ml["ST-LSTM decouple loss"]) - float(g["decouple"])) < 1e-3 * abs(float(g["decouple"]))
 
 
+@pytest.mark.parametrize("B,Cin,Ch,H,W", [(3, 8, 24, 12, 20), (2, 16, 128, 16, 16), (5, 48, 40, 9, 33)])
+def test_stlstm_one_launch_weight_gradient_matches_first_generation(vpx, B, Cin, Ch, H, W):
+    """The four 5x5 weight gradients of an ST-LSTM step from the one-launch split-operand kernel (stw: pair table, three tap
+    passes, K split of tap row 4, half-empty column tiles, ragged maps / row tiles) against the first-generation launches
+    (VPX_OPT_EXPERIMENT bit 6) — same operands, same bf16x3 split: fp32 summation order only."""
+    from golden_util import seeded_randn
+    k = 5
+    tag = f"stw.{B}.{Cin}.{Ch}.{H}.{W}"
+    names = ("x", "h", "c", "m")
+    inp = {n: seeded_randn((B, Cin if n == "x" else Ch, H, W), name_seed(f"{tag}.{n}"), 0.5).cuda() for n in names}
+    shapes = {"Wx": (7 * Ch, Cin, k, k), "Wh": (4 * Ch, Ch, k, k), "Wm": (3 * Ch, Ch, k, k), "Wo": (Ch, 2 * Ch, k, k), "Wlast": (Ch, 2 * Ch, 1, 1)}
+    Ws = {n: seeded_randn(s, name_seed(f"{tag}.{n}"), 1.0 / np.sqrt(s[1] * s[2] * s[3])).cuda() for n, s in shapes.items()}
+    gout = [seeded_randn((B, Ch, H, W), name_seed(f"{tag}.g{i}")).cuda() for i in range(5)]
+
+    def run():
+        a = [inp[n].clone().requires_grad_(True) for n in names]
+        w = [Ws[n].clone().requires_grad_(True) for n in shapes]
+        outs = vpx.ops.stlstm_step(*a, *w, precision="bf16x3")
+        sum((o * g).sum() for o, g in zip(outs, gout)).backward()
+        return [t.grad for t in w]
+    L = vpx._lib.lib()
+    new = run()
+    prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, 64)
+    try:
+        old = run()
+    finally:
+        L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, prev)
+    for n, a, b in zip(shapes, new, old):
+        assert _relmax(a, b) < 2e-6, (n, _relmax(a, b))
+    again = run()
+    for a, b in zip(new, again):
+        assert torch.equal(a, b)   # no atomics: bit-reproducible
+
+
 def test_decouple_and_conv2d_vs_golden_and_autograd(vpx):
     """K4 (vpx_decouple_fwd/_bwd) against the reference-generated pin; K5-style conv2d fwd/bwd against torch autograd."""
     from golden_util import seeded_randn

@@ -721,9 +721,15 @@ __host__ __device__ constexpr int cq_aoff(int p, int abuf) { return (p >= 5 ? ab
 // ring holds TWO chunks and turns over in halves (a chunk = [half][...]: column tiles 0-3 | 4-7): sync point X_q sits before
 // the weight read of column tile 4 of step q; after its barrier every wave has read tiles 0-3 of chunk q and all of chunk q-1, so
 // half 1 of chunk q+1 and half 0 of chunk q+2 are requested there, each with a whole step to land (as in the ring of three).
-template <class Epi, bool ALLG, int NW>
+// PLAIN (round 4; half tile only): VPX_PREC_BF16 — the hi parts of both operands only (BASELINE configs[1]'s literal dtype, ~2e-3,
+// outside the 1e-4 bar): one MFMA per product instead of three, the lo planes of a stage and the lo half of every weight chunk are
+// neither copied nor read (halves the LDS-DMA bytes and the fragment reads); same stage image, same pack, same epilogue.
+template <class Epi, bool ALLG, int NW, bool PLAIN = false>
 __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, const Epi epi) {
     using G = CQGeom<NW>;
+    static_assert(!PLAIN || NW == 4, "plain-bf16 form: half tile only (its hi planes are exactly three pieces per thread)");
+    constexpr int NPC = PLAIN ? G::NPIECE / 2 : G::NPIECE;   // stage-copy pieces per thread (planes 0, 1 = hi come first)
+    constexpr int WPC = PLAIN ? 1 : G::WPIECE;               // copies per thread and half chunk (piece 0 = the hi part)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -789,7 +795,7 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
     };
     auto issue_Wh = [&](int chunk, int slot, int half) {   // one 8 KiB half of a weight chunk
 #pragma unroll
-        for (int w = 0; w < G::WPIECE; ++w)
+        for (int w = 0; w < WPC; ++w)
             c2_dma16(wtile + (size_t)chunk * CQ_WCHUNK + half * 8192 + w * (G::NT * 16),
                      Wbuf + slot * CQ_WCHUNK + half * 8192 + w * (G::NT * 16) + dma_off);
     };
@@ -819,13 +825,13 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
         const int base = cq_kind(p) == 0 ? base1 : (cq_kind(p) == 1 ? base16 : bx);
         const char* a = smem + base + cq_aoff(p, G::ABUF) + m * (C2_HALO_W * 16);
         F.ah[m] = *reinterpret_cast<const bf16x8*>(a);
-        F.al[m] = *reinterpret_cast<const bf16x8*>(a + 2 * G::PLANE);
+        if constexpr (!PLAIN) F.al[m] = *reinterpret_cast<const bf16x8*>(a + 2 * G::PLANE);
     };
     auto load_B = [&](int p, int nt) {           // weight fragments (hi, lo) of column tile nt of period step p -> set nt & 1
         const int base = NW == 8 ? wb0 + (p % 3) * CQ_WCHUNK : ((p & 1) ? wb1 : wb0);
         const char* w = smem + base + (nt >> 2) * 8192 + (nt & 3) * 256;
         F.bh[nt & 1] = *reinterpret_cast<const bf16x8*>(w);
-        F.bl[nt & 1] = *reinterpret_cast<const bf16x8*>(w + 4096);
+        if constexpr (!PLAIN) F.bl[nt & 1] = *reinterpret_cast<const bf16x8*>(w + 4096);
     };
 
     // NW = 8: waves 4-7 meet each sync point at THEIR tile 1 instead of tile 5, i.e. they run half a chunk behind waves 0-3: the two
@@ -835,12 +841,12 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
     const bool late_sync = NW == 8 && !(P._q & 1) && wave >= 4;
     if (S > 0) {
 #pragma unroll
-        for (int u = 0; u < G::NPIECE; ++u) issue_A1(0, 0, u);
+        for (int u = 0; u < NPC; ++u) issue_A1(0, 0, u);
         issue_Wh(0, 0, 0); issue_Wh(0, 0, 1);
-        if (Q > 1) {   // NW = 8: all of chunk 1; NW = 4: its first half — two copies per thread either way
+        if (Q > 1) {   // NW = 8: all of chunk 1; NW = 4: its first half — two copies per thread either way (PLAIN: one)
             issue_Wh(1, 1, 0);
             if constexpr (NW == 8) issue_Wh(1, 1, 1);
-            C2_WAIT_VM(2);
+            if constexpr (PLAIN) C2_WAIT_VM(1); else C2_WAIT_VM(2);
         } else C2_WAIT_VM(0);
         C2_STAMP(1);
         c2_barrier();
@@ -871,7 +877,7 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
                     } else {
                         if (nt == 3) {
                             // ---- sync point X_q: the fragments of tiles 0-3 are in registers (lgkmcnt) before their half chunk is given away ----
-                            if (stage_flies) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                            if (stage_flies) { if constexpr (PLAIN) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); }
                             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                             c2_barrier();
                         }
@@ -886,8 +892,10 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
                     for (int m = 0; m < 4; ++m) {
                         if (ALLG || nt < 2 * ngr) {
                             f32x4 c = acc[m][nt];
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.al[m], F.bh[nt & 1], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bl[nt & 1], c, 0, 0, 0);
+                            if constexpr (!PLAIN) {
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.al[m], F.bh[nt & 1], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bl[nt & 1], c, 0, 0, 0);
+                            }
                             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bh[nt & 1], c, 0, 0, 0);
                             acc[m][nt] = c;
                         }
@@ -916,7 +924,7 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
                         if ((p == 0 && odd) || (p == 5 && more)) {
                             const int st = p == 0 ? s0 + 1 : s0 + 2, bf = p == 0 ? 1 : 0;
                             if (nt == 4) { issue_A1(st, bf, 0); issue_A1(st, bf, 1); issue_A1(st, bf, 2); }
-                            if (nt == 5) { issue_A1(st, bf, 3); issue_A1(st, bf, 4); issue_A1(st, bf, 5); }
+                            if constexpr (!PLAIN) { if (nt == 5) { issue_A1(st, bf, 3); issue_A1(st, bf, 4); issue_A1(st, bf, 5); } }
                         }
                     }
                 }
@@ -966,10 +974,23 @@ static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStrea
 #ifdef VPX_ABLATE
         { const char* e = getenv("VPX_C2_STAMP_BLOCK"); p._p = e ? atoi(e) : -1; }
 #endif
-        if (cell2_half_tile(p, std::is_same<Epi, Conv2Epi>::value)) {
+        if (plan.plain || cell2_half_tile(p, std::is_same<Epi, Conv2Epi>::value)) {
             p.tiles_y = (p.H + 15) / 16;
             p.grid_m = p.B * p.tiles_x * p.tiles_y;
             const long long per_xcd_h = ((long long)p.grid_m * p.n_tiles + 7) / 8;
+            if constexpr (std::is_same<Epi, Cell2Epi>::value && ALLG) {
+                if (plan.plain) {
+                    static bool attr_plain = false;
+                    if (!attr_plain) {
+                        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CQGeom<4>::LDS);
+                        if (e != hipSuccess) return e;
+                        attr_plain = true;
+                    }
+                    hipLaunchKernelGGL((cell2_kernel_q<Epi, ALLG, 4, true>), dim3((unsigned)(per_xcd_h * 8)), dim3(256), CQGeom<4>::LDS, s, p, epi);
+                    return hipGetLastError();
+                }
+            }
+            if (plan.plain) return hipErrorInvalidValue;   // (only the fused cell step has the plain form)
             hipLaunchKernelGGL((cell2_kernel_q<Epi, ALLG, 4>), dim3((unsigned)(per_xcd_h * 8)), dim3(256), CQGeom<4>::LDS, s, p, epi);
             return hipGetLastError();
         }

@@ -84,7 +84,7 @@ size_t vpx_decouple_workspace_bytes(int B, int Ch, int H, int W) {
 
 static bool decouple_prec_ok(int prec, const char* who) {
     if (prec == VPX_PREC_F32 || prec == VPX_PREC_BF16X3 || prec == VPX_PREC_BF16) return true;
-    set_error(std::string(who) + ": unknown precision"); return false;
+    set_error("%s: unknown precision %d", who, prec); return false;
 }
 int vpx_decouple_fwd(const float* delta_c, const float* delta_m, const float* adapter, float* value, int B, int Ch,
                      int H, int W, int prec, void* workspace, size_t workspace_bytes, void* stream_) {

@@ -20,7 +20,14 @@ struct STBwdLayout {
     struct DG { int nstage, chunks, tiles, ng, ksplit, mw; ConvStage stage[MAX_STAGE]; size_t wpk; } o, l, x, h, m;
     int n_slices;
     size_t slab_floats;
+    // stw (wgrad2.hip): the four k x k weight gradients in one launch on split operands — 5x5, bf16x3, channels in 8s
+    bool stw; int stw_pairs, stw_ns;
 };
+
+// VPX_OPT_EXPERIMENT bit 6 keeps the first-generation weight-gradient launches (A/B runs, tests)
+bool stw_applicable(const vpx_stlstm_desc* d) {
+    return d->k == 5 && d->precision == VPX_PREC_BF16X3 && !(d->Ch & 7) && !(d->Cin & 7) && !d->layer_norm && !(g_experiment & 64);
+}
 
 int mk_dg(STBwdLayout::DG& g, const int* segC, int nseg, int k, int n_out, int prec, long long m_tiles) {
     const int taps = k * k;
@@ -56,6 +63,17 @@ int st_bwd_layout(const vpx_stlstm_desc* d, STBwdLayout& L) {
     if ((size_t)4 * Ch * Ch * L.taps > mx) mx = (size_t)4 * Ch * Ch * L.taps;
     if ((size_t)2 * Ch * Ch * L.taps > mx) mx = (size_t)2 * Ch * Ch * L.taps;
     L.slab_floats = mx * L.n_slices;
+    L.stw = stw_applicable(d); L.stw_pairs = 0; L.stw_ns = 0;
+    if (L.stw) {
+        static thread_local STWArgs sa; static thread_local STWOut so;
+        L.stw_pairs = stw_build(sa, so, d->B, d->H, d->W, Cin, Ch);
+        if (L.stw_pairs < 1) L.stw = false;
+        else {
+            L.stw_ns = stw_slices(L.stw_pairs, (long long)d->B * ((d->W + 15) / 16) * ((d->H + 3) / 4));
+            const size_t need = sa.slab_stride * L.stw_ns;
+            if (need > L.slab_floats) L.slab_floats = need;
+        }
+    }
     return VPX_OK;
 }
 
@@ -68,6 +86,7 @@ size_t stlstm_bwd_workspace_bytes(const vpx_stlstm_desc* d) {
     size_t b = align256(L.n_g7 * 4) + 4 * align256(L.n_state * 4);  // dG7, dlc, dcn_conv, dmn_conv, dm scratch
     b += align256(L.o.wpk * 4) + align256(L.l.wpk * 4) + align256(L.x.wpk * 4) + align256(L.h.wpk * 4) + align256(L.m.wpk * 4);
     b += align256(L.slab_floats * 4);
+    if (L.stw) b += align256(L.n_g7 * 4) + align256(L.n_x * 4) + 4 * align256(L.n_state * 4);   // split copies: dG7, x, h, m, c_new, m_new
     if (d->layout == VPX_LAYOUT_NCHW) b += 2 * align256(L.n_x * 4) + 14 * align256(L.n_state * 4);
     return b;
 }
@@ -179,6 +198,11 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     float* wpk_h = ws.take(L.h.wpk);
     float* wpk_m = ws.take(L.m.wpk);
     float* slabs = ws.take(L.slab_floats);
+    char *g7_sp = nullptr, *x_sp = nullptr, *st_sp[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (L.stw) {
+        g7_sp = (char*)ws.take(L.n_g7); x_sp = (char*)ws.take(L.n_x);
+        for (auto& q : st_sp) q = (char*)ws.take(L.n_state);
+    }
 
     const float *xn = x, *hn = h, *cn = c, *mn = m, *cnn = c_new, *mnn = m_new;
     const float *g_h = dh_new, *g_c = dc_new, *g_m = dm_new, *g_dc = ddelta_c, *g_dm = ddelta_m;
@@ -317,14 +341,31 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.m.tiles, stream));
     }
     // ---- E: weight gradients ----
-    if (dWo && (rc = run_wgrad(d, L, dG7 + 3 * Ch, Ch, ldG, cnn, Ch, mnn, Ch, k, nullptr, 0, Ch, slabs, dWo, stream))) return rc;
+    const bool stw = L.stw && dWx && dWh && dWm && dWo;
+    if (stw) {
+        // all four k x k tensors in one launch (wgrad2.hip, stw): operands once more in the split format
+        static thread_local STWArgs sa; static thread_local STWOut so;
+        if (stw_build(sa, so, B, H, Wd, Cin, Ch) != L.stw_pairs) { set_error("stlstm bwd: pair table changed"); return VPX_ERR_ARG; }
+        const long long npix = (long long)B * (long long)HW;
+        VPX_CHECK_HIP(launch_split_convert(dG7, g7_sp, npix, 7 * Ch, stream));
+        VPX_CHECK_HIP(launch_split_convert(xn, x_sp, npix, Cin, stream));
+        const float* st_src[4] = {hn, mn, cnn, mnn};
+        for (int i = 0; i < 4; ++i) VPX_CHECK_HIP(launch_split_convert(st_src[i], st_sp[i], npix, Ch, stream));
+        sa.g_sp = g7_sp;
+        sa.src[0] = STWSrc{x_sp, Cin};
+        for (int i = 0; i < 4; ++i) sa.src[1 + i] = STWSrc{st_sp[i], Ch};
+        sa.n_slices = L.stw_ns; sa.slabs = slabs;
+        so.dW[0] = dWx; so.dW[1] = dWh; so.dW[2] = dWm; so.dW[3] = dWo;
+        VPX_CHECK_HIP(launch_stw(sa, so, stream));
+    }
+    if (!stw && dWo && (rc = run_wgrad(d, L, dG7 + 3 * Ch, Ch, ldG, cnn, Ch, mnn, Ch, k, nullptr, 0, Ch, slabs, dWo, stream))) return rc;
     if (dWlast && (rc = run_wgrad(d, L, dlc, Ch, Ch, cnn, Ch, mnn, Ch, 1, nullptr, 0, Ch, slabs, dWlast, stream))) return rc;
-    if (dWx) {
+    if (!stw && dWx) {
         const int rowblk[8] = {0, 1, 2, 6, 3, 4, 5, 0};
         if ((rc = run_wgrad(d, L, dG7, 7 * Ch, ldG, xn, Cin, nullptr, 0, k, rowblk, Ch, 7 * Ch, slabs, dWx, stream))) return rc;
     }
-    if (dWh && (rc = run_wgrad(d, L, dG7, 4 * Ch, ldG, hn, Ch, nullptr, 0, k, nullptr, 0, 4 * Ch, slabs, dWh, stream))) return rc;
-    if (dWm && (rc = run_wgrad(d, L, dG7 + 4 * Ch, 3 * Ch, ldG, mn, Ch, nullptr, 0, k, nullptr, 0, 3 * Ch, slabs, dWm, stream))) return rc;
+    if (!stw && dWh && (rc = run_wgrad(d, L, dG7, 4 * Ch, ldG, hn, Ch, nullptr, 0, k, nullptr, 0, 4 * Ch, slabs, dWh, stream))) return rc;
+    if (!stw && dWm && (rc = run_wgrad(d, L, dG7 + 4 * Ch, 3 * Ch, ldG, mn, Ch, nullptr, 0, k, nullptr, 0, 3 * Ch, slabs, dWm, stream))) return rc;
 
     if (d->layout == VPX_LAYOUT_NCHW) {
         if (dx) VPX_CHECK_HIP(launch_nhwc_to_nchw(dxn, dx, B, Cin, H, Wd, stream));

@@ -446,6 +446,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             P2.chunks_total = 3 * ((Cin + Ch) / 16);
             P2.wpk = wpk2;
             P2.qform = qform;
+            P2.plain = d->precision == VPX_PREC_BF16 ? 1 : 0;
             // h_t in operand format: the reserve (training), the caller's `out` buffer laid out [B][T][HW][Ch] (OUT_SPLIT), or a two-slot ring
             const long long hsp_bs = out_split ? (long long)((size_t)T * HW * Ch * 4) : (long long)(HW * Ch * 4);
             auto h_slot = [&](int tt) -> char* {

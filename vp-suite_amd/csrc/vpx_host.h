@@ -98,7 +98,12 @@ static inline int cell2_mode() {
 }
 static inline bool cell2_applicable(const vpx_convlstm_desc* d) {
     if (cell2_mode() == 0) return false;
-    if (d->precision != VPX_PREC_BF16X3 || d->kh != 3 || d->kw != 3) return false;
+    if (d->kh != 3 || d->kw != 3) return false;
+    if (d->precision == VPX_PREC_BF16) {
+        // plain bf16 (BASELINE configs[1]'s literal dtype): inference only, on the half tile of the 16x16x32 form (cell2_kernel_q<.., 4, true>);
+        // a call that saves for the backward pass stays on the first-generation kernel, whose BPTT kernels know this mode
+        if ((d->flags & VPX_FLAG_SAVE_FOR_BWD) || mfma_shape() != 1 || (d->H & 15) || (d->W & 15) || (d->Ch & 31)) return false;
+    } else if (d->precision != VPX_PREC_BF16X3) return false;
     if ((d->Cin & 15) || (d->Ch & 15) || (d->Cin + d->Ch) / 16 > MAX_STAGE) return false;
     // 16-row maps: on the half tile (q form) only. Measured at B=128, (96,96,16x16): 128 -> 106 us per step against the
     // first-generation kernel (384 workgroups of four waves); VPX_CELL2_H16=0 keeps them there

@@ -124,6 +124,7 @@ struct Cell2Seg { const char* sp; long long bstride; int C; int _pad; };   // sp
 struct Cell2Plan {
     int B, H, W, tiles_x, tiles_y, n_tiles, nx, nh, hs_off, chunks_total, grid_m, _p;
     int qform, _q;            // 1: the 16x16x32 main loop (cell2_kernel_q); wpk / chunks_total then describe K = 32 chunks (below)
+    int plain;                // q form, half tile: VPX_PREC_BF16 (hi parts only, one MFMA per product)
     int n_groups, gpt;        // conv2 only: 32-column output groups in total / per N tile (the last tile may hold fewer)
     Cell2Seg seg[2];
     const char* wpk;          // [n_tiles][chunks_total][24576 B]
@@ -409,6 +410,24 @@ static inline int wgrad2_slices(int target, int rows128, int n_ctiles, bool half
 hipError_t launch_wgrad2(const WgradArgs& a, int max_slices, int* used_slices, int* tail_col0, int* tail_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce_tail(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int tail_col0, int tail_slices,
                                     hipStream_t s);
+// wgrad2.hip, stw: the four 5x5 weight gradients of one ST-LSTM cell step in one launch (operands in split format)
+constexpr int STW_MAX_PAIRS = 48;
+struct STWSrc { const char* sp; int C; };          // split tensor [B][HW][C]
+struct STWHalf { int src, c0, cn, cglobal; };      // channels [c0, c0 + cn) of source src = columns cglobal.. of the tensor (cn = 0: empty)
+struct STWPair { int n0, tensor; STWHalf h[2]; };  // rows n0 .. n0 + 127 of dG7 x 64 columns
+struct STWArgs {
+    int B, H, W, HW, Ch, N7;
+    const char* g_sp;            // dG7 [B][HW][7Ch], split format
+    STWSrc src[5];               // x, h, m, c_new, m_new
+    int npairs, n_slices;
+    STWPair pair[STW_MAX_PAIRS];
+    float* slabs;                // [n_slices][npairs][25][128][64]
+    size_t slab_stride;          // floats per slice
+};
+struct STWOut { float* dW[4]; int Ct[4]; signed char blockmap[4][8]; };   // Wx, Wh, Wm, Wo
+int stw_build(STWArgs& a, STWOut& o, int B, int H, int W, int Cin, int Ch);   // fills the pair table; returns npairs (-1: too many)
+int stw_slices(int npairs, long long items);
+hipError_t launch_stw(const STWArgs& a, const STWOut& o, hipStream_t s);       // kernel + slice reduction into dW[0..3] (overwritten)
 // same, but launch tap t lands at tap index tapmap[t] of a dW with real_taps taps per (row, channel); tapmap[t] < 0: dropped
 hipError_t launch_wgrad_reduce_map(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int real_taps,
                                    const int* tapmap, hipStream_t s);

@@ -461,4 +461,310 @@ hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices
     return hipGetLastError();
 }
 
+
+// =====================================================================================================================
+// stw: the four 5x5 weight gradients of ONE ST-LSTM cell step (autograd of predrnn.py:57-83: conv_x, conv_h, conv_m, conv_o)
+// in ONE launch on the wgrad2 machinery (round 4). dW*[n][c][tap] = sum over (b, pixel) dG7[b,pixel][n] * src[pixel + tap][c]
+// with dG7 [B,HW,7Ch] = d(pre-activations) ordered (i,f,g | o | i',f',g') and the sources x, h, m, c_new, m_new — all six
+// tensors in the split operand format, staged by LDS-DMA. What differs from wgrad2_kernel<true>:
+//   * 5x5: the halo tile of a 4 x 16-pixel item is 8 x 20 positions (two item buffers of 72 KiB); the 25 taps are three
+//     PASSES of a workgroup's (128 rows x 64 channels) tile — tap rows {0,1}, {2,3}, {4}: a wave's tap group is one tap row
+//     (5 accumulator tiles = the same 160 registers). In pass 2 both tap groups take tap row 4 and split the K = 32 steps
+//     of every item between them; the pair's accumulators meet in LDS after the loop (fixed order).
+//   * the work list is a table of PAIRS (128-row tile of dG7, 64-column tile of one source) instead of a dense row x column
+//     grid: x pairs with all rows, h with the first 4Ch, m with the last 3Ch, [c_new | m_new] with the o block — one launch
+//     of npairs x 3 passes x K slices workgroups of equal shape instead of eight launches of the first-generation kernel
+//     (which re-staged fp32 operands through registers, one item buffer, taps 9 + 9 + 7).
+//   * every pair's slab block is [tap][128][64]; stw_reduce_kernel sums the K slices and scatters into the four OIHW tensors
+//     (the row-block permutation of Wx is a per-tensor block map there).
+// =====================================================================================================================
+constexpr int W5_HALO_W = 20;
+constexpr int W5_NPOS = (W2_TH + 4) * W5_HALO_W;  // 160 halo positions
+constexpr int W5_APL = W5_NPOS * 128;             // 20480 B per plane
+constexpr int W5_BUF = W2_A0 + 2 * W5_APL;        // 73728 B per item
+constexpr int W5_LDS = 2 * W5_BUF;                // 147456 B
+constexpr int W5_APIECES = 2 * W5_NPOS * 8;       // 2560 pieces = 5 per thread exactly
+constexpr int W5_BLOCK = 25 * 128 * 64;           // floats of a pair's slab block
+
+__global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
+    constexpr int TA = 5;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = wave >> 2, wn = (wave >> 1) & 1, wc = wave & 1;
+    int slice, pair_i, pass;
+    {
+        const int per_slice = a.npairs * 3;
+        const long long total = (long long)per_slice * a.n_slices;
+        const long long per_xcd = (total + 7) / 8;
+        const unsigned L = blockIdx.x;
+        const long long v = (long long)(L & 7) * per_xcd + (L >> 3);
+        if ((long long)(L >> 3) >= per_xcd || v >= total) return;
+        slice = (int)(v / per_slice);
+        const int rem = (int)(v - (long long)slice * per_slice);
+        // the long passes (tap rows {0,1}, {2,3}) of every pair first, the short pass last
+        if (rem < 2 * a.npairs) { pair_i = rem >> 1; pass = rem & 1; } else { pair_i = rem - 2 * a.npairs; pass = 2; }
+        slice = __builtin_amdgcn_readfirstlane(slice); pair_i = __builtin_amdgcn_readfirstlane(pair_i); pass = __builtin_amdgcn_readfirstlane(pass);
+    }
+    const STWPair pr = a.pair[pair_i];
+    const STWHalf ch0 = pr.h[0], ch1 = pr.h[1];
+    const int n0 = pr.n0;
+    const bool ksplit = ch1.cn == 0;                 // half-empty column tile: the wave pair (wc) shares the channels and splits K
+    const bool tsplit = pass == 2 && !ksplit;        // tap row 4: the tap groups share it and split K
+    const int trow = tsplit ? 4 : 2 * pass + tg;     // this wave's tap row
+    const bool active = trow < 5;
+
+    f32x4 accq[4][2][TA];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int t = 0; t < TA; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accq[rt][ct][t][r] = 0.0f;
+
+    const int L16 = lane & 15, q = L16 >> 2, p = L16 & 3, kgq = lane >> 4;
+    const int g_laneq = w2_swz<true>(((16 * (kgq >> 1) + 4 * (kgq & 1) + q) * 64 + 4 * p) * 2);
+    const int a_lane = (((kgq >> 1) * W5_HALO_W + 4 * (kgq & 1) + q) * 64 + (ksplit ? 0 : wc) * 32 + 4 * p) * 2;
+    const int taprow_off = trow * W5_HALO_W * 128;
+
+    const int tiles_x = (a.W + 15) / 16, tiles_y = (a.H + W2_TH - 1) / W2_TH, tiles = tiles_x * tiles_y;
+    const int n_items = a.B * tiles;
+
+    // ---- DMA pieces (as wgrad2_kernel): dG7 one slot of each of the four planes; activations five pieces per thread ----
+    const int g_px = tid >> 3;
+    const int g_sl = (w2_swz<true>(g_px * 128 + (tid & 7) * 16) & 127) >> 4;
+    const bool g_ok0 = n0 + g_sl * 8 < a.N7, g_ok1 = n0 + 64 + g_sl * 8 < a.N7;
+    const unsigned g_prow = (unsigned)a.N7 * 4u;
+    const unsigned g_toff = (unsigned)((g_px >> 4) * a.W + (g_px & 15)) * g_prow + (unsigned)(n0 + g_sl * 8) * 4u;
+    const unsigned prow0 = (unsigned)a.src[ch0.src].C * 4u, prow1 = (unsigned)a.src[ch1.src].C * 4u;
+    int pc_hyx[5];
+    unsigned pc_toff[5];
+    bool pc_h1[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int piece = tid + 512 * u;
+        const int plane = piece >= W5_NPOS * 8 ? 1 : 0;
+        const int qq = piece - plane * W5_NPOS * 8;
+        const int pos = qq >> 3;
+        const int sl = (w2_swz<true>(pos * 128 + (qq & 7) * 16) & 127) >> 4;
+        const int hy = pos / W5_HALO_W, hx = pos - hy * W5_HALO_W;
+        const bool h1 = (sl >> 2) != 0;
+        const STWHalf hf = h1 ? ch1 : ch0;
+        const bool ok = (sl & 3) * 8 < hf.cn;
+        pc_hyx[u] = ok ? ((hy << 16) | hx) : -1;
+        pc_toff[u] = (unsigned)(hy * a.W + hx) * (h1 ? prow1 : prow0) + (unsigned)(hf.c0 + (sl & 3) * 8) * 4u + (unsigned)plane * 16u;
+        pc_h1[u] = h1;
+    }
+    auto dma_item = [&](int w, char* buf) {
+        const int b = __builtin_amdgcn_readfirstlane(w / tiles);
+        const int tile = w - b * tiles;
+        const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
+        const int y0 = ty * W2_TH, x0 = tx * 16;
+        {
+            const bool pix_ok = (y0 + (g_px >> 4) < a.H) & (x0 + (g_px & 15) < a.W);
+            const char* const gbase = a.g_sp + ((size_t)b * a.HW + (size_t)(y0 * a.W + x0)) * g_prow;
+            const char* row = gbase + g_toff;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = pix_ok & ((u >> 1) ? g_ok1 : g_ok0);
+                const char* src = ok ? row + (u >> 1) * 256 + (u & 1) * 16 : reinterpret_cast<const char*>(w2_zero16);
+                w2_dma16(src, buf + u * W2_GPL + wave * 1024);
+            }
+        }
+        const long long org = (long long)(y0 - 2) * a.W + (x0 - 2);
+        const char* const ab0 = a.src[ch0.src].sp + (size_t)b * a.HW * prow0 + org * (long long)prow0;
+        const char* const ab1 = a.src[ch1.src].sp + (size_t)b * a.HW * prow1 + org * (long long)prow1;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int gy = y0 - 2 + (pc_hyx[u] >> 16), gx = x0 - 2 + (pc_hyx[u] & 0xffff);
+            const bool ok = (pc_hyx[u] >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W);
+            const char* src = ok ? (pc_h1[u] ? ab1 : ab0) + pc_toff[u] : reinterpret_cast<const char*>(w2_zero16);
+            w2_dma16(src, buf + W2_A0 + (512 * u + wave * 64) * 16);
+        }
+    };
+
+    const int s_lo = ksplit ? wc : (tsplit ? tg : 0), s_hi = (ksplit || tsplit) ? s_lo + 1 : 2;
+    auto multiply = [&](const char* buf) {
+        const char* gb = buf + wn * 2 * W2_GPL;
+#pragma unroll 1
+        for (int s2 = s_lo; s2 < s_hi; ++s2) {
+            bf16x8 gh[4], gl[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                gh[rt] = w2_frag<1024>(gb + (g_laneq ^ (rt * 32)) + s2 * 4096);
+                gl[rt] = w2_frag<1024>(gb + W2_GPL + (g_laneq ^ (rt * 32)) + s2 * 4096);
+            }
+            const int arow = a_lane + s2 * 2 * W5_HALO_W * 128 + taprow_off;
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                bf16x8 ah[2], al[2];
+                const int aoff = w2_swz<true>(arow + t * 128);
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    ah[ct] = w2_frag<1024>(buf + W2_A0 + (aoff ^ (ct * 32)));
+                    al[ct] = w2_frag<1024>(buf + W2_A0 + W5_APL + (aoff ^ (ct * 32)));
+                }
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) accq[rt][ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl[rt], ah[ct], accq[rt][ct][t], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) accq[rt][ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[rt], al[ct], accq[rt][ct][t], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) accq[rt][ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[rt], ah[ct], accq[rt][ct][t], 0, 0, 0);
+            }
+        }
+    };
+
+    int cur = slice, nxt = slice + a.n_slices;
+    if (cur < n_items) dma_item(cur, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int bsel = 0;
+    while (cur < n_items) {
+        char* bcur = smem + bsel * W5_BUF;
+        char* bnxt = smem + (bsel ^ 1) * W5_BUF;
+        if (nxt < n_items) dma_item(nxt, bnxt);
+        if (active) multiply(bcur);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        cur = nxt; nxt += a.n_slices; bsel ^= 1;
+    }
+
+    if (ksplit || tsplit) {
+        // pair reduction: the second wave of each pair parks its accumulators in LDS, the first adds them (two row tiles at a time:
+        // 4 pairs x 20 KiB). ksplit: pairs (wave, wave ^ 1); tsplit: pairs (wave, wave ^ 4).
+        const bool parks = ksplit ? wc == 1 : tg == 1;
+        float* red = reinterpret_cast<float*>(smem) + (ksplit ? (wave >> 1) : (wave & 3)) * (TA * 16 * 64);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            __syncthreads();
+            if (parks && active) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int t = 0; t < TA; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) red[(((rr * 2 + ct) * TA + t) * 4 + r) * 64 + lane] = accq[2 * nb + rr][ct][t][r];
+            }
+            __syncthreads();
+            if (!parks && active) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int t = 0; t < TA; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) accq[2 * nb + rr][ct][t][r] += red[(((rr * 2 + ct) * TA + t) * 4 + r) * 64 + lane];
+            }
+        }
+        if (parks) return;
+    }
+    if (!active) return;
+    // slab block of the pair: [tap][128 rows][64 columns]
+    float* blk = a.slabs + (size_t)slice * a.slab_stride + (size_t)pair_i * W5_BLOCK + (size_t)(trow * 5) * (128 * 64);
+    const int wcol = ksplit ? 0 : wc * 32;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int col = wcol + ct * 16 + (lane & 15);
+#pragma unroll
+            for (int t = 0; t < TA; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int nl = wn * 64 + rt * 16 + 4 * (lane >> 4) + r;
+                    blk[(size_t)t * (128 * 64) + nl * 64 + col] = accq[rt][ct][t][r];
+                }
+        }
+}
+
+// dW_k[row][col][tap] = sum over slices of the pair blocks; row = blockmap_k[n / Ch] * Ch + n % Ch for dG7 channel n
+__global__ __launch_bounds__(256) void stw_reduce_kernel(const STWArgs a, const STWOut o) {
+    const long long total = (long long)a.npairs * W5_BLOCK;
+    const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e & 63), nl = (int)((e >> 6) & 127);
+    const int tap = (int)((e >> 13) % 25), pi = (int)((e >> 13) / 25);
+    const STWPair pr = a.pair[pi];
+    const STWHalf hf = pr.h[c >> 5];
+    const int n = pr.n0 + nl;
+    if ((c & 31) >= hf.cn || n >= a.N7) return;
+    const int db = o.blockmap[pr.tensor][n / a.Ch];
+    if (db < 0) return;
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* src = a.slabs + e;
+    int s = 0;
+    for (; s + 4 <= a.n_slices; s += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] += src[(size_t)(s + k) * a.slab_stride];
+    }
+    for (int k = 0; s < a.n_slices; ++s, ++k) p[k] += src[(size_t)s * a.slab_stride];
+    const int row = db * a.Ch + n % a.Ch, col = hf.cglobal + (c & 31);
+    o.dW[pr.tensor][((size_t)row * o.Ct[pr.tensor] + col) * 25 + tap] = (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+// pairs of one cell step. Sources: 0 x (Cin), 1 h, 2 m, 3 c_new, 4 m_new (Ch each); tensors: 0 Wx, 1 Wh, 2 Wm, 3 Wo.
+int stw_build(STWArgs& a, STWOut& o, int B, int H, int W, int Cin, int Ch) {
+    a.B = B; a.H = H; a.W = W; a.HW = H * W; a.Ch = Ch; a.N7 = 7 * Ch;
+    a.npairs = 0;
+    static const signed char maps[4][7] = {{0, 1, 2, 6, 3, 4, 5}, {0, 1, 2, 3, -1, -1, -1}, {-1, -1, -1, -1, 0, 1, 2}, {-1, -1, -1, 0, -1, -1, -1}};
+    for (int k = 0; k < 4; ++k) for (int i = 0; i < 7; ++i) o.blockmap[k][i] = maps[k][i];
+    o.Ct[0] = Cin; o.Ct[1] = Ch; o.Ct[2] = Ch; o.Ct[3] = 2 * Ch;
+    struct Col { int tensor, src, C, cg; };
+    const Col cols[5] = {{0, 0, Cin, 0}, {1, 1, Ch, 0}, {2, 2, Ch, 0}, {3, 3, Ch, 0}, {3, 4, Ch, Ch}};
+    for (int n0 = 0; n0 < 7 * Ch; n0 += 128) {
+        const int n1 = n0 + 128 < 7 * Ch ? n0 + 128 : 7 * Ch;
+        for (int k = 0; k < 4; ++k) {
+            bool any = false;   // does the row tile hold a row of tensor k?
+            for (int blk = n0 / Ch; blk <= (n1 - 1) / Ch; ++blk) any = any || maps[k][blk] >= 0;
+            if (!any) continue;
+            // the tensor's columns in 32-channel halves, two per pair (the two sources of Wo continue one another)
+            STWHalf hv[64]; int nh = 0;
+            for (const Col& cc : cols) {
+                if (cc.tensor != k) continue;
+                for (int c0 = 0; c0 < cc.C; c0 += 32) { if (nh >= 64) return -1; hv[nh++] = STWHalf{cc.src, c0, cc.C - c0 < 32 ? cc.C - c0 : 32, cc.cg + c0}; }
+            }
+            for (int i = 0; i < nh; i += 2) {
+                if (a.npairs >= STW_MAX_PAIRS) return -1;
+                STWPair& pr = a.pair[a.npairs++];
+                pr.n0 = n0; pr.tensor = k; pr.h[0] = hv[i];
+                pr.h[1] = i + 1 < nh ? hv[i + 1] : STWHalf{hv[i].src, 0, 0, 0};
+            }
+        }
+    }
+    a.slab_stride = (size_t)a.npairs * W5_BLOCK;
+    return a.npairs;
+}
+
+// K slices: about two rounds of one-per-CU workgroups (npairs x 3 workgroups per slice), every slice at least 8 items
+int stw_slices(int npairs, long long items) {
+    int ns = (480 + npairs * 3 / 2) / (npairs * 3);
+    if (ns > items / 8) ns = (int)(items / 8);
+    return ns < 1 ? 1 : ns;
+}
+
+hipError_t launch_stw(const STWArgs& a, const STWOut& o, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W5_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long long total = (long long)a.npairs * 3 * a.n_slices;
+    hipLaunchKernelGGL(stw_kernel, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W5_LDS, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long long n = (long long)a.npairs * W5_BLOCK;
+    hipLaunchKernelGGL(stw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, o);
+    return hipGetLastError();
+}
+
 }  // namespace vpx
