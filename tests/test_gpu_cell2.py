@@ -54,7 +54,7 @@ def _inputs(tag):
     return d
 
 
-def _run(vpx, tag, grads):
+def _run(vpx, tag, grads, precision="bf16x3"):
     Cin, Ch, H, W, B, T, with_x, with_state, peep, order = CASES[tag]
     inp = {k: (None if v is None else v.cuda()) for k, v in _inputs(tag).items()}
     leaves = {}
@@ -64,7 +64,7 @@ def _run(vpx, tag, grads):
                 leaves[k] = inp[k].clone().requires_grad_(True)
                 inp[k] = leaves[k]
     out, hT, cT = vpx.ops.convlstm_seq(inp["x"], inp["h0"], inp["c0"], inp["W"], inp["b"], inp["Wci"], inp["Wcf"], inp["Wco"],
-                                       seq_len=T, in_channels=Cin, gate_order=order, precision="bf16x3")
+                                       seq_len=T, in_channels=Cin, gate_order=order, precision=precision)
     if grads:
         ((out * inp["g_out"]).sum() + (cT * inp["g_cT"]).sum()).backward()
     return out.detach(), hT.detach(), cT.detach(), {k: v.grad for k, v in leaves.items()}
@@ -98,6 +98,25 @@ def test_cell2_bit_identical_to_first_generation_and_matches_oracle(vpx, cell2_s
     assert _relmax(o2, o1) < 2e-6 and _relmax(c2, c1) < 2e-6 and _relmax(h2, h1) < 2e-6
     ro, rh, rc, _ = _oracle(tag)
     assert _relmax(o2, ro) < 2e-5 and _relmax(c2, rc) < 2e-5 and _relmax(h2, rh) < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["enc2", "fore1_states", "fore3_noinput"])
+def test_plain_bf16_on_the_q_kernel_matches_first_generation_bf16(vpx, cell2_switch, tag):
+    """VPX_PREC_BF16 (BASELINE configs[1]'s literal dtype; hi parts only, one MFMA per product, NOT inside the 1e-4 bar) on
+    cell2_kernel_q<.., 4, true> (inference, maps in whole 16x16 tiles) against the first-generation kernel's bf16 mode — the same
+    operand rounding, fp32 summation order differs — and against the oracle at the mode's own tolerance, max|d| / max|ref| <= 1e-2."""
+    cell2_switch(0)
+    with torch.no_grad():
+        o1, h1, c1, _ = _run(vpx, tag, grads=False, precision="bf16")
+        cell2_switch(2)
+        o2, h2, c2, _ = _run(vpx, tag, grads=False, precision="bf16")
+        o3, _, _, _ = _run(vpx, tag, grads=False, precision="bf16")
+    assert torch.equal(o2, o3)
+    # recurrence: a one-ulp difference in a rounded h_t operand is a 2^-9 relative change of that operand; 3 steps stay below 1e-3
+    assert _relmax(o2, o1) < 2e-3 and _relmax(c2, c1) < 2e-3 and _relmax(h2, h1) < 2e-3, (_relmax(o2, o1), _relmax(c2, c1))
+    ro, rh, rc, _ = _oracle(tag)
+    assert _relmax(o2, ro) < 1e-2 and _relmax(c2, rc) < 1e-2
+    assert _relmax(o2, ro) > 1e-5   # it really is the reduced-precision mode
 
 
 @pytest.mark.parametrize("tag", ["enc1_ragged", "fore1_states", "ifog_nopeep"])
