@@ -268,14 +268,18 @@ def roofline(spec, ps):
         "kernel": ((f"cell2_kernel_q<Cell2Epi, true, 4> (second-generation fused ConvLSTM cell step: pre-split bf16x3 operands, "
                     f"LDS-DMA staging, v_mfma_f32_16x16x32_bf16, 16x16-pixel tiles at two workgroups per CU; cell3_kernel — 8-channel "
                     f"slices, hoisted input projection — on grids below 256 workgroups), forward" if spec.precision == "bf16x3" else
-                    f"conv_gemm_kernel<EpiConvLSTM, {spec.precision}> (fused ConvLSTM cell step, forward)")
+                    ("cell2_kernel_q<Cell2Epi, true, 4, true> (the same fused step on the hi parts only: one v_mfma_f32_16x16x32_bf16 per "
+                     "product, no lo planes staged; 16x16 maps / small grids: conv_gemm_kernel<EpiConvLSTM, bf16>), forward"
+                     if spec.precision == "bf16" else
+                     f"conv_gemm_kernel<EpiConvLSTM, {spec.precision}> (fused ConvLSTM cell step, forward)"))
                    if spec.model == "convlstm-shi" else
                    f"conv_gemm_kernel<EpiSTGate/EpiSTOut/EpiPlain, {spec.precision}> (ST-LSTM cell step, forward)"),
         "note": ("achieved = algorithmic fp32 FLOPs / kernel time. bf16x3 issues 3 bf16 MFMAs per algorithmic "
                  "product: peak = 2500 TF dense bf16 / 3, i.e. frac is the share of the bf16 MFMA pipe's dense "
                  "peak the kernel keeps busy; frac_of_bf16_dense_peak prices the same time against the plain 2500 TF"
                  if spec.precision == "bf16x3" else
-                 ("plain bf16 operands: outside the 1e-4 parity bar, reported as an extra" if spec.precision == "bf16"
+                 ("plain bf16 operands (hi parts only, one MFMA per product: cell2_kernel_q<.., 4, true>): outside the 1e-4 parity bar, "
+                  "reported as an extra" if spec.precision == "bf16"
                   else "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)")),
         "frac_of_bf16_dense_peak": (round(ach_tflops / BF16_DENSE_TFLOPS, 4) if spec.precision != "f32" else None),
         "vs_fp32_matrix_peak": round(ach_tflops / PEAK_TFLOPS["f32"], 4),
@@ -412,6 +416,9 @@ def extras_for(world):
             Spec("train_b32", mode="train", batch=32),
             Spec("train_b128", mode="train", batch=128),
             Spec("infer_b128_f32", precision="f32"),
+            # BASELINE configs[1]'s literal dtype: plain bf16 operands (hi parts only) — OUTSIDE the 1e-4 parity bar (max|d|/max|ref|
+            # ~2e-3 per block, 3e-2 held at model level), reported next to the bf16x3 headline, never mixed into it
+            Spec("infer_b128_bf16", precision="bf16"),
             Spec("predrnn_infer_b128", model="predrnn-pp"),
             Spec("c4_infer_b4_128x128x3_10to20", batch=4, img=128, channels=3, pred=20),
             Spec("c4_train_b4_128x128x3_10to20", mode="train", batch=4, img=128, channels=3, pred=20),
@@ -419,6 +426,7 @@ def extras_for(world):
             Spec("cell_64x64x64_b128", cell=(64, 64, 64, 64), batch=128),
             Spec("cell_64x64x64_b32", cell=(64, 64, 64, 64), batch=32),
             Spec("cell_64x64x64_b4", cell=(64, 64, 64, 64), batch=4),
+            Spec("cell_64x64x64_b128_bf16", cell=(64, 64, 64, 64), batch=128, precision="bf16"),
             # ... and the six block shapes of convlstm-shi at the default batch
             Spec("cell_enc1_16x64x64_b128", cell=(16, 64, 64, 64), batch=128),
             Spec("cell_enc2_64x96x32_b128", cell=(64, 96, 32, 32), batch=128),

@@ -273,7 +273,7 @@ def test_flat_adam_invalidates_packed_weight_caches(vpx):
 @pytest.mark.gpu
 def test_backward_weight_pack_reuse_matches_repacking(vpx, monkeypatch):
     """The ST-LSTM backward keeps its five transposed weight packs in a per-cell workspace while the weights are unchanged
-    (VPX_FLAG_WEIGHTS_PACKED); VPX_NO_BWD_HOLDER=1 repacks on every call. Two optimizer steps (the weights change in
+    (VPX_FLAG_WEIGHTS_PACKED); ops.BWD_WEIGHT_PACK_REUSE = False repacks on every call. Two optimizer steps (the weights change in
     between, the packs must follow) give the same model either way."""
     import copy
     from vp_suite_amd.models import MODEL_CLASSES
@@ -287,11 +287,8 @@ def test_backward_weight_pack_reuse_matches_repacking(vpx, monkeypatch):
     # of a near-zero gradient into a full lr-sized step (the test was flaky without it, 1 run in 6)
     torch.use_deterministic_algorithms(True)
     try:
-        for m, env in ((m1, None), (m2, "1")):
-            if env is None:
-                monkeypatch.delenv("VPX_NO_BWD_HOLDER", raising=False)
-            else:
-                monkeypatch.setenv("VPX_NO_BWD_HOLDER", env)
+        for m, reuse in ((m1, True), (m2, False)):
+            monkeypatch.setattr(vpx.ops, "BWD_WEIGHT_PACK_REUSE", reuse)
             o = torch.optim.Adam(m.parameters(), lr=1e-2)
             for _ in range(2):
                 o.zero_grad()

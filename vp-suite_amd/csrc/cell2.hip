@@ -972,7 +972,7 @@ static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStrea
     if (plan.qform) {
         p._q = g_experiment;
 #ifdef VPX_ABLATE
-        { const char* e = getenv("VPX_C2_STAMP_BLOCK"); p._p = e ? atoi(e) : -1; }
+        p._p = dev_switch("VPX_C2_STAMP_BLOCK", -1);
 #endif
         if (plan.plain || cell2_half_tile(p, std::is_same<Epi, Conv2Epi>::value)) {
             p.tiles_y = (p.H + 15) / 16;
@@ -999,7 +999,7 @@ static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStrea
         return hipGetLastError();
     }
 #ifdef VPX_ABLATE
-    { const char* e = getenv("VPX_C2_STAMP_BLOCK"); p._p = e ? atoi(e) : -1; }
+    p._p = dev_switch("VPX_C2_STAMP_BLOCK", -1);
 #endif
     const long long per_xcd = ((long long)p.grid_m * p.n_tiles + 7) / 8;
     hipLaunchKernelGGL((cell2_kernel<Epi, ALLG>), dim3((unsigned)(per_xcd * 8)), dim3(512), C2_LDS, s, p, epi);

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void cell3_kernel(const Cell3Args P) {
 
 // bf16x3, 3x3, recurrent channels in whole 16-channel stages that fit the LDS, whole 16x16 tiles. VPX_CELL3=0 disables.
 int cell3_mode() {
-    if (g_cell3_mode < 0) { const char* e = getenv("VPX_CELL3"); g_cell3_mode = e ? (atoi(e) ? 1 : 0) : 1; }
+    if (g_cell3_mode < 0) g_cell3_mode = dev_switch("VPX_CELL3", 1) ? 1 : 0;
     return g_cell3_mode;
 }
 bool cell3_applicable(const vpx_convlstm_desc* d) {

@@ -181,7 +181,7 @@ int ex_check(const vpx_conv_desc* d, ExGeo& g) {
 // stride-1 halo keeps two such workgroups per CU; VPX_GLUE_MW=1/2 forces a form (experiments)
 static int ex_mw(const vpx_conv_desc* d, int Ht, int Wt, int sd) {
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("VPX_GLUE_MW"); forced = e ? atoi(e) : 0; }
+    if (forced < 0) forced = dev_switch("VPX_GLUE_MW", 0);
     if (d->precision == VPX_PREC_F32) return 1;
     if (forced == 1 || forced == 2) return forced;
     if (sd != 1) return 1;
@@ -305,7 +305,7 @@ int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float*
 // 64 -> 16 3x3 stays on the first-generation kernel (0.92 vs 1.22). VPX_CONVQ=0 / 2: never / wherever it applies.
 static bool exq_preferred(const vpx_conv_desc* d, const ExGeo& g, ConvQProblem& pr) {
     static int mode = -1;
-    if (mode < 0) { const char* e = getenv("VPX_CONVQ"); mode = e ? atoi(e) : 1; }
+    if (mode < 0) mode = dev_switch("VPX_CONVQ", 1);
     if (mode == 0 || !exq_problem(d, g, pr) || convq_wpk_bytes(pr) == 0) return false;
     if (mode == 2) return true;
     if (d->Co < 64) return false;

@@ -675,7 +675,7 @@ __global__ __launch_bounds__(NTHREADS * MW, (MW == 2 ? 4 : 3)) void conv_gemm_du
 
 static bool xcd_map_enabled() {  // VPX_XCD_MAP=0 restores the plain 2-D grid (experiments)
     static int on = -1;
-    if (on < 0) { const char* e = getenv("VPX_XCD_MAP"); on = e ? atoi(e) : 1; }
+    if (on < 0) on = dev_switch("VPX_XCD_MAP", 1);
     return on != 0;
 }
 
@@ -703,7 +703,7 @@ static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tile
 template <class Epi>
 static hipError_t launch_conv(const ConvPlan& plan_in, const Epi& epi, int n_tiles, hipStream_t s) {
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("VPX_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = dev_switch("VPX_DBG", 0);
     ConvPlan plan = plan_in;
     plan.dbg = dbg;
     if (!Epi::SPLITK) plan.ksplit = 0;  // only the plain epilogue can combine partial sums
@@ -712,7 +712,7 @@ static hipError_t launch_conv(const ConvPlan& plan_in, const Epi& epi, int n_til
     if (plan.prec == VPX_PREC_F32) return plan.qpc == 3 ? hipErrorInvalidValue : launch_conv_m<Epi, 0, 1>(plan, epi, n_tiles, s);  // fp32 is MFMA-bound: MW=1 only
     if (plan.prec == VPX_PREC_BF16X3) {
         static int ms = -1;  // 16x16 tile as 4 waves x 2 sub-tiles (VPX_MS=2) instead of 8 waves x 1
-        if (ms < 0) { const char* e = getenv("VPX_MS"); ms = e ? atoi(e) : 1; }
+        if (ms < 0) ms = dev_switch("VPX_MS", 1);
         if constexpr (Epi::Q3OK) {  // 3 k-steps per weight chunk (ConvLSTM cell and its data gradient on 3x3 kernels)
             if (plan.qpc == 3 && mw <= 2 && ms != 2)
                 return mw == 2 ? launch_conv_m<Epi, 1, 2, 1, 3>(plan, epi, n_tiles, s) : launch_conv_m<Epi, 1, 1, 1, 3>(plan, epi, n_tiles, s);
@@ -770,7 +770,7 @@ int plain_groups(int Co, long long m_tiles) {
 
 int pick_ksplit(long long wgs, int nstage, bool bwd) {
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("VPX_KSPLIT"); forced = e ? atoi(e) : 0; }
+    if (forced < 0) forced = dev_switch("VPX_KSPLIT", 0);
     if (g_deterministic) return 1;
     int k = 1;
     if (forced > 0) k = forced;
@@ -879,7 +879,7 @@ int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, in
 // fp32, B=32: 64 ch -> 95 TF (1 WG/CU), 32 -> 118 TF (2), 16 -> 120-128 TF (3).  VPX_CS overrides for experiments.
 int pick_mw(int B, int H, int W, int n_tiles, int prec) {
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("VPX_MW"); forced = e ? atoi(e) : 0; }
+    if (forced < 0) forced = dev_switch("VPX_MW", 0);
     if (prec == VPX_PREC_F32) return 1;  // fp32 is MFMA-bound: the 8-wave form is not instantiated
     if (forced == 1 || forced == 2 || (forced == 4 && prec == VPX_PREC_BF16X3)) return forced;
     // 8-wave workgroups halve the weight traffic per pixel; worth it only when the launch still fills the chip
@@ -890,8 +890,7 @@ int pick_mw(int B, int H, int W, int n_tiles, int prec) {
 int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw, int stride, int qpc) {
     static int forced = -1;
     if (forced < 0) {
-        const char* e = getenv("VPX_CS");
-        forced = e ? atoi(e) : 0;
+        forced = dev_switch("VPX_CS", 0);
         if (forced < 8 || (forced & 7) || forced > CS_MAX) forced = 0;
     }
     const int kstep = mode_kstep(prec);

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void conv_many_to_few_kernel(const float* __re
 // 0: not a few-channel layer; 1: few -> many 3x3; 2: many -> few 1x1; 3: the 1x1 transposed layer (adjoint of 2)
 int conv_small_kind(const vpx_conv_desc* d) {
     static int env = -1;   // VPX_CONV_SMALL=0: implicit-GEMM kernel for these layers too (experiments)
-    if (env < 0) { const char* e = getenv("VPX_CONV_SMALL"); env = e ? atoi(e) : 1; }
+    if (env < 0) env = dev_switch("VPX_CONV_SMALL", 1);
     if (!env || d->stride != 1 || d->kh != d->kw) return 0;
     if (!d->transposed && d->kh == 3 && d->pad == 1 && (d->Ci == 1 || d->Ci == 3) && (d->Co & 7) == 0 && d->Co <= 64) return 1;
     if (!d->transposed && d->kh == 1 && d->pad == 0 && (d->Ci & 3) == 0 && d->Ci <= 64 && (d->Co == 1 || d->Co == 3)) return 2;

@@ -50,7 +50,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     // forward on the second-generation cell: the gate-backward kernel also writes dG in split operand format and the data
     // gradient runs on the cell2 main loop with a plain epilogue (conv2); VPX_CONV2_DGRAD=0 keeps the first-generation kernel
     static int c2d_env = -1;
-    if (c2d_env < 0) { const char* e = getenv("VPX_CONV2_DGRAD"); c2d_env = e ? atoi(e) : 1; }
+    if (c2d_env < 0) c2d_env = dev_switch("VPX_CONV2_DGRAD", 1);
     const bool c2d = L.v2 && c2d_env != 0;
     char* dG_sp_all = nullptr; char* wpk2 = nullptr;
     if (L.v2) {

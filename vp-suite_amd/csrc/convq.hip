@@ -463,7 +463,7 @@ struct QBuild {
 // waves per workgroup: 4 = the half tile (two workgroups per CU), 3x3-halo layers only; VPX_CONVQ_NW=8 / experiment bit 4 keep the 32x16 tile
 int convq_pick_nw(const ConvQProblem& pr) {
     static int env = -1;
-    if (env < 0) { const char* e = getenv("VPX_CONVQ_NW"); env = e ? atoi(e) : 4; }
+    if (env < 0) env = dev_switch("VPX_CONVQ_NW", 4);
     if (g_experiment & 16) return 8;   // VPX_OPT_EXPERIMENT bit 4: the 32x16 tile (A/B runs, tests)
     return (pr.halo == 2 && env == 4) ? 4 : 8;
 }
@@ -580,7 +580,7 @@ int convq_build_impl(const ConvQProblem& pr, QBuild& out, int max_cpack = 8) {
         int ci = -1, afirst = 0, late = 0;
         static const int m_hi[4] = {3, 2, 2, 1}, m_af[4] = {0, 0, 1, 1}, m_late[4] = {0, 1, 0, 1};
         static int mode_mask = -1;   // VPX_CONVQ_MODES: bit m allows mode m (experiments)
-        if (mode_mask < 0) { const char* e = getenv("VPX_CONVQ_MODES"); mode_mask = e ? atoi(e) : 15; }
+        if (mode_mask < 0) mode_mask = dev_switch("VPX_CONVQ_MODES", 15);
         for (int mode = 0; mode < 4 && ci < 0; ++mode) {
             if (!((mode_mask >> mode) & 1)) continue;
             const int hi = fu[t] - m_hi[mode];
@@ -745,7 +745,7 @@ int convq_run(const ConvQProblem& pr, const ConvQEpiArgs& ea_in, char* wpk, bool
         VPX_CHECK_HIP(hipGetLastError());
     }
     b.P.wpk = wpk;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VPX_CQ_DBG"); dbg = e ? atoi(e) : 0; } b.P.dbg = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = dev_switch("VPX_CQ_DBG", 0); b.P.dbg = dbg; }
     ConvQEpi epi{ea_in};
     epi.a.gpt = b.P.gpt;
     epi.a.phases = pr.phases;

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const float* __restric
 
 bool wgrad_small_applicable(int Co, int C, int kh, int kw, int stride, int pad) {
     static int env = -1;   // VPX_WGRAD_SMALL=0: MFMA kernels for these layers too (experiments)
-    if (env < 0) { const char* e = getenv("VPX_WGRAD_SMALL"); env = e ? atoi(e) : 1; }
+    if (env < 0) env = dev_switch("VPX_WGRAD_SMALL", 1);
     if (!env || stride != 1 || kh != kw) return false;
     if (kh == 3 && pad == 1) return (C == 1 && Co % 16 == 0 && Co <= 64) || (C == 3 && Co % 4 == 0 && Co <= 64);
     if (kh == 1 && pad == 0) return C == 16 && (Co == 1 || Co == 3);
@@ -1118,7 +1118,7 @@ static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int ta
     };
     WgradArgs a = a_in;
 #ifdef VPX_ABLATE
-    { const char* e = getenv("VPX_WG_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = dev_switch("VPX_WG_DBG", 0);
 #endif
     const dim3 grid = xcd_grid(a, ((a.N4 + 63) / 64) * a.n_ctiles);
     if (a.prec == VPX_PREC_BF16X3 || a.prec == VPX_PREC_BF16) {
@@ -1144,7 +1144,7 @@ static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int ta
         }
         // tap-group form (wgrad_tg_kernel)
         static int tg_env = -1;  // VPX_WGRAD_TG=0 falls back to the older forms below (experiments)
-        if (tg_env < 0) { const char* e = getenv("VPX_WGRAD_TG"); tg_env = e ? atoi(e) : 1; }
+        if (tg_env < 0) tg_env = dev_switch("VPX_WGRAD_TG", 1);
         if constexpr (NTAPS >= 2) {
             const long long items = (long long)a.T * a.B * ((a.W + TILE_W - 1) / TILE_W) * ((a.H + TILE_H - 1) / TILE_H);
             if (tg_env && a.vec_all && items + n_slices < (1ll << 31)) {
@@ -1153,19 +1153,19 @@ static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int ta
                 if (a.kh <= 3 && a.kw <= 3) {
                     const size_t l2 = 2 * (size_t)(2 * 128 * 128 + 2 * npos * 128);
                     static int asp_env = -1;  // VPX_WGRAD_ASP=0: convert the activation operand in the kernel as before (experiments)
-                    if (asp_env < 0) { const char* e = getenv("VPX_WGRAD_ASP"); asp_env = e ? atoi(e) : 1; }
+                    if (asp_env < 0) asp_env = dev_switch("VPX_WGRAD_ASP", 1);
                     if (a.a_split && asp_env && !a.a_sub && !a.use_org && NTAPS == 9 && npos * 16 <= 6 * 512)
                         return go(&wgrad_tg_kernel<NTAPS, 8, 6, true, true>, grid, 512, l2);
                     return go(&wgrad_tg_kernel<NTAPS, 8, 6>, grid, 512, l2);
                 }
                 static int tg1_env = -1;  // VPX_WGRAD_TG1=0: larger kernels on the 128-row form below
-                if (tg1_env < 0) { const char* e = getenv("VPX_WGRAD_TG1"); tg1_env = e ? atoi(e) : 1; }
+                if (tg1_env < 0) tg1_env = dev_switch("VPX_WGRAD_TG1", 1);
                 if (tg1_env && npos <= 256)  // up to 5x5: one item buffer, 8 activation vectors per thread
                     return go(&wgrad_tg_kernel<NTAPS, 8, 8, false>, grid, 512, (size_t)(2 * 128 * 128 + 2 * npos * 128));
             }
         }
         static int rb_env = -1;  // VPX_WGRAD_RB=1 forces the 4-wave, 64-row form
-        if (rb_env < 0) { const char* e = getenv("VPX_WGRAD_RB"); rb_env = e ? atoi(e) : 0; }
+        if (rb_env < 0) rb_env = dev_switch("VPX_WGRAD_RB", 0);
         // 8 waves / 128 rows / pipelined items when the 4-wave form's planes (> 80 KB: 5x5 and larger) allow one workgroup
         // per CU anyway; 3x3 keeps two independent 4-wave workgroups per CU (measured, training step: ConvLSTM 3x3
         // 46.2 ms vs 50.9 ms with the 8-wave form; PredRNN 5x5 134.7 ms vs 127.6 ms). VPX_WGRAD_RB=1/2 forces a form.

@@ -23,7 +23,7 @@ int g_cell2_mode = -1;
 int g_experiment = 0;
 int g_mfma_shape = -1;
 int mfma_shape() {
-    if (g_mfma_shape < 0) { const char* e = getenv("VPX_MFMA_SHAPE"); g_mfma_shape = e ? (atoi(e) ? 1 : 0) : VPX_MFMA_SHAPE_DEFAULT; }
+    if (g_mfma_shape < 0) g_mfma_shape = dev_switch("VPX_MFMA_SHAPE", VPX_MFMA_SHAPE_DEFAULT) ? 1 : 0;
     return g_mfma_shape;
 }
 
@@ -122,7 +122,7 @@ int vpx_convlstm_writes_split_output(const vpx_convlstm_desc* d) {   // the seco
 // 40 frames 64 -> 4x96 channels at 32x32: 84 -> ~25 us against the first-generation launch. VPX_HOIST_Q=0 keeps the latter.
 static bool hoist_q_problem(const vpx_convlstm_desc* d, ConvQProblem& pr) {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("VPX_HOIST_Q"); on = e ? atoi(e) : 1; }
+    if (on < 0) on = dev_switch("VPX_HOIST_Q", 1);
     memset(&pr, 0, sizeof(pr));
     if (g_experiment & 32) return false;   // VPX_OPT_EXPERIMENT bit 5: the first-generation launch (tests, A/B)
     if (!on || d->precision != VPX_PREC_BF16X3 || d->kh != 3 || d->kw != 3 || (d->Cin & 15) || d->Cin < 16 || d->layout != VPX_LAYOUT_NHWC) return false;

@@ -66,7 +66,7 @@ static inline int check_convlstm_desc(const vpx_convlstm_desc* d) {
 // lower the number of resident workgroups. bf16 modes only. VPX_QPC=2/3 forces it.
 static inline int pick_qpc(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw) {
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("VPX_QPC"); forced = e ? atoi(e) : 0; }
+    if (forced < 0) forced = dev_switch("VPX_QPC", 0);
     if (prec == VPX_PREC_F32 || (kh * kw) % 3 != 0 || mw > 2) return 2;
     if (forced == 2 || forced == 3) return forced;
     auto residency = [&](int qpc) {
@@ -83,7 +83,7 @@ static inline int pick_qpc(const int* segC, int nseg, int kh, int kw, int ng, in
 // workgroups a weight-gradient launch aims at (K slices x output tiles); VPX_WGRAD_WGS overrides (experiments)
 static inline int wgrad_target_wgs() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("VPX_WGRAD_WGS"); v = e ? atoi(e) : 1024; }
+    if (v < 0) v = dev_switch("VPX_WGRAD_WGS", 1024);
     return v;
 }
 
@@ -93,7 +93,7 @@ static inline int wgrad_target_wgs() {
 // wherever the shape allows (experiments).
 extern int g_cell2_mode;  // vpx_api.hip: -1 = not yet read from the environment
 static inline int cell2_mode() {
-    if (g_cell2_mode < 0) { const char* e = getenv("VPX_CELL2"); g_cell2_mode = e ? atoi(e) : 1; }
+    if (g_cell2_mode < 0) g_cell2_mode = dev_switch("VPX_CELL2", 1);
     return g_cell2_mode;
 }
 static inline bool cell2_applicable(const vpx_convlstm_desc* d) {
@@ -108,14 +108,14 @@ static inline bool cell2_applicable(const vpx_convlstm_desc* d) {
     // 16-row maps: on the half tile (q form) only. Measured at B=128, (96,96,16x16): 128 -> 106 us per step against the
     // first-generation kernel (384 workgroups of four waves); VPX_CELL2_H16=0 keeps them there
     static int h16 = -1;
-    if (h16 < 0) { const char* e = getenv("VPX_CELL2_H16"); h16 = e ? atoi(e) : 1; }
+    if (h16 < 0) h16 = dev_switch("VPX_CELL2_H16", 1);
     if (d->H < 16 || (d->H == 16 && !(h16 && mfma_shape() == 1 && (d->W & 15) == 0 && (d->Ch & 31) == 0))) return false;
     if (cell2_mode() == 2) return true;
     const long long wgs = (long long)d->B * ((d->H + 31) / 32) * ((d->W + 15) / 16) * ((d->Ch + 31) / 32);
     static int min_wgs = -1;   // VPX_CELL2_MIN_WGS: experiment override of the bar below
     // 64 (= 128 half tiles of four waves, cell2_kernel_q<.., 4>): the B=4 steps of the 64x64 blocks, whose first-generation launch
     // has exactly 256 workgroups, run 48 -> 38 us there (B=4 step 2.13 -> 1.93 ms; B=4 at 3x128x128 6.71 -> 5.89 ms)
-    if (min_wgs < 0) { const char* e = getenv("VPX_CELL2_MIN_WGS"); min_wgs = e ? atoi(e) : 64; }
+    if (min_wgs < 0) min_wgs = dev_switch("VPX_CELL2_MIN_WGS", 64);
     return wgs >= min_wgs;
 }
 
@@ -158,7 +158,7 @@ struct ConvLSTMLayout {  // derived sizes shared by workspace query, fwd and bwd
 // kernel writes dG in both forms. VPX_WGRAD2_WSP=0 disables.
 static inline bool wgrad2_wsp(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
     static int env = -1;
-    if (env < 0) { const char* e = getenv("VPX_WGRAD2_WSP"); env = e ? atoi(e) : 1; }
+    if (env < 0) env = dev_switch("VPX_WGRAD2_WSP", 1);
     return env && !L.v2 && d->precision == VPX_PREC_BF16X3 && d->kh == 3 && d->kw == 3 && (d->Cin & 7) == 0 && (d->Ch & 7) == 0;
 }
 
@@ -178,9 +178,9 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
         // the fused launch would leave CUs idle (small batches / maps). Measured on MI355X, bf16x3, (96,96,16x16):
         // B=4 (24 workgroups fused) 20 -> 39 TF with the split; B=32 (192 workgroups) 155 -> 164 TF with 2 splits
         static int bar = -1;  // VPX_SPLIT_BAR: experiment override of the workgroup-count bar below
-        if (bar < 0) { const char* e = getenv("VPX_SPLIT_BAR"); bar = e ? atoi(e) : 256; }
+        if (bar < 0) bar = dev_switch("VPX_SPLIT_BAR", 256);
         static int bar3 = -1;  // VPX_CELL3_BAR: workgroup count of the fused launch below which cell3.hip takes the step (where it applies)
-        if (bar3 < 0) { const char* e = getenv("VPX_CELL3_BAR"); bar3 = e ? atoi(e) : 256; }
+        if (bar3 < 0) bar3 = dev_switch("VPX_CELL3_BAR", 256);
         const bool force2 = cell2_mode() == 2 && cell2_applicable(d);   // "wherever the shape allows": also on small grids (tests, A/B)
         const bool want3 = !force2 && m_tiles * L.n_tiles < bar3 && cell3_applicable(d);
         if (!force2 && (m_tiles * L.n_tiles < bar || want3)) {
@@ -195,7 +195,7 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
             if (ks > 1) { L.split = ks; L.s_ng = ng; L.s_tiles = tiles; }
             L.hoist = 0;
             static int hoist_on = -1;  // VPX_HOIST=0 disables (experiments)
-            if (hoist_on < 0) { const char* e = getenv("VPX_HOIST"); hoist_on = e ? atoi(e) : 1; }
+            if (hoist_on < 0) hoist_on = dev_switch("VPX_HOIST", 1);
             if (L.split && d->T > 1 && hoist_on) {
                 const int sx[1] = {d->Cin}, sh[1] = {d->Ch};
                 L.hx_nstage = build_stages(L.hx_stage, &L.hx_chunks, sx, 1, L.taps, pick_stage_channels(sx, 1, d->kh, d->kw, ng, d->precision), d->precision);

@@ -1,5 +1,6 @@
 // vpx_internal.h — shared declarations of libvpx_hip.so (gfx950 only; no CUDA / multi-backend paths).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -146,6 +147,15 @@ hipError_t launch_split_convert(const float* src, void* dst, long long npix, int
 hipError_t launch_cell2_pack(const Cell2Pack& pk, void* dst, hipStream_t s);
 size_t cell2_packed_bytes(int n_tiles, int chunks_total);   // 32x32x16 form: chunks of 24 KiB (3 per stage)
 size_t cell2_packed_bytes_q(int n_tiles, int S);             // q form: cell2_qchunks(S) chunks of 16 KiB
+// Developer switches (VPX_* kernel-selection experiments of rounds 1-3, listed in DESIGN.md). The PRODUCT library never reads the
+// process environment: dev_switch() yields the default there, so kernel selection depends on the descriptor and on
+// vpx_set_option / vpx_set_deterministic only. The developer build (`make -C vp-suite_amd/csrc ablate`, -DVPX_DEV_SWITCHES; loaded
+// through VPX_LIB by the scripts under tools/) reads the variable of that name.
+#ifdef VPX_DEV_SWITCHES
+static inline int dev_switch(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline int dev_switch(const char*, int dflt) { return dflt; }
+#endif
 extern int g_experiment;   // vpx_api.hip: bits of kernel experiments in flight (vpx_set_option(VPX_OPT_EXPERIMENT)); 0 in the product
 extern int g_mfma_shape;   // vpx_api.hip: -1 = not yet read from the environment (VPX_MFMA_SHAPE), else 0 / 1 (vpx_set_option)
 int mfma_shape();

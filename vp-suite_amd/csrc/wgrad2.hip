@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
 // Applies when launch_wgrad would pick the pre-split tap-group kernel AND dG is available in split format: 3x3, bf16x3.
 bool wgrad2_applicable(const WgradArgs& a) {
     static int env = -1;   // VPX_WGRAD2=0: keep wgrad_tg_kernel (experiments)
-    if (env < 0) { const char* e = getenv("VPX_WGRAD2"); env = e ? atoi(e) : 1; }
+    if (env < 0) env = dev_switch("VPX_WGRAD2", 1);
     if (!env || !a.a_split || !a.g_sp || a.kh != 3 || a.kw != 3 || a.prec != VPX_PREC_BF16X3) return false;
     if (a.a_sub || a.use_org || a.blk || (a.n_out && a.n_out != a.N4) || (a.N4 & 7) || (a.Cin & 7) || (a.Ch & 7)) return false;
     const long long items = (long long)a.T * a.B * ((a.W + 15) / 16) * ((a.H + W2_TH - 1) / W2_TH);
@@ -420,7 +420,7 @@ bool wgrad2_applicable(const WgradArgs& a) {
 
 int wgrad2_target_wgs() {
     static int target = -1;
-    if (target < 0) { const char* e = getenv("VPX_WGRAD2_WGS"); target = e ? atoi(e) : 512; }
+    if (target < 0) target = dev_switch("VPX_WGRAD2_WGS", 512);
     return target;
 }
 

@@ -27,6 +27,7 @@ class KernelProfile:
 
 
 PROFILE = None  # set to a KernelProfile() to collect
+BWD_WEIGHT_PACK_REUSE = True   #: ST-LSTM backward: keep the transposed weight packs between the steps of one cell (tests switch it off)
 
 def _require_gpu(t: torch.Tensor, what: str):
     _sync_determinism()
@@ -797,7 +798,7 @@ class _STLSTMStepFn(torch.autograd.Function):
         dln_arr = (ctypes.c_void_p * 8)(*[None if t is None else t.data_ptr() for t in dln]) if ctx.use_ln else None
         ws_bytes = L.vpx_stlstm_workspace_bytes(ctypes.byref(d))
         flags0 = d.flags
-        if ctx.bwd_holder is not None and not os.environ.get("VPX_NO_BWD_HOLDER"):
+        if ctx.bwd_holder is not None and BWD_WEIGHT_PACK_REUSE:
             # (which transposed packs a call makes depends on the data gradients it is asked for)
             ws, packed = ctx.bwd_holder.get(ws_bytes, dev, (ctx.wkey, dx is not None, dh is not None, dm is not None))
             if packed:
