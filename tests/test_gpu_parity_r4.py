@@ -47,10 +47,26 @@ def _predrnn_training_parity(vpx, parity_log, tag, img_shape, B, ctx, P, layers,
     assert calls["n"] == 2
 
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    # the decoupling loss is a mean of |cos|: a term whose cosine sits within rounding of zero takes sign +1 on one side and -1 on
+    # the other, and flips a whole row of the adapter's gradient (weight 100 / (layer-steps * B * Ch) each). Count them in the oracle.
+    near_kink = {"n": 0, "min": 1.0}
+    plain_decouple = tr.decouple_term
+
+    def counting_decouple(dc, dm, aw):
+        with torch.no_grad():
+            Bc, Chc = dc.shape[:2]
+            a = torch.nn.functional.normalize(torch.nn.functional.conv2d(dc, aw).view(Bc, Chc, -1), dim=2)
+            b = torch.nn.functional.normalize(torch.nn.functional.conv2d(dm, aw).view(Bc, Chc, -1), dim=2)
+            cs = torch.cosine_similarity(a, b, dim=2).abs()
+            near_kink["n"] += int((cs < 2e-5).sum())
+            near_kink["min"] = min(near_kink["min"], float(cs.min()))
+        return plain_decouple(dc, dm, aw)
+    tr.decouple_term = counting_decouple
     total = 0.0
     for k, fr in enumerate((frames, torch.flip(frames, dims=[1]))):
         pred, dec = tr.predrnn_v2_forward(sd, fr, P, patch_size=m.patch_size, num_layers=L, mask_true=masks[k])
         total = total + tr.mse_measure(pred, fr[:, ctx:]) + dec
+    tr.decouple_term = plain_decouple
     total = total / 2
     total.backward()
     rel = abs(float(loss) - float(total)) / abs(float(total))
@@ -59,9 +75,17 @@ def _predrnn_training_parity(vpx, parity_log, tag, img_shape, B, ctx, P, layers,
     bad = {}
     for k, p in m.named_parameters():
         e = parity_log(f"{tag}.grad.{k}", p.grad, sd[k].grad, w_bound)
-        if e >= w_bound:
+        if k == "adapter.weight" and near_kink["n"] > 0:
+            # |cos| kinks present (c3 run of round 4: max-norm 1.2e-2 from such terms, every other tensor <= 5.3e-5): hold the tensor
+            # to a relative L2 error instead — a wrong kernel is off by O(1), a handful of flipped signs by < 5e-3
+            g, r = p.grad.detach().cpu().numpy(), sd[k].grad.numpy()
+            l2 = float(np.sqrt(((g - r) ** 2).sum() / (r ** 2).sum()))
+            if l2 > 5e-3:
+                bad[k] = ("l2", l2, near_kink)
+        elif e >= w_bound:
             bad[k] = e
-    assert not bad, bad
+    parity_log(f"{tag}.decouple_terms_within_2e-5_of_the_abs_kink", torch.tensor([float(near_kink["n"])]), torch.tensor([1.0]), None)
+    assert not bad, (bad, near_kink)
 
 
 def test_predrnn_c3_training_gradients_vs_oracle(vpx, parity_log):

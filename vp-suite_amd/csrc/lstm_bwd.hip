@@ -1278,7 +1278,8 @@ __global__ void st_bwd_out_kernel(const STBwdOutArgs a) {
     const float dh = a.dh_new ? a.dh_new[e] : 0.0f;
     const float o = a.o[e], tl = a.tl[e];
     a.dG7[pix * a.ldG + a.o_off + ch] = dh * tl * o * (1.0f - o);  // d(o_x + o_h + conv_o(mem))
-    a.dlc[e] = dh * o * (1.0f - tl * tl);                          // d conv_last(mem)
+    if (a.dlc_off >= 0) a.dG7[pix * a.ldG + a.dlc_off + ch] = dh * o * (1.0f - tl * tl);
+    else a.dlc[e] = dh * o * (1.0f - tl * tl);                     // d conv_last(mem)
 }
 
 __global__ void st_bwd_gates_kernel(const STBwdGateArgs a) {
@@ -1310,11 +1311,124 @@ __global__ void st_bwd_gates_kernel(const STBwdGateArgs a) {
     }
 }
 
+// The same two stages, eight channels of a pixel per thread (Ch % 8 == 0): 16-byte accesses throughout and — SPLIT — dG7 written
+// straight in the split operand format ([pixel][group of 8 channels][8 hi bf16 | 8 lo bf16]) that the one-launch weight gradient
+// (stw, wgrad2.hip) stages by LDS-DMA and that the data-gradient convolutions read without conversion (ConvSeg.split): no fp32
+// copy of dG7 exists then and the separate split_convert pass (117 MB read + written per cell step at B = 128) is gone.
+typedef float f32x4_b __attribute__((ext_vector_type(4)));
+struct F8 { f32x4_b a, b; };
+__device__ __forceinline__ F8 ld8(const float* p) { return F8{*reinterpret_cast<const f32x4_b*>(p), *reinterpret_cast<const f32x4_b*>(p + 4)}; }
+__device__ __forceinline__ F8 ld8z(const float* p, long long e) { return p ? ld8(p + e) : F8{f32x4_b{0.f, 0.f, 0.f, 0.f}, f32x4_b{0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ float f8get(const F8& v, int i) { return i < 4 ? v.a[i] : v.b[i - 4]; }
+template <bool SPLIT>
+__device__ __forceinline__ void st8(float* base, const float (&v)[8]) {   // base: the 8-channel group's 32 bytes
+    if constexpr (SPLIT) {
+        unsigned h[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const __bf16 hb = (__bf16)v[i];
+            h[i] = __builtin_bit_cast(unsigned short, hb);
+            const __bf16 lb = (__bf16)(v[i] - __builtin_bit_cast(float, h[i] << 16));
+            l[i] = __builtin_bit_cast(unsigned short, lb);
+        }
+        uint4* d = reinterpret_cast<uint4*>(base);
+        d[0] = uint4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+        d[1] = uint4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
+    } else {
+        *reinterpret_cast<f32x4_b*>(base) = f32x4_b{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4_b*>(base + 4) = f32x4_b{v[4], v[5], v[6], v[7]};
+    }
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void st_bwd_out8_kernel(const STBwdOutArgs a) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const int G = a.Ch >> 3;
+    if (t >= a.n / 8) return;
+    const long long pix = t / G;
+    const int ch = (int)(t - pix * G) * 8;
+    const long long e = pix * a.Ch + ch;
+    const F8 dh = ld8z(a.dh_new, e), o = ld8(a.o + e), tl = ld8(a.tl + e);
+    float go[8], gl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float d = f8get(dh, i), oo = f8get(o, i), tt = f8get(tl, i);
+        go[i] = d * tt * oo * (1.0f - oo);
+        gl[i] = d * oo * (1.0f - tt * tt);
+    }
+    st8<SPLIT>(a.dG7 + pix * a.ldG + a.o_off + ch, go);
+    if (a.dlc_off >= 0) st8<SPLIT>(a.dG7 + pix * a.ldG + a.dlc_off + ch, gl);
+    else st8<false>(a.dlc + e, gl);
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void st_bwd_gates8_kernel(const STBwdGateArgs a) {
+    const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const int Ch = a.Ch, G = Ch >> 3;
+    if (t >= a.npix * G) return;
+    const long long pix = t / G;
+    const int ch = (int)(t - pix * G) * 8;
+    const long long e = pix * Ch + ch;
+    float* dg = a.dG7 + pix * a.ldG + ch;
+    {
+        const float* gs = a.gates_c + pix * 3 * Ch + ch;
+        const F8 i_ = ld8(gs), f_ = ld8(gs + Ch), g_ = ld8(gs + 2 * Ch), cv = ld8(a.c + e), dc1 = ld8z(a.dcn_ext, e), dc2 = ld8(a.dcn_conv + e),
+                 dd = ld8z(a.ddc_ext, e);
+        float r0[8], r1[8], r2[8], r3[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float ii = f8get(i_, k), ff = f8get(f_, k), gg = f8get(g_, k);
+            const float dcn = f8get(dc1, k) + f8get(dc2, k);
+            const float ddl = dcn + f8get(dd, k);
+            r0[k] = ddl * gg * ii * (1.0f - ii);
+            r1[k] = dcn * f8get(cv, k) * ff * (1.0f - ff);
+            r2[k] = ddl * ii * (1.0f - gg * gg);
+            r3[k] = dcn * ff;
+        }
+        st8<SPLIT>(dg, r0); st8<SPLIT>(dg + Ch, r1); st8<SPLIT>(dg + 2 * Ch, r2);
+        if (a.dc) st8<false>(a.dc + e, r3);
+    }
+    {
+        const float* gs = a.gates_m + pix * 3 * Ch + ch;
+        const F8 i_ = ld8(gs), f_ = ld8(gs + Ch), g_ = ld8(gs + 2 * Ch), mv = ld8(a.m + e), dm1 = ld8z(a.dmn_ext, e), dm2 = ld8(a.dmn_conv + e),
+                 dd = ld8z(a.ddm_ext, e);
+        float r0[8], r1[8], r2[8], r3[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float ii = f8get(i_, k), ff = f8get(f_, k), gg = f8get(g_, k);
+            const float dmn = f8get(dm1, k) + f8get(dm2, k);
+            const float ddl = dmn + f8get(dd, k);
+            r0[k] = ddl * gg * ii * (1.0f - ii);
+            r1[k] = dmn * f8get(mv, k) * ff * (1.0f - ff);
+            r2[k] = ddl * ii * (1.0f - gg * gg);
+            r3[k] = dmn * ff;
+        }
+        st8<SPLIT>(dg + 4 * Ch, r0); st8<SPLIT>(dg + 5 * Ch, r1); st8<SPLIT>(dg + 6 * Ch, r2);
+        st8<false>(a.dm + e, r3);
+    }
+}
+
+static bool st_vec8_ok(int Ch, int ldG, const void* p0, const void* p1) {
+    return !(Ch & 7) && !(ldG & 7) && !(reinterpret_cast<uintptr_t>(p0) & 15) && !(reinterpret_cast<uintptr_t>(p1) & 15);
+}
+
 hipError_t launch_st_bwd_out(const STBwdOutArgs& a, hipStream_t s) {
+    if (a.split || st_vec8_ok(a.Ch, a.ldG, a.dG7, a.dlc_off >= 0 ? (const void*)a.dG7 : (const void*)a.dlc)) {
+        const long long n8 = a.n / 8;
+        if (a.split) hipLaunchKernelGGL(st_bwd_out8_kernel<true>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(st_bwd_out8_kernel<false>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(st_bwd_out_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_st_bwd_gates(const STBwdGateArgs& a, hipStream_t s) {
+    if (a.split || st_vec8_ok(a.Ch, a.ldG, a.dG7, a.dm)) {
+        const long long n8 = a.npix * (a.Ch >> 3);
+        if (a.split) hipLaunchKernelGGL(st_bwd_gates8_kernel<true>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(st_bwd_gates8_kernel<false>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     const long long n = a.npix * a.Ch;
     hipLaunchKernelGGL(st_bwd_gates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();

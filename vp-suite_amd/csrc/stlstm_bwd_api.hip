@@ -46,7 +46,7 @@ int st_bwd_layout(const vpx_stlstm_desc* d, STBwdLayout& L) {
     L.taps = d->k * d->k; L.Ch = Ch; L.Cin = Cin;
     L.n_state = (size_t)d->B * d->H * d->W * Ch;
     L.n_x = (size_t)d->B * d->H * d->W * Cin;
-    L.n_g7 = L.n_state * 7;
+    L.n_g7 = L.n_state * (stw_applicable(d) ? 8 : 7);   // the one-launch weight gradient keeps d conv_last as an eighth block
     const int s1[1] = {Ch}, s3[3] = {3 * Ch, Ch, 3 * Ch}, s4[1] = {4 * Ch}, s3m[1] = {3 * Ch};
     const int pr = d->precision;
     const long long mt = (long long)d->B * ((d->W + TILE_W - 1) / TILE_W) * ((d->H + TILE_H - 1) / TILE_H);
@@ -69,7 +69,7 @@ int st_bwd_layout(const vpx_stlstm_desc* d, STBwdLayout& L) {
         L.stw_pairs = stw_build(sa, so, d->B, d->H, d->W, Cin, Ch);
         if (L.stw_pairs < 1) L.stw = false;
         else {
-            L.stw_ns = stw_slices(L.stw_pairs, (long long)d->B * ((d->W + 15) / 16) * ((d->H + 3) / 4));
+            L.stw_ns = stw_slices(sa.npairs5, (long long)d->B * ((d->W + 15) / 16) * ((d->H + 3) / 4));
             const size_t need = sa.slab_stride * L.stw_ns;
             if (need > L.slab_floats) L.slab_floats = need;
         }
@@ -86,7 +86,7 @@ size_t stlstm_bwd_workspace_bytes(const vpx_stlstm_desc* d) {
     size_t b = align256(L.n_g7 * 4) + 4 * align256(L.n_state * 4);  // dG7, dlc, dcn_conv, dmn_conv, dm scratch
     b += align256(L.o.wpk * 4) + align256(L.l.wpk * 4) + align256(L.x.wpk * 4) + align256(L.h.wpk * 4) + align256(L.m.wpk * 4);
     b += align256(L.slab_floats * 4);
-    if (L.stw) b += align256(L.n_g7 * 4) + align256(L.n_x * 4) + 4 * align256(L.n_state * 4);   // split copies: dG7, x, h, m, c_new, m_new
+    if (L.stw) b += align256(L.n_x * 4) + 4 * align256(L.n_state * 4);   // split copies: x, h, m, c_new, m_new
     if (d->layout == VPX_LAYOUT_NCHW) b += 2 * align256(L.n_x * 4) + 14 * align256(L.n_state * 4);
     return b;
 }
@@ -147,7 +147,6 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     hipStream_t stream = (hipStream_t)stream_;
     const int B = d->B, Cin = d->Cin, Ch = d->Ch, H = d->H, Wd = d->W, k = d->k;
     const size_t HW = (size_t)H * Wd;
-    const int ldG = 7 * Ch;
     vpx_stlstm_desc d2;
     if (d->layer_norm) {
         if (!ln) { set_error("vpx_stlstm_step_bwd: layer_norm set but ln is NULL"); return VPX_ERR_ARG; }
@@ -198,9 +197,9 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     float* wpk_h = ws.take(L.h.wpk);
     float* wpk_m = ws.take(L.m.wpk);
     float* slabs = ws.take(L.slab_floats);
-    char *g7_sp = nullptr, *x_sp = nullptr, *st_sp[4] = {nullptr, nullptr, nullptr, nullptr};
+    char *x_sp = nullptr, *st_sp[4] = {nullptr, nullptr, nullptr, nullptr};
     if (L.stw) {
-        g7_sp = (char*)ws.take(L.n_g7); x_sp = (char*)ws.take(L.n_x);
+        x_sp = (char*)ws.take(L.n_x);
         for (auto& q : st_sp) q = (char*)ws.take(L.n_state);
     }
 
@@ -256,9 +255,14 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         }
         return hipSuccess;
     };
+    // The one-launch weight gradient wants dG7 in the split operand format: the two pointwise stages then write that format ONLY
+    // (the data-gradient convolutions read it without conversion, ConvSeg.split) — no fp32 dG7, no conversion pass.
+    const bool stw = L.stw && dWx && dWh && dWm && dWo && dWlast;
+    const int g7s = stw ? 1 : 0;
+    const int ldG = stw ? 8 * Ch : 7 * Ch;   // stw: dG8 = the seven gate blocks + d conv_last (block 7), all in the split format
     // ---- A: through h_new = o * tanh(conv_last(mem)) ----
     {
-        STBwdOutArgs a{(long long)L.n_state, Ch, ldG, 3 * Ch, g_h, o_save, tl_save, dG7, dlc};
+        STBwdOutArgs a{(long long)L.n_state, Ch, ldG, 3 * Ch, stw ? 7 * Ch : -1, g_h, o_save, tl_save, dG7, dlc, g7s};
         VPX_CHECK_HIP(launch_st_bwd_out(a, stream));
     }
     // ---- B: grads of mem = [c_new | m_new] through conv_o (k x k) and conv_last (1 x 1) ----
@@ -268,7 +272,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         pack_plain_T(pd, L.o, L.taps, 2 * Ch);
         if (!packed) VPX_CHECK_HIP(launch_pack_weights(pd, wpk_o, stream));
         ConvPlan P = plan_for(L.o, k, wpk_o);
-        P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG};
+        P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG, g7s};
         PlainEpiArgs ea{};
         ea.Co = 2 * Ch; ea.split = Ch; ea.ng = L.o.ng;
         ea.out0 = dcn_conv; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
@@ -281,7 +285,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         pack_plain_T(pl, L.l, 1, 2 * Ch);
         if (!packed) VPX_CHECK_HIP(launch_pack_weights(pl, wpk_l, stream));
         ConvPlan Q = plan_for(L.l, 1, wpk_l);
-        Q.nseg = 1; Q.seg[0] = ConvSeg{dlc, (long long)(HW * Ch), Ch, 0};
+        Q.nseg = 1; Q.seg[0] = stw ? ConvSeg{dG7 + 7 * Ch, (long long)(HW * ldG), Ch, ldG, 1} : ConvSeg{dlc, (long long)(HW * Ch), Ch, 0};
         ea.accumulate = 1;
         VPX_CHECK_HIP(split_plan(Q, L.l, dcn_conv, dmn_conv, L.n_state, true));
         VPX_CHECK_HIP(launch_conv_plain_f32(Q, ea, L.l.tiles, stream));
@@ -293,7 +297,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         a.gates_c = gates_c; a.gates_m = gates_m; a.c = cn; a.m = mn;
         a.dcn_ext = g_c; a.dmn_ext = g_m; a.ddc_ext = g_dc; a.ddm_ext = g_dm;
         a.dcn_conv = dcn_conv; a.dmn_conv = dmn_conv;
-        a.dG7 = dG7; a.dc = dcn; a.dm = dmn;
+        a.dG7 = dG7; a.dc = dcn; a.dm = dmn; a.split = g7s;
         VPX_CHECK_HIP(launch_st_bwd_gates(a, stream));
     }
     // ---- D: data gradients ----
@@ -307,9 +311,9 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         if (!packed) VPX_CHECK_HIP(launch_pack_weights(pd, wpk_x, stream));
         ConvPlan P = plan_for(L.x, k, wpk_x);
         P.nseg = 3;
-        P.seg[0] = ConvSeg{dG7, (long long)(HW * ldG), 3 * Ch, ldG};
-        P.seg[1] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG};
-        P.seg[2] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG};
+        P.seg[0] = ConvSeg{dG7, (long long)(HW * ldG), 3 * Ch, ldG, g7s};
+        P.seg[1] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG, g7s};
+        P.seg[2] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG, g7s};
         PlainEpiArgs ea{};
         ea.Co = Cin; ea.split = Cin; ea.ng = L.x.ng; ea.out0 = dxn; ea.bstride0 = (long long)(HW * Cin); ea.ld0 = Cin;
         VPX_CHECK_HIP(split_plan(P, L.x, dxn, nullptr, L.n_x, false));
@@ -321,7 +325,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         pack_plain_T(pd, L.h, L.taps, Ch);
         if (!packed) VPX_CHECK_HIP(launch_pack_weights(pd, wpk_h, stream));
         ConvPlan P = plan_for(L.h, k, wpk_h);
-        P.nseg = 1; P.seg[0] = ConvSeg{dG7, (long long)(HW * ldG), 4 * Ch, ldG};
+        P.nseg = 1; P.seg[0] = ConvSeg{dG7, (long long)(HW * ldG), 4 * Ch, ldG, g7s};
         PlainEpiArgs ea{};
         ea.Co = Ch; ea.split = Ch; ea.ng = L.h.ng; ea.out0 = dhn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
         VPX_CHECK_HIP(split_plan(P, L.h, dhn, nullptr, L.n_state, false));
@@ -333,7 +337,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         pack_plain_T(pd, L.m, L.taps, Ch);
         if (!packed) VPX_CHECK_HIP(launch_pack_weights(pd, wpk_m, stream));
         ConvPlan P = plan_for(L.m, k, wpk_m);
-        P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG};
+        P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 4 * Ch, (long long)(HW * ldG), 3 * Ch, ldG, g7s};
         PlainEpiArgs ea{};
         ea.Co = Ch; ea.split = Ch; ea.ng = L.m.ng; ea.out0 = dmn; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
         ea.accumulate = 1;  // onto dm_new_total * f' written by stage C
@@ -341,25 +345,23 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.m.tiles, stream));
     }
     // ---- E: weight gradients ----
-    const bool stw = L.stw && dWx && dWh && dWm && dWo;
     if (stw) {
         // all four k x k tensors in one launch (wgrad2.hip, stw): operands once more in the split format
         static thread_local STWArgs sa; static thread_local STWOut so;
         if (stw_build(sa, so, B, H, Wd, Cin, Ch) != L.stw_pairs) { set_error("stlstm bwd: pair table changed"); return VPX_ERR_ARG; }
         const long long npix = (long long)B * (long long)HW;
-        VPX_CHECK_HIP(launch_split_convert(dG7, g7_sp, npix, 7 * Ch, stream));
         VPX_CHECK_HIP(launch_split_convert(xn, x_sp, npix, Cin, stream));
         const float* st_src[4] = {hn, mn, cnn, mnn};
         for (int i = 0; i < 4; ++i) VPX_CHECK_HIP(launch_split_convert(st_src[i], st_sp[i], npix, Ch, stream));
-        sa.g_sp = g7_sp;
+        sa.g_sp = reinterpret_cast<const char*>(dG7);   // written in the split format by stages A and C
         sa.src[0] = STWSrc{x_sp, Cin};
         for (int i = 0; i < 4; ++i) sa.src[1 + i] = STWSrc{st_sp[i], Ch};
         sa.n_slices = L.stw_ns; sa.slabs = slabs;
-        so.dW[0] = dWx; so.dW[1] = dWh; so.dW[2] = dWm; so.dW[3] = dWo;
+        so.dW[0] = dWx; so.dW[1] = dWh; so.dW[2] = dWm; so.dW[3] = dWo; so.dW[4] = dWlast;
         VPX_CHECK_HIP(launch_stw(sa, so, stream));
     }
     if (!stw && dWo && (rc = run_wgrad(d, L, dG7 + 3 * Ch, Ch, ldG, cnn, Ch, mnn, Ch, k, nullptr, 0, Ch, slabs, dWo, stream))) return rc;
-    if (dWlast && (rc = run_wgrad(d, L, dlc, Ch, Ch, cnn, Ch, mnn, Ch, 1, nullptr, 0, Ch, slabs, dWlast, stream))) return rc;
+    if (!stw && dWlast && (rc = run_wgrad(d, L, dlc, Ch, Ch, cnn, Ch, mnn, Ch, 1, nullptr, 0, Ch, slabs, dWlast, stream))) return rc;
     if (!stw && dWx) {
         const int rowblk[8] = {0, 1, 2, 6, 3, 4, 5, 0};
         if ((rc = run_wgrad(d, L, dG7, 7 * Ch, ldG, xn, Cin, nullptr, 0, k, rowblk, Ch, 7 * Ch, slabs, dWx, stream))) return rc;

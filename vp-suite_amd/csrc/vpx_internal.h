@@ -426,15 +426,15 @@ struct STWSrc { const char* sp; int C; };          // split tensor [B][HW][C]
 struct STWHalf { int src, c0, cn, cglobal; };      // channels [c0, c0 + cn) of source src = columns cglobal.. of the tensor (cn = 0: empty)
 struct STWPair { int n0, tensor; STWHalf h[2]; };  // rows n0 .. n0 + 127 of dG7 x 64 columns
 struct STWArgs {
-    int B, H, W, HW, Ch, N7;
-    const char* g_sp;            // dG7 [B][HW][7Ch], split format
+    int B, H, W, HW, Ch, N7;     // N7: channels per pixel of the row operand (8Ch)
+    const char* g_sp;            // dG8 [B][HW][8Ch], split format: gate blocks (i,f,g | o | i',f',g') + d conv_last
     STWSrc src[5];               // x, h, m, c_new, m_new
-    int npairs, n_slices;
+    int npairs, npairs5, n_slices;   // pairs [0, npairs5): k x k tensors (three tap passes); [npairs5, npairs): the 1 x 1 tensor (centre tap)
     STWPair pair[STW_MAX_PAIRS];
     float* slabs;                // [n_slices][npairs][25][128][64]
     size_t slab_stride;          // floats per slice
 };
-struct STWOut { float* dW[4]; int Ct[4]; signed char blockmap[4][8]; };   // Wx, Wh, Wm, Wo
+struct STWOut { float* dW[5]; int Ct[5]; int ntaps[5]; signed char blockmap[5][8]; };   // Wx, Wh, Wm, Wo, Wlast
 int stw_build(STWArgs& a, STWOut& o, int B, int H, int W, int Cin, int Ch);   // fills the pair table; returns npairs (-1: too many)
 int stw_slices(int npairs, long long items);
 hipError_t launch_stw(const STWArgs& a, const STWOut& o, hipStream_t s);       // kernel + slice reduction into dW[0..3] (overwritten)
@@ -446,8 +446,10 @@ hipError_t launch_wgrad_reduce_map(const float* slabs, float* dW, int n_slices, 
 struct STBwdOutArgs {         // stage A: through h_new = o * tanh(lc)
     long long n;              // B*HW*Ch
     int Ch, ldG, o_off;       // d(o pre-activation) is written into dG7[pix*ldG + o_off + ch]
+    int dlc_off;              // >= 0: d conv_last goes to dG7[pix*ldG + dlc_off + ch] in dG7's own format instead of the fp32 tensor dlc
     const float* dh_new; const float* o; const float* tl;
     float* dG7; float* dlc;
+    int split;                // dG7 is written in the split operand format (Ch % 8 == 0, ldG % 8 == 0); dlc stays fp32
 };
 struct STBwdGateArgs {        // stage B: through the two gate groups
     long long npix;           // B*HW
@@ -460,6 +462,7 @@ struct STBwdGateArgs {        // stage B: through the two gate groups
     float* dG7;               // blocks (i,f,g | o | i',f',g'), o block already filled by stage A
     float* dc;                // out: dL/dc (may be null)
     float* dm;                // out: direct part of dL/dm = dm_new_total * f' (conv part is accumulated later)
+    int split;                // dG7 blocks written in the split operand format
 };
 // ---- LayerNorm ST-LSTM variant (layernorm.hip) ----
 hipError_t launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* xhat,

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
     const int tg = wave >> 2, wn = (wave >> 1) & 1, wc = wave & 1;
     int slice, pair_i, pass;
     {
-        const int per_slice = a.npairs * 3;
+        const int per_slice = a.npairs5 * 3 + (a.npairs - a.npairs5);
         const long long total = (long long)per_slice * a.n_slices;
         const long long per_xcd = (total + 7) / 8;
         const unsigned L = blockIdx.x;
@@ -502,16 +502,20 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
         slice = (int)(v / per_slice);
         const int rem = (int)(v - (long long)slice * per_slice);
         // the long passes (tap rows {0,1}, {2,3}) of every pair first, the short pass last
-        if (rem < 2 * a.npairs) { pair_i = rem >> 1; pass = rem & 1; } else { pair_i = rem - 2 * a.npairs; pass = 2; }
+        // (pairs [npairs5, npairs) are the 1x1 tensor's: one pass, centre tap only)
+        if (rem < 2 * a.npairs5) { pair_i = rem >> 1; pass = rem & 1; }
+        else if (rem < 3 * a.npairs5) { pair_i = rem - 2 * a.npairs5; pass = 2; }
+        else { pair_i = rem - 2 * a.npairs5; pass = 3; }
         slice = __builtin_amdgcn_readfirstlane(slice); pair_i = __builtin_amdgcn_readfirstlane(pair_i); pass = __builtin_amdgcn_readfirstlane(pass);
     }
     const STWPair pr = a.pair[pair_i];
     const STWHalf ch0 = pr.h[0], ch1 = pr.h[1];
     const int n0 = pr.n0;
     const bool ksplit = ch1.cn == 0;                 // half-empty column tile: the wave pair (wc) shares the channels and splits K
-    const bool tsplit = pass == 2 && !ksplit;        // tap row 4: the tap groups share it and split K
-    const int trow = tsplit ? 4 : 2 * pass + tg;     // this wave's tap row
-    const bool active = trow < 5;
+    const bool centre = pass == 3;                   // conv_last (1x1): tap (2, 2) only
+    const bool tsplit = pass >= 2 && !ksplit;        // tap row 4 (or the centre tap): the tap groups share it and split K
+    const int trow = centre ? 2 : (tsplit ? 4 : 2 * pass + tg);   // this wave's tap row
+    const bool active = centre ? (tsplit || tg == 0) : trow < 5;
 
     f32x4 accq[4][2][TA];
 #pragma unroll
@@ -598,6 +602,7 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
             const int arow = a_lane + s2 * 2 * W5_HALO_W * 128 + taprow_off;
 #pragma unroll
             for (int t = 0; t < TA; ++t) {
+                if (centre && t != 2) continue;
                 bf16x8 ah[2], al[2];
                 const int aoff = w2_swz<true>(arow + t * 128);
 #pragma unroll
@@ -699,6 +704,8 @@ __global__ __launch_bounds__(256) void stw_reduce_kernel(const STWArgs a, const 
     if ((c & 31) >= hf.cn || n >= a.N7) return;
     const int db = o.blockmap[pr.tensor][n / a.Ch];
     if (db < 0) return;
+    const bool one = o.ntaps[pr.tensor] == 1;        // the 1x1 tensor: only the centre tap of its blocks was written
+    if (one && tap != 12) return;
     float p[4] = {0.f, 0.f, 0.f, 0.f};
     const float* src = a.slabs + e;
     int s = 0;
@@ -708,21 +715,25 @@ __global__ __launch_bounds__(256) void stw_reduce_kernel(const STWArgs a, const 
     }
     for (int k = 0; s < a.n_slices; ++s, ++k) p[k] += src[(size_t)s * a.slab_stride];
     const int row = db * a.Ch + n % a.Ch, col = hf.cglobal + (c & 31);
-    o.dW[pr.tensor][((size_t)row * o.Ct[pr.tensor] + col) * 25 + tap] = (p[0] + p[1]) + (p[2] + p[3]);
+    o.dW[pr.tensor][one ? (size_t)row * o.Ct[pr.tensor] + col : ((size_t)row * o.Ct[pr.tensor] + col) * 25 + tap] = (p[0] + p[1]) + (p[2] + p[3]);
 }
 
-// pairs of one cell step. Sources: 0 x (Cin), 1 h, 2 m, 3 c_new, 4 m_new (Ch each); tensors: 0 Wx, 1 Wh, 2 Wm, 3 Wo.
+// pairs of one cell step. The row operand is dG8 [B,HW,8Ch] = the seven gate blocks (i,f,g | o | i',f',g') + d conv_last as block 7.
+// Sources: 0 x (Cin), 1 h, 2 m, 3 c_new, 4 m_new (Ch each); tensors: 0 Wx, 1 Wh, 2 Wm, 3 Wo (k x k), 4 Wlast (1 x 1, pairs listed last).
 int stw_build(STWArgs& a, STWOut& o, int B, int H, int W, int Cin, int Ch) {
-    a.B = B; a.H = H; a.W = W; a.HW = H * W; a.Ch = Ch; a.N7 = 7 * Ch;
-    a.npairs = 0;
-    static const signed char maps[4][7] = {{0, 1, 2, 6, 3, 4, 5}, {0, 1, 2, 3, -1, -1, -1}, {-1, -1, -1, -1, 0, 1, 2}, {-1, -1, -1, 0, -1, -1, -1}};
-    for (int k = 0; k < 4; ++k) for (int i = 0; i < 7; ++i) o.blockmap[k][i] = maps[k][i];
-    o.Ct[0] = Cin; o.Ct[1] = Ch; o.Ct[2] = Ch; o.Ct[3] = 2 * Ch;
+    a.B = B; a.H = H; a.W = W; a.HW = H * W; a.Ch = Ch; a.N7 = 8 * Ch;
+    a.npairs = 0; a.npairs5 = 0;
+    static const signed char maps[5][8] = {{0, 1, 2, 6, 3, 4, 5, -1}, {0, 1, 2, 3, -1, -1, -1, -1}, {-1, -1, -1, -1, 0, 1, 2, -1},
+                                           {-1, -1, -1, 0, -1, -1, -1, -1}, {-1, -1, -1, -1, -1, -1, -1, 0}};
+    for (int k = 0; k < 5; ++k) for (int i = 0; i < 8; ++i) o.blockmap[k][i] = maps[k][i];
+    o.Ct[0] = Cin; o.Ct[1] = Ch; o.Ct[2] = Ch; o.Ct[3] = 2 * Ch; o.Ct[4] = 2 * Ch;
+    for (int k = 0; k < 5; ++k) o.ntaps[k] = k == 4 ? 1 : 25;
     struct Col { int tensor, src, C, cg; };
-    const Col cols[5] = {{0, 0, Cin, 0}, {1, 1, Ch, 0}, {2, 2, Ch, 0}, {3, 3, Ch, 0}, {3, 4, Ch, Ch}};
-    for (int n0 = 0; n0 < 7 * Ch; n0 += 128) {
-        const int n1 = n0 + 128 < 7 * Ch ? n0 + 128 : 7 * Ch;
-        for (int k = 0; k < 4; ++k) {
+    const Col cols[7] = {{0, 0, Cin, 0}, {1, 1, Ch, 0}, {2, 2, Ch, 0}, {3, 3, Ch, 0}, {3, 4, Ch, Ch}, {4, 3, Ch, 0}, {4, 4, Ch, Ch}};
+    for (int kpass = 0; kpass < 2; ++kpass)   // the k x k tensors' pairs first, then the 1 x 1 tensor's
+    for (int n0 = 0; n0 < 8 * Ch; n0 += 128) {
+        const int n1 = n0 + 128 < 8 * Ch ? n0 + 128 : 8 * Ch;
+        for (int k = kpass ? 4 : 0; k < (kpass ? 5 : 4); ++k) {
             bool any = false;   // does the row tile hold a row of tensor k?
             for (int blk = n0 / Ch; blk <= (n1 - 1) / Ch; ++blk) any = any || maps[k][blk] >= 0;
             if (!any) continue;
@@ -737,6 +748,7 @@ int stw_build(STWArgs& a, STWOut& o, int B, int H, int W, int Cin, int Ch) {
                 STWPair& pr = a.pair[a.npairs++];
                 pr.n0 = n0; pr.tensor = k; pr.h[0] = hv[i];
                 pr.h[1] = i + 1 < nh ? hv[i + 1] : STWHalf{hv[i].src, 0, 0, 0};
+                if (!kpass) a.npairs5 = a.npairs;
             }
         }
     }
@@ -745,7 +757,7 @@ int stw_build(STWArgs& a, STWOut& o, int B, int H, int W, int Cin, int Ch) {
 }
 
 // K slices: about two rounds of one-per-CU workgroups (npairs x 3 workgroups per slice), every slice at least 8 items
-int stw_slices(int npairs, long long items) {
+int stw_slices(int npairs, long long items) {   // npairs: the k x k tensors' pairs (three workgroups each; the 1 x 1 pairs add one short one)
     int ns = (480 + npairs * 3 / 2) / (npairs * 3);
     if (ns > items / 8) ns = (int)(items / 8);
     return ns < 1 ? 1 : ns;
@@ -758,7 +770,7 @@ hipError_t launch_stw(const STWArgs& a, const STWOut& o, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const long long total = (long long)a.npairs * 3 * a.n_slices;
+    const long long total = (long long)(a.npairs5 * 3 + (a.npairs - a.npairs5)) * a.n_slices;
     hipLaunchKernelGGL(stw_kernel, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W5_LDS, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
