@@ -760,4 +760,287 @@ int convq_run(const ConvQProblem& pr, const ConvQEpiArgs& ea_in, char* wpk, bool
     return VPX_OK;
 }
 
+
+// =====================================================================================================================
+// c5: 5x5 'same' convolutions of the ST-LSTM step on 16x16-pixel tiles (round 4) — PredRNN's maps are 16x16 (MovingMNIST / 4)
+// or 32x32 (128x128 / 4): the 32-row tile of convq_kernel<.., 4, 8> is half empty there and its one workgroup per CU has nothing
+// to run under its prologue / epilogue. What makes a 20x20-position halo tile fit two workgroups per CU:
+//   * a K stage is EIGHT channels (one 32-byte group of the split format: 16 B hi | 16 B lo per pixel), not sixteen: a stage buffer
+//     is 2 planes x 400 positions x 16 B (padded to 512 positions = 4 LDS-DMA pieces per thread exactly): 16 KiB, two of them;
+//   * a K = 32 step multiplies FOUR (stage, tap) slots — the lane's k group (lane >> 4) selects the slot, its 8 k values are the
+//     slot's 8 channels. Slots run tap-major through the stages, 100 slots = 25 steps per PERIOD of four stages; at most two
+//     stages are live at a time (stage j of a period is read in steps floor(25 j / 4) .. floor((25 j + 24) / 4)), so two buffers
+//     suffice: stage j + 1 is requested at period step 0 / 7 / 13 / 19, three steps or more before its first fragment read and
+//     after the last read of the stage whose buffer it takes;
+//   * weights: one 16 KiB (8 KiB for 64-column tiles) chunk per step, [half][part][k group][column][8 bf16], ring of three as in
+//     cell2_kernel_q<.., 8>: sync point S_q before the 6th column tile of step q (counted vmcnt -> barrier -> copy of chunk q + 2).
+// LDS: 32 + 48 = 80 KiB (NT = 8) / 64 KiB (NT = 4; the epilogue's transposition space) -> two workgroups per CU.
+// One launch runs a TABLE of jobs over the same split-format source (the ST-LSTM backward's dG8): job = (channel ranges of the
+// source = its K, packed weights, destination, 128- or 64-column N tiles). The jobs of a launch differ in K (dx: 7Ch, dh: 4Ch,
+// dm: 3Ch channels): every XCD gets every job's tiles of ITS pixel tiles, longest job first, the N tiles of a pixel tile
+// adjacent in the XCD's dispatch order (they share the stage in its L2).
+// =====================================================================================================================
+constexpr int C5_PLANE = 512 * 16;       // one plane (hi or lo) of a stage buffer, padded from 400 positions
+constexpr int C5_ABUF = 2 * C5_PLANE;    // 16 KiB
+template <int NT> struct C5Geom {
+    static constexpr int WCH = NT * 2048;                 // weight chunk of one K = 32 step: 16 | 8 KiB
+    static constexpr int WP = WCH / (256 * 16);           // DMAs per thread and chunk: 4 | 2
+    static constexpr int LDS = 2 * C5_ABUF + (3 * WCH > 32768 ? 3 * WCH : 32768);   // >= 64 KiB: 4 waves x 16 KiB in the epilogue
+};
+
+__device__ __forceinline__ int c5_chan_of_stage(const C5Job& j, int s8) {   // first source channel of the job's stage s8
+    int c = 8 * s8;
+    if (c < j.r_n[0]) return j.r_c0[0] + c;
+    c -= j.r_n[0];
+    if (c < j.r_n[1]) return j.r_c0[1] + c;
+    return j.r_c0[2] + (c - j.r_n[1]);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
+    using G = C5Geom<NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+
+    // ---- which (job, pixel tile, N tile): XCD x owns the pixel tiles m = x, x + 8, ...; its list = job 0's tiles, job 1's, ... ----
+    const int xcd = blockIdx.x & 7;
+    int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3));
+    const int Mx = (P.m_tiles + 7) / 8;
+    // (static indices into the kernel-argument table: a run-time index would move the whole table to scratch memory)
+    C5Job J = P.job[0];
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < C5_MAX_JOBS; ++k) {
+        if (!found && k < P.njobs) {
+            const int cnt = Mx * P.job[k].n_tiles;
+            if (i < cnt) { J = P.job[k]; found = true; }
+            else i -= cnt;
+        }
+    }
+    if (!found) return;
+    const int mt = (i / J.n_tiles) * 8 + xcd, n_tile = i % J.n_tiles;
+    if (mt >= P.m_tiles) return;
+    const int tpi = P.tiles_x * P.tiles_y;
+    const int b = mt / tpi, tr = mt - b * tpi;
+    const int ty = tr / P.tiles_x, tx = tr - ty * P.tiles_x;
+    const int y0 = ty * 16, x0 = tx * 16;
+
+    char* const Abuf = smem;
+    char* const Wbuf = smem + 2 * C5_ABUF;
+    const int dma_off = wave * 1024;
+
+    // stage copy: 4 pieces per thread = [plane][512 positions]
+    int pixoff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int piece = tid + 256 * u;
+        const int pos = piece & 511;
+        const int hy = pos / 20, hx = pos - hy * 20;
+        const int gy = y0 - 2 + hy, gx = x0 - 2 + hx;
+        pixoff[u] = (pos < 400 && (unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W) ? gy * P.W + gx : -1;
+    }
+    const char* const srcb = P.src + (size_t)b * P.src_bstride;
+    const unsigned prow = (unsigned)P.src_prow;
+    auto issue_A = [&](int s8, int buf) {   // stages past the job's K are filled with zeros (their weights are zeros too)
+        const char* base = s8 < J.S8 ? srcb + (size_t)c5_chan_of_stage(J, s8) * 4 : nullptr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const char* src = (base != nullptr && pixoff[u] >= 0) ? base + (size_t)((unsigned)pixoff[u] * (unsigned long long)prow) + (u >> 1) * 16
+                                                                   : reinterpret_cast<const char*>(c2_zero16);
+            c2_dma16(src, Abuf + buf * C5_ABUF + dma_off + u * 4096);
+        }
+    };
+    const char* const wtile = J.wpk + (size_t)n_tile * J.Q * G::WCH + tid * 16;
+    auto issue_W = [&](int q, int slot) {
+#pragma unroll
+        for (int w = 0; w < G::WP; ++w) c2_dma16(wtile + (size_t)q * G::WCH + w * 4096, Wbuf + slot * G::WCH + dma_off + w * 4096);
+    };
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][nt][r] = 0.0f;
+
+    // fragments. A: row m of the wave's four tile rows, this lane's slot of period step p (k group kg): slot s = 4p + kg,
+    // stage j = s / 25 (buffer j & 1), tap t = s % 25 = (dy, dx)
+    const int a_lane = ((4 * wave) * 20 + r16) * 16;
+    auto a_off = [&](int p) {
+        const int sl = 4 * p + kg;
+        const int j = (sl * 41) >> 10, t = sl - 25 * j;
+        const int dy = (t * 13) >> 6, dx = t - 5 * dy;
+        return a_lane + (j & 1) * C5_ABUF + (dy * 20 + dx) * 16;
+    };
+    bf16x8 ah[4], al[4], bh[2], bl[2];
+    auto load_A1 = [&](int off, int m) {
+        const char* a = smem + off + m * (20 * 16);
+        ah[m] = *reinterpret_cast<const bf16x8*>(a);
+        al[m] = *reinterpret_cast<const bf16x8*>(a + C5_PLANE);
+    };
+    // B: chunk [half = nt >> 2][part][k group][64 columns][16 B] (NT = 4: one half)
+    const int w_lane = 2 * C5_ABUF + kg * 1024 + r16 * 16;
+    auto load_B = [&](int slot, int nt) {
+        const char* w = smem + w_lane + slot * G::WCH + (nt >> 2) * 8192 + (nt & 3) * 256;
+        bh[nt & 1] = *reinterpret_cast<const bf16x8*>(w);
+        bl[nt & 1] = *reinterpret_cast<const bf16x8*>(w + 4096);
+    };
+
+    const int Q = J.Q;
+    if (Q > 0) {
+        issue_A(0, 0);
+        issue_W(0, 0);
+        if (Q > 1) { issue_W(1, 1); if constexpr (G::WP == 4) C2_WAIT_VM(4); else C2_WAIT_VM(2); }
+        else C2_WAIT_VM(0);
+        c2_barrier();
+        const int o0 = a_off(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) load_A1(o0, m);
+        load_B(0, 0);
+    }
+    constexpr int SYNC_NT = NT == 8 ? 5 : 2;    // the sync point sits before this column tile of every step
+    int q = 0, slot = 0;                        // global step, its ring slot (q % 3)
+    bool flies = false;                         // a stage copy was issued in the previous step (it may still fly at this step's sync)
+#pragma unroll 1
+    for (int P0 = 0; q < Q; P0 += 4) {          // period: stages P0 .. P0 + 3
+#pragma unroll 1
+        for (int p = 0; p < 25 && q < Q; ++p, ++q) {
+            const int nslot = slot == 2 ? 0 : slot + 1;
+            // stage requested at this step (after its sync point): period steps 0 / 7 / 13 / 19 -> stages P0 + 1 / + 2 / + 3 / + 4
+            const int want = p == 0 ? P0 + 1 : (p == 7 ? P0 + 2 : (p == 13 ? P0 + 3 : (p == 19 ? P0 + 4 : -1)));
+            const bool issue = want >= 0 && want <= J.S8;   // (== S8: zero fill of the buffer a partial last step still reads)
+            const int np = p == 24 ? 0 : p + 1;
+            const int n_off = a_off(np);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt == SYNC_NT) {
+                    // ---- sync point S_q: chunk q + 1 has landed (the stage requested one step ago may still fly) ----
+                    if (flies) C2_WAIT_VM(4); else C2_WAIT_VM(0);
+                    c2_barrier();
+                }
+                if (nt < NT - 1) load_B(slot, nt + 1);
+                else load_B(nslot, 0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x4 c = acc[m][nt];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[nt & 1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[nt & 1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[nt & 1], c, 0, 0, 0);
+                    acc[m][nt] = c;
+                    if (nt == NT - 1) load_A1(n_off, m);   // the step's last tile frees row m: the next step's fragments
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (nt == SYNC_NT) { if (q + 2 < Q) issue_W(q + 2, slot == 0 ? 2 : slot - 1); }
+                if (nt == SYNC_NT + 1 && issue) issue_A(want, want & 1);
+            }
+            flies = issue;
+            slot = nslot;
+        }
+    }
+    C2_WAIT_VM(0);
+    // ---- epilogue: ConvQEpi (fp32 destination, optional accumulate), the wave's four tile rows ----
+    ConvQEpi epi{};
+    epi.a.Co = J.Co; epi.a.split = J.Co; epi.a.gpt = NT / 2; epi.a.phases = 0; epi.a.accumulate = J.accumulate;
+    epi.a.oys = 1; epi.a.oxs = 1; epi.a.oyo = 0; epi.a.oxo = 0; epi.a.Hmem = P.H; epi.a.Wmem = P.W;
+    epi.a.out0 = J.out; epi.a.bstride0 = J.out_bstride; epi.a.ld0 = J.ld;
+    int ngr = (J.Co + 31) / 32 - n_tile * (NT / 2);
+    if (ngr > NT / 2) ngr = NT / 2;
+    if constexpr (NT == 8) {
+        epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+    } else {
+        f32x4 acc8[4][8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) acc8[m][nt] = nt < 4 ? acc[m][nt] : f32x4{0.f, 0.f, 0.f, 0.f};
+        epi.finish16(acc8, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+    }
+}
+
+// weight pack of one job: [n_tile][step q][(half)][part][k group][column][8 bf16]; element (column oc, source channel c, tap t) =
+// w[(w_row(c)) * s_row + (w_col0 + oc) * s_col + tap'] with tap' = 24 - t for a data gradient (flip)
+struct C5PackArgs {
+    const float* w; long long s_row, s_col; int w_col0, flip, NT;
+    int nrange, r_n[3], r_w0[3];   // weight rows of the job's K ranges (in stage order)
+    int S8, Q, Co, n_tiles;
+};
+__global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
+    const int wch2 = pk.NT * 1024;   // bf16 elements of a chunk
+    const long long total = (long long)pk.n_tiles * pk.Q * wch2;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e & 7);
+        long long r = e >> 3;
+        int n = (int)(r & 63); r >>= 6;
+        const int kg = (int)(r & 3); r >>= 2;
+        const int part = (int)(r & 1); r >>= 1;
+        if (pk.NT == 8) { n += (int)(r & 1) * 64; r >>= 1; }
+        const int q = (int)(r % pk.Q);
+        const int n_tile = (int)(r / pk.Q);
+        const int p = q % 25, sl = 4 * p + kg;
+        const int j = sl / 25, t = sl - 25 * j;
+        const int s8 = 4 * (q / 25) + j;
+        const int oc = n_tile * (pk.NT * 16) + n;
+        float v = 0.0f;
+        if (s8 < pk.S8 && oc < pk.Co) {
+            int c = 8 * s8 + i, row;
+            if (c < pk.r_n[0]) row = pk.r_w0[0] + c;
+            else { c -= pk.r_n[0]; if (c < pk.r_n[1]) row = pk.r_w0[1] + c; else row = pk.r_w0[2] + (c - pk.r_n[1]); }
+            v = pk.w[(long long)row * pk.s_row + (long long)(pk.w_col0 + oc) * pk.s_col + (pk.flip ? 24 - t : t)];
+        }
+        unsigned hi, lo;
+        c2_split(v, hi, lo);
+        reinterpret_cast<unsigned short*>(dst)[e] = (unsigned short)(part ? lo : hi);
+    }
+}
+
+size_t c5_wpk_bytes(int K, int Co, int NT) {
+    const int S8 = K / 8, Q = (25 * S8 + 3) / 4, n_tiles = (Co + NT * 16 - 1) / (NT * 16);
+    return (size_t)n_tiles * Q * NT * 2048;
+}
+
+// fills the job's derived fields (S8, Q, n_tiles) and packs its weights into job.wpk unless `packed`
+int c5_prepare_job(C5Job& j, int NT, const float* w, long long s_row, long long s_col, int w_col0, int flip, const int* r_w0, bool packed,
+                   hipStream_t s) {
+    int K = 0;
+    for (int i = 0; i < 3; ++i) { if (i >= j.nrange) { j.r_n[i] = 0; j.r_c0[i] = 0; } K += j.r_n[i]; if ((j.r_n[i] | j.r_c0[i]) & 7) { set_error("c5: channel ranges in 8s"); return VPX_ERR_ARG; } }
+    j.S8 = K / 8; j.Q = (25 * j.S8 + 3) / 4; j.n_tiles = (j.Co + NT * 16 - 1) / (NT * 16);
+    if (!packed) {
+        C5PackArgs pk{};
+        pk.w = w; pk.s_row = s_row; pk.s_col = s_col; pk.w_col0 = w_col0; pk.flip = flip; pk.NT = NT;
+        pk.nrange = j.nrange;
+        for (int i = 0; i < 3; ++i) { pk.r_n[i] = j.r_n[i]; pk.r_w0[i] = r_w0[i]; }
+        pk.S8 = j.S8; pk.Q = j.Q; pk.Co = j.Co; pk.n_tiles = j.n_tiles;
+        const long long total = (long long)j.n_tiles * j.Q * NT * 1024;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(c5_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, const_cast<char*>(j.wpk));
+        VPX_CHECK_HIP(hipGetLastError());
+    }
+    return VPX_OK;
+}
+
+hipError_t launch_c5(const C5Plan& P_in, int NT, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&c5_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, C5Geom<8>::LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&c5_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, C5Geom<4>::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    C5Plan P = P_in;
+    P.tiles_x = (P.W + 15) / 16; P.tiles_y = (P.H + 15) / 16; P.m_tiles = P.B * P.tiles_x * P.tiles_y;
+    const int Mx = (P.m_tiles + 7) / 8;
+    long long per_xcd = 0;
+    for (int j = 0; j < P.njobs; ++j) per_xcd += (long long)Mx * P.job[j].n_tiles;
+    if (per_xcd < 1) return hipSuccess;
+    if (NT == 8) hipLaunchKernelGGL(c5_kernel<8>, dim3((unsigned)(per_xcd * 8)), dim3(256), C5Geom<8>::LDS, s, P);
+    else hipLaunchKernelGGL(c5_kernel<4>, dim3((unsigned)(per_xcd * 8)), dim3(256), C5Geom<4>::LDS, s, P);
+    return hipGetLastError();
+}
+
 }  // namespace vpx

@@ -22,7 +22,10 @@ struct STBwdLayout {
     size_t slab_floats;
     // stw (wgrad2.hip): the four k x k weight gradients in one launch on split operands — 5x5, bf16x3, channels in 8s
     bool stw; int stw_pairs, stw_ns;
+    // c5 (convq.hip): the k x k data gradients on 16x16-pixel tiles over the split-format dG8, two launches (conv_o's adjoint; dx | dh | dm)
+    bool c5; size_t c5_wpk[5];   // bytes of the packs: conv_o -> c, conv_o -> m, dx, dh, dm
 };
+constexpr int C5_NT = 4;   // 64-column N tiles: 6 jobs x 128 pixel tiles of unequal K balance over the chip (see convq.hip)
 
 // VPX_OPT_EXPERIMENT bit 6 keeps the first-generation weight-gradient launches (A/B runs, tests)
 bool stw_applicable(const vpx_stlstm_desc* d) {
@@ -74,6 +77,12 @@ int st_bwd_layout(const vpx_stlstm_desc* d, STBwdLayout& L) {
             if (need > L.slab_floats) L.slab_floats = need;
         }
     }
+    // VPX_OPT_EXPERIMENT bit 7 keeps the first-generation data-gradient launches (A/B runs, tests)
+    L.c5 = L.stw && !(g_experiment & 128);
+    if (L.c5) {
+        const int K[5] = {Ch, Ch, 7 * Ch, 4 * Ch, 3 * Ch}, Co[5] = {Ch, Ch, Cin, Ch, Ch};
+        for (int i = 0; i < 5; ++i) L.c5_wpk[i] = align256(c5_wpk_bytes(K[i], Co[i], C5_NT));
+    }
     return VPX_OK;
 }
 
@@ -87,6 +96,7 @@ size_t stlstm_bwd_workspace_bytes(const vpx_stlstm_desc* d) {
     b += align256(L.o.wpk * 4) + align256(L.l.wpk * 4) + align256(L.x.wpk * 4) + align256(L.h.wpk * 4) + align256(L.m.wpk * 4);
     b += align256(L.slab_floats * 4);
     if (L.stw) b += align256(L.n_x * 4) + 4 * align256(L.n_state * 4);   // split copies: x, h, m, c_new, m_new
+    if (L.c5) for (int i = 0; i < 5; ++i) b += L.c5_wpk[i];
     if (d->layout == VPX_LAYOUT_NCHW) b += 2 * align256(L.n_x * 4) + 14 * align256(L.n_state * 4);
     return b;
 }
@@ -202,6 +212,8 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         x_sp = (char*)ws.take(L.n_x);
         for (auto& q : st_sp) q = (char*)ws.take(L.n_state);
     }
+    char* c5w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (L.c5) for (int i = 0; i < 5; ++i) c5w[i] = (char*)ws.take(L.c5_wpk[i] / 4);
 
     const float *xn = x, *hn = h, *cn = c, *mn = m, *cnn = c_new, *mnn = m_new;
     const float *g_h = dh_new, *g_c = dc_new, *g_m = dm_new, *g_dc = ddelta_c, *g_dm = ddelta_m;
@@ -266,19 +278,41 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         VPX_CHECK_HIP(launch_st_bwd_out(a, stream));
     }
     // ---- B: grads of mem = [c_new | m_new] through conv_o (k x k) and conv_last (1 x 1) ----
+    const bool c5 = L.c5 && stw;
+    C5Plan cp{};
+    cp.B = B; cp.H = H; cp.W = Wd; cp.src = reinterpret_cast<const char*>(dG7);
+    cp.src_bstride = (long long)HW * ldG * 4; cp.src_prow = ldG * 4;
+    auto c5_job = [&](int slot, int Co_, float* out, int ld_out, int acc, const float* w, long long s_row, int w_col0, int nrange,
+                      const int (*rng)[3]) -> int {   // rng[i] = {source channel 0, channels, weight row 0}
+        C5Job& j = cp.job[cp.njobs++];
+        j = C5Job{};
+        j.nrange = nrange;
+        int rw0[3] = {0, 0, 0};
+        for (int i = 0; i < nrange; ++i) { j.r_c0[i] = rng[i][0]; j.r_n[i] = rng[i][1]; rw0[i] = rng[i][2]; }
+        j.Co = Co_; j.ld = ld_out; j.accumulate = acc; j.wpk = c5w[slot]; j.out = out; j.out_bstride = (long long)HW * ld_out;
+        return c5_prepare_job(j, C5_NT, w, s_row, L.taps, w_col0, 1, rw0, packed, stream);
+    };
+    if (c5) {
+        const int ro[1][3] = {{3 * Ch, Ch, 0}};
+        if ((rc = c5_job(0, Ch, dcn_conv, Ch, 0, Wo, (long long)2 * Ch * L.taps, 0, 1, ro))) return rc;
+        if ((rc = c5_job(1, Ch, dmn_conv, Ch, 0, Wo, (long long)2 * Ch * L.taps, Ch, 1, ro))) return rc;
+        VPX_CHECK_HIP(launch_c5(cp, C5_NT, stream));
+    }
     {
         PackDesc pd{};
         pd.seg[0] = PackSeg{Wo, (long long)2 * Ch * L.taps, L.taps, 0, Ch};
         pack_plain_T(pd, L.o, L.taps, 2 * Ch);
-        if (!packed) VPX_CHECK_HIP(launch_pack_weights(pd, wpk_o, stream));
+        if (!packed && !c5) VPX_CHECK_HIP(launch_pack_weights(pd, wpk_o, stream));
         ConvPlan P = plan_for(L.o, k, wpk_o);
         P.nseg = 1; P.seg[0] = ConvSeg{dG7 + 3 * Ch, (long long)(HW * ldG), Ch, ldG, g7s};
         PlainEpiArgs ea{};
         ea.Co = 2 * Ch; ea.split = Ch; ea.ng = L.o.ng;
         ea.out0 = dcn_conv; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch;
         ea.out1 = dmn_conv; ea.bstride1 = (long long)(HW * Ch); ea.ld1 = Ch;
-        VPX_CHECK_HIP(split_plan(P, L.o, dcn_conv, dmn_conv, L.n_state, false));
-        VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.o.tiles, stream));
+        if (!c5) {
+            VPX_CHECK_HIP(split_plan(P, L.o, dcn_conv, dmn_conv, L.n_state, false));
+            VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.o.tiles, stream));
+        }
 
         PackDesc pl{};
         pl.seg[0] = PackSeg{Wlast, (long long)2 * Ch, 1, 0, Ch};
@@ -301,7 +335,23 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         VPX_CHECK_HIP(launch_st_bwd_gates(a, stream));
     }
     // ---- D: data gradients ----
-    if (dxn) {
+    if (c5) {   // dx | dh | dm as the jobs of ONE launch, longest K first
+        cp.njobs = 0;
+        if (dxn) {
+            const int rx[3][3] = {{0, 3 * Ch, 0}, {3 * Ch, Ch, 6 * Ch}, {4 * Ch, 3 * Ch, 3 * Ch}};   // dG8 blocks (i,f,g | o | i',f',g') <-> Wx row blocks 0-2 | 6 | 3-5
+            if ((rc = c5_job(2, Cin, dxn, Cin, 0, Wx, (long long)Cin * L.taps, 0, 3, rx))) return rc;
+        }
+        if (dhn) {
+            const int rh[1][3] = {{0, 4 * Ch, 0}};
+            if ((rc = c5_job(3, Ch, dhn, Ch, 0, Wh, (long long)Ch * L.taps, 0, 1, rh))) return rc;
+        }
+        if (dm) {
+            const int rm[1][3] = {{4 * Ch, 3 * Ch, 0}};
+            if ((rc = c5_job(4, Ch, dmn, Ch, 1, Wm, (long long)Ch * L.taps, 0, 1, rm))) return rc;   // onto dm_new_total * f' written by stage C
+        }
+        if (cp.njobs) VPX_CHECK_HIP(launch_c5(cp, C5_NT, stream));
+    }
+    if (!c5 && dxn) {
         PackDesc pd{};
         const long long ldo = (long long)Cin * L.taps;
         pd.seg[0] = PackSeg{Wx, ldo, L.taps, 0, 3 * Ch};        // dG7 blocks (i,f,g)     <-> Wx row blocks 0,1,2
@@ -319,7 +369,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         VPX_CHECK_HIP(split_plan(P, L.x, dxn, nullptr, L.n_x, false));
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.x.tiles, stream));
     }
-    if (dhn) {
+    if (!c5 && dhn) {
         PackDesc pd{};
         pd.seg[0] = PackSeg{Wh, (long long)Ch * L.taps, L.taps, 0, 4 * Ch};
         pack_plain_T(pd, L.h, L.taps, Ch);
@@ -331,7 +381,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         VPX_CHECK_HIP(split_plan(P, L.h, dhn, nullptr, L.n_state, false));
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.h.tiles, stream));
     }
-    if (dm) {
+    if (!c5 && dm) {
         PackDesc pd{};
         pd.seg[0] = PackSeg{Wm, (long long)Ch * L.taps, L.taps, 0, 3 * Ch};
         pack_plain_T(pd, L.m, L.taps, Ch);

@@ -167,7 +167,7 @@ int stlstm_ln_bwd(const vpx_stlstm_desc* d, const float* x, const float* h, cons
 
     // A: through h_new = o * tanh(lc): d(o pre-activation) -> dG7 block 3, d conv_last
     {
-        STBwdOutArgs a{(long long)s.n_state, Ch, ldG, 3 * Ch, dh_new, R.o, R.tl, dG7, dlc};
+        STBwdOutArgs a{(long long)s.n_state, Ch, ldG, 3 * Ch, -1, dh_new, R.o, R.tl, dG7, dlc, 0};
         VPX_CHECK_HIP(launch_st_bwd_out(a, stream));
     }
     // B: LayerNorm of conv_o backward (dy = dG7 block 3), then grads of mem through conv_o and conv_last

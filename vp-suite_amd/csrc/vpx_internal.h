@@ -420,6 +420,24 @@ static inline int wgrad2_slices(int target, int rows128, int n_ctiles, bool half
 hipError_t launch_wgrad2(const WgradArgs& a, int max_slices, int* used_slices, int* tail_col0, int* tail_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce_tail(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int tail_col0, int tail_slices,
                                     hipStream_t s);
+// convq.hip, c5: 5x5 'same' convolutions on 16x16-pixel tiles over ONE split-format source, a table of jobs per launch
+constexpr int C5_MAX_JOBS = 6;
+struct C5Job {
+    int nrange, r_c0[3], r_n[3];   // the job's K: source channel ranges [r_c0, r_c0 + r_n), multiples of 8, in stage order
+    int S8, Q, n_tiles;            // derived (c5_prepare_job): 8-channel stages, K = 32 steps, N tiles
+    int Co, ld, accumulate;        // output channels, destination pixel pitch (floats), += instead of =
+    const char* wpk;               // packed weights [n_tile][Q][chunk]
+    float* out; long long out_bstride;
+};
+struct C5Plan {
+    int B, H, W, tiles_x, tiles_y, m_tiles;
+    const char* src; long long src_bstride; int src_prow;   // split-format source [B][H][W][C]: bytes per image / per pixel
+    int njobs; C5Job job[C5_MAX_JOBS];
+};
+size_t c5_wpk_bytes(int K, int Co, int NT);
+int c5_prepare_job(C5Job& j, int NT, const float* w, long long s_row, long long s_col, int w_col0, int flip, const int* r_w0, bool packed,
+                   hipStream_t s);
+hipError_t launch_c5(const C5Plan& P, int NT, hipStream_t s);   // NT = 8: 128-column N tiles, 4: 64-column
 // wgrad2.hip, stw: the four 5x5 weight gradients of one ST-LSTM cell step in one launch (operands in split format)
 constexpr int STW_MAX_PAIRS = 48;
 struct STWSrc { const char* sp; int C; };          // split tensor [B][HW][C]
