@@ -157,7 +157,9 @@ def test_stlstm_second_generation_backward_matches_first_generation(vpx, B, Cin,
         passes, K split of tap row 4 / of the centre tap, half-empty column tiles, ragged maps and row tiles) — VPX_OPT_EXPERIMENT
         bit 6 switches it (and everything built on its split dG8) off;
       * c5 (convq.hip): the 5x5 data gradients (conv_o's adjoint; dx | dh | dm as the jobs of one launch) on 16x16-pixel tiles with
-        8-channel stages — bit 7 switches it off alone."""
+        8-channel stages — bit 7 switches it off alone;
+      * c5 forward (channels in 32s): both gate groups as the jobs of one launch (gate-interleaved N tiles, fused gate math, c_new /
+        m_new also written in the split format), conv_o + output gate as another — bit 8 switches it off."""
     from golden_util import seeded_randn
     k = 5
     tag = f"stw.{B}.{Cin}.{Ch}.{H}.{W}"
@@ -172,16 +174,16 @@ def test_stlstm_second_generation_backward_matches_first_generation(vpx, B, Cin,
         w = [Ws[n].clone().requires_grad_(True) for n in shapes]
         outs = vpx.ops.stlstm_step(*a, *w, precision="bf16x3")
         sum((o * g).sum() for o, g in zip(outs, gout)).backward()
-        return [t.grad for t in a + w]
+        return [o.detach() for o in outs] + [t.grad for t in a + w]
     L = vpx._lib.lib()
-    labels = list(names) + list(shapes)
+    labels = ["h_new", "c_new", "m_new", "delta_c", "delta_m"] + list(names) + list(shapes)
     # deterministic mode for every run: the first generation's K-split data gradients otherwise add their partial sums with
     # atomics, and two runs then see dG differing in the last bits (the comparisons below would be flaky at their 5e-6 bar)
     torch.use_deterministic_algorithms(True)
     try:
         new = run()
         res = {}
-        for bits in (64, 128):
+        for bits in (64, 128, 256, 64 + 256):
             prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, bits)
             try:
                 res[bits] = run()

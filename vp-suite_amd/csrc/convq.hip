@@ -788,12 +788,113 @@ template <int NT> struct C5Geom {
     static constexpr int LDS = 2 * C5_ABUF + (3 * WCH > 32768 ? 3 * WCH : 32768);   // >= 64 KiB: 4 waves x 16 KiB in the epilogue
 };
 
-__device__ __forceinline__ int c5_chan_of_stage(const C5Job& j, int s8) {   // first source channel of the job's stage s8
+__device__ __forceinline__ void c5_chan_of_stage(const C5Job& j, int s8, int& src, int& chan) {   // source and first channel of the job's stage s8
     int c = 8 * s8;
-    if (c < j.r_n[0]) return j.r_c0[0] + c;
+    if (c < j.r_n[0]) { src = j.r_src[0]; chan = j.r_c0[0] + c; return; }
     c -= j.r_n[0];
-    if (c < j.r_n[1]) return j.r_c0[1] + c;
-    return j.r_c0[2] + (c - j.r_n[1]);
+    if (c < j.r_n[1]) { src = j.r_src[1]; chan = j.r_c0[1] + c; return; }
+    src = j.r_src[2]; chan = j.r_c0[2] + (c - j.r_n[1]);
+}
+
+// ---- ST-LSTM forward epilogues on the c5 tile: the wave's 4 tile rows x (NG gates x 32 channels) go through its private 16 KiB of
+//      LDS so that a lane owns four channels of a pixel for every gate (16-byte global accesses) ----
+__device__ __forceinline__ void c5_store_split4(char* sp, size_t pix, int Ch, int c, const f32x4& v) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c2_split(v[q], h[q], l[q]);
+    char* dst = sp + pix * ((size_t)Ch * 4u) + (unsigned)((c >> 3) * 32 + (c & 7) * 2);
+    *reinterpret_cast<uint2*>(dst) = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+    *reinterpret_cast<uint2*>(dst + 16) = uint2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+}
+
+// gates (predrnn.py:61-77): groups (i, f, g[, o_pre]) of 32 channels -> s_new = f * s_in + i * g, delta = i * g
+__device__ __forceinline__ void c5_finish_gates(const f32x4 (&acc)[4][8], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
+                                                const C5Job& J, int H, int W) {
+    c2_barrier();
+    float* ldsf = reinterpret_cast<float*>(smem + wave * 16384);
+    const int c16 = lane & 15, q4 = lane >> 4, cg = lane & 7, p4 = lane >> 3;
+    const int ch = n_tile * 32 + cg * 4, Ch = J.Ch, ng = J.ng;
+#pragma unroll
+    for (int mp = 0; mp < 2; ++mp) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+                if ((nt >> 1) < ng)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ldsf[(nt >> 1) * 1024 + (mm * 16 + 4 * q4 + r) * 32 + (nt & 1) * 16 + c16] = acc[2 * mp + mm][nt][r];
+        if (ch < Ch) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ip = k * 8 + p4;
+                const int y = y0 + 4 * wave + 2 * mp + (ip >> 4), x = x0 + (ip & 15);
+                if (y >= H || x >= W) continue;
+                const size_t pix = ((size_t)b * H + y) * W + x, sidx = pix * Ch + ch;
+                const f32x4 vi = *reinterpret_cast<const f32x4*>(ldsf + ip * 32 + cg * 4);
+                const f32x4 vf = *reinterpret_cast<const f32x4*>(ldsf + 1024 + ip * 32 + cg * 4);
+                const f32x4 vg = *reinterpret_cast<const f32x4*>(ldsf + 2048 + ip * 32 + cg * 4);
+                const f32x4 sin = *reinterpret_cast<const f32x4*>(J.e_in0 + sidx);
+                f32x4 gi, gf, gg, dl, sn;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    gi[q] = sigmoid_f(vi[q]); gf[q] = sigmoid_f(vf[q] + J.fbias); gg[q] = tanh_f(vg[q]);
+                    dl[q] = gi[q] * gg[q];
+                    sn[q] = gf[q] * sin[q] + dl[q];
+                }
+                *reinterpret_cast<f32x4*>(J.e_out[0] + sidx) = sn;
+                *reinterpret_cast<f32x4*>(J.e_out[1] + sidx) = dl;
+                if (ng == 4) *reinterpret_cast<f32x4*>(J.e_out[2] + sidx) = *reinterpret_cast<const f32x4*>(ldsf + 3072 + ip * 32 + cg * 4);
+                if (J.e_out[3]) {
+                    float* gs = J.e_out[3] + pix * 3 * Ch + ch;
+                    *reinterpret_cast<f32x4*>(gs) = gi;
+                    *reinterpret_cast<f32x4*>(gs + Ch) = gf;
+                    *reinterpret_cast<f32x4*>(gs + 2 * Ch) = gg;
+                }
+                if (J.e_sp) c5_store_split4(J.e_sp, pix, Ch, ch, sn);
+            }
+        }
+    }
+}
+
+// output gate (predrnn.py:80-81): acc = conv_o(mem) -> h_new = sigmoid(o_pre + acc) * tanh(conv_last(mem)); 64-column tiles (groups 0, 1)
+__device__ __forceinline__ void c5_finish_out(const f32x4 (&acc)[4][8], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
+                                              int gpt, const C5Job& J, int H, int W) {
+    c2_barrier();
+    float* ldsf = reinterpret_cast<float*>(smem + wave * 16384);
+    const int c16 = lane & 15, q4 = lane >> 4, cg = lane & 7, p4 = lane >> 3;
+    const int Ch = J.Ch;
+#pragma unroll
+    for (int mp = 0; mp < 2; ++mp) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+                if ((nt >> 1) < gpt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ldsf[(nt >> 1) * 1024 + (mm * 16 + 4 * q4 + r) * 32 + (nt & 1) * 16 + c16] = acc[2 * mp + mm][nt][r];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = (n_tile * gpt + g) * 32 + cg * 4;
+            if (g >= gpt || ch >= Ch) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ip = k * 8 + p4;
+                const int y = y0 + 4 * wave + 2 * mp + (ip >> 4), x = x0 + (ip & 15);
+                if (y >= H || x >= W) continue;
+                const size_t pix = ((size_t)b * H + y) * W + x, sidx = pix * Ch + ch;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ldsf + g * 1024 + ip * 32 + cg * 4);
+                const f32x4 op = *reinterpret_cast<const f32x4*>(J.e_in0 + sidx), lc = *reinterpret_cast<const f32x4*>(J.e_in1 + sidx);
+                f32x4 o, tl, hn;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { o[q] = sigmoid_f(op[q] + v[q]); tl[q] = tanh_f(lc[q]); hn[q] = o[q] * tl[q]; }
+                *reinterpret_cast<f32x4*>(J.e_out[0] + sidx) = hn;
+                if (J.e_out[1]) { *reinterpret_cast<f32x4*>(J.e_out[1] + sidx) = o; *reinterpret_cast<f32x4*>(J.e_out[2] + sidx) = tl; }
+                if (J.e_sp) c5_store_split4(J.e_sp, pix, Ch, ch, hn);
+            }
+        }
+    }
 }
 
 template <int NT>
@@ -841,10 +942,16 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
         const int gy = y0 - 2 + hy, gx = x0 - 2 + hx;
         pixoff[u] = (pos < 400 && (unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W) ? gy * P.W + gx : -1;
     }
-    const char* const srcb = P.src + (size_t)b * P.src_bstride;
-    const unsigned prow = (unsigned)P.src_prow;
     auto issue_A = [&](int s8, int buf) {   // stages past the job's K are filled with zeros (their weights are zeros too)
-        const char* base = s8 < J.S8 ? srcb + (size_t)c5_chan_of_stage(J, s8) * 4 : nullptr;
+        const char* base = nullptr;
+        unsigned prow = 0;
+        if (s8 < J.S8) {
+            int si, chan;
+            c5_chan_of_stage(J, s8, si, chan);
+            const C5Src sc = si == 0 ? P.src[0] : (si == 1 ? P.src[1] : (si == 2 ? P.src[2] : P.src[3]));
+            base = sc.p + (size_t)b * sc.bstride + (size_t)chan * 4;
+            prow = (unsigned)sc.prow;
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const char* src = (base != nullptr && pixoff[u] >= 0) ? base + (size_t)((unsigned)pixoff[u] * (unsigned long long)prow) + (u >> 1) * 16
@@ -890,6 +997,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     };
 
     const int Q = J.Q;
+    const int nt_active = J.nt_active;
     if (Q > 0) {
         issue_A(0, 0);
         issue_W(0, 0);
@@ -924,13 +1032,16 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
                 if (nt < NT - 1) load_B(slot, nt + 1);
                 else load_B(nslot, 0);
                 __builtin_amdgcn_s_setprio(1);
+                const bool go = nt < nt_active;   // (a job whose N tile holds fewer column tiles skips the MFMAs of the empty ones)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    f32x4 c = acc[m][nt];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[nt & 1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[nt & 1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[nt & 1], c, 0, 0, 0);
-                    acc[m][nt] = c;
+                    if (go) {
+                        f32x4 c = acc[m][nt];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[nt & 1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[nt & 1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[nt & 1], c, 0, 0, 0);
+                        acc[m][nt] = c;
+                    }
                     if (nt == NT - 1) load_A1(n_off, m);   // the step's last tile frees row m: the next step's fragments
                 }
                 __builtin_amdgcn_s_setprio(0);
@@ -950,23 +1061,28 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     int ngr = (J.Co + 31) / 32 - n_tile * (NT / 2);
     if (ngr > NT / 2) ngr = NT / 2;
     if constexpr (NT == 8) {
-        epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+        if (J.epi == 1) c5_finish_gates(acc, smem, wave, lane, b, y0, x0, n_tile, J, P.H, P.W);
+        else if (J.epi == 2) c5_finish_out(acc, smem, wave, lane, b, y0, x0, n_tile, 4, J, P.H, P.W);
+        else epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
     } else {
         f32x4 acc8[4][8];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) acc8[m][nt] = nt < 4 ? acc[m][nt] : f32x4{0.f, 0.f, 0.f, 0.f};
-        epi.finish16(acc8, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+        if (J.epi == 2) c5_finish_out(acc8, smem, wave, lane, b, y0, x0, n_tile, 2, J, P.H, P.W);
+        else epi.finish16(acc8, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
     }
 }
 
-// weight pack of one job: [n_tile][step q][(half)][part][k group][column][8 bf16]; element (column oc, source channel c, tap t) =
-// w[(w_row(c)) * s_row + (w_col0 + oc) * s_col + tap'] with tap' = 24 - t for a data gradient (flip)
+// weight pack of one job: [n_tile][step q][(half)][part][k group][column][8 bf16]. Element (column oc, source channel c of range r,
+// tap t) = w_r[ocidx * s_oc_r + (c0_r + c) * s_c_r + tap'] with tap' = 24 - t for a data gradient (flip) and ocidx = col0_r + oc, or —
+// gate-interleaved N tiles (forward): column n of N tile nt is gate n / 32, channel nt * 32 + n % 32: ocidx = gate0_r[n / 32] + that.
 struct C5PackArgs {
-    const float* w; long long s_row, s_col; int w_col0, flip, NT;
-    int nrange, r_n[3], r_w0[3];   // weight rows of the job's K ranges (in stage order)
-    int S8, Q, Co, n_tiles;
+    C5PackRange rg[3];
+    int nrange, r_n[3];
+    int flip, NT, gates;       // gates: number of gate groups of an N tile (0 = plain column order)
+    int S8, Q, Co, n_tiles;    // Co: plain: output channels; gates: channels per gate (Ch)
 };
 __global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
     const int wch2 = pk.NT * 1024;   // bf16 elements of a chunk
@@ -983,13 +1099,20 @@ __global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
         const int p = q % 25, sl = 4 * p + kg;
         const int j = sl / 25, t = sl - 25 * j;
         const int s8 = 4 * (q / 25) + j;
-        const int oc = n_tile * (pk.NT * 16) + n;
         float v = 0.0f;
-        if (s8 < pk.S8 && oc < pk.Co) {
-            int c = 8 * s8 + i, row;
-            if (c < pk.r_n[0]) row = pk.r_w0[0] + c;
-            else { c -= pk.r_n[0]; if (c < pk.r_n[1]) row = pk.r_w0[1] + c; else row = pk.r_w0[2] + (c - pk.r_n[1]); }
-            v = pk.w[(long long)row * pk.s_row + (long long)(pk.w_col0 + oc) * pk.s_col + (pk.flip ? 24 - t : t)];
+        if (s8 < pk.S8) {
+            int c = 8 * s8 + i, ri = 0;
+            if (c >= pk.r_n[0]) { c -= pk.r_n[0]; ri = 1; if (c >= pk.r_n[1]) { c -= pk.r_n[1]; ri = 2; } }
+            const C5PackRange rg = pk.rg[ri];
+            long long ocidx = -1;
+            if (pk.gates) {
+                const int g = n >> 5, chn = n_tile * 32 + (n & 31);
+                if (g < pk.gates && chn < pk.Co) ocidx = rg.gate0[g] + chn;
+            } else {
+                const int oc = n_tile * (pk.NT * 16) + n;
+                if (oc < pk.Co) ocidx = rg.gate0[0] + oc;
+            }
+            if (ocidx >= 0) v = rg.w[ocidx * rg.s_oc + (long long)(rg.c0 + c) * rg.s_c + (pk.flip ? 24 - t : t)];
         }
         unsigned hi, lo;
         c2_split(v, hi, lo);
@@ -997,22 +1120,28 @@ __global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
     }
 }
 
-size_t c5_wpk_bytes(int K, int Co, int NT) {
-    const int S8 = K / 8, Q = (25 * S8 + 3) / 4, n_tiles = (Co + NT * 16 - 1) / (NT * 16);
+size_t c5_wpk_bytes(int K, int Co, int NT, int gates) {
+    const int S8 = K / 8, Q = (25 * S8 + 3) / 4, n_tiles = gates ? (Co + 31) / 32 : (Co + NT * 16 - 1) / (NT * 16);
     return (size_t)n_tiles * Q * NT * 2048;
 }
 
-// fills the job's derived fields (S8, Q, n_tiles) and packs its weights into job.wpk unless `packed`
-int c5_prepare_job(C5Job& j, int NT, const float* w, long long s_row, long long s_col, int w_col0, int flip, const int* r_w0, bool packed,
-                   hipStream_t s) {
+// fills the job's derived fields (S8, Q, n_tiles, nt_active) and packs its weights into job.wpk unless `packed`.
+// gates = 0: plain column order, Co output channels; gates = 3 | 4: gate-interleaved N tiles of 32 channels (NT = 8), Co = channels per gate
+int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s) {
     int K = 0;
-    for (int i = 0; i < 3; ++i) { if (i >= j.nrange) { j.r_n[i] = 0; j.r_c0[i] = 0; } K += j.r_n[i]; if ((j.r_n[i] | j.r_c0[i]) & 7) { set_error("c5: channel ranges in 8s"); return VPX_ERR_ARG; } }
-    j.S8 = K / 8; j.Q = (25 * j.S8 + 3) / 4; j.n_tiles = (j.Co + NT * 16 - 1) / (NT * 16);
+    for (int i = 0; i < 3; ++i) {
+        if (i >= j.nrange) { j.r_n[i] = 0; j.r_c0[i] = 0; j.r_src[i] = 0; }
+        K += j.r_n[i];
+        if ((j.r_n[i] | j.r_c0[i]) & 7) { set_error("c5: channel ranges in 8s"); return VPX_ERR_ARG; }
+    }
+    if (gates && NT != 8) { set_error("c5: gate-interleaved tiles need NT = 8"); return VPX_ERR_ARG; }
+    j.S8 = K / 8; j.Q = (25 * j.S8 + 3) / 4;
+    j.n_tiles = gates ? (j.Co + 31) / 32 : (j.Co + NT * 16 - 1) / (NT * 16);
+    j.nt_active = gates ? 2 * gates : NT;
     if (!packed) {
         C5PackArgs pk{};
-        pk.w = w; pk.s_row = s_row; pk.s_col = s_col; pk.w_col0 = w_col0; pk.flip = flip; pk.NT = NT;
-        pk.nrange = j.nrange;
-        for (int i = 0; i < 3; ++i) { pk.r_n[i] = j.r_n[i]; pk.r_w0[i] = r_w0[i]; }
+        pk.nrange = j.nrange; pk.flip = flip; pk.NT = NT; pk.gates = gates;
+        for (int i = 0; i < 3; ++i) { pk.r_n[i] = j.r_n[i]; if (i < j.nrange) pk.rg[i] = rg[i]; }
         pk.S8 = j.S8; pk.Q = j.Q; pk.Co = j.Co; pk.n_tiles = j.n_tiles;
         const long long total = (long long)j.n_tiles * j.Q * NT * 1024;
         int blocks = (int)((total + 255) / 256);

@@ -23,7 +23,16 @@ struct STLayout {
     ConvStage stage_l[MAX_STAGE];
     size_t n_state, n_x;
     size_t wpk_c, wpk_m, wpk_o, wpk_l;  // float counts
+    // c5 (convq.hip, round 4): the two gate groups as the jobs of one launch, conv_o + output gate as another, on 16x16-pixel tiles
+    // over split-format operands; conv_last (1x1) stays on the first-generation kernel
+    bool c5; size_t c5_wc, c5_wm, c5_wo;   // bytes of its weight packs
 };
+constexpr int C5F_NT_O = 4;   // conv_o: 64-column N tiles (Ch = 128 -> 2 per pixel tile)
+
+// VPX_OPT_EXPERIMENT bit 8 keeps the first-generation forward launches (A/B runs, tests)
+bool c5_fwd_applicable(const vpx_stlstm_desc* d) {
+    return d->k == 5 && d->precision == VPX_PREC_BF16X3 && !(d->Ch & 31) && !(d->Cin & 7) && !d->layer_norm && !(g_experiment & 256);
+}
 
 int check_st_desc(const vpx_stlstm_desc* d) {
     if (!d) { set_error("stlstm desc is NULL"); return VPX_ERR_ARG; }
@@ -66,6 +75,12 @@ int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
     L.wpk_o = packed_weight_bytes(L.o_tiles, L.chunks_o, L.o_ng, d->precision) / 4;
     L.wpk_l = packed_weight_bytes(L.tiles128, L.chunks_l, L.ng_l, d->precision) / 4;
     L.ksplit_l = pick_ksplit(m_tiles * L.tiles128, L.nstage_l);
+    L.c5 = c5_fwd_applicable(d);
+    if (L.c5) {
+        L.c5_wc = align256(c5_wpk_bytes(d->Cin + d->Ch, d->Ch, 8, 4));
+        L.c5_wm = align256(c5_wpk_bytes(d->Cin + d->Ch, d->Ch, 8, 3));
+        L.c5_wo = align256(c5_wpk_bytes(2 * d->Ch, d->Ch, C5F_NT_O));
+    }
     return VPX_OK;
 }
 
@@ -97,6 +112,7 @@ size_t vpx_stlstm_workspace_bytes(const vpx_stlstm_desc* d) {
     if (d->layer_norm) return stlstm_ln_workspace_bytes(d);
     size_t b = align256(L.wpk_c * 4) + align256(L.wpk_m * 4) + align256(L.wpk_o * 4) + align256(L.wpk_l * 4);
     b += 2 * align256(L.n_state * 4);  // o_pre, lc
+    if (L.c5) b += L.c5_wc + L.c5_wm + L.c5_wo + align256(L.n_x * 4) + 4 * align256(L.n_state * 4);   // packs; x, h, m, c_new, m_new in split format
     if (d->layout == VPX_LAYOUT_NCHW) b += align256(L.n_x * 4) + 8 * align256(L.n_state * 4);
     size_t bwd = 0;
     if (d->flags & VPX_FLAG_SAVE_FOR_BWD) bwd = stlstm_bwd_workspace_bytes(d);
@@ -133,6 +149,12 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
     float* wpk_l = ws.take(L.wpk_l);
     float* o_pre = ws.take(L.n_state);
     float* lc = ws.take(L.n_state);
+    char *c5wc = nullptr, *c5wm = nullptr, *c5wo = nullptr, *x_sp = nullptr, *h_sp = nullptr, *m_sp = nullptr, *cn_sp = nullptr, *mn_sp = nullptr;
+    if (L.c5 && !d->layer_norm) {
+        c5wc = (char*)ws.take(L.c5_wc / 4); c5wm = (char*)ws.take(L.c5_wm / 4); c5wo = (char*)ws.take(L.c5_wo / 4);
+        x_sp = (char*)ws.take(L.n_x); h_sp = (char*)ws.take(L.n_state); m_sp = (char*)ws.take(L.n_state);
+        cn_sp = (char*)ws.take(L.n_state); mn_sp = (char*)ws.take(L.n_state);
+    }
 
     if (d->layer_norm) {  // unfused LayerNorm path (stlstm_ln_api.hip); same layout adaptation around it
         if (!ln) { set_error("vpx_stlstm_step_fwd: layer_norm set but ln is NULL"); return VPX_ERR_ARG; }
@@ -169,6 +191,56 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         hO = st[3]; cO = st[4]; mO = st[5]; dcO = st[6]; dmO = st[7];
     }
 
+    float *gates_c = nullptr, *gates_m = nullptr, *o_save = nullptr, *tl_save = nullptr;
+    if (save) {
+        char* r = (char*)reserve;
+        gates_c = (float*)r; r += align256(3 * L.n_state * 4);
+        gates_m = (float*)r; r += align256(3 * L.n_state * 4);
+        o_save = (float*)r; r += align256(L.n_state * 4);
+        tl_save = (float*)r;
+    }
+    const bool packed = (d->flags & VPX_FLAG_WEIGHTS_PACKED) != 0;
+    if (L.c5) {
+        // ---- round-4 path: operands in the split format, gate groups + conv_o on the 16x16-tile kernel (convq.hip, c5) ----
+        const long long npix = (long long)B * (long long)HW;
+        VPX_CHECK_HIP(launch_split_convert(xn, x_sp, npix, Cin, stream));
+        VPX_CHECK_HIP(launch_split_convert(hn, h_sp, npix, Ch, stream));
+        VPX_CHECK_HIP(launch_split_convert(mn, m_sp, npix, Ch, stream));
+        C5Plan cp{};
+        cp.B = B; cp.H = H; cp.W = Wd;
+        cp.src[0] = C5Src{x_sp, (long long)HW * Cin * 4, Cin * 4, 0};
+        cp.src[1] = C5Src{h_sp, (long long)HW * Ch * 4, Ch * 4, 0};
+        cp.src[2] = C5Src{m_sp, (long long)HW * Ch * 4, Ch * 4, 0};
+        const long long sx = (long long)Cin * L.taps, sh = (long long)Ch * L.taps;
+        for (int grp = 0; grp < 2; ++grp) {   // 0: c group (i,f,g,o_pre) from [x | h]; 1: m group (i',f',g') from [x | m]
+            C5Job& j = cp.job[cp.njobs++];
+            j = C5Job{};
+            j.nrange = 2;
+            j.r_src[0] = 0; j.r_c0[0] = 0; j.r_n[0] = Cin;
+            j.r_src[1] = grp ? 2 : 1; j.r_c0[1] = 0; j.r_n[1] = Ch;
+            j.epi = 1; j.Co = Ch; j.Ch = Ch; j.ng = grp ? 3 : 4; j.fbias = 1.0f;
+            j.wpk = grp ? c5wm : c5wc;
+            j.e_in0 = grp ? mn : cn;
+            j.e_out[0] = grp ? mO : cO; j.e_out[1] = grp ? dmO : dcO; j.e_out[2] = grp ? nullptr : o_pre; j.e_out[3] = grp ? gates_m : gates_c;
+            j.e_sp = grp ? mn_sp : cn_sp;
+            C5PackRange pr[2];
+            // x rows: (i,f,g,o) = blocks 0,1,2,6 of Wx, (i',f',g') = blocks 3,4,5 (predrnn.py:61); recurrent rows: blocks 0.. of Wh / Wm (:62-63)
+            if (grp == 0) pr[0] = C5PackRange{Wx, sx, (long long)L.taps, 0, {0, Ch, 2 * Ch, 6 * Ch}};
+            else pr[0] = C5PackRange{Wx, sx, (long long)L.taps, 0, {3 * Ch, 4 * Ch, 5 * Ch, 0}};
+            pr[1] = C5PackRange{grp ? Wm : Wh, sh, (long long)L.taps, 0, {0, Ch, 2 * Ch, 3 * Ch}};
+            if ((rc = c5_prepare_job(j, 8, pr, grp ? 3 : 4, 0, packed, stream))) return rc;
+        }
+        VPX_CHECK_HIP(launch_c5(cp, 8, stream));
+        if (!packed) {   // conv_last's first-generation pack
+            PackDesc pl{};
+            pl.seg[0] = PackSeg{Wlast, (long long)2 * Ch, 1, 0, Ch};
+            pl.seg[1] = PackSeg{Wlast, (long long)2 * Ch, 1, Ch, Ch};
+            memcpy(pl.stage, L.stage_l, sizeof(ConvStage) * L.nstage_l);
+            pl.nstage = L.nstage_l; pl.chunks_total = L.chunks_l; pl.prec = d->precision; pl.taps = 1;
+            fill_plain_pack(pl, Ch, 0, L.ng_l);
+            VPX_CHECK_HIP(launch_pack_weights(pl, wpk_l, stream));
+        }
+    } else
     // ---- weight repack (skipped when the caller vouches the workspace still holds it) ----
     if (!(d->flags & VPX_FLAG_WEIGHTS_PACKED)) {
         PackDesc pd{};
@@ -205,17 +277,9 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         VPX_CHECK_HIP(launch_pack_weights(pl, wpk_l, stream));
     }
 
-    float *gates_c = nullptr, *gates_m = nullptr, *o_save = nullptr, *tl_save = nullptr;
-    if (save) {
-        char* r = (char*)reserve;
-        gates_c = (float*)r; r += align256(3 * L.n_state * 4);
-        gates_m = (float*)r; r += align256(3 * L.n_state * 4);
-        o_save = (float*)r; r += align256(L.n_state * 4);
-        tl_save = (float*)r;
-    }
 
     // ---- launch 1: c group ----
-    {
+    if (!L.c5) {
         ConvPlan P = base_plan(d, k);
         set_plan_tiles(P, L.mw_g);
         P.nseg = 2;
@@ -246,7 +310,24 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.tiles128, stream));
     }
     // ---- launch 4: conv_o(mem) + output gate ----
-    {
+    if (L.c5) {
+        C5Plan cp{};
+        cp.B = B; cp.H = H; cp.W = Wd;
+        cp.src[0] = C5Src{cn_sp, (long long)HW * Ch * 4, Ch * 4, 0};
+        cp.src[1] = C5Src{mn_sp, (long long)HW * Ch * 4, Ch * 4, 0};
+        C5Job& j = cp.job[cp.njobs++];
+        j = C5Job{};
+        j.nrange = 2;
+        j.r_src[0] = 0; j.r_c0[0] = 0; j.r_n[0] = Ch;
+        j.r_src[1] = 1; j.r_c0[1] = 0; j.r_n[1] = Ch;
+        j.epi = 2; j.Co = Ch; j.Ch = Ch; j.wpk = c5wo;
+        j.e_in0 = o_pre; j.e_in1 = lc;
+        j.e_out[0] = hO; j.e_out[1] = o_save; j.e_out[2] = tl_save;
+        const long long so = (long long)2 * Ch * L.taps;
+        C5PackRange pr[2] = {C5PackRange{Wo, so, (long long)L.taps, 0, {0, 0, 0, 0}}, C5PackRange{Wo, so, (long long)L.taps, Ch, {0, 0, 0, 0}}};
+        if ((rc = c5_prepare_job(j, C5F_NT_O, pr, 0, 0, packed, stream))) return rc;
+        VPX_CHECK_HIP(launch_c5(cp, C5F_NT_O, stream));
+    } else {
         ConvPlan P = base_plan(d, k);
         set_plan_tiles(P, L.mw_o);
         P.nseg = 2;

@@ -280,17 +280,21 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     // ---- B: grads of mem = [c_new | m_new] through conv_o (k x k) and conv_last (1 x 1) ----
     const bool c5 = L.c5 && stw;
     C5Plan cp{};
-    cp.B = B; cp.H = H; cp.W = Wd; cp.src = reinterpret_cast<const char*>(dG7);
-    cp.src_bstride = (long long)HW * ldG * 4; cp.src_prow = ldG * 4;
+    cp.B = B; cp.H = H; cp.W = Wd;
+    cp.src[0] = C5Src{reinterpret_cast<const char*>(dG7), (long long)HW * ldG * 4, ldG * 4, 0};
+    // rng[i] = {source channel 0, channels, weight row 0}: the job's K = channel ranges of dG8, each multiplying rows of `w`
     auto c5_job = [&](int slot, int Co_, float* out, int ld_out, int acc, const float* w, long long s_row, int w_col0, int nrange,
-                      const int (*rng)[3]) -> int {   // rng[i] = {source channel 0, channels, weight row 0}
+                      const int (*rng)[3]) -> int {
         C5Job& j = cp.job[cp.njobs++];
         j = C5Job{};
         j.nrange = nrange;
-        int rw0[3] = {0, 0, 0};
-        for (int i = 0; i < nrange; ++i) { j.r_c0[i] = rng[i][0]; j.r_n[i] = rng[i][1]; rw0[i] = rng[i][2]; }
+        C5PackRange pr[3] = {};
+        for (int i = 0; i < nrange; ++i) {
+            j.r_src[i] = 0; j.r_c0[i] = rng[i][0]; j.r_n[i] = rng[i][1];
+            pr[i] = C5PackRange{w, (long long)L.taps, s_row, rng[i][2], {w_col0, 0, 0, 0}};   // data gradient: column = the weight's input channel
+        }
         j.Co = Co_; j.ld = ld_out; j.accumulate = acc; j.wpk = c5w[slot]; j.out = out; j.out_bstride = (long long)HW * ld_out;
-        return c5_prepare_job(j, C5_NT, w, s_row, L.taps, w_col0, 1, rw0, packed, stream);
+        return c5_prepare_job(j, C5_NT, pr, 0, 1, packed, stream);
     };
     if (c5) {
         const int ro[1][3] = {{3 * Ch, Ch, 0}};

@@ -422,21 +422,27 @@ hipError_t launch_wgrad_reduce_tail(const float* slabs, float* dW, int n_slices,
                                     hipStream_t s);
 // convq.hip, c5: 5x5 'same' convolutions on 16x16-pixel tiles over ONE split-format source, a table of jobs per launch
 constexpr int C5_MAX_JOBS = 6;
+struct C5Src { const char* p; long long bstride; int prow, _pad; };   // split-format tensor [B][H][W][C]: bytes per image / per pixel
 struct C5Job {
-    int nrange, r_c0[3], r_n[3];   // the job's K: source channel ranges [r_c0, r_c0 + r_n), multiples of 8, in stage order
-    int S8, Q, n_tiles;            // derived (c5_prepare_job): 8-channel stages, K = 32 steps, N tiles
-    int Co, ld, accumulate;        // output channels, destination pixel pitch (floats), += instead of =
-    const char* wpk;               // packed weights [n_tile][Q][chunk]
-    float* out; long long out_bstride;
+    int nrange, r_src[3], r_c0[3], r_n[3];   // the job's K: channel ranges [r_c0, r_c0 + r_n) of source r_src, multiples of 8, in stage order
+    int S8, Q, n_tiles, nt_active;           // derived (c5_prepare_job): 8-channel stages, K = 32 steps, N tiles, column tiles in use
+    int epi;                                 // 0: fp32 destination (optional +=); 1: ST-LSTM gate group; 2: ST-LSTM output gate
+    int Co, ld, accumulate;                  // epi 0: output channels, destination pixel pitch (floats), += instead of =
+    const char* wpk;                         // packed weights [n_tile][Q][chunk]
+    float* out; long long out_bstride;       // epi 0
+    int Ch, ng; float fbias;                 // epi 1 / 2: channels of the state tensors [B,HW,Ch]; epi 1: gate groups (4: i,f,g,o_pre; 3: i',f',g'), forget bias
+    const float* e_in0; const float* e_in1;  // epi 1: s_in (c or m); epi 2: o_pre, conv_last(mem)
+    float* e_out[4];                         // epi 1: s_new, delta, o_pre (ng = 4), saved gates [B,HW,3Ch] or null; epi 2: h_new, o_save, tl_save (or null)
+    char* e_sp;                              // epi 1 / 2: s_new / h_new once more in the split format, or null
 };
 struct C5Plan {
     int B, H, W, tiles_x, tiles_y, m_tiles;
-    const char* src; long long src_bstride; int src_prow;   // split-format source [B][H][W][C]: bytes per image / per pixel
+    C5Src src[4];
     int njobs; C5Job job[C5_MAX_JOBS];
 };
-size_t c5_wpk_bytes(int K, int Co, int NT);
-int c5_prepare_job(C5Job& j, int NT, const float* w, long long s_row, long long s_col, int w_col0, int flip, const int* r_w0, bool packed,
-                   hipStream_t s);
+struct C5PackRange { const float* w; long long s_oc, s_c; int c0; int gate0[4]; };   // weights of one K range (see c5_pack_kernel)
+size_t c5_wpk_bytes(int K, int Co, int NT, int gates = 0);
+int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s);
 hipError_t launch_c5(const C5Plan& P, int NT, hipStream_t s);   // NT = 8: 128-column N tiles, 4: 64-column
 // wgrad2.hip, stw: the four 5x5 weight gradients of one ST-LSTM cell step in one launch (operands in split format)
 constexpr int STW_MAX_PAIRS = 48;
