@@ -783,8 +783,10 @@ int convq_run(const ConvQProblem& pr, const ConvQEpiArgs& ea_in, char* wpk, bool
 constexpr int C5_PLANE = 512 * 16;       // one plane (hi or lo) of a stage buffer, padded from 400 positions
 constexpr int C5_ABUF = 2 * C5_PLANE;    // 16 KiB
 template <int NT> struct C5Geom {
-    static constexpr int WCH = NT * 2048;                 // weight chunk of one K = 32 step: 16 | 8 KiB
-    static constexpr int WP = WCH / (256 * 16);           // DMAs per thread and chunk: 4 | 2
+    static constexpr int WCH = NT * 2048;                 // weight chunk of one K = 32 step: 16 | 8 | 4 KiB
+    static constexpr int WP = WCH / (256 * 16);           // DMAs per thread and chunk: 4 | 2 | 1
+    static constexpr int HCOLS = NT >= 4 ? 64 : NT * 16;  // columns of a chunk half ([half][part][k group][HCOLS][16 B])
+    static constexpr int KGS = HCOLS * 16, PARTS = 4 * KGS;
     static constexpr int LDS = 2 * C5_ABUF + (3 * WCH > 32768 ? 3 * WCH : 32768);   // >= 64 KiB: 4 waves x 16 KiB in the epilogue
 };
 
@@ -989,11 +991,11 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
         al[m] = *reinterpret_cast<const bf16x8*>(a + C5_PLANE);
     };
     // B: chunk [half = nt >> 2][part][k group][64 columns][16 B] (NT = 4: one half)
-    const int w_lane = 2 * C5_ABUF + kg * 1024 + r16 * 16;
+    const int w_lane = 2 * C5_ABUF + kg * G::KGS + r16 * 16;
     auto load_B = [&](int slot, int nt) {
         const char* w = smem + w_lane + slot * G::WCH + (nt >> 2) * 8192 + (nt & 3) * 256;
         bh[nt & 1] = *reinterpret_cast<const bf16x8*>(w);
-        bl[nt & 1] = *reinterpret_cast<const bf16x8*>(w + 4096);
+        bl[nt & 1] = *reinterpret_cast<const bf16x8*>(w + G::PARTS);
     };
 
     const int Q = J.Q;
@@ -1001,7 +1003,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     if (Q > 0) {
         issue_A(0, 0);
         issue_W(0, 0);
-        if (Q > 1) { issue_W(1, 1); if constexpr (G::WP == 4) C2_WAIT_VM(4); else C2_WAIT_VM(2); }
+        if (Q > 1) { issue_W(1, 1); if constexpr (G::WP == 4) C2_WAIT_VM(4); else if constexpr (G::WP == 2) C2_WAIT_VM(2); else C2_WAIT_VM(1); }
         else C2_WAIT_VM(0);
         c2_barrier();
         const int o0 = a_off(0);
@@ -1009,7 +1011,8 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
         for (int m = 0; m < 4; ++m) load_A1(o0, m);
         load_B(0, 0);
     }
-    constexpr int SYNC_NT = NT == 8 ? 5 : 2;    // the sync point sits before this column tile of every step
+    constexpr int SYNC_NT = NT == 8 ? 5 : (NT == 4 ? 2 : 1);    // the sync point sits before this column tile of every step
+    constexpr int STAGE_NT = SYNC_NT + 1 < NT ? SYNC_NT + 1 : NT - 1;   // the stage copy follows the weight copy (same tile when there is no later one)
     int q = 0, slot = 0;                        // global step, its ring slot (q % 3)
     bool flies = false;                         // a stage copy was issued in the previous step (it may still fly at this step's sync)
 #pragma unroll 1
@@ -1046,7 +1049,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
                 }
                 __builtin_amdgcn_s_setprio(0);
                 if (nt == SYNC_NT) { if (q + 2 < Q) issue_W(q + 2, slot == 0 ? 2 : slot - 1); }
-                if (nt == SYNC_NT + 1 && issue) issue_A(want, want & 1);
+                if (nt == STAGE_NT && issue) issue_A(want, want & 1);
             }
             flies = issue;
             slot = nslot;
@@ -1069,8 +1072,11 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) acc8[m][nt] = nt < 4 ? acc[m][nt] : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (J.epi == 2) c5_finish_out(acc8, smem, wave, lane, b, y0, x0, n_tile, 2, J, P.H, P.W);
+            for (int nt = 0; nt < 8; ++nt) {
+                if constexpr (NT == 4) acc8[m][nt] = nt < 4 ? acc[m][nt] : f32x4{0.f, 0.f, 0.f, 0.f};
+                else acc8[m][nt] = nt < 2 ? acc[m][nt < 2 ? nt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        if (J.epi == 2) c5_finish_out(acc8, smem, wave, lane, b, y0, x0, n_tile, NT / 2, J, P.H, P.W);
         else epi.finish16(acc8, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
     }
 }
@@ -1090,7 +1096,8 @@ __global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int i = (int)(e & 7);
         long long r = e >> 3;
-        int n = (int)(r & 63); r >>= 6;
+        int n;
+        if (pk.NT >= 4) { n = (int)(r & 63); r >>= 6; } else { n = (int)(r & 31); r >>= 5; }
         const int kg = (int)(r & 3); r >>= 2;
         const int part = (int)(r & 1); r >>= 1;
         if (pk.NT == 8) { n += (int)(r & 1) * 64; r >>= 1; }
@@ -1159,6 +1166,8 @@ hipError_t launch_c5(const C5Plan& P_in, int NT, hipStream_t s) {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&c5_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, C5Geom<4>::LDS);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&c5_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, C5Geom<2>::LDS);
+        if (e != hipSuccess) return e;
         attr_set = true;
     }
     C5Plan P = P_in;
@@ -1168,7 +1177,8 @@ hipError_t launch_c5(const C5Plan& P_in, int NT, hipStream_t s) {
     for (int j = 0; j < P.njobs; ++j) per_xcd += (long long)Mx * P.job[j].n_tiles;
     if (per_xcd < 1) return hipSuccess;
     if (NT == 8) hipLaunchKernelGGL(c5_kernel<8>, dim3((unsigned)(per_xcd * 8)), dim3(256), C5Geom<8>::LDS, s, P);
-    else hipLaunchKernelGGL(c5_kernel<4>, dim3((unsigned)(per_xcd * 8)), dim3(256), C5Geom<4>::LDS, s, P);
+    else if (NT == 4) hipLaunchKernelGGL(c5_kernel<4>, dim3((unsigned)(per_xcd * 8)), dim3(256), C5Geom<4>::LDS, s, P);
+    else hipLaunchKernelGGL(c5_kernel<2>, dim3((unsigned)(per_xcd * 8)), dim3(256), C5Geom<2>::LDS, s, P);
     return hipGetLastError();
 }
 

@@ -27,7 +27,12 @@ struct STLayout {
     // over split-format operands; conv_last (1x1) stays on the first-generation kernel
     bool c5; size_t c5_wc, c5_wm, c5_wo;   // bytes of its weight packs
 };
-constexpr int C5F_NT_O = 4;   // conv_o: 64-column N tiles (Ch = 128 -> 2 per pixel tile)
+// conv_o on c5: 64-column N tiles, or 32-column ones when those would leave the chip half empty (B = 128 on 16x16 maps, Ch = 128: 256
+// workgroups of four waves = one wave per SIMD; 512 at 32 columns)
+static inline int c5f_nt_o(const vpx_stlstm_desc* d) {
+    const long long mt = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
+    return mt * ((d->Ch + 63) / 64) < 384 ? 2 : 4;
+}
 
 // VPX_OPT_EXPERIMENT bit 8 keeps the first-generation forward launches (A/B runs, tests)
 bool c5_fwd_applicable(const vpx_stlstm_desc* d) {
@@ -79,7 +84,7 @@ int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
     if (L.c5) {
         L.c5_wc = align256(c5_wpk_bytes(d->Cin + d->Ch, d->Ch, 8, 4));
         L.c5_wm = align256(c5_wpk_bytes(d->Cin + d->Ch, d->Ch, 8, 3));
-        L.c5_wo = align256(c5_wpk_bytes(2 * d->Ch, d->Ch, C5F_NT_O));
+        L.c5_wo = align256(c5_wpk_bytes(2 * d->Ch, d->Ch, c5f_nt_o(d)));
     }
     return VPX_OK;
 }
@@ -301,6 +306,10 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         P.nseg = 2;
         P.seg[0] = ConvSeg{cO, (long long)(HW * Ch), Ch, 0};
         P.seg[1] = ConvSeg{mO, (long long)(HW * Ch), Ch, 0};
+        if (L.c5) {   // the gate epilogues left c_new / m_new in the split format as well: staged without conversion
+            P.seg[0] = ConvSeg{reinterpret_cast<const float*>(cn_sp), (long long)(HW * Ch), Ch, 0, 1};
+            P.seg[1] = ConvSeg{reinterpret_cast<const float*>(mn_sp), (long long)(HW * Ch), Ch, 0, 1};
+        }
         P.nstage = L.nstage_l; memcpy(P.stage, L.stage_l, sizeof(ConvStage) * L.nstage_l);
         P.chunks_total = L.chunks_l; P.a_bytes = conv_a_bytes(L.stage_l, L.nstage_l, 1, 1); P.wpk = wpk_l;
         PlainEpiArgs ea{};
@@ -325,8 +334,8 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         j.e_out[0] = hO; j.e_out[1] = o_save; j.e_out[2] = tl_save;
         const long long so = (long long)2 * Ch * L.taps;
         C5PackRange pr[2] = {C5PackRange{Wo, so, (long long)L.taps, 0, {0, 0, 0, 0}}, C5PackRange{Wo, so, (long long)L.taps, Ch, {0, 0, 0, 0}}};
-        if ((rc = c5_prepare_job(j, C5F_NT_O, pr, 0, 0, packed, stream))) return rc;
-        VPX_CHECK_HIP(launch_c5(cp, C5F_NT_O, stream));
+        if ((rc = c5_prepare_job(j, c5f_nt_o(d), pr, 0, 0, packed, stream))) return rc;
+        VPX_CHECK_HIP(launch_c5(cp, c5f_nt_o(d), stream));
     } else {
         ConvPlan P = base_plan(d, k);
         set_plan_tiles(P, L.mw_o);
