@@ -159,7 +159,8 @@ def test_stlstm_second_generation_backward_matches_first_generation(vpx, B, Cin,
       * c5 (convq.hip): the 5x5 data gradients (conv_o's adjoint; dx | dh | dm as the jobs of one launch) on 16x16-pixel tiles with
         8-channel stages — bit 7 switches it off alone;
       * c5 forward (channels in 32s): both gate groups as the jobs of one launch (gate-interleaved N tiles, fused gate math, c_new /
-        m_new also written in the split format), conv_o + output gate as another — bit 8 switches it off."""
+        m_new also written in the split format), conv_o + output gate as another — bit 8 switches it off;
+      * c1 (conv1.hip): conv_last and its adjoint as a streaming kernel with register-resident weights (Ch = 128 only) — bit 9."""
     from golden_util import seeded_randn
     k = 5
     tag = f"stw.{B}.{Cin}.{Ch}.{H}.{W}"
@@ -183,7 +184,7 @@ def test_stlstm_second_generation_backward_matches_first_generation(vpx, B, Cin,
     try:
         new = run()
         res = {}
-        for bits in (64, 128, 256, 64 + 256):
+        for bits in (64, 128, 256, 64 + 256, 512):
             prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, bits)
             try:
                 res[bits] = run()

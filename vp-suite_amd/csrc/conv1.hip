@@ -1,0 +1,111 @@
+// conv1.hip — c1: the ST-LSTM step's 1x1 convolutions (conv_last over mem = [c_new | m_new], predrnn.py:79-81; its adjoint in the
+// backward pass; the decoupling tail's adapter, predrnn_v2.py:197-198) as a streaming kernel (round 4).
+// These layers are 2 GFLOP over 50 MB: HBM-bound by a factor of 20 even at the bf16x3 matrix rate — but on the implicit-GEMM
+// kernel (LDS-staged halo tiles, a weight stream per workgroup, one launch of 256 short workgroups) they took 42-44 us each,
+// 4.9 % matrix-pipe use, five of them per cell step. Here nothing goes through LDS and nothing is synchronised:
+//   * a wave keeps ITS share of the weights — Co / 4 columns x all K — as MFMA B fragments in registers for the whole kernel
+//     (128 VGPRs: (Co, K) = (128, 256) | (256, 128); split into hi / lo bf16 once);
+//   * the A fragment of a lane (pixel = lane & 15, k group = lane >> 4) is eight consecutive fp32 channels of one pixel: two
+//     16-byte global loads, split in registers (v_cvt_pk_bf16_f32) — the input is read as plain fp32 NHWC, no operand format needed;
+//     all K / 32 steps of a 16-pixel tile are requested before the first MFMA (16 loads in flight per lane);
+//   * the four waves of a workgroup take the same pixels (the loads of three of them hit L1 / TA) and different columns.
+// y[p][n] (+)= sum_c [x0 | x1][p][c] * w(n, c), fp32 in and out, products hi*hi + hi*lo + lo*hi (bf16x3), fp32 accumulation.
+#include "cell2_dev.h"
+#include "vpx_host.h"
+
+namespace vpx {
+
+template <int NTW, int KS>   // column tiles (of 16) per wave, K = 32 steps
+__global__ __launch_bounds__(256, 2) void c1_kernel(const C1Args a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kg = lane >> 4;
+    // B fragments: column n = (wave * NTW + t) * 16 + r16, k = ks * 32 + kg * 8 .. + 7
+    bf16x8 bh[NTW][KS], bl[NTW][KS];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int n = (wave * NTW + t) * 16 + r16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            unsigned h[8], l[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = ks * 32 + kg * 8 + i;
+                const float v = n < a.Co ? a.w[(long long)n * a.w_sn + (long long)c * a.w_sc] : 0.0f;
+                c2_split(v, h[i], l[i]);
+            }
+            bh[t][ks] = __builtin_bit_cast(bf16x8, uint4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)});
+            bl[t][ks] = __builtin_bit_cast(bf16x8, uint4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)});
+        }
+    }
+    const long long ntile = (a.npix + 15) / 16;
+    const int ks0 = a.xc[0] / 32;   // steps served by the first source
+#pragma unroll 1
+    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long long p = tile * 16 + r16;
+        const bool ok = p < a.npix;
+        f32x4 raw[KS][2];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bool first = ks < ks0;
+            const float* src = (first ? a.x[0] + p * a.xld[0] + ks * 32 : a.x[1] + p * a.xld[1] + (ks - ks0) * 32) + kg * 8;
+            if (ok) { raw[ks][0] = *reinterpret_cast<const f32x4*>(src); raw[ks][1] = *reinterpret_cast<const f32x4*>(src + 4); }
+            else { raw[ks][0] = f32x4{0.f, 0.f, 0.f, 0.f}; raw[ks][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        f32x4 acc[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            unsigned h[8], l[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c2_split(i < 4 ? raw[ks][0][i] : raw[ks][1][i - 4], h[i], l[i]);
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, uint4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)});
+            const bf16x8 al = __builtin_bit_cast(bf16x8, uint4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)});
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[t][ks], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[t][ks], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[t][ks], acc[t], 0, 0, 0);
+            }
+        }
+        // D[pixel 4 * kg + r][column r16] of every column tile
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int n = (wave * NTW + t) * 16 + r16;
+            if (n >= a.Co) continue;
+            const bool lo_half = n < a.ysplit;
+            float* const yb = lo_half ? a.y[0] : a.y[1];
+            const int ld = lo_half ? a.yld[0] : a.yld[1], nn = lo_half ? n : n - a.ysplit;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long q = tile * 16 + 4 * kg + r;
+                if (q >= a.npix) continue;
+                float* dst = yb + q * ld + nn;
+                *dst = a.accumulate ? *dst + acc[t][r] : acc[t][r];
+            }
+        }
+    }
+}
+
+bool c1_applicable(const C1Args& a, int prec) {
+    if (prec != VPX_PREC_BF16X3 || (g_experiment & 512)) return false;   // VPX_OPT_EXPERIMENT bit 9: the implicit-GEMM kernel (A/B runs, tests)
+    const int K = a.xc[0] + a.xc[1];
+    if ((a.xc[0] & 31) || (a.xc[1] & 31) || a.xc[0] < 32) return false;
+    if (!((a.Co == 128 && K == 256) || (a.Co == 256 && K == 128) || (a.Co == 128 && K == 128))) return false;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!al16(a.x[0]) || (a.xld[0] & 3) || (a.xc[1] && (!al16(a.x[1]) || (a.xld[1] & 3)))) return false;
+    return a.npix > 0;
+}
+
+hipError_t launch_c1(const C1Args& a, hipStream_t s) {
+    const int K = a.xc[0] + a.xc[1];
+    const long long ntile = (a.npix + 15) / 16;
+    const unsigned grid = (unsigned)(ntile < 1024 ? ntile : 1024);   // two workgroups per CU x 2 rounds; the weights are re-read per workgroup only
+    if (a.Co == 128 && K == 256) hipLaunchKernelGGL((c1_kernel<2, 8>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.Co == 256 && K == 128) hipLaunchKernelGGL((c1_kernel<4, 4>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((c1_kernel<2, 4>), dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace vpx

@@ -67,6 +67,20 @@ int vpx_conv2d_nhwc_fwd_ex(const float* x, const float* w, const float* bias, fl
 static int decouple_adapter_pair(hipStream_t stream, int prec, ConvGeo g, const float* sc, const float* sm, const float* adapter,
                                  float* oc, float* om, size_t n, int Ch, bool transposed, float* wpk) {
     int rc;
+    {   // streaming 1x1 kernel (conv1.hip): weights resident in registers, fp32 in and out
+        C1Args c{};
+        c.x[0] = sc; c.xld[0] = Ch; c.xc[0] = Ch; c.x[1] = nullptr; c.xld[1] = 0; c.xc[1] = 0;
+        c.npix = (long long)g.N * g.H * g.W;
+        c.w = adapter; c.w_sn = transposed ? 1 : Ch; c.w_sc = transposed ? Ch : 1;
+        c.y[0] = oc; c.y[1] = nullptr; c.yld[0] = Ch; c.yld[1] = 0; c.ysplit = Ch; c.Co = Ch; c.accumulate = 0;
+        if (c1_applicable(c, prec)) {
+            if (sm == sc + n && om == oc + n) { c.npix *= 2; VPX_CHECK_HIP(launch_c1(c, stream)); return VPX_OK; }
+            VPX_CHECK_HIP(launch_c1(c, stream));
+            c.x[0] = sm; c.y[0] = om;
+            VPX_CHECK_HIP(launch_c1(c, stream));
+            return VPX_OK;
+        }
+    }
     if (sm == sc + n && om == oc + n) {
         const ConvGeo g2{2 * g.N, g.H, g.W};
         return plain_conv(stream, prec, g2, sc, Ch, Ch, adapter, Ch, 1, 1, 1, Ch, transposed, nullptr, oc, Ch, false, wpk);

@@ -1279,7 +1279,7 @@ __global__ void st_bwd_out_kernel(const STBwdOutArgs a) {
     const float o = a.o[e], tl = a.tl[e];
     a.dG7[pix * a.ldG + a.o_off + ch] = dh * tl * o * (1.0f - o);  // d(o_x + o_h + conv_o(mem))
     if (a.dlc_off >= 0) a.dG7[pix * a.ldG + a.dlc_off + ch] = dh * o * (1.0f - tl * tl);
-    else a.dlc[e] = dh * o * (1.0f - tl * tl);                     // d conv_last(mem)
+    if (a.dlc) a.dlc[e] = dh * o * (1.0f - tl * tl);               // d conv_last(mem)
 }
 
 __global__ void st_bwd_gates_kernel(const STBwdGateArgs a) {
@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(256) void st_bwd_out8_kernel(const STBwdOutArgs a) 
     }
     st8<SPLIT>(a.dG7 + pix * a.ldG + a.o_off + ch, go);
     if (a.dlc_off >= 0) st8<SPLIT>(a.dG7 + pix * a.ldG + a.dlc_off + ch, gl);
-    else st8<false>(a.dlc + e, gl);
+    if (a.dlc) st8<false>(a.dlc + e, gl);
 }
 
 template <bool SPLIT>

@@ -301,7 +301,14 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         VPX_CHECK_HIP(launch_st_gates_dual(P, ea, Pm, em, L.tiles32, stream));
     }
     // ---- launch 3: conv_last(mem) 1x1 -> lc ----
-    {
+    C1Args c1{};
+    c1.x[0] = cO; c1.x[1] = mO; c1.xld[0] = c1.xld[1] = Ch; c1.xc[0] = c1.xc[1] = Ch;
+    c1.npix = (long long)B * (long long)HW;
+    c1.w = Wlast; c1.w_sn = 2 * Ch; c1.w_sc = 1;
+    c1.y[0] = lc; c1.yld[0] = Ch; c1.ysplit = Ch; c1.Co = Ch;
+    if (c1_applicable(c1, d->precision)) {
+        VPX_CHECK_HIP(launch_c1(c1, stream));   // streaming form (conv1.hip): no weight pack, no LDS
+    } else {
         ConvPlan P = base_plan(d, 1);
         P.nseg = 2;
         P.seg[0] = ConvSeg{cO, (long long)(HW * Ch), Ch, 0};

@@ -274,6 +274,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     const int ldG = stw ? 8 * Ch : 7 * Ch;   // stw: dG8 = the seven gate blocks + d conv_last (block 7), all in the split format
     // ---- A: through h_new = o * tanh(conv_last(mem)) ----
     {
+        // (stw: d conv_last goes to dG8 block 7 in the split format for the weight gradient AND to the fp32 tensor dlc for the streaming 1x1 adjoint)
         STBwdOutArgs a{(long long)L.n_state, Ch, ldG, 3 * Ch, stw ? 7 * Ch : -1, g_h, o_save, tl_save, dG7, dlc, g7s};
         VPX_CHECK_HIP(launch_st_bwd_out(a, stream));
     }
@@ -318,6 +319,14 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
             VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.o.tiles, stream));
         }
 
+        C1Args c1{};   // conv_last's adjoint: [dc_new | dm_new] += Wlast^T d conv_last
+        c1.x[0] = dlc; c1.xld[0] = Ch; c1.xc[0] = Ch;
+        c1.npix = (long long)B * (long long)HW;
+        c1.w = Wlast; c1.w_sn = 1; c1.w_sc = 2 * Ch;
+        c1.y[0] = dcn_conv; c1.y[1] = dmn_conv; c1.yld[0] = c1.yld[1] = Ch; c1.ysplit = Ch; c1.Co = 2 * Ch; c1.accumulate = 1;
+        if (c1_applicable(c1, d->precision)) {
+            VPX_CHECK_HIP(launch_c1(c1, stream));   // streaming form (conv1.hip)
+        } else {
         PackDesc pl{};
         pl.seg[0] = PackSeg{Wlast, (long long)2 * Ch, 1, 0, Ch};
         pack_plain_T(pl, L.l, 1, 2 * Ch);
@@ -327,6 +336,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         ea.accumulate = 1;
         VPX_CHECK_HIP(split_plan(Q, L.l, dcn_conv, dmn_conv, L.n_state, true));
         VPX_CHECK_HIP(launch_conv_plain_f32(Q, ea, L.l.tiles, stream));
+        }
     }
     // ---- C: gate groups ----
     {

@@ -420,6 +420,16 @@ static inline int wgrad2_slices(int target, int rows128, int n_ctiles, bool half
 hipError_t launch_wgrad2(const WgradArgs& a, int max_slices, int* used_slices, int* tail_col0, int* tail_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce_tail(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int tail_col0, int tail_slices,
                                     hipStream_t s);
+// conv1.hip, c1: 1x1 convolution as a streaming kernel (weights resident in registers), fp32 NHWC in and out, bf16x3 arithmetic
+struct C1Args {
+    const float* x[2]; int xld[2], xc[2];   // up to two sources concatenated along K: pixel pitch (floats), channels (multiples of 32; xc[1] = 0: one source)
+    long long npix;
+    const float* w; long long w_sn, w_sc;   // weight element (column n, channel c) at w[n * w_sn + c * w_sc]
+    float* y[2]; int yld[2], ysplit;        // columns [0, ysplit) go to y[0], the rest to y[1] (pixel pitches yld)
+    int Co, accumulate;
+};
+bool c1_applicable(const C1Args& a, int prec);   // (Co, K) in {(128, 256), (256, 128), (128, 128)}, aligned operands, bf16x3
+hipError_t launch_c1(const C1Args& a, hipStream_t s);
 // convq.hip, c5: 5x5 'same' convolutions on 16x16-pixel tiles over ONE split-format source, a table of jobs per launch
 constexpr int C5_MAX_JOBS = 6;
 struct C5Src { const char* p; long long bstride; int prow, _pad; };   // split-format tensor [B][H][W][C]: bytes per image / per pixel
