@@ -28,12 +28,21 @@ __global__ __launch_bounds__(256, 2) void c1_kernel(const C1Args a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             unsigned h[8], l[8];
+            float wv[8];
+            if (a.w_sc == 1 && n < a.Co) {   // channels contiguous: two 16-byte loads (eight scalar loads of 64 different lines each were TA-bound)
+                const float* wp = a.w + (long long)n * a.w_sn + ks * 32 + kg * 8;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = ks * 32 + kg * 8 + i;
-                const float v = n < a.Co ? a.w[(long long)n * a.w_sn + (long long)c * a.w_sc] : 0.0f;
-                c2_split(v, h[i], l[i]);
+                for (int i = 0; i < 8; ++i) wv[i] = i < 4 ? w0[i] : w1[i - 4];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = ks * 32 + kg * 8 + i;
+                    wv[i] = n < a.Co ? a.w[(long long)n * a.w_sn + (long long)c * a.w_sc] : 0.0f;
+                }
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c2_split(wv[i], h[i], l[i]);
             bh[t][ks] = __builtin_bit_cast(bf16x8, uint4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)});
             bl[t][ks] = __builtin_bit_cast(bf16x8, uint4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)});
         }
@@ -95,13 +104,14 @@ bool c1_applicable(const C1Args& a, int prec) {
     if (!((a.Co == 128 && K == 256) || (a.Co == 256 && K == 128) || (a.Co == 128 && K == 128))) return false;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!al16(a.x[0]) || (a.xld[0] & 3) || (a.xc[1] && (!al16(a.x[1]) || (a.xld[1] & 3)))) return false;
+    if (a.w_sc == 1 && (!al16(a.w) || (a.w_sn & 3))) return false;
     return a.npix > 0;
 }
 
 hipError_t launch_c1(const C1Args& a, hipStream_t s) {
     const int K = a.xc[0] + a.xc[1];
     const long long ntile = (a.npix + 15) / 16;
-    const unsigned grid = (unsigned)(ntile < 1024 ? ntile : 1024);   // two workgroups per CU x 2 rounds; the weights are re-read per workgroup only
+    const unsigned grid = (unsigned)(ntile < 512 ? ntile : 512);   // two workgroups per CU, one round: every workgroup reads the weights once
     if (a.Co == 128 && K == 256) hipLaunchKernelGGL((c1_kernel<2, 8>), dim3(grid), dim3(256), 0, s, a);
     else if (a.Co == 256 && K == 128) hipLaunchKernelGGL((c1_kernel<4, 4>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((c1_kernel<2, 4>), dim3(grid), dim3(256), 0, s, a);
