@@ -35,8 +35,14 @@ static inline int c5f_nt_o(const vpx_stlstm_desc* d) {
 }
 
 // VPX_OPT_EXPERIMENT bit 8 keeps the first-generation forward launches (A/B runs, tests)
+// Grid rule (measured, tools/ab_predrnn.py, predrnn-pp inference, ms per forward c5 vs first generation): 16x16 maps B = 8 / 16 / 32 / 64 /
+// 128: 23.5 / 23.7 / 24.4 / 30.5 / 53.8 vs 13.7 / 14.1 / 17.1 / 26.9 / 58.5; 32x32 maps (128x128x3, 4 layers, 10 -> 30) B = 4 / 8 / 16:
+// 72.5 / 78.1 / 90.9 vs 45.0 / 53.0 / 83.5 — a c5 workgroup runs its whole K (200 steps of 96 MFMAs) on one CU, the first generation
+// splits K over workgroups when the pixel tiles do not fill the chip. c5 from 96 pixel tiles of 16x16 on.
 bool c5_fwd_applicable(const vpx_stlstm_desc* d) {
-    return d->k == 5 && d->precision == VPX_PREC_BF16X3 && !(d->Ch & 31) && !(d->Cin & 7) && !d->layer_norm && !(g_experiment & 256);
+    const long long mt = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
+    return d->k == 5 && d->precision == VPX_PREC_BF16X3 && !(d->Ch & 31) && !(d->Cin & 7) && !d->layer_norm && !(g_experiment & 256) &&
+           (mt >= 96 || (g_experiment & 1024));   // (bit 10 forces it on small grids: tests)
 }
 
 int check_st_desc(const vpx_stlstm_desc* d) {

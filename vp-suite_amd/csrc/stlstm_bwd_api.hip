@@ -78,7 +78,11 @@ int st_bwd_layout(const vpx_stlstm_desc* d, STBwdLayout& L) {
         }
     }
     // VPX_OPT_EXPERIMENT bit 7 keeps the first-generation data-gradient launches (A/B runs, tests)
-    L.c5 = L.stw && !(g_experiment & 128);
+    // ... from 96 pixel tiles of 16x16 on (the grid rule of the forward launches, stlstm_api.hip: below, the first generation's K-split
+    // data gradients fill the chip; measured training step at 16x16 maps, c5 vs first-generation data gradients: B = 8 130 vs 78 ms,
+    // B = 32 165 vs 136 ms, B = 128 361 vs ~405 ms)
+    const long long mt16 = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
+    L.c5 = L.stw && !(g_experiment & 128) && (mt16 >= 96 || (g_experiment & 1024));
     if (L.c5) {
         const int K[5] = {Ch, Ch, 7 * Ch, 4 * Ch, 3 * Ch}, Co[5] = {Ch, Ch, Cin, Ch, Ch};
         for (int i = 0; i < 5; ++i) L.c5_wpk[i] = align256(c5_wpk_bytes(K[i], Co[i], C5_NT));
