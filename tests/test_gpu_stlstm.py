@@ -160,7 +160,9 @@ def test_stlstm_second_generation_backward_matches_first_generation(vpx, B, Cin,
         8-channel stages — bit 7 switches it off alone;
       * c5 forward (channels in 32s): both gate groups as the jobs of one launch (gate-interleaved N tiles, fused gate math, c_new /
         m_new also written in the split format), conv_o + output gate as another — bit 8 switches it off;
-      * c1 (conv1.hip): conv_last and its adjoint as a streaming kernel with register-resident weights (Ch = 128 only) — bit 9."""
+      * c1 (conv1.hip): conv_last and its adjoint as a streaming kernel with register-resident weights (Ch = 128 only) — bit 9;
+      * on grids below 96 pixel tiles (every shape here) the c5 launches run K-SPLIT (chunks of K as separate jobs writing partial sums,
+        st_pointwise.hip adds them): the default; bit 10 forces the unsplit forms, bit 11 the first generation."""
     from golden_util import seeded_randn
     k = 5
     tag = f"stw.{B}.{Cin}.{Ch}.{H}.{W}"
@@ -186,8 +188,10 @@ def test_stlstm_second_generation_backward_matches_first_generation(vpx, B, Cin,
     try:
         new = run()
         res = {}
-        for bits in (64, 128, 256, 64 + 256, 512, 0):
-            prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, bits if bits == 0 else bits | FORCE)
+        # 0 = the product's choice on these small grids: the K-split job forms of c5 (partial sums + pointwise stages); 2048 = the
+        # first generation there
+        for bits in (FORCE | 64, FORCE | 128, FORCE | 256, FORCE | 64 | 256, FORCE | 512, 0, 2048, 2048 | 64):
+            prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, bits)
             try:
                 res[bits] = run()
             finally:

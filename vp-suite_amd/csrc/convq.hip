@@ -1088,6 +1088,7 @@ struct C5PackArgs {
     C5PackRange rg[3];
     int nrange, r_n[3];
     int flip, NT, gates;       // gates: number of gate groups of an N tile (0 = plain column order)
+    int gate_major;            // gates > 0: plain column order oc = gate * Co + channel instead of gate-interleaved N tiles
     int S8, Q, Co, n_tiles;    // Co: plain: output channels; gates: channels per gate (Ch)
 };
 __global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
@@ -1112,7 +1113,10 @@ __global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
             if (c >= pk.r_n[0]) { c -= pk.r_n[0]; ri = 1; if (c >= pk.r_n[1]) { c -= pk.r_n[1]; ri = 2; } }
             const C5PackRange rg = pk.rg[ri];
             long long ocidx = -1;
-            if (pk.gates) {
+            if (pk.gates && pk.gate_major) {
+                const int oc = n_tile * (pk.NT * 16) + n, g = oc / pk.Co;
+                if (g < pk.gates) ocidx = rg.gate0[g] + (oc - g * pk.Co);
+            } else if (pk.gates) {
                 const int g = n >> 5, chn = n_tile * 32 + (n & 31);
                 if (g < pk.gates && chn < pk.Co) ocidx = rg.gate0[g] + chn;
             } else {
@@ -1134,22 +1138,23 @@ size_t c5_wpk_bytes(int K, int Co, int NT, int gates) {
 
 // fills the job's derived fields (S8, Q, n_tiles, nt_active) and packs its weights into job.wpk unless `packed`.
 // gates = 0: plain column order, Co output channels; gates = 3 | 4: gate-interleaved N tiles of 32 channels (NT = 8), Co = channels per gate
-int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s) {
+int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s, int gate_major) {
     int K = 0;
     for (int i = 0; i < 3; ++i) {
         if (i >= j.nrange) { j.r_n[i] = 0; j.r_c0[i] = 0; j.r_src[i] = 0; }
         K += j.r_n[i];
         if ((j.r_n[i] | j.r_c0[i]) & 7) { set_error("c5: channel ranges in 8s"); return VPX_ERR_ARG; }
     }
-    if (gates && NT != 8) { set_error("c5: gate-interleaved tiles need NT = 8"); return VPX_ERR_ARG; }
+    if (gates && !gate_major && NT != 8) { set_error("c5: gate-interleaved tiles need NT = 8"); return VPX_ERR_ARG; }
     j.S8 = K / 8; j.Q = (25 * j.S8 + 3) / 4;
-    j.n_tiles = gates ? (j.Co + 31) / 32 : (j.Co + NT * 16 - 1) / (NT * 16);
-    j.nt_active = gates ? 2 * gates : NT;
+    // gate_major: j.Co = all columns (gates x channels per gate), plain epilogue; else gates > 0: j.Co = channels per gate
+    j.n_tiles = (gates && !gate_major) ? (j.Co + 31) / 32 : (j.Co + NT * 16 - 1) / (NT * 16);
+    j.nt_active = (gates && !gate_major) ? 2 * gates : NT;
     if (!packed) {
         C5PackArgs pk{};
-        pk.nrange = j.nrange; pk.flip = flip; pk.NT = NT; pk.gates = gates;
+        pk.nrange = j.nrange; pk.flip = flip; pk.NT = NT; pk.gates = gates; pk.gate_major = gate_major;
         for (int i = 0; i < 3; ++i) { pk.r_n[i] = j.r_n[i]; if (i < j.nrange) pk.rg[i] = rg[i]; }
-        pk.S8 = j.S8; pk.Q = j.Q; pk.Co = j.Co; pk.n_tiles = j.n_tiles;
+        pk.S8 = j.S8; pk.Q = j.Q; pk.Co = (gates && gate_major) ? j.Co / gates : j.Co; pk.n_tiles = j.n_tiles;
         const long long total = (long long)j.n_tiles * j.Q * NT * 1024;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
@@ -1157,6 +1162,31 @@ int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip,
         VPX_CHECK_HIP(hipGetLastError());
     }
     return VPX_OK;
+}
+
+// chunk k of ks of a job's K (whole 8-channel stages): the chunk's channel ranges and the matching weight ranges
+void c5_chunk_job(const C5Job& full, const C5PackRange* prf, int k, int ks, C5Job& j, C5PackRange* pr) {
+    const int S8 = (full.r_n[0] + full.r_n[1] + full.r_n[2]) / 8;
+    const int c_lo = 8 * (int)((long long)S8 * k / ks), c_hi = 8 * (int)((long long)S8 * (k + 1) / ks);
+    j = full;
+    j.nrange = 0;
+    for (int i = 0; i < 3; ++i) { j.r_src[i] = 0; j.r_c0[i] = 0; j.r_n[i] = 0; }
+    int base = 0;
+    for (int i = 0; i < full.nrange; ++i) {
+        const int lo = c_lo > base ? c_lo : base, hi = c_hi < base + full.r_n[i] ? c_hi : base + full.r_n[i];
+        if (lo < hi) {
+            const int q = j.nrange++;
+            j.r_src[q] = full.r_src[i]; j.r_c0[q] = full.r_c0[i] + (lo - base); j.r_n[q] = hi - lo;
+            pr[q] = prf[i]; pr[q].c0 += lo - base;
+        }
+        base += full.r_n[i];
+    }
+}
+// bytes of chunk k's pack
+size_t c5_chunk_wpk_bytes(int K, int k, int ks, int cols, int NT) {
+    const int S8 = K / 8;
+    const int s8 = (int)((long long)S8 * (k + 1) / ks) - (int)((long long)S8 * k / ks);
+    return (size_t)((cols + NT * 16 - 1) / (NT * 16)) * ((25 * s8 + 3) / 4) * NT * 2048;
 }
 
 hipError_t launch_c5(const C5Plan& P_in, int NT, hipStream_t s) {

@@ -26,6 +26,9 @@ struct STLayout {
     // c5 (convq.hip, round 4): the two gate groups as the jobs of one launch, conv_o + output gate as another, on 16x16-pixel tiles
     // over split-format operands; conv_last (1x1) stays on the first-generation kernel
     bool c5; size_t c5_wc, c5_wm, c5_wo;   // bytes of its weight packs
+    // c5k: the same convolutions K-SPLIT on small grids — every K chunk is a job of the launch and writes fp32 partial sums,
+    // pointwise kernels (st_pointwise.hip) add them and apply the gates
+    bool c5k; int ks_g, ks_o, nt_o; size_t k_wc[6], k_wm[6], k_wo[6];
 };
 // conv_o on c5: 64-column N tiles, or 32-column ones when those would leave the chip half empty (B = 128 on 16x16 maps, Ch = 128: 256
 // workgroups of four waves = one wave per SIMD; 512 at 32 columns)
@@ -39,10 +42,21 @@ static inline int c5f_nt_o(const vpx_stlstm_desc* d) {
 // 128: 23.5 / 23.7 / 24.4 / 30.5 / 53.8 vs 13.7 / 14.1 / 17.1 / 26.9 / 58.5; 32x32 maps (128x128x3, 4 layers, 10 -> 30) B = 4 / 8 / 16:
 // 72.5 / 78.1 / 90.9 vs 45.0 / 53.0 / 83.5 — a c5 workgroup runs its whole K (200 steps of 96 MFMAs) on one CU, the first generation
 // splits K over workgroups when the pixel tiles do not fill the chip. c5 from 96 pixel tiles of 16x16 on.
+static bool c5_shape_ok(const vpx_stlstm_desc* d) {
+    return d->k == 5 && d->precision == VPX_PREC_BF16X3 && !(d->Ch & 31) && !(d->Cin & 7) && !d->layer_norm && !(g_experiment & 256);
+}
 bool c5_fwd_applicable(const vpx_stlstm_desc* d) {
     const long long mt = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
-    return d->k == 5 && d->precision == VPX_PREC_BF16X3 && !(d->Ch & 31) && !(d->Cin & 7) && !d->layer_norm && !(g_experiment & 256) &&
-           (mt >= 96 || (g_experiment & 1024));   // (bit 10 forces it on small grids: tests)
+    return c5_shape_ok(d) && (mt >= 96 || (g_experiment & 1024));   // (bit 10 forces the unsplit form on small grids: tests)
+}
+// below the bar: K-split jobs (VPX_OPT_EXPERIMENT bit 11 keeps the first-generation launches there)
+bool c5k_fwd_applicable(const vpx_stlstm_desc* d) { return c5_shape_ok(d) && !c5_fwd_applicable(d) && !(g_experiment & 2048); }
+// K chunks so that the launch has about 448 workgroups, every chunk at least four 8-channel stages (25 steps), at most six chunks
+static int c5k_chunks(long long wgs1, int S8) {
+    int ks = (int)((448 + wgs1 / 2) / (wgs1 > 0 ? wgs1 : 1));
+    if (ks > S8 / 4) ks = S8 / 4;
+    if (ks > 6) ks = 6;
+    return ks < 1 ? 1 : ks;
 }
 
 int check_st_desc(const vpx_stlstm_desc* d) {
@@ -92,6 +106,18 @@ int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
         L.c5_wm = align256(c5_wpk_bytes(d->Cin + d->Ch, d->Ch, 8, 3));
         L.c5_wo = align256(c5_wpk_bytes(2 * d->Ch, d->Ch, c5f_nt_o(d)));
     }
+    L.c5k = c5k_fwd_applicable(d);
+    if (L.c5k) {
+        const long long mt = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
+        L.ks_g = c5k_chunks(mt * ((7 * d->Ch + 127) / 128), (d->Cin + d->Ch) / 8);
+        L.nt_o = mt * ((d->Ch + 63) / 64) * 6 < 320 ? 2 : 4;
+        L.ks_o = c5k_chunks(mt * ((d->Ch + L.nt_o * 16 - 1) / (L.nt_o * 16)), 2 * d->Ch / 8);
+        for (int k = 0; k < L.ks_g; ++k) {
+            L.k_wc[k] = align256(c5_chunk_wpk_bytes(d->Cin + d->Ch, k, L.ks_g, 4 * d->Ch, 8));
+            L.k_wm[k] = align256(c5_chunk_wpk_bytes(d->Cin + d->Ch, k, L.ks_g, 3 * d->Ch, 8));
+        }
+        for (int k = 0; k < L.ks_o; ++k) L.k_wo[k] = align256(c5_chunk_wpk_bytes(2 * d->Ch, k, L.ks_o, d->Ch, L.nt_o));
+    }
     return VPX_OK;
 }
 
@@ -124,6 +150,11 @@ size_t vpx_stlstm_workspace_bytes(const vpx_stlstm_desc* d) {
     size_t b = align256(L.wpk_c * 4) + align256(L.wpk_m * 4) + align256(L.wpk_o * 4) + align256(L.wpk_l * 4);
     b += 2 * align256(L.n_state * 4);  // o_pre, lc
     if (L.c5) b += L.c5_wc + L.c5_wm + L.c5_wo + align256(L.n_x * 4) + 4 * align256(L.n_state * 4);   // packs; x, h, m, c_new, m_new in split format
+    if (L.c5k) {   // chunk packs; the split copies; partial sums of the gate groups (7Ch per chunk) / of conv_o (Ch per chunk)
+        for (int k = 0; k < L.ks_g; ++k) b += L.k_wc[k] + L.k_wm[k];
+        for (int k = 0; k < L.ks_o; ++k) b += L.k_wo[k];
+        b += align256(L.n_x * 4) + 4 * align256(L.n_state * 4) + align256((size_t)L.ks_g * 7 * L.n_state * 4) + align256((size_t)L.ks_o * L.n_state * 4);
+    }
     if (d->layout == VPX_LAYOUT_NCHW) b += align256(L.n_x * 4) + 8 * align256(L.n_state * 4);
     size_t bwd = 0;
     if (d->flags & VPX_FLAG_SAVE_FOR_BWD) bwd = stlstm_bwd_workspace_bytes(d);
@@ -165,6 +196,15 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         c5wc = (char*)ws.take(L.c5_wc / 4); c5wm = (char*)ws.take(L.c5_wm / 4); c5wo = (char*)ws.take(L.c5_wo / 4);
         x_sp = (char*)ws.take(L.n_x); h_sp = (char*)ws.take(L.n_state); m_sp = (char*)ws.take(L.n_state);
         cn_sp = (char*)ws.take(L.n_state); mn_sp = (char*)ws.take(L.n_state);
+    }
+    char *kwc[6] = {}, *kwm[6] = {}, *kwo[6] = {};
+    float *part_g = nullptr, *part_o = nullptr;
+    if (L.c5k && !d->layer_norm) {
+        for (int k = 0; k < L.ks_g; ++k) { kwc[k] = (char*)ws.take(L.k_wc[k] / 4); kwm[k] = (char*)ws.take(L.k_wm[k] / 4); }
+        for (int k = 0; k < L.ks_o; ++k) kwo[k] = (char*)ws.take(L.k_wo[k] / 4);
+        x_sp = (char*)ws.take(L.n_x); h_sp = (char*)ws.take(L.n_state); m_sp = (char*)ws.take(L.n_state);
+        cn_sp = (char*)ws.take(L.n_state); mn_sp = (char*)ws.take(L.n_state);
+        part_g = ws.take((size_t)L.ks_g * 7 * L.n_state); part_o = ws.take((size_t)L.ks_o * L.n_state);
     }
 
     if (d->layer_norm) {  // unfused LayerNorm path (stlstm_ln_api.hip); same layout adaptation around it
@@ -251,6 +291,54 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
             fill_plain_pack(pl, Ch, 0, L.ng_l);
             VPX_CHECK_HIP(launch_pack_weights(pl, wpk_l, stream));
         }
+    } else if (L.c5k) {
+        // ---- small grid: the same two gate groups, K-split into ks_g chunks = 2 * ks_g jobs of one launch writing partial sums ----
+        const long long npix = (long long)B * (long long)HW;
+        VPX_CHECK_HIP(launch_split_convert(xn, x_sp, npix, Cin, stream));
+        VPX_CHECK_HIP(launch_split_convert(hn, h_sp, npix, Ch, stream));
+        VPX_CHECK_HIP(launch_split_convert(mn, m_sp, npix, Ch, stream));
+        C5Plan cp{};
+        cp.B = B; cp.H = H; cp.W = Wd;
+        cp.src[0] = C5Src{x_sp, (long long)HW * Cin * 4, Cin * 4, 0};
+        cp.src[1] = C5Src{h_sp, (long long)HW * Ch * 4, Ch * 4, 0};
+        cp.src[2] = C5Src{m_sp, (long long)HW * Ch * 4, Ch * 4, 0};
+        const long long sx = (long long)Cin * L.taps, sh = (long long)Ch * L.taps;
+        for (int grp = 0; grp < 2; ++grp) {
+            C5Job full{};
+            full.nrange = 2;
+            full.r_src[0] = 0; full.r_c0[0] = 0; full.r_n[0] = Cin;
+            full.r_src[1] = grp ? 2 : 1; full.r_c0[1] = 0; full.r_n[1] = Ch;
+            full.epi = 0; full.Co = (grp ? 3 : 4) * Ch; full.ld = 7 * Ch; full.accumulate = 0;
+            full.out_bstride = (long long)HW * 7 * Ch;
+            C5PackRange prf[2];
+            if (grp == 0) prf[0] = C5PackRange{Wx, sx, (long long)L.taps, 0, {0, Ch, 2 * Ch, 6 * Ch}};
+            else prf[0] = C5PackRange{Wx, sx, (long long)L.taps, 0, {3 * Ch, 4 * Ch, 5 * Ch, 0}};
+            prf[1] = C5PackRange{grp ? Wm : Wh, sh, (long long)L.taps, 0, {0, Ch, 2 * Ch, 3 * Ch}};
+            for (int kk = 0; kk < L.ks_g; ++kk) {
+                C5Job& j = cp.job[cp.njobs++];
+                C5PackRange pr[3];
+                c5_chunk_job(full, prf, kk, L.ks_g, j, pr);
+                j.wpk = grp ? kwm[kk] : kwc[kk];
+                j.out = part_g + (size_t)kk * 7 * L.n_state + (grp ? 4 * Ch : 0);
+                if ((rc = c5_prepare_job(j, 8, pr, grp ? 3 : 4, 0, packed, stream, 1))) return rc;
+            }
+        }
+        VPX_CHECK_HIP(launch_c5(cp, 8, stream));
+        STGatesKSArgs ga{};
+        ga.npix = npix; ga.Ch = Ch; ga.ks = L.ks_g; ga.pstride = (long long)(7 * L.n_state); ga.fbias = 1.0f;
+        ga.part = part_g; ga.c = cn; ga.m = mn;
+        ga.c_new = cO; ga.m_new = mO; ga.delta_c = dcO; ga.delta_m = dmO; ga.o_pre = o_pre; ga.gates_c = gates_c; ga.gates_m = gates_m;
+        ga.cn_sp = cn_sp; ga.mn_sp = mn_sp;
+        VPX_CHECK_HIP(launch_st_gates_ks(ga, stream));
+        if (!packed) {   // conv_last's first-generation pack (used when the streaming form does not apply)
+            PackDesc pl{};
+            pl.seg[0] = PackSeg{Wlast, (long long)2 * Ch, 1, 0, Ch};
+            pl.seg[1] = PackSeg{Wlast, (long long)2 * Ch, 1, Ch, Ch};
+            memcpy(pl.stage, L.stage_l, sizeof(ConvStage) * L.nstage_l);
+            pl.nstage = L.nstage_l; pl.chunks_total = L.chunks_l; pl.prec = d->precision; pl.taps = 1;
+            fill_plain_pack(pl, Ch, 0, L.ng_l);
+            VPX_CHECK_HIP(launch_pack_weights(pl, wpk_l, stream));
+        }
     } else
     // ---- weight repack (skipped when the caller vouches the workspace still holds it) ----
     if (!(d->flags & VPX_FLAG_WEIGHTS_PACKED)) {
@@ -290,7 +378,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
 
 
     // ---- launch 1: c group ----
-    if (!L.c5) {
+    if (!L.c5 && !L.c5k) {
         ConvPlan P = base_plan(d, k);
         set_plan_tiles(P, L.mw_g);
         P.nseg = 2;
@@ -319,7 +407,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         P.nseg = 2;
         P.seg[0] = ConvSeg{cO, (long long)(HW * Ch), Ch, 0};
         P.seg[1] = ConvSeg{mO, (long long)(HW * Ch), Ch, 0};
-        if (L.c5) {   // the gate epilogues left c_new / m_new in the split format as well: staged without conversion
+        if (L.c5 || L.c5k) {   // the gate stage left c_new / m_new in the split format as well: staged without conversion
             P.seg[0] = ConvSeg{reinterpret_cast<const float*>(cn_sp), (long long)(HW * Ch), Ch, 0, 1};
             P.seg[1] = ConvSeg{reinterpret_cast<const float*>(mn_sp), (long long)(HW * Ch), Ch, 0, 1};
         }
@@ -349,6 +437,31 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         C5PackRange pr[2] = {C5PackRange{Wo, so, (long long)L.taps, 0, {0, 0, 0, 0}}, C5PackRange{Wo, so, (long long)L.taps, Ch, {0, 0, 0, 0}}};
         if ((rc = c5_prepare_job(j, c5f_nt_o(d), pr, 0, 0, packed, stream))) return rc;
         VPX_CHECK_HIP(launch_c5(cp, c5f_nt_o(d), stream));
+    } else if (L.c5k) {
+        C5Plan cp{};
+        cp.B = B; cp.H = H; cp.W = Wd;
+        cp.src[0] = C5Src{cn_sp, (long long)HW * Ch * 4, Ch * 4, 0};
+        cp.src[1] = C5Src{mn_sp, (long long)HW * Ch * 4, Ch * 4, 0};
+        C5Job full{};
+        full.nrange = 2;
+        full.r_src[0] = 0; full.r_c0[0] = 0; full.r_n[0] = Ch;
+        full.r_src[1] = 1; full.r_c0[1] = 0; full.r_n[1] = Ch;
+        full.epi = 0; full.Co = Ch; full.ld = Ch; full.accumulate = 0; full.out_bstride = (long long)HW * Ch;
+        const long long so = (long long)2 * Ch * L.taps;
+        const C5PackRange prf[2] = {C5PackRange{Wo, so, (long long)L.taps, 0, {0, 0, 0, 0}}, C5PackRange{Wo, so, (long long)L.taps, Ch, {0, 0, 0, 0}}};
+        for (int kk = 0; kk < L.ks_o; ++kk) {
+            C5Job& j = cp.job[cp.njobs++];
+            C5PackRange pr[3];
+            c5_chunk_job(full, prf, kk, L.ks_o, j, pr);
+            j.wpk = kwo[kk];
+            j.out = part_o + (size_t)kk * L.n_state;
+            if ((rc = c5_prepare_job(j, L.nt_o, pr, 0, 0, packed, stream))) return rc;
+        }
+        VPX_CHECK_HIP(launch_c5(cp, L.nt_o, stream));
+        STOutKSArgs oa{};
+        oa.n = (long long)L.n_state; oa.ks = L.ks_o; oa.pstride = (long long)L.n_state; oa.part = part_o;
+        oa.o_pre = o_pre; oa.lc = lc; oa.h_new = hO; oa.o_save = o_save; oa.tl_save = tl_save;
+        VPX_CHECK_HIP(launch_st_out_ks(oa, stream));
     } else {
         ConvPlan P = base_plan(d, k);
         set_plan_tiles(P, L.mw_o);

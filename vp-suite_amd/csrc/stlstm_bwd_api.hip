@@ -23,7 +23,9 @@ struct STBwdLayout {
     // stw (wgrad2.hip): the four k x k weight gradients in one launch on split operands — 5x5, bf16x3, channels in 8s
     bool stw; int stw_pairs, stw_ns;
     // c5 (convq.hip): the k x k data gradients on 16x16-pixel tiles over the split-format dG8, two launches (conv_o's adjoint; dx | dh | dm)
-    bool c5; size_t c5_wpk[5];   // bytes of the packs: conv_o -> c, conv_o -> m, dx, dh, dm
+    // slots: conv_o -> c, conv_o -> m, dx, dh, dm. On small grids (< 96 pixel tiles) every slot's K is cut into c5_ks chunks that run
+    // as separate jobs writing fp32 partial sums (no atomics), added by sum_partials_kernel (st_pointwise.hip)
+    bool c5; int c5_ks[5]; size_t c5_wpk[5][6]; size_t c5_part[5];   // bytes of the chunk packs; floats of a slot's partial buffers (0: none)
 };
 constexpr int C5_NT = 4;   // 64-column N tiles: 6 jobs x 128 pixel tiles of unequal K balance over the chip (see convq.hip)
 
@@ -78,14 +80,22 @@ int st_bwd_layout(const vpx_stlstm_desc* d, STBwdLayout& L) {
         }
     }
     // VPX_OPT_EXPERIMENT bit 7 keeps the first-generation data-gradient launches (A/B runs, tests)
-    // ... from 96 pixel tiles of 16x16 on (the grid rule of the forward launches, stlstm_api.hip: below, the first generation's K-split
-    // data gradients fill the chip; measured training step at 16x16 maps, c5 vs first-generation data gradients: B = 8 130 vs 78 ms,
-    // B = 32 165 vs 136 ms, B = 128 361 vs ~405 ms)
+    // From 96 pixel tiles of 16x16 on, a job runs its whole K (the grid rule of the forward launches, stlstm_api.hip; measured training
+    // step at 16x16 maps, unsplit c5 vs first-generation K-split data gradients: B = 8 130 vs 78 ms, B = 32 165 vs 136 ms, B = 128 361
+    // vs ~405 ms); below, the K of every slot is cut into chunks (bit 11 of VPX_OPT_EXPERIMENT keeps the first generation there).
     const long long mt16 = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
-    L.c5 = L.stw && !(g_experiment & 128) && (mt16 >= 96 || (g_experiment & 1024));
+    const bool big = mt16 >= 96 || (g_experiment & 1024);
+    L.c5 = L.stw && !(g_experiment & 128) && (big || !(g_experiment & 2048));
     if (L.c5) {
         const int K[5] = {Ch, Ch, 7 * Ch, 4 * Ch, 3 * Ch}, Co[5] = {Ch, Ch, Cin, Ch, Ch};
-        for (int i = 0; i < 5; ++i) L.c5_wpk[i] = align256(c5_wpk_bytes(K[i], Co[i], C5_NT));
+        const int ks_small[5] = {4, 4, 6, 3, 3}, ks_mid[5] = {2, 2, 4, 2, 2};
+        for (int i = 0; i < 5; ++i) {
+            int ks = big ? 1 : (mt16 <= 16 ? ks_small[i] : ks_mid[i]);
+            if (ks > K[i] / 32) ks = K[i] / 32 > 0 ? K[i] / 32 : 1;   // at least four 8-channel stages per chunk
+            L.c5_ks[i] = ks;
+            for (int k = 0; k < ks; ++k) L.c5_wpk[i][k] = align256(c5_chunk_wpk_bytes(K[i], k, ks, Co[i], C5_NT));
+            L.c5_part[i] = ks > 1 ? (size_t)ks * (i == 2 ? L.n_x : L.n_state) : 0;
+        }
     }
     return VPX_OK;
 }
@@ -100,7 +110,7 @@ size_t stlstm_bwd_workspace_bytes(const vpx_stlstm_desc* d) {
     b += align256(L.o.wpk * 4) + align256(L.l.wpk * 4) + align256(L.x.wpk * 4) + align256(L.h.wpk * 4) + align256(L.m.wpk * 4);
     b += align256(L.slab_floats * 4);
     if (L.stw) b += align256(L.n_x * 4) + 4 * align256(L.n_state * 4);   // split copies: x, h, m, c_new, m_new
-    if (L.c5) for (int i = 0; i < 5; ++i) b += L.c5_wpk[i];
+    if (L.c5) for (int i = 0; i < 5; ++i) { for (int k = 0; k < L.c5_ks[i]; ++k) b += L.c5_wpk[i][k]; b += align256(L.c5_part[i] * 4); }
     if (d->layout == VPX_LAYOUT_NCHW) b += 2 * align256(L.n_x * 4) + 14 * align256(L.n_state * 4);
     return b;
 }
@@ -216,8 +226,12 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         x_sp = (char*)ws.take(L.n_x);
         for (auto& q : st_sp) q = (char*)ws.take(L.n_state);
     }
-    char* c5w[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (L.c5) for (int i = 0; i < 5; ++i) c5w[i] = (char*)ws.take(L.c5_wpk[i] / 4);
+    char* c5w[5][6] = {};
+    float* c5p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (L.c5) for (int i = 0; i < 5; ++i) {
+        for (int k = 0; k < L.c5_ks[i]; ++k) c5w[i][k] = (char*)ws.take(L.c5_wpk[i][k] / 4);
+        if (L.c5_part[i]) c5p[i] = ws.take(L.c5_part[i]);
+    }
 
     const float *xn = x, *hn = h, *cn = c, *mn = m, *cnn = c_new, *mnn = m_new;
     const float *g_h = dh_new, *g_c = dc_new, *g_m = dm_new, *g_dc = ddelta_c, *g_dm = ddelta_m;
@@ -288,24 +302,47 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     cp.B = B; cp.H = H; cp.W = Wd;
     cp.src[0] = C5Src{reinterpret_cast<const char*>(dG7), (long long)HW * ldG * 4, ldG * 4, 0};
     // rng[i] = {source channel 0, channels, weight row 0}: the job's K = channel ranges of dG8, each multiplying rows of `w`
+    struct Pending { float* out; const float* part; long long n; int ks, acc; } pend[5];
+    int npend = 0;
     auto c5_job = [&](int slot, int Co_, float* out, int ld_out, int acc, const float* w, long long s_row, int w_col0, int nrange,
                       const int (*rng)[3]) -> int {
-        C5Job& j = cp.job[cp.njobs++];
-        j = C5Job{};
-        j.nrange = nrange;
-        C5PackRange pr[3] = {};
+        C5Job full{};
+        full.nrange = nrange;
+        C5PackRange prf[3] = {};
         for (int i = 0; i < nrange; ++i) {
-            j.r_src[i] = 0; j.r_c0[i] = rng[i][0]; j.r_n[i] = rng[i][1];
-            pr[i] = C5PackRange{w, (long long)L.taps, s_row, rng[i][2], {w_col0, 0, 0, 0}};   // data gradient: column = the weight's input channel
+            full.r_src[i] = 0; full.r_c0[i] = rng[i][0]; full.r_n[i] = rng[i][1];
+            prf[i] = C5PackRange{w, (long long)L.taps, s_row, rng[i][2], {w_col0, 0, 0, 0}};   // data gradient: column = the weight's input channel
         }
-        j.Co = Co_; j.ld = ld_out; j.accumulate = acc; j.wpk = c5w[slot]; j.out = out; j.out_bstride = (long long)HW * ld_out;
-        return c5_prepare_job(j, C5_NT, pr, 0, 1, packed, stream);
+        full.Co = Co_; full.ld = ld_out; full.accumulate = acc; full.out = out; full.out_bstride = (long long)HW * ld_out;
+        const int ks = L.c5_ks[slot];
+        if (ks == 1) {
+            C5Job& j = cp.job[cp.njobs++];
+            j = full; j.wpk = c5w[slot][0];
+            return c5_prepare_job(j, C5_NT, prf, 0, 1, packed, stream);
+        }
+        const long long n = (long long)B * (long long)HW * ld_out;
+        for (int kk = 0; kk < ks; ++kk) {   // chunk jobs write partial sums; sum_partials_kernel adds them (onto `out` when acc)
+            C5Job& j = cp.job[cp.njobs++];
+            C5PackRange pr[3];
+            c5_chunk_job(full, prf, kk, ks, j, pr);
+            j.wpk = c5w[slot][kk]; j.accumulate = 0; j.out = c5p[slot] + (size_t)kk * n;
+            const int rcj = c5_prepare_job(j, C5_NT, pr, 0, 1, packed, stream);
+            if (rcj) return rcj;
+        }
+        pend[npend++] = Pending{out, c5p[slot], n, ks, acc};
+        return VPX_OK;
+    };
+    auto c5_flush = [&]() -> int {
+        if (cp.njobs) VPX_CHECK_HIP(launch_c5(cp, C5_NT, stream));
+        for (int i = 0; i < npend; ++i) VPX_CHECK_HIP(launch_sum_partials(pend[i].out, pend[i].part, pend[i].n, pend[i].ks, pend[i].n, pend[i].acc, stream));
+        cp.njobs = 0; npend = 0;
+        return VPX_OK;
     };
     if (c5) {
         const int ro[1][3] = {{3 * Ch, Ch, 0}};
         if ((rc = c5_job(0, Ch, dcn_conv, Ch, 0, Wo, (long long)2 * Ch * L.taps, 0, 1, ro))) return rc;
         if ((rc = c5_job(1, Ch, dmn_conv, Ch, 0, Wo, (long long)2 * Ch * L.taps, Ch, 1, ro))) return rc;
-        VPX_CHECK_HIP(launch_c5(cp, C5_NT, stream));
+        if ((rc = c5_flush())) return rc;
     }
     {
         PackDesc pd{};
@@ -367,7 +404,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
             const int rm[1][3] = {{4 * Ch, 3 * Ch, 0}};
             if ((rc = c5_job(4, Ch, dmn, Ch, 1, Wm, (long long)Ch * L.taps, 0, 1, rm))) return rc;   // onto dm_new_total * f' written by stage C
         }
-        if (cp.njobs) VPX_CHECK_HIP(launch_c5(cp, C5_NT, stream));
+        if ((rc = c5_flush())) return rc;
     }
     if (!c5 && dxn) {
         PackDesc pd{};

@@ -420,6 +420,23 @@ static inline int wgrad2_slices(int target, int rows128, int n_ctiles, bool half
 hipError_t launch_wgrad2(const WgradArgs& a, int max_slices, int* used_slices, int* tail_col0, int* tail_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce_tail(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int tail_col0, int tail_slices,
                                     hipStream_t s);
+// st_pointwise.hip: the pointwise stages behind K-split c5 launches (small grids)
+struct STGatesKSArgs {
+    long long npix; int Ch, ks; long long pstride; float fbias;
+    const float* part;                       // ks buffers [B,HW,7Ch] of pre-activation partial sums: (i,f,g,o | i',f',g')
+    const float* c; const float* m;
+    float *c_new, *m_new, *delta_c, *delta_m, *o_pre, *gates_c, *gates_m;   // gates_*: [B,HW,3Ch] or null
+    char *cn_sp, *mn_sp;                     // c_new / m_new once more in the split format, or null
+};
+struct STOutKSArgs {
+    long long n; int ks; long long pstride;  // n = B*HW*Ch
+    const float* part;                       // ks buffers [B,HW,Ch]: partial sums of conv_o(mem)
+    const float* o_pre; const float* lc;
+    float *h_new, *o_save, *tl_save;
+};
+hipError_t launch_st_gates_ks(const STGatesKSArgs& a, hipStream_t s);
+hipError_t launch_st_out_ks(const STOutKSArgs& a, hipStream_t s);
+hipError_t launch_sum_partials(float* out, const float* part, long long pstride, int ks, long long n, int accumulate, hipStream_t s);
 // conv1.hip, c1: 1x1 convolution as a streaming kernel (weights resident in registers), fp32 NHWC in and out, bf16x3 arithmetic
 struct C1Args {
     const float* x[2]; int xld[2], xc[2];   // up to two sources concatenated along K: pixel pitch (floats), channels (multiples of 32; xc[1] = 0: one source)
@@ -431,7 +448,7 @@ struct C1Args {
 bool c1_applicable(const C1Args& a, int prec);   // (Co, K) in {(128, 256), (256, 128), (128, 128)}, aligned operands, bf16x3
 hipError_t launch_c1(const C1Args& a, hipStream_t s);
 // convq.hip, c5: 5x5 'same' convolutions on 16x16-pixel tiles over ONE split-format source, a table of jobs per launch
-constexpr int C5_MAX_JOBS = 6;
+constexpr int C5_MAX_JOBS = 12;
 struct C5Src { const char* p; long long bstride; int prow, _pad; };   // split-format tensor [B][H][W][C]: bytes per image / per pixel
 struct C5Job {
     int nrange, r_src[3], r_c0[3], r_n[3];   // the job's K: channel ranges [r_c0, r_c0 + r_n) of source r_src, multiples of 8, in stage order
@@ -452,7 +469,9 @@ struct C5Plan {
 };
 struct C5PackRange { const float* w; long long s_oc, s_c; int c0; int gate0[4]; };   // weights of one K range (see c5_pack_kernel)
 size_t c5_wpk_bytes(int K, int Co, int NT, int gates = 0);
-int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s);
+int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s, int gate_major = 0);
+void c5_chunk_job(const C5Job& full, const C5PackRange* prf, int k, int ks, C5Job& j, C5PackRange* pr);   // K-split: chunk k of ks
+size_t c5_chunk_wpk_bytes(int K, int k, int ks, int cols, int NT);
 hipError_t launch_c5(const C5Plan& P, int NT, hipStream_t s);   // NT = 8: 128-column N tiles, 4: 64-column
 // wgrad2.hip, stw: the four 5x5 weight gradients of one ST-LSTM cell step in one launch (operands in split format)
 constexpr int STW_MAX_PAIRS = 48;
