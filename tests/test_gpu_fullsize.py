@@ -183,6 +183,35 @@ def test_c1_literal_batch4_full_model_vs_oracle(vpx):
     assert _relmax(pred3[:1], ref3) < 1e-4 and not torch.equal(pred3, pred)
 
 
+@pytest.mark.parametrize("img,chan,pred", [(64, 1, 10), (128, 3, 7)])
+def test_small_batch_stream_pipeline_is_bit_identical(vpx, img, chan, pred):
+    """Small-batch inference cuts the sequence into time chunks that the blocks run pipelined on side streams (models/ef_conv_lstm.py):
+    same kernels, same arithmetic — the prediction must equal the one-stream order bit for bit, run after run, also right after
+    unrelated work was queued on the main stream (ordering through events, no stale reads)."""
+    from vp_suite_amd.models import ef_conv_lstm as ef
+    m = _model("convlstm-shi", f"ef.pipe{img}", img_shape=(chan, img, img), cell_precision="bf16x3")
+    x = seeded_rand((4, 10, chan, img, img), name_seed(f"ef.pipe{img}.x")).cuda()
+    assert ef._pipeline_chunks(4, 10, m.encoder.rnn1) is not None or img > 64
+    prev = ef.PIPELINE_CHUNKS
+    try:
+        with torch.no_grad():
+            ef.PIPELINE_CHUNKS = 0
+            want, _ = m(x, pred_frames=pred)
+            ef.PIPELINE_CHUNKS = 2
+            outs = []
+            for rep in range(3):
+                junk = torch.rand(2048, 2048, device="cuda") @ torch.rand(2048, 2048, device="cuda")   # main-stream work in front
+                got, _ = m(x + 0.0, pred_frames=pred)
+                outs.append(got.clone())
+                del junk
+            ef.PIPELINE_CHUNKS = 3
+            got3, _ = m(x, pred_frames=pred)
+    finally:
+        ef.PIPELINE_CHUNKS = prev
+    for got in outs + [got3]:
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("Cin", [16, 128])
 def test_stlstm_step_backward_at_batch128(vpx, Cin):
     """ST-LSTM step (PredRNN default shapes: 16 | 128 -> 128 channels, 16x16 maps, 5x5) forward + backward at B = 128 — the

@@ -41,27 +41,38 @@ hipError_t launch_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H
 // decoupling-loss tail. F.normalize(dim=2, eps=1e-12) then cosine_similarity(dim=2, eps=1e-8), abs, mean.
 // One thread per (b, co) walks the H*W axis (channels are contiguous -> coalesced across the wave).
 // ---------------------------------------------------------------------------------------------------------------
-// block = 32 channels x 8 pixel slices: every thread sums its slice of the H*W axis, LDS combines the 8 slices
-__global__ void decouple_stats_kernel(const float* __restrict__ yc, const float* __restrict__ ym,
-                                      float* __restrict__ stats, int B, int HW, int Ch) {
-    __shared__ float red[3][8][32];
-    const int b = blockIdx.x, co = blockIdx.y * 32 + (threadIdx.x & 31), slice = threadIdx.x >> 5;
+// block = 32 channels x 32 pixel slices: every thread sums its slice of the H*W axis with four loads of each operand in flight, LDS
+// combines the slices in a fixed order. (Round 3 had 8 slices and a serial walk: 40 us for a 32x32 map at B = 4 — 16 blocks on the
+// whole chip, one load in flight per thread.)
+__global__ __launch_bounds__(1024) void decouple_stats_kernel(const float* __restrict__ yc, const float* __restrict__ ym,
+                                                              float* __restrict__ stats, int B, int HW, int Ch) {
+    constexpr int NS = 32;
+    __shared__ float red[3][NS][32];
+    const int b = blockIdx.x, lane32 = threadIdx.x & 31, co = blockIdx.y * 32 + lane32, slice = threadIdx.x >> 5;
     float scc = 0.f, smm = 0.f, scm = 0.f;
     if (co < Ch) {
         const float* pc = yc + (size_t)b * HW * Ch + co;
         const float* pm = ym + (size_t)b * HW * Ch + co;
-        for (int p = slice; p < HW; p += 8) {
+        int p = slice;
+        for (; p + 3 * NS < HW; p += 4 * NS) {
+            float a[4], m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k] = pc[(size_t)(p + k * NS) * Ch]; m[k] = pm[(size_t)(p + k * NS) * Ch]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { scc += a[k] * a[k]; smm += m[k] * m[k]; scm += a[k] * m[k]; }
+        }
+        for (; p < HW; p += NS) {
             const float a = pc[(size_t)p * Ch], m = pm[(size_t)p * Ch];
             scc += a * a; smm += m * m; scm += a * m;
         }
     }
-    red[0][slice][threadIdx.x & 31] = scc;
-    red[1][slice][threadIdx.x & 31] = smm;
-    red[2][slice][threadIdx.x & 31] = scm;
+    red[0][slice][lane32] = scc;
+    red[1][slice][lane32] = smm;
+    red[2][slice][lane32] = scm;
     __syncthreads();
     if (slice == 0 && co < Ch) {
         scc = smm = scm = 0.f;
-        for (int s = 0; s < 8; ++s) { scc += red[0][s][threadIdx.x]; smm += red[1][s][threadIdx.x]; scm += red[2][s][threadIdx.x]; }
+        for (int s = 0; s < NS; ++s) { scc += red[0][s][lane32]; smm += red[1][s][lane32]; scm += red[2][s][lane32]; }
         const float nc = fmaxf(sqrtf(scc), 1e-12f), nm = fmaxf(sqrtf(smm), 1e-12f);
         // after normalisation |u| = sqrt(scc)/nc, |v| = sqrt(smm)/nm (1 unless degenerate); cos = u.v / max(|u||v|, 1e-8)
         const float un = sqrtf(scc) / nc, vn = sqrtf(smm) / nm;
@@ -121,7 +132,7 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 }
 
 hipError_t launch_decouple_stats(const float* yc, const float* ym, float* stats, int B, int HW, int Ch, hipStream_t s) {
-    hipLaunchKernelGGL(decouple_stats_kernel, dim3(B, (Ch + 31) / 32), dim3(256), 0, s, yc, ym, stats, B, HW, Ch);
+    hipLaunchKernelGGL(decouple_stats_kernel, dim3(B, (Ch + 31) / 32), dim3(1024), 0, s, yc, ym, stats, B, HW, Ch);
     return hipGetLastError();
 }
 hipError_t launch_decouple_mean(const float* stats, float* value, int n, hipStream_t s) {

@@ -149,6 +149,49 @@ def _block_out_split(rnn, next_stage, batch, seq_len):
     return _stage_takes_split(next_stage, batch * seq_len, rnn.enc_c, rnn.state_h, rnn.state_w, getattr(rnn, "precision", "f32"))
 
 
+# ---- small-batch inference: time-chunk pipeline over side streams ------------------------------------------------------------
+# At B = 4 (BASELINE configs[0]'s batch, configs[3]'s per-GPU shard) a cell step is 48-128 workgroups: half the chip or less, and the
+# reference's order — ALL T steps of block l, then block l + 1 (ef_blocks.py:67-82 batches over T for convenience only) — leaves it
+# that way for the whole forward. The dependency is per frame: block l + 1 at step t needs block l at step t. So the sequence is cut
+# into PIPELINE_CHUNKS time chunks; block l runs chunk c on ITS stream while block l + 1 runs chunk c - 1 on another (a layer keeps
+# its stream, so its recurrent state, workspace and weight packs never cross streams; a chunk's output sequence does, under an
+# event + record_stream). Same kernels, same arithmetic, bit-identical results.
+PIPELINE_CHUNKS = 2          #: 0 / 1 switches the pipeline off (A/B)
+PIPELINE_MAX_TILES = 256     #: applies while batch x 16x16-pixel tiles of the largest map stays at or below this
+
+_side = {}
+
+
+def _side_streams(device, n):
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), n)
+    if key not in _side:
+        _side[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _side[key]
+
+
+def _record(x, stream):
+    """x (tensor, SplitActivation or tuple of tensors) was produced on another stream and is about to be read on `stream`."""
+    if x is None:
+        return
+    if isinstance(x, ops.SplitActivation):
+        x.buf.record_stream(stream)
+    elif isinstance(x, (tuple, list)):
+        for t in x:
+            _record(t, stream)
+    else:
+        x.record_stream(stream)
+
+
+def _pipeline_chunks(batch, steps, rnn):
+    if PIPELINE_CHUNKS < 2 or torch.is_grad_enabled() or steps < 2 * PIPELINE_CHUNKS or not hasattr(rnn, "Wci"):
+        return None   # (ConvLSTM blocks only: their state is an (h, c) pair and their call takes it back)
+    tiles = batch * ((rnn.state_h + 15) // 16) * ((rnn.state_w + 15) // 16)
+    if tiles > PIPELINE_MAX_TILES:
+        return None
+    n = PIPELINE_CHUNKS
+    return [(steps * c // n, steps * (c + 1) // n) for c in range(n)]
+
+
 class Encoder(nn.Module):
     def __init__(self, subnets, rnns):
         super().__init__()
@@ -165,7 +208,37 @@ class Encoder(nn.Module):
             return rnn(input, None, seq_len=t, out_split=True)
         return rnn(input, None, seq_len=t)
 
+    def _forward_pipelined(self, input, chunks):
+        dev = input.device
+        main = torch.cuda.current_stream(dev)
+        streams = _side_streams(dev, self.blocks)
+        start = torch.cuda.Event()
+        start.record(main)
+        states = [None] * self.blocks
+        for t0, t1 in chunks:
+            cur, ev = input[:, t0:t1], start
+            for i in range(1, self.blocks + 1):
+                s = streams[i - 1]
+                rnn, subnet = getattr(self, f"rnn{i}"), getattr(self, f"stage{i}")
+                nxt = getattr(self, f"stage{i + 1}") if i < self.blocks else None
+                with torch.cuda.stream(s):
+                    s.wait_event(ev)
+                    _record(cur, s)
+                    seq = _apply_framewise(subnet, cur, getattr(rnn, "precision", "f32"), consumer=rnn)
+                    b, t = seq.shape[:2]
+                    osp = (i == self.blocks or nxt is not None) and _block_out_split(rnn, nxt, b, t)
+                    cur, states[i - 1] = rnn(seq, states[i - 1], seq_len=t, out_split=True) if osp else rnn(seq, states[i - 1], seq_len=t)
+                    ev = torch.cuda.Event()
+                    ev.record(s)
+        for s in streams:
+            main.wait_stream(s)
+        _record(states, main)
+        return tuple(states)
+
     def forward(self, input):
+        chunks = _pipeline_chunks(input.shape[0], input.shape[1], self.rnn1) if input.is_cuda else None
+        if chunks:
+            return self._forward_pipelined(input, chunks)
         hidden_states = []
         for i in range(1, self.blocks + 1):
             nxt = getattr(self, f"stage{i + 1}") if i < self.blocks else None   # the last block's sequence has no reader (states only)
@@ -191,7 +264,46 @@ class Forecaster(nn.Module):
             input, _ = rnn(input, state, pred_frames)
         return _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"), consumer=next_rnn)
 
+    def _forward_pipelined(self, hidden_states, chunks):
+        dev = hidden_states[0][0].device
+        main = torch.cuda.current_stream(dev)
+        streams = _side_streams(dev, self.blocks)
+        start = torch.cuda.Event()
+        start.record(main)
+        states = list(hidden_states)
+        for st, s in zip(states, streams):
+            _record(st, s)
+        outs = []
+        for t0, t1 in chunks:
+            cur, ev = None, start
+            for i in range(self.blocks, 0, -1):
+                s = streams[i - 1]
+                rnn, subnet = getattr(self, f"rnn{i}"), getattr(self, f"stage{i}")
+                nxt_rnn = getattr(self, f"rnn{i - 1}") if i > 1 else None
+                with torch.cuda.stream(s):
+                    s.wait_event(ev)
+                    _record(cur, s)
+                    b = states[i - 1][0].shape[0]
+                    if _block_out_split(rnn, subnet, b, t1 - t0):
+                        out, states[i - 1] = rnn(cur, states[i - 1], t1 - t0, out_split=True)
+                    else:
+                        out, states[i - 1] = rnn(cur, states[i - 1], t1 - t0)
+                    cur = _apply_framewise(subnet, out, getattr(rnn, "precision", "f32"), consumer=nxt_rnn)
+                    ev = torch.cuda.Event()
+                    ev.record(s)
+            outs.append(cur)
+        with torch.cuda.stream(streams[0]):
+            pred = torch.cat(outs, dim=1)
+        for s in streams:
+            main.wait_stream(s)
+        _record(pred, main)
+        return pred
+
     def forward(self, hidden_states, pred_frames):
+        st0 = hidden_states[0][0]
+        chunks = _pipeline_chunks(st0.shape[0], pred_frames, self.rnn1) if st0.is_cuda else None
+        if chunks:
+            return self._forward_pipelined(hidden_states, chunks)
         # like the reference (ef_blocks.py:109-110) the top block is addressed as stage3/rnn3 and gets no input
         input = self.forward_by_stage(None, hidden_states[-1], pred_frames, self.stage3, self.rnn3,
                                       getattr(self, f"rnn{self.blocks - 1}", None) if self.blocks > 1 else None)
