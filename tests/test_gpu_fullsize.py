@@ -184,32 +184,46 @@ def test_c1_literal_batch4_full_model_vs_oracle(vpx):
 
 
 @pytest.mark.parametrize("img,chan,pred", [(64, 1, 10), (128, 3, 7)])
-def test_small_batch_stream_pipeline_is_bit_identical(vpx, img, chan, pred):
-    """Small-batch inference cuts the sequence into time chunks that the blocks run pipelined on side streams (models/ef_conv_lstm.py):
-    same kernels, same arithmetic — the prediction must equal the one-stream order bit for bit, run after run, also right after
-    unrelated work was queued on the main stream (ordering through events, no stale reads)."""
+def test_small_batch_pipelined_graph_matches_one_stream_order(vpx, img, chan, pred):
+    """Small-batch inference cuts the sequence into time chunks that the blocks run pipelined on side streams, captured and replayed as
+    one HIP graph (models/ef_conv_lstm.py). Same kernels per frame; chunked calls see other launch shapes (20 instead of 40 frames per
+    glue launch: other K splits), so predictions agree with the one-stream eager order to fp32 summation order (2e-6 of the maximum),
+    are BIT-identical run after run in deterministic mode — also with unrelated work queued in front on the main stream and after the
+    caller has overwritten its input — and follow an in-place weight update (the graph is re-captured)."""
     from vp_suite_amd.models import ef_conv_lstm as ef
     m = _model("convlstm-shi", f"ef.pipe{img}", img_shape=(chan, img, img), cell_precision="bf16x3")
     x = seeded_rand((4, 10, chan, img, img), name_seed(f"ef.pipe{img}.x")).cuda()
-    assert ef._pipeline_chunks(4, 10, m.encoder.rnn1) is not None or img > 64
-    prev = ef.PIPELINE_CHUNKS
+    prev = ef.GRAPH_SMALL_BATCH
+    torch.use_deterministic_algorithms(True)
     try:
         with torch.no_grad():
-            ef.PIPELINE_CHUNKS = 0
+            ef.GRAPH_SMALL_BATCH = False
             want, _ = m(x, pred_frames=pred)
-            ef.PIPELINE_CHUNKS = 2
+            assert getattr(m, "_vpx_graph", None) is None
+            ef.GRAPH_SMALL_BATCH = True
             outs = []
             for rep in range(3):
                 junk = torch.rand(2048, 2048, device="cuda") @ torch.rand(2048, 2048, device="cuda")   # main-stream work in front
-                got, _ = m(x + 0.0, pred_frames=pred)
-                outs.append(got.clone())
+                xin = x.clone()
+                got, _ = m(xin, pred_frames=pred)
+                xin.zero_()                                                                             # the graph has its own copy
+                outs.append(got)
                 del junk
-            ef.PIPELINE_CHUNKS = 3
-            got3, _ = m(x, pred_frames=pred)
+            assert m._vpx_graph[0][0] != "failed"
+            for got in outs:
+                assert _relmax(got, want) < 2e-6
+                assert torch.equal(got, outs[0])
+            m.encoder.rnn1._conv.weight.mul_(1.25)
+            ef.GRAPH_SMALL_BATCH = False
+            want2, _ = m(x, pred_frames=pred)
+            ef.GRAPH_SMALL_BATCH = True
+            got2, _ = m(x, pred_frames=pred)
+            assert _relmax(got2, want2) < 2e-6 and _relmax(got2, want) > 1e-4
     finally:
-        ef.PIPELINE_CHUNKS = prev
-    for got in outs + [got3]:
-        assert torch.equal(got, want)
+        ef.GRAPH_SMALL_BATCH = prev
+        torch.use_deterministic_algorithms(False)
+    import pickle
+    assert pickle.loads(pickle.dumps(m)) is not None   # the captured graph is not part of the pickled model
 
 
 @pytest.mark.parametrize("Cin", [16, 128])

@@ -156,9 +156,12 @@ def _block_out_split(rnn, next_stage, batch, seq_len):
 # into PIPELINE_CHUNKS time chunks; block l runs chunk c on ITS stream while block l + 1 runs chunk c - 1 on another (a layer keeps
 # its stream, so its recurrent state, workspace and weight packs never cross streams; a chunk's output sequence does, under an
 # event + record_stream). Same kernels, same arithmetic, bit-identical results.
-PIPELINE_CHUNKS = 2          #: 0 / 1 switches the pipeline off (A/B)
+PIPELINE_CHUNKS = 5          #: 0 / 1 switches the pipeline off (A/B)
+GRAPH_SMALL_BATCH = True     #: replay the pipelined forward as ONE HIP graph (issued eagerly it is host-bound: measured B = 4, 64x64:
+                             #: 1.82 ms one stream, 2.00 / 2.77 / 3.65 ms with 2 / 3 / 5 chunks — every chunk doubles the library calls)
 PIPELINE_MAX_TILES = 256     #: applies while batch x 16x16-pixel tiles of the largest map stays at or below this
 
+_PIPE_ACTIVE = False         # set while the graphed forward warms up / captures (and by tests): the chunked order is only worth it inside a graph
 _side = {}
 
 
@@ -171,7 +174,7 @@ def _side_streams(device, n):
 
 def _record(x, stream):
     """x (tensor, SplitActivation or tuple of tensors) was produced on another stream and is about to be read on `stream`."""
-    if x is None:
+    if x is None or torch.cuda.is_current_stream_capturing():   # (a captured graph owns its memory for good: nothing to guard)
         return
     if isinstance(x, ops.SplitActivation):
         x.buf.record_stream(stream)
@@ -183,8 +186,10 @@ def _record(x, stream):
 
 
 def _pipeline_chunks(batch, steps, rnn):
-    if PIPELINE_CHUNKS < 2 or torch.is_grad_enabled() or steps < 2 * PIPELINE_CHUNKS or not hasattr(rnn, "Wci"):
+    if PIPELINE_CHUNKS < 2 or torch.is_grad_enabled() or steps < PIPELINE_CHUNKS or not hasattr(rnn, "Wci"):
         return None   # (ConvLSTM blocks only: their state is an (h, c) pair and their call takes it back)
+    if not (_PIPE_ACTIVE or torch.cuda.is_current_stream_capturing()):
+        return None
     tiles = batch * ((rnn.state_h + 15) // 16) * ((rnn.state_w + 15) // 16)
     if tiles > PIPELINE_MAX_TILES:
         return None
@@ -342,7 +347,7 @@ class Encoder_Forecaster(VPModel):
         enc_convs, enc_rnns, dec_convs, dec_rnns = self._build_encoder_decoder()
         self.encoder = Encoder(enc_convs, enc_rnns).to(self.device)
         self.forecaster = Forecaster(dec_convs, dec_rnns).to(self.device)
-        self.NON_CONFIG_VARS.extend(["encoder", "forecaster"])
+        self.NON_CONFIG_VARS.extend(["encoder", "forecaster", "_vpx_graph"])
 
     def _build_encoder_decoder(self):
         raise NotImplementedError
@@ -350,8 +355,75 @@ class Encoder_Forecaster(VPModel):
     def pred_1(self, x, **kwargs):
         return self(x, pred_frames=1, **kwargs)[0].squeeze(dim=1)
 
+    def _forward_eager(self, x, pred_frames):
+        return self.forecaster(self.encoder(x), pred_frames)
+
+    def _graph_key(self, x, pred_frames):
+        return (tuple(x.shape), x.dtype, x.device, int(pred_frames), PIPELINE_CHUNKS, ops._kernel_options(),
+                torch.are_deterministic_algorithms_enabled(), tuple(p._version for p in self.parameters()),
+                tuple(p.data_ptr() for p in self.parameters()))
+
+    def __getstate__(self):   # (the captured graph is a cache, not state: models are pickled whole, vpsuite.py:394)
+        d = self.__dict__.copy()
+        d.pop("_vpx_graph", None)
+        return d
+
+    def _graphable(self, x, pred_frames):
+        global _PIPE_ACTIVE
+        if not (GRAPH_SMALL_BATCH and x.is_cuda and not torch.is_grad_enabled() and ops.PROFILE is None
+                and not torch.cuda.is_current_stream_capturing()):
+            return False
+        prev, _PIPE_ACTIVE = _PIPE_ACTIVE, True
+        try:
+            return (_pipeline_chunks(x.shape[0], x.shape[1], self.encoder.rnn1) is not None
+                    and _pipeline_chunks(x.shape[0], pred_frames, self.forecaster.rnn1) is not None)
+        finally:
+            _PIPE_ACTIVE = prev
+
+    def _forward_graphed(self, x, pred_frames):
+        """Small-batch inference: the pipelined forward captured once per (shape, horizon, weight versions) and replayed — the
+        pipeline multiplies the library calls and is host-bound when issued eagerly. The graph reads a private copy of the input and
+        the caller gets a copy of its output; workspaces the captured kernels use are pinned with the graph."""
+        key = self._graph_key(x, pred_frames)
+        ent = getattr(self, "_vpx_graph", None)
+        if ent is None or ent[0] != key:
+            if ent is not None and ent[0] == ("failed",) + key:
+                return self._forward_eager(x, pred_frames)
+            main = torch.cuda.current_stream(x.device)
+            sx = x.clone()
+            warm = torch.cuda.Stream(device=x.device)
+            warm.wait_stream(main)
+            global _PIPE_ACTIVE
+            prev, _PIPE_ACTIVE = _PIPE_ACTIVE, True
+            try:
+                with torch.cuda.stream(warm):   # (capture needs warmed-up kernels: attributes set, packs made, caches filled)
+                    for _ in range(2):
+                        self._forward_eager(sx, pred_frames)
+                main.wait_stream(warm)
+                pins = [e[3] for e in list(ops._clstm_ws.ents.values()) + list(ops._convq_ws.ents.values())]
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    so = self._forward_eager(sx, pred_frames)
+                ent = (key, g, sx, so, pins)
+            except Exception as exc:   # capture is an optimisation: say so once and stay on the eager path for this key
+                import warnings
+                warnings.warn(f"EF small-batch graph capture failed ({type(exc).__name__}: {exc}); running eagerly", RuntimeWarning)
+                _PIPE_ACTIVE = prev
+                object.__setattr__(self, "_vpx_graph", (("failed",) + key,))
+                torch.cuda.synchronize()
+                return self._forward_eager(x, pred_frames)
+            finally:
+                _PIPE_ACTIVE = prev
+            object.__setattr__(self, "_vpx_graph", ent)
+        _, g, sx, so, _ = ent
+        sx.copy_(x)
+        g.replay()
+        return so.clone()
+
     def forward(self, x, pred_frames: int = 1, **kwargs):
-        return self.forecaster(self.encoder(x), pred_frames), None
+        if self._graphable(x, pred_frames):
+            return self._forward_graphed(x, pred_frames), None
+        return self._forward_eager(x, pred_frames), None
 
 
 class EF_ConvLSTM(Encoder_Forecaster):
