@@ -163,6 +163,16 @@ PIPELINE_MAX_TILES = 256     #: applies while batch x 16x16-pixel tiles of the l
 
 _PIPE_ACTIVE = False         # set while the graphed forward warms up / captures (and by tests): the chunked order is only worth it inside a graph
 _side = {}
+_events = []                 # events recorded while a capture is in flight stay alive until it ends (destroying one in between crashed the
+                             # runtime in hipStreamEndCapture); the graphed forward takes them over
+
+
+def _event(stream):
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    if torch.cuda.is_current_stream_capturing():
+        _events.append(ev)
+    return ev
 
 
 def _side_streams(device, n):
@@ -217,8 +227,7 @@ class Encoder(nn.Module):
         dev = input.device
         main = torch.cuda.current_stream(dev)
         streams = _side_streams(dev, self.blocks)
-        start = torch.cuda.Event()
-        start.record(main)
+        start = _event(main)
         states = [None] * self.blocks
         for t0, t1 in chunks:
             cur, ev = input[:, t0:t1], start
@@ -233,8 +242,7 @@ class Encoder(nn.Module):
                     b, t = seq.shape[:2]
                     osp = (i == self.blocks or nxt is not None) and _block_out_split(rnn, nxt, b, t)
                     cur, states[i - 1] = rnn(seq, states[i - 1], seq_len=t, out_split=True) if osp else rnn(seq, states[i - 1], seq_len=t)
-                    ev = torch.cuda.Event()
-                    ev.record(s)
+                    ev = _event(s)
         for s in streams:
             main.wait_stream(s)
         _record(states, main)
@@ -273,8 +281,7 @@ class Forecaster(nn.Module):
         dev = hidden_states[0][0].device
         main = torch.cuda.current_stream(dev)
         streams = _side_streams(dev, self.blocks)
-        start = torch.cuda.Event()
-        start.record(main)
+        start = _event(main)
         states = list(hidden_states)
         for st, s in zip(states, streams):
             _record(st, s)
@@ -294,8 +301,7 @@ class Forecaster(nn.Module):
                     else:
                         out, states[i - 1] = rnn(cur, states[i - 1], t1 - t0)
                     cur = _apply_framewise(subnet, out, getattr(rnn, "precision", "f32"), consumer=nxt_rnn)
-                    ev = torch.cuda.Event()
-                    ev.record(s)
+                    ev = _event(s)
             outs.append(cur)
         with torch.cuda.stream(streams[0]):
             pred = torch.cat(outs, dim=1)
@@ -402,9 +408,11 @@ class Encoder_Forecaster(VPModel):
                 main.wait_stream(warm)
                 pins = [e[3] for e in list(ops._clstm_ws.ents.values()) + list(ops._convq_ws.ents.values())]
                 g = torch.cuda.CUDAGraph()
+                del _events[:]
                 with torch.cuda.graph(g):
                     so = self._forward_eager(sx, pred_frames)
-                ent = (key, g, sx, so, pins)
+                ent = (key, g, sx, so, pins + list(_events))
+                del _events[:]
             except Exception as exc:   # capture is an optimisation: say so once and stay on the eager path for this key
                 import warnings
                 warnings.warn(f"EF small-batch graph capture failed ({type(exc).__name__}: {exc}); running eagerly", RuntimeWarning)
