@@ -1,0 +1,49 @@
+import sys, torch, faulthandler
+faulthandler.enable()
+sys.path.insert(0, ".")
+import vp_suite_amd
+from vp_suite_amd import ops
+from vp_suite_amd.models import MODEL_CLASSES, ef_conv_lstm as ef
+which = sys.argv[1]
+x = torch.rand(4, 10, 1, 64, 64, device="cuda")
+s1 = torch.cuda.Stream()
+keep = []
+def ev(stream):
+    e = torch.cuda.Event(); e.record(stream); keep.append(e); return e
+if which == "a":      # torch ops only, two streams
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        main = torch.cuda.current_stream()
+        e = ev(main)
+        with torch.cuda.stream(s1):
+            s1.wait_event(e); y = x * 2
+        main.wait_stream(s1)
+    g.replay(); torch.cuda.synchronize(); print("a ok", float(y.sum()))
+elif which in ("b", "c"):   # one ConvLSTM block call: b on a side stream, c on the capture stream
+    W = torch.randn(256, 80, 3, 3, device="cuda") * 0.05; b = torch.zeros(256, device="cuda")
+    xs = torch.rand(4, 5, 16, 64, 64, device="cuda")
+    with torch.no_grad():
+        for _ in range(2): ops.convlstm_seq(xs, None, None, W, b, seq_len=5, in_channels=16, precision="bf16x3")
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            main = torch.cuda.current_stream()
+            if which == "b":
+                e = ev(main)
+                with torch.cuda.stream(s1):
+                    s1.wait_event(e)
+                    out = ops.convlstm_seq(xs, None, None, W, b, seq_len=5, in_channels=16, precision="bf16x3")[0]
+                main.wait_stream(s1)
+            else:
+                out = ops.convlstm_seq(xs, None, None, W, b, seq_len=5, in_channels=16, precision="bf16x3")[0]
+        g.replay(); torch.cuda.synchronize(); print(which, "ok", float(out.sum()))
+elif which == "d":    # whole model, ONE stream (no pipeline)
+    m = MODEL_CLASSES["convlstm-shi"]("cuda", img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0., 1.], cell_precision="bf16x3").cuda()
+    ef.GRAPH_SMALL_BATCH = False
+    with torch.no_grad():
+        for _ in range(2): m(x, pred_frames=10)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y, _ = m(x, pred_frames=10)
+        g.replay(); torch.cuda.synchronize(); print("d ok", float(y.sum()))
