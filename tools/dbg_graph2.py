@@ -47,3 +47,28 @@ elif which == "d":    # whole model, ONE stream (no pipeline)
         with torch.cuda.graph(g):
             y, _ = m(x, pred_frames=10)
         g.replay(); torch.cuda.synchronize(); print("d ok", float(y.sum()))
+elif which in ("e", "f", "g", "h", "i"):
+    m = MODEL_CLASSES["convlstm-shi"]("cuda", img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0., 1.], cell_precision="bf16x3").cuda()
+    ef.GRAPH_SMALL_BATCH = False
+    enc, fo = m.encoder, m.forecaster
+    def run():
+        if which == "e":   # first stage glue only
+            return ef._apply_framewise(enc.stage1, x, "bf16x3", consumer=enc.rnn1)
+        if which == "f":   # stage 1 + rnn1
+            return enc.forward_by_stage(x, enc.stage1, enc.rnn1, enc.stage2)[0]
+        if which == "g":   # encoder
+            return enc(x)
+        if which == "h":   # encoder + forecaster rnn3 stage
+            hs = enc(x)
+            return fo.forward_by_stage(None, hs[-1], 10, fo.stage3, fo.rnn3, fo.rnn2)
+        if which == "i":
+            hs = enc(x)
+            inp = fo.forward_by_stage(None, hs[-1], 10, fo.stage3, fo.rnn3, fo.rnn2)
+            return fo.forward_by_stage(inp, hs[1], 10, fo.stage2, fo.rnn2, fo.rnn1)
+    with torch.no_grad():
+        for _ in range(2): run()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = run()
+        g.replay(); torch.cuda.synchronize(); print(which, "ok")
