@@ -47,7 +47,7 @@ elif which == "d":    # whole model, ONE stream (no pipeline)
         with torch.cuda.graph(g):
             y, _ = m(x, pred_frames=10)
         g.replay(); torch.cuda.synchronize(); print("d ok", float(y.sum()))
-elif which in ("e", "f", "g", "h", "i"):
+elif which in ("e", "f", "g", "h", "i", "j", "k", "l"):
     m = MODEL_CLASSES["convlstm-shi"]("cuda", img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0., 1.], cell_precision="bf16x3").cuda()
     ef.GRAPH_SMALL_BATCH = False
     enc, fo = m.encoder, m.forecaster
@@ -61,6 +61,16 @@ elif which in ("e", "f", "g", "h", "i"):
         if which == "h":   # encoder + forecaster rnn3 stage
             hs = enc(x)
             return fo.forward_by_stage(None, hs[-1], 10, fo.stage3, fo.rnn3, fo.rnn2)
+        if which in ("j", "k", "l"):
+            hs = enc(x)
+            inp = fo.forward_by_stage(None, hs[-1], 10, fo.stage3, fo.rnn3, fo.rnn2)
+            inp = fo.forward_by_stage(inp, hs[1], 10, fo.stage2, fo.rnn2, fo.rnn1)
+            if which == "j":
+                return fo.forward_by_stage(inp, hs[0], 10, fo.stage1, fo.rnn1, None)
+            if which == "k":   # rnn1 only, fp32 output
+                return fo.rnn1(inp, hs[0], 10)[0]
+            out, _ = fo.rnn1(inp, hs[0], 10)   # l: rnn1 (fp32 out) + glue on fp32
+            return ef._apply_framewise(fo.stage1, out, "bf16x3", consumer=None)
         if which == "i":
             hs = enc(x)
             inp = fo.forward_by_stage(None, hs[-1], 10, fo.stage3, fo.rnn3, fo.rnn2)
