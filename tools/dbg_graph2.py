@@ -82,3 +82,25 @@ elif which in ("e", "f", "g", "h", "i", "j", "k", "l"):
         with torch.cuda.graph(g):
             y = run()
         g.replay(); torch.cuda.synchronize(); print(which, "ok")
+elif which in ("m", "n", "o"):
+    m = MODEL_CLASSES["convlstm-shi"]("cuda", img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0., 1.], cell_precision="bf16x3").cuda()
+    ef.GRAPH_SMALL_BATCH = False
+    ef.PIPELINE_CHUNKS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    enc, fo = m.encoder, m.forecaster
+    with torch.no_grad():
+        ef._PIPE_ACTIVE = False
+        hs0 = enc(x)
+        ef._PIPE_ACTIVE = True
+        def run():
+            if which == "m":
+                return enc(x)
+            if which == "n":
+                return fo(hs0, 10)
+            return fo(enc(x), 10)
+        for _ in range(2): run()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = run()
+        keep.extend(ef._events)
+        g.replay(); torch.cuda.synchronize(); print(which, "ok")
