@@ -175,8 +175,10 @@ def _event(stream):
     return ev
 
 
-def _side_streams(device, n):
-    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), n)
+def _side_streams(device, n, tag):
+    # (encoder and forecaster fork their OWN streams: forking the same side streams a second time inside one stream capture, after
+    # they had re-joined the capturing stream, crashed the runtime in hipStreamEndCapture — ROCm 7.2, measured with tools/dbg_graph2.py)
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), n, tag)
     if key not in _side:
         _side[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
     return _side[key]
@@ -226,7 +228,7 @@ class Encoder(nn.Module):
     def _forward_pipelined(self, input, chunks):
         dev = input.device
         main = torch.cuda.current_stream(dev)
-        streams = _side_streams(dev, self.blocks)
+        streams = _side_streams(dev, self.blocks, "enc")
         start = _event(main)
         states = [None] * self.blocks
         for t0, t1 in chunks:
@@ -280,7 +282,7 @@ class Forecaster(nn.Module):
     def _forward_pipelined(self, hidden_states, chunks):
         dev = hidden_states[0][0].device
         main = torch.cuda.current_stream(dev)
-        streams = _side_streams(dev, self.blocks)
+        streams = _side_streams(dev, self.blocks, "fore")
         start = _event(main)
         states = list(hidden_states)
         for st, s in zip(states, streams):
