@@ -149,66 +149,6 @@ def _block_out_split(rnn, next_stage, batch, seq_len):
     return _stage_takes_split(next_stage, batch * seq_len, rnn.enc_c, rnn.state_h, rnn.state_w, getattr(rnn, "precision", "f32"))
 
 
-# ---- small-batch inference: time-chunk pipeline over side streams ------------------------------------------------------------
-# At B = 4 (BASELINE configs[0]'s batch, configs[3]'s per-GPU shard) a cell step is 48-128 workgroups: half the chip or less, and the
-# reference's order — ALL T steps of block l, then block l + 1 (ef_blocks.py:67-82 batches over T for convenience only) — leaves it
-# that way for the whole forward. The dependency is per frame: block l + 1 at step t needs block l at step t. So the sequence is cut
-# into PIPELINE_CHUNKS time chunks; block l runs chunk c on ITS stream while block l + 1 runs chunk c - 1 on another (a layer keeps
-# its stream, so its recurrent state, workspace and weight packs never cross streams; a chunk's output sequence does, under an
-# event + record_stream). Same kernels, same arithmetic, bit-identical results.
-PIPELINE_CHUNKS = 5          #: 0 / 1 switches the pipeline off (A/B)
-GRAPH_SMALL_BATCH = True     #: replay the pipelined forward as ONE HIP graph (issued eagerly it is host-bound: measured B = 4, 64x64:
-                             #: 1.82 ms one stream, 2.00 / 2.77 / 3.65 ms with 2 / 3 / 5 chunks — every chunk doubles the library calls)
-PIPELINE_MAX_TILES = 256     #: applies while batch x 16x16-pixel tiles of the largest map stays at or below this
-
-_PIPE_ACTIVE = False         # set while the graphed forward warms up / captures (and by tests): the chunked order is only worth it inside a graph
-_side = {}
-_events = []                 # events recorded while a capture is in flight stay alive until it ends (destroying one in between crashed the
-                             # runtime in hipStreamEndCapture); the graphed forward takes them over
-
-
-def _event(stream):
-    ev = torch.cuda.Event()
-    ev.record(stream)
-    if torch.cuda.is_current_stream_capturing():
-        _events.append(ev)
-    return ev
-
-
-def _side_streams(device, n, tag):
-    # (encoder and forecaster fork their OWN streams: forking the same side streams a second time inside one stream capture, after
-    # they had re-joined the capturing stream, crashed the runtime in hipStreamEndCapture — ROCm 7.2, measured with tools/dbg_graph2.py)
-    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), n, tag)
-    if key not in _side:
-        _side[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
-    return _side[key]
-
-
-def _record(x, stream):
-    """x (tensor, SplitActivation or tuple of tensors) was produced on another stream and is about to be read on `stream`."""
-    if x is None or torch.cuda.is_current_stream_capturing():   # (a captured graph owns its memory for good: nothing to guard)
-        return
-    if isinstance(x, ops.SplitActivation):
-        x.buf.record_stream(stream)
-    elif isinstance(x, (tuple, list)):
-        for t in x:
-            _record(t, stream)
-    else:
-        x.record_stream(stream)
-
-
-def _pipeline_chunks(batch, steps, rnn):
-    if PIPELINE_CHUNKS < 2 or torch.is_grad_enabled() or steps < PIPELINE_CHUNKS or not hasattr(rnn, "Wci"):
-        return None   # (ConvLSTM blocks only: their state is an (h, c) pair and their call takes it back)
-    if not (_PIPE_ACTIVE or torch.cuda.is_current_stream_capturing()):
-        return None
-    tiles = batch * ((rnn.state_h + 15) // 16) * ((rnn.state_w + 15) // 16)
-    if tiles > PIPELINE_MAX_TILES:
-        return None
-    n = PIPELINE_CHUNKS
-    return [(steps * c // n, steps * (c + 1) // n) for c in range(n)]
-
-
 class Encoder(nn.Module):
     def __init__(self, subnets, rnns):
         super().__init__()
@@ -225,35 +165,7 @@ class Encoder(nn.Module):
             return rnn(input, None, seq_len=t, out_split=True)
         return rnn(input, None, seq_len=t)
 
-    def _forward_pipelined(self, input, chunks):
-        dev = input.device
-        main = torch.cuda.current_stream(dev)
-        streams = _side_streams(dev, self.blocks, "enc")
-        start = _event(main)
-        states = [None] * self.blocks
-        for t0, t1 in chunks:
-            cur, ev = input[:, t0:t1], start
-            for i in range(1, self.blocks + 1):
-                s = streams[i - 1]
-                rnn, subnet = getattr(self, f"rnn{i}"), getattr(self, f"stage{i}")
-                nxt = getattr(self, f"stage{i + 1}") if i < self.blocks else None
-                with torch.cuda.stream(s):
-                    s.wait_event(ev)
-                    _record(cur, s)
-                    seq = _apply_framewise(subnet, cur, getattr(rnn, "precision", "f32"), consumer=rnn)
-                    b, t = seq.shape[:2]
-                    osp = (i == self.blocks or nxt is not None) and _block_out_split(rnn, nxt, b, t)
-                    cur, states[i - 1] = rnn(seq, states[i - 1], seq_len=t, out_split=True) if osp else rnn(seq, states[i - 1], seq_len=t)
-                    ev = _event(s)
-        for s in streams:
-            main.wait_stream(s)
-        _record(states, main)
-        return tuple(states)
-
     def forward(self, input):
-        chunks = _pipeline_chunks(input.shape[0], input.shape[1], self.rnn1) if input.is_cuda else None
-        if chunks:
-            return self._forward_pipelined(input, chunks)
         hidden_states = []
         for i in range(1, self.blocks + 1):
             nxt = getattr(self, f"stage{i + 1}") if i < self.blocks else None   # the last block's sequence has no reader (states only)
@@ -279,44 +191,7 @@ class Forecaster(nn.Module):
             input, _ = rnn(input, state, pred_frames)
         return _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"), consumer=next_rnn)
 
-    def _forward_pipelined(self, hidden_states, chunks):
-        dev = hidden_states[0][0].device
-        main = torch.cuda.current_stream(dev)
-        streams = _side_streams(dev, self.blocks, "fore")
-        start = _event(main)
-        states = list(hidden_states)
-        for st, s in zip(states, streams):
-            _record(st, s)
-        outs = []
-        for t0, t1 in chunks:
-            cur, ev = None, start
-            for i in range(self.blocks, 0, -1):
-                s = streams[i - 1]
-                rnn, subnet = getattr(self, f"rnn{i}"), getattr(self, f"stage{i}")
-                nxt_rnn = getattr(self, f"rnn{i - 1}") if i > 1 else None
-                with torch.cuda.stream(s):
-                    s.wait_event(ev)
-                    _record(cur, s)
-                    b = states[i - 1][0].shape[0]
-                    if _block_out_split(rnn, subnet, b, t1 - t0):
-                        out, states[i - 1] = rnn(cur, states[i - 1], t1 - t0, out_split=True)
-                    else:
-                        out, states[i - 1] = rnn(cur, states[i - 1], t1 - t0)
-                    cur = _apply_framewise(subnet, out, getattr(rnn, "precision", "f32"), consumer=nxt_rnn)
-                    ev = _event(s)
-            outs.append(cur)
-        with torch.cuda.stream(streams[0]):
-            pred = torch.cat(outs, dim=1)
-        for s in streams:
-            main.wait_stream(s)
-        _record(pred, main)
-        return pred
-
     def forward(self, hidden_states, pred_frames):
-        st0 = hidden_states[0][0]
-        chunks = _pipeline_chunks(st0.shape[0], pred_frames, self.rnn1) if st0.is_cuda else None
-        if chunks:
-            return self._forward_pipelined(hidden_states, chunks)
         # like the reference (ef_blocks.py:109-110) the top block is addressed as stage3/rnn3 and gets no input
         input = self.forward_by_stage(None, hidden_states[-1], pred_frames, self.stage3, self.rnn3,
                                       getattr(self, f"rnn{self.blocks - 1}", None) if self.blocks > 1 else None)
@@ -355,7 +230,7 @@ class Encoder_Forecaster(VPModel):
         enc_convs, enc_rnns, dec_convs, dec_rnns = self._build_encoder_decoder()
         self.encoder = Encoder(enc_convs, enc_rnns).to(self.device)
         self.forecaster = Forecaster(dec_convs, dec_rnns).to(self.device)
-        self.NON_CONFIG_VARS.extend(["encoder", "forecaster", "_vpx_graph"])
+        self.NON_CONFIG_VARS.extend(["encoder", "forecaster"])
 
     def _build_encoder_decoder(self):
         raise NotImplementedError
@@ -363,77 +238,8 @@ class Encoder_Forecaster(VPModel):
     def pred_1(self, x, **kwargs):
         return self(x, pred_frames=1, **kwargs)[0].squeeze(dim=1)
 
-    def _forward_eager(self, x, pred_frames):
-        return self.forecaster(self.encoder(x), pred_frames)
-
-    def _graph_key(self, x, pred_frames):
-        return (tuple(x.shape), x.dtype, x.device, int(pred_frames), PIPELINE_CHUNKS, ops._kernel_options(),
-                torch.are_deterministic_algorithms_enabled(), tuple(p._version for p in self.parameters()),
-                tuple(p.data_ptr() for p in self.parameters()))
-
-    def __getstate__(self):   # (the captured graph is a cache, not state: models are pickled whole, vpsuite.py:394)
-        d = self.__dict__.copy()
-        d.pop("_vpx_graph", None)
-        return d
-
-    def _graphable(self, x, pred_frames):
-        global _PIPE_ACTIVE
-        if not (GRAPH_SMALL_BATCH and x.is_cuda and not torch.is_grad_enabled() and ops.PROFILE is None
-                and not torch.cuda.is_current_stream_capturing()):
-            return False
-        prev, _PIPE_ACTIVE = _PIPE_ACTIVE, True
-        try:
-            return (_pipeline_chunks(x.shape[0], x.shape[1], self.encoder.rnn1) is not None
-                    and _pipeline_chunks(x.shape[0], pred_frames, self.forecaster.rnn1) is not None)
-        finally:
-            _PIPE_ACTIVE = prev
-
-    def _forward_graphed(self, x, pred_frames):
-        """Small-batch inference: the pipelined forward captured once per (shape, horizon, weight versions) and replayed — the
-        pipeline multiplies the library calls and is host-bound when issued eagerly. The graph reads a private copy of the input and
-        the caller gets a copy of its output; workspaces the captured kernels use are pinned with the graph."""
-        key = self._graph_key(x, pred_frames)
-        ent = getattr(self, "_vpx_graph", None)
-        if ent is None or ent[0] != key:
-            if ent is not None and ent[0] == ("failed",) + key:
-                return self._forward_eager(x, pred_frames)
-            main = torch.cuda.current_stream(x.device)
-            sx = x.clone()
-            warm = torch.cuda.Stream(device=x.device)
-            warm.wait_stream(main)
-            global _PIPE_ACTIVE
-            prev, _PIPE_ACTIVE = _PIPE_ACTIVE, True
-            try:
-                with torch.cuda.stream(warm):   # (capture needs warmed-up kernels: attributes set, packs made, caches filled)
-                    for _ in range(2):
-                        self._forward_eager(sx, pred_frames)
-                main.wait_stream(warm)
-                pins = [e[3] for e in list(ops._clstm_ws.ents.values()) + list(ops._convq_ws.ents.values())]
-                g = torch.cuda.CUDAGraph()
-                del _events[:]
-                with torch.cuda.graph(g):
-                    so = self._forward_eager(sx, pred_frames)
-                ent = (key, g, sx, so, pins + list(_events))
-                del _events[:]
-            except Exception as exc:   # capture is an optimisation: say so once and stay on the eager path for this key
-                import warnings
-                warnings.warn(f"EF small-batch graph capture failed ({type(exc).__name__}: {exc}); running eagerly", RuntimeWarning)
-                _PIPE_ACTIVE = prev
-                object.__setattr__(self, "_vpx_graph", (("failed",) + key,))
-                torch.cuda.synchronize()
-                return self._forward_eager(x, pred_frames)
-            finally:
-                _PIPE_ACTIVE = prev
-            object.__setattr__(self, "_vpx_graph", ent)
-        _, g, sx, so, _ = ent
-        sx.copy_(x)
-        g.replay()
-        return so.clone()
-
     def forward(self, x, pred_frames: int = 1, **kwargs):
-        if self._graphable(x, pred_frames):
-            return self._forward_graphed(x, pred_frames), None
-        return self._forward_eager(x, pred_frames), None
+        return self.forecaster(self.encoder(x), pred_frames), None
 
 
 class EF_ConvLSTM(Encoder_Forecaster):
