@@ -143,6 +143,17 @@ int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, const float
 /* ---- ST-LSTM cell step (PredRNN-V2) -------------------------------------------------------------------------- */
 size_t vpx_stlstm_workspace_bytes(const vpx_stlstm_desc* d);
 size_t vpx_stlstm_reserve_bytes(const vpx_stlstm_desc* d);
+/* Split-format shadows (round 4). The bf16x3 5x5 kernels read every activation in the split operand format (above); a tensor that a
+ * previous step produced — h_new is the next step's h and the next layer's x, m_new the next layer's m — need not be converted
+ * again when the caller hands its split copy back:
+ *   vpx_stlstm_uses_split(d)            1 when calls with this descriptor consume / produce shadows, else 0 (they are ignored)
+ *   vpx_stlstm_set_split_operands(in, out)   applies to the NEXT vpx_stlstm_step_fwd / _bwd call of THIS thread and is consumed by it.
+ *       in[5]  = {x, h, m, c_new, m_new}: NULL or the tensor once more in the split format, B*H*W*C*4 bytes (forward reads the first
+ *                three, backward all five; a NULL entry is converted by the library as before)
+ *       out[3] = {h_new, c_new, m_new}: NULL or caller buffers of B*H*W*Ch*4 bytes the forward fills with these outputs in the split format
+ *       either array may be NULL. NHWC layout only. */
+int vpx_stlstm_uses_split(const vpx_stlstm_desc* d);
+int vpx_stlstm_set_split_operands(const void* const* in5, void* const* out3);
 
 /* Weights in reference layout: Wx [7Ch,Cin,k,k] Wh [4Ch,Ch,k,k] Wm [3Ch,Ch,k,k] Wo [Ch,2Ch,k,k] Wlast [Ch,2Ch,1,1].
  * ln: NULL or 8 pointers {x_gamma,x_beta,h_gamma,h_beta,m_gamma,m_beta,o_gamma,o_beta}, each in reference [C,H,W]. */

@@ -207,6 +207,49 @@ def test_stlstm_second_generation_backward_matches_first_generation(vpx, B, Cin,
         assert torch.equal(a, b)   # no atomics in either kernel or in the slice reduction: bit-reproducible
 
 
+@pytest.mark.parametrize("B", [3, 100])
+def test_stlstm_split_shadows_change_nothing(vpx, B):
+    """h_new / c_new / m_new of a step carry a shadow in the split operand format (`_vpx_sp`); the next step takes the shadows of
+    its x, h, m instead of converting them, the backward those of all five sources. Same bits either way: two chained steps with the
+    outputs passed on as they are (shadows used) against the same steps on clones (no shadow: the library converts), forward and
+    every gradient — small grid (K-split forms) and 100 pixel tiles (unsplit forms). A shadow whose tensor was written in place is dropped."""
+    from golden_util import seeded_randn
+    Cin = Ch = 128
+    H = W = 16
+    k = 5
+    tag = f"shadow.{B}"
+    shapes = {"Wx": (7 * Ch, Cin, k, k), "Wh": (4 * Ch, Ch, k, k), "Wm": (3 * Ch, Ch, k, k), "Wo": (Ch, 2 * Ch, k, k), "Wlast": (Ch, 2 * Ch, 1, 1)}
+    Ws = {n: seeded_randn(s_, name_seed(f"{tag}.{n}"), 1.0 / np.sqrt(s_[1] * s_[2] * s_[3])).cuda() for n, s_ in shapes.items()}
+    st = [seeded_randn((B, Ch, H, W), name_seed(f"{tag}.s{i}"), 0.5).cuda() for i in range(4)]
+    gout = [seeded_randn((B, Ch, H, W), name_seed(f"{tag}.g{i}")).cuda() for i in range(5)]
+
+    def run(pass_on):
+        w = [Ws[n].clone().requires_grad_(True) for n in shapes]
+        a = [t.clone().requires_grad_(True) for t in st]
+        o1 = vpx.ops.stlstm_step(*a, *w, precision="bf16x3")
+        assert all(hasattr(t, "_vpx_sp") for t in o1[:3])
+        x2, h2, c2, m2 = o1[0], o1[0], o1[1], o1[2]          # next layer: x = h_new; same cell next step: h, c; zig-zag memory: m_new
+        if not pass_on:
+            x2, h2, c2, m2 = (t * 1.0 for t in (x2, h2, c2, m2))   # new tensors: no shadow
+            assert not hasattr(x2, "_vpx_sp")
+        o2 = vpx.ops.stlstm_step(x2, h2, c2, m2, *w, precision="bf16x3")
+        sum((o * g).sum() for o, g in zip(o2, gout)).backward()
+        return [o.detach() for o in o2] + [t.grad for t in a + w]
+    torch.use_deterministic_algorithms(True)
+    try:
+        with_sh, without = run(True), run(False)
+    finally:
+        torch.use_deterministic_algorithms(False)
+    for a, b in zip(with_sh, without):
+        assert torch.equal(a, b)
+    # in-place writes invalidate a shadow
+    with torch.no_grad():
+        o = vpx.ops.stlstm_step(*st, *[Ws[n] for n in shapes], precision="bf16x3")
+        assert vpx.ops._shadow_of(o[0], o[0]) is not None
+        o[0].mul_(2.0)
+        assert vpx.ops._shadow_of(o[0], o[0]) is None
+
+
 def test_decouple_and_conv2d_vs_golden_and_autograd(vpx):
     """K4 (vpx_decouple_fwd/_bwd) against the reference-generated pin; K5-style conv2d fwd/bwd against torch autograd."""
     from golden_util import seeded_randn

@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes", "vpx_convlstm_takes_split_input", "vpx_convlstm_writes_split_output", "vpx_convlstm_seq_fwd",
     "vpx_convlstm_seq_bwd",
     "vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes", "vpx_stlstm_step_fwd", "vpx_stlstm_step_bwd",
+    "vpx_stlstm_uses_split", "vpx_stlstm_set_split_operands",
     "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
     "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_conv2d_bwd_workspace_bytes", "vpx_conv2d_nhwc_bwd",
     "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd", "vpx_conv2d_ex_fwd_split",
@@ -108,6 +109,10 @@ def lib():
         L.vpx_convlstm_seq_fwd.argtypes = [ctypes.POINTER(ConvLSTMDesc)] + [vp] * 11 + [vp, sz, vp, sz, vp]
         L.vpx_convlstm_seq_bwd.restype = ctypes.c_int
         L.vpx_convlstm_seq_bwd.argtypes = [ctypes.POINTER(ConvLSTMDesc)] + [vp] * 8 + [vp, sz] + [vp] * 11 + [vp, sz, vp]
+        L.vpx_stlstm_uses_split.restype = ctypes.c_int
+        L.vpx_stlstm_uses_split.argtypes = [ctypes.POINTER(STLSTMDesc)]
+        L.vpx_stlstm_set_split_operands.restype = ctypes.c_int
+        L.vpx_stlstm_set_split_operands.argtypes = [vp, vp]
         L.vpx_stlstm_step_fwd.restype = ctypes.c_int
         L.vpx_stlstm_step_fwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 9 + [vp] + [vp] * 5 + [vp, sz, vp, sz, vp]
         L.vpx_stlstm_step_bwd.restype = ctypes.c_int

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void st_out_ks_kernel(const STOutKSArgs a) {
     }
     st8v(a.h_new + e, hn);
     if (a.o_save) { st8v(a.o_save + e, o); st8v(a.tl_save + e, tl); }
+    if (a.h_sp) st8split(a.h_sp, e / a.Ch, a.Ch, (int)(e % a.Ch), hn);
 }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(float* __restrict__ out, const float* __restrict__ part, long long pstride, int ks,

@@ -132,7 +132,25 @@ ConvPlan base_plan(const vpx_stlstm_desc* d, int k) {
 
 }  // namespace
 
+namespace vpx {
+thread_local STSplitShadows g_st_shadows = {};
+STSplitShadows take_st_shadows() { STSplitShadows s = g_st_shadows; g_st_shadows = STSplitShadows{}; return s; }
+}  // namespace vpx
+
 extern "C" {
+
+int vpx_stlstm_uses_split(const vpx_stlstm_desc* d) {
+    if (check_st_desc(d) != VPX_OK || d->layout != VPX_LAYOUT_NHWC) return 0;
+    return (c5_fwd_applicable(d) || c5k_fwd_applicable(d)) ? 1 : 0;
+}
+int vpx_stlstm_set_split_operands(const void* const* in5, void* const* out3) {
+    STSplitShadows s{};
+    if (in5) for (int i = 0; i < 5; ++i) s.in[i] = reinterpret_cast<const char*>(in5[i]);
+    if (out3) for (int i = 0; i < 3; ++i) s.out[i] = reinterpret_cast<char*>(out3[i]);
+    s.set = 1;
+    g_st_shadows = s;
+    return VPX_OK;
+}
 
 size_t vpx_stlstm_reserve_bytes(const vpx_stlstm_desc* d) {
     STLayout L;
@@ -166,8 +184,10 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
                         const float* const* ln, float* h_new, float* c_new, float* m_new, float* delta_c,
                         float* delta_m, void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
                         void* stream_) {
+    STSplitShadows sh = take_st_shadows();   // (consumed by this call whatever happens next)
     int rc = check_st_desc(d);
     if (rc != VPX_OK) return rc;
+    if (d->layout != VPX_LAYOUT_NHWC) sh = STSplitShadows{};
     STLayout L;
     if ((rc = st_layout(d, L)) != VPX_OK) return rc;
     hipStream_t stream = (hipStream_t)stream_;
@@ -254,9 +274,12 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
     if (L.c5) {
         // ---- round-4 path: operands in the split format, gate groups + conv_o on the 16x16-tile kernel (convq.hip, c5) ----
         const long long npix = (long long)B * (long long)HW;
-        VPX_CHECK_HIP(launch_split_convert(xn, x_sp, npix, Cin, stream));
-        VPX_CHECK_HIP(launch_split_convert(hn, h_sp, npix, Ch, stream));
-        VPX_CHECK_HIP(launch_split_convert(mn, m_sp, npix, Ch, stream));
+        // operands a previous call left in the split format come back as shadows; the others are converted here
+        if (sh.in[0]) x_sp = const_cast<char*>(sh.in[0]); else VPX_CHECK_HIP(launch_split_convert(xn, x_sp, npix, Cin, stream));
+        if (sh.in[1]) h_sp = const_cast<char*>(sh.in[1]); else VPX_CHECK_HIP(launch_split_convert(hn, h_sp, npix, Ch, stream));
+        if (sh.in[2]) m_sp = const_cast<char*>(sh.in[2]); else VPX_CHECK_HIP(launch_split_convert(mn, m_sp, npix, Ch, stream));
+        if (sh.out[1]) cn_sp = sh.out[1];
+        if (sh.out[2]) mn_sp = sh.out[2];
         C5Plan cp{};
         cp.B = B; cp.H = H; cp.W = Wd;
         cp.src[0] = C5Src{x_sp, (long long)HW * Cin * 4, Cin * 4, 0};
@@ -294,9 +317,12 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
     } else if (L.c5k) {
         // ---- small grid: the same two gate groups, K-split into ks_g chunks = 2 * ks_g jobs of one launch writing partial sums ----
         const long long npix = (long long)B * (long long)HW;
-        VPX_CHECK_HIP(launch_split_convert(xn, x_sp, npix, Cin, stream));
-        VPX_CHECK_HIP(launch_split_convert(hn, h_sp, npix, Ch, stream));
-        VPX_CHECK_HIP(launch_split_convert(mn, m_sp, npix, Ch, stream));
+        // operands a previous call left in the split format come back as shadows; the others are converted here
+        if (sh.in[0]) x_sp = const_cast<char*>(sh.in[0]); else VPX_CHECK_HIP(launch_split_convert(xn, x_sp, npix, Cin, stream));
+        if (sh.in[1]) h_sp = const_cast<char*>(sh.in[1]); else VPX_CHECK_HIP(launch_split_convert(hn, h_sp, npix, Ch, stream));
+        if (sh.in[2]) m_sp = const_cast<char*>(sh.in[2]); else VPX_CHECK_HIP(launch_split_convert(mn, m_sp, npix, Ch, stream));
+        if (sh.out[1]) cn_sp = sh.out[1];
+        if (sh.out[2]) mn_sp = sh.out[2];
         C5Plan cp{};
         cp.B = B; cp.H = H; cp.W = Wd;
         cp.src[0] = C5Src{x_sp, (long long)HW * Cin * 4, Cin * 4, 0};
@@ -433,6 +459,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         j.epi = 2; j.Co = Ch; j.Ch = Ch; j.wpk = c5wo;
         j.e_in0 = o_pre; j.e_in1 = lc;
         j.e_out[0] = hO; j.e_out[1] = o_save; j.e_out[2] = tl_save;
+        j.e_sp = sh.out[0];
         const long long so = (long long)2 * Ch * L.taps;
         C5PackRange pr[2] = {C5PackRange{Wo, so, (long long)L.taps, 0, {0, 0, 0, 0}}, C5PackRange{Wo, so, (long long)L.taps, Ch, {0, 0, 0, 0}}};
         if ((rc = c5_prepare_job(j, c5f_nt_o(d), pr, 0, 0, packed, stream))) return rc;
@@ -460,7 +487,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         VPX_CHECK_HIP(launch_c5(cp, L.nt_o, stream));
         STOutKSArgs oa{};
         oa.n = (long long)L.n_state; oa.ks = L.ks_o; oa.pstride = (long long)L.n_state; oa.part = part_o;
-        oa.o_pre = o_pre; oa.lc = lc; oa.h_new = hO; oa.o_save = o_save; oa.tl_save = tl_save;
+        oa.o_pre = o_pre; oa.lc = lc; oa.h_new = hO; oa.o_save = o_save; oa.tl_save = tl_save; oa.h_sp = sh.out[0]; oa.Ch = Ch;
         VPX_CHECK_HIP(launch_st_out_ks(oa, stream));
     } else {
         ConvPlan P = base_plan(d, k);

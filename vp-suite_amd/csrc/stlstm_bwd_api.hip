@@ -156,7 +156,9 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
                                    const float* ddelta_m, float* dx, float* dh, float* dc, float* dm, float* dWx,
                                    float* dWh, float* dWm, float* dWo, float* dWlast, float* const* dln, void* workspace,
                                    size_t workspace_bytes, void* stream_) {
+    STSplitShadows sh = take_st_shadows();   // (consumed by this call whatever happens next)
     if (!d) { set_error("stlstm desc is NULL"); return VPX_ERR_ARG; }
+    if (d->layout != VPX_LAYOUT_NHWC) sh = STSplitShadows{};
     if ((d->precision < VPX_PREC_F32 || d->precision > VPX_PREC_BF16)) { set_error("stlstm: precision %d not implemented", d->precision); return VPX_ERR_UNSUPPORTED; }
     if (!(d->flags & VPX_FLAG_SAVE_FOR_BWD)) { set_error("vpx_stlstm_step_bwd: desc lacks VPX_FLAG_SAVE_FOR_BWD"); return VPX_ERR_ARG; }
     if (!x || !h || !c || !m || !c_new || !m_new || !Wx || !Wh || !Wm || !Wo || !Wlast || !reserve) {
@@ -455,9 +457,12 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         static thread_local STWArgs sa; static thread_local STWOut so;
         if (stw_build(sa, so, B, H, Wd, Cin, Ch) != L.stw_pairs) { set_error("stlstm bwd: pair table changed"); return VPX_ERR_ARG; }
         const long long npix = (long long)B * (long long)HW;
-        VPX_CHECK_HIP(launch_split_convert(xn, x_sp, npix, Cin, stream));
+        if (sh.in[0]) x_sp = const_cast<char*>(sh.in[0]); else VPX_CHECK_HIP(launch_split_convert(xn, x_sp, npix, Cin, stream));
         const float* st_src[4] = {hn, mn, cnn, mnn};
-        for (int i = 0; i < 4; ++i) VPX_CHECK_HIP(launch_split_convert(st_src[i], st_sp[i], npix, Ch, stream));
+        for (int i = 0; i < 4; ++i) {   // the forward's split shadows of h, m, c_new, m_new where the caller kept them
+            if (sh.in[1 + i]) st_sp[i] = const_cast<char*>(sh.in[1 + i]);
+            else VPX_CHECK_HIP(launch_split_convert(st_src[i], st_sp[i], npix, Ch, stream));
+        }
         sa.g_sp = reinterpret_cast<const char*>(dG7);   // written in the split format by stages A and C
         sa.src[0] = STWSrc{x_sp, Cin};
         for (int i = 0; i < 4; ++i) sa.src[1 + i] = STWSrc{st_sp[i], Ch};

@@ -722,6 +722,18 @@ class STWorkspace:
         return self.buf, valid
 
 
+def _shadow_of(t, tl):
+    """The split-format copy a previous library call attached to tensor `t` (as `t._vpx_sp = (buffer, version, address)`), if it still
+    describes the memory `tl` that is about to be handed to the library: same tensor version, same address, same device."""
+    sp = getattr(t, "_vpx_sp", None)
+    if sp is None:
+        return None
+    buf, version, addr = sp
+    if version != t._version or addr != tl.data_ptr() or buf.device != tl.device:
+        return None
+    return buf
+
+
 class _STLSTMStepFn(torch.autograd.Function):
     """(h_new, c_new, m_new, delta_c, delta_m) = ST-LSTM cell step (predrnn.py:57-83) in one library call.
     `ln` = () or the 8 LayerNorm tensors (x_gamma, x_beta, h_gamma, h_beta, m_gamma, m_beta, o_gamma, o_beta)."""
@@ -744,7 +756,7 @@ class _STLSTMStepFn(torch.autograd.Function):
         if ws_bytes == 0:
             check(-4 if b"not implemented" in L.vpx_last_error() else -1, "vpx_stlstm_workspace_bytes")
         rs_bytes = L.vpx_stlstm_reserve_bytes(ctypes.byref(d))
-        key = (B, Cin, Ch, H, Wd, k, precision, flags, _det_state, tuple((w.data_ptr(), w._version) for w in W5),
+        key = (B, Cin, Ch, H, Wd, k, precision, flags, _det_state, _kernel_options(), tuple((w.data_ptr(), w._version) for w in W5),
                tuple((t.data_ptr(), t._version) for t in lnc))
         if wsholder is not None:
             ws, packed = wsholder.get(ws_bytes, dev, key)
@@ -757,6 +769,16 @@ class _STLSTMStepFn(torch.autograd.Function):
         dd = new_channels_last((2 * B, Ch, H, Wd), dev)  # delta_c | delta_m adjacent: the decoupling tail runs the pair as one conv
         outs += [dd[:B], dd[B:]]
         ln_arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in lnc]) if use_ln else None
+        # split-format shadows (vpx.h): operands a previous step left in the kernels' operand format are handed back instead of being
+        # converted again (h_new is the next step's h and the next layer's x, m_new the next layer's m), and this step's h_new / c_new /
+        # m_new come back with shadows of their own
+        sp_in, sp_out = [None] * 5, None
+        if not use_ln and L.vpx_stlstm_uses_split(ctypes.byref(d)):
+            sp_in[:3] = [_shadow_of(x, xs), _shadow_of(h, hs), _shadow_of(m, ms)]
+            sp_out = [torch.empty(B * H * Wd * Ch, dtype=torch.float32, device=dev) for _ in range(3)]
+            in_arr = (ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in sp_in])
+            out_arr = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in sp_out])
+            L.vpx_stlstm_set_split_operands(in_arr, out_arr)
         if PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -767,7 +789,11 @@ class _STLSTMStepFn(torch.autograd.Function):
             ev1.record()
             fl, by = stlstm_algorithmic_work(B, Cin, Ch, H, Wd, k)
             PROFILE.records.append((ev0, ev1, fl, by, 4, "stlstm_fwd"))
+        if sp_out is not None:
+            for t, buf in zip(outs[:3], sp_out):
+                t._vpx_sp = (buf, t._version, t.data_ptr())
         if need_grad:
+            ctx.sp = None if sp_out is None else (sp_in[0], sp_in[1], sp_in[2], sp_out[1], sp_out[2])   # x, h, m, c_new, m_new
             ctx.save_for_backward(xs, hs, cs, ms, outs[1], outs[2], *W5, reserve, *lnc)
             d.flags = flags
             ctx.desc = d
@@ -805,6 +831,8 @@ class _STLSTMStepFn(torch.autograd.Function):
                 d.flags = flags0 | _lib.FLAG_WEIGHTS_PACKED
         else:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        if getattr(ctx, "sp", None) is not None:   # the forward's split shadows: the weight-gradient kernel stages them as they are
+            L.vpx_stlstm_set_split_operands((ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in ctx.sp]), None)
         rc = L.vpx_stlstm_step_bwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), ptr(c_new), ptr(m_new), ptr(Wx),
                                    ptr(Wh), ptr(Wm), ptr(Wo), ptr(Wlast), ln_arr, ptr(reserve), ctx.rs_bytes,
                                    *[ptr(g) for g in gin], ptr(dx), ptr(dh), ptr(dc), ptr(dm), *[ptr(g) for g in dWs],
