@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: the round's rocprofv3 evidence in one call (kernel stats + PMC passes of the headline, then of the extras that
+# changed this round). Summaries: tools/summarize_profiles.py r04; tools/summarize_extra.py r04 <tag> <name> for each tag below.
+bash tools/collect_profiles.sh > gpurun_out/collect_r04.log 2>&1
+for spec in "cell_64x64x64_b128|--cell 64,64,64,64 --batch 128 --name cell_64x64x64_b128" \
+            "cell_64x64x64_b128_bf16|--cell 64,64,64,64 --batch 128 --precision bf16 --name cell_64x64x64_b128_bf16" \
+            "infer_b128_bf16|--precision bf16 --name infer_b128_bf16" \
+            "predrnn_infer_b128|--model predrnn-pp --name predrnn_infer_b128" \
+            "predrnn_train_b128|--model predrnn-pp --mode train --name predrnn_train_b128" \
+            "c5_infer_b4|--model predrnn-pp --batch 4 --img 128 --channels 3 --pred 30 --layers 4 --name c5_infer_b4_128x128x3_10to30_L4" \
+            "c5_train_b2|--model predrnn-pp --mode train --batch 2 --img 128 --channels 3 --pred 30 --layers 4 --name c5_train_b2_128x128x3_10to30_L4" \
+            "infer_b4|--batch 4 --name infer_b4" \
+            "c4_infer_b4|--batch 4 --img 128 --channels 3 --pred 20 --name c4_infer_b4_128x128x3_10to20"; do
+  tag=${spec%%|*}; args=${spec#*|}
+  bash tools/prof_extra.sh $tag $args >> gpurun_out/collect_r04.log 2>&1
+done
+du -sh gpurun_out/prof_final gpurun_out/prof_extra

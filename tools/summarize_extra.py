@@ -10,7 +10,7 @@ ROUND, TAG, NAME = sys.argv[1], sys.argv[2], sys.argv[3]
 SRC = os.path.join(ROOT, "gpurun_out", "prof_extra", TAG)
 DST = os.path.join(ROOT, "profiles")
 CELL = ("cell2_kernel", "cell3_kernel", "EpiConvLSTM", "convlstm_pointwise_kernel", "conv_gemm_dual_kernel", "EpiSTOut", "EpiSTGate",
-        "st_ln_", "st_gates", "st_out")
+        "st_ln_", "st_gates", "st_out", "c5_kernel", "c1_kernel<2, 8>")   # round 4: the ST-LSTM step = c5 launches + conv_last (c1<2,8>) + K-split pointwise stages
 
 
 def one(pattern):
