@@ -8,7 +8,7 @@ import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROUND, TAG, NAME = sys.argv[1], sys.argv[2], sys.argv[3]
 SRC = os.path.join(ROOT, "gpurun_out", "prof_extra", TAG)
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("VPX_PROFILES_DST") or os.path.join(ROOT, "profiles")   # (the GPU box writes under gpurun_out/: only that comes back)
 CELL = ("cell2_kernel", "cell3_kernel", "EpiConvLSTM", "convlstm_pointwise_kernel", "conv_gemm_dual_kernel", "EpiSTOut", "EpiSTGate",
         "st_ln_", "st_gates", "st_out", "c5_kernel", "c1_kernel<2, 8>")   # round 4: the ST-LSTM step = c5 launches + conv_last (c1<2,8>) + K-split pointwise stages
 

@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("VPX_PROFILES_DST") or os.path.join(ROOT, "profiles")   # (the GPU box writes under gpurun_out/: only that comes back)
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
 DOMINANT = ("EpiConvLSTM", "cell2_kernel")   # fused cell step: first-generation kernel / second generation (cell2.hip)
 
