@@ -780,14 +780,24 @@ int convq_run(const ConvQProblem& pr, const ConvQEpiArgs& ea_in, char* wpk, bool
 // dm: 3Ch channels): every XCD gets every job's tiles of ITS pixel tiles, longest job first, the N tiles of a pixel tile
 // adjacent in the XCD's dispatch order (they share the stage in its L2).
 // =====================================================================================================================
-constexpr int C5_PLANE = 512 * 16;       // one plane (hi or lo) of a stage buffer, padded from 400 positions
-constexpr int C5_ABUF = 2 * C5_PLANE;    // 16 KiB
-template <int NT> struct C5Geom {
+// KS = 5 (the ST-LSTM step) or 3 (the ConvLSTM step on small grids, round 4: "c3"). 3x3: 18x18 halo positions (planes padded to 384 = 3
+// pieces per thread), nine slots per stage = nine steps per period of four stages; a stage lives 2-3 steps only, so the period's four
+// stages have a buffer EACH (4 x 12 KiB): stage j of the NEXT period is requested at period step 3 / 5 / 7 / (next) 0, right after the
+// last read of stage j of this one, six steps before its first read.
+template <int NT, int KS = 5> struct C5Geom {
+    static constexpr int HWP = 16 + KS - 1;               // halo tile width / height: 20 | 18
+    static constexpr int NPOS = HWP * HWP;                // 400 | 324
+    static constexpr int PLP = KS == 5 ? 512 : 384;       // padded positions of a plane
+    static constexpr int PLANE = PLP * 16;                // one plane (hi or lo) of a stage buffer
+    static constexpr int ABUF = 2 * PLANE;                // 16 | 12 KiB
+    static constexpr int NPC = 2 * PLP / 256;             // stage-copy pieces per thread: 4 | 3
+    static constexpr int NBUF = KS == 5 ? 2 : 4;
+    static constexpr int SPS = KS * KS;                   // slots per stage = steps per period of four stages
     static constexpr int WCH = NT * 2048;                 // weight chunk of one K = 32 step: 16 | 8 | 4 KiB
     static constexpr int WP = WCH / (256 * 16);           // DMAs per thread and chunk: 4 | 2 | 1
     static constexpr int HCOLS = NT >= 4 ? 64 : NT * 16;  // columns of a chunk half ([half][part][k group][HCOLS][16 B])
     static constexpr int KGS = HCOLS * 16, PARTS = 4 * KGS;
-    static constexpr int LDS = 2 * C5_ABUF + (3 * WCH > 32768 ? 3 * WCH : 32768);   // >= 64 KiB: 4 waves x 16 KiB in the epilogue
+    static constexpr int LDS = NBUF * ABUF + 3 * WCH >= 65536 ? NBUF * ABUF + 3 * WCH : 65536;   // >= 64 KiB: 4 waves x 16 KiB in the epilogue
 };
 
 __device__ __forceinline__ void c5_chan_of_stage(const C5Job& j, int s8, int& src, int& chan) {   // source and first channel of the job's stage s8
@@ -899,9 +909,66 @@ __device__ __forceinline__ void c5_finish_out(const f32x4 (&acc)[4][8], char* sm
     }
 }
 
+// ConvLSTM step on a gate-interleaved N tile of GC = NT * 4 channels (columns g * GC + j, gates i, f, g, o): the wave's 64 pixels x NT * 16
+// columns go through its private LDS as [pixel][column]; a lane then owns four channels of a pixel for all four gates.
 template <int NT>
+__device__ __forceinline__ void c5_finish_clstm(const f32x4 (&acc)[4][NT], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
+                                                const C5Job& J, int H, int W) {
+    static_assert(NT <= 4, "64 pixels x NT * 16 columns must fit the wave's 16 KiB");
+    constexpr int NC = NT * 16, GC = NC / 4, LPP = GC / 4, PPP = 64 / LPP;   // lanes per pixel, pixels per pass
+    c2_barrier();
+    float* ldsf = reinterpret_cast<float*>(smem + wave * 16384);
+    const int c16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ldsf[(m * 16 + 4 * q4 + r) * NC + nt * 16 + c16] = acc[m][nt][r];
+    const int cgi = lane % LPP, pl = lane / LPP;
+    const int ch = n_tile * GC + cgi * 4, Ch = J.Ch;
+    if (ch >= Ch) return;
+    f32x4 bi = {0.f, 0.f, 0.f, 0.f}, bf = bi, bg = bi, bo = bi;
+    if (J.bias) {
+        bi = *reinterpret_cast<const f32x4*>(J.bias + J.gate_pos[0] * Ch + ch);
+        bf = *reinterpret_cast<const f32x4*>(J.bias + J.gate_pos[1] * Ch + ch);
+        bg = *reinterpret_cast<const f32x4*>(J.bias + J.gate_pos[2] * Ch + ch);
+        bo = *reinterpret_cast<const f32x4*>(J.bias + J.gate_pos[3] * Ch + ch);
+    }
+    float* const hout = J.e_out[0] ? J.e_out[0] + (size_t)b * J.h_bstride : nullptr;
+    char* const hsp = J.e_sp ? J.e_sp + (size_t)b * J.sp_bstride : nullptr;
+#pragma unroll
+    for (int pass = 0; pass < 64 / PPP; ++pass) {
+        const int pix = pass * PPP + pl;
+        const int y = y0 + 4 * wave + (pix >> 4), x = x0 + (pix & 15);
+        if (y >= H || x >= W) continue;
+        const size_t hw = (size_t)y * W + x, e = hw * Ch + ch, sidx = ((size_t)b * H * W) * Ch + e;
+        const float* row = ldsf + pix * NC + cgi * 4;
+        const f32x4 vi = *reinterpret_cast<const f32x4*>(row), vf = *reinterpret_cast<const f32x4*>(row + GC);
+        const f32x4 vg = *reinterpret_cast<const f32x4*>(row + 2 * GC), vo = *reinterpret_cast<const f32x4*>(row + 3 * GC);
+        f32x4 cp = {0.f, 0.f, 0.f, 0.f}, wi = cp, wf = cp, wo = cp;
+        if (J.e_in0) cp = *reinterpret_cast<const f32x4*>(J.e_in0 + sidx);
+        if (J.e_in1) { wi = *reinterpret_cast<const f32x4*>(J.e_in1 + e); wf = *reinterpret_cast<const f32x4*>(J.e_in2 + e); }
+        if (J.e_in3) wo = *reinterpret_cast<const f32x4*>(J.e_in3 + e);
+        f32x4 cn, hn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float i_ = sigmoid_f(vi[q] + bi[q] + wi[q] * cp[q]), f_ = sigmoid_f(vf[q] + bf[q] + wf[q] * cp[q]);
+            const float g_ = tanh_f(vg[q] + bg[q]);
+            cn[q] = f_ * cp[q] + i_ * g_;
+            const float o_ = sigmoid_f(vo[q] + bo[q] + wo[q] * cn[q]);
+            hn[q] = o_ * tanh_f(cn[q]);
+        }
+        *reinterpret_cast<f32x4*>(J.e_out[1] + sidx) = cn;
+        if (hout) *reinterpret_cast<f32x4*>(hout + e) = hn;
+        if (hsp) c5_store_split4(hsp, hw, Ch, ch, hn);
+    }
+}
+
+template <int NT, int KS = 5>
 __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
-    using G = C5Geom<NT>;
+    using G = C5Geom<NT, KS>;
+    constexpr int C5_ABUF = G::ABUF, C5_PLANE = G::PLANE, HWP = G::HWP, ORG = KS / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -931,18 +998,19 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     const int y0 = ty * 16, x0 = tx * 16;
 
     char* const Abuf = smem;
-    char* const Wbuf = smem + 2 * C5_ABUF;
+    char* const Wbuf = smem + G::NBUF * C5_ABUF;
     const int dma_off = wave * 1024;
 
-    // stage copy: 4 pieces per thread = [plane][512 positions]
-    int pixoff[4];
+    // stage copy: NPC pieces per thread = [plane][PLP positions]
+    int pixoff[G::NPC], choff[G::NPC];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < G::NPC; ++u) {
         const int piece = tid + 256 * u;
-        const int pos = piece & 511;
-        const int hy = pos / 20, hx = pos - hy * 20;
-        const int gy = y0 - 2 + hy, gx = x0 - 2 + hx;
-        pixoff[u] = (pos < 400 && (unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W) ? gy * P.W + gx : -1;
+        const int plane = piece / G::PLP, pos = piece - plane * G::PLP;
+        const int hy = pos / HWP, hx = pos - hy * HWP;
+        const int gy = y0 - ORG + hy, gx = x0 - ORG + hx;
+        pixoff[u] = (pos < G::NPOS && (unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W) ? gy * P.W + gx : -1;
+        choff[u] = plane * 16;
     }
     auto issue_A = [&](int s8, int buf) {   // stages past the job's K are filled with zeros (their weights are zeros too)
         const char* base = nullptr;
@@ -955,8 +1023,8 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
             prow = (unsigned)sc.prow;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const char* src = (base != nullptr && pixoff[u] >= 0) ? base + (size_t)((unsigned)pixoff[u] * (unsigned long long)prow) + (u >> 1) * 16
+        for (int u = 0; u < G::NPC; ++u) {
+            const char* src = (base != nullptr && pixoff[u] >= 0) ? base + (size_t)((unsigned)pixoff[u] * (unsigned long long)prow) + choff[u]
                                                                    : reinterpret_cast<const char*>(c2_zero16);
             c2_dma16(src, Abuf + buf * C5_ABUF + dma_off + u * 4096);
         }
@@ -977,21 +1045,27 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
 
     // fragments. A: row m of the wave's four tile rows, this lane's slot of period step p (k group kg): slot s = 4p + kg,
     // stage j = s / 25 (buffer j & 1), tap t = s % 25 = (dy, dx)
-    const int a_lane = ((4 * wave) * 20 + r16) * 16;
+    const int a_lane = ((4 * wave) * HWP + r16) * 16;
     auto a_off = [&](int p) {
         const int sl = 4 * p + kg;
-        const int j = (sl * 41) >> 10, t = sl - 25 * j;
-        const int dy = (t * 13) >> 6, dx = t - 5 * dy;
-        return a_lane + (j & 1) * C5_ABUF + (dy * 20 + dx) * 16;
+        if constexpr (KS == 5) {
+            const int j = (sl * 41) >> 10, t = sl - 25 * j;
+            const int dy = (t * 13) >> 6, dx = t - 5 * dy;
+            return a_lane + (j & 1) * C5_ABUF + (dy * HWP + dx) * 16;
+        } else {
+            const int j = (sl * 57) >> 9, t = sl - 9 * j;          // sl / 9 for sl < 36
+            const int dy = (t * 11) >> 5, dx = t - 3 * dy;         // t / 3 for t < 9
+            return a_lane + j * C5_ABUF + (dy * HWP + dx) * 16;
+        }
     };
     bf16x8 ah[4], al[4], bh[2], bl[2];
     auto load_A1 = [&](int off, int m) {
-        const char* a = smem + off + m * (20 * 16);
+        const char* a = smem + off + m * (HWP * 16);
         ah[m] = *reinterpret_cast<const bf16x8*>(a);
         al[m] = *reinterpret_cast<const bf16x8*>(a + C5_PLANE);
     };
     // B: chunk [half = nt >> 2][part][k group][64 columns][16 B] (NT = 4: one half)
-    const int w_lane = 2 * C5_ABUF + kg * G::KGS + r16 * 16;
+    const int w_lane = G::NBUF * C5_ABUF + kg * G::KGS + r16 * 16;
     auto load_B = [&](int slot, int nt) {
         const char* w = smem + w_lane + slot * G::WCH + (nt >> 2) * 8192 + (nt & 3) * 256;
         bh[nt & 1] = *reinterpret_cast<const bf16x8*>(w);
@@ -1002,6 +1076,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     const int nt_active = J.nt_active;
     if (Q > 0) {
         issue_A(0, 0);
+        if constexpr (KS == 3) { issue_A(1, 1); issue_A(2, 2); issue_A(3, 3); }   // (stages past the job's K: zero fill)
         issue_W(0, 0);
         if (Q > 1) { issue_W(1, 1); if constexpr (G::WP == 4) C2_WAIT_VM(4); else if constexpr (G::WP == 2) C2_WAIT_VM(2); else C2_WAIT_VM(1); }
         else C2_WAIT_VM(0);
@@ -1018,18 +1093,22 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
 #pragma unroll 1
     for (int P0 = 0; q < Q; P0 += 4) {          // period: stages P0 .. P0 + 3
 #pragma unroll 1
-        for (int p = 0; p < 25 && q < Q; ++p, ++q) {
+        for (int p = 0; p < G::SPS && q < Q; ++p, ++q) {
             const int nslot = slot == 2 ? 0 : slot + 1;
-            // stage requested at this step (after its sync point): period steps 0 / 7 / 13 / 19 -> stages P0 + 1 / + 2 / + 3 / + 4
-            const int want = p == 0 ? P0 + 1 : (p == 7 ? P0 + 2 : (p == 13 ? P0 + 3 : (p == 19 ? P0 + 4 : -1)));
+            // stage requested at this step (after its sync point). 5x5: period steps 0 / 7 / 13 / 19 -> stages P0 + 1 / + 2 / + 3 / + 4;
+            // 3x3: steps 3 / 5 / 7 -> stages P0 + 4 / + 5 / + 6 (the next period's first three), step 0 -> stage P0 + 3 (the prologue
+            // loaded the first period's)
+            int want;
+            if constexpr (KS == 5) want = p == 0 ? P0 + 1 : (p == 7 ? P0 + 2 : (p == 13 ? P0 + 3 : (p == 19 ? P0 + 4 : -1)));
+            else want = p == 3 ? P0 + 4 : (p == 5 ? P0 + 5 : (p == 7 ? P0 + 6 : ((p == 0 && P0 > 0) ? P0 + 3 : -1)));
             const bool issue = want >= 0 && want <= J.S8;   // (== S8: zero fill of the buffer a partial last step still reads)
-            const int np = p == 24 ? 0 : p + 1;
+            const int np = p == G::SPS - 1 ? 0 : p + 1;
             const int n_off = a_off(np);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (nt == SYNC_NT) {
                     // ---- sync point S_q: chunk q + 1 has landed (the stage requested one step ago may still fly) ----
-                    if (flies) C2_WAIT_VM(4); else C2_WAIT_VM(0);
+                    if (flies) { if constexpr (G::NPC == 4) C2_WAIT_VM(4); else C2_WAIT_VM(3); } else C2_WAIT_VM(0);
                     c2_barrier();
                 }
                 if (nt < NT - 1) load_B(slot, nt + 1);
@@ -1049,7 +1128,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
                 }
                 __builtin_amdgcn_s_setprio(0);
                 if (nt == SYNC_NT) { if (q + 2 < Q) issue_W(q + 2, slot == 0 ? 2 : slot - 1); }
-                if (nt == STAGE_NT && issue) issue_A(want, want & 1);
+                if (nt == STAGE_NT && issue) issue_A(want, KS == 5 ? (want & 1) : (want & 3));
             }
             flies = issue;
             slot = nslot;
@@ -1063,6 +1142,9 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     epi.a.out0 = J.out; epi.a.bstride0 = J.out_bstride; epi.a.ld0 = J.ld;
     int ngr = (J.Co + 31) / 32 - n_tile * (NT / 2);
     if (ngr > NT / 2) ngr = NT / 2;
+    if constexpr (KS == 3) {
+        if (J.epi == 3) { c5_finish_clstm<NT>(acc, smem, wave, lane, b, y0, x0, n_tile, J, P.H, P.W); return; }
+    }
     if constexpr (NT == 8) {
         if (J.epi == 1) c5_finish_gates(acc, smem, wave, lane, b, y0, x0, n_tile, J, P.H, P.W);
         else if (J.epi == 2) c5_finish_out(acc, smem, wave, lane, b, y0, x0, n_tile, 4, J, P.H, P.W);
@@ -1089,6 +1171,7 @@ struct C5PackArgs {
     int nrange, r_n[3];
     int flip, NT, gates;       // gates: number of gate groups of an N tile (0 = plain column order)
     int gate_major;            // gates > 0: plain column order oc = gate * Co + channel instead of gate-interleaved N tiles
+    int sps, gc;               // slots per stage (taps: 25 | 9); channels per gate of a gate-interleaved N tile (32; the ConvLSTM forms: NT * 4)
     int S8, Q, Co, n_tiles;    // Co: plain: output channels; gates: channels per gate (Ch)
 };
 __global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
@@ -1104,9 +1187,9 @@ __global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
         if (pk.NT == 8) { n += (int)(r & 1) * 64; r >>= 1; }
         const int q = (int)(r % pk.Q);
         const int n_tile = (int)(r / pk.Q);
-        const int p = q % 25, sl = 4 * p + kg;
-        const int j = sl / 25, t = sl - 25 * j;
-        const int s8 = 4 * (q / 25) + j;
+        const int p = q % pk.sps, sl = 4 * p + kg;
+        const int j = sl / pk.sps, t = sl - pk.sps * j;
+        const int s8 = 4 * (q / pk.sps) + j;
         float v = 0.0f;
         if (s8 < pk.S8) {
             int c = 8 * s8 + i, ri = 0;
@@ -1117,13 +1200,13 @@ __global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
                 const int oc = n_tile * (pk.NT * 16) + n, g = oc / pk.Co;
                 if (g < pk.gates) ocidx = rg.gate0[g] + (oc - g * pk.Co);
             } else if (pk.gates) {
-                const int g = n >> 5, chn = n_tile * 32 + (n & 31);
+                const int g = n / pk.gc, chn = n_tile * pk.gc + (n - g * pk.gc);
                 if (g < pk.gates && chn < pk.Co) ocidx = rg.gate0[g] + chn;
             } else {
                 const int oc = n_tile * (pk.NT * 16) + n;
                 if (oc < pk.Co) ocidx = rg.gate0[0] + oc;
             }
-            if (ocidx >= 0) v = rg.w[ocidx * rg.s_oc + (long long)(rg.c0 + c) * rg.s_c + (pk.flip ? 24 - t : t)];
+            if (ocidx >= 0) v = rg.w[ocidx * rg.s_oc + (long long)(rg.c0 + c) * rg.s_c + (pk.flip ? pk.sps - 1 - t : t)];
         }
         unsigned hi, lo;
         c2_split(v, hi, lo);
@@ -1131,28 +1214,30 @@ __global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
     }
 }
 
-size_t c5_wpk_bytes(int K, int Co, int NT, int gates) {
-    const int S8 = K / 8, Q = (25 * S8 + 3) / 4, n_tiles = gates ? (Co + 31) / 32 : (Co + NT * 16 - 1) / (NT * 16);
+size_t c5_wpk_bytes(int K, int Co, int NT, int gates, int ks) {
+    const int gc = ks == 3 ? NT * 4 : 32;   // channels per gate of a gate-interleaved N tile
+    const int S8 = K / 8, Q = (ks * ks * S8 + 3) / 4, n_tiles = gates ? (Co + gc - 1) / gc : (Co + NT * 16 - 1) / (NT * 16);
     return (size_t)n_tiles * Q * NT * 2048;
 }
 
 // fills the job's derived fields (S8, Q, n_tiles, nt_active) and packs its weights into job.wpk unless `packed`.
 // gates = 0: plain column order, Co output channels; gates = 3 | 4: gate-interleaved N tiles of 32 channels (NT = 8), Co = channels per gate
-int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s, int gate_major) {
+int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s, int gate_major, int ks) {
+    const int sps = ks * ks, gc = ks == 3 ? NT * 4 : 32;
     int K = 0;
     for (int i = 0; i < 3; ++i) {
         if (i >= j.nrange) { j.r_n[i] = 0; j.r_c0[i] = 0; j.r_src[i] = 0; }
         K += j.r_n[i];
         if ((j.r_n[i] | j.r_c0[i]) & 7) { set_error("c5: channel ranges in 8s"); return VPX_ERR_ARG; }
     }
-    if (gates && !gate_major && NT != 8) { set_error("c5: gate-interleaved tiles need NT = 8"); return VPX_ERR_ARG; }
-    j.S8 = K / 8; j.Q = (25 * j.S8 + 3) / 4;
+    if (gates && !gate_major && ks == 5 && NT != 8) { set_error("c5: gate-interleaved 5x5 tiles need NT = 8"); return VPX_ERR_ARG; }
+    j.S8 = K / 8; j.Q = (sps * j.S8 + 3) / 4;
     // gate_major: j.Co = all columns (gates x channels per gate), plain epilogue; else gates > 0: j.Co = channels per gate
-    j.n_tiles = (gates && !gate_major) ? (j.Co + 31) / 32 : (j.Co + NT * 16 - 1) / (NT * 16);
-    j.nt_active = (gates && !gate_major) ? 2 * gates : NT;
+    j.n_tiles = (gates && !gate_major) ? (j.Co + gc - 1) / gc : (j.Co + NT * 16 - 1) / (NT * 16);
+    j.nt_active = (gates && !gate_major && ks == 5) ? 2 * gates : NT;
     if (!packed) {
         C5PackArgs pk{};
-        pk.nrange = j.nrange; pk.flip = flip; pk.NT = NT; pk.gates = gates; pk.gate_major = gate_major;
+        pk.nrange = j.nrange; pk.flip = flip; pk.NT = NT; pk.gates = gates; pk.gate_major = gate_major; pk.sps = sps; pk.gc = gc;
         for (int i = 0; i < 3; ++i) { pk.r_n[i] = j.r_n[i]; if (i < j.nrange) pk.rg[i] = rg[i]; }
         pk.S8 = j.S8; pk.Q = j.Q; pk.Co = (gates && gate_major) ? j.Co / gates : j.Co; pk.n_tiles = j.n_tiles;
         const long long total = (long long)j.n_tiles * j.Q * NT * 1024;
@@ -1183,33 +1268,41 @@ void c5_chunk_job(const C5Job& full, const C5PackRange* prf, int k, int ks, C5Jo
     }
 }
 // bytes of chunk k's pack
-size_t c5_chunk_wpk_bytes(int K, int k, int ks, int cols, int NT) {
+size_t c5_chunk_wpk_bytes(int K, int k, int ks, int cols, int NT) {   // (5x5 jobs)
     const int S8 = K / 8;
     const int s8 = (int)((long long)S8 * (k + 1) / ks) - (int)((long long)S8 * k / ks);
     return (size_t)((cols + NT * 16 - 1) / (NT * 16)) * ((25 * s8 + 3) / 4) * NT * 2048;
 }
 
-hipError_t launch_c5(const C5Plan& P_in, int NT, hipStream_t s) {
+template <int NT, int KS>
+static hipError_t launch_c5_t(const C5Plan& P, unsigned grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&c5_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, C5Geom<8>::LDS);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&c5_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, C5Geom<4>::LDS);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&c5_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, C5Geom<2>::LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&c5_kernel<NT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, C5Geom<NT, KS>::LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    constexpr int lds = C5Geom<NT, KS>::LDS;
+    hipLaunchKernelGGL((c5_kernel<NT, KS>), dim3(grid), dim3(256), lds, s, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_c5(const C5Plan& P_in, int NT, hipStream_t s) {
     C5Plan P = P_in;
     P.tiles_x = (P.W + 15) / 16; P.tiles_y = (P.H + 15) / 16; P.m_tiles = P.B * P.tiles_x * P.tiles_y;
     const int Mx = (P.m_tiles + 7) / 8;
     long long per_xcd = 0;
     for (int j = 0; j < P.njobs; ++j) per_xcd += (long long)Mx * P.job[j].n_tiles;
     if (per_xcd < 1) return hipSuccess;
-    if (NT == 8) hipLaunchKernelGGL(c5_kernel<8>, dim3((unsigned)(per_xcd * 8)), dim3(256), C5Geom<8>::LDS, s, P);
-    else if (NT == 4) hipLaunchKernelGGL(c5_kernel<4>, dim3((unsigned)(per_xcd * 8)), dim3(256), C5Geom<4>::LDS, s, P);
-    else hipLaunchKernelGGL(c5_kernel<2>, dim3((unsigned)(per_xcd * 8)), dim3(256), C5Geom<2>::LDS, s, P);
-    return hipGetLastError();
+    const unsigned grid = (unsigned)(per_xcd * 8);
+    if (P.ks == 3) {   // the ConvLSTM step on small grids
+        if (NT == 4) return launch_c5_t<4, 3>(P, grid, s);
+        if (NT == 2) return launch_c5_t<2, 3>(P, grid, s);
+        return hipErrorInvalidValue;
+    }
+    if (NT == 8) return launch_c5_t<8, 5>(P, grid, s);
+    if (NT == 4) return launch_c5_t<4, 5>(P, grid, s);
+    return launch_c5_t<2, 5>(P, grid, s);
 }
 
 }  // namespace vpx

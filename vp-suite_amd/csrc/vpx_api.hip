@@ -88,10 +88,25 @@ size_t vpx_convlstm_reserve_bytes(const vpx_convlstm_desc* d) {
 }
 
 // one cell2 weight pack: an upper bound over both MFMA forms (the q form rounds an odd stage count up by half a stage)
+// c3 (convq.hip: c5_kernel<NT, 3>, round 4): the fused step on 16x16-pixel tiles x (4 gates x NT * 4 channels) with 8-channel stages, for the
+// launches in which the half tile of cell2_kernel_q leaves most of the chip empty (B = 4 on 64x64 maps: 128 workgroups of four waves,
+// one wave per SIMD on half the CUs, each running 36 steps of 96 MFMAs plus a 25 k-cycle epilogue alone). Halving / quartering the N
+// tile doubles / quadruples the waves and shortens each wave's critical path. Inference only (it does not write the saved gates).
+// VPX_OPT_EXPERIMENT bit 12 keeps the half tile there (A/B runs, tests).
+static int c3_nt(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {   // 0: not applicable; else column tiles per N tile (4 | 2)
+    if (!L.v2 || !cell2_q_applicable(d) || d->precision != VPX_PREC_BF16X3 || (d->flags & VPX_FLAG_SAVE_FOR_BWD) || (g_experiment & 4096)) return 0;
+    if ((d->Cin & 7) || (d->Ch & 15)) return 0;
+    const long long mt = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
+    if (mt * L.n_tiles >= 256) return 0;                 // the half tile fills the chip
+    return mt * (d->Ch / 16) >= 384 ? 4 : ((d->Ch & 7) ? 4 : 2);
+}
+
 static size_t cell2_wpk_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
     const int S = (d->Cin + d->Ch) / 16;
     const size_t a = cell2_packed_bytes(L.n_tiles, 3 * S), b = cell2_packed_bytes_q(L.n_tiles, S);
-    return a > b ? a : b;
+    size_t m = a > b ? a : b;
+    for (int nt = 2; nt <= 4; nt += 2) { const size_t c = c5_wpk_bytes(d->Cin + d->Ch, d->Ch, nt, 4, 3); if (c > m) m = c; }
+    return m;
 }
 
 static size_t convlstm_wpk_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
@@ -290,6 +305,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     // q form (16x16x32 MFMAs): the K = 32 steps pair taps over the sequence of PRESENT stages, so steps with different operand
     // sets (t = 0 without an initial state: x only; no input tensor: h only) read different packs — at most two per call
     const int qform = (L.v2 && cell2_q_applicable(d)) ? 1 : 0;
+    const int c3nt = c3_nt(d, L);   // > 0: the small-grid 3x3 form on the c5 machinery takes the steps (its packs replace the q packs)
     const int combo0 = (xn ? 1 : 0) | (h0n ? 2 : 0), combo1 = (xn ? 1 : 0) | 2;   // operand sets of step 0 / of steps t >= 1
     auto pack_of = [&](int combo) -> char* { return combo == combo1 ? wpk2 : wpk2b; };
     if (L.v2) {
@@ -309,7 +325,17 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
                 if (combo & 1) for (int s = 0; s < Cin / 16; ++s) pk.stage_col[pk.S++] = 16 * s;
                 if (combo & 2) for (int s = 0; s < Ch / 16; ++s) pk.stage_col[pk.S++] = Cin + 16 * s;
                 pk.chunks_total = cell2_qchunks(pk.S);
-                if (!wp) VPX_CHECK_HIP(launch_cell2_pack(pk, pack_of(combo), stream));
+                if (!wp && !c3nt) VPX_CHECK_HIP(launch_cell2_pack(pk, pack_of(combo), stream));
+                if (!wp && c3nt) {   // the same operand sets, packed for c5_kernel<NT, 3>
+                    C5Job j{};
+                    C5PackRange pr[2];
+                    const long long so = (long long)(Cin + Ch) * 9;
+                    if (combo & 1) { j.r_n[j.nrange] = Cin; pr[j.nrange] = C5PackRange{W, so, 9, 0, {gp[0] * Ch, gp[1] * Ch, gp[2] * Ch, gp[3] * Ch}}; ++j.nrange; }
+                    if (combo & 2) { j.r_n[j.nrange] = Ch; pr[j.nrange] = C5PackRange{W, so, 9, Cin, {gp[0] * Ch, gp[1] * Ch, gp[2] * Ch, gp[3] * Ch}}; ++j.nrange; }
+                    j.Co = Ch; j.wpk = pack_of(combo);
+                    int rcp = c5_prepare_job(j, c3nt, pr, 4, 0, false, stream, 0, 3);
+                    if (rcp) return rcp;
+                }
             }
         }
         // operands of the steps in split form: the whole input sequence and the initial hidden state, once
@@ -468,7 +494,26 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
                 P2.wpk = pack_of((P2.nx ? 1 : 0) | (P2.nh ? 2 : 0));
             }
             // the split copy of h_t feeds step t+1 only: the last step does not need it
-            VPX_CHECK_HIP(launch_cell2(P2, ea, (t + 1 < T || out_split) ? h_slot(t) : nullptr, hsp_bs, stream));
+            char* const hsp_t = (t + 1 < T || out_split) ? h_slot(t) : nullptr;
+            if (c3nt) {
+                C5Plan cp{};
+                cp.B = B; cp.H = H; cp.W = Wd; cp.ks = 3;
+                cp.src[0] = C5Src{P2.seg[0].sp, P2.seg[0].bstride, Cin * 4, 0};
+                cp.src[1] = C5Src{P2.seg[1].sp, P2.seg[1].bstride, Ch * 4, 0};
+                C5Job& j = cp.job[cp.njobs++];
+                j = C5Job{};
+                if (P2.nx) { j.r_src[j.nrange] = 0; j.r_n[j.nrange] = Cin; ++j.nrange; }
+                if (P2.nh) { j.r_src[j.nrange] = 1; j.r_n[j.nrange] = Ch; ++j.nrange; }
+                j.epi = 3; j.Co = Ch; j.Ch = Ch; j.wpk = P2.wpk;
+                j.e_in0 = ea.c_in; j.e_in1 = ea.wci; j.e_in2 = ea.wcf; j.e_in3 = ea.wco; j.bias = ea.bias;
+                for (int g = 0; g < 4; ++g) j.gate_pos[g] = ea.gate_pos[g];
+                j.e_out[0] = ea.h_out; j.e_out[1] = ea.c_out; j.h_bstride = ea.h_bstride;
+                j.e_sp = hsp_t; j.sp_bstride = hsp_bs;
+                const int rcj = c5_prepare_job(j, c3nt, nullptr, 4, 0, true, stream, 0, 3);   // (derived fields only: the pack is in place)
+                if (rcj) return rcj;
+                VPX_CHECK_HIP(launch_c5(cp, c3nt, stream));
+            } else
+            VPX_CHECK_HIP(launch_cell2(P2, ea, hsp_t, hsp_bs, stream));
         } else if (hoist) {
             // the step contracts only h_{t-1} and accumulates (atomics when K is split) into its slice of the hoisted input
             // projection; the pointwise kernel reads that slice (batch stride T*HW*4Ch) and writes gates / c / h

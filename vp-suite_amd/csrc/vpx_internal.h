@@ -463,16 +463,22 @@ struct C5Job {
     int Ch, ng; float fbias;                 // epi 1 / 2: channels of the state tensors [B,HW,Ch]; epi 1: gate groups (4: i,f,g,o_pre; 3: i',f',g'), forget bias
     const float* e_in0; const float* e_in1;  // epi 1: s_in (c or m); epi 2: o_pre, conv_last(mem)
     float* e_out[4];                         // epi 1: s_new, delta, o_pre (ng = 4), saved gates [B,HW,3Ch] or null; epi 2: h_new, o_save, tl_save (or null)
-    char* e_sp;                              // epi 1 / 2: s_new / h_new once more in the split format, or null
+    char* e_sp;                              // epi 1 / 2 / 3: s_new / h_new once more in the split format, or null
+    // epi 3 (3x3 jobs): the ConvLSTM step (conv_lstm_hzzone.py:59-68 / conv_lstm_ndrplz.py:31-41) on a gate-interleaved N tile of NT * 4 channels:
+    // e_in0 = c_in (or null: zeros), e_in1..3 = peepholes Wci, Wcf, Wco [H,W,Ch] (or null together), e_out[0] = h_out (or null), e_out[1] = c_out
+    const float* e_in2; const float* e_in3; const float* bias;   // bias: reference layout [4Ch] or null
+    int gate_pos[4];                         // position of the logical gates (i,f,g,o) in the reference's 4Ch axis
+    long long h_bstride, sp_bstride;         // elements between batch items of h_out; BYTES between batch items of e_sp
 };
 struct C5Plan {
     int B, H, W, tiles_x, tiles_y, m_tiles;
     C5Src src[4];
+    int ks;                                  // kernel size of every job: 0 | 5 = 5x5 (ST-LSTM step), 3 = 3x3 (ConvLSTM step on small grids)
     int njobs; C5Job job[C5_MAX_JOBS];
 };
 struct C5PackRange { const float* w; long long s_oc, s_c; int c0; int gate0[4]; };   // weights of one K range (see c5_pack_kernel)
-size_t c5_wpk_bytes(int K, int Co, int NT, int gates = 0);
-int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s, int gate_major = 0);
+size_t c5_wpk_bytes(int K, int Co, int NT, int gates = 0, int ks = 5);
+int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s, int gate_major = 0, int ks = 5);
 void c5_chunk_job(const C5Job& full, const C5PackRange* prf, int k, int ks, C5Job& j, C5PackRange* pr);   // K-split: chunk k of ks
 size_t c5_chunk_wpk_bytes(int K, int k, int ks, int cols, int NT);
 hipError_t launch_c5(const C5Plan& P, int NT, hipStream_t s);   // NT = 8: 128-column N tiles, 4: 64-column
