@@ -797,8 +797,16 @@ template <int NT, int KS = 5> struct C5Geom {
     static constexpr int WP = WCH / (256 * 16);           // DMAs per thread and chunk: 4 | 2 | 1
     static constexpr int HCOLS = NT >= 4 ? 64 : NT * 16;  // columns of a chunk half ([half][part][k group][HCOLS][16 B])
     static constexpr int KGS = HCOLS * 16, PARTS = 4 * KGS;
-    static constexpr int LDS = NBUF * ABUF + 3 * WCH >= 65536 ? NBUF * ABUF + 3 * WCH : 65536;   // >= 64 KiB: 4 waves x 16 KiB in the epilogue
+    // Weight ring: RD chunks, chunk q + RD - 1 is requested at the sync point of step q. Three for the 128-column tiles (96 MFMAs per wave
+    // and step: one step of MFMA time covers the copy's latency); the narrow tiles run 48 / 24 MFMAs per step — less than a copy takes to
+    // land (measured: c5_kernel<2, 3> 34 us for 36 steps = 0.9 us per step, the L2 latency, against 14 k cycles of MFMAs) — and request
+    // three / four steps ahead.
+    static constexpr int RD = NT == 8 ? 3 : (KS == 3 && NT == 4 ? 4 : 5);
+    static constexpr int PD = RD - 1;                     // prefetch distance in steps
+    static constexpr int WAITN = (PD - 2) * WP;           // copies that may still fly at a sync point (the chunks after q + 1)
+    static constexpr int LDS = NBUF * ABUF + RD * WCH >= 65536 ? NBUF * ABUF + RD * WCH : 65536;   // >= 64 KiB: 4 waves x 16 KiB in the epilogue
 };
+template <int N> __device__ __forceinline__ void c5_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 __device__ __forceinline__ void c5_chan_of_stage(const C5Job& j, int s8, int& src, int& chan) {   // source and first channel of the job's stage s8
     int c = 8 * s8;
@@ -1078,8 +1086,14 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
         issue_A(0, 0);
         if constexpr (KS == 3) { issue_A(1, 1); issue_A(2, 2); issue_A(3, 3); }   // (stages past the job's K: zero fill)
         issue_W(0, 0);
-        if (Q > 1) { issue_W(1, 1); if constexpr (G::WP == 4) C2_WAIT_VM(4); else if constexpr (G::WP == 2) C2_WAIT_VM(2); else C2_WAIT_VM(1); }
-        else C2_WAIT_VM(0);
+        if (Q >= G::PD) {   // chunks 1 .. PD - 1 go out too; everything before them has landed when only they still fly
+#pragma unroll
+            for (int c = 1; c < G::PD; ++c) issue_W(c, c);
+            c5_wait_vm<(G::PD - 1) * G::WP>();
+        } else {
+            for (int c = 1; c < Q; ++c) issue_W(c, c);
+            C2_WAIT_VM(0);
+        }
         c2_barrier();
         const int o0 = a_off(0);
 #pragma unroll
@@ -1094,7 +1108,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     for (int P0 = 0; q < Q; P0 += 4) {          // period: stages P0 .. P0 + 3
 #pragma unroll 1
         for (int p = 0; p < G::SPS && q < Q; ++p, ++q) {
-            const int nslot = slot == 2 ? 0 : slot + 1;
+            const int nslot = slot == G::RD - 1 ? 0 : slot + 1;
             // stage requested at this step (after its sync point). 5x5: period steps 0 / 7 / 13 / 19 -> stages P0 + 1 / + 2 / + 3 / + 4;
             // 3x3: steps 3 / 5 / 7 -> stages P0 + 4 / + 5 / + 6 (the next period's first three), step 0 -> stage P0 + 3 (the prologue
             // loaded the first period's)
@@ -1108,7 +1122,13 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
             for (int nt = 0; nt < NT; ++nt) {
                 if (nt == SYNC_NT) {
                     // ---- sync point S_q: chunk q + 1 has landed (the stage requested one step ago may still fly) ----
-                    if (flies) { if constexpr (G::NPC == 4) C2_WAIT_VM(4); else C2_WAIT_VM(3); } else C2_WAIT_VM(0);
+                    if constexpr (G::PD == 2) {
+                        if (flies) c5_wait_vm<G::NPC>(); else C2_WAIT_VM(0);
+                    } else {
+                        // chunks q + 2 .. q + PD - 1 may fly (a stage copy among them lands early: in-order completion); at the tail, where
+                        // no further chunk is behind q + 1, everything must have landed
+                        if (q + G::PD <= Q) c5_wait_vm<G::WAITN>(); else C2_WAIT_VM(0);
+                    }
                     c2_barrier();
                 }
                 if (nt < NT - 1) load_B(slot, nt + 1);
@@ -1127,7 +1147,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
                     if (nt == NT - 1) load_A1(n_off, m);   // the step's last tile frees row m: the next step's fragments
                 }
                 __builtin_amdgcn_s_setprio(0);
-                if (nt == SYNC_NT) { if (q + 2 < Q) issue_W(q + 2, slot == 0 ? 2 : slot - 1); }
+                if (nt == SYNC_NT) { if (q + G::PD < Q) issue_W(q + G::PD, slot == 0 ? G::RD - 1 : slot - 1); }
                 if (nt == STAGE_NT && issue) issue_A(want, KS == 5 ? (want & 1) : (want & 3));
             }
             flies = issue;
