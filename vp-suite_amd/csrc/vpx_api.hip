@@ -97,8 +97,12 @@ static int c3_nt(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {   // 0: 
     if (!L.v2 || !cell2_q_applicable(d) || d->precision != VPX_PREC_BF16X3 || (d->flags & VPX_FLAG_SAVE_FOR_BWD) || (g_experiment & 4096)) return 0;
     if ((d->Cin & 7) || (d->Ch & 15)) return 0;
     const long long mt = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
-    if (mt * L.n_tiles >= 256) return 0;                 // the half tile fills the chip
-    return mt * (d->Ch / 16) >= 384 ? 4 : ((d->Ch & 7) ? 4 : 2);
+    // Measured (round 4, B = 4): 64x64 maps, Ch = 64 (128 half-tile workgroups): 39 -> 34 us per step with 32-column tiles (512 workgroups;
+    // 64-column tiles 36 us), inference step 1.90 -> 1.74 ms; with 192 half-tile workgroups (64x64 maps, Ch = 96: configs[3]'s shard) the
+    // half tile wins (5.64 vs 5.97 ms per step). The narrow tiles are bound by their per-step overhead (24 MFMAs between sync points:
+    // PMC MFMA busy 27 %), not by the copy latency (a five-deep weight ring changed nothing).
+    if (mt * L.n_tiles > 128) return 0;
+    return (d->Ch & 7) ? 4 : 2;
 }
 
 static size_t cell2_wpk_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
