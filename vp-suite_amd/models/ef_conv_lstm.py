@@ -56,6 +56,13 @@ def _conv_cfg(m):
     return None
 
 
+def _glue_precision(cell_precision: str) -> str:
+    """Arithmetic of the stage glue for a model whose cells run in `cell_precision`. The plain-bf16 cell mode (inference extras) keeps the
+    glue on bf16x3: the schedule-driven split-operand kernels (convq, operand-format handovers) only exist there, they are FASTER than the
+    first-generation bf16 forms (measured B = 128: glue 3.7 vs 1.9 ms of a 14.2 ms step) and more accurate."""
+    return "bf16x3" if cell_precision == "bf16" else cell_precision
+
+
 def _stage_takes_split(subnet: nn.Sequential, n, c, h, w, precision):
     """True when the stage's first layer can read its input in the split-bf16 operand format (inference): the producing
     recurrent block then writes that format only."""
@@ -146,7 +153,7 @@ def _block_out_split(rnn, next_stage, batch, seq_len):
         return False
     if next_stage is None:
         return True
-    return _stage_takes_split(next_stage, batch * seq_len, rnn.enc_c, rnn.state_h, rnn.state_w, getattr(rnn, "precision", "f32"))
+    return _stage_takes_split(next_stage, batch * seq_len, rnn.enc_c, rnn.state_h, rnn.state_w, _glue_precision(getattr(rnn, "precision", "f32")))
 
 
 class Encoder(nn.Module):
@@ -159,7 +166,7 @@ class Encoder(nn.Module):
             setattr(self, f"rnn{index}", rnn)
 
     def forward_by_stage(self, input, subnet, rnn, next_stage=None, last=False):
-        input = _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"), consumer=rnn)
+        input = _apply_framewise(subnet, input, _glue_precision(getattr(rnn, "precision", "f32")), consumer=rnn)
         b, t = input.shape[:2]
         if (last or next_stage is not None) and _block_out_split(rnn, next_stage, b, t):
             return rnn(input, None, seq_len=t, out_split=True)
@@ -189,7 +196,7 @@ class Forecaster(nn.Module):
             input, _ = rnn(input, state, pred_frames, out_split=True)
         else:
             input, _ = rnn(input, state, pred_frames)
-        return _apply_framewise(subnet, input, getattr(rnn, "precision", "f32"), consumer=next_rnn)
+        return _apply_framewise(subnet, input, _glue_precision(getattr(rnn, "precision", "f32")), consumer=next_rnn)
 
     def forward(self, hidden_states, pred_frames):
         # like the reference (ef_blocks.py:109-110) the top block is addressed as stage3/rnn3 and gets no input
