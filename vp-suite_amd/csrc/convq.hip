@@ -1082,6 +1082,9 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
 
     const int Q = J.Q;
     const int nt_active = J.nt_active;
+    // developer timing stamps (P.stamps != nullptr only from tools/): shader clock of one workgroup's waves at the phase boundaries
+    const bool stamp = P.stamps != nullptr && (int)blockIdx.x == P.stamp_block && lane == 0;
+    if (stamp) P.stamps[wave * 8 + 0] = __builtin_amdgcn_s_memtime();
     if (Q > 0) {
         issue_A(0, 0);
         if constexpr (KS == 3) { issue_A(1, 1); issue_A(2, 2); issue_A(3, 3); }   // (stages past the job's K: zero fill)
@@ -1102,7 +1105,8 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     }
     constexpr int SYNC_NT = NT == 8 ? 5 : (NT == 4 ? 2 : 1);    // the sync point sits before this column tile of every step
     constexpr int STAGE_NT = SYNC_NT + 1 < NT ? SYNC_NT + 1 : NT - 1;   // the stage copy follows the weight copy (same tile when there is no later one)
-    int q = 0, slot = 0;                        // global step, its ring slot (q % 3)
+    if (stamp) P.stamps[wave * 8 + 1] = __builtin_amdgcn_s_memtime();
+    int q = 0, slot = 0;                        // global step, its ring slot (q % RD)
     bool flies = false;                         // a stage copy was issued in the previous step (it may still fly at this step's sync)
 #pragma unroll 1
     for (int P0 = 0; q < Q; P0 += 4) {          // period: stages P0 .. P0 + 3
@@ -1155,6 +1159,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
         }
     }
     C2_WAIT_VM(0);
+    if (stamp) P.stamps[wave * 8 + 2] = __builtin_amdgcn_s_memtime();
     // ---- epilogue: ConvQEpi (fp32 destination, optional accumulate), the wave's four tile rows ----
     ConvQEpi epi{};
     epi.a.Co = J.Co; epi.a.split = J.Co; epi.a.gpt = NT / 2; epi.a.phases = 0; epi.a.accumulate = J.accumulate;
@@ -1163,7 +1168,11 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     int ngr = (J.Co + 31) / 32 - n_tile * (NT / 2);
     if (ngr > NT / 2) ngr = NT / 2;
     if constexpr (KS == 3) {
-        if (J.epi == 3) { c5_finish_clstm<NT>(acc, smem, wave, lane, b, y0, x0, n_tile, J, P.H, P.W); return; }
+        if (J.epi == 3) {
+            c5_finish_clstm<NT>(acc, smem, wave, lane, b, y0, x0, n_tile, J, P.H, P.W);
+            if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); P.stamps[wave * 8 + 3] = __builtin_amdgcn_s_memtime(); }
+            return;
+        }
     }
     if constexpr (NT == 8) {
         if (J.epi == 1) c5_finish_gates(acc, smem, wave, lane, b, y0, x0, n_tile, J, P.H, P.W);
@@ -1307,8 +1316,17 @@ static hipError_t launch_c5_t(const C5Plan& P, unsigned grid, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifdef VPX_DEV_SWITCHES
+static unsigned long long* g_c5_stamps = nullptr;
+static int g_c5_stamp_block = 0;
+extern "C" int vpx_dbg_c5_stamps(unsigned long long* dev_buf, int block) { g_c5_stamps = dev_buf; g_c5_stamp_block = block; return 0; }
+#endif
+
 hipError_t launch_c5(const C5Plan& P_in, int NT, hipStream_t s) {
     C5Plan P = P_in;
+#ifdef VPX_DEV_SWITCHES
+    P.stamps = g_c5_stamps; P.stamp_block = g_c5_stamp_block;
+#endif
     P.tiles_x = (P.W + 15) / 16; P.tiles_y = (P.H + 15) / 16; P.m_tiles = P.B * P.tiles_x * P.tiles_y;
     const int Mx = (P.m_tiles + 7) / 8;
     long long per_xcd = 0;

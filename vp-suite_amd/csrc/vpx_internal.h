@@ -474,6 +474,7 @@ struct C5Plan {
     int B, H, W, tiles_x, tiles_y, m_tiles;
     C5Src src[4];
     int ks;                                  // kernel size of every job: 0 | 5 = 5x5 (ST-LSTM step), 3 = 3x3 (ConvLSTM step on small grids)
+    unsigned long long* stamps; int stamp_block;   // developer timing stamps (null in the product; vpx_dbg_c5_stamps)
     int njobs; C5Job job[C5_MAX_JOBS];
 };
 struct C5PackRange { const float* w; long long s_oc, s_c; int c0; int gate0[4]; };   // weights of one K range (see c5_pack_kernel)
