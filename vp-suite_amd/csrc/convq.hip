@@ -797,14 +797,14 @@ template <int NT, int KS = 5> struct C5Geom {
     static constexpr int WP = WCH / (256 * 16);           // DMAs per thread and chunk: 4 | 2 | 1
     static constexpr int HCOLS = NT >= 4 ? 64 : NT * 16;  // columns of a chunk half ([half][part][k group][HCOLS][16 B])
     static constexpr int KGS = HCOLS * 16, PARTS = 4 * KGS;
-    // Sync points. The 128-column tiles run 96 MFMAs per wave and step and synchronise every step; the narrow tiles (48 / 24 MFMAs per
-    // step) spent more time at their per-step sync point than in the MFMAs (in-kernel stamps, c5_kernel<2, 3> at B = 4: 1 420-1 660
-    // cycles per step for 384 cycles of MFMAs; a five-deep weight ring changed nothing: not the copy latency) — they take SS = 2 steps
-    // per sync point: the weight ring holds three MACRO chunks of SS steps, chunk m + 2 is requested at the sync point of macro step m.
-    static constexpr int SS = (NT == 8 || (KS == 3 && NT == 4)) ? 1 : 2;
-    static constexpr int MCH = SS * WCH;                  // bytes of a macro chunk
-    static constexpr int RD = 3;
-    static constexpr int LDS = NBUF * ABUF + RD * MCH >= 65536 ? NBUF * ABUF + RD * MCH : 65536;   // >= 64 KiB: 4 waves x 16 KiB in the epilogue
+    // Weight ring: RD chunks, chunk q + RD - 1 is requested at the sync point of step q. Three for the 128-column tiles (96 MFMAs per wave
+    // and step: one step of MFMA time covers the copy's latency); the narrow tiles run 48 / 24 MFMAs per step — less than a copy takes to
+    // land (measured: c5_kernel<2, 3> 34 us for 36 steps = 0.9 us per step, the L2 latency, against 14 k cycles of MFMAs) — and request
+    // three / four steps ahead.
+    static constexpr int RD = NT == 8 ? 3 : (KS == 3 && NT == 4 ? 4 : 5);
+    static constexpr int PD = RD - 1;                     // prefetch distance in steps
+    static constexpr int WAITN = (PD - 2) * WP;           // copies that may still fly at a sync point (the chunks after q + 1)
+    static constexpr int LDS = NBUF * ABUF + RD * WCH >= 65536 ? NBUF * ABUF + RD * WCH : 65536;   // >= 64 KiB: 4 waves x 16 KiB in the epilogue
 };
 template <int N> __device__ __forceinline__ void c5_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
@@ -1038,9 +1038,9 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
         }
     };
     const char* const wtile = J.wpk + (size_t)n_tile * J.Q * G::WCH + tid * 16;
-    auto issue_W = [&](int mq, int slot) {   // macro chunk mq = steps SS * mq .. + SS - 1 (the pack is padded to whole macro chunks)
+    auto issue_W = [&](int q, int slot) {
 #pragma unroll
-        for (int w = 0; w < G::SS * G::WP; ++w) c2_dma16(wtile + (size_t)mq * G::MCH + w * 4096, Wbuf + slot * G::MCH + dma_off + w * 4096);
+        for (int w = 0; w < G::WP; ++w) c2_dma16(wtile + (size_t)q * G::WCH + w * 4096, Wbuf + slot * G::WCH + dma_off + w * 4096);
     };
 
     f32x4 acc[4][NT];
@@ -1074,8 +1074,8 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     };
     // B: chunk [half = nt >> 2][part][k group][64 columns][16 B] (NT = 4: one half)
     const int w_lane = G::NBUF * C5_ABUF + kg * G::KGS + r16 * 16;
-    auto load_B = [&](int slot, int sub, int nt) {   // ring slot of the macro chunk, step inside it, column tile
-        const char* w = smem + w_lane + slot * G::MCH + sub * G::WCH + (nt >> 2) * 8192 + (nt & 3) * 256;
+    auto load_B = [&](int slot, int nt) {
+        const char* w = smem + w_lane + slot * G::WCH + (nt >> 2) * 8192 + (nt & 3) * 256;
         bh[nt & 1] = *reinterpret_cast<const bf16x8*>(w);
         bl[nt & 1] = *reinterpret_cast<const bf16x8*>(w + G::PARTS);
     };
@@ -1088,33 +1088,34 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     if (Q > 0) {
         issue_A(0, 0);
         if constexpr (KS == 3) { issue_A(1, 1); issue_A(2, 2); issue_A(3, 3); }   // (stages past the job's K: zero fill)
-        const int MQ = (Q + G::SS - 1) / G::SS;   // macro steps
         issue_W(0, 0);
-        if (MQ > 1) { issue_W(1, 1); c5_wait_vm<G::SS * G::WP>(); }   // (macro chunk 1 may still fly)
-        else C2_WAIT_VM(0);
+        if (Q >= G::PD) {   // chunks 1 .. PD - 1 go out too; everything before them has landed when only they still fly
+#pragma unroll
+            for (int c = 1; c < G::PD; ++c) issue_W(c, c);
+            c5_wait_vm<(G::PD - 1) * G::WP>();
+        } else {
+            for (int c = 1; c < Q; ++c) issue_W(c, c);
+            C2_WAIT_VM(0);
+        }
         c2_barrier();
         const int o0 = a_off(0);
 #pragma unroll
         for (int m = 0; m < 4; ++m) load_A1(o0, m);
-        load_B(0, 0, 0);
+        load_B(0, 0);
     }
     constexpr int SYNC_NT = NT == 8 ? 5 : (NT == 4 ? 2 : 1);    // the sync point sits before this column tile of every step
     constexpr int STAGE_NT = SYNC_NT + 1 < NT ? SYNC_NT + 1 : NT - 1;   // the stage copy follows the weight copy (same tile when there is no later one)
     if (stamp) P.stamps[wave * 8 + 1] = __builtin_amdgcn_s_memtime();
-    const int MQ = (Q + G::SS - 1) / G::SS;
-    int q = 0, slot = 0, sub = 0, mq = 0;       // global step; ring slot of its macro chunk; step inside the macro chunk; macro step
-    bool flies = false, flies_now = false;      // a stage copy was issued in the previous / in this macro step
+    int q = 0, slot = 0;                        // global step, its ring slot (q % RD)
+    bool flies = false;                         // a stage copy was issued in the previous step (it may still fly at this step's sync)
 #pragma unroll 1
     for (int P0 = 0; q < Q; P0 += 4) {          // period: stages P0 .. P0 + 3
 #pragma unroll 1
         for (int p = 0; p < G::SPS && q < Q; ++p, ++q) {
             const int nslot = slot == G::RD - 1 ? 0 : slot + 1;
-            const bool last_sub = sub == G::SS - 1;
-            // stage requested at this step. 5x5: period steps 0 / 7 / 13 / 19 -> stages P0 + 1 / + 2 / + 3 / + 4; 3x3: steps 3 / 5 / 7 ->
-            // stages P0 + 4 / + 5 / + 6 (the next period's first three), step 0 -> stage P0 + 3 (the prologue loaded the first period's).
-            // A copy requested in macro step m may fly at the sync point of m + 1 and has landed at that of m + 2: at most four steps
-            // later, always before the first read of the stage (and never before the last read of the buffer's previous tenant: the
-            // sync point of this or the previous step lies behind it).
+            // stage requested at this step (after its sync point). 5x5: period steps 0 / 7 / 13 / 19 -> stages P0 + 1 / + 2 / + 3 / + 4;
+            // 3x3: steps 3 / 5 / 7 -> stages P0 + 4 / + 5 / + 6 (the next period's first three), step 0 -> stage P0 + 3 (the prologue
+            // loaded the first period's)
             int want;
             if constexpr (KS == 5) want = p == 0 ? P0 + 1 : (p == 7 ? P0 + 2 : (p == 13 ? P0 + 3 : (p == 19 ? P0 + 4 : -1)));
             else want = p == 3 ? P0 + 4 : (p == 5 ? P0 + 5 : (p == 7 ? P0 + 6 : ((p == 0 && P0 > 0) ? P0 + 3 : -1)));
@@ -1123,14 +1124,19 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
             const int n_off = a_off(np);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if (nt == SYNC_NT && sub == 0) {
-                    // ---- sync point of macro step mq: macro chunk mq + 1 has landed (the stage requested in the previous macro step may still fly) ----
-                    if (flies) c5_wait_vm<G::NPC>(); else C2_WAIT_VM(0);
+                if (nt == SYNC_NT) {
+                    // ---- sync point S_q: chunk q + 1 has landed (the stage requested one step ago may still fly) ----
+                    if constexpr (G::PD == 2) {
+                        if (flies) c5_wait_vm<G::NPC>(); else C2_WAIT_VM(0);
+                    } else {
+                        // chunks q + 2 .. q + PD - 1 may fly (a stage copy among them lands early: in-order completion); at the tail, where
+                        // no further chunk is behind q + 1, everything must have landed
+                        if (q + G::PD <= Q) c5_wait_vm<G::WAITN>(); else C2_WAIT_VM(0);
+                    }
                     c2_barrier();
                 }
-                if (nt < NT - 1) load_B(slot, sub, nt + 1);
-                else if (!last_sub) load_B(slot, sub + 1, 0);
-                else load_B(nslot, 0, 0);
+                if (nt < NT - 1) load_B(slot, nt + 1);
+                else load_B(nslot, 0);
                 __builtin_amdgcn_s_setprio(1);
                 const bool go = nt < nt_active;   // (a job whose N tile holds fewer column tiles skips the MFMAs of the empty ones)
 #pragma unroll
@@ -1145,12 +1151,11 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
                     if (nt == NT - 1) load_A1(n_off, m);   // the step's last tile frees row m: the next step's fragments
                 }
                 __builtin_amdgcn_s_setprio(0);
-                if (nt == SYNC_NT && sub == 0) { if (mq + 2 < MQ) issue_W(mq + 2, slot == 0 ? G::RD - 1 : slot - 1); }
+                if (nt == SYNC_NT) { if (q + G::PD < Q) issue_W(q + G::PD, slot == 0 ? G::RD - 1 : slot - 1); }
                 if (nt == STAGE_NT && issue) issue_A(want, KS == 5 ? (want & 1) : (want & 3));
             }
-            flies_now = flies_now || issue;
-            if (last_sub) { flies = flies_now; flies_now = false; slot = nslot; sub = 0; ++mq; }
-            else ++sub;
+            flies = issue;
+            slot = nslot;
         }
     }
     C2_WAIT_VM(0);
@@ -1241,7 +1246,7 @@ __global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
 size_t c5_wpk_bytes(int K, int Co, int NT, int gates, int ks) {
     const int gc = ks == 3 ? NT * 4 : 32;   // channels per gate of a gate-interleaved N tile
     const int S8 = K / 8, Q = (ks * ks * S8 + 3) / 4, n_tiles = gates ? (Co + gc - 1) / gc : (Co + NT * 16 - 1) / (NT * 16);
-    return (size_t)n_tiles * Q * NT * 2048 + (size_t)NT * 2048;   // (+ one step: the last macro chunk's copy may run past an odd step count)
+    return (size_t)n_tiles * Q * NT * 2048;
 }
 
 // fills the job's derived fields (S8, Q, n_tiles, nt_active) and packs its weights into job.wpk unless `packed`.
@@ -1295,7 +1300,7 @@ void c5_chunk_job(const C5Job& full, const C5PackRange* prf, int k, int ks, C5Jo
 size_t c5_chunk_wpk_bytes(int K, int k, int ks, int cols, int NT) {   // (5x5 jobs)
     const int S8 = K / 8;
     const int s8 = (int)((long long)S8 * (k + 1) / ks) - (int)((long long)S8 * k / ks);
-    return (size_t)((cols + NT * 16 - 1) / (NT * 16)) * ((25 * s8 + 3) / 4) * NT * 2048 + (size_t)NT * 2048;
+    return (size_t)((cols + NT * 16 - 1) / (NT * 16)) * ((25 * s8 + 3) / 4) * NT * 2048;
 }
 
 template <int NT, int KS>
