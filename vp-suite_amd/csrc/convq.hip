@@ -1020,15 +1020,34 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
         pixoff[u] = (pos < G::NPOS && (unsigned)gy < (unsigned)P.H && (unsigned)gx < (unsigned)P.W) ? gy * P.W + gx : -1;
         choff[u] = plane * 16;
     }
+    // the job's (up to three) channel ranges: base of this sample's first channel and pixel pitch, resolved ONCE (a look-up of P.src inside
+    // the K loop is a scalar load from the kernel arguments: s_waitcnt lgkmcnt(0) with every fragment read of the step in flight)
+    // (kept in VECTOR registers on purpose: the kernel sits at the SGPR limit — as scalars these nine values spill to scratch memory,
+    //  whose reloads wait on vmcnt(0) with the copies in flight; as an indexed array they live there outright)
+    auto in_vgpr = [](unsigned x) { unsigned r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; };
+    auto range_of = [&](const char* p0, long long bs, int n, unsigned long long& base) {
+        const unsigned long long v = (p0 != nullptr && n > 0) ? reinterpret_cast<unsigned long long>(p0 + (size_t)b * bs) : 0ull;
+        base = ((unsigned long long)in_vgpr((unsigned)(v >> 32)) << 32) | in_vgpr((unsigned)v);
+    };
+    unsigned long long rb0, rb1, rb2;
+    range_of(J.r_p[0], J.r_bs[0], J.r_n[0], rb0);
+    range_of(J.r_p[1], J.r_bs[1], J.r_n[1], rb1);
+    range_of(J.r_p[2], J.r_bs[2], J.r_n[2], rb2);
+    const unsigned rp0 = in_vgpr((unsigned)J.r_prow[0]), rp1 = in_vgpr((unsigned)J.r_prow[1]), rp2 = in_vgpr((unsigned)J.r_prow[2]);
+    const int rn0 = J.r_n[0], rn1 = J.r_n[1];
     auto issue_A = [&](int s8, int buf) {   // stages past the job's K are filled with zeros (their weights are zeros too)
         const char* base = nullptr;
         unsigned prow = 0;
         if (s8 < J.S8) {
-            int si, chan;
-            c5_chan_of_stage(J, s8, si, chan);
-            const C5Src sc = si == 0 ? P.src[0] : (si == 1 ? P.src[1] : (si == 2 ? P.src[2] : P.src[3]));
-            base = sc.p + (size_t)b * sc.bstride + (size_t)chan * 4;
-            prow = (unsigned)sc.prow;
+            const int c = 8 * s8;
+            const bool in0 = c < rn0, in1 = c - rn0 < rn1;
+            // (masks, not conditionals: a conditional between captured values becomes the selection of an ADDRESS inside the closure — a
+            //  run-time index that keeps the closure, and with it every local it refers to, in scratch memory)
+            const unsigned long long m0 = in0 ? ~0ull : 0ull, m1 = (!in0 && in1) ? ~0ull : 0ull, m2 = ~(m0 | m1);
+            const unsigned long long rb = (rb0 & m0) | (rb1 & m1) | (rb2 & m2);
+            const int cc = c - (in0 ? 0 : rn0) - ((in0 || in1) ? 0 : rn1);
+            base = rb != 0 ? reinterpret_cast<const char*>(rb + (unsigned long long)cc * 4u) : nullptr;
+            prow = (rp0 & (unsigned)m0) | (rp1 & (unsigned)m1) | (rp2 & (unsigned)m2);
         }
 #pragma unroll
         for (int u = 0; u < G::NPC; ++u) {
@@ -1138,7 +1157,9 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
                 if (nt < NT - 1) load_B(slot, nt + 1);
                 else load_B(nslot, 0);
                 __builtin_amdgcn_s_setprio(1);
-                const bool go = nt < nt_active;   // (a job whose N tile holds fewer column tiles skips the MFMAs of the empty ones)
+                // (a gate job of three gates holds six column tiles of the eight: it skips the MFMAs of the last two. Only those two carry
+                //  the test — a branch around every MFMA group cuts the step into basic blocks the scheduler cannot interleave.)
+                const bool go = (NT < 8 || nt < 6) ? true : nt < nt_active;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     if (go) {
@@ -1327,6 +1348,15 @@ hipError_t launch_c5(const C5Plan& P_in, int NT, hipStream_t s) {
 #ifdef VPX_DEV_SWITCHES
     P.stamps = g_c5_stamps; P.stamp_block = g_c5_stamp_block;
 #endif
+    for (int j = 0; j < P.njobs; ++j)
+        for (int r = 0; r < 3; ++r) {
+            C5Job& J = P.job[j];
+            const C5Src& sc = P.src[(J.r_n[r] > 0 && J.r_src[r] >= 0 && J.r_src[r] < 4) ? J.r_src[r] : 0];
+            const bool live = J.r_n[r] > 0 && sc.p != nullptr;
+            J.r_p[r] = live ? sc.p + (size_t)J.r_c0[r] * 4 : nullptr;
+            J.r_bs[r] = live ? sc.bstride : 0;
+            J.r_prow[r] = live ? sc.prow : 0;
+        }
     P.tiles_x = (P.W + 15) / 16; P.tiles_y = (P.H + 15) / 16; P.m_tiles = P.B * P.tiles_x * P.tiles_y;
     const int Mx = (P.m_tiles + 7) / 8;
     long long per_xcd = 0;

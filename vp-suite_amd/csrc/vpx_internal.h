@@ -469,6 +469,9 @@ struct C5Job {
     const float* e_in2; const float* e_in3; const float* bias;   // bias: reference layout [4Ch] or null
     int gate_pos[4];                         // position of the logical gates (i,f,g,o) in the reference's 4Ch axis
     long long h_bstride, sp_bstride;         // elements between batch items of h_out; BYTES between batch items of e_sp
+    // derived (launch_c5): the ranges resolved against C5Plan::src — first byte of range r in sample 0 (or null), bytes per sample / per pixel.
+    // (The kernel reads these, not src[r_src[r]]: a look-up of the source table inside its K loop was a scalar load with the step's reads in flight.)
+    const char* r_p[3]; long long r_bs[3]; int r_prow[3], _rpad;
 };
 struct C5Plan {
     int B, H, W, tiles_x, tiles_y, m_tiles;
@@ -477,6 +480,7 @@ struct C5Plan {
     unsigned long long* stamps; int stamp_block;   // developer timing stamps (null in the product; vpx_dbg_c5_stamps)
     int njobs; C5Job job[C5_MAX_JOBS];
 };
+static_assert(sizeof(C5Plan) <= 4096, "C5Plan travels as a kernel argument (4 KiB)");
 struct C5PackRange { const float* w; long long s_oc, s_c; int c0; int gate0[4]; };   // weights of one K range (see c5_pack_kernel)
 size_t c5_wpk_bytes(int K, int Co, int NT, int gates = 0, int ks = 5);
 int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s, int gate_major = 0, int ks = 5);
