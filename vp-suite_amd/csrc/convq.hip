@@ -801,7 +801,8 @@ template <int NT, int KS = 5> struct C5Geom {
     // and step: one step of MFMA time covers the copy's latency); the narrow tiles run 48 / 24 MFMAs per step — less than a copy takes to
     // land (measured: c5_kernel<2, 3> 34 us for 36 steps = 0.9 us per step, the L2 latency, against 14 k cycles of MFMAs) — and request
     // three / four steps ahead.
-    static constexpr int RD = NT == 8 ? 3 : (KS == 3 && NT == 4 ? 4 : 5);
+    // 3x3: the period of nine steps is unrolled (below) and a ring of three makes the slot of every step a constant.
+    static constexpr int RD = (NT == 8 || KS == 3) ? 3 : 5;
     static constexpr int PD = RD - 1;                     // prefetch distance in steps
     static constexpr int WAITN = (PD - 2) * WP;           // copies that may still fly at a sync point (the chunks after q + 1)
     static constexpr int LDS = NBUF * ABUF + RD * WCH >= 65536 ? NBUF * ABUF + RD * WCH : 65536;   // >= 64 KiB: 4 waves x 16 KiB in the epilogue
@@ -1101,6 +1102,11 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
 
     const int Q = J.Q;
     const int nt_active = J.nt_active;
+#if defined(VPX_DEV_SWITCHES) && defined(VPX_C5_ABL)   // (its branches cost the loop a third: a build of its own, hipcc -DVPX_C5_ABL)
+    const int abl = P.ablate;   // 1: no stage copies, 2: no weight copies, 4: no sync points, 8: no MFMAs, 16: no A reads, 32: no B reads (K loop only)
+#else
+    constexpr int abl = 0;
+#endif
     // developer timing stamps (P.stamps != nullptr only from tools/): shader clock of one workgroup's waves at the phase boundaries
     const bool stamp = P.stamps != nullptr && (int)blockIdx.x == P.stamp_block && lane == 0;
     if (stamp) P.stamps[wave * 8 + 0] = __builtin_amdgcn_s_memtime();
@@ -1125,12 +1131,25 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     constexpr int SYNC_NT = NT == 8 ? 5 : (NT == 4 ? 2 : 1);    // the sync point sits before this column tile of every step
     constexpr int STAGE_NT = SYNC_NT + 1 < NT ? SYNC_NT + 1 : NT - 1;   // the stage copy follows the weight copy (same tile when there is no later one)
     if (stamp) P.stamps[wave * 8 + 1] = __builtin_amdgcn_s_memtime();
-    int q = 0, slot = 0;                        // global step, its ring slot (q % RD)
+    // A wave issues one instruction per four cycles: a step of the narrow tiles holds 24 or 48 MFMAs (384 / 768 cycles of the pipe), and
+    // the step's scalar bookkeeping (which stage to request, the fragment offsets: three integer divisions per lane, the ring slot) stood
+    // beside them with a hundred instructions of its own — with every copy, read, MFMA and sync point removed the loop still took 950
+    // cycles per step (developer build, VPX_C5_ABLATE = 63). 3x3: the period's nine steps are unrolled — the stage schedule and the ring
+    // slot (9 = 3 x RD) become constants, the fragment offsets of the nine steps nine registers.
+    constexpr int UNR = KS == 3 ? G::SPS : 1;
+    int aoffs[KS == 3 ? G::SPS : 1];
+    if constexpr (KS == 3) {
+#pragma unroll
+        for (int p = 0; p < G::SPS; ++p) aoffs[p] = a_off(p);
+    }
+    int q = 0, slot_rt = 0;                     // global step, its ring slot (q % RD)
     bool flies = false;                         // a stage copy was issued in the previous step (it may still fly at this step's sync)
 #pragma unroll 1
     for (int P0 = 0; q < Q; P0 += 4) {          // period: stages P0 .. P0 + 3
-#pragma unroll 1
-        for (int p = 0; p < G::SPS && q < Q; ++p, ++q) {
+#pragma unroll UNR
+        for (int p = 0; p < G::SPS; ++p) {
+            if (q >= Q) continue;   // (not a loop exit: a loop with sync points unrolls only with an exact trip count)
+            const int slot = KS == 3 ? p % G::RD : slot_rt;
             const int nslot = slot == G::RD - 1 ? 0 : slot + 1;
             // stage requested at this step (after its sync point). 5x5: period steps 0 / 7 / 13 / 19 -> stages P0 + 1 / + 2 / + 3 / + 4;
             // 3x3: steps 3 / 5 / 7 -> stages P0 + 4 / + 5 / + 6 (the next period's first three), step 0 -> stage P0 + 3 (the prologue
@@ -1140,21 +1159,24 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
             else want = p == 3 ? P0 + 4 : (p == 5 ? P0 + 5 : (p == 7 ? P0 + 6 : ((p == 0 && P0 > 0) ? P0 + 3 : -1)));
             const bool issue = want >= 0 && want <= J.S8;   // (== S8: zero fill of the buffer a partial last step still reads)
             const int np = p == G::SPS - 1 ? 0 : p + 1;
-            const int n_off = a_off(np);
+            int n_off;
+            if constexpr (KS == 3) n_off = aoffs[np]; else n_off = a_off(np);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (nt == SYNC_NT) {
                     // ---- sync point S_q: chunk q + 1 has landed (the stage requested one step ago may still fly) ----
-                    if constexpr (G::PD == 2) {
+                    if (abl & 4) {
+                    } else if constexpr (G::PD == 2) {
                         if (flies) c5_wait_vm<G::NPC>(); else C2_WAIT_VM(0);
                     } else {
                         // chunks q + 2 .. q + PD - 1 may fly (a stage copy among them lands early: in-order completion); at the tail, where
                         // no further chunk is behind q + 1, everything must have landed
                         if (q + G::PD <= Q) c5_wait_vm<G::WAITN>(); else C2_WAIT_VM(0);
                     }
-                    c2_barrier();
+                    if (!(abl & 4)) c2_barrier();
                 }
-                if (nt < NT - 1) load_B(slot, nt + 1);
+                if (abl & 32) {
+                } else if (nt < NT - 1) load_B(slot, nt + 1);
                 else load_B(nslot, 0);
                 __builtin_amdgcn_s_setprio(1);
                 // (a gate job of three gates holds six column tiles of the eight: it skips the MFMAs of the last two. Only those two carry
@@ -1162,21 +1184,22 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
                 const bool go = (NT < 8 || nt < 6) ? true : nt < nt_active;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    if (go) {
+                    if (go && !(abl & 8)) {
                         f32x4 c = acc[m][nt];
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[nt & 1], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[nt & 1], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[nt & 1], c, 0, 0, 0);
                         acc[m][nt] = c;
                     }
-                    if (nt == NT - 1) load_A1(n_off, m);   // the step's last tile frees row m: the next step's fragments
+                    if (nt == NT - 1 && !(abl & 16)) load_A1(n_off, m);   // the step's last tile frees row m: the next step's fragments
                 }
                 __builtin_amdgcn_s_setprio(0);
-                if (nt == SYNC_NT) { if (q + G::PD < Q) issue_W(q + G::PD, slot == 0 ? G::RD - 1 : slot - 1); }
-                if (nt == STAGE_NT && issue) issue_A(want, KS == 5 ? (want & 1) : (want & 3));
+                if (nt == SYNC_NT) { if (q + G::PD < Q && !(abl & 2)) issue_W(q + G::PD, slot == 0 ? G::RD - 1 : slot - 1); }
+                if (nt == STAGE_NT && issue && !(abl & 1)) issue_A(want, KS == 5 ? (want & 1) : (want & 3));
             }
             flies = issue;
-            slot = nslot;
+            slot_rt = nslot;
+            ++q;
         }
     }
     C2_WAIT_VM(0);
@@ -1347,6 +1370,9 @@ hipError_t launch_c5(const C5Plan& P_in, int NT, hipStream_t s) {
     C5Plan P = P_in;
 #ifdef VPX_DEV_SWITCHES
     P.stamps = g_c5_stamps; P.stamp_block = g_c5_stamp_block;
+    P.ablate = dev_switch("VPX_C5_ABLATE", 0);
+#else
+    P.ablate = 0;
 #endif
     for (int j = 0; j < P.njobs; ++j)
         for (int r = 0; r < 3; ++r) {
