@@ -801,8 +801,9 @@ template <int NT, int KS = 5> struct C5Geom {
     // and step: one step of MFMA time covers the copy's latency); the narrow tiles run 48 / 24 MFMAs per step — less than a copy takes to
     // land (measured: c5_kernel<2, 3> 34 us for 36 steps = 0.9 us per step, the L2 latency, against 14 k cycles of MFMAs) — and request
     // three / four steps ahead.
-    // 3x3: the period of nine steps is unrolled (below) and a ring of three makes the slot of every step a constant.
+    // The period (nine / 25 steps) is unrolled (below); a ring of three (3x3) / five (5x5, narrow tiles) makes the slot of every step a constant.
     static constexpr int RD = (NT == 8 || KS == 3) ? 3 : 5;
+    static constexpr bool STATIC_SLOT = SPS % RD == 0;
     static constexpr int PD = RD - 1;                     // prefetch distance in steps
     static constexpr int WAITN = (PD - 2) * WP;           // copies that may still fly at a sync point (the chunks after q + 1)
     static constexpr int LDS = NBUF * ABUF + RD * WCH >= 65536 ? NBUF * ABUF + RD * WCH : 65536;   // >= 64 KiB: 4 waves x 16 KiB in the epilogue
@@ -1136,12 +1137,10 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     // beside them with a hundred instructions of its own — with every copy, read, MFMA and sync point removed the loop still took 950
     // cycles per step (developer build, VPX_C5_ABLATE = 63). 3x3: the period's nine steps are unrolled — the stage schedule and the ring
     // slot (9 = 3 x RD) become constants, the fragment offsets of the nine steps nine registers.
-    constexpr int UNR = KS == 3 ? G::SPS : 1;
-    int aoffs[KS == 3 ? G::SPS : 1];
-    if constexpr (KS == 3) {
+    constexpr int UNR = G::SPS;
+    int aoffs[G::SPS];
 #pragma unroll
-        for (int p = 0; p < G::SPS; ++p) aoffs[p] = a_off(p);
-    }
+    for (int p = 0; p < G::SPS; ++p) aoffs[p] = a_off(p);
     int q = 0, slot_rt = 0;                     // global step, its ring slot (q % RD)
     bool flies = false;                         // a stage copy was issued in the previous step (it may still fly at this step's sync)
 #pragma unroll 1
@@ -1149,7 +1148,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
 #pragma unroll UNR
         for (int p = 0; p < G::SPS; ++p) {
             if (q >= Q) continue;   // (not a loop exit: a loop with sync points unrolls only with an exact trip count)
-            const int slot = KS == 3 ? p % G::RD : slot_rt;
+            const int slot = G::STATIC_SLOT ? p % G::RD : slot_rt;
             const int nslot = slot == G::RD - 1 ? 0 : slot + 1;
             // stage requested at this step (after its sync point). 5x5: period steps 0 / 7 / 13 / 19 -> stages P0 + 1 / + 2 / + 3 / + 4;
             // 3x3: steps 3 / 5 / 7 -> stages P0 + 4 / + 5 / + 6 (the next period's first three), step 0 -> stage P0 + 3 (the prologue
@@ -1159,8 +1158,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
             else want = p == 3 ? P0 + 4 : (p == 5 ? P0 + 5 : (p == 7 ? P0 + 6 : ((p == 0 && P0 > 0) ? P0 + 3 : -1)));
             const bool issue = want >= 0 && want <= J.S8;   // (== S8: zero fill of the buffer a partial last step still reads)
             const int np = p == G::SPS - 1 ? 0 : p + 1;
-            int n_off;
-            if constexpr (KS == 3) n_off = aoffs[np]; else n_off = a_off(np);
+            const int n_off = aoffs[np];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (nt == SYNC_NT) {
