@@ -921,11 +921,36 @@ __device__ __forceinline__ void c5_finish_out(const f32x4 (&acc)[4][8], char* sm
 
 // ConvLSTM step on a gate-interleaved N tile of GC = NT * 4 channels (columns g * GC + j, gates i, f, g, o): the wave's 64 pixels x NT * 16
 // columns go through its private LDS as [pixel][column]; a lane then owns four channels of a pixel for all four gates.
+// The epilogue's global operands (c_in, the three peepholes) do not depend on the K loop: c5_clstm_prefetch requests them BEFORE it, so that
+// their latency (1.5-2 k cycles of a 6 k cycle epilogue on the small grids this form serves) passes under the MFMAs.
+template <int NT> struct ClstmPre {
+    static constexpr int NPASS = (NT * 16 / 4 / 4);   // = 64 / PPP
+    f32x4 cp[NPASS], wi[NPASS], wf[NPASS], wo[NPASS];
+};
 template <int NT>
-__device__ __forceinline__ void c5_finish_clstm(const f32x4 (&acc)[4][NT], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
-                                                const C5Job& J, int H, int W) {
+__device__ __forceinline__ void c5_clstm_prefetch(ClstmPre<NT>& pre, int wave, int lane, int b, int y0, int x0, int n_tile, const C5Job& J, int H, int W) {
+    constexpr int NC = NT * 16, GC = NC / 4, LPP = GC / 4, PPP = 64 / LPP;
+    const int cgi = lane % LPP, pl = lane / LPP;
+    const int ch = n_tile * GC + cgi * 4, Ch = J.Ch;
+#pragma unroll
+    for (int pass = 0; pass < 64 / PPP; ++pass) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        pre.cp[pass] = z; pre.wi[pass] = z; pre.wf[pass] = z; pre.wo[pass] = z;
+        const int pix = pass * PPP + pl;
+        const int y = y0 + 4 * wave + (pix >> 4), x = x0 + (pix & 15);
+        if (ch >= Ch || y >= H || x >= W) continue;
+        const size_t e = ((size_t)y * W + x) * Ch + ch, sidx = ((size_t)b * H * W) * Ch + e;
+        if (J.e_in0) pre.cp[pass] = *reinterpret_cast<const f32x4*>(J.e_in0 + sidx);
+        if (J.e_in1) { pre.wi[pass] = *reinterpret_cast<const f32x4*>(J.e_in1 + e); pre.wf[pass] = *reinterpret_cast<const f32x4*>(J.e_in2 + e); }
+        if (J.e_in3) pre.wo[pass] = *reinterpret_cast<const f32x4*>(J.e_in3 + e);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void c5_finish_clstm(const f32x4 (&acc)[4][NT], const ClstmPre<NT>& pre, char* smem, int wave, int lane, int b, int y0, int x0,
+                                                int n_tile, const C5Job& J, int H, int W) {
     static_assert(NT <= 4, "64 pixels x NT * 16 columns must fit the wave's 16 KiB");
     constexpr int NC = NT * 16, GC = NC / 4, LPP = GC / 4, PPP = 64 / LPP;   // lanes per pixel, pixels per pass
+    static_assert(ClstmPre<NT>::NPASS == 64 / PPP, "");
     c2_barrier();
     float* ldsf = reinterpret_cast<float*>(smem + wave * 16384);
     const int c16 = lane & 15, q4 = lane >> 4;
@@ -956,10 +981,7 @@ __device__ __forceinline__ void c5_finish_clstm(const f32x4 (&acc)[4][NT], char*
         const float* row = ldsf + pix * NC + cgi * 4;
         const f32x4 vi = *reinterpret_cast<const f32x4*>(row), vf = *reinterpret_cast<const f32x4*>(row + GC);
         const f32x4 vg = *reinterpret_cast<const f32x4*>(row + 2 * GC), vo = *reinterpret_cast<const f32x4*>(row + 3 * GC);
-        f32x4 cp = {0.f, 0.f, 0.f, 0.f}, wi = cp, wf = cp, wo = cp;
-        if (J.e_in0) cp = *reinterpret_cast<const f32x4*>(J.e_in0 + sidx);
-        if (J.e_in1) { wi = *reinterpret_cast<const f32x4*>(J.e_in1 + e); wf = *reinterpret_cast<const f32x4*>(J.e_in2 + e); }
-        if (J.e_in3) wo = *reinterpret_cast<const f32x4*>(J.e_in3 + e);
+        const f32x4 cp = pre.cp[pass], wi = pre.wi[pass], wf = pre.wf[pass], wo = pre.wo[pass];
         f32x4 cn, hn;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1111,11 +1133,22 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     // developer timing stamps (P.stamps != nullptr only from tools/): shader clock of one workgroup's waves at the phase boundaries
     const bool stamp = P.stamps != nullptr && (int)blockIdx.x == P.stamp_block && lane == 0;
     if (stamp) P.stamps[wave * 8 + 0] = __builtin_amdgcn_s_memtime();
+    bool flies = false;                         // a stage copy was issued in the previous step (it may still fly at this step's sync)
+    ClstmPre<(KS == 3 ? NT : 1)> clstm_pre;
+    if constexpr (KS == 3) {
+        // (ahead of every copy: vmcnt counts in order, the counted waits below name the NEWEST requests that may still fly)
+        if (J.epi == 3) c5_clstm_prefetch<NT>(clstm_pre, wave, lane, b, y0, x0, n_tile, J, P.H, P.W);
+    }
     if (Q > 0) {
         issue_A(0, 0);
-        if constexpr (KS == 3) { issue_A(1, 1); issue_A(2, 2); issue_A(3, 3); }   // (stages past the job's K: zero fill)
         issue_W(0, 0);
-        if (Q >= G::PD) {   // chunks 1 .. PD - 1 go out too; everything before them has landed when only they still fly
+        if constexpr (KS == 3) {
+            // the first step needs stage 0 and chunk 0 only: chunk 1 and stage 1 fly behind them (stage 1 is first read for step 2), stages
+            // 2 and 3 are requested by steps 0 and 1 of the first period (first read for steps 4 and 6)
+            static_assert(G::PD == 2, "");
+            if (Q >= 2) { issue_W(1, 1); issue_A(1, 1); c5_wait_vm<G::WP + G::NPC>(); flies = true; }
+            else C2_WAIT_VM(0);
+        } else if (Q >= G::PD) {   // chunks 1 .. PD - 1 go out too; everything before them has landed when only they still fly
 #pragma unroll
             for (int c = 1; c < G::PD; ++c) issue_W(c, c);
             c5_wait_vm<(G::PD - 1) * G::WP>();
@@ -1142,7 +1175,6 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
 #pragma unroll
     for (int p = 0; p < G::SPS; ++p) aoffs[p] = a_off(p);
     int q = 0, slot_rt = 0;                     // global step, its ring slot (q % RD)
-    bool flies = false;                         // a stage copy was issued in the previous step (it may still fly at this step's sync)
 #pragma unroll 1
     for (int P0 = 0; q < Q; P0 += 4) {          // period: stages P0 .. P0 + 3
 #pragma unroll UNR
@@ -1151,11 +1183,11 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
             const int slot = G::STATIC_SLOT ? p % G::RD : slot_rt;
             const int nslot = slot == G::RD - 1 ? 0 : slot + 1;
             // stage requested at this step (after its sync point). 5x5: period steps 0 / 7 / 13 / 19 -> stages P0 + 1 / + 2 / + 3 / + 4;
-            // 3x3: steps 3 / 5 / 7 -> stages P0 + 4 / + 5 / + 6 (the next period's first three), step 0 -> stage P0 + 3 (the prologue
-            // loaded the first period's)
+            // 3x3: steps 3 / 5 / 7 -> stages P0 + 4 / + 5 / + 6 (the next period's first three), step 0 -> stage P0 + 3; the first period's
+            // stages 2 and 3 at its steps 0 and 1 (the prologue requests stages 0 and 1 only)
             int want;
             if constexpr (KS == 5) want = p == 0 ? P0 + 1 : (p == 7 ? P0 + 2 : (p == 13 ? P0 + 3 : (p == 19 ? P0 + 4 : -1)));
-            else want = p == 3 ? P0 + 4 : (p == 5 ? P0 + 5 : (p == 7 ? P0 + 6 : ((p == 0 && P0 > 0) ? P0 + 3 : -1)));
+            else want = p == 3 ? P0 + 4 : (p == 5 ? P0 + 5 : (p == 7 ? P0 + 6 : (p == 0 ? (P0 > 0 ? P0 + 3 : 2) : ((p == 1 && P0 == 0) ? 3 : -1))));
             const bool issue = want >= 0 && want <= J.S8;   // (== S8: zero fill of the buffer a partial last step still reads)
             const int np = p == G::SPS - 1 ? 0 : p + 1;
             const int n_off = aoffs[np];
@@ -1180,16 +1212,39 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
                 // (a gate job of three gates holds six column tiles of the eight: it skips the MFMAs of the last two. Only those two carry
                 //  the test — a branch around every MFMA group cuts the step into basic blocks the scheduler cannot interleave.)
                 const bool go = (NT < 8 || nt < 6) ? true : nt < nt_active;
+                if (nt < NT - 1) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if (go && !(abl & 8)) {
-                        f32x4 c = acc[m][nt];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[nt & 1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[nt & 1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[nt & 1], c, 0, 0, 0);
-                        acc[m][nt] = c;
+                    for (int m = 0; m < 4; ++m) {
+                        if (go && !(abl & 8)) {
+                            f32x4 c = acc[m][nt];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[nt & 1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[nt & 1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[nt & 1], c, 0, 0, 0);
+                            acc[m][nt] = c;
+                        }
                     }
-                    if (nt == NT - 1 && !(abl & 16)) load_A1(n_off, m);   // the step's last tile frees row m: the next step's fragments
+                } else {
+                    // the step's last tile, in three rounds over the four rows: the lo fragments are free after the first round and the next
+                    // step's are requested there — eight MFMAs ahead of their first use (the scheduler left to itself requests all eight
+                    // fragments behind the tenth MFMA and the next step opens with a wait); the hi fragments follow row by row in the third
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (go && !(abl & 8)) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[nt & 1], acc[m][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(abl & 16)) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) al[m] = *reinterpret_cast<const bf16x8*>(smem + n_off + m * (HWP * 16) + C5_PLANE);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (go && !(abl & 8)) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[nt & 1], acc[m][nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        if (go && !(abl & 8)) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[nt & 1], acc[m][nt], 0, 0, 0);
+                        if (!(abl & 16)) ah[m] = *reinterpret_cast<const bf16x8*>(smem + n_off + m * (HWP * 16));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_s_setprio(0);
                 if (nt == SYNC_NT) { if (q + G::PD < Q && !(abl & 2)) issue_W(q + G::PD, slot == 0 ? G::RD - 1 : slot - 1); }
@@ -1211,7 +1266,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
     if (ngr > NT / 2) ngr = NT / 2;
     if constexpr (KS == 3) {
         if (J.epi == 3) {
-            c5_finish_clstm<NT>(acc, smem, wave, lane, b, y0, x0, n_tile, J, P.H, P.W);
+            c5_finish_clstm<NT>(acc, clstm_pre, smem, wave, lane, b, y0, x0, n_tile, J, P.H, P.W);
             if (stamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); P.stamps[wave * 8 + 3] = __builtin_amdgcn_s_memtime(); }
             return;
         }
