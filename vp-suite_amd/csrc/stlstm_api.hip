@@ -34,6 +34,7 @@ struct STLayout {
 // workgroups of four waves = one wave per SIMD; 512 at 32 columns)
 static inline int c5f_nt_o(const vpx_stlstm_desc* d) {
     const long long mt = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
+    if (const int f = dev_switch("VPX_C5_NT_O", 0)) return f;   // (developer build only)
     return mt * ((d->Ch + 63) / 64) < 384 ? 2 : 4;
 }
 

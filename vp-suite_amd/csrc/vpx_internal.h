@@ -501,6 +501,7 @@ struct STWArgs {
     STWPair pair[STW_MAX_PAIRS];
     float* slabs;                // [n_slices][npairs][25][128][64]
     size_t slab_stride;          // floats per slice
+    unsigned long long* stamps; int stamp_block, _spad;   // developer timing stamps (null in the product; vpx_dbg_stw_stamps)
 };
 struct STWOut { float* dW[5]; int Ct[5]; int ntaps[5]; signed char blockmap[5][8]; };   // Wx, Wh, Wm, Wo, Wlast
 int stw_build(STWArgs& a, STWOut& o, int B, int H, int W, int Cin, int Ch);   // fills the pair table; returns npairs (-1: too many)

@@ -631,14 +631,38 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int bsel = 0;
+#ifdef VPX_DEV_SWITCHES
+    // developer timing stamps: shader cycles of one workgroup's waves spent requesting copies / multiplying / at the item's sync point
+    const bool stamp = a.stamps != nullptr && (int)blockIdx.x == a.stamp_block;
+    unsigned long long t_dma = 0, t_mul = 0, t_sync = 0, n_it = 0;
+#endif
     while (cur < n_items) {
         char* bcur = smem + bsel * W5_BUF;
         char* bnxt = smem + (bsel ^ 1) * W5_BUF;
+#ifdef VPX_DEV_SWITCHES
+        const unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+#endif
         if (nxt < n_items) dma_item(nxt, bnxt);
+#ifdef VPX_DEV_SWITCHES
+        const unsigned long long t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+#endif
         if (active) multiply(bcur);
+#ifdef VPX_DEV_SWITCHES
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef VPX_DEV_SWITCHES
+        if (stamp) { const unsigned long long t3 = __builtin_amdgcn_s_memtime(); t_dma += t1 - t0; t_mul += t2 - t1; t_sync += t3 - t2; ++n_it; }
+#endif
         cur = nxt; nxt += a.n_slices; bsel ^= 1;
     }
+#ifdef VPX_DEV_SWITCHES
+    if (stamp && lane == 0) {
+        a.stamps[wave * 8 + 0] = t_dma; a.stamps[wave * 8 + 1] = t_mul; a.stamps[wave * 8 + 2] = t_sync; a.stamps[wave * 8 + 3] = n_it;
+        a.stamps[wave * 8 + 4] = (unsigned long long)pass; a.stamps[wave * 8 + 5] = (unsigned long long)pair_i;
+    }
+#endif
 
     if (ksplit || tsplit) {
         // pair reduction: the second wave of each pair parks its accumulators in LDS, the first adds them (two row tiles at a time:
@@ -763,7 +787,19 @@ int stw_slices(int npairs, long long items) {   // npairs: the k x k tensors' pa
     return ns < 1 ? 1 : ns;
 }
 
-hipError_t launch_stw(const STWArgs& a, const STWOut& o, hipStream_t s) {
+#ifdef VPX_DEV_SWITCHES
+static unsigned long long* g_stw_stamps = nullptr;
+static int g_stw_stamp_block = 0;
+extern "C" int vpx_dbg_stw_stamps(unsigned long long* dev_buf, int block) { g_stw_stamps = dev_buf; g_stw_stamp_block = block; return 0; }
+#endif
+
+hipError_t launch_stw(const STWArgs& a_in, const STWOut& o, hipStream_t s) {
+    STWArgs a = a_in;
+#ifdef VPX_DEV_SWITCHES
+    a.stamps = g_stw_stamps; a.stamp_block = g_stw_stamp_block;
+#else
+    a.stamps = nullptr; a.stamp_block = 0;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W5_LDS);
