@@ -560,11 +560,30 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
         pc_toff[u] = (unsigned)(hy * a.W + hx) * (h1 ? prow1 : prow0) + (unsigned)(hf.c0 + (sl & 3) * 8) * 4u + (unsigned)plane * 16u;
         pc_h1[u] = h1;
     }
-    auto dma_item = [&](int w, char* buf) {
-        const int b = __builtin_amdgcn_readfirstlane(w / tiles);
-        const int tile = w - b * tiles;
-        const int ty = __builtin_amdgcn_readfirstlane(tile / tiles_x), tx = tile - ty * tiles_x;
-        const int y0 = ty * W2_TH, x0 = tx * 16;
+    // An item = (sample b, tile row ty, tile column tx); a workgroup's items lie n_slices apart: the next one is found by carrying, not by
+    // dividing (two scalar divisions per item were a fifth of the 250 instructions a wave spent requesting an item's copies — as long as
+    // a quarter of its products, in-kernel stamps), and the two sources' base addresses stay in vector registers (the kernel is at the
+    // SGPR limit: as scalars they were reloaded from the kernel arguments for every item, s_waitcnt lgkmcnt(0) included).
+    struct SItem { int w, b, ty, tx; };
+    const int it_db = a.n_slices / tiles, it_dty = (a.n_slices % tiles) / tiles_x, it_dtx = (a.n_slices % tiles) % tiles_x;
+    auto advance = [&](SItem& it) {
+        it.w += a.n_slices;
+        it.tx += it_dtx; if (it.tx >= tiles_x) { it.tx -= tiles_x; ++it.ty; }
+        it.ty += it_dty; if (it.ty >= tiles_y) { it.ty -= tiles_y; ++it.b; }
+        it.b += it_db;
+    };
+    auto keep_in_vgprs = [](const char* p) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        unsigned lo, hi;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(lo) : "v"((unsigned)v));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(hi) : "v"((unsigned)(v >> 32)));
+        return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    };
+    const char* const sp0 = keep_in_vgprs(a.src[ch0.src].sp);
+    const char* const sp1 = keep_in_vgprs(a.src[ch1.src].sp);
+    auto dma_item = [&](const SItem& it, char* buf) {
+        const int b = it.b;
+        const int y0 = it.ty * W2_TH, x0 = it.tx * 16;
         {
             const bool pix_ok = (y0 + (g_px >> 4) < a.H) & (x0 + (g_px & 15) < a.W);
             const char* const gbase = a.g_sp + ((size_t)b * a.HW + (size_t)(y0 * a.W + x0)) * g_prow;
@@ -576,9 +595,9 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
                 w2_dma16(src, buf + u * W2_GPL + wave * 1024);
             }
         }
-        const long long org = (long long)(y0 - 2) * a.W + (x0 - 2);
-        const char* const ab0 = a.src[ch0.src].sp + (size_t)b * a.HW * prow0 + org * (long long)prow0;
-        const char* const ab1 = a.src[ch1.src].sp + (size_t)b * a.HW * prow1 + org * (long long)prow1;
+        const long long org = (long long)b * a.HW + (long long)(y0 - 2) * a.W + (x0 - 2);   // pixels from the tensor's first to the halo origin
+        const char* const ab0 = sp0 + org * (long long)prow0;
+        const char* const ab1 = sp1 + org * (long long)prow1;
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
             const int gy = y0 - 2 + (pc_hyx[u] >> 16), gx = x0 - 2 + (pc_hyx[u] & 0xffff);
@@ -626,8 +645,16 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
         }
     };
 
-    int cur = slice, nxt = slice + a.n_slices;
-    if (cur < n_items) dma_item(cur, smem);
+    SItem cur;
+    {
+        cur.w = slice; cur.b = slice / tiles;
+        const int tile = slice - cur.b * tiles;
+        cur.ty = tile / tiles_x; cur.tx = tile - cur.ty * tiles_x;
+        cur.b = __builtin_amdgcn_readfirstlane(cur.b); cur.ty = __builtin_amdgcn_readfirstlane(cur.ty); cur.tx = __builtin_amdgcn_readfirstlane(cur.tx);
+    }
+    SItem nxt = cur;
+    advance(nxt);
+    if (cur.w < n_items) dma_item(cur, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int bsel = 0;
@@ -636,13 +663,13 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
     const bool stamp = a.stamps != nullptr && (int)blockIdx.x == a.stamp_block;
     unsigned long long t_dma = 0, t_mul = 0, t_sync = 0, n_it = 0;
 #endif
-    while (cur < n_items) {
+    while (cur.w < n_items) {
         char* bcur = smem + bsel * W5_BUF;
         char* bnxt = smem + (bsel ^ 1) * W5_BUF;
 #ifdef VPX_DEV_SWITCHES
         const unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 #endif
-        if (nxt < n_items) dma_item(nxt, bnxt);
+        if (nxt.w < n_items) dma_item(nxt, bnxt);
 #ifdef VPX_DEV_SWITCHES
         const unsigned long long t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 #endif
@@ -655,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
 #ifdef VPX_DEV_SWITCHES
         if (stamp) { const unsigned long long t3 = __builtin_amdgcn_s_memtime(); t_dma += t1 - t0; t_mul += t2 - t1; t_sync += t3 - t2; ++n_it; }
 #endif
-        cur = nxt; nxt += a.n_slices; bsel ^= 1;
+        cur = nxt; advance(nxt); bsel ^= 1;
     }
 #ifdef VPX_DEV_SWITCHES
     if (stamp && lane == 0) {
