@@ -52,6 +52,13 @@ def test_glue_layer_on_split_input_vs_torch(vpx, tag):
     # second call: packed weights re-used from the layer's workspace
     y2, _, _ = vpx.ops.conv2d_ex_from_split(xbuf, (N, Ci, H, W), w, b, s, p, tr, slope, "bf16x3")
     assert torch.equal(y, y2)
+    # an in-place update of the weight (an optimizer step) invalidates the pack: the third call follows the new values
+    w.mul_(0.5)
+    y3, _, _ = vpx.ops.conv2d_ex_from_split(xbuf, (N, Ci, H, W), w, b, s, p, tr, slope, "bf16x3")
+    ref3 = F.conv_transpose2d(x, w, b, stride=s, padding=p) if tr else F.conv2d(x, w, b, stride=s, padding=p)
+    if slope:
+        ref3 = F.leaky_relu(ref3, slope)
+    assert _relmax(y3, ref3) < 2e-5, tag
 
 
 @pytest.mark.parametrize("tag", ["deconv2_t2k4", "conv3_s2k3", "conv2_s2k3_co64", "deconv3_t1k3_co16", "ragged_s2k3", "ragged_t2k4"])

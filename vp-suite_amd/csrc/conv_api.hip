@@ -205,7 +205,7 @@ static int ex_mw(const vpx_conv_desc* d, int Ht, int Wt, int sd) {
 // one launch: tile space Ht x Wt, kernel taps th x tw, halo origin (oy, ox), input step `sd`
 int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
               const ExGeo& g, int Ht, int Wt, int th, int tw, int sd, int oy, int ox, const int* tapmap, bool flip,
-              int omap, int oys, int oyo, int oxs, int oxo, float* wpk, char* y_split = nullptr, bool x_split = false) {
+              int omap, int oys, int oyo, int oxs, int oxo, float* wpk, char* y_split = nullptr, bool x_split = false, bool packed = false) {
     const int prec = d->precision;
     ConvPlan P{};
     int chunks = 0;
@@ -225,7 +225,7 @@ int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const 
     pd.transposed = d->transposed ? 1 : 0;
     pd.flip = flip ? 1 : 0;
     if (tapmap) { pd.src_taps = src_taps; for (int i = 0; i < th * tw; ++i) pd.tapmap[i] = tapmap[i]; }
-    VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));
+    if (!packed) VPX_CHECK_HIP(launch_pack_weights(pd, wpk, stream));   // (packed: the caller's workspace still holds this launch's pack)
     P.B = d->N; P.H = Ht; P.W = Wt; P.kh = th; P.kw = tw;
     set_plan_tiles(P, mw);
     P.stride = sd; P.use_org = 1; P.org_y = oy; P.org_x = ox; P.Hin = d->H; P.Win = d->W;
@@ -245,7 +245,7 @@ int ex_launch(hipStream_t stream, const vpx_conv_desc* d, const float* x, const 
 }
 
 int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const float* w, const float* bias, float* y, float* wpk,
-               hipStream_t stream, char* y_split = nullptr, bool x_split = false);
+               hipStream_t stream, char* y_split = nullptr, bool x_split = false, bool packed = false);
 bool exq_problem(const vpx_conv_desc* d, const ExGeo& g, ConvQProblem& pr);
 int ex_forward_q(const vpx_conv_desc* d, const ExGeo& g, const char* x_sp, long long x_bstride, long long x_tstride, int x_nT,
                  const float* w, const float* bias, float* y, char* y_sp, char* wpk, bool weights_packed, hipStream_t stream);
@@ -369,15 +369,17 @@ int vpx_conv2d_ex_fwd_from_split(const vpx_conv_desc* d, const void* x_split, lo
                             wpk, weights_packed != 0, (hipStream_t)stream_);
     if (x_nT > 1 || x_bstride != dense) { set_error("vpx_conv2d_ex_fwd_from_split: this layer needs a dense batch of split images"); return VPX_ERR_UNSUPPORTED; }
     return ex_forward(d, g, reinterpret_cast<const float*>(x_split), w, bias, y, reinterpret_cast<float*>(wpk), (hipStream_t)stream_,
-                      reinterpret_cast<char*>(y_split), true);
+                      reinterpret_cast<char*>(y_split), true, weights_packed != 0);
 }
 
 }  // extern "C"
 
 namespace {
 
+// packed: the workspace still holds the layer's packed weights — honoured by the single-launch forms (the four phase launches of a
+// stride-2 transposed layer pack into the same space one after the other)
 int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const float* w, const float* bias, float* y, float* wpk,
-               hipStream_t stream, char* y_split, bool x_split) {
+               hipStream_t stream, char* y_split, bool x_split, bool packed) {
     int rc;
     const int small_kind = x_split ? 0 : conv_small_kind(d);   // (the streaming kernels read fp32)
     if (const int kind = small_kind) {   // few-channel layers: streaming kernels (conv_small.hip)
@@ -388,10 +390,10 @@ int ex_forward(const vpx_conv_desc* d, const ExGeo& g, const float* x, const flo
     }
     if (!d->transposed)  // y[o] = sum_k x[o*s - pad + k] w[k]
         return ex_launch(stream, d, x, w, bias, y, g, g.Ho, g.Wo, d->kh, d->kw, d->stride, -d->pad, -d->pad, nullptr, false,
-                         0, 1, 0, 1, 0, wpk, y_split, x_split);
+                         0, 1, 0, 1, 0, wpk, y_split, x_split, packed);
     if (d->stride == 1)  // y[o] = sum_k x[o + pad - k] w[k]  ==  correlation with the flipped kernel, origin -(k-1-pad)
         return ex_launch(stream, d, x, w, bias, y, g, g.Ho, g.Wo, d->kh, d->kw, 1, -(d->kh - 1 - d->pad), -(d->kw - 1 - d->pad),
-                         nullptr, true, 0, 1, 0, 1, 0, wpk, y_split, x_split);
+                         nullptr, true, 0, 1, 0, 1, 0, wpk, y_split, x_split, packed);
     // stride 2: output phase (py, px) is a stride-1 correlation of x with the taps k == (p + pad) mod 2 of that axis
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
