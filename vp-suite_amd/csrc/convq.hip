@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(256, 2) void c5_kernel(const C5Plan P) {
         }
     }
     if (!found) return;
-    const int mt = (i / J.n_tiles) * 8 + xcd, n_tile = i % J.n_tiles;
+    const int mt = (P.order ? i % Mx : i / J.n_tiles) * 8 + xcd, n_tile = P.order ? i / Mx : i % J.n_tiles;
     if (mt >= P.m_tiles) return;
     const int tpi = P.tiles_x * P.tiles_y;
     const int b = mt / tpi, tr = mt - b * tpi;
@@ -1421,9 +1421,15 @@ extern "C" int vpx_dbg_c5_stamps(unsigned long long* dev_buf, int block) { g_c5_
 
 hipError_t launch_c5(const C5Plan& P_in, int NT, hipStream_t s) {
     C5Plan P = P_in;
+    // Block order inside an XCD. The 128-column launches (the forward gate groups: 14 N tiles per pixel tile, 23 MB of packed weights
+    // against 4 MB of L2) run the pixel tiles of an N tile next to each other — the XCD's 16 pixel tiles then stream one N tile's weights
+    // together: FETCH_SIZE 211 -> 170 MB per launch at B = 128, same time; the narrow launches keep the N tiles of a pixel tile together
+    // (conv_o: 49 MB that way, 55 MB the other).
+    P.order = NT == 8 ? 1 : 0;
 #ifdef VPX_DEV_SWITCHES
     P.stamps = g_c5_stamps; P.stamp_block = g_c5_stamp_block;
     P.ablate = dev_switch("VPX_C5_ABLATE", 0);
+    { const int o = dev_switch("VPX_C5_ORDER", -1); if (o >= 0) P.order = (o >> (NT == 8 ? 0 : (NT == 4 ? 1 : 2))) & 1; }   // bit 0 / 1 / 2: 128- / 64- / 32-column launches
 #else
     P.ablate = 0;
 #endif

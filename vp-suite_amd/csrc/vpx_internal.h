@@ -478,7 +478,7 @@ struct C5Plan {
     C5Src src[4];
     int ks;                                  // kernel size of every job: 0 | 5 = 5x5 (ST-LSTM step), 3 = 3x3 (ConvLSTM step on small grids)
     unsigned long long* stamps; int stamp_block;   // developer timing stamps (null in the product; vpx_dbg_c5_stamps)
-    int ablate, _apad;                       // developer build only (VPX_C5_ABLATE): parts of the K loop left out, to price them (results are wrong)
+    int ablate, order;                       // ablate: developer build only (VPX_C5_ABLATE). order: 0 = the N tiles of a pixel tile adjacent in an XCD's dispatch order, 1 = the pixel tiles of an N tile adjacent
     int njobs; C5Job job[C5_MAX_JOBS];
 };
 static_assert(sizeof(C5Plan) <= 4096, "C5Plan travels as a kernel argument (4 KiB)");
