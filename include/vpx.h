@@ -236,7 +236,9 @@ int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float*
  * Ci % 16 == 0, stride 1 or 2, taps within one pixel of the (sub-)image grid (3x3 pad 1, 4x4 stride 2 pad 1, plain or transposed)
  * — vpx_conv2d_ex_takes_split says whether a descriptor qualifies (0 no; 1 yes; 2 yes, and on the schedule-driven K = 32 kernel,
  *   which is worth a vpx_split_convert of an fp32 input for stride-2 transposed layers). y (fp32) and y_split may each be NULL, not both.
- * weights_packed: the workspace still holds this layer's packed weights (same values, same descriptor). */
+ * weights_packed: the workspace still holds this layer's packed weights (same values, same descriptor) — the pack launch is skipped
+ *   (both kernels; on the first-generation kernel for the single-launch forms: a stride-2 transposed layer's four phase launches
+ *   share the space and pack every time). */
 int vpx_conv2d_ex_takes_split(const vpx_conv_desc* d);
 /* fp32 channels-last pixels [n_pixels][C] -> the split-bf16 operand format (per pixel and 8 channels: 8 hi bf16, 8 lo bf16; the
  * same n_pixels * C * 4 bytes), C % 8 == 0: what the recurrent blocks and vpx_conv2d_ex_fwd_split write themselves. */
