@@ -888,9 +888,9 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
                     else load_B(p + 1, 0);
                     // ---- 12 MFMAs of column tile nt ----
                     __builtin_amdgcn_s_setprio(1);
+                    if constexpr (ALLG) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        if (ALLG || nt < 2 * ngr) {
+                        for (int m = 0; m < 4; ++m) {
                             f32x4 c = acc[m][nt];
                             if constexpr (!PLAIN) {
                                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.al[m], F.bh[nt & 1], c, 0, 0, 0);
@@ -898,9 +898,28 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
                             }
                             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bh[nt & 1], c, 0, 0, 0);
                             acc[m][nt] = c;
+                            // the last column tile frees row m's fragments: refill them for the next step
+                            if (nt == 7) load_A1(p == 8 ? 0 : p + 1, m, bx);
                         }
-                        // the last column tile frees row m's fragments: refill them for the next step
-                        if (nt == 7) load_A1(p == 8 ? 0 : p + 1, m, bx);
+                    } else {
+                        // An N tile that holds fewer than four 32-column groups (a data gradient's Cin + Ch columns: 80, 160, 192 in
+                        // convlstm-shi) skips the MFMAs of its empty column tiles — with ONE test per column tile (the first two always
+                        // hold outputs). Inside the row loop the same test put a branch around each of the period's 288 MFMA groups:
+                        // 497 branches and 689 waits in the loop's ISA against 33 and 171 in the all-groups form.
+                        if (nt < 2 || nt < 2 * ngr) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) {
+                                f32x4 c = acc[m][nt];
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.al[m], F.bh[nt & 1], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bl[nt & 1], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bh[nt & 1], c, 0, 0, 0);
+                                acc[m][nt] = c;
+                            }
+                        }
+                        if (nt == 7) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) load_A1(p == 8 ? 0 : p + 1, m, bx);
+                        }
                     }
                     __builtin_amdgcn_s_setprio(0);
                     // ---- this sync point's copies, behind the MFMAs of the following column tiles: the weights first, then the stage ----
