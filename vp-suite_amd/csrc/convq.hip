@@ -166,6 +166,11 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
     // 36 instead of 48 ds_read_b128 per 96 MFMAs — the phase form is LDS-read-bound. Same products, same order.
     constexpr bool REMAP = PHASE && NW == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef VPX_DEV_SWITCHES
+    const int dbg_bits = P.dbg;   // timing ablations of the developer build (VPX_CQ_DBG)
+#else
+    constexpr int dbg_bits = 0;   // (the product carries none of their tests: seven run-time tests per chunk of 96 MFMAs)
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kg = lane >> 4;
@@ -278,8 +283,8 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
     if (S > 0 && P.nsub > 0) {
         // ---- prologue: stage 0 (and stage 1 where the schedule expects it to be under way), chunks 0 and 1 ----
         Src aq_src = stage_src(0);
-        if (P.dbg & 32) return;
-        if (!(P.dbg & 16)) {
+        if (dbg_bits & 32) return;
+        if (!(dbg_bits & 16)) {
 #pragma unroll
         for (int u = 0; u < NP; ++u) issue_A1(aq_src, 0, u);
         }
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
         if (P.nchunk_total > 1) { issue_W1(1, 1, 0); issue_W1(1, 1, 1); }
         C2_WAIT_VM(0);
         c2_barrier();
-        if (P.dbg & 64) return;
+        if (dbg_bits & 64) return;
 
         int idx = 0, base = 0, c = 0;
         bool a_pending = false;                 // a stage copy issued AFTER the last weight chunk may still fly at the next sync
@@ -316,9 +321,9 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
             const int slot = c % WSLOTS, nslot = (c + 1) % WSLOTS;
             // ring of three: chunk c+2 into the slot chunk c-1 has left; ring of two: chunk c+1 (chunk 1 went out with the prologue)
             const int wq_c = WSLOTS == 3 ? c + 2 : (c > 0 ? c + 1 : 1 << 30);
-            const int wq = (wq_c < P.nchunk_total && !(P.dbg & 4)) ? wq_c : -1, wq_slot = wq_c % WSLOTS;
+            const int wq = (wq_c < P.nchunk_total && !(dbg_bits & 4)) ? wq_c : -1, wq_slot = wq_c % WSLOTS;
             bool aq = false, aq_first = false; int aq_buf = 0;
-            if (cur.issue && !(P.dbg & 2)) {
+            if (cur.issue && !(dbg_bits & 2)) {
                 const int st = base + cur.istage;
                 if (st <= S) {           // st == S: zero fill (a cross step may read that buffer against zero weights)
                     aq_src = stage_src(st);
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
                     const int at = PHASE ? t : k;        // accumulator tile
                     const int bt = REMAP ? k : t;        // weight-fragment set
                     if (!REMAP) { if (t < 7) load_B(slot, t + 1); else if (WSLOTS == 3) load_B(nslot, 0); }
-                    const bool go = on && ((tmask >> (REMAP ? 2 * wave + k : at)) & 1) && !(P.dbg & 1);
+                    const bool go = on && ((tmask >> (REMAP ? 2 * wave + k : at)) & 1) && !(dbg_bits & 1);
                     if (go) {
                         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(64 * NW, 2) void convq_kernel(const ConvQPlan P, co
         }
         C2_WAIT_VM(0);                            // no copy may land in the epilogue's transposition space
     }
-    if (!(P.dbg & 8)) epi.template finish16<REMAP>(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
+    if (!(dbg_bits & 8)) epi.template finish16<REMAP>(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
 }
 
 // ---- weight pack: [n_tile][chunk][part][k group][n][8 bf16]; the table says, per chunk of a pass and 16-column tile, which
