@@ -121,7 +121,8 @@ size_t vpx_convlstm_workspace_bytes(const vpx_convlstm_desc* d); /* scratch, con
 /* Split-bf16 operand format ("split"): a [N,H,W,C] fp32 NHWC tensor re-encoded, same byte count, as per pixel, per group of 8
  * channels: 8 hi bf16 (round-to-nearest of the value) then 8 lo bf16 (round-to-nearest of value - hi) — what the bf16x3
  * kernels multiply. Producers: vpx_conv2d_ex_fwd_split (the stage glue feeding a recurrent block). 1 = this descriptor's
- * forward consumes x in that form when VPX_FLAG_X_SPLIT is set (second-generation cell kernel, inference), 0 = fp32 only. */
+ * forward consumes x in that form when VPX_FLAG_X_SPLIT is set (inference: the second-generation cell kernel, and the small-grid
+ * kernel where its hoisted input projection runs on the schedule-driven convolution), 0 = fp32 only. */
 int vpx_convlstm_takes_split_input(const vpx_convlstm_desc* d);
 int vpx_convlstm_writes_split_output(const vpx_convlstm_desc* d);   /* 1 = VPX_FLAG_OUT_SPLIT is available for this descriptor */
 size_t vpx_convlstm_reserve_bytes(const vpx_convlstm_desc* d);   /* saved-for-backward, 0 without SAVE_FOR_BWD */

@@ -118,10 +118,23 @@ static size_t convlstm_wpk_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayou
                    : packed_weight_bytes(L.n_tiles, L.chunks_total, 4, d->precision, L.qpc);
 }
 
+static bool hoist_q_problem(const vpx_convlstm_desc* d, ConvQProblem& pr);
+
+static bool second_generation_inference(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
+    return L.v2 && d->layout == VPX_LAYOUT_NHWC && !(d->flags & VPX_FLAG_SAVE_FOR_BWD);
+}
+
 int vpx_convlstm_takes_split_input(const vpx_convlstm_desc* d) {
     ConvLSTMLayout L;
     if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
-    return (L.v2 && d->layout == VPX_LAYOUT_NHWC && !(d->flags & VPX_FLAG_SAVE_FOR_BWD)) ? 1 : 0;
+    if (second_generation_inference(d, L)) return 1;
+    // small grids (cell3): x only feeds the hoisted projection W_x (*) x_t of all frames; where that runs on the schedule-driven kernel
+    // it reads the operand format — the producing stage then writes it directly (no fp32 copy, no conversion launch)
+    if (L.v3 && d->layout == VPX_LAYOUT_NHWC && !(d->flags & VPX_FLAG_SAVE_FOR_BWD)) {
+        static thread_local ConvQProblem pr;
+        return hoist_q_problem(d, pr) && convq_wpk_bytes(pr) ? 1 : 0;
+    }
+    return 0;
 }
 
 int vpx_split_convert(const float* x, void* x_split, long long n_pixels, int C, void* stream) {
@@ -131,7 +144,9 @@ int vpx_split_convert(const float* x, void* x_split, long long n_pixels, int C, 
 }
 
 int vpx_convlstm_writes_split_output(const vpx_convlstm_desc* d) {   // the second-generation cell writes h_t in operand format anyway
-    return vpx_convlstm_takes_split_input(d);
+    ConvLSTMLayout L;
+    if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
+    return second_generation_inference(d, L) ? 1 : 0;
 }
 
 }  // extern "C"
