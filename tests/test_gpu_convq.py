@@ -108,8 +108,25 @@ def test_convlstm_block_hands_its_output_over_in_operand_format(vpx):
     assert torch.equal(hT2, hT) and torch.equal(cT2, cT)
     want, _ = vpx.ops.split_convert(out)          # [B, T, H, W, C/8, 2, 8] bf16 of the fp32 sequence
     assert torch.equal(sp.buf.view(torch.int32), want.view(torch.int32))
-    # small grids take other kernels: no split output there, and asking for it is an error
-    assert not vpx.ops.convlstm_writes_split(2, T, Cin, Ch, 16, 16, 3, 0, "bf16x3")
+    # small grids (cell3_kernel, which keeps h_t in operand format for its own recurrence) hand the sequence out the same way — with
+    # operand-format INPUT as well where the hoisted projection runs on the schedule-driven kernel; decoded: bit for bit the fp32 call
+    xs, ps = x[:2, :, :, :16, :16].contiguous(), [p[..., :16, :16].contiguous() for p in peep]
+    assert vpx.ops.convlstm_writes_split(2, T, Cin, Ch, 16, 16, 3, 0, "bf16x3")
+    h0 = seeded_randn((2, Ch, 16, 16), name_seed("osplit.h0"), 0.3).cuda()
+    c0 = seeded_randn((2, Ch, 16, 16), name_seed("osplit.c0"), 0.3).cuda()
+    with torch.no_grad():
+        out_s, hT_s, cT_s = vpx.ops.convlstm_seq(xs, h0, c0, Wt, b, *ps, seq_len=T, in_channels=Cin, precision="bf16x3")
+        sp_s, hT_s2, cT_s2 = vpx.ops.convlstm_seq(xs, h0, c0, Wt, b, *ps, seq_len=T, in_channels=Cin, precision="bf16x3", out_split=True)
+        assert isinstance(sp_s, vpx.ops.SplitActivation) and sp_s.shape == (2, T, Ch, 16, 16)
+        assert torch.equal(hT_s2, hT_s) and torch.equal(cT_s2, cT_s)
+        want_s, _ = vpx.ops.split_convert(out_s)
+        assert torch.equal(sp_s.buf.view(torch.int32), want_s.view(torch.int32))
+        if vpx.ops.convlstm_takes_split(2, T, Cin, Ch, 16, 16, 3, 0, "bf16x3"):
+            xbuf, _ = vpx.ops.split_convert(xs.reshape(2 * T, Cin, 16, 16))
+            out_x, hT_x, cT_x = vpx.ops.convlstm_seq(vpx.ops.SplitActivation(xbuf, (2, T, Cin, 16, 16)), h0, c0, Wt, b, *ps, seq_len=T,
+                                                     in_channels=Cin, precision="bf16x3")
+            assert torch.equal(out_x, out_s) and torch.equal(hT_x, hT_s) and torch.equal(cT_x, cT_s)
+    # exact-fp32 operands have no operand format: no split output, and asking for it is an error
+    assert not vpx.ops.convlstm_writes_split(2, T, Cin, Ch, 16, 16, 3, 0, "f32")
     with pytest.raises(Exception):
-        vpx.ops.convlstm_seq(x[:2, :, :, :16, :16], None, None, Wt, b, *[p[..., :16, :16] for p in peep], seq_len=T, in_channels=Cin,
-                             precision="bf16x3", out_split=True)
+        vpx.ops.convlstm_seq(xs, None, None, Wt, b, *ps, seq_len=T, in_channels=Cin, precision="f32", out_split=True)

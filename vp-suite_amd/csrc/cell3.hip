@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void cell3_kernel(const Cell3Args P) {
         hn[q] = o4[q] * tanh_f(cn[q]);
     }
     *reinterpret_cast<f32x4*>(a.c_out + e) = cn;
-    *reinterpret_cast<f32x4*>(a.h_out + (size_t)b * a.h_bstride + pe) = hn;
+    if (a.h_out) *reinterpret_cast<f32x4*>(a.h_out + (size_t)b * a.h_bstride + pe) = hn;   // (null: VPX_FLAG_OUT_SPLIT — the sequence goes out in operand format only)
     if (a.gates) {
         float* gs = a.gates + ((size_t)b * P.H * P.W + pix) * 4 * uCh + ch;
         *reinterpret_cast<f32x4*>(gs) = i4;

@@ -146,7 +146,8 @@ int vpx_split_convert(const float* x, void* x_split, long long n_pixels, int C, 
 int vpx_convlstm_writes_split_output(const vpx_convlstm_desc* d) {   // the second-generation cell writes h_t in operand format anyway
     ConvLSTMLayout L;
     if (check_convlstm_desc(d) != VPX_OK || convlstm_layout(d, L) != VPX_OK) return 0;
-    return second_generation_inference(d, L) ? 1 : 0;
+    if (second_generation_inference(d, L)) return 1;
+    return (L.v3 && d->layout == VPX_LAYOUT_NHWC && !(d->flags & VPX_FLAG_SAVE_FOR_BWD)) ? 1 : 0;   // (cell3 keeps h_t in operand format for its own recurrence)
 }
 
 }  // extern "C"
@@ -483,6 +484,17 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
             c3.pre_bstride = (long long)((size_t)T * HW * 4 * Ch);
             c3.h_sp_out = (t + 1 < T) ? h_ring3[t & 1] : nullptr;
             c3.h_sp_out_bstride = (long long)(HW * Ch * 4);
+            if (out_split) {
+                // the caller's `out` [B][T][HW][Ch] takes the steps' operand-format h_t (it is also where step t + 1 reads h_t); no fp32
+                // sequence — the last step still hands h_T out in fp32 where the caller wants it
+                const long long seq_bs = (long long)((size_t)T * HW * Ch * 4);
+                char* const out_sp = reinterpret_cast<char*>(outn);
+                if (t > 0) { c3.h_sp = out_sp + (size_t)(t - 1) * HW * Ch * 4; c3.h_bstride = seq_bs; }
+                c3.h_sp_out = out_sp + (size_t)t * HW * Ch * 4;
+                c3.h_sp_out_bstride = seq_bs;
+                ea.h_out = (t == T - 1) ? hTn : nullptr;
+                ea.h_bstride = (long long)(HW * Ch);
+            }
             c3.ea = ea;
             VPX_CHECK_HIP(launch_cell3(c3, stream));
         } else if (L.v2) {
