@@ -284,22 +284,24 @@ def experiment_switch(vpx):
 
 @pytest.mark.parametrize("tag", list(CASESQ))
 def test_small_grid_32_column_tiles_match_the_half_tile(vpx, cell2_switch, shape_switch, experiment_switch, tag):
-    """c3 (c5_kernel<2, 3>, round 4): the fused step on 16x16-pixel tiles x (4 gates x 8 channels), 8-channel stages, four stage
-    buffers — what inference runs where the half tile has at most 128 workgroups (every case here). Same operand split and products,
-    other summation order: 2e-6 against the half tile (VPX_OPT_EXPERIMENT bit 12), 2e-5 against the oracle, bit-identical run to run;
-    x-only / h-only / x + h packs, both gate orders, with and without peepholes, odd stage counts."""
+    """c3 (c5_kernel<4, 3> — the product's choice — and c5_kernel<2, 3>, VPX_OPT_EXPERIMENT bit 13; round 4): the fused step on
+    16x16-pixel tiles x (4 gates x 16 | 8 channels), 8-channel stages, four stage buffers — what inference runs where the half tile
+    has at most 128 workgroups (every case here). Same operand split and products, other summation order: 2e-6 against the half tile
+    (bit 12), 2e-5 against the oracle, bit-identical run to run; x-only / h-only / x + h packs, both gate orders, with and without
+    peepholes, odd stage counts."""
     cell2_switch(2)
     shape_switch(1)
+    ro, rh, rc, _ = _oracle(tag)
     with torch.no_grad():
         experiment_switch(4096)
         o1, h1, c1, _ = _run(vpx, tag, grads=False)
-        experiment_switch(0)
-        o2, h2, c2, _ = _run(vpx, tag, grads=False)
-        o3, _, _, _ = _run(vpx, tag, grads=False)
-    assert torch.equal(o2, o3)
-    assert _relmax(o2, o1) < 2e-6 and _relmax(c2, c1) < 2e-6 and _relmax(h2, h1) < 2e-6, (_relmax(o2, o1), _relmax(c2, c1))
-    ro, rh, rc, _ = _oracle(tag)
-    assert _relmax(o2, ro) < 2e-5 and _relmax(c2, rc) < 2e-5 and _relmax(h2, rh) < 2e-5
+        for bits in (0, 8192):   # 64-column tiles, 32-column tiles
+            experiment_switch(bits)
+            o2, h2, c2, _ = _run(vpx, tag, grads=False)
+            o3, _, _, _ = _run(vpx, tag, grads=False)
+            assert torch.equal(o2, o3), bits
+            assert _relmax(o2, o1) < 2e-6 and _relmax(c2, c1) < 2e-6 and _relmax(h2, h1) < 2e-6, (bits, _relmax(o2, o1), _relmax(c2, c1))
+            assert _relmax(o2, ro) < 2e-5 and _relmax(c2, rc) < 2e-5 and _relmax(h2, rh) < 2e-5, bits
 
 
 @pytest.mark.parametrize("tag", list(CASESQ))

@@ -97,12 +97,14 @@ static int c3_nt(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {   // 0: 
     if (!L.v2 || !cell2_q_applicable(d) || d->precision != VPX_PREC_BF16X3 || (d->flags & VPX_FLAG_SAVE_FOR_BWD) || (g_experiment & 4096)) return 0;
     if ((d->Cin & 7) || (d->Ch & 15)) return 0;
     const long long mt = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
-    // Measured (round 4, B = 4): 64x64 maps, Ch = 64 (128 half-tile workgroups): 39 -> 34 us per step with 32-column tiles (512 workgroups;
-    // 64-column tiles 36 us), inference step 1.90 -> 1.74 ms; with 192 half-tile workgroups (64x64 maps, Ch = 96: configs[3]'s shard) the
-    // half tile wins (5.64 vs 5.97 ms per step). The narrow tiles are bound by their per-step overhead (24 MFMAs between sync points:
-    // PMC MFMA busy 27 %), not by the copy latency (a five-deep weight ring changed nothing).
-    if (mt * L.n_tiles > 128) return 0;
-    return (d->Ch & 7) ? 4 : 2;
+    // Measured (round 4, B = 4, 64x64 maps, Ch = 64: 128 half-tile workgroups of 39 us). First pass: 32-column tiles (512 workgroups) 34 us,
+    // 64-column tiles (256) 36 us — the narrow tiles were bound by their K loop's bookkeeping. With that gone (convq.hip, "the K loop's
+    // diet") the 64-column tiles win: cell (64,64,64^2) B = 4 0.309 vs 0.336 ms per 10 steps, inference step 1.60 vs 1.63 ms
+    // (tools/ab_c3_rule.sh) — half the stage copies per MFMA. With 192 half-tile workgroups (64x64 maps, Ch = 96: configs[3]'s shard) the
+    // half tile still wins on the whole model (5.72 vs 5.88 ms per step) although the (64,96,64^2) cell alone is 2 % faster on c3.
+    if (mt * L.n_tiles > dev_switch("VPX_C3_MAX", 128)) return 0;
+    if (const int f = dev_switch("VPX_C3_NT", 0)) return f;   // (developer build only)
+    return (g_experiment & 8192) ? 2 : 4;   // VPX_OPT_EXPERIMENT bit 13: the 32-column tiles (tests, A/B runs)
 }
 
 static size_t cell2_wpk_bytes(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {
