@@ -161,7 +161,7 @@ def test_stlstm_second_generation_backward_matches_first_generation(vpx, B, Cin,
       * c5 forward (channels in 32s): both gate groups as the jobs of one launch (gate-interleaved N tiles, fused gate math, c_new /
         m_new also written in the split format), conv_o + output gate as another — bit 8 switches it off;
       * c1 (conv1.hip): conv_last and its adjoint as a streaming kernel with register-resident weights (Ch = 128 only) — bit 9;
-      * on grids below 96 pixel tiles (every shape here) the c5 launches run K-SPLIT (chunks of K as separate jobs writing partial sums,
+      * on grids below 48 (forward) / 96 (backward) pixel tiles (every shape here) the c5 launches run K-SPLIT (chunks of K as separate jobs writing partial sums,
         st_pointwise.hip adds them): the default; bit 10 forces the unsplit forms, bit 11 the first generation."""
     from golden_util import seeded_randn
     k = 5

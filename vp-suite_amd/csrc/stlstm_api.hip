@@ -42,13 +42,16 @@ static inline int c5f_nt_o(const vpx_stlstm_desc* d) {
 // Grid rule (measured, tools/ab_predrnn.py, predrnn-pp inference, ms per forward c5 vs first generation): 16x16 maps B = 8 / 16 / 32 / 64 /
 // 128: 23.5 / 23.7 / 24.4 / 30.5 / 53.8 vs 13.7 / 14.1 / 17.1 / 26.9 / 58.5; 32x32 maps (128x128x3, 4 layers, 10 -> 30) B = 4 / 8 / 16:
 // 72.5 / 78.1 / 90.9 vs 45.0 / 53.0 / 83.5 — a c5 workgroup runs its whole K (200 steps of 96 MFMAs) on one CU, the first generation
-// splits K over workgroups when the pixel tiles do not fill the chip. c5 from 96 pixel tiles of 16x16 on.
+// splits K over workgroups when the pixel tiles do not fill the chip. c5 from 96 pixel tiles of 16x16 on — first pass of round 4. After the
+// K loop's diet (convq.hip) the unsplit form wins from 48 tiles on against its own K-split job forms (tools/ab_c5_min.sh, 16x16 maps,
+// ms per forward unsplit vs K-split: B = 40 30.2 vs 28.9, 48 30.7 vs 33.2, 56 32.1 vs 34.7, 64 33.5 vs 36.2, 80 47.1 vs 50.4); the backward
+// launches keep 96 (training step B = 48 221 vs 211 ms, 64 246 vs 242, 80 309.5 vs 309.1).
 static bool c5_shape_ok(const vpx_stlstm_desc* d) {
     return d->k == 5 && d->precision == VPX_PREC_BF16X3 && !(d->Ch & 31) && !(d->Cin & 7) && !d->layer_norm && !(g_experiment & 256);
 }
 bool c5_fwd_applicable(const vpx_stlstm_desc* d) {
     const long long mt = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
-    return c5_shape_ok(d) && (mt >= 96 || (g_experiment & 1024));   // (bit 10 forces the unsplit form on small grids: tests)
+    return c5_shape_ok(d) && (mt >= dev_switch("VPX_C5_MIN_TILES", 48) || (g_experiment & 1024));   // (bit 10 forces the unsplit form on small grids: tests)
 }
 // below the bar: K-split jobs (VPX_OPT_EXPERIMENT bit 11 keeps the first-generation launches there)
 bool c5k_fwd_applicable(const vpx_stlstm_desc* d) { return c5_shape_ok(d) && !c5_fwd_applicable(d) && !(g_experiment & 2048); }

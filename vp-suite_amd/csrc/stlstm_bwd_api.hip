@@ -84,7 +84,7 @@ int st_bwd_layout(const vpx_stlstm_desc* d, STBwdLayout& L) {
     // step at 16x16 maps, unsplit c5 vs first-generation K-split data gradients: B = 8 130 vs 78 ms, B = 32 165 vs 136 ms, B = 128 361
     // vs ~405 ms); below, the K of every slot is cut into chunks (bit 11 of VPX_OPT_EXPERIMENT keeps the first generation there).
     const long long mt16 = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
-    const bool big = mt16 >= 96 || (g_experiment & 1024);
+    const bool big = mt16 >= dev_switch("VPX_C5B_MIN_TILES", 96) || (g_experiment & 1024);
     L.c5 = L.stw && !(g_experiment & 128) && (big || !(g_experiment & 2048));
     if (L.c5) {
         const int K[5] = {Ch, Ch, 7 * Ch, 4 * Ch, 3 * Ch}, Co[5] = {Ch, Ch, Cin, Ch, Ch};
