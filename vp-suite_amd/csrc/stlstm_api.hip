@@ -57,7 +57,8 @@ bool c5_fwd_applicable(const vpx_stlstm_desc* d) {
 bool c5k_fwd_applicable(const vpx_stlstm_desc* d) { return c5_shape_ok(d) && !c5_fwd_applicable(d) && !(g_experiment & 2048); }
 // K chunks so that the launch has about 448 workgroups, every chunk at least four 8-channel stages (25 steps), at most six chunks
 static int c5k_chunks(long long wgs1, int S8) {
-    int ks = (int)((448 + wgs1 / 2) / (wgs1 > 0 ? wgs1 : 1));
+    const long long target = dev_switch("VPX_C5K_TARGET", 448);   // workgroups the chunked launch aims at
+    int ks = (int)((target + wgs1 / 2) / (wgs1 > 0 ? wgs1 : 1));
     if (ks > S8 / 4) ks = S8 / 4;
     if (ks > 6) ks = 6;
     return ks < 1 ? 1 : ks;
@@ -115,6 +116,7 @@ int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
         const long long mt = (long long)d->B * ((d->H + 15) / 16) * ((d->W + 15) / 16);
         L.ks_g = c5k_chunks(mt * ((7 * d->Ch + 127) / 128), (d->Cin + d->Ch) / 8);
         L.nt_o = mt * ((d->Ch + 63) / 64) * 6 < 320 ? 2 : 4;
+        if (const int f = dev_switch("VPX_C5_NT_O", 0)) L.nt_o = f;   // (developer build only)
         L.ks_o = c5k_chunks(mt * ((d->Ch + L.nt_o * 16 - 1) / (L.nt_o * 16)), 2 * d->Ch / 8);
         for (int k = 0; k < L.ks_g; ++k) {
             L.k_wc[k] = align256(c5_chunk_wpk_bytes(d->Cin + d->Ch, k, L.ks_g, 4 * d->Ch, 8));
