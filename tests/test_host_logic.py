@@ -41,14 +41,20 @@ def test_workspace_queries_run_without_gpu(vpx):
 def test_workspace_queries_follow_the_kernel_selection(vpx):
     """The size queries (pure host logic, no GPU) reflect which kernel a descriptor gets: the second-generation cell keeps split
     copies of its operands in the reserve and takes split input; the small-grid kernel needs the hoisted input projection of
-    all steps in the workspace and takes fp32 input; the backward of either carries dG of all steps in split format too."""
+    all steps in the workspace — it takes split input where that projection runs on the schedule-driven kernel (input channels
+    in 16s) and fp32 otherwise, and hands its output sequence out in split format either way (it keeps h_t that way for its own
+    recurrence); nothing of that with SAVE_FOR_BWD; the backward of either carries dG of all steps in split format too."""
     L = vpx._lib.lib()
     BF16X3, SAVE = vpx._lib.PREC_BF16X3, vpx._lib.FLAG_SAVE_FOR_BWD
     def desc(B, T, Cin, Ch, H, W, flags):
         return vpx._lib.ConvLSTMDesc(B, T, Cin, Ch, H, W, 3, 3, 0, vpx._lib.LAYOUT_NHWC, BF16X3, flags)
     big, small = desc(128, 10, 64, 64, 64, 64, 0), desc(4, 10, 64, 96, 32, 32, 0)
     assert L.vpx_convlstm_takes_split_input(ctypes.byref(big)) == 1       # cell2: 2048 workgroups
-    assert L.vpx_convlstm_takes_split_input(ctypes.byref(small)) == 0     # cell3: small grid
+    assert L.vpx_convlstm_takes_split_input(ctypes.byref(small)) == 1     # cell3, 64 input channels: hoisted projection on convq
+    assert L.vpx_convlstm_takes_split_input(ctypes.byref(desc(4, 10, 8, 96, 32, 32, 0))) == 0    # 8 input channels: first-generation projection, fp32
+    assert L.vpx_convlstm_writes_split_output(ctypes.byref(big)) == 1 and L.vpx_convlstm_writes_split_output(ctypes.byref(small)) == 1
+    for dd in (desc(128, 10, 64, 64, 64, 64, SAVE), desc(4, 10, 64, 96, 32, 32, SAVE)):       # training: fp32 in, fp32 out
+        assert L.vpx_convlstm_takes_split_input(ctypes.byref(dd)) == 0 and L.vpx_convlstm_writes_split_output(ctypes.byref(dd)) == 0
     n_state, n_x = 128 * 64 * 64 * 64, 128 * 10 * 64 * 64 * 64
     rs = L.vpx_convlstm_reserve_bytes(ctypes.byref(desc(128, 10, 64, 64, 64, 64, SAVE)))
     assert rs >= 10 * n_state * 5 * 4 + n_x * 4 + n_state * 4 + 10 * n_state * 4   # gates + c, then x, h0, h_1..h_T split
@@ -340,3 +346,18 @@ def test_ef_trajgru_registry_and_state_dict_contract(vpx):
     with pytest.raises(NotImplementedError):
         Activation("swish")(torch.zeros(1))
     pickle.loads(pickle.dumps(m))
+
+
+def test_tools_compile_and_referenced_tools_exist():
+    """Every tools/*.py byte-compiles, every tools/*.sh passes `bash -n`, and every tools/ path named in DESIGN.md / README.md /
+    INTEGRATION.md exists (profiles/README.md also names tools of earlier rounds that were pruned: it says so next to each)."""
+    import glob, py_compile, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in glob.glob(os.path.join(root, "tools", "*.py")):
+        py_compile.compile(f, doraise=True)
+    for f in glob.glob(os.path.join(root, "tools", "*.sh")):
+        assert subprocess.run(["bash", "-n", f]).returncode == 0, f
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md"):
+        text = open(os.path.join(root, doc)).read()
+        for t in set(re.findall(r"tools/[A-Za-z0-9_]+\.(?:py|sh)", text)):
+            assert os.path.exists(os.path.join(root, t)), (doc, t)
