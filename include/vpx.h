@@ -109,7 +109,7 @@ int vpx_set_deterministic(int on);
  *                        tail's adapter) on the implicit-GEMM kernel instead of the streaming one (c1, conv1.hip); 1024 the c5 launches
  *                        unsplit on grids below their 96-pixel-tile bar (tests); 2048 the first-generation launches instead of the
  *                        K-split c5 jobs on those grids; 4096 the half tile of the fused ConvLSTM step
- *                        instead of its narrow-tile form (c3: c5_kernel<4, 3>) on grids of at most 128 half-tile workgroups;
+ *                        instead of its narrow-tile form (c3: c5_kernel<4, 3>) on grids of at most 256 half-tile workgroups;
  *                        8192 c3 with 32-column tiles (c5_kernel<2, 3>) instead of 64-column ones */
 #define VPX_OPT_EXPERIMENT 4
 int vpx_set_option(int option, int value);

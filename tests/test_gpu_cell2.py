@@ -286,7 +286,7 @@ def experiment_switch(vpx):
 def test_small_grid_32_column_tiles_match_the_half_tile(vpx, cell2_switch, shape_switch, experiment_switch, tag):
     """c3 (c5_kernel<4, 3> — the product's choice — and c5_kernel<2, 3>, VPX_OPT_EXPERIMENT bit 13; round 4): the fused step on
     16x16-pixel tiles x (4 gates x 16 | 8 channels), 8-channel stages, four stage buffers — what inference runs where the half tile
-    has at most 128 workgroups (every case here). Same operand split and products, other summation order: 2e-6 against the half tile
+    has at most 256 workgroups (every case here). Same operand split and products, other summation order: 2e-6 against the half tile
     (bit 12), 2e-5 against the oracle, bit-identical run to run; x-only / h-only / x + h packs, both gate orders, with and without
     peepholes, odd stage counts."""
     cell2_switch(2)

@@ -101,8 +101,10 @@ static int c3_nt(const vpx_convlstm_desc* d, const ConvLSTMLayout& L) {   // 0: 
     // 64-column tiles (256) 36 us — the narrow tiles were bound by their K loop's bookkeeping. With that gone (convq.hip, "the K loop's
     // diet") the 64-column tiles win: cell (64,64,64^2) B = 4 0.309 vs 0.336 ms per 10 steps, inference step 1.60 vs 1.63 ms
     // (tools/ab_c3_rule.sh) — half the stage copies per MFMA. With 192 half-tile workgroups (64x64 maps, Ch = 96: configs[3]'s shard) the
-    // half tile still wins on the whole model (5.72 vs 5.88 ms per step) although the (64,96,64^2) cell alone is 2 % faster on c3.
-    if (mt * L.n_tiles > dev_switch("VPX_C3_MAX", 128)) return 0;
+    // 64-column c3 tiles are 1.4 % ahead on the whole model (5.70 vs 5.78 ms per step, the (64,96,64^2) cell alone 2 %), equal at B = 8 / 16 on
+    // 64x64 maps with Ch = 64 (256 / 512 half-tile workgroups) — and behind once the 128x128 maps' 512 workgroups join (5.88 vs 5.72):
+    // c3 up to 256 half-tile workgroups (128 in the first pass of the round, for the 32-column tiles).
+    if (mt * L.n_tiles > dev_switch("VPX_C3_MAX", 256)) return 0;
     if (const int f = dev_switch("VPX_C3_NT", 0)) return f;   // (developer build only)
     return (g_experiment & 8192) ? 2 : 4;   // VPX_OPT_EXPERIMENT bit 13: the 32-column tiles (tests, A/B runs)
 }
