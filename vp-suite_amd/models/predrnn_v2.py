@@ -137,16 +137,21 @@ class PredRNN_V2(VPModel):
         h_t = [zeros(i) for i in range(self.num_layers)]
         c_t = [zeros(i) for i in range(self.num_layers)]
         memory = zeros(0)
-        mask_true = self._scheduled_sampling(b, context_frames, pred_frames, train)
+        # Test-time sampling masks are constants (predrnn_v2.py:300-309: zeros, and ones over the context frames in reverse mode): the
+        # blend mask * x + (1 - mask) * x_gen (:171-176) then IS one of its two operands, bit for bit on finite inputs — taken directly instead of
+        # through four elementwise launches per predicted frame (2 % of a small-batch forward).
+        mask_true = self._scheduled_sampling(b, context_frames, pred_frames, train) if train else None
         first_blend = 1 if self.reverse_scheduled_sampling else context_frames
         k = self.filter_size
         x_gen, next_frames, decouple = None, [], []
         for t in range(total_frames - 1):
             if t < first_blend:
                 net = x_patch[:, t]
-            else:
+            elif train:
                 mk = mask_true[:, t - first_blend]
                 net = mk * x_patch[:, t] + (1 - mk) * x_gen
+            else:
+                net = x_patch[:, t] if (self.reverse_scheduled_sampling and t < context_frames) else x_gen
             action = a_patch[:, t] if a_patch is not None else None
             if self.conv_actions_on_input:   # two stride-2 convolutions on the frame and on the action map (:178-188)
                 shape1 = net.shape[-2:]
