@@ -112,6 +112,12 @@ int vpx_set_deterministic(int on);
  *                        instead of its narrow-tile form (c3: c5_kernel<4, 3>) on grids of at most 256 half-tile workgroups;
  *                        8192 c3 with 32-column tiles (c5_kernel<2, 3>) instead of 64-column ones */
 #define VPX_OPT_EXPERIMENT 4
+/*   VPX_OPT_DRY_RUN      1 = every entry point does all of its host-side work (argument checks, kernel selection, workspace carving
+ *                        and the bounds checks of everything it would write into the workspace) but issues no HIP call: needs no GPU
+ *                        and touches none of the pointers (they only have to be non-NULL where the call requires a tensor). A sizing
+ *                        rule of a `*_workspace_bytes` query that disagrees with the launch code returns VPX_ERR_WORKSPACE. For the
+ *                        CPU test-suite (tests/test_workspace_contract.py); a process that ran dry must not launch afterwards. */
+#define VPX_OPT_DRY_RUN 5
 int vpx_set_option(int option, int value);
 /* A counter that advances with every vpx_set_option / vpx_set_deterministic call: callers that cache anything kernel-selection
  * dependent (a workspace with weight packs, VPX_FLAG_WEIGHTS_PACKED) key it on this value. */

@@ -22,6 +22,7 @@ FLAG_OUT_SPLIT = 8
 OPT_CELL2 = 1
 OPT_CELL3 = 2
 OPT_EXPERIMENT = 4
+OPT_DRY_RUN = 5      # host-side work only, no HIP call (tests/test_workspace_contract.py)
 OPT_MFMA_SHAPE = 3   # 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_f32_16x16x32_bf16 in the second-generation kernels' main loop
 
 EXPORTED_SYMBOLS = [

@@ -109,8 +109,8 @@ int vpx_acst_gates_fwd(const float* xc, const float* hc, const float* ac, const 
         return VPX_ERR_ARG;
     }
     AcstGateArgs a{npix, Ch, forget_bias, xc, hc, ac, mc, c, m, c_new, m_new, delta_c, delta_m, o_pre, mem, save};
-    hipLaunchKernelGGL(acst_gates_fwd_kernel, dim3((unsigned)((npix * Ch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-    VPX_CHECK_HIP(hipGetLastError());
+    VPX_LAUNCH(acst_gates_fwd_kernel, dim3((unsigned)((npix * Ch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    VPX_CHECK_HIP(vpx_hip_last_error());
     return VPX_OK;
 }
 
@@ -122,8 +122,8 @@ int vpx_acst_gates_bwd(const float* hc, const float* ac, const float* c, const f
         return VPX_ERR_ARG;
     }
     AcstGateBwdArgs a{npix, Ch, hc, ac, c, m, save, d_cn, d_mn, d_dc, d_dm, d_opre, d_mem, dxc, dhc, dac, dmc, dc, dm};
-    hipLaunchKernelGGL(acst_gates_bwd_kernel, dim3((unsigned)((npix * Ch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-    VPX_CHECK_HIP(hipGetLastError());
+    VPX_LAUNCH(acst_gates_bwd_kernel, dim3((unsigned)((npix * Ch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    VPX_CHECK_HIP(vpx_hip_last_error());
     return VPX_OK;
 }
 
@@ -136,8 +136,8 @@ int vpx_st_out_fwd(const float* o_pre, const float* oc, const float* lc, float* 
 
 int vpx_st_out_bwd(const float* dh, const float* o, const float* tl, float* d_o, float* d_lc, long long n, void* stream) {
     if (!dh || !o || !tl || !d_o || !d_lc || n < 1) { set_error("vpx_st_out_bwd: bad argument"); return VPX_ERR_ARG; }
-    hipLaunchKernelGGL(st_out_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, o, tl, d_o, d_lc, n);
-    VPX_CHECK_HIP(hipGetLastError());
+    VPX_LAUNCH(st_out_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, o, tl, d_o, d_lc, n);
+    VPX_CHECK_HIP(vpx_hip_last_error());
     return VPX_OK;
 }
 

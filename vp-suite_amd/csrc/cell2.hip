@@ -46,9 +46,10 @@ __global__ __launch_bounds__(256) void split_convert_kernel(const float* __restr
 
 hipError_t launch_split_convert(const float* src, void* dst, long long npix, int C, hipStream_t s) {
     const long long ngroups = npix * (C / 8);
+    if (!ws_write_ok(dst, (size_t)ngroups * 32, "operand conversion (split_convert_kernel)")) return hipErrorInvalidValue;
     const long long blocks = (ngroups + 255) / 256;
-    hipLaunchKernelGGL(split_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, reinterpret_cast<char*>(dst), ngroups, C / 8);
-    return hipGetLastError();
+    VPX_LAUNCH(split_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, reinterpret_cast<char*>(dst), ngroups, C / 8);
+    return vpx_hip_last_error();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -114,11 +115,12 @@ __global__ void cell2_pack_kernel(const Cell2Pack pk, char* __restrict__ dst) {
 
 hipError_t launch_cell2_pack(const Cell2Pack& pk, void* dst, hipStream_t s) {
     const long long total = (long long)pk.n_tiles * pk.chunks_total * ((pk.qform ? CQ_WCHUNK : C2_WCHUNK) / 2);
+    if (!ws_write_ok(dst, (size_t)total * 2, "weight pack (cell2_pack_kernel)")) return hipErrorInvalidValue;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    if (pk.qform) hipLaunchKernelGGL(cell2_pack_q_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
-    else hipLaunchKernelGGL(cell2_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
-    return hipGetLastError();
+    if (pk.qform) VPX_LAUNCH(cell2_pack_q_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
+    else VPX_LAUNCH(cell2_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
+    return vpx_hip_last_error();
 }
 
 size_t cell2_packed_bytes(int n_tiles, int chunks_total) { return (size_t)n_tiles * chunks_total * C2_WCHUNK; }
@@ -978,13 +980,13 @@ template <class Epi, bool ALLG>
 static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel<Epi, ALLG>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
+        hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&cell2_kernel<Epi, ALLG>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, CQGeom<8>::LDS);
+        e = vpx_func_attr(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, CQGeom<8>::LDS);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, CQGeom<4>::LDS);
+        e = vpx_func_attr(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, CQGeom<4>::LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = !g_dry_run;
     }
     Cell2Plan p = plan;
     p.grid_m = plan.B * plan.tiles_x * plan.tiles_y;
@@ -1001,28 +1003,28 @@ static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStrea
                 if (plan.plain) {
                     static bool attr_plain = false;
                     if (!attr_plain) {
-                        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CQGeom<4>::LDS);
+                        hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CQGeom<4>::LDS);
                         if (e != hipSuccess) return e;
-                        attr_plain = true;
+                        attr_plain = !g_dry_run;
                     }
-                    hipLaunchKernelGGL((cell2_kernel_q<Epi, ALLG, 4, true>), dim3((unsigned)(per_xcd_h * 8)), dim3(256), CQGeom<4>::LDS, s, p, epi);
-                    return hipGetLastError();
+                    VPX_LAUNCH((cell2_kernel_q<Epi, ALLG, 4, true>), dim3((unsigned)(per_xcd_h * 8)), dim3(256), CQGeom<4>::LDS, s, p, epi);
+                    return vpx_hip_last_error();
                 }
             }
             if (plan.plain) return hipErrorInvalidValue;   // (only the fused cell step has the plain form)
-            hipLaunchKernelGGL((cell2_kernel_q<Epi, ALLG, 4>), dim3((unsigned)(per_xcd_h * 8)), dim3(256), CQGeom<4>::LDS, s, p, epi);
-            return hipGetLastError();
+            VPX_LAUNCH((cell2_kernel_q<Epi, ALLG, 4>), dim3((unsigned)(per_xcd_h * 8)), dim3(256), CQGeom<4>::LDS, s, p, epi);
+            return vpx_hip_last_error();
         }
         const long long per_xcd_q = ((long long)p.grid_m * p.n_tiles + 7) / 8;
-        hipLaunchKernelGGL((cell2_kernel_q<Epi, ALLG, 8>), dim3((unsigned)(per_xcd_q * 8)), dim3(512), CQGeom<8>::LDS, s, p, epi);
-        return hipGetLastError();
+        VPX_LAUNCH((cell2_kernel_q<Epi, ALLG, 8>), dim3((unsigned)(per_xcd_q * 8)), dim3(512), CQGeom<8>::LDS, s, p, epi);
+        return vpx_hip_last_error();
     }
 #ifdef VPX_ABLATE
     p._p = dev_switch("VPX_C2_STAMP_BLOCK", -1);
 #endif
     const long long per_xcd = ((long long)p.grid_m * p.n_tiles + 7) / 8;
-    hipLaunchKernelGGL((cell2_kernel<Epi, ALLG>), dim3((unsigned)(per_xcd * 8)), dim3(512), C2_LDS, s, p, epi);
-    return hipGetLastError();
+    VPX_LAUNCH((cell2_kernel<Epi, ALLG>), dim3((unsigned)(per_xcd * 8)), dim3(512), C2_LDS, s, p, epi);
+    return vpx_hip_last_error();
 }
 
 hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s) {
@@ -1089,15 +1091,16 @@ __global__ void conv2_pack_q_kernel(const Conv2Pack pk, int S, char* __restrict_
 
 hipError_t launch_conv2_pack(const Conv2Pack& pk, void* dst, hipStream_t s) {
     const long long total = (long long)pk.n_tiles * pk.chunks_total * ((pk.qform ? CQ_WCHUNK : C2_WCHUNK) / 2);
+    if (!ws_write_ok(dst, (size_t)total * 2, "weight pack (conv2_pack_kernel)")) return hipErrorInvalidValue;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (pk.qform) {
         const int S = (2 * pk.chunks_total) / 9;   // chunks_total = cell2_qchunks(S)
-        hipLaunchKernelGGL(conv2_pack_q_kernel, dim3(blocks), dim3(256), 0, s, pk, S, reinterpret_cast<char*>(dst));
+        VPX_LAUNCH(conv2_pack_q_kernel, dim3(blocks), dim3(256), 0, s, pk, S, reinterpret_cast<char*>(dst));
     } else {
-        hipLaunchKernelGGL(conv2_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
+        VPX_LAUNCH(conv2_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
     }
-    return hipGetLastError();
+    return vpx_hip_last_error();
 }
 
 hipError_t launch_conv2(const Conv2Args& c, hipStream_t s) {

@@ -69,10 +69,11 @@ __global__ void cell3_pack_kernel(const Cell3Pack pk, char* __restrict__ dst) {
 
 hipError_t launch_cell3_pack(const Cell3Pack& pk, void* dst, hipStream_t s) {
     const long long total = (long long)pk.n_slices * pk.nk * (C3_KSTEP / 2);
+    if (!ws_write_ok(dst, (size_t)total * 2, "weight pack (cell3_pack_kernel)")) return hipErrorInvalidValue;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(cell3_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
-    return hipGetLastError();
+    VPX_LAUNCH(cell3_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, reinterpret_cast<char*>(dst));
+    return vpx_hip_last_error();
 }
 
 size_t cell3_packed_bytes(int Ch) { return (size_t)(Ch / 8) * (9 * Ch / 16) * C3_KSTEP; }
@@ -271,14 +272,14 @@ hipError_t launch_cell3(const Cell3Args& args, hipStream_t s) {
     const int lds = 2 * C3_ABUF + P.nk * C3_KSTEP;
     static int attr_lds = 0;
     if (lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cell3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C3_ABUF + (9 * C3_MAX_CH / 16) * C3_KSTEP);
+        hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&cell3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C3_ABUF + (9 * C3_MAX_CH / 16) * C3_KSTEP);
         if (e != hipSuccess) return e;
         attr_lds = 2 * C3_ABUF + (9 * C3_MAX_CH / 16) * C3_KSTEP;
     }
     const long long total = (long long)P.B * P.tiles_x * P.tiles_y * P.n_slices;
     const long long per_xcd = (total + 7) / 8;
-    hipLaunchKernelGGL(cell3_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), lds, s, P);
-    return hipGetLastError();
+    VPX_LAUNCH(cell3_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), lds, s, P);
+    return vpx_hip_last_error();
 }
 
 }  // namespace vpx

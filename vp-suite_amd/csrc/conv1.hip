@@ -121,10 +121,10 @@ hipError_t launch_c1(const C1Args& a, hipStream_t s) {
     const long long ntile = (a.npix + 15) / 16;
     const long long gmax = dev_switch("VPX_C1_GRID", 512);
     const unsigned grid = (unsigned)(ntile < gmax ? ntile : gmax);   // two workgroups per CU, one round: every workgroup reads the weights once
-    if (a.Co == 128 && K == 256) hipLaunchKernelGGL((c1_kernel<2, 8>), dim3(grid), dim3(256), 0, s, a);
-    else if (a.Co == 256 && K == 128) hipLaunchKernelGGL((c1_kernel<4, 4>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((c1_kernel<2, 4>), dim3(grid), dim3(256), 0, s, a);
-    return hipGetLastError();
+    if (a.Co == 128 && K == 256) VPX_LAUNCH((c1_kernel<2, 8>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.Co == 256 && K == 128) VPX_LAUNCH((c1_kernel<4, 4>), dim3(grid), dim3(256), 0, s, a);
+    else VPX_LAUNCH((c1_kernel<2, 4>), dim3(grid), dim3(256), 0, s, a);
+    return vpx_hip_last_error();
 }
 
 }  // namespace vpx

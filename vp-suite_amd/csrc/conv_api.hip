@@ -25,11 +25,11 @@ int vpx_conv2d_nhwc_bwd(const float* x, const float* w, const float* dy, float* 
     if ((precision < VPX_PREC_F32 || precision > VPX_PREC_BF16)) { set_error("vpx_conv2d_nhwc_bwd: precision %d not implemented", precision); return VPX_ERR_UNSUPPORTED; }
     if (!workspace || workspace_bytes < vpx_conv2d_bwd_workspace_bytes(N, H, W, Ci, Co, kh, kw)) { set_error("vpx_conv2d_nhwc_bwd: workspace too small"); return VPX_ERR_WORKSPACE; }
     hipStream_t stream = (hipStream_t)stream_;
-    Carver ws{(char*)workspace, 0, workspace_bytes};
-    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    Carver ws(workspace, workspace_bytes);
     float* wpk = ws.take(plain_conv_wpk_floats(Co, Ci, kh, kw));
     float* slabs = ws.take((size_t)wgrad_slices(N, H, W) * kh * kw * Co * Ci);
     float* db_part = ws.take((size_t)COLSUM_BLOCKS * Co);
+    VPX_CHECK_CARVE(ws, "vpx_conv2d_nhwc_bwd");
     const ConvGeo g{N, H, W};
     int rc;
     if (dx && (rc = plain_conv(stream, precision, g, dy, Co, Co, w, (long long)Ci * kh * kw, kh * kw, kh, kw, Ci, true,
@@ -50,8 +50,10 @@ int vpx_conv2d_nhwc_fwd_ex(const float* x, const float* w, const float* bias, fl
     }
     if ((precision < VPX_PREC_F32 || precision > VPX_PREC_BF16)) { set_error("vpx_conv2d_nhwc_fwd_ex: precision %d not implemented", precision); return VPX_ERR_UNSUPPORTED; }
     if (!workspace || workspace_bytes < vpx_conv2d_workspace_bytes(Ci, Co, kh, kw)) { set_error("vpx_conv2d_nhwc_fwd_ex: workspace too small"); return VPX_ERR_WORKSPACE; }
-    float* wpk = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     const ConvGeo g{N, H, W};
+    Carver ws(workspace, workspace_bytes);
+    float* wpk = ws.take(plain_conv_pack_floats(precision, g, Ci, kh, kw, Co));
+    VPX_CHECK_CARVE(ws, "vpx_conv2d_nhwc_fwd_ex");
     return plain_conv((hipStream_t)stream_, precision, g, x, Ci, Ci, w, (long long)Ci * kh * kw, kh * kw, kh, kw, Co, false, bias, y, Co,
                       accumulate != 0, wpk, leaky_slope);
 }
@@ -107,13 +109,13 @@ int vpx_decouple_fwd(const float* delta_c, const float* delta_m, const float* ad
     if (!workspace || workspace_bytes < vpx_decouple_workspace_bytes(B, Ch, H, W)) { set_error("vpx_decouple_fwd: workspace too small"); return VPX_ERR_WORKSPACE; }
     hipStream_t stream = (hipStream_t)stream_;
     const size_t n = (size_t)B * H * W * Ch;
-    Carver ws{(char*)workspace, 0, workspace_bytes};
-    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    Carver ws(workspace, workspace_bytes);
     float* yc = ws.take(n);
     float* ym = ws.take(n);
     ws.take(n); ws.take(n);  // (backward's dYc / dYm slots)
     float* stats = ws.take((size_t)B * Ch * 4);
     float* wpk = ws.take(plain_conv_wpk_floats(Ch, Ch, 1, 1));
+    VPX_CHECK_CARVE(ws, "vpx_decouple_fwd");
     const ConvGeo g{B, H, W};
     int rc;
     if ((rc = decouple_adapter_pair(stream, prec, g, delta_c, delta_m, adapter, yc, ym, n, Ch, false, wpk))) return rc;
@@ -130,8 +132,7 @@ int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* ad
     if (!workspace || workspace_bytes < vpx_decouple_workspace_bytes(B, Ch, H, W)) { set_error("vpx_decouple_bwd: workspace too small"); return VPX_ERR_WORKSPACE; }
     hipStream_t stream = (hipStream_t)stream_;
     const size_t n = (size_t)B * H * W * Ch;
-    Carver ws{(char*)workspace, 0, workspace_bytes};
-    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    Carver ws(workspace, workspace_bytes);
     float* yc = ws.take(n);
     float* ym = ws.take(n);
     float* dyc = ws.take(n);
@@ -140,6 +141,7 @@ int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* ad
     float* wpk = ws.take(plain_conv_wpk_floats(Ch, Ch, 1, 1));
     float* slabs = ws.take((size_t)wgrad_slices(B, H, W) * Ch * Ch);
     float* dA2 = ws.take((size_t)Ch * Ch);
+    VPX_CHECK_CARVE(ws, "vpx_decouple_bwd");
     const ConvGeo g{B, H, W};
     int rc;
     // recompute the adapter outputs (cheaper than keeping them alive between forward and backward)
@@ -292,9 +294,9 @@ int vpx_conv2d_ex_fwd(const vpx_conv_desc* d, const float* x, const float* w, co
     if (rc != VPX_OK) return rc;
     if (!x || !w || !y) { set_error("vpx_conv2d_ex_fwd: NULL tensor argument"); return VPX_ERR_ARG; }
     if (!workspace || workspace_bytes < vpx_conv2d_ex_workspace_bytes(d)) { set_error("vpx_conv2d_ex_fwd: workspace too small"); return VPX_ERR_WORKSPACE; }
-    Carver ws{(char*)workspace, 0, workspace_bytes};
-    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    Carver ws(workspace, workspace_bytes);
     float* wpk = ws.take(ex_wpk_floats(d));
+    VPX_CHECK_CARVE(ws, "vpx_conv2d_ex_fwd");
     return ex_forward(d, g, x, w, bias, y, wpk, (hipStream_t)stream_);
 }
 
@@ -306,9 +308,9 @@ int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float*
     if (!x || !w || !y_split) { set_error("vpx_conv2d_ex_fwd_split: NULL tensor argument"); return VPX_ERR_ARG; }
     if (d->Co & 7) { set_error("vpx_conv2d_ex_fwd_split: the split format needs Co to be a multiple of 8 (got %d)", d->Co); return VPX_ERR_UNSUPPORTED; }
     if (!workspace || workspace_bytes < vpx_conv2d_ex_workspace_bytes(d)) { set_error("vpx_conv2d_ex_fwd_split: workspace too small"); return VPX_ERR_WORKSPACE; }
-    Carver ws{(char*)workspace, 0, workspace_bytes};
-    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    Carver ws(workspace, workspace_bytes);
     float* wpk = ws.take(ex_wpk_floats(d));
+    VPX_CHECK_CARVE(ws, "vpx_conv2d_ex_fwd_split");
     return ex_forward(d, g, x, w, bias, y, wpk, (hipStream_t)stream_, reinterpret_cast<char*>(y_split));
 }
 
@@ -360,7 +362,9 @@ int vpx_conv2d_ex_fwd_from_split(const vpx_conv_desc* d, const void* x_split, lo
     const size_t need = vpx_conv2d_ex_split_workspace_bytes(d);
     if (!need) { set_error("vpx_conv2d_ex_fwd_from_split: layer not implemented on split input (vpx_conv2d_ex_takes_split)"); return VPX_ERR_UNSUPPORTED; }
     if (!workspace || workspace_bytes < need) { set_error("vpx_conv2d_ex_fwd_from_split: workspace too small"); return VPX_ERR_WORKSPACE; }
-    char* wpk = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    Carver ws(workspace, workspace_bytes);
+    char* wpk = reinterpret_cast<char*>(ws.take((need - 512) / 4));
+    VPX_CHECK_CARVE(ws, "vpx_conv2d_ex_fwd_from_split");
     const long long dense = (long long)d->H * d->W * d->Ci * 4;
     if (x_bstride == 0) x_bstride = dense;
     static thread_local ConvQProblem pr;
@@ -606,13 +610,13 @@ int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, co
     if (!x || !w || !dy) { set_error("vpx_conv2d_ex_bwd: NULL tensor argument"); return VPX_ERR_ARG; }
     if (!workspace || workspace_bytes < vpx_conv2d_ex_bwd_workspace_bytes(d)) { set_error("vpx_conv2d_ex_bwd: workspace too small"); return VPX_ERR_WORKSPACE; }
     hipStream_t stream = (hipStream_t)stream_;
-    Carver ws{(char*)workspace, 0, workspace_bytes};
-    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    Carver ws(workspace, workspace_bytes);
     float* wpk = ws.take(ex_wpk_floats(&a));
     float* slabs = ws.take(ex_bwd_slab_floats(d, g));
     const size_t n_dy = (size_t)d->N * g.Ho * g.Wo * d->Co;
     float* dys = ws.take(n_dy);
     float* db_part = ws.take((size_t)COLSUM_BLOCKS * d->Co);
+    VPX_CHECK_CARVE(ws, "vpx_conv2d_ex_bwd");
     if (d->leaky_slope != 0.0f) {
         // d(pre-activation) = dy * LeakyReLU'(.), the derivative read off the sign of the forward OUTPUT (same sign as the
         // pre-activation for a positive slope) — one pass that also yields the bias gradient

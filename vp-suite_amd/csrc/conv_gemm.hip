@@ -90,11 +90,12 @@ __global__ void pack_weights_kernel(const PackDesc pd, char* __restrict__ dst) {
 
 hipError_t launch_pack_weights(const PackDesc& pd, float* dst, hipStream_t s) {
     const long long total = (long long)pd.n_tiles * pd.chunks_total * pd.NG * 32 * mode_kc(pd.prec, pd.qpc);
+    if (!ws_write_ok(dst, (size_t)total * 4, "weight pack (pack_weights_kernel)")) return hipErrorInvalidValue;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, pd, reinterpret_cast<char*>(dst));
-    return hipGetLastError();
+    VPX_LAUNCH(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, pd, reinterpret_cast<char*>(dst));
+    return vpx_hip_last_error();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -684,10 +685,10 @@ static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tile
     const size_t lds = (size_t)plan.a_bytes + 2 * (Epi::NG * 32 * (ModeTraits<MODE, QPCN>::WROW_DATA + 16));
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<Epi, MODE, MW, MS, QPCN>),
+        hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&conv_gemm_kernel<Epi, MODE, MW, MS, QPCN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = !g_dry_run;
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     ConvPlan p2 = plan;
@@ -696,8 +697,8 @@ static hipError_t launch_conv_m(const ConvPlan& plan, const Epi& epi, int n_tile
     const long long per_xcd = ((long long)p2.grid_m * n_tiles + 7) / 8;
     dim3 grid = p2.grid_n ? dim3((unsigned)(per_xcd * 8), 1, plan.ksplit > 1 ? plan.ksplit : 1)
                           : dim3(p2.grid_m, n_tiles, plan.ksplit > 1 ? plan.ksplit : 1);
-    hipLaunchKernelGGL((conv_gemm_kernel<Epi, MODE, MW, MS, QPCN>), grid, dim3(NTHREADS * MW), lds, s, p2, epi);
-    return hipGetLastError();
+    VPX_LAUNCH((conv_gemm_kernel<Epi, MODE, MW, MS, QPCN>), grid, dim3(NTHREADS * MW), lds, s, p2, epi);
+    return vpx_hip_last_error();
 }
 
 template <class Epi>
@@ -816,10 +817,10 @@ static hipError_t launch_st_dual_m(const ConvPlan& pc, const STGateArgs& ec, con
     const size_t lds = lc > lm ? lc : lm;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_dual_kernel<KA, KB, MODE, MW>),
+        hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&conv_gemm_dual_kernel<KA, KB, MODE, MW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = !g_dry_run;
     }
     if (lds > 160 * 1024 || pc.tiles_x != pm.tiles_x || pc.tiles_y != pm.tiles_y || pc.B != pm.B) return hipErrorInvalidValue;
     ConvPlan pc2 = pc;
@@ -828,8 +829,8 @@ static hipError_t launch_st_dual_m(const ConvPlan& pc, const STGateArgs& ec, con
     (void)&xcd_map_enabled;
     const long long per_xcd = ((long long)pc2.grid_m * 2 * n_tiles + 7) / 8;
     dim3 grid = pc2.grid_n ? dim3((unsigned)(per_xcd * 8), 1) : dim3(pc2.grid_m, 2 * n_tiles);
-    hipLaunchKernelGGL((conv_gemm_dual_kernel<KA, KB, MODE, MW>), grid, dim3(NTHREADS * MW), lds, s, pc2, KA{ec}, n_tiles, pm, KB{em});
-    return hipGetLastError();
+    VPX_LAUNCH((conv_gemm_dual_kernel<KA, KB, MODE, MW>), grid, dim3(NTHREADS * MW), lds, s, pc2, KA{ec}, n_tiles, pm, KB{em});
+    return vpx_hip_last_error();
 }
 
 hipError_t launch_st_gates_dual(const ConvPlan& pc, const STGateArgs& ec, const ConvPlan& pm, const STGateArgs& em,

@@ -188,26 +188,26 @@ hipError_t launch_conv_small(const vpx_conv_desc* d, int kind, const float* x, c
     const long long npix = (long long)d->N * d->H * d->W;
     if (kind == 2) {
         const dim3 grid((unsigned)((npix + 255) / 256));
-        if (d->Co == 1) hipLaunchKernelGGL(conv_many_to_few_kernel<1>, grid, dim3(256), 0, s, x, w, bias, y, npix, d->Ci, d->leaky_slope);
-        else hipLaunchKernelGGL(conv_many_to_few_kernel<3>, grid, dim3(256), 0, s, x, w, bias, y, npix, d->Ci, d->leaky_slope);
-        return hipGetLastError();
+        if (d->Co == 1) VPX_LAUNCH(conv_many_to_few_kernel<1>, grid, dim3(256), 0, s, x, w, bias, y, npix, d->Ci, d->leaky_slope);
+        else VPX_LAUNCH(conv_many_to_few_kernel<3>, grid, dim3(256), 0, s, x, w, bias, y, npix, d->Ci, d->leaky_slope);
+        return vpx_hip_last_error();
     }
     const int tr = kind == 3;
     if (d->Co == 16) {   // one thread per pixel
         const dim3 g16((unsigned)((npix + 255) / 256));
-        if (kind == 1 && d->Ci == 1) hipLaunchKernelGGL((conv_few_to_16_kernel<1, 3>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 1, d->leaky_slope, 0);
-        else if (kind == 1) hipLaunchKernelGGL((conv_few_to_16_kernel<3, 3>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 1, d->leaky_slope, 0);
-        else if (d->Ci == 1) hipLaunchKernelGGL((conv_few_to_16_kernel<1, 1>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 0, d->leaky_slope, tr);
-        else hipLaunchKernelGGL((conv_few_to_16_kernel<3, 1>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 0, d->leaky_slope, tr);
-        return hipGetLastError();
+        if (kind == 1 && d->Ci == 1) VPX_LAUNCH((conv_few_to_16_kernel<1, 3>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 1, d->leaky_slope, 0);
+        else if (kind == 1) VPX_LAUNCH((conv_few_to_16_kernel<3, 3>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 1, d->leaky_slope, 0);
+        else if (d->Ci == 1) VPX_LAUNCH((conv_few_to_16_kernel<1, 1>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 0, d->leaky_slope, tr);
+        else VPX_LAUNCH((conv_few_to_16_kernel<3, 1>), g16, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, 0, d->leaky_slope, tr);
+        return vpx_hip_last_error();
     }
     const long long threads = npix * (d->Co / 4);
     const dim3 grid((unsigned)((threads + 255) / 256));
-    if (kind == 1 && d->Ci == 1) hipLaunchKernelGGL((conv_few_to_many_kernel<1, 3>), grid, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, d->Co, 1, d->leaky_slope, 0);
-    else if (kind == 1) hipLaunchKernelGGL((conv_few_to_many_kernel<3, 3>), grid, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, d->Co, 1, d->leaky_slope, 0);
-    else if (d->Ci == 1) hipLaunchKernelGGL((conv_few_to_many_kernel<1, 1>), grid, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, d->Co, 0, d->leaky_slope, tr);
-    else hipLaunchKernelGGL((conv_few_to_many_kernel<3, 1>), grid, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, d->Co, 0, d->leaky_slope, tr);
-    return hipGetLastError();
+    if (kind == 1 && d->Ci == 1) VPX_LAUNCH((conv_few_to_many_kernel<1, 3>), grid, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, d->Co, 1, d->leaky_slope, 0);
+    else if (kind == 1) VPX_LAUNCH((conv_few_to_many_kernel<3, 3>), grid, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, d->Co, 1, d->leaky_slope, 0);
+    else if (d->Ci == 1) VPX_LAUNCH((conv_few_to_many_kernel<1, 1>), grid, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, d->Co, 0, d->leaky_slope, tr);
+    else VPX_LAUNCH((conv_few_to_many_kernel<3, 1>), grid, dim3(256), 0, s, x, w, bias, y, y_sp, npix, d->H, d->W, d->Co, 0, d->leaky_slope, tr);
+    return vpx_hip_last_error();
 }
 
 }  // namespace vpx

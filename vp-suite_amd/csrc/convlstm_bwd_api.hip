@@ -32,8 +32,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
     const int B = d->B, T = d->T, Cin = d->Cin, Ch = d->Ch, H = d->H, Wd = d->W;
     const int N4 = 4 * Ch, Ct = Cin + Ch;
     const size_t HW = (size_t)H * Wd;
-    Carver ws{(char*)workspace, 0, workspace_bytes};
-    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    Carver ws(workspace, workspace_bytes);
     float* wpk = ws.take(packed_weight_bytes(L.d_tiles_full, L.d_chunks, 4, d->precision, L.d_qpc) / sizeof(float));
     float* dG_all = ws.take((size_t)T * L.n_state * 4);
     float* dh_buf = ws.take(L.n_state);
@@ -66,6 +65,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         h0sp_w = (char*)ws.take(L.n_state);
     }
 
+    VPX_CHECK_CARVE(ws, "vpx_convlstm_seq_bwd");
     // ---- layout adaptation ----
     const float *xn = x, *h0n = h0, *c0n = c0, *outn = out, *doutn = dout, *dhTn = dhT, *dcTn = dcT;
     const float *wci = Wci, *wcf = Wcf, *wco = Wco;
@@ -79,6 +79,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         for (auto& p : st) p = ws.take(L.n_state);
         float* pp[6];
         for (auto& p : pp) p = ws.take(L.n_peep);
+        VPX_CHECK_CARVE(ws, "vpx_convlstm_seq_bwd");
         if (x) { VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B * T, Cin, H, Wd, stream)); xn = bx; }
         VPX_CHECK_HIP(launch_nchw_to_nhwc(out, bout, B * T, Ch, H, Wd, stream)); outn = bout;
         if (dout) { VPX_CHECK_HIP(launch_nchw_to_nhwc(dout, bdout, B * T, Ch, H, Wd, stream)); doutn = bdout; }
@@ -105,11 +106,11 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
 
     const bool peep_sliced = dpeep && gb_slices > 1;
     if (peep_sliced) {
-        for (auto pp_ : peep_part) VPX_CHECK_HIP(hipMemsetAsync(pp_, 0, (size_t)gb_slices * L.n_peep * sizeof(float), stream));
+        for (auto pp_ : peep_part) VPX_CHECK_HIP(vpx_memset_async(pp_, 0, (size_t)gb_slices * L.n_peep * sizeof(float), stream));
     } else if (dpeep) {
-        VPX_CHECK_HIP(hipMemsetAsync(dwci, 0, L.n_peep * sizeof(float), stream));
-        VPX_CHECK_HIP(hipMemsetAsync(dwcf, 0, L.n_peep * sizeof(float), stream));
-        VPX_CHECK_HIP(hipMemsetAsync(dwco, 0, L.n_peep * sizeof(float), stream));
+        VPX_CHECK_HIP(vpx_memset_async(dwci, 0, L.n_peep * sizeof(float), stream));
+        VPX_CHECK_HIP(vpx_memset_async(dwcf, 0, L.n_peep * sizeof(float), stream));
+        VPX_CHECK_HIP(vpx_memset_async(dwco, 0, L.n_peep * sizeof(float), stream));
     }
 
     // ---- data-gradient weights: contraction over the 4Ch gate rows, outputs over [x | h] (or only h) columns ----
@@ -227,7 +228,7 @@ extern "C" int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, 
         }
         wa.slabs = slabs;
         // every launched tile stores all of its slab elements; only the skipped x columns need a clear
-        if (!xn) VPX_CHECK_HIP(hipMemsetAsync(slabs, 0, L.slab_floats * sizeof(float), stream));
+        if (!xn) VPX_CHECK_HIP(vpx_memset_async(slabs, 0, L.slab_floats * sizeof(float), stream));
         wa.g_sp = (c2d || wsp) ? dG_sp_all : nullptr;
         int ns_used = L.n_slices, tail_col0 = Ct, tail_slices = L.n_slices;
         if (L.n_slices2 > 0 && wgrad2_applicable(wa)) VPX_CHECK_HIP(launch_wgrad2(wa, L.n_slices2, &ns_used, &tail_col0, &tail_slices, stream));

@@ -717,13 +717,13 @@ hipError_t launch_convq_t(const ConvQPlan& P, const ConvQEpi& epi, hipStream_t s
     constexpr int LDS = 2 * 4 * convq_ppos(HALO, NW) * 16 + (NW == 8 ? 3 : 2) * CQ_WCHUNK;   // 128 | 80 KiB (3x3 halo)
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convq_kernel<NTS, PHASE, HALO, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&convq_kernel<NTS, PHASE, HALO, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = !g_dry_run;
     }
     const long long per_xcd = ((long long)P.grid_m * P.n_tiles + 7) / 8;
-    hipLaunchKernelGGL((convq_kernel<NTS, PHASE, HALO, NW>), dim3((unsigned)(per_xcd * 8)), dim3(64 * NW), LDS, s, P, epi);
-    return hipGetLastError();
+    VPX_LAUNCH((convq_kernel<NTS, PHASE, HALO, NW>), dim3((unsigned)(per_xcd * 8)), dim3(64 * NW), LDS, s, P, epi);
+    return vpx_hip_last_error();
 }
 template <int NTS, bool PHASE>
 hipError_t launch_convq_h2(const ConvQPlan& P, const ConvQEpi& epi, int nw, hipStream_t s) {
@@ -744,10 +744,11 @@ int convq_run(const ConvQProblem& pr, const ConvQEpiArgs& ea_in, char* wpk, bool
     if (rc != VPX_OK) return rc;
     if (!weights_packed) {
         const long long total = (long long)b.pk.n_tiles * b.pk.nchunk_total * (CQ_WCHUNK / 2);
+        if (!ws_write_ok(wpk, (size_t)total * 2, "weight pack (convq_pack_kernel)")) { set_error("%s", ws_violation()); return VPX_ERR_WORKSPACE; }
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(convq_pack_kernel, dim3(blocks), dim3(256), 0, s, b.pk, wpk);
-        VPX_CHECK_HIP(hipGetLastError());
+        VPX_LAUNCH(convq_pack_kernel, dim3(blocks), dim3(256), 0, s, b.pk, wpk);
+        VPX_CHECK_HIP(vpx_hip_last_error());
     }
     b.P.wpk = wpk;
     { static int dbg = -1; if (dbg < 0) dbg = dev_switch("VPX_CQ_DBG", 0); b.P.dbg = dbg; }
@@ -1372,10 +1373,11 @@ int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip,
         for (int i = 0; i < 3; ++i) { pk.r_n[i] = j.r_n[i]; if (i < j.nrange) pk.rg[i] = rg[i]; }
         pk.S8 = j.S8; pk.Q = j.Q; pk.Co = (gates && gate_major) ? j.Co / gates : j.Co; pk.n_tiles = j.n_tiles;
         const long long total = (long long)j.n_tiles * j.Q * NT * 1024;
+        if (!ws_write_ok(j.wpk, (size_t)total * 2, "weight pack (c5_pack_kernel)")) { set_error("%s", ws_violation()); return VPX_ERR_WORKSPACE; }
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(c5_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, const_cast<char*>(j.wpk));
-        VPX_CHECK_HIP(hipGetLastError());
+        VPX_LAUNCH(c5_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, const_cast<char*>(j.wpk));
+        VPX_CHECK_HIP(vpx_hip_last_error());
     }
     return VPX_OK;
 }
@@ -1409,13 +1411,13 @@ template <int NT, int KS>
 static hipError_t launch_c5_t(const C5Plan& P, unsigned grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&c5_kernel<NT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, C5Geom<NT, KS>::LDS);
+        hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&c5_kernel<NT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, C5Geom<NT, KS>::LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = !g_dry_run;
     }
     constexpr int lds = C5Geom<NT, KS>::LDS;
-    hipLaunchKernelGGL((c5_kernel<NT, KS>), dim3(grid), dim3(256), lds, s, P);
-    return hipGetLastError();
+    VPX_LAUNCH((c5_kernel<NT, KS>), dim3(grid), dim3(256), lds, s, P);
+    return vpx_hip_last_error();
 }
 
 #ifdef VPX_DEV_SWITCHES

@@ -57,14 +57,14 @@ __global__ void ln_apply_kernel(const float* __restrict__ x, const float* __rest
 
 hipError_t launch_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* xhat,
                                 float* stats, double* partial, int B, long long n, hipStream_t s) {
-    hipLaunchKernelGGL(ln_partial_kernel, dim3(B, LN_CHUNKS), dim3(256), 0, s, x, n, stats, 0, partial);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, s, partial, n, 0, stats, B);
-    hipLaunchKernelGGL(ln_partial_kernel, dim3(B, LN_CHUNKS), dim3(256), 0, s, x, n, stats, 1, partial);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, s, partial, n, 1, stats, B);
+    VPX_LAUNCH(ln_partial_kernel, dim3(B, LN_CHUNKS), dim3(256), 0, s, x, n, stats, 0, partial);
+    VPX_LAUNCH(ln_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, s, partial, n, 0, stats, B);
+    VPX_LAUNCH(ln_partial_kernel, dim3(B, LN_CHUNKS), dim3(256), 0, s, x, n, stats, 1, partial);
+    VPX_LAUNCH(ln_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, s, partial, n, 1, stats, B);
     const long long tot = n * B;
-    hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, stats, gamma, beta, y,
+    VPX_LAUNCH(ln_apply_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, stats, gamma, beta, y,
                        xhat, n, B);
-    return hipGetLastError();
+    return vpx_hip_last_error();
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------
@@ -150,11 +150,11 @@ hipError_t launch_layernorm_bwd(const float* dy, int ldy, int Cb, const int* blk
     for (int i = 0; i < 8; ++i) a.blk[i] = blk ? blk[i] : i;
     a.xhat = xhat; a.stats = stats; a.gamma = gamma; a.B = B; a.HW = HW; a.C = C;
     a.partial = partial; a.sums = sums; a.du = du; a.dgamma = dgamma; a.dbeta = dbeta;
-    hipLaunchKernelGGL(ln_bwd_partial_kernel, dim3(B, LN_CHUNKS), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, s, a);
+    VPX_LAUNCH(ln_bwd_partial_kernel, dim3(B, LN_CHUNKS), dim3(256), 0, s, a);
+    VPX_LAUNCH(ln_bwd_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, s, a);
     const long long n = (long long)HW * C;
-    hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
-    return hipGetLastError();
+    VPX_LAUNCH(ln_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return vpx_hip_last_error();
 }
 
 // ---- pointwise gate stages of the LayerNorm ST-LSTM (predrnn.py:61-81 on already-normalised conv outputs) -------------
@@ -205,14 +205,14 @@ __global__ void st_ln_out_kernel(const float* __restrict__ o_pre, const float* _
 
 hipError_t launch_st_ln_gates(const STLNGateArgs& a, hipStream_t s) {
     const long long n = a.npix * a.Ch;
-    hipLaunchKernelGGL(st_ln_gates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
-    return hipGetLastError();
+    VPX_LAUNCH(st_ln_gates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return vpx_hip_last_error();
 }
 hipError_t launch_st_ln_out(const float* o_pre, const float* oc, const float* lc, float* h_new, float* o_save,
                             float* tl_save, long long n, hipStream_t s) {
-    hipLaunchKernelGGL(st_ln_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, o_pre, oc, lc, h_new, o_save,
+    VPX_LAUNCH(st_ln_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, o_pre, oc, lc, h_new, o_save,
                        tl_save, n);
-    return hipGetLastError();
+    return vpx_hip_last_error();
 }
 
 }  // namespace vpx

@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void convlstm_gate_bwd_kernel(const GateBwdArg
 
 hipError_t launch_gate_bwd(const GateBwdArgs& a, hipStream_t s) {
     const bool one_owner = a.dwci != nullptr && a.peep_slice_stride == 0;
-    hipLaunchKernelGGL(convlstm_gate_bwd_kernel, dim3(gate_bwd_blocks(a.HW, a.Ch), gate_bwd_slices(a.HW, a.Ch, a.B, one_owner)), dim3(256), 0, s, a);
-    return hipGetLastError();
+    VPX_LAUNCH(convlstm_gate_bwd_kernel, dim3(gate_bwd_blocks(a.HW, a.Ch), gate_bwd_slices(a.HW, a.Ch, a.B, one_owner)), dim3(256), 0, s, a);
+    return vpx_hip_last_error();
 }
 
 __global__ __launch_bounds__(256) void peep_reduce_kernel(const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ p2,
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void peep_reduce_kernel(const float* __restric
 
 hipError_t launch_peep_reduce(const float* p0, const float* p1, const float* p2, float* d0, float* d1, float* d2, int slices, long long n,
                               hipStream_t s) {
-    hipLaunchKernelGGL(peep_reduce_kernel, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, s, p0, p1, p2, d0, d1, d2, slices, n);
-    return hipGetLastError();
+    VPX_LAUNCH(peep_reduce_kernel, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, s, p0, p1, p2, d0, d1, d2, slices, n);
+    return vpx_hip_last_error();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -208,10 +208,12 @@ hipError_t launch_colsum(const float* m, const float* y, float slope, float* sca
     const long long rpb = (rows + blocks - 1) / blocks;
     blocks = (int)((rows + rpb - 1) / rpb);
     const bool v4 = (cols & 3) == 0 && (((uintptr_t)m | (uintptr_t)y | (uintptr_t)scaled | (uintptr_t)partial_ws) & 15) == 0;
-    if (v4) hipLaunchKernelGGL(colsum_l1_kernel<4>, dim3(blocks), dim3(256), 0, s, m, y, slope, scaled, out ? partial_ws : nullptr, rows, cols, rpb);
-    else hipLaunchKernelGGL(colsum_l1_kernel<1>, dim3(blocks), dim3(256), 0, s, m, y, slope, scaled, out ? partial_ws : nullptr, rows, cols, rpb);
-    if (out) hipLaunchKernelGGL(colsum_l2_kernel, dim3((cols + 15) / 16), dim3(256), 0, s, partial_ws, out, blocks, cols);
-    return hipGetLastError();
+    if (out && !ws_write_ok(partial_ws, (size_t)blocks * cols * sizeof(float), "column-sum partials (colsum_l1_kernel)")) return hipErrorInvalidValue;
+    if (scaled && !ws_write_ok(scaled, (size_t)rows * cols * sizeof(float), "scaled gradient (colsum_l1_kernel)")) return hipErrorInvalidValue;
+    if (v4) VPX_LAUNCH(colsum_l1_kernel<4>, dim3(blocks), dim3(256), 0, s, m, y, slope, scaled, out ? partial_ws : nullptr, rows, cols, rpb);
+    else VPX_LAUNCH(colsum_l1_kernel<1>, dim3(blocks), dim3(256), 0, s, m, y, slope, scaled, out ? partial_ws : nullptr, rows, cols, rpb);
+    if (out) VPX_LAUNCH(colsum_l2_kernel, dim3((cols + 15) / 16), dim3(256), 0, s, partial_ws, out, blocks, cols);
+    return vpx_hip_last_error();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -282,13 +284,14 @@ hipError_t launch_wgrad_small(const float* dy, const float* x, int N, int H, int
     int blocks = WGRAD_SMALL_BLOCKS;
     if ((npix + 255) / 256 < blocks) blocks = (int)((npix + 255) / 256);
     const int cols = Co * C * k * k;
-    if (k == 3 && C == 1) hipLaunchKernelGGL((wgrad_small_kernel<16, 1, 3>), dim3(blocks, Co / 16), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
-    else if (k == 3 && C == 3) hipLaunchKernelGGL((wgrad_small_kernel<4, 3, 3>), dim3(blocks, Co / 4), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
-    else if (k == 1 && Co == 1) hipLaunchKernelGGL((wgrad_small_kernel<1, 16, 1>), dim3(blocks, 1), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
-    else if (k == 1 && Co == 3) hipLaunchKernelGGL((wgrad_small_kernel<3, 16, 1>), dim3(blocks, 1), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
+    if (!ws_write_ok(partial_ws, (size_t)blocks * cols * sizeof(float), "weight-gradient partials (wgrad_small_kernel)")) return hipErrorInvalidValue;
+    if (k == 3 && C == 1) VPX_LAUNCH((wgrad_small_kernel<16, 1, 3>), dim3(blocks, Co / 16), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
+    else if (k == 3 && C == 3) VPX_LAUNCH((wgrad_small_kernel<4, 3, 3>), dim3(blocks, Co / 4), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
+    else if (k == 1 && Co == 1) VPX_LAUNCH((wgrad_small_kernel<1, 16, 1>), dim3(blocks, 1), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
+    else if (k == 1 && Co == 3) VPX_LAUNCH((wgrad_small_kernel<3, 16, 1>), dim3(blocks, 1), dim3(256), 0, s, dy, x, N, H, W, Co, pad, partial_ws);
     else return hipErrorInvalidValue;
-    hipLaunchKernelGGL(colsum_l2_kernel, dim3((cols + 15) / 16), dim3(256), 0, s, partial_ws, dw, blocks, cols);
-    return hipGetLastError();
+    VPX_LAUNCH(colsum_l2_kernel, dim3((cols + 15) / 16), dim3(256), 0, s, partial_ws, dw, blocks, cols);
+    return vpx_hip_last_error();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1106,10 +1109,10 @@ template <int NTAPS>
 static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int tap_base, int groups, size_t lds, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NTAPS>),
+        hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&wgrad_kernel<NTAPS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = !g_dry_run;
     }
     auto xcd_grid = [&](WgradArgs& w, int gx) {  // see wg_block
         w.grid_x = gx; w.grid_slices = n_slices;
@@ -1125,10 +1128,10 @@ static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int ta
         // activation vectors per thread and item: halo positions * 16 / 256 (3x3: 12, 5x5: 15, 7x7: 20)
         const int npos = (TILE_H + a.kh - 1) * (TILE_W + a.kw - 1);
         auto go = [&](auto kern, dim3 g, int nth, size_t lds_bytes) -> hipError_t {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, g, dim3(nth), lds_bytes, s, a, tap_base);
-            return hipGetLastError();
+            VPX_LAUNCH(kern, g, dim3(nth), lds_bytes, s, a, tap_base);
+            return vpx_hip_last_error();
         };
         {   // 16-byte vector loads throughout: aligned bases, channel counts and strides in multiples of 4 floats
             auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -1181,14 +1184,16 @@ static hipError_t launch_wgrad_group(const WgradArgs& a_in, int n_slices, int ta
         }
         return go(&wgrad_bf16x3_kernel<NTAPS, 0, 0, 1>, grid, NTHREADS, lds);
     } else {
-        hipLaunchKernelGGL(wgrad_kernel<NTAPS>, grid, dim3(NTHREADS), lds, s, a, tap_base);
+        VPX_LAUNCH(wgrad_kernel<NTAPS>, grid, dim3(NTHREADS), lds, s, a, tap_base);
     }
-    return hipGetLastError();
+    return vpx_hip_last_error();
 }
 
 hipError_t launch_wgrad(const WgradArgs& a, int n_slices, hipStream_t s) {
     constexpr int MAXT = 9;  // taps per workgroup: 9 accumulator tiles per wave
     const int taps = a.kh * a.kw;
+    if (!ws_write_ok(a.slabs, (size_t)n_slices * taps * (a.n_out ? a.n_out : a.N4) * a.Ct * sizeof(float), "weight-gradient slabs (wgrad_kernel)"))
+        return hipErrorInvalidValue;
     const int full = taps / MAXT, rem = taps % MAXT;
     const int npos = (TILE_H + a.kh - 1) * (TILE_W + a.kw - 1);
     const size_t lds = 128 * 64 * 4 + (size_t)npos * 64 * 4;
@@ -1242,17 +1247,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __re
 
 hipError_t launch_wgrad_reduce(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, hipStream_t s) {
     const long long total = (long long)N4 * Ct * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
+    VPX_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
                        taps, N4, Ct, TapMap{}, Ct, n_slices);
-    return hipGetLastError();
+    return vpx_hip_last_error();
 }
 
 hipError_t launch_wgrad_reduce_tail(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int tail_col0, int tail_slices,
                                     hipStream_t s) {
     const long long total = (long long)N4 * Ct * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
+    VPX_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
                        taps, N4, Ct, TapMap{}, tail_col0, tail_slices);
-    return hipGetLastError();
+    return vpx_hip_last_error();
 }
 
 hipError_t launch_wgrad_reduce_map(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int real_taps,
@@ -1262,9 +1267,9 @@ hipError_t launch_wgrad_reduce_map(const float* slabs, float* dW, int n_slices, 
     tm.real_taps = real_taps;
     for (int i = 0; i < taps; ++i) tm.map[i] = tapmap[i];
     const long long total = (long long)N4 * Ct * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
+    VPX_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, dW, n_slices,
                        taps, N4, Ct, tm, Ct, n_slices);
-    return hipGetLastError();
+    return vpx_hip_last_error();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1415,23 +1420,23 @@ static bool st_vec8_ok(int Ch, int ldG, const void* p0, const void* p1) {
 hipError_t launch_st_bwd_out(const STBwdOutArgs& a, hipStream_t s) {
     if (a.split || st_vec8_ok(a.Ch, a.ldG, a.dG7, a.dlc_off >= 0 ? (const void*)a.dG7 : (const void*)a.dlc)) {
         const long long n8 = a.n / 8;
-        if (a.split) hipLaunchKernelGGL(st_bwd_out8_kernel<true>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(st_bwd_out8_kernel<false>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
-        return hipGetLastError();
+        if (a.split) VPX_LAUNCH(st_bwd_out8_kernel<true>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
+        else VPX_LAUNCH(st_bwd_out8_kernel<false>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
+        return vpx_hip_last_error();
     }
-    hipLaunchKernelGGL(st_bwd_out_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
-    return hipGetLastError();
+    VPX_LAUNCH(st_bwd_out_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
+    return vpx_hip_last_error();
 }
 hipError_t launch_st_bwd_gates(const STBwdGateArgs& a, hipStream_t s) {
     if (a.split || st_vec8_ok(a.Ch, a.ldG, a.dG7, a.dm)) {
         const long long n8 = a.npix * (a.Ch >> 3);
-        if (a.split) hipLaunchKernelGGL(st_bwd_gates8_kernel<true>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(st_bwd_gates8_kernel<false>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
-        return hipGetLastError();
+        if (a.split) VPX_LAUNCH(st_bwd_gates8_kernel<true>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
+        else VPX_LAUNCH(st_bwd_gates8_kernel<false>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, a);
+        return vpx_hip_last_error();
     }
     const long long n = a.npix * a.Ch;
-    hipLaunchKernelGGL(st_bwd_gates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
-    return hipGetLastError();
+    VPX_LAUNCH(st_bwd_gates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return vpx_hip_last_error();
 }
 
 }  // namespace vpx

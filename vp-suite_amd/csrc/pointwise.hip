@@ -24,10 +24,10 @@ static hipError_t launch_transpose(const float* src, float* dst, int N, int R, i
     for (int n0 = 0; n0 < N; n0 += 65535) {
         const int nn = (N - n0 < 65535) ? (N - n0) : 65535;
         dim3 grid((C + 31) / 32, (R + 31) / 32, nn);
-        hipLaunchKernelGGL(transpose_rc_kernel, grid, dim3(32, 8), 0, s, src + (size_t)n0 * R * C,
+        VPX_LAUNCH(transpose_rc_kernel, grid, dim3(32, 8), 0, s, src + (size_t)n0 * R * C,
                            dst + (size_t)n0 * R * C, R, C);
     }
-    return hipGetLastError();
+    return vpx_hip_last_error();
 }
 
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s) {
@@ -132,23 +132,23 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 }
 
 hipError_t launch_decouple_stats(const float* yc, const float* ym, float* stats, int B, int HW, int Ch, hipStream_t s) {
-    hipLaunchKernelGGL(decouple_stats_kernel, dim3(B, (Ch + 31) / 32), dim3(1024), 0, s, yc, ym, stats, B, HW, Ch);
-    return hipGetLastError();
+    VPX_LAUNCH(decouple_stats_kernel, dim3(B, (Ch + 31) / 32), dim3(1024), 0, s, yc, ym, stats, B, HW, Ch);
+    return vpx_hip_last_error();
 }
 hipError_t launch_decouple_mean(const float* stats, float* value, int n, hipStream_t s) {
-    hipLaunchKernelGGL(decouple_mean_kernel, dim3(1), dim3(256), 0, s, stats, value, n);
-    return hipGetLastError();
+    VPX_LAUNCH(decouple_mean_kernel, dim3(1), dim3(256), 0, s, stats, value, n);
+    return vpx_hip_last_error();
 }
 hipError_t launch_decouple_bwd_pointwise(const float* yc, const float* ym, const float* stats, const float* dvalue,
                                          float* dyc, float* dym, int B, int HW, int Ch, hipStream_t s) {
     const long long n = (long long)B * HW * Ch;
-    hipLaunchKernelGGL(decouple_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, yc, ym, stats,
+    VPX_LAUNCH(decouple_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, yc, ym, stats,
                        dvalue, dyc, dym, B, HW, Ch);
-    return hipGetLastError();
+    return vpx_hip_last_error();
 }
 hipError_t launch_axpy(float* y, const float* x, long long n, hipStream_t s) {
-    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, x, n);
-    return hipGetLastError();
+    VPX_LAUNCH(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, x, n);
+    return vpx_hip_last_error();
 }
 
 // ---- ConvLSTM gate / state update on pre-activations (K-split step on small maps) ---------------------------------
@@ -188,8 +188,8 @@ hipError_t launch_convlstm_pointwise(const ConvLSTMStepArgs& ea, const float* pr
                                      long long pre_bstride) {
     const long long n = (long long)B * HW * ea.Ch;
     if (pre_bstride <= 0) pre_bstride = HW * 4 * ea.Ch;
-    hipLaunchKernelGGL(convlstm_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ea, pre, pre_bstride, B, HW);
-    return hipGetLastError();
+    VPX_LAUNCH(convlstm_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ea, pre, pre_bstride, B, HW);
+    return vpx_hip_last_error();
 }
 
 }  // namespace vpx

@@ -104,17 +104,17 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(float* __restrict__ o
 
 hipError_t launch_st_gates_ks(const STGatesKSArgs& a, hipStream_t s) {
     const long long n = a.npix * (a.Ch >> 3);
-    hipLaunchKernelGGL(st_gates_ks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
-    return hipGetLastError();
+    VPX_LAUNCH(st_gates_ks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return vpx_hip_last_error();
 }
 hipError_t launch_st_out_ks(const STOutKSArgs& a, hipStream_t s) {
     const long long n = a.n / 8;
-    hipLaunchKernelGGL(st_out_ks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
-    return hipGetLastError();
+    VPX_LAUNCH(st_out_ks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return vpx_hip_last_error();
 }
 hipError_t launch_sum_partials(float* out, const float* part, long long pstride, int ks, long long n, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, out, part, pstride, ks, n, accumulate);
-    return hipGetLastError();
+    VPX_LAUNCH(sum_partials_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, out, part, pstride, ks, n, accumulate);
+    return vpx_hip_last_error();
 }
 
 }  // namespace vpx

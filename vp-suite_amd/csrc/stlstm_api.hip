@@ -209,8 +209,29 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
     }
     const int B = d->B, Cin = d->Cin, Ch = d->Ch, H = d->H, Wd = d->W, k = d->k;
     const size_t HW = (size_t)H * Wd;
-    Carver ws{(char*)workspace, 0, workspace_bytes};
-    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    if (d->layer_norm) {  // unfused LayerNorm path (stlstm_ln_api.hip); same layout adaptation around it
+        if (!ln) { set_error("vpx_stlstm_step_fwd: layer_norm set but ln is NULL"); return VPX_ERR_ARG; }
+        Carver w2(workspace, workspace_bytes);
+        const float *xn = x, *hn = h, *cn = c, *mn = m;
+        float *outs[5] = {h_new, c_new, m_new, delta_c, delta_m}, *outn[5] = {h_new, c_new, m_new, delta_c, delta_m};
+        if (d->layout == VPX_LAYOUT_NCHW) {
+            float* bx = w2.take(L.n_x);
+            float* st[8];
+            for (auto& p : st) p = w2.take(L.n_state);
+            VPX_CHECK_CARVE(w2, "vpx_stlstm_step_fwd (LayerNorm, NCHW)");
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B, Cin, H, Wd, stream)); xn = bx;
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(h, st[0], B, Ch, H, Wd, stream)); hn = st[0];
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(c, st[1], B, Ch, H, Wd, stream)); cn = st[1];
+            VPX_CHECK_HIP(launch_nchw_to_nhwc(m, st[2], B, Ch, H, Wd, stream)); mn = st[2];
+            for (int i = 0; i < 5; ++i) outn[i] = st[3 + i];
+        }
+        rc = stlstm_ln_fwd(d, xn, hn, cn, mn, Wx, Wh, Wm, Wo, Wlast, ln, outn[0], outn[1], outn[2], outn[3], outn[4], reserve, w2, stream);
+        if (rc != VPX_OK) return rc;
+        if (d->layout == VPX_LAYOUT_NCHW)
+            for (int i = 0; i < 5; ++i) VPX_CHECK_HIP(launch_nhwc_to_nchw(outn[i], outs[i], B, Ch, H, Wd, stream));
+        return VPX_OK;
+    }
+    Carver ws(workspace, workspace_bytes);
     float* wpk_c = ws.take(L.wpk_c);
     float* wpk_m = ws.take(L.wpk_m);
     float* wpk_o = ws.take(L.wpk_o);
@@ -233,34 +254,14 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         part_g = ws.take((size_t)L.ks_g * 7 * L.n_state); part_o = ws.take((size_t)L.ks_o * L.n_state);
     }
 
-    if (d->layer_norm) {  // unfused LayerNorm path (stlstm_ln_api.hip); same layout adaptation around it
-        if (!ln) { set_error("vpx_stlstm_step_fwd: layer_norm set but ln is NULL"); return VPX_ERR_ARG; }
-        Carver w2{(char*)workspace, 0, workspace_bytes};
-        w2.off = (256 - ((uintptr_t)workspace & 255)) & 255;
-        const float *xn = x, *hn = h, *cn = c, *mn = m;
-        float *outs[5] = {h_new, c_new, m_new, delta_c, delta_m}, *outn[5] = {h_new, c_new, m_new, delta_c, delta_m};
-        if (d->layout == VPX_LAYOUT_NCHW) {
-            float* bx = w2.take(L.n_x);
-            float* st[8];
-            for (auto& p : st) p = w2.take(L.n_state);
-            VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B, Cin, H, Wd, stream)); xn = bx;
-            VPX_CHECK_HIP(launch_nchw_to_nhwc(h, st[0], B, Ch, H, Wd, stream)); hn = st[0];
-            VPX_CHECK_HIP(launch_nchw_to_nhwc(c, st[1], B, Ch, H, Wd, stream)); cn = st[1];
-            VPX_CHECK_HIP(launch_nchw_to_nhwc(m, st[2], B, Ch, H, Wd, stream)); mn = st[2];
-            for (int i = 0; i < 5; ++i) outn[i] = st[3 + i];
-        }
-        rc = stlstm_ln_fwd(d, xn, hn, cn, mn, Wx, Wh, Wm, Wo, Wlast, ln, outn[0], outn[1], outn[2], outn[3], outn[4], reserve, w2, stream);
-        if (rc != VPX_OK) return rc;
-        if (d->layout == VPX_LAYOUT_NCHW)
-            for (int i = 0; i < 5; ++i) VPX_CHECK_HIP(launch_nhwc_to_nchw(outn[i], outs[i], B, Ch, H, Wd, stream));
-        return VPX_OK;
-    }
+    VPX_CHECK_CARVE(ws, "vpx_stlstm_step_fwd");
     const float *xn = x, *hn = h, *cn = c, *mn = m;
     float *hO = h_new, *cO = c_new, *mO = m_new, *dcO = delta_c, *dmO = delta_m;
     if (d->layout == VPX_LAYOUT_NCHW) {
         float* bx = ws.take(L.n_x);
         float* st[8];
         for (auto& p : st) p = ws.take(L.n_state);
+        VPX_CHECK_CARVE(ws, "vpx_stlstm_step_fwd");
         VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B, Cin, H, Wd, stream)); xn = bx;
         VPX_CHECK_HIP(launch_nchw_to_nhwc(h, st[0], B, Ch, H, Wd, stream)); hn = st[0];
         VPX_CHECK_HIP(launch_nchw_to_nhwc(c, st[1], B, Ch, H, Wd, stream)); cn = st[1];
@@ -448,7 +449,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         PlainEpiArgs ea{};
         ea.Co = Ch; ea.split = Ch; ea.out0 = lc; ea.bstride0 = (long long)(HW * Ch); ea.ld0 = Ch; ea.ng = L.ng_l;
         P.ksplit = L.ksplit_l;
-        if (P.ksplit > 1) VPX_CHECK_HIP(hipMemsetAsync(lc, 0, L.n_state * sizeof(float), stream));
+        if (P.ksplit > 1) VPX_CHECK_HIP(vpx_memset_async(lc, 0, L.n_state * sizeof(float), stream));
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.tiles128, stream));
     }
     // ---- launch 4: conv_o(mem) + output gate ----

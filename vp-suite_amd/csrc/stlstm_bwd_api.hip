@@ -176,8 +176,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     vpx_stlstm_desc d2;
     if (d->layer_norm) {
         if (!ln) { set_error("vpx_stlstm_step_bwd: layer_norm set but ln is NULL"); return VPX_ERR_ARG; }
-        Carver w2{(char*)workspace, 0, workspace_bytes};
-        w2.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+        Carver w2(workspace, workspace_bytes);
         if (d->layout == VPX_LAYOUT_NHWC)
             return stlstm_ln_bwd(d, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, ln, reserve, dh_new, dc_new, dm_new, ddelta_c, ddelta_m,
                                  dx, dh, dc, dm, dWx, dWh, dWm, dWo, dWlast, dln, w2, stream);
@@ -189,6 +188,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         float* bdx = w2.take(n_x);
         float* st[12];
         for (auto& p : st) p = w2.take(n_s);
+        VPX_CHECK_CARVE(w2, "vpx_stlstm_step_bwd (LayerNorm, NCHW)");
         const float* in_nchw[9] = {h, c, m, dh_new, dc_new, dm_new, ddelta_c, ddelta_m, nullptr};
         const float* in_nhwc[9] = {};
         VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B, Cin, H, Wd, stream));
@@ -210,8 +210,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     // requested data gradients left behind — its five transposed weight packs are reused (PredRNN: 57 cell steps per
     // training step share four cells' weights)
     const bool packed = (d->flags & VPX_FLAG_WEIGHTS_PACKED) != 0;
-    Carver ws{(char*)workspace, 0, workspace_bytes};
-    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    Carver ws(workspace, workspace_bytes);
     float* dG7 = ws.take(L.n_g7);
     float* dlc = ws.take(L.n_state);
     float* dcn_conv = ws.take(L.n_state);
@@ -235,6 +234,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         if (L.c5_part[i]) c5p[i] = ws.take(L.c5_part[i]);
     }
 
+    VPX_CHECK_CARVE(ws, "vpx_stlstm_step_bwd");
     const float *xn = x, *hn = h, *cn = c, *mn = m, *cnn = c_new, *mnn = m_new;
     const float *g_h = dh_new, *g_c = dc_new, *g_m = dm_new, *g_dc = ddelta_c, *g_dm = ddelta_m;
     float *dxn = dx, *dhn = dh, *dcn = dc, *dmn = dm;
@@ -243,6 +243,7 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
         float* bdx = ws.take(L.n_x);
         float* st[14];
         for (auto& p : st) p = ws.take(L.n_state);
+        VPX_CHECK_CARVE(ws, "vpx_stlstm_step_bwd");
         VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B, Cin, H, Wd, stream)); xn = bx;
         const float* ins[10] = {h, c, m, c_new, m_new, dh_new, dc_new, dm_new, ddelta_c, ddelta_m};
         const float** outs[10] = {&hn, &cn, &mn, &cnn, &mnn, &g_h, &g_c, &g_m, &g_dc, &g_dm};
@@ -281,8 +282,8 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
     auto split_plan = [&](ConvPlan& P, const STBwdLayout::DG& g, float* o0, float* o1, size_t n, bool accumulate) -> hipError_t {
         P.ksplit = g.ksplit;
         if (g.ksplit > 1 && !accumulate) {
-            hipError_t e = hipMemsetAsync(o0, 0, n * sizeof(float), stream);
-            if (e == hipSuccess && o1) e = hipMemsetAsync(o1, 0, n * sizeof(float), stream);
+            hipError_t e = vpx_memset_async(o0, 0, n * sizeof(float), stream);
+            if (e == hipSuccess && o1) e = vpx_memset_async(o1, 0, n * sizeof(float), stream);
             return e;
         }
         return hipSuccess;

@@ -110,6 +110,7 @@ int stlstm_ln_fwd(const vpx_stlstm_desc* d, const float* x, const float* h, cons
     float* oc = ws.take(s.n_state);
     float* lc = ws.take(s.n_state);
     float* mem_ws = ws.take(2 * s.n_state);
+    VPX_CHECK_CARVE(ws, "vpx_stlstm_step_fwd (LayerNorm)");
     float* mem = save ? R.mem : mem_ws;
     const long long n1 = (long long)s.HW * Ch;
     // conv_x / conv_h / conv_m, each followed by its own LayerNorm (predrnn.py:58-60 with :24-36)
@@ -163,6 +164,7 @@ int stlstm_ln_bwd(const vpx_stlstm_desc* d, const float* x, const float* h, cons
     float* dlnp[8];
     const int mult[4] = {7, 4, 3, 1};
     for (int i = 0; i < 8; ++i) dlnp[i] = ws.take(s.HW * mult[i / 2] * Ch);
+    VPX_CHECK_CARVE(ws, "vpx_stlstm_step_bwd (LayerNorm)");
     float* dm_out = dm ? dm : dm_scratch;
 
     // A: through h_new = o * tanh(lc): d(o pre-activation) -> dG7 block 3, d conv_last
@@ -176,8 +178,8 @@ int stlstm_ln_bwd(const vpx_stlstm_desc* d, const float* x, const float* h, cons
     if ((rc = plain_conv(stream, prec, g, du_o, Ch, Ch, Wo, (long long)2 * Ch * k * k, k * k, k, k, 2 * Ch, true, nullptr, dmem, 2 * Ch, false, wpk))) return rc;
     if ((rc = plain_conv(stream, prec, g, dlc, Ch, Ch, Wlast, (long long)2 * Ch, 1, 1, 1, 2 * Ch, true, nullptr, dmem, 2 * Ch, true, wpk))) return rc;
     // split dmem [B,HW,2Ch] into the two state gradients the gate stage expects
-    VPX_CHECK_HIP(hipMemcpy2DAsync(dcn, (size_t)Ch * 4, dmem, (size_t)2 * Ch * 4, (size_t)Ch * 4, (size_t)B * HW, hipMemcpyDeviceToDevice, stream));
-    VPX_CHECK_HIP(hipMemcpy2DAsync(dmn, (size_t)Ch * 4, dmem + Ch, (size_t)2 * Ch * 4, (size_t)Ch * 4, (size_t)B * HW, hipMemcpyDeviceToDevice, stream));
+    VPX_CHECK_HIP(vpx_memcpy2d_async(dcn, (size_t)Ch * 4, dmem, (size_t)2 * Ch * 4, (size_t)Ch * 4, (size_t)B * HW, hipMemcpyDeviceToDevice, stream));
+    VPX_CHECK_HIP(vpx_memcpy2d_async(dmn, (size_t)Ch * 4, dmem + Ch, (size_t)2 * Ch * 4, (size_t)Ch * 4, (size_t)B * HW, hipMemcpyDeviceToDevice, stream));
     // C: gate groups -> dG7 blocks (i,f,g | o | i',f',g') w.r.t. the SUMS of normalised conv outputs
     {
         STBwdGateArgs a{};

@@ -124,11 +124,11 @@ int vpx_mse_loss(const float* pred, const float* target, long long n_elements, l
     long long blocks = (n_elements + MSE_THREADS * 4 - 1) / (MSE_THREADS * 4);
     if (blocks > MSE_MAX_BLOCKS) blocks = MSE_MAX_BLOCKS;
     const double mult = (double)scale / (double)n_frames;
-    hipLaunchKernelGGL(mse_partial_kernel, dim3((unsigned)blocks), dim3(MSE_THREADS), 0, stream, pred, target, n_elements,
+    VPX_LAUNCH(mse_partial_kernel, dim3((unsigned)blocks), dim3(MSE_THREADS), 0, stream, pred, target, n_elements,
                        (float)(2.0 * mult), dpred, partial);
-    VPX_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, stream, partial, (int)blocks, mult, loss);
-    VPX_CHECK_HIP(hipGetLastError());
+    VPX_CHECK_HIP(vpx_hip_last_error());
+    VPX_LAUNCH(mse_final_kernel, dim3(1), dim3(64), 0, stream, partial, (int)blocks, mult, loss);
+    VPX_CHECK_HIP(vpx_hip_last_error());
     return VPX_OK;
 }
 
@@ -144,8 +144,8 @@ int vpx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                (float)weight_decay, (float)grad_scale};
     long long blocks = (n + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
-    VPX_CHECK_HIP(hipGetLastError());
+    VPX_LAUNCH(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    VPX_CHECK_HIP(vpx_hip_last_error());
     return VPX_OK;
 }
 

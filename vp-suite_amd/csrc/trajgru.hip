@@ -214,8 +214,8 @@ int vpx_trajgru_warp_fwd(const float* h, const float* flows, float* warped, int 
     if (rc != VPX_OK) return rc;
     if (!h || !flows || !warped) { set_error("vpx_trajgru_warp_fwd: NULL tensor argument"); return VPX_ERR_ARG; }
     const long long total = (long long)B * H * W * L * (C / 4);
-    hipLaunchKernelGGL(trajgru_warp_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, h, flows, warped);
-    VPX_CHECK_HIP(hipGetLastError());
+    VPX_LAUNCH(trajgru_warp_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, h, flows, warped);
+    VPX_CHECK_HIP(vpx_hip_last_error());
     return VPX_OK;
 }
 
@@ -230,9 +230,9 @@ int vpx_trajgru_warp_bwd(const float* h, const float* flows, const float* dwarpe
         return VPX_ERR_UNSUPPORTED;
     }
     const long long total = (long long)B * H * W * L;
-    hipLaunchKernelGGL(trajgru_warp_bwd_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, h, flows,
+    VPX_LAUNCH(trajgru_warp_bwd_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, h, flows,
                        dwarped, dh, dflows, (long long*)nullptr);
-    VPX_CHECK_HIP(hipGetLastError());
+    VPX_CHECK_HIP(vpx_hip_last_error());
     return VPX_OK;
 }
 
@@ -254,13 +254,13 @@ int vpx_trajgru_warp_bwd_det(const float* h, const float* flows, const float* dw
     hipStream_t stream = (hipStream_t)stream_;
     long long* acc = dh ? reinterpret_cast<long long*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255) : nullptr;
     const long long n = (long long)B * H * W * C, total = (long long)B * H * W * L;
-    if (acc) VPX_CHECK_HIP(hipMemsetAsync(acc, 0, (size_t)n * sizeof(long long), stream));
-    hipLaunchKernelGGL(trajgru_warp_bwd_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, g, h, flows, dwarped, dh,
+    if (acc) VPX_CHECK_HIP(vpx_memset_async(acc, 0, (size_t)n * sizeof(long long), stream));
+    VPX_LAUNCH(trajgru_warp_bwd_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, g, h, flows, dwarped, dh,
                        dflows, acc);
-    VPX_CHECK_HIP(hipGetLastError());
+    VPX_CHECK_HIP(vpx_hip_last_error());
     if (acc) {
-        hipLaunchKernelGGL(trajgru_fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc, dh, n);
-        VPX_CHECK_HIP(hipGetLastError());
+        VPX_LAUNCH(trajgru_fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc, dh, n);
+        VPX_CHECK_HIP(vpx_hip_last_error());
     }
     return VPX_OK;
 }
@@ -269,8 +269,8 @@ int vpx_trajgru_gates_fwd(const float* i2h, long long i2h_bstride, const float* 
                           int B, int HW, int C, int act, float slope, void* stream) {
     if (B < 1 || HW < 1 || C < 1 || !h2h || !prev || !next || (act != 0 && act != 1)) { set_error("vpx_trajgru_gates_fwd: bad argument"); return VPX_ERR_ARG; }
     GruArgs a{(long long)B * HW * C, HW * C, C, act, slope, i2h, i2h_bstride, h2h, prev, next, save};
-    hipLaunchKernelGGL(trajgru_gates_fwd_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-    VPX_CHECK_HIP(hipGetLastError());
+    VPX_LAUNCH(trajgru_gates_fwd_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    VPX_CHECK_HIP(vpx_hip_last_error());
     return VPX_OK;
 }
 
@@ -281,8 +281,8 @@ int vpx_trajgru_gates_bwd(const float* dnext, const float* h2h, const float* pre
         return VPX_ERR_ARG;
     }
     GruBwdArgs a{(long long)B * HW * C, HW * C, C, act, slope, dnext, h2h, prev, save, di2h, di2h_bstride, dh2h, dprev};
-    hipLaunchKernelGGL(trajgru_gates_bwd_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
-    VPX_CHECK_HIP(hipGetLastError());
+    VPX_LAUNCH(trajgru_gates_bwd_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    VPX_CHECK_HIP(vpx_hip_last_error());
     return VPX_OK;
 }
 

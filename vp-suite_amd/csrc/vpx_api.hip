@@ -17,6 +17,37 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- workspace accounting (vpx_internal.h) ----
+static thread_local Carver* g_carver = nullptr;
+static thread_local char g_ws_violation[256] = "";
+
+Carver::Carver(void* workspace, size_t bytes)
+    : base((char*)workspace), off((256 - ((uintptr_t)workspace & 255)) & 255), cap(bytes), nslot(0), over(false), prev(g_carver) {
+    if (off > cap) over = true;
+    g_carver = this;
+    g_ws_violation[0] = 0;
+}
+Carver::~Carver() { g_carver = prev; }
+
+const char* ws_violation() { return g_ws_violation; }
+
+bool ws_write_ok(const void* dst_, size_t bytes, const char* what) {
+    const char* dst = (const char*)dst_;
+    for (const Carver* c = g_carver; c; c = c->prev) {
+        if (dst < c->base || dst >= c->base + c->cap) continue;   // not in this call's workspace: the caller's own tensor
+        const char* end = c->base + c->cap;
+        size_t room = (size_t)(end - dst);
+        for (int i = 0; i < c->nslot; ++i)
+            if (dst >= c->slot[i].p && dst < c->slot[i].p + c->slot[i].n) { room = (size_t)(c->slot[i].p + c->slot[i].n - dst); break; }
+        if (bytes <= room) return true;
+        snprintf(g_ws_violation, sizeof(g_ws_violation), "%s: %zu bytes do not fit the %zu bytes carved for them (workspace sizing rule and launch disagree)",
+                 what, bytes, room);
+        return false;
+    }
+    return true;
+}
+
+int g_dry_run = 0;
 int g_deterministic = 0;
 int g_cell3_mode = -1;
 int g_cell2_mode = -1;
@@ -53,6 +84,11 @@ int vpx_set_option(int option, int value) {
     if (option == VPX_OPT_MFMA_SHAPE) {
         const int prev = mfma_shape();
         vpx::g_mfma_shape = value ? 1 : 0;
+        return prev;
+    }
+    if (option == VPX_OPT_DRY_RUN) {
+        const int prev = vpx::g_dry_run;
+        vpx::g_dry_run = value ? 1 : 0;
         return prev;
     }
     if (option == VPX_OPT_CELL3) {
@@ -245,8 +281,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
     }
     const int B = d->B, T = d->T, Cin = d->Cin, Ch = d->Ch, H = d->H, Wd = d->W;
     const size_t HW = (size_t)H * Wd;
-    Carver ws{(char*)workspace, 0, workspace_bytes};
-    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    Carver ws(workspace, workspace_bytes);
     float* wpk = ws.take(convlstm_wpk_bytes(d, L) / sizeof(float));
     float* c_scratch = ws.take(L.n_state);
     float* pre_scratch = L.split ? ws.take(4 * L.n_state) : nullptr;
@@ -289,6 +324,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         }
     }
 
+    VPX_CHECK_CARVE(ws, "vpx_convlstm_seq_fwd");
     // ---- layout adaptation (reference NCHW -> native NHWC) ----
     const float *xn = x, *h0n = h0, *c0n = c0, *wci = Wci, *wcf = Wcf, *wco = Wco;
     float *outn = out, *hTn = hT, *cTn = cT;
@@ -302,6 +338,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         float* p0 = ws.take(L.n_peep);
         float* p1 = ws.take(L.n_peep);
         float* p2 = ws.take(L.n_peep);
+        VPX_CHECK_CARVE(ws, "vpx_convlstm_seq_fwd");
         if (x) { VPX_CHECK_HIP(launch_nchw_to_nhwc(x, bx, B * T, Cin, H, Wd, stream)); xn = bx; }
         if (h0) { VPX_CHECK_HIP(launch_nchw_to_nhwc(h0, bh0, B, Ch, H, Wd, stream)); h0n = bh0; }
         if (c0) { VPX_CHECK_HIP(launch_nchw_to_nhwc(c0, bc0, B, Ch, H, Wd, stream)); c0n = bc0; }
@@ -576,7 +613,7 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
         } else if (L.split) {
             // pre-activations of all four gates by a K-split plain convolution (atomic partial sums), then the gates
             float* pre = ea.gates ? ea.gates : pre_scratch;  // with SAVE_FOR_BWD the reserve slot doubles as scratch
-            VPX_CHECK_HIP(hipMemsetAsync(pre, 0, 4 * L.n_state * sizeof(float), stream));
+            VPX_CHECK_HIP(vpx_memset_async(pre, 0, 4 * L.n_state * sizeof(float), stream));
             PlainEpiArgs pa{};
             pa.Co = 4 * Ch; pa.split = 4 * Ch; pa.ng = L.s_ng;
             pa.out0 = pre; pa.bstride0 = (long long)(HW * 4 * Ch); pa.ld0 = 4 * Ch;
@@ -591,9 +628,9 @@ int vpx_convlstm_seq_fwd(const vpx_convlstm_desc* d, const float* x, const float
 
     // ---- final states ----
     if (cTn && save)
-        VPX_CHECK_HIP(hipMemcpyAsync(cTn, cs_all + (size_t)(T - 1) * L.n_state, L.n_state * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        VPX_CHECK_HIP(vpx_memcpy_async(cTn, cs_all + (size_t)(T - 1) * L.n_state, L.n_state * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (hTn && !out_split)
-        VPX_CHECK_HIP(hipMemcpy2DAsync(hTn, HW * Ch * sizeof(float), outn + (size_t)(T - 1) * HW * Ch,
+        VPX_CHECK_HIP(vpx_memcpy2d_async(hTn, HW * Ch * sizeof(float), outn + (size_t)(T - 1) * HW * Ch,
                                        (size_t)T * HW * Ch * sizeof(float), HW * Ch * sizeof(float), B,
                                        hipMemcpyDeviceToDevice, stream));
     if (d->layout == VPX_LAYOUT_NCHW) {
@@ -610,14 +647,16 @@ size_t vpx_conv2d_workspace_bytes(int Ci, int Co, int kh, int kw) {
     ConvStage st[MAX_STAGE];
     int chunks = 0;
     const int segC[1] = {Ci};
-    // sized for the larger of the two operand modes
-    size_t best = 0;
+    // one query serves vpx_conv2d_nhwc_fwd (stage size of the 4-group tile) and vpx_conv2d_nhwc_fwd_ex (plain_conv: stage size of
+    // the tiling it picks) in every operand mode: the larger of the two packs. (Round 4 sized only the first — the 5x5 layers
+    // with <= 32 outputs of the TrajGRU flow generator then packed 4 % more than the workspace held.)
+    size_t best = plain_conv_wpk_floats(Ci, Co, kh, kw) * 4;
     for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16; ++prec) {
         if (build_stages(st, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, 4, prec), prec) < 0) return 0;
-        const size_t b = align256(packed_weight_bytes(plain_tiles(Co), chunks, plain_groups(Co), prec));
+        const size_t b = packed_weight_bytes(plain_tiles(Co), chunks, plain_groups(Co), prec);
         if (b > best) best = b;
     }
-    return best + 256;
+    return align256(best) + 256;
 }
 
 int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Ci,
@@ -638,9 +677,9 @@ int vpx_conv2d_nhwc_fwd(const float* x, const float* w, const float* bias, float
         set_error("vpx_conv2d_nhwc_fwd: workspace too small");
         return VPX_ERR_WORKSPACE;
     }
-    Carver ws{(char*)workspace, 0, workspace_bytes};
-    ws.off = (256 - ((uintptr_t)workspace & 255)) & 255;
+    Carver ws(workspace, workspace_bytes);
     float* wpk = ws.take(packed_weight_bytes(n_tiles, chunks, plain_groups(Co), precision) / sizeof(float));
+    VPX_CHECK_CARVE(ws, "vpx_conv2d_nhwc_fwd");
     PackDesc pd{};
     pd.seg[0] = PackSeg{w, (long long)Ci * kh * kw, kh * kw, 0, Ci};
     memcpy(pd.stage, P.stage, sizeof(ConvStage) * P.nstage);

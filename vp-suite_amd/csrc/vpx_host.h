@@ -7,22 +7,17 @@
 
 namespace vpx {
 
-static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-struct Carver {  // bump allocator over the caller's workspace
-    char* base;
-    size_t off, cap;
-    float* take(size_t nfloat) {
-        float* p = reinterpret_cast<float*>(base + off);
-        off += align256(nfloat * sizeof(float));
-        return p;
-    }
-};
+// (Carver — the bump allocator over the caller's workspace — lives in vpx_internal.h: the launchers check their writes against it)
 
 #define VPX_CHECK_HIP(expr)                                                                   \
     do {                                                                                      \
         hipError_t e__ = (expr);                                                              \
         if (e__ != hipSuccess) {                                                              \
+            if (ws_violation()[0]) {   /* a launcher refused to write past its workspace slot */ \
+                set_error("%s (%s:%d)", ws_violation(), __FILE__, __LINE__);                   \
+                return VPX_ERR_WORKSPACE;                                                     \
+            }                                                                                 \
             set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
             return VPX_ERR_LAUNCH;                                                            \
         }                                                                                     \
@@ -312,15 +307,28 @@ static inline int plain_conv(hipStream_t stream, int prec, ConvGeo g, const floa
     // small maps: split K over workgroups (atomic partial sums) — needs a dense or already-initialised destination
     P.ksplit = leaky != 0.0f ? 1 : pick_ksplit(m_tiles * pd.n_tiles, P.nstage);   // partial sums cannot be activated
     if (P.ksplit > 1 && !accumulate) {
-        if (out_ld == Co) VPX_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)g.N * g.H * g.W * Co * sizeof(float), stream));
+        if (out_ld == Co) VPX_CHECK_HIP(vpx_memset_async(out, 0, (size_t)g.N * g.H * g.W * Co * sizeof(float), stream));
         else P.ksplit = 1;
     }
     VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, pd.n_tiles, stream));
     return VPX_OK;
 }
 
+// floats of the weight pack plain_conv() writes for this problem (the launch's own rule: N tiling from plain_groups, stage size from
+// that tiling) — what a caller that knows the geometry carves
+static inline size_t plain_conv_pack_floats(int prec, ConvGeo g, int C, int kh, int kw, int Co) {
+    const long long m_tiles = (long long)g.N * ((g.H + TILE_H - 1) / TILE_H) * ((g.W + TILE_W - 1) / TILE_W);
+    const int ng = plain_groups(Co, m_tiles);
+    ConvStage st[MAX_STAGE];
+    int chunks = 0;
+    const int segC[1] = {C};
+    if (build_stages(st, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, ng, prec), prec) < 0) return 0;
+    return packed_weight_bytes(plain_tiles_ng(Co, ng), chunks, ng, prec) / 4;
+}
+
 static inline size_t plain_conv_wpk_floats(int C, int Co, int kh, int kw) {
-    // upper bound over operand modes, N tilings (ng = 1..4) and the stage sizes they select
+    // upper bound over operand modes and over EVERY N tiling (ng = 1..4, each with the stage size and the tile count it selects):
+    // holds whatever plain_groups() picks for the launch's geometry
     size_t best = 0;
     ConvStage st[MAX_STAGE];
     for (int prec = VPX_PREC_F32; prec <= VPX_PREC_BF16; ++prec)
@@ -328,7 +336,7 @@ static inline size_t plain_conv_wpk_floats(int C, int Co, int kh, int kw) {
             int chunks = 0;
             const int segC[1] = {C};
             if (build_stages(st, &chunks, segC, 1, kh * kw, pick_stage_channels(segC, 1, kh, kw, ng, prec), prec) < 0) return 0;
-            const size_t b = packed_weight_bytes(1, chunks, plain_rows_bound(Co) / 32, prec) / 4;
+            const size_t b = packed_weight_bytes(plain_tiles_ng(Co, ng), chunks, ng, prec) / 4;
             if (b > best) best = b;
         }
     return best;

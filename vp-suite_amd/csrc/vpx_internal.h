@@ -88,6 +88,68 @@ struct PackDesc {
 };
 
 void set_error(const char* fmt, ...);
+
+// ---- dry run (vpx_set_option(VPX_OPT_DRY_RUN, 1)) -----------------------------------------------------------------
+// Every entry point does ALL of its host-side work — argument checks, plans, workspace carving, the ws_write_ok() checks of
+// the launchers — and skips the HIP runtime calls themselves. Needs no GPU: the CPU test-suite sweeps the models' layer
+// shapes through every entry point this way (tests/test_workspace_contract.py), so a sizing rule that drifts from a launch
+// fails in the container, not as memory corruption on the GPU box. Every HIP runtime call of the library goes through the
+// wrappers below. A process that has run dry must not launch for real afterwards (function attributes were not set).
+extern int g_dry_run;
+#define VPX_LAUNCH(...) do { if (!::vpx::g_dry_run) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+static inline hipError_t vpx_hip_last_error() { return g_dry_run ? hipSuccess : hipGetLastError(); }
+static inline hipError_t vpx_func_attr(const void* f, hipFuncAttribute a, int v) { return g_dry_run ? hipSuccess : hipFuncSetAttribute(f, a, v); }
+static inline hipError_t vpx_memset_async(void* p, int v, size_t n, hipStream_t s) { return g_dry_run ? hipSuccess : hipMemsetAsync(p, v, n, s); }
+static inline hipError_t vpx_memcpy_async(void* d, const void* s_, size_t n, hipMemcpyKind k, hipStream_t s) { return g_dry_run ? hipSuccess : hipMemcpyAsync(d, s_, n, k, s); }
+static inline hipError_t vpx_memcpy2d_async(void* d, size_t dp, const void* s_, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t s) {
+    return g_dry_run ? hipSuccess : hipMemcpy2DAsync(d, dp, s_, sp, w, h, k, s);
+}
+
+// ---- workspace accounting ---------------------------------------------------------------------------------------
+// Every extern "C" entry that is handed a workspace carves it with ONE Carver, which registers itself for the duration of the
+// call (thread-local). The launchers that write derived data of a computed size (weight packs, K-slice slabs, operand
+// conversions, partial sums) ask ws_write_ok() first: a write that starts inside a carved slot must end inside it, a write
+// that starts elsewhere in the workspace must end before the workspace does. A size rule that drifted between a
+// `*_workspace_bytes` query and the launch code is then an error return (VPX_ERR_WORKSPACE), never a write into memory the
+// caller did not hand over (round 4's intermittent abort: the 5x5 convolutions of the TrajGRU flow generator packed
+// 26 weight chunks per 32 channels into a workspace sized for 25).
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+struct Carver {  // bump allocator over the caller's workspace
+    struct Slot { const char* p; size_t n; };
+    static constexpr int MAX_SLOTS = 64;
+    char* base;
+    size_t off, cap;
+    Slot slot[MAX_SLOTS];
+    int nslot;
+    bool over;       // a take() ran past `cap`: the layout needs more than the caller gave
+    Carver* prev;
+    Carver(void* workspace, size_t bytes);   // starts at the first 256-byte boundary; registers itself (vpx_api.hip)
+    ~Carver();
+    Carver(const Carver&) = delete;
+    Carver& operator=(const Carver&) = delete;
+    float* take(size_t nfloat) {
+        const size_t n = align256(nfloat * sizeof(float));
+        float* p = reinterpret_cast<float*>(base + off);
+        if (off > cap || n > cap - off) over = true;
+        else if (nslot < MAX_SLOTS) slot[nslot++] = Slot{base + off, n};
+        off += n;
+        return p;
+    }
+    bool ok() const { return !over; }
+    size_t used() const { return off; }
+};
+// true when [dst, dst + bytes) is a legal write for the running call (see above); false + ws_violation() text otherwise
+bool ws_write_ok(const void* dst, size_t bytes, const char* what);
+const char* ws_violation();   // "" when the running call had none
+// after carving: the layout must fit what the caller handed over
+#define VPX_CHECK_CARVE(ws, who)                                                                                      \
+    do {                                                                                                              \
+        if (!(ws).ok()) {                                                                                             \
+            set_error("%s: workspace layout needs %zu bytes, the caller's workspace holds %zu", who, (ws).used(), (ws).cap); \
+            return VPX_ERR_WORKSPACE;                                                                                 \
+        }                                                                                                             \
+    } while (0)
+
 int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int prec, int qpc = 2);
 int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw = 1, int stride = 1, int qpc = 2);
 int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw = 1, int stride = 1);

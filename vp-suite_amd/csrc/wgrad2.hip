@@ -428,11 +428,11 @@ int wgrad2_target_wgs() {
 hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices, int* tail_col0, int* tail_slices, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
+        hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&wgrad2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
+        e = vpx_func_attr(reinterpret_cast<const void*>(&wgrad2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = !g_dry_run;
     }
     const int target = wgrad2_target_wgs();
     WgradArgs a = a_in;
@@ -456,9 +456,10 @@ hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices
     *tail_col0 = half_tail ? a.ct[a.n_ctiles - 1].h[0].cglobal : a.Ct;
     *tail_slices = half_tail ? a.w2_ns_half : ns;
     const long long total = (long long)nf * ns + (long long)a.w2_nh * a.w2_ns_half;
-    if (mfma_shape() == 1) hipLaunchKernelGGL(wgrad2_kernel<true>, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
-    else hipLaunchKernelGGL(wgrad2_kernel<false>, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
-    return hipGetLastError();
+    if (!ws_write_ok(a.slabs, (size_t)ns * 9 * a.N4 * a.Ct * sizeof(float), "weight-gradient slabs (wgrad2_kernel)")) return hipErrorInvalidValue;
+    if (mfma_shape() == 1) VPX_LAUNCH(wgrad2_kernel<true>, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
+    else VPX_LAUNCH(wgrad2_kernel<false>, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
+    return vpx_hip_last_error();
 }
 
 
@@ -848,17 +849,18 @@ hipError_t launch_stw(const STWArgs& a_in, const STWOut& o, hipStream_t s) {
 #endif
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W5_LDS);
+        hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&stw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W5_LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = !g_dry_run;
     }
     const long long total = (long long)(a.npairs5 * 3 + (a.npairs - a.npairs5)) * a.n_slices;
-    hipLaunchKernelGGL(stw_kernel, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W5_LDS, s, a);
-    hipError_t e = hipGetLastError();
+    if (!ws_write_ok(a.slabs, (size_t)a.n_slices * a.slab_stride * sizeof(float), "weight-gradient slabs (stw_kernel)")) return hipErrorInvalidValue;
+    VPX_LAUNCH(stw_kernel, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W5_LDS, s, a);
+    hipError_t e = vpx_hip_last_error();
     if (e != hipSuccess) return e;
     const long long n = (long long)a.npairs * (W5_BLOCK / 4);
-    hipLaunchKernelGGL(stw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, o);
-    return hipGetLastError();
+    VPX_LAUNCH(stw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, o);
+    return vpx_hip_last_error();
 }
 
 }  // namespace vpx
