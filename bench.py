@@ -275,7 +275,7 @@ def roofline(spec, ps):
                    if spec.model == "convlstm-shi" else
                    ("c5_kernel<8> + c5_kernel<2|4> + c1_kernel (ST-LSTM cell step, forward: both gate groups as the jobs of one launch on 16x16-pixel "
                     "tiles with 8-channel stages, fused gate math; conv_o + output gate; conv_last as a streaming 1x1; K-split job forms + "
-                    "pointwise stages on grids below 96 pixel tiles)" if spec.precision == "bf16x3" else
+                    "pointwise stages on grids below 48 pixel tiles)" if spec.precision == "bf16x3" else
                     f"conv_gemm_kernel<EpiSTGate/EpiSTOut/EpiPlain, {spec.precision}> (ST-LSTM cell step, forward)")),
         "note": ("achieved = algorithmic fp32 FLOPs / kernel time. bf16x3 issues 3 bf16 MFMAs per algorithmic "
                  "product: peak = 2500 TF dense bf16 / 3, i.e. frac is the share of the bf16 MFMA pipe's dense "

@@ -107,7 +107,7 @@ int vpx_set_deterministic(int on);
  *                        first-generation kernel instead of the 16x16-tile job-table kernel (c5, convq.hip); 256 the same for its forward
  *                        launches (gate groups, conv_o + output gate); 512 the 1x1 layers (conv_last, its adjoint, the decoupling
  *                        tail's adapter) on the implicit-GEMM kernel instead of the streaming one (c1, conv1.hip); 1024 the c5 launches
- *                        unsplit on grids below their 96-pixel-tile bar (tests); 2048 the first-generation launches instead of the
+ *                        unsplit on grids below their pixel-tile bar (48 tiles forward, 96 backward; tests); 2048 the first-generation launches instead of the
  *                        K-split c5 jobs on those grids; 4096 the half tile of the fused ConvLSTM step
  *                        instead of its narrow-tile form (c3: c5_kernel<4, 3>) on grids of at most 256 half-tile workgroups;
  *                        8192 c3 with 32-column tiles (c5_kernel<2, 3>) instead of 64-column ones */
@@ -152,17 +152,19 @@ int vpx_convlstm_seq_bwd(const vpx_convlstm_desc* d, const float* x, const float
 /* ---- ST-LSTM cell step (PredRNN-V2) -------------------------------------------------------------------------- */
 size_t vpx_stlstm_workspace_bytes(const vpx_stlstm_desc* d);
 size_t vpx_stlstm_reserve_bytes(const vpx_stlstm_desc* d);
-/* Split-format shadows (round 4). The bf16x3 5x5 kernels read every activation in the split operand format (above); a tensor that a
+/* Split-format shadows. The bf16x3 5x5 kernels read every activation in the split operand format (above); a tensor that a
  * previous step produced — h_new is the next step's h and the next layer's x, m_new the next layer's m — need not be converted
- * again when the caller hands its split copy back:
- *   vpx_stlstm_uses_split(d)            1 when calls with this descriptor consume / produce shadows, else 0 (they are ignored)
- *   vpx_stlstm_set_split_operands(in, out)   applies to the NEXT vpx_stlstm_step_fwd / _bwd call of THIS thread and is consumed by it.
- *       in[5]  = {x, h, m, c_new, m_new}: NULL or the tensor once more in the split format, B*H*W*C*4 bytes (forward reads the first
- *                three, backward all five; a NULL entry is converted by the library as before)
- *       out[3] = {h_new, c_new, m_new}: NULL or caller buffers of B*H*W*Ch*4 bytes the forward fills with these outputs in the split format
- *       either array may be NULL. NHWC layout only. */
+ * again when the caller hands its split copy back. The shadows are an ARGUMENT of the step call they belong to
+ * (vpx_stlstm_step_fwd_ex / _bwd_ex; round 4 passed them through a thread-local setter that a failed or skipped call could leave
+ * armed for an unrelated one — removed):
+ *   vpx_stlstm_uses_split(d)   1 when calls with this descriptor consume / produce shadows, else 0 (they are ignored)
+ *   in[5]  = {x, h, m, c_new, m_new}: NULL or the tensor once more in the split format, B*H*W*C*4 bytes (forward reads the first
+ *            three, backward all five; a NULL entry is converted by the library as before)
+ *   out[3] = {h_new, c_new, m_new}: NULL or caller buffers of B*H*W*Ch*4 bytes the forward fills with these outputs in the split
+ *            format (ignored by the backward)
+ *   NHWC layout only (ignored otherwise). `shadows` may be NULL: vpx_stlstm_step_fwd / _bwd are exactly that. */
+typedef struct vpx_stlstm_shadows { const void* in[5]; void* out[3]; } vpx_stlstm_shadows;
 int vpx_stlstm_uses_split(const vpx_stlstm_desc* d);
-int vpx_stlstm_set_split_operands(const void* const* in5, void* const* out3);
 
 /* Weights in reference layout: Wx [7Ch,Cin,k,k] Wh [4Ch,Ch,k,k] Wm [3Ch,Ch,k,k] Wo [Ch,2Ch,k,k] Wlast [Ch,2Ch,1,1].
  * ln: NULL or 8 pointers {x_gamma,x_beta,h_gamma,h_beta,m_gamma,m_beta,o_gamma,o_beta}, each in reference [C,H,W]. */
@@ -182,6 +184,20 @@ int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, const float* h
                         const float* dc_new, const float* dm_new, const float* ddelta_c, const float* ddelta_m,
                         float* dx, float* dh, float* dc, float* dm, float* dWx, float* dWh, float* dWm, float* dWo,
                         float* dWlast, float* const* dln, void* workspace, size_t workspace_bytes, void* stream);
+/* the same calls with split-format shadows (see above) */
+int vpx_stlstm_step_fwd_ex(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c, const float* m,
+                           const float* Wx, const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
+                           const float* const* ln, float* h_new, float* c_new, float* m_new, float* delta_c,
+                           float* delta_m, void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                           void* stream, const vpx_stlstm_shadows* shadows);
+int vpx_stlstm_step_bwd_ex(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c, const float* m,
+                           const float* c_new, const float* m_new,
+                           const float* Wx, const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
+                           const float* const* ln, const void* reserve, size_t reserve_bytes, const float* dh_new,
+                           const float* dc_new, const float* dm_new, const float* ddelta_c, const float* ddelta_m,
+                           float* dx, float* dh, float* dc, float* dm, float* dWx, float* dWh, float* dWm, float* dWo,
+                           float* dWlast, float* const* dln, void* workspace, size_t workspace_bytes, void* stream,
+                           const vpx_stlstm_shadows* shadows);
 
 /* ---- decoupling-loss term: mean_{b,ch} |cos(normalize(A*dc), normalize(A*dm))| over H*W ---------------------- */
 /* delta_c/delta_m [B,H,W,Ch] (NHWC) ; adapter [Ch,Ch] ; value / dvalue: 1 float on device.

@@ -147,11 +147,34 @@ def test_ef_trajgru_model_vs_golden(vpx):
             assert _relmax(p.grad, g["grad." + k]) < 2e-4, k
         else:
             assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
-    big = MODEL_CLASSES["trajgru"]("cuda", img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0],
-                                   cell_precision="bf16x3").cuda()
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f32", "bf16"])
+def test_ef_trajgru_default_size_forward(vpx, precision):
+    """Shape contract of the default 64x64 EF-TrajGRU (L = 13, `ret` with 13*96 input channels; ef_traj_gru.py:31-75) in every operand
+    mode, seeded. This is the forward that aborted GPUTEST_r04: its 5x5 flow-generator layers (h2f_conv1 64|96 -> 32, flows_conv
+    32 -> 26) packed 4-12 KB more weights than vpx_conv2d_workspace_bytes sized (tests/test_workspace_contract.py pins the sizing
+    rule on the CPU; the guard bands of tests/canary.py check the memory around every tensor of this call)."""
+    from vp_suite_amd.models import MODEL_CLASSES
+    big = MODEL_CLASSES["trajgru"]("cuda", img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0], cell_precision=precision)
+    fill_state_dict_(big, name_seed("ef_trajgru.default"))
+    big = big.cuda()
+    x = seeded_rand((2, 4, 1, 64, 64), name_seed("ef_trajgru.default.x")).cuda()
     with torch.no_grad():
-        out, _ = big(torch.rand(2, 4, 1, 64, 64, device="cuda"), pred_frames=3)
+        out, _ = big(x, pred_frames=3)
+        out2, _ = big(x, pred_frames=3)
     assert out.shape == (2, 3, 1, 64, 64) and bool(torch.isfinite(out).all())
+    torch.use_deterministic_algorithms(True)
+    try:
+        with torch.no_grad():
+            d1, _ = big(x, pred_frames=3)
+            d2, _ = big(x, pred_frames=3)
+    finally:
+        torch.use_deterministic_algorithms(False)
+    assert torch.equal(d1, d2)                       # no K-split atomics in deterministic mode: bit-reproducible
+    # (plain bf16 rounds every activation to 8 bits of mantissa: a last-bit difference in summation order can flip a rounding)
+    bound = 1e-2 if precision == "bf16" else 1e-4
+    assert _relmax(out, d1) < bound and _relmax(out2, d1) < bound
 
 
 @pytest.mark.parametrize("tag", list(gc.PRED_ACTION_CASES))

@@ -226,13 +226,13 @@ def test_stlstm_split_shadows_change_nothing(vpx, B):
     def run(pass_on):
         w = [Ws[n].clone().requires_grad_(True) for n in shapes]
         a = [t.clone().requires_grad_(True) for t in st]
-        o1 = vpx.ops.stlstm_step(*a, *w, precision="bf16x3")
+        o1 = vpx.ops.stlstm_step(*a, *w, precision="bf16x3", use_shadows=True)
         assert all(hasattr(t, "_vpx_sp") for t in o1[:3])
         x2, h2, c2, m2 = o1[0], o1[0], o1[1], o1[2]          # next layer: x = h_new; same cell next step: h, c; zig-zag memory: m_new
         if not pass_on:
             x2, h2, c2, m2 = (t * 1.0 for t in (x2, h2, c2, m2))   # new tensors: no shadow
             assert not hasattr(x2, "_vpx_sp")
-        o2 = vpx.ops.stlstm_step(x2, h2, c2, m2, *w, precision="bf16x3")
+        o2 = vpx.ops.stlstm_step(x2, h2, c2, m2, *w, precision="bf16x3", use_shadows=True)
         sum((o * g).sum() for o, g in zip(o2, gout)).backward()
         return [o.detach() for o in o2] + [t.grad for t in a + w]
     torch.use_deterministic_algorithms(True)
@@ -242,12 +242,29 @@ def test_stlstm_split_shadows_change_nothing(vpx, B):
         torch.use_deterministic_algorithms(False)
     for a, b in zip(with_sh, without):
         assert torch.equal(a, b)
-    # in-place writes invalidate a shadow
+    # what ends a shadow's life: an in-place write (version counter), a consumer with another channel count, a new epoch (the next
+    # model forward), an explicit invalidate — the answer to writes the version counter cannot see (`.data`, raw-pointer kernels)
+    Wl = [Ws[n] for n in shapes]
     with torch.no_grad():
-        o = vpx.ops.stlstm_step(*st, *[Ws[n] for n in shapes], precision="bf16x3")
-        assert vpx.ops._shadow_of(o[0], o[0]) is not None
+        o = vpx.ops.stlstm_step(*st, *Wl, precision="bf16x3", use_shadows=True)
+        assert vpx.ops._shadow_of(o[0], o[0], Ch) is not None
+        assert vpx.ops._shadow_of(o[0], o[0], Ch // 2) is None
         o[0].mul_(2.0)
-        assert vpx.ops._shadow_of(o[0], o[0]) is None
+        assert vpx.ops._shadow_of(o[0], o[0], Ch) is None
+        assert vpx.ops._shadow_of(o[2], o[2], Ch) is not None
+        vpx.ops.new_shadow_epoch()
+        assert vpx.ops._shadow_of(o[2], o[2], Ch) is None
+        # a write through .data: invisible to the version counter — after invalidate_shadow the step reads the tensor itself
+        o = vpx.ops.stlstm_step(*st, *Wl, precision="bf16x3", use_shadows=True)
+        o[0].data.mul_(0.5)
+        vpx.ops.invalidate_shadow(o[0])
+        got = vpx.ops.stlstm_step(o[0], o[0], o[1], o[2], *Wl, precision="bf16x3", use_shadows=True)
+        want = vpx.ops.stlstm_step(*(t.clone() for t in (o[0], o[0], o[1], o[2])), *Wl, precision="bf16x3")
+        for a, b in zip(got, want):
+            assert _relmax(a, b) < 1e-6
+        # without the opt-in (a cell driven by user code) no shadow is ever attached or read
+        o = vpx.ops.stlstm_step(*st, *Wl, precision="bf16x3")
+        assert not any(hasattr(t, "_vpx_sp") for t in o)
 
 
 def test_decouple_and_conv2d_vs_golden_and_autograd(vpx):

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "vpx_convlstm_workspace_bytes", "vpx_convlstm_reserve_bytes", "vpx_convlstm_takes_split_input", "vpx_convlstm_writes_split_output", "vpx_convlstm_seq_fwd",
     "vpx_convlstm_seq_bwd",
     "vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes", "vpx_stlstm_step_fwd", "vpx_stlstm_step_bwd",
-    "vpx_stlstm_uses_split", "vpx_stlstm_set_split_operands",
+    "vpx_stlstm_uses_split", "vpx_stlstm_step_fwd_ex", "vpx_stlstm_step_bwd_ex",
     "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
     "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_conv2d_bwd_workspace_bytes", "vpx_conv2d_nhwc_bwd",
     "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd", "vpx_conv2d_ex_fwd_split",
@@ -59,6 +59,11 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "W", "Ci", "Co", "kh", "kw", "stride", "pad", "transposed")] + \
                [("leaky_slope", ctypes.c_float), ("precision", ctypes.c_int32), ("out_pad_h", ctypes.c_int32),
                 ("out_pad_w", ctypes.c_int32)]
+
+
+class STLSTMShadows(ctypes.Structure):
+    """vpx_stlstm_shadows: split-format copies of (x, h, m, c_new, m_new) handed in, buffers for (h_new, c_new, m_new) handed out."""
+    _fields_ = [("inp", ctypes.c_void_p * 5), ("out", ctypes.c_void_p * 3)]
 
 
 class VpxError(RuntimeError):
@@ -112,12 +117,14 @@ def lib():
         L.vpx_convlstm_seq_bwd.argtypes = [ctypes.POINTER(ConvLSTMDesc)] + [vp] * 8 + [vp, sz] + [vp] * 11 + [vp, sz, vp]
         L.vpx_stlstm_uses_split.restype = ctypes.c_int
         L.vpx_stlstm_uses_split.argtypes = [ctypes.POINTER(STLSTMDesc)]
-        L.vpx_stlstm_set_split_operands.restype = ctypes.c_int
-        L.vpx_stlstm_set_split_operands.argtypes = [vp, vp]
         L.vpx_stlstm_step_fwd.restype = ctypes.c_int
         L.vpx_stlstm_step_fwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 9 + [vp] + [vp] * 5 + [vp, sz, vp, sz, vp]
         L.vpx_stlstm_step_bwd.restype = ctypes.c_int
         L.vpx_stlstm_step_bwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 11 + [vp] + [vp, sz] + [vp] * 5 + [vp] * 9 + [vp] + [vp, sz, vp]
+        L.vpx_stlstm_step_fwd_ex.restype = ctypes.c_int
+        L.vpx_stlstm_step_fwd_ex.argtypes = L.vpx_stlstm_step_fwd.argtypes + [ctypes.POINTER(STLSTMShadows)]
+        L.vpx_stlstm_step_bwd_ex.restype = ctypes.c_int
+        L.vpx_stlstm_step_bwd_ex.argtypes = L.vpx_stlstm_step_bwd.argtypes + [ctypes.POINTER(STLSTMShadows)]
         L.vpx_decouple_workspace_bytes.restype = sz
         L.vpx_decouple_workspace_bytes.argtypes = [ctypes.c_int] * 4
         L.vpx_decouple_fwd.restype = ctypes.c_int

@@ -139,8 +139,14 @@ ConvPlan base_plan(const vpx_stlstm_desc* d, int k) {
 }  // namespace
 
 namespace vpx {
-thread_local STSplitShadows g_st_shadows = {};
-STSplitShadows take_st_shadows() { STSplitShadows s = g_st_shadows; g_st_shadows = STSplitShadows{}; return s; }
+STSplitShadows st_shadows_of(const vpx_stlstm_shadows* p) {
+    STSplitShadows s{};
+    if (!p) return s;
+    for (int i = 0; i < 5; ++i) s.in[i] = reinterpret_cast<const char*>(p->in[i]);
+    for (int i = 0; i < 3; ++i) s.out[i] = reinterpret_cast<char*>(p->out[i]);
+    s.set = 1;
+    return s;
+}
 }  // namespace vpx
 
 extern "C" {
@@ -148,14 +154,6 @@ extern "C" {
 int vpx_stlstm_uses_split(const vpx_stlstm_desc* d) {
     if (check_st_desc(d) != VPX_OK || d->layout != VPX_LAYOUT_NHWC) return 0;
     return (c5_fwd_applicable(d) || c5k_fwd_applicable(d)) ? 1 : 0;
-}
-int vpx_stlstm_set_split_operands(const void* const* in5, void* const* out3) {
-    STSplitShadows s{};
-    if (in5) for (int i = 0; i < 5; ++i) s.in[i] = reinterpret_cast<const char*>(in5[i]);
-    if (out3) for (int i = 0; i < 3; ++i) s.out[i] = reinterpret_cast<char*>(out3[i]);
-    s.set = 1;
-    g_st_shadows = s;
-    return VPX_OK;
 }
 
 size_t vpx_stlstm_reserve_bytes(const vpx_stlstm_desc* d) {
@@ -190,7 +188,16 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
                         const float* const* ln, float* h_new, float* c_new, float* m_new, float* delta_c,
                         float* delta_m, void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
                         void* stream_) {
-    STSplitShadows sh = take_st_shadows();   // (consumed by this call whatever happens next)
+    return vpx_stlstm_step_fwd_ex(d, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, ln, h_new, c_new, m_new, delta_c, delta_m, reserve, reserve_bytes,
+                                  workspace, workspace_bytes, stream_, nullptr);
+}
+
+int vpx_stlstm_step_fwd_ex(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c, const float* m,
+                           const float* Wx, const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
+                           const float* const* ln, float* h_new, float* c_new, float* m_new, float* delta_c,
+                           float* delta_m, void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes,
+                           void* stream_, const vpx_stlstm_shadows* shadows) {
+    STSplitShadows sh = st_shadows_of(shadows);   // an argument of THIS call: nothing survives it, nothing precedes it
     int rc = check_st_desc(d);
     if (rc != VPX_OK) return rc;
     if (d->layout != VPX_LAYOUT_NHWC) sh = STSplitShadows{};
@@ -292,7 +299,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         cp.src[0] = C5Src{x_sp, (long long)HW * Cin * 4, Cin * 4, 0};
         cp.src[1] = C5Src{h_sp, (long long)HW * Ch * 4, Ch * 4, 0};
         cp.src[2] = C5Src{m_sp, (long long)HW * Ch * 4, Ch * 4, 0};
-        const long long sx = (long long)Cin * L.taps, sh = (long long)Ch * L.taps;
+        const long long ws_x = (long long)Cin * L.taps, ws_h = (long long)Ch * L.taps;   // weight strides of one output channel
         for (int grp = 0; grp < 2; ++grp) {   // 0: c group (i,f,g,o_pre) from [x | h]; 1: m group (i',f',g') from [x | m]
             C5Job& j = cp.job[cp.njobs++];
             j = C5Job{};
@@ -306,9 +313,9 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
             j.e_sp = grp ? mn_sp : cn_sp;
             C5PackRange pr[2];
             // x rows: (i,f,g,o) = blocks 0,1,2,6 of Wx, (i',f',g') = blocks 3,4,5 (predrnn.py:61); recurrent rows: blocks 0.. of Wh / Wm (:62-63)
-            if (grp == 0) pr[0] = C5PackRange{Wx, sx, (long long)L.taps, 0, {0, Ch, 2 * Ch, 6 * Ch}};
-            else pr[0] = C5PackRange{Wx, sx, (long long)L.taps, 0, {3 * Ch, 4 * Ch, 5 * Ch, 0}};
-            pr[1] = C5PackRange{grp ? Wm : Wh, sh, (long long)L.taps, 0, {0, Ch, 2 * Ch, 3 * Ch}};
+            if (grp == 0) pr[0] = C5PackRange{Wx, ws_x, (long long)L.taps, 0, {0, Ch, 2 * Ch, 6 * Ch}};
+            else pr[0] = C5PackRange{Wx, ws_x, (long long)L.taps, 0, {3 * Ch, 4 * Ch, 5 * Ch, 0}};
+            pr[1] = C5PackRange{grp ? Wm : Wh, ws_h, (long long)L.taps, 0, {0, Ch, 2 * Ch, 3 * Ch}};
             if ((rc = c5_prepare_job(j, 8, pr, grp ? 3 : 4, 0, packed, stream))) return rc;
         }
         VPX_CHECK_HIP(launch_c5(cp, 8, stream));
@@ -335,7 +342,7 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
         cp.src[0] = C5Src{x_sp, (long long)HW * Cin * 4, Cin * 4, 0};
         cp.src[1] = C5Src{h_sp, (long long)HW * Ch * 4, Ch * 4, 0};
         cp.src[2] = C5Src{m_sp, (long long)HW * Ch * 4, Ch * 4, 0};
-        const long long sx = (long long)Cin * L.taps, sh = (long long)Ch * L.taps;
+        const long long ws_x = (long long)Cin * L.taps, ws_h = (long long)Ch * L.taps;   // weight strides of one output channel
         for (int grp = 0; grp < 2; ++grp) {
             C5Job full{};
             full.nrange = 2;
@@ -344,9 +351,9 @@ int vpx_stlstm_step_fwd(const vpx_stlstm_desc* d, const float* x, const float* h
             full.epi = 0; full.Co = (grp ? 3 : 4) * Ch; full.ld = 7 * Ch; full.accumulate = 0;
             full.out_bstride = (long long)HW * 7 * Ch;
             C5PackRange prf[2];
-            if (grp == 0) prf[0] = C5PackRange{Wx, sx, (long long)L.taps, 0, {0, Ch, 2 * Ch, 6 * Ch}};
-            else prf[0] = C5PackRange{Wx, sx, (long long)L.taps, 0, {3 * Ch, 4 * Ch, 5 * Ch, 0}};
-            prf[1] = C5PackRange{grp ? Wm : Wh, sh, (long long)L.taps, 0, {0, Ch, 2 * Ch, 3 * Ch}};
+            if (grp == 0) prf[0] = C5PackRange{Wx, ws_x, (long long)L.taps, 0, {0, Ch, 2 * Ch, 6 * Ch}};
+            else prf[0] = C5PackRange{Wx, ws_x, (long long)L.taps, 0, {3 * Ch, 4 * Ch, 5 * Ch, 0}};
+            prf[1] = C5PackRange{grp ? Wm : Wh, ws_h, (long long)L.taps, 0, {0, Ch, 2 * Ch, 3 * Ch}};
             for (int kk = 0; kk < L.ks_g; ++kk) {
                 C5Job& j = cp.job[cp.njobs++];
                 C5PackRange pr[3];

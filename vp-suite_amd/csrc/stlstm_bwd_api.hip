@@ -156,7 +156,19 @@ extern "C" int vpx_stlstm_step_bwd(const vpx_stlstm_desc* d, const float* x, con
                                    const float* ddelta_m, float* dx, float* dh, float* dc, float* dm, float* dWx,
                                    float* dWh, float* dWm, float* dWo, float* dWlast, float* const* dln, void* workspace,
                                    size_t workspace_bytes, void* stream_) {
-    STSplitShadows sh = take_st_shadows();   // (consumed by this call whatever happens next)
+    return vpx_stlstm_step_bwd_ex(d, x, h, c, m, c_new, m_new, Wx, Wh, Wm, Wo, Wlast, ln, reserve, reserve_bytes, dh_new, dc_new, dm_new,
+                                  ddelta_c, ddelta_m, dx, dh, dc, dm, dWx, dWh, dWm, dWo, dWlast, dln, workspace, workspace_bytes, stream_, nullptr);
+}
+
+extern "C" int vpx_stlstm_step_bwd_ex(const vpx_stlstm_desc* d, const float* x, const float* h, const float* c,
+                                      const float* m, const float* c_new, const float* m_new, const float* Wx,
+                                      const float* Wh, const float* Wm, const float* Wo, const float* Wlast,
+                                      const float* const* ln, const void* reserve, size_t reserve_bytes,
+                                      const float* dh_new, const float* dc_new, const float* dm_new, const float* ddelta_c,
+                                      const float* ddelta_m, float* dx, float* dh, float* dc, float* dm, float* dWx,
+                                      float* dWh, float* dWm, float* dWo, float* dWlast, float* const* dln, void* workspace,
+                                      size_t workspace_bytes, void* stream_, const vpx_stlstm_shadows* shadows) {
+    STSplitShadows sh = st_shadows_of(shadows);   // an argument of THIS call
     if (!d) { set_error("stlstm desc is NULL"); return VPX_ERR_ARG; }
     if (d->layout != VPX_LAYOUT_NHWC) sh = STSplitShadows{};
     if ((d->precision < VPX_PREC_F32 || d->precision > VPX_PREC_BF16)) { set_error("stlstm: precision %d not implemented", d->precision); return VPX_ERR_UNSUPPORTED; }

@@ -490,8 +490,8 @@ struct STGatesKSArgs {
     float *c_new, *m_new, *delta_c, *delta_m, *o_pre, *gates_c, *gates_m;   // gates_*: [B,HW,3Ch] or null
     char *cn_sp, *mn_sp;                     // c_new / m_new once more in the split format, or null
 };
-struct STSplitShadows { const char* in[5]; char* out[3]; int set; };   // vpx_stlstm_set_split_operands (stlstm_api.hip)
-STSplitShadows take_st_shadows();   // this thread's pending shadows, cleared
+struct STSplitShadows { const char* in[5]; char* out[3]; int set; };   // vpx_stlstm_shadows of the running call (stlstm_api.hip)
+STSplitShadows st_shadows_of(const vpx_stlstm_shadows* p);
 struct STOutKSArgs {
     char* h_sp; int Ch;                      // h_new once more in the split format, or null
     long long n; int ks; long long pstride;  // n = B*HW*Ch

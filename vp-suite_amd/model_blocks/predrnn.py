@@ -26,6 +26,9 @@ class SpatioTemporalLSTMCell(VPModelBlock):
     MATCHES_REFERENCE = "Yes"
 
     precision = "f32"
+    #: hand the states on with split-format shadows (ops.stlstm_step(use_shadows=True)). Set by a model whose time loop owns the state
+    #: tensors from one step to the next (PredRNN_V2.forward); off for a cell that user code drives directly.
+    use_shadows = False
 
     def __init__(self, in_channel, num_hidden, height, width, filter_size, stride, layer_norm):
         super().__init__()
@@ -60,7 +63,7 @@ class SpatioTemporalLSTMCell(VPModelBlock):
             ln = tuple(p for seq in (self.conv_x, self.conv_h, self.conv_m, self.conv_o) for p in (seq[1].weight, seq[1].bias))
         return ops.stlstm_step(x_t, h_t, c_t, m_t, self.conv_x[0].weight, self.conv_h[0].weight, self.conv_m[0].weight,
                                self.conv_o[0].weight, self.conv_last.weight, precision=self.precision, wsholder=self._ws,
-                               ln=ln)
+                               ln=ln, use_shadows=self.use_shadows)
 
 
 class ActionConditionalSpatioTemporalLSTMCell(VPModelBlock):

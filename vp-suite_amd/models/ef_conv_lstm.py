@@ -40,7 +40,24 @@ def _stage(spec: "OrderedDict[str, list]") -> nn.Sequential:
             layers.append(("relu_" + name, nn.ReLU(inplace=True)))
         elif "leaky" in name:
             layers.append(("leaky_" + name, nn.LeakyReLU(negative_slope=0.2, inplace=True)))
-    return nn.Sequential(OrderedDict(layers))
+    seq = nn.Sequential(OrderedDict(layers))
+    _validate_stage(seq)
+    return seq
+
+
+def _validate_stage(subnet: nn.Sequential):
+    """Construction-time check of a stage's convolutions against what the library's glue entry points implement — there is no second
+    backend, so an unsupported layer is an error when the model is BUILT (not at its first forward, and not as late as its backward)."""
+    mods = list(subnet.children())
+    for i, m in enumerate(mods):
+        if not isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            continue
+        if _conv_cfg(m) is None:
+            raise ops.VpxError(f"EF stage glue: {m} is outside vpx_conv2d_ex (stride 1 or 2, kernel <= 7, square stride / padding, no "
+                               f"dilation / groups / output_padding; transposed: padding <= kernel - 1 at stride 1, kernel >= 2 at "
+                               f"stride 2): unsupported layer configuration")
+        if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU) and mods[i + 1].negative_slope < 0:
+            raise ops.VpxError(f"EF stage glue: LeakyReLU with negative slope {mods[i + 1].negative_slope} after {m}: unsupported")
 
 
 def _conv_cfg(m):
@@ -78,15 +95,19 @@ def _stage_takes_split(subnet: nn.Sequential, n, c, h, w, precision):
 def _run_stage(subnet: nn.Sequential, x, precision: str, split_last: bool = False):
     """Executes a stage built by _stage() on a channels-last [N,C,H,W] batch — or on (buffer, (N,C,H,W)) in the split-bf16 operand
     format, which the stage's first convolution then reads directly. Conv2d / ConvTranspose2d layers (with a directly following
-    LeakyReLU fused in) run through libvpx_hip's glue entry points when the configuration is one they implement; every other
-    layer (pool, ReLU, exotic strides) runs as the stock GPU module."""
+    LeakyReLU fused in) run through libvpx_hip's glue entry points; a configuration they do not implement was refused when the
+    stage was built (_validate_stage). Only parameter-free layers (pool, ReLU, Identity) run as stock modules. Tensors must live on
+    the GPU: a CPU tensor raises VpxError naming exactly that (there is no CPU path)."""
     mods = list(subnet.children())
     i = 0
     while i < len(mods):
         m = mods[i]
         cfg = _conv_cfg(m)
         x_split = isinstance(x, tuple)
-        if cfg is not None and (x_split or x.is_cuda):
+        if not x_split and not x.is_cuda:
+            raise ops.VpxError(f"EF stage glue: tensors must live on the GPU (got device '{x.device}'). The model runs only as HIP kernels "
+                               f"on MI355X; there is no CPU fallback.")
+        if cfg is not None:
             kh, kw, stride, pad, tr = cfg
             slope = 0.0
             if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
@@ -115,9 +136,8 @@ def _run_stage(subnet: nn.Sequential, x, precision: str, split_last: bool = Fals
         if isinstance(x, tuple):
             raise RuntimeError(f"EF stage glue: {m} cannot read a split-format input (stage was offered one by mistake)")
         if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
-            # no stock-torch convolution in the product path: a glue layer the library does not implement fails loudly
-            raise ops.VpxError(f"EF stage glue: {m} is outside vpx_conv2d_ex (ops.glue_supported: stride 1 or 2, kernel <= 7, square "
-                               f"stride / padding, no dilation / groups / output_padding): unsupported")
+            # (unreachable for stages built by _stage(); a module swapped in afterwards) no stock-torch convolution in the product path
+            raise ops.VpxError(f"EF stage glue: {m} is outside vpx_conv2d_ex (ops.glue_supported): unsupported layer configuration")
         x = m(x)   # activations / Identity only
         i += 1
     return x

@@ -131,6 +131,10 @@ class PredRNN_V2(VPModel):
             a_patch = actions.to(dev)[..., None, None].expand(-1, -1, -1, self.patch_h, self.patch_w)
         prec = self.cell_precision
         nh, top = self.num_hidden, self.num_layers - 1
+        # split-format shadows of the states live from one step of THIS loop to the next and no longer (ops.new_shadow_epoch)
+        ops.new_shadow_epoch()
+        for cell in self.cell_list:
+            cell.use_shadows = True
 
         def zeros(i):
             return torch.zeros(b, nh[i], self.rnn_h, self.rnn_w, device=dev)

@@ -92,6 +92,8 @@ class _WorkspaceCache:
         for k in [k for k, (ref, version, a, _, ep) in self.ents.items()
                   if ref() is None or ref()._version != version or ref().data_ptr() != a or ep != epoch]:
             self._drop(k)
+        if ws.numel() > self.budget:   # larger than the whole budget: never kept (the caller re-packs every call)
+            return
         while self.ents and self.bytes + ws.numel() > self.budget:
             self._drop(next(iter(self.ents)))
         try:
@@ -408,10 +410,16 @@ def conv2d_same(x, w, bias=None, precision="f32"):
 class _ConvExFn(torch.autograd.Function):
     """Conv2d / ConvTranspose2d (stride 1 or 2) + bias + LeakyReLU in ONE library launch (4 for a stride-2 transposed
     conv) — the EF stage glue of ef_blocks.py:15-49. Forward and backward (LeakyReLU', bias / data / weight gradients)
-    run in libvpx_hip; a layer outside the library (kernel smaller than its stride, negative slope) raises VpxError."""
+    run in libvpx_hip. A layer whose backward the library does not implement (kernel smaller than its stride, negative slope)
+    raises VpxError in the FORWARD of a call that will need gradients — not after a whole forward pass has been spent."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, padding, transposed, slope, precision, out_pad=(0, 0)):
+        kh, kw = int(w.shape[2]), int(w.shape[3])
+        if any(ctx.needs_input_grad[:3]) and (kh < stride or kw < stride or slope < 0.0):
+            raise _lib.VpxError(f"conv2d_ex: layer (k={kh}x{kw}, stride={stride}, transposed={bool(transposed)}, slope={slope}) has no backward "
+                                f"in the library (vpx_conv2d_ex_bwd needs kernel >= stride and a non-negative LeakyReLU slope): "
+                                f"unsupported in a call that requires gradients")
         _require_gpu(x, "conv2d_ex")
         xs = to_channels_last(x)
         N, Ci, H, Wd = xs.shape
@@ -546,7 +554,7 @@ def conv2d_ex_from_split(xbuf, xshape, w, bias, stride, padding, transposed=Fals
     ws_bytes = L.vpx_conv2d_ex_split_workspace_bytes(ctypes.byref(d))
     if ws_bytes == 0:
         raise _lib.VpxError("conv2d_ex_from_split: layer not implemented on split input: " + L.vpx_last_error().decode())
-    key = (id(w), N, H, Wd, int(stride), int(padding), bool(transposed), precision,
+    key = (id(w), N, H, Wd, Ci, Co, kh, kw, int(stride), int(padding), bool(transposed), precision, L.vpx_conv2d_ex_takes_split(ctypes.byref(d)),
            torch.are_deterministic_algorithms_enabled(), _kernel_options())
     packed = 0
     ws = _convq_ws.get(key, w, w.data_ptr(), ws_bytes, xbuf.device, exact=False)
@@ -578,7 +586,8 @@ def conv_transpose2d_to_size(x, w, stride, padding, out_hw, precision="f32"):
 
 
 def glue_supported(kh, kw, stride, padding, transposed) -> bool:
-    """Configurations vpx_conv2d_ex_fwd implements (anything else stays on the stock GPU op)."""
+    """Configurations vpx_conv2d_ex_fwd implements. Anything else is refused when a model is built (models/ef_conv_lstm._validate_stage):
+    the product has no second convolution backend."""
     if stride not in (1, 2) or kh > 7 or kw > 7 or padding < 0:
         return False
     if transposed and stride == 1:
@@ -722,14 +731,40 @@ class STWorkspace:
         return self.buf, valid
 
 
-def _shadow_of(t, tl):
-    """The split-format copy a previous library call attached to tensor `t` (as `t._vpx_sp = (buffer, version, address)`), if it still
-    describes the memory `tl` that is about to be handed to the library: same tensor version, same address, same device."""
+_shadow_epoch = 0
+
+
+def new_shadow_epoch():
+    """Ends the life of every split-format shadow attached so far. A model calls this at the start of each forward pass: a shadow then
+    only ever describes a tensor produced earlier in the SAME pass, inside the model's own time loop — memory no user code gets
+    to write through an alias the version counter cannot see (`.data`, dlpack, a raw-pointer kernel) while the shadow lives."""
+    global _shadow_epoch
+    _shadow_epoch += 1
+
+
+def _attach_shadow(t, buf):
+    """Records `buf` as the split-format copy of the tensor `t` a library call just wrote: (buffer, version, address, shape, epoch)."""
+    t._vpx_sp = (buf, t._version, t.data_ptr(), tuple(t.shape), _shadow_epoch)
+
+
+def invalidate_shadow(t):
+    """Drops a tensor's split-format shadow. Code that writes into a tensor WITHOUT bumping its version counter — `.data.copy_()`,
+    a raw-pointer kernel, dlpack aliases — must call this (or `ops.clear_layout_cache()` for everything)."""
+    if getattr(t, "_vpx_sp", None) is not None:
+        t._vpx_sp = None
+
+
+def _shadow_of(t, tl, channels):
+    """The split-format copy a previous library call attached to tensor `t`, if it still describes the memory `tl` that is about to
+    be handed to the library as an operand with `channels` channels: same shadow epoch (new_shadow_epoch), same tensor version, same
+    address, same device and the same logical shape [B, channels, H, W] as when it was attached. The attribute lives on the very
+    object the library returned — views, clones and `.data` aliases never carry it."""
     sp = getattr(t, "_vpx_sp", None)
     if sp is None:
         return None
-    buf, version, addr = sp
-    if version != t._version or addr != tl.data_ptr() or buf.device != tl.device:
+    buf, version, addr, shape, epoch = sp
+    if epoch != _shadow_epoch or version != t._version or addr != tl.data_ptr() or buf.device != tl.device or shape != tuple(tl.shape) or shape[1] != channels \
+            or buf.numel() != tl.numel():
         return None
     return buf
 
@@ -739,7 +774,7 @@ class _STLSTMStepFn(torch.autograd.Function):
     `ln` = () or the 8 LayerNorm tensors (x_gamma, x_beta, h_gamma, h_beta, m_gamma, m_beta, o_gamma, o_beta)."""
 
     @staticmethod
-    def forward(ctx, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision, need_grad, wsholder, *ln):
+    def forward(ctx, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision, need_grad, wsholder, use_shadows, *ln):
         _require_gpu(x, "stlstm_step")
         dev = x.device
         B, Cin, H, Wd = x.shape
@@ -772,18 +807,18 @@ class _STLSTMStepFn(torch.autograd.Function):
         # split-format shadows (vpx.h): operands a previous step left in the kernels' operand format are handed back instead of being
         # converted again (h_new is the next step's h and the next layer's x, m_new the next layer's m), and this step's h_new / c_new /
         # m_new come back with shadows of their own
-        sp_in, sp_out = [None] * 5, None
-        if not use_ln and L.vpx_stlstm_uses_split(ctypes.byref(d)):
-            sp_in[:3] = [_shadow_of(x, xs), _shadow_of(h, hs), _shadow_of(m, ms)]
+        sp_in, sp_out, shadows = [None] * 5, None, None
+        if use_shadows and not use_ln and L.vpx_stlstm_uses_split(ctypes.byref(d)):
+            sp_in[:3] = [_shadow_of(x, xs, Cin), _shadow_of(h, hs, Ch), _shadow_of(m, ms, Ch)]
             sp_out = [torch.empty(B * H * Wd * Ch, dtype=torch.float32, device=dev) for _ in range(3)]
-            in_arr = (ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in sp_in])
-            out_arr = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in sp_out])
-            L.vpx_stlstm_set_split_operands(in_arr, out_arr)
+            shadows = _lib.STLSTMShadows((ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in sp_in]),
+                                         (ctypes.c_void_p * 3)(*[t.data_ptr() for t in sp_out]))
         if PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        rc = L.vpx_stlstm_step_fwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), *[ptr(w) for w in W5], ln_arr,
-                                   *[ptr(o) for o in outs], ptr(reserve), rs_bytes, ptr(ws), ws_bytes, _stream())
+        rc = L.vpx_stlstm_step_fwd_ex(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), *[ptr(w) for w in W5], ln_arr,
+                                      *[ptr(o) for o in outs], ptr(reserve), rs_bytes, ptr(ws), ws_bytes, _stream(),
+                                      None if shadows is None else ctypes.byref(shadows))
         check(rc, "vpx_stlstm_step_fwd")
         if PROFILE is not None:
             ev1.record()
@@ -791,7 +826,7 @@ class _STLSTMStepFn(torch.autograd.Function):
             PROFILE.records.append((ev0, ev1, fl, by, 4, "stlstm_fwd"))
         if sp_out is not None:
             for t, buf in zip(outs[:3], sp_out):
-                t._vpx_sp = (buf, t._version, t.data_ptr())
+                _attach_shadow(t, buf)
         if need_grad:
             ctx.sp = None if sp_out is None else (sp_in[0], sp_in[1], sp_in[2], sp_out[1], sp_out[2])   # x, h, m, c_new, m_new
             ctx.save_for_backward(xs, hs, cs, ms, outs[1], outs[2], *W5, reserve, *lnc)
@@ -819,7 +854,7 @@ class _STLSTMStepFn(torch.autograd.Function):
         dc = new_channels_last(tuple(cs.shape), dev) if needs[2] else None
         dm = new_channels_last(tuple(ms.shape), dev) if needs[3] else None
         dWs = [torch.empty_like(w) if needs[4 + i] else None for i, w in enumerate((Wx, Wh, Wm, Wo, Wlast))]
-        dln = [torch.empty_like(t) if needs[12 + i] else None for i, t in enumerate(lnc)]
+        dln = [torch.empty_like(t) if needs[13 + i] else None for i, t in enumerate(lnc)]
         ln_arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in lnc]) if ctx.use_ln else None
         dln_arr = (ctypes.c_void_p * 8)(*[None if t is None else t.data_ptr() for t in dln]) if ctx.use_ln else None
         ws_bytes = L.vpx_stlstm_workspace_bytes(ctypes.byref(d))
@@ -831,15 +866,16 @@ class _STLSTMStepFn(torch.autograd.Function):
                 d.flags = flags0 | _lib.FLAG_WEIGHTS_PACKED
         else:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        shadows = None
         if getattr(ctx, "sp", None) is not None:   # the forward's split shadows: the weight-gradient kernel stages them as they are
-            L.vpx_stlstm_set_split_operands((ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in ctx.sp]), None)
-        rc = L.vpx_stlstm_step_bwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), ptr(c_new), ptr(m_new), ptr(Wx),
-                                   ptr(Wh), ptr(Wm), ptr(Wo), ptr(Wlast), ln_arr, ptr(reserve), ctx.rs_bytes,
-                                   *[ptr(g) for g in gin], ptr(dx), ptr(dh), ptr(dc), ptr(dm), *[ptr(g) for g in dWs],
-                                   dln_arr, ptr(ws), ws_bytes, _stream())
+            shadows = _lib.STLSTMShadows((ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in ctx.sp]), (ctypes.c_void_p * 3)())
+        rc = L.vpx_stlstm_step_bwd_ex(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), ptr(c_new), ptr(m_new), ptr(Wx),
+                                      ptr(Wh), ptr(Wm), ptr(Wo), ptr(Wlast), ln_arr, ptr(reserve), ctx.rs_bytes,
+                                      *[ptr(g) for g in gin], ptr(dx), ptr(dh), ptr(dc), ptr(dm), *[ptr(g) for g in dWs],
+                                      dln_arr, ptr(ws), ws_bytes, _stream(), None if shadows is None else ctypes.byref(shadows))
         d.flags = flags0
         check(rc, "vpx_stlstm_step_bwd")
-        return (dx, dh, dc, dm, *dWs, None, None, None, *dln)
+        return (dx, dh, dc, dm, *dWs, None, None, None, None, *dln)
 
 
 def stlstm_algorithmic_work(B, Cin, Ch, H, W, k, dt=4):
@@ -850,13 +886,16 @@ def stlstm_algorithmic_work(B, Cin, Ch, H, W, k, dt=4):
     return flops, nbytes
 
 
-def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=None, ln=()):
-    """ln: () or the 8 LayerNorm parameter tensors [C,H,W] (x_gamma, x_beta, h_.., m_.., o_..) of the LayerNorm variant."""
+def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=None, ln=(), use_shadows=False):
+    """ln: () or the 8 LayerNorm parameter tensors [C,H,W] (x_gamma, x_beta, h_.., m_.., o_..) of the LayerNorm variant.
+    use_shadows: hand h_new / c_new / m_new out with split-format shadows and take the shadows of x / h / m where a previous step of
+    the same shadow epoch attached them (no second conversion). Opt-in: the caller vouches that nothing writes those tensors behind
+    the version counter's back between the steps (PredRNN_V2.forward: the tensors never leave its loop)."""
     ln = tuple(ln)
     if len(ln) not in (0, 8):
         raise ValueError("stlstm_step: ln must hold 0 or 8 tensors")
     need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (x, h, c, m, Wx, Wh, Wm, Wo, Wlast) + ln)
-    return _STLSTMStepFn.apply(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, PRECISIONS[precision], need_grad, wsholder, *ln)
+    return _STLSTMStepFn.apply(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, PRECISIONS[precision], need_grad, wsholder, bool(use_shadows), *ln)
 
 
 class _LayerNormCHWFn(torch.autograd.Function):
