@@ -137,6 +137,48 @@ def test_predrnn_train_iter_vs_golden(vpx):
     assert abs(m.sampling_eta - float(g["sampling_eta_after2"])) < 1e-9
 
 
+@pytest.mark.parametrize("mode", ["standard", "reverse_sampling", "action"])
+def test_fused_reversed_pass_equals_two_passes(vpx, mode):
+    """training_loss with the sequence and its time-reversal as ONE batch of 2B samples (fuse_reversed_pass, the default) against the
+    reference's two passes one after the other (predrnn_v2.py:326-352): same sampling masks from the same RNG stream (real coin flips:
+    sampling_eta ~ 0.5), same schedule state afterwards, loss and every gradient equal up to fp32 summation order."""
+    from golden_util import seeded_randn
+    from vp_suite_amd.measure import PredictionLossProvider
+    lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
+    if mode == "action":
+        kw, extra, tag = dict(gc.PRED_ACTION_KW, **gc.PRED_ACTION_CASES["plain"]), dict(sampling_eta=0.5), "action"
+        from vp_suite_amd.models import MODEL_CLASSES
+        def make():
+            m = MODEL_CLASSES["predrnn-pp"]("cuda", **kw)
+            fill_state_dict_(m, name_seed("predrnn_action.plain"))
+            return m.cuda()
+    else:
+        kw, tag = dict(img_shape=(1, 32, 32), action_size=0, tensor_value_range=[0.0, 1.0], num_layers=2, num_hidden=[16, 16], cell_precision="bf16x3"), "fuse"
+        extra = dict(reverse_scheduled_sampling=True) if mode == "reverse_sampling" else {}
+        def make():
+            return _predrnn(tag, dict(kw, **extra))
+    c, h, w = kw["img_shape"]
+    B, Ttot, P = 3, 7, 3
+    frames = seeded_rand((B, Ttot, c, h, w), name_seed(f"predrnn.{tag}.frames")).cuda()
+    actions = seeded_randn((B, Ttot, kw["action_size"]), name_seed(f"predrnn.{tag}.actions")).cuda() if mode == "action" else None
+    res = {}
+    for fused in (True, False):
+        m = make()
+        m.fuse_reversed_pass = fused
+        m.sampling_eta, m.training_iteration = 0.5, 30000   # both schedules in their stochastic range
+        torch.manual_seed(1234)
+        kwargs = {"actions": actions} if actions is not None else {}
+        loss = m.training_loss(frames, frames[:, Ttot - P:], P, lp, **kwargs)
+        loss.backward()
+        named = dict(m.named_parameters())
+        res[fused] = (float(loss), np.concatenate([named[k].grad.detach().cpu().numpy().reshape(-1) for k in sorted(named)]),
+                      m.sampling_eta, m.training_iteration, float(torch.rand(1, device="cuda")))
+    a, b = res[True], res[False]
+    assert abs(a[0] - b[0]) < 2e-6 * abs(b[0])
+    assert _relmax(a[1], b[1]) < 2e-5
+    assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4]   # schedule state and the RNG stream's position
+
+
 def test_predrnn_full_size_vs_golden(vpx):
     """BASELINE config C3: default predrnn-pp, 64x64, 10 -> 10."""
     g = load_golden("predrnn_full_c1")

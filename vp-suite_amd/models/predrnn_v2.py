@@ -54,6 +54,10 @@ class PredRNN_V2(VPModel):
     training_iteration: int = None
     sampling_eta: float = None
     cell_precision = "f32"  #: arithmetic of the fused ST-LSTM kernels
+    #: training_loss runs the sequence and its time-reversal (predrnn_v2.py:326-352) as ONE batch of 2B samples: the two passes share the
+    #: weights and nothing else, so this is the same arithmetic per sample with every launch on twice the grid and half the launches
+    #: (what the 2-sample shards of BASELINE configs[4] need most). False: two forward passes one after the other, as the reference does.
+    fuse_reversed_pass: bool = True
 
     def __init__(self, device, **model_kwargs):
         super().__init__(device, **model_kwargs)
@@ -144,7 +148,9 @@ class PredRNN_V2(VPModel):
         # Test-time sampling masks are constants (predrnn_v2.py:300-309: zeros, and ones over the context frames in reverse mode): the
         # blend mask * x + (1 - mask) * x_gen (:171-176) then IS one of its two operands, bit for bit on finite inputs — taken directly instead of
         # through four elementwise launches per predicted frame (2 % of a small-batch forward).
-        mask_true = self._scheduled_sampling(b, context_frames, pred_frames, train) if train else None
+        mask_true = kwargs.get("_mask_true")   # (training_loss: the masks of a fused forward + reversed pair, drawn in the reference's order)
+        if mask_true is None and train:
+            mask_true = self._scheduled_sampling(b, context_frames, pred_frames, train)
         first_blend = 1 if self.reverse_scheduled_sampling else context_frames
         k = self.filter_size
         x_gen, next_frames, decouple = None, [], []
@@ -258,12 +264,30 @@ class PredRNN_V2(VPModel):
         `reversed_pair` = (input, target) of the reversed sequence as `unpack_data(reverse=True)` makes them; by default
         the flip of the complete input sequence (identical whenever the data holds exactly context+pred frames)."""
         fwd_kwargs.pop("train", None)
+        if self.reverse_input and reversed_pair is None:
+            inp_r = torch.flip(inp, dims=[1])
+            reversed_pair = (inp_r, inp_r[:, inp.shape[1] - pred_frames:])
+        if self.reverse_input and self.fuse_reversed_pass and reversed_pair[0].shape == inp.shape and reversed_pair[1].shape == targets.shape:
+            # One batch of 2B: rows [0, B) the sequence, rows [B, 2B) its reversal. Exact: the samples of a batch only meet in the two
+            # batch MEANS of the loss — MSE (mean over b, t of the per-frame sum, base_measure.py:57) and the decoupling term (mean over
+            # b, channel, predrnn_v2.py:197-211, then over steps x layers) — and a mean over two halves of equal size is the average of
+            # the halves' means, i.e. (total + total_rev) / 2 term by term. The sampling masks are drawn in the reference's order (the
+            # forward pass's, then the reversed pass's: same RNG stream, same per-call decrement of sampling_eta); the actions go to
+            # both halves unreversed, as the reference passes them (:340-341).
+            b, ctx = inp.shape[0], inp.shape[1] - pred_frames
+            m1 = self._scheduled_sampling(b, ctx, pred_frames, True)
+            m2 = self._scheduled_sampling(b, ctx, pred_frames, True)
+            kw = dict(fwd_kwargs)
+            if kw.get("actions") is not None and torch.is_tensor(kw["actions"]) and kw["actions"].dim() == 3:
+                kw["actions"] = torch.cat([kw["actions"], kw["actions"]], dim=0)
+            inp_r, targets_r = reversed_pair
+            preds, ml = self(torch.cat([inp, inp_r], dim=0), pred_frames=pred_frames, train=True, _mask_true=torch.cat([m1, m2], dim=0), **kw)
+            total = self._total_loss(preds, torch.cat([targets, targets_r], dim=0), ml, loss_provider)
+            self.training_iteration += 1
+            return total
         preds, ml = self(inp, pred_frames=pred_frames, train=True, **fwd_kwargs)
         total = self._total_loss(preds, targets, ml, loss_provider)
         if self.reverse_input:
-            if reversed_pair is None:
-                inp_r = torch.flip(inp, dims=[1])
-                reversed_pair = (inp_r, inp_r[:, inp.shape[1] - pred_frames:])
             inp_r, targets_r = reversed_pair
             preds_r, ml_r = self(inp_r, pred_frames=pred_frames, train=True, **fwd_kwargs)
             total = (total + self._total_loss(preds_r, targets_r, ml_r, loss_provider)) / 2
