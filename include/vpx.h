@@ -288,34 +288,35 @@ int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, co
 int vpx_conv2d_nhwc_fwd_ex(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Ci, int Co,
                            int kh, int kw, int precision, int accumulate, float leaky_slope, void* workspace,
                            size_t workspace_bytes, void* stream);
-/* dys = dy * LeakyReLU'(y) (from the sign of the activated output y) and db[c] = sum_rows dys[.][c], one pass over
- * [rows][cols] matrices, fixed summation order. dys and db may each be NULL. */
-size_t vpx_leaky_bwd_workspace_bytes(int cols);
-int vpx_leaky_bwd(const float* dy, const float* y, float slope, float* dys, float* db, long long rows, int cols, void* workspace,
-                  size_t workspace_bytes, void* stream);
-/* y[i] += x[i] */
-int vpx_axpy(float* y, const float* x, long long n, void* stream);
-
-/* ---- TrajGRU step pieces (vp_suite/model_blocks/traj_gru.py:148-162, 190-203), NHWC -------------------------------- *
- * warp: warped[b,p, l*C + c] = bilinear sample of h[b,:,:,c] at pixel p displaced by -flows[b,p,2l..2l+1] with the
- *       reference's normalisation (divide by W-1 / H-1, grid_sample align_corners=False, zero padding); C % 4 == 0.
- *       backward: dh += scatter (float atomics; dh may be NULL), dflows written (may be NULL). The float scatter is the one
- *       place where summation order depends on timing; under vpx_set_deterministic(1) this entry refuses a non-NULL dh and
- *       vpx_trajgru_warp_bwd_det takes its place: the same scatter in 2^40-scaled 64-bit integers (associative, hence
- *       bit-reproducible; resolution 9e-13, range +-8.4e6 per element), converted and added onto dh by a second kernel.
- * gates: r = s(i0+h0), u = s(i1+h1), m = act(i2 + r*h2), next = u*prev + (1-u)*m; i2h (a [HW,3C] slice per batch item,
- *       batch stride in elements) may be NULL; act 0 = LeakyReLU(slope) (slope 0 = ReLU), 1 = sigmoid; save [B,HW,3C]
- *       receives (r, u, m) for the backward, which writes di2h (may be NULL), dh2h and dprev = u * dnext. */
-int vpx_trajgru_warp_fwd(const float* h, const float* flows, float* warped, int B, int H, int W, int C, int L, void* stream);
-int vpx_trajgru_warp_bwd(const float* h, const float* flows, const float* dwarped, float* dh, float* dflows, int B, int H, int W,
-                         int C, int L, void* stream);
-size_t vpx_trajgru_warp_bwd_det_workspace_bytes(int B, int H, int W, int C);
-int vpx_trajgru_warp_bwd_det(const float* h, const float* flows, const float* dwarped, float* dh, float* dflows, int B, int H, int W,
-                             int C, int L, void* workspace, size_t workspace_bytes, void* stream);
-int vpx_trajgru_gates_fwd(const float* i2h, long long i2h_bstride, const float* h2h, const float* prev, float* next, float* save,
-                          int B, int HW, int C, int act, float slope, void* stream);
-int vpx_trajgru_gates_bwd(const float* dnext, const float* h2h, const float* prev, const float* save, float* di2h,
-                          long long di2h_bstride, float* dh2h, float* dprev, int B, int HW, int C, int act, float slope, void* stream);
+/* ---- TrajGRU over a sequence (vp_suite/model_blocks/traj_gru.py:164-214), time-major NHWC ---------------------------------- *
+ * One call runs the block's whole time loop: the input projection i2h of all frames (one launch), then per step the flow generator
+ * (two 5x5 convolutions summed + LeakyReLU, the 5x5 flow convolution, :134-146), the L bilinear warps of h_{t-1} along -flow with the
+ * reference's normalisation (divide by W-1 / H-1, grid_sample align_corners=False, zero padding, :148-162), the 1x1 `ret`
+ * convolution and the GRU gates r = s(i0+h0), u = s(i1+h1), m = leaky(i2 + r*h2), h_t = u*h_{t-1} + (1-u)*m (:190-203). The backward
+ * is the explicit BPTT schedule of the same launches (the warped operand is recomputed per step, not stored).
+ *   x  [T][B][H*W][Cin] or NULL (no input: zero projection)      h0 [B][H*W][C] or NULL (zero state); not both NULL
+ *   params / dparams: 10 pointers in the order (i2h, i2f_conv1, h2f_conv1, flows_conv, ret) x (weight OIHW, bias); with x == NULL the
+ *        first four gradients are not written (may be NULL). Parameter gradients are OVERWRITTEN.
+ *   hs [T][B][H*W][C]: h_1 .. h_T (forward output, backward input)       dout [T][B][H*W][C] or NULL, dhT [B][H*W][C] or NULL
+ *   reserve: vpx_trajgru_reserve_bytes (0 without VPX_FLAG_SAVE_FOR_BWD); workspace: vpx_trajgru_workspace_bytes
+ * The warp backward scatters with float atomics (like torch's grid_sample backward: sum order depends on timing); under
+ * vpx_set_deterministic(1) it scatters 2^40-scaled 64-bit integers instead (associative, hence bit-reproducible; resolution 9e-13,
+ * range +-8.4e6 per element). Restrictions: C % 4 == 0, i2h a square odd stride-1 'same' convolution, slope > 0, zoneout = 0. */
+typedef struct vpx_trajgru_desc {
+    int32_t B, T, Cin, C, H, W;
+    int32_t L;             /* flow fields / warps per step */
+    int32_t k_i2h;         /* kernel size of the input projection */
+    int32_t precision;     /* vpx_precision: arithmetic of the five convolutions */
+    int32_t flags;         /* VPX_FLAG_SAVE_FOR_BWD */
+    float slope;           /* LeakyReLU negative slope (> 0) */
+} vpx_trajgru_desc;
+size_t vpx_trajgru_workspace_bytes(const vpx_trajgru_desc* d);
+size_t vpx_trajgru_reserve_bytes(const vpx_trajgru_desc* d);
+int vpx_trajgru_seq_fwd(const vpx_trajgru_desc* d, const float* x, const float* h0, const float* const* params, float* hs, void* reserve,
+                        size_t reserve_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int vpx_trajgru_seq_bwd(const vpx_trajgru_desc* d, const float* x, const float* h0, const float* const* params, const float* hs,
+                        const void* reserve, size_t reserve_bytes, const float* dout, const float* dhT, float* dx, float* dh0,
+                        float* const* dparams, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- action-conditional ST-LSTM cell, pointwise half (vp_suite/model_blocks/predrnn.py:139-169), NHWC ---------------- *
  * gates: from the conv outputs xc [npix,7Ch] (i,f,g,i',f',g',o), hc [npix,4Ch], ac [npix,4Ch] (multiplies hc; NULL = plain

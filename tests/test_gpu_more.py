@@ -146,12 +146,16 @@ def test_conv2d_ex_vs_torch(vpx):
         (False, 3, 16, 3, 1, 1, 19, 21), (False, 16, 3, 1, 1, 0, 18, 20),   # few-channel layers: wgrad_small_kernel (with 1->16, 16->1 above)
     ]
     _conv2d_ex_cases(vpx, cases, F)   # backward: vpx_conv2d_ex_bwd (adjoint layer + strided MFMA weight gradient)
-    # a layer outside the library's glue backward (kernel smaller than its stride) raises instead of falling back to ATen
+    # a layer outside the library's glue backward (kernel smaller than its stride) raises instead of falling back to ATen — in the
+    # FORWARD of a call that will need gradients (not after a whole forward pass has been spent); inference runs
     x = torch.rand(1, 4, 8, 8, device="cuda", requires_grad=True)
     w = torch.rand(4, 4, 1, 1, device="cuda", requires_grad=True)
-    y = vpx.ops.conv2d_ex(x, w, None, 2, 0, False, 0.2, "f32")
     with pytest.raises(vpx.ops.VpxError, match="unsupported"):
-        y.sum().backward()
+        vpx.ops.conv2d_ex(x, w, None, 2, 0, False, 0.2, "f32")
+    with torch.no_grad():
+        y = vpx.ops.conv2d_ex(x, w, None, 2, 0, False, 0.2, "f32")
+    ref = F.leaky_relu(F.conv2d(x.detach(), w.detach(), None, 2, 0), 0.2)
+    assert float((y - ref).abs().max()) < 1e-5
 
 
 def _conv2d_ex_cases(vpx, cases, F):

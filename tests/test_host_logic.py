@@ -109,10 +109,10 @@ def test_unsupported_glue_fails_when_the_model_is_built_and_cpu_tensors_are_name
     with pytest.raises(vpx.VpxError, match="must live on the GPU"):
         ef_conv_lstm._run_stage(st, torch.rand(2, 3, 8, 8), "f32")
 
-    class Ctx:
-        needs_input_grad = (True, True, False)
     with pytest.raises(vpx.VpxError, match="no backward"):                             # 1x1 kernel with stride 2: forward-only in the library
-        vpx.ops._ConvExFn.forward(Ctx(), torch.rand(1, 4, 8, 8), torch.rand(4, 4, 1, 1), None, 2, 0, False, 0.0, 0)
+        vpx.ops.conv2d_ex(torch.rand(1, 4, 8, 8), torch.rand(4, 4, 1, 1, requires_grad=True), None, 2, 0, False, 0.0, "f32")
+    with torch.no_grad(), pytest.raises(vpx.VpxError, match="must live on the GPU"):   # inference: the layer itself is fine, the device is not
+        vpx.ops.conv2d_ex(torch.rand(1, 4, 8, 8), torch.rand(4, 4, 1, 1, requires_grad=True), None, 2, 0, False, 0.0, "f32")
 
 
 def test_workspace_cache_never_keeps_an_entry_larger_than_its_budget(vpx):

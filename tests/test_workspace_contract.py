@@ -239,17 +239,35 @@ def test_stage_glue(L, det):
             L.vpx_set_option(_lib.OPT_EXPERIMENT, prev)
 
 
+def test_trajgru_sequence(L):
+    """vpx_trajgru_seq_fwd / _bwd over the default EF-TrajGRU blocks (ef_traj_gru.py:31-75) and small / ragged shapes, every operand mode."""
+    from vp_suite_amd._lib import TrajGRUDesc
+    blocks = [(16, 64, 64, 64, 13), (64, 96, 32, 32, 13), (96, 96, 16, 16, 13), (96, 96, 32, 32, 13), (96, 64, 64, 64, 13), (4, 8, 16, 16, 3), (6, 12, 9, 11, 5)]
+    for det in (0, 1):
+        L.vpx_set_deterministic(det)
+        for (Cin, C, H, W, nl), B, T, prec, save in itertools.product(blocks, (1, 2, 8), (1, 4), (0, 1, 2), (0, 1)):
+            d = TrajGRUDesc(B, T, Cin, C, H, W, nl, 3, prec, _lib.FLAG_SAVE_FOR_BWD if save else 0, 0.2)
+            nb, rs = L.vpx_trajgru_workspace_bytes(ctypes.byref(d)), L.vpx_trajgru_reserve_bytes(ctypes.byref(d))
+            assert nb > 0 and (rs > 0) == bool(save)
+            params = (ctypes.c_void_p * 10)(*[0x200000000000 + i * (1 << 32) for i in range(10)])
+            dparams = (ctypes.c_void_p * 10)(*[0x300000000000 + i * (1 << 32) for i in range(10)])
+            tag = f"trajgru {(Cin, C, H, W, nl)} B={B} T={T} prec={prec} save={save} det={det}"
+            for (x, h0) in ((_fake(1), _fake(2)), (None, _fake(2)), (_fake(1), None)):
+                rc = L.vpx_trajgru_seq_fwd(ctypes.byref(d), x, h0, params, _fake(3), _fake(4), rs, ctypes.c_void_p(WS_BASE), nb, None)
+                _ok(L, rc, tag + " fwd", allow_unsupported=False)
+                if save:
+                    rc = L.vpx_trajgru_seq_bwd(ctypes.byref(d), x, h0, params, _fake(3), _fake(4), rs, _fake(5), _fake(6), None if x is None else _fake(7),
+                                               None if h0 is None else _fake(8), dparams, ctypes.c_void_p(WS_BASE_ODD), nb, None)
+                    _ok(L, rc, tag + " bwd", allow_unsupported=False)
+    d = TrajGRUDesc(2, 3, 4, 6, 8, 8, 3, 3, 0, 0, 0.2)   # C % 4 != 0
+    assert L.vpx_trajgru_workspace_bytes(ctypes.byref(d)) == 0
+
+
 def test_small_workspaces(L):
-    """leaky_bwd, LayerNorm, TrajGRU's deterministic warp backward, MSE."""
-    for cols, rows in itertools.product((8, 26, 32, 96), (64, 6 * 64 * 64, 128 * 16 * 16)):
-        nb = L.vpx_leaky_bwd_workspace_bytes(cols)
-        _ok(L, L.vpx_leaky_bwd(_fake(1), _fake(2), 0.2, _fake(3), _fake(4), rows, cols, ctypes.c_void_p(WS_BASE), nb, None), f"leaky_bwd {cols} {rows}", False)
+    """LayerNorm, MSE."""
     for B in (1, 2, 8, 128):
         nb = L.vpx_layernorm_workspace_bytes(B)
         _ok(L, L.vpx_layernorm_fwd(_fake(1), _fake(2), _fake(3), _fake(4), _fake(5), _fake(6), B, 128 * 16 * 16, ctypes.c_void_p(WS_BASE), nb, None), "ln fwd", False)
         _ok(L, L.vpx_layernorm_bwd(_fake(1), _fake(2), _fake(3), _fake(4), _fake(5), _fake(6), _fake(7), B, 256, 128, ctypes.c_void_p(WS_BASE), nb, None), "ln bwd", False)
-    for (B, H, W, C) in ((2, 16, 16, 96), (6, 64, 64, 64), (1, 8, 8, 8)):
-        nb = L.vpx_trajgru_warp_bwd_det_workspace_bytes(B, H, W, C)
-        _ok(L, L.vpx_trajgru_warp_bwd_det(_fake(1), _fake(2), _fake(3), _fake(4), _fake(5), B, H, W, C, 13, ctypes.c_void_p(WS_BASE), nb, None), "warp_bwd_det", False)
     nb = L.vpx_mse_loss_workspace_bytes()
     _ok(L, L.vpx_mse_loss(_fake(1), _fake(2), 128 * 10 * 64 * 64, 1280, 1.0, _fake(3), _fake(4), ctypes.c_void_p(WS_BASE), nb, None), "mse", False)

@@ -36,9 +36,9 @@ EXPORTED_SYMBOLS = [
     "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd", "vpx_conv2d_ex_fwd_split",
     "vpx_conv2d_ex_takes_split", "vpx_split_convert", "vpx_conv2d_ex_split_workspace_bytes", "vpx_conv2d_ex_fwd_from_split",
     "vpx_conv2d_ex_bwd_workspace_bytes", "vpx_conv2d_ex_bwd",
-    "vpx_conv2d_nhwc_fwd_ex", "vpx_leaky_bwd_workspace_bytes", "vpx_leaky_bwd", "vpx_axpy",
+    "vpx_conv2d_nhwc_fwd_ex",
     "vpx_acst_gates_fwd", "vpx_acst_gates_bwd", "vpx_st_out_fwd", "vpx_st_out_bwd",
-    "vpx_trajgru_warp_fwd", "vpx_trajgru_warp_bwd", "vpx_trajgru_warp_bwd_det_workspace_bytes", "vpx_trajgru_warp_bwd_det", "vpx_trajgru_gates_fwd", "vpx_trajgru_gates_bwd",
+    "vpx_trajgru_workspace_bytes", "vpx_trajgru_reserve_bytes", "vpx_trajgru_seq_fwd", "vpx_trajgru_seq_bwd",
     "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
     "vpx_layernorm_workspace_bytes", "vpx_layernorm_fwd", "vpx_layernorm_bwd",
     "vpx_mse_loss_workspace_bytes", "vpx_mse_loss", "vpx_adam_step",
@@ -59,6 +59,10 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "W", "Ci", "Co", "kh", "kw", "stride", "pad", "transposed")] + \
                [("leaky_slope", ctypes.c_float), ("precision", ctypes.c_int32), ("out_pad_h", ctypes.c_int32),
                 ("out_pad_w", ctypes.c_int32)]
+
+
+class TrajGRUDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "T", "Cin", "C", "H", "W", "L", "k_i2h", "precision", "flags")] + [("slope", ctypes.c_float)]
 
 
 class STLSTMShadows(ctypes.Structure):
@@ -152,12 +156,6 @@ def lib():
         ll, fl, ci = ctypes.c_longlong, ctypes.c_float, ctypes.c_int
         L.vpx_conv2d_nhwc_fwd_ex.restype = ci
         L.vpx_conv2d_nhwc_fwd_ex.argtypes = [vp] * 4 + [ci] * 9 + [fl, vp, sz, vp]
-        L.vpx_leaky_bwd_workspace_bytes.restype = sz
-        L.vpx_leaky_bwd_workspace_bytes.argtypes = [ci]
-        L.vpx_leaky_bwd.restype = ci
-        L.vpx_leaky_bwd.argtypes = [vp, vp, fl, vp, vp, ll, ci, vp, sz, vp]
-        L.vpx_axpy.restype = ci
-        L.vpx_axpy.argtypes = [vp, vp, ll, vp]
         L.vpx_acst_gates_fwd.restype = ci
         L.vpx_acst_gates_fwd.argtypes = [vp] * 13 + [ll, ci, fl, vp]
         L.vpx_acst_gates_bwd.restype = ci
@@ -166,18 +164,13 @@ def lib():
         L.vpx_st_out_fwd.argtypes = [vp] * 6 + [ll, vp]
         L.vpx_st_out_bwd.restype = ci
         L.vpx_st_out_bwd.argtypes = [vp] * 5 + [ll, vp]
-        L.vpx_trajgru_warp_fwd.restype = ci
-        L.vpx_trajgru_warp_fwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
-        L.vpx_trajgru_warp_bwd.restype = ci
-        L.vpx_trajgru_warp_bwd.argtypes = [vp] * 5 + [ci] * 5 + [vp]
-        L.vpx_trajgru_warp_bwd_det_workspace_bytes.restype = sz
-        L.vpx_trajgru_warp_bwd_det_workspace_bytes.argtypes = [ci] * 4
-        L.vpx_trajgru_warp_bwd_det.restype = ci
-        L.vpx_trajgru_warp_bwd_det.argtypes = [vp] * 5 + [ci] * 5 + [vp, sz, vp]
-        L.vpx_trajgru_gates_fwd.restype = ci
-        L.vpx_trajgru_gates_fwd.argtypes = [vp, ll, vp, vp, vp, vp, ci, ci, ci, ci, fl, vp]
-        L.vpx_trajgru_gates_bwd.restype = ci
-        L.vpx_trajgru_gates_bwd.argtypes = [vp, vp, vp, vp, vp, ll, vp, vp, ci, ci, ci, ci, fl, vp]
+        for name in ("vpx_trajgru_workspace_bytes", "vpx_trajgru_reserve_bytes"):
+            getattr(L, name).restype = sz
+            getattr(L, name).argtypes = [ctypes.POINTER(TrajGRUDesc)]
+        L.vpx_trajgru_seq_fwd.restype = ci
+        L.vpx_trajgru_seq_fwd.argtypes = [ctypes.POINTER(TrajGRUDesc), vp, vp, vp, vp, vp, sz, vp, sz, vp]
+        L.vpx_trajgru_seq_bwd.restype = ci
+        L.vpx_trajgru_seq_bwd.argtypes = [ctypes.POINTER(TrajGRUDesc), vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, sz, vp]
         L.vpx_conv2d_ex_fwd_split.restype = ci
         L.vpx_conv2d_ex_fwd_split.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 5 + [vp, sz, vp]
         L.vpx_conv2d_ex_takes_split.restype = ci

@@ -416,10 +416,6 @@ class _ConvExFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, padding, transposed, slope, precision, out_pad=(0, 0)):
         kh, kw = int(w.shape[2]), int(w.shape[3])
-        if any(ctx.needs_input_grad[:3]) and (kh < stride or kw < stride or slope < 0.0):
-            raise _lib.VpxError(f"conv2d_ex: layer (k={kh}x{kw}, stride={stride}, transposed={bool(transposed)}, slope={slope}) has no backward "
-                                f"in the library (vpx_conv2d_ex_bwd needs kernel >= stride and a non-negative LeakyReLU slope): "
-                                f"unsupported in a call that requires gradients")
         _require_gpu(x, "conv2d_ex")
         xs = to_channels_last(x)
         N, Ci, H, Wd = xs.shape
@@ -473,6 +469,12 @@ class _ConvExFn(torch.autograd.Function):
 
 def conv2d_ex(x, w, bias, stride, padding, transposed=False, leaky_slope=0.0, precision="f32", output_padding=(0, 0)):
     """Conv2d / ConvTranspose2d (stride 1 or 2; `output_padding` for transposed layers) + bias + LeakyReLU, differentiable."""
+    kh, kw = int(w.shape[2]), int(w.shape[3])
+    # (decided here: inside Function.forward grad mode is always off and needs_input_grad ignores torch.no_grad())
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, bias)) and (kh < stride or kw < stride or leaky_slope < 0.0):
+        raise _lib.VpxError(f"conv2d_ex: layer (k={kh}x{kw}, stride={stride}, transposed={bool(transposed)}, slope={leaky_slope}) has no backward "
+                            f"in the library (vpx_conv2d_ex_bwd needs kernel >= stride and a non-negative LeakyReLU slope): "
+                            f"unsupported in a call that requires gradients")
     return _ConvExFn.apply(x, w, bias, stride, padding, transposed, leaky_slope, PRECISIONS[precision], tuple(output_padding))
 
 
