@@ -134,6 +134,8 @@ class Runner:
         self.model = MODEL_CLASSES[spec.model](str(dev), **kw).to(dev)
         if os.environ.get("VPX_BENCH_FUSE_REVERSED") in ("0", "1") and hasattr(self.model, "fuse_reversed_pass"):   # A/B runs (tools/)
             self.model.fuse_reversed_pass = os.environ["VPX_BENCH_FUSE_REVERSED"] == "1"
+        if os.environ.get("VPX_BENCH_DEFER_WGRAD") in ("0", "1") and hasattr(self.model, "defer_weight_gradients"):   # A/B runs (tools/)
+            self.model.defer_weight_gradients = os.environ["VPX_BENCH_DEFER_WGRAD"] == "1"
         with torch.no_grad():
             for n, p in self.model.named_parameters():
                 if n.split(".")[-1] in ("Wci", "Wcf", "Wco"):

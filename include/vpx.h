@@ -162,9 +162,21 @@ size_t vpx_stlstm_reserve_bytes(const vpx_stlstm_desc* d);
  *            three, backward all five; a NULL entry is converted by the library as before)
  *   out[3] = {h_new, c_new, m_new}: NULL or caller buffers of B*H*W*Ch*4 bytes the forward fills with these outputs in the split
  *            format (ignored by the backward)
+ *   dg8_out (backward only; NULL = off): DEFERRED WEIGHT GRADIENTS. The step writes its d(pre-activations) dG8 [B][H*W][8Ch]
+ *            (gate blocks i,f,g | o | i',f',g' + d conv_last; split format, B*H*W*8Ch*4 bytes) there, computes the data gradients as
+ *            usual and leaves dWx .. dWlast alone (they may be NULL). The caller keeps the dG8 of the T steps of one cell and the five
+ *            sources x, h, m, c_new, m_new (split format) in dense slabs [T][B][H*W][C] and calls vpx_stlstm_wgrad_batch ONCE with a
+ *            descriptor whose B is T*B: the same kernel over all the steps' images — one launch, one slab reduction and no per-step
+ *            accumulation of the results. Available where vpx_stlstm_defers_wgrad(d) says 1 (5x5, bf16x3, channels in 8s, no LayerNorm).
  *   NHWC layout only (ignored otherwise). `shadows` may be NULL: vpx_stlstm_step_fwd / _bwd are exactly that. */
-typedef struct vpx_stlstm_shadows { const void* in[5]; void* out[3]; } vpx_stlstm_shadows;
+typedef struct vpx_stlstm_shadows { const void* in[5]; void* out[3]; void* dg8_out; } vpx_stlstm_shadows;
 int vpx_stlstm_uses_split(const vpx_stlstm_desc* d);
+int vpx_stlstm_defers_wgrad(const vpx_stlstm_desc* d);
+size_t vpx_stlstm_wgrad_batch_workspace_bytes(const vpx_stlstm_desc* d);   /* d->B = all images of the batch (T*B) */
+/* dg8_split [N][H*W][8Ch], src5_split = {x [N][H*W][Cin], h, m, c_new, m_new [N][H*W][Ch]} with N = d->B, all in the split format;
+ * weight gradients in reference layout (as vpx_stlstm_step_bwd), OVERWRITTEN. */
+int vpx_stlstm_wgrad_batch(const vpx_stlstm_desc* d, const void* dg8_split, const void* const* src5_split, float* dWx, float* dWh,
+                           float* dWm, float* dWo, float* dWlast, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weights in reference layout: Wx [7Ch,Cin,k,k] Wh [4Ch,Ch,k,k] Wm [3Ch,Ch,k,k] Wo [Ch,2Ch,k,k] Wlast [Ch,2Ch,1,1].
  * ln: NULL or 8 pointers {x_gamma,x_beta,h_gamma,h_beta,m_gamma,m_beta,o_gamma,o_beta}, each in reference [C,H,W]. */

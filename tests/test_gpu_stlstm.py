@@ -141,7 +141,9 @@ def test_predrnn_train_iter_vs_golden(vpx):
 def test_fused_reversed_pass_equals_two_passes(vpx, mode):
     """training_loss with the sequence and its time-reversal as ONE batch of 2B samples (fuse_reversed_pass, the default) against the
     reference's two passes one after the other (predrnn_v2.py:326-352): same sampling masks from the same RNG stream (real coin flips:
-    sampling_eta ~ 0.5), same schedule state afterwards, loss and every gradient equal up to fp32 summation order."""
+    sampling_eta ~ 0.5), same schedule state afterwards, loss and every gradient equal up to fp32 summation order. Crossed with
+    defer_weight_gradients (ops.STWeightBank: a cell's weight gradients once per pass over all its steps; the action-conditional model
+    has no such path and must simply ignore the switch)."""
     from golden_util import seeded_randn
     from vp_suite_amd.measure import PredictionLossProvider
     lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
@@ -162,21 +164,23 @@ def test_fused_reversed_pass_equals_two_passes(vpx, mode):
     frames = seeded_rand((B, Ttot, c, h, w), name_seed(f"predrnn.{tag}.frames")).cuda()
     actions = seeded_randn((B, Ttot, kw["action_size"]), name_seed(f"predrnn.{tag}.actions")).cuda() if mode == "action" else None
     res = {}
-    for fused in (True, False):
+    for fused, defer in ((True, True), (True, False), (False, True), (False, False)):
         m = make()
-        m.fuse_reversed_pass = fused
+        m.fuse_reversed_pass, m.defer_weight_gradients = fused, defer
         m.sampling_eta, m.training_iteration = 0.5, 30000   # both schedules in their stochastic range
         torch.manual_seed(1234)
         kwargs = {"actions": actions} if actions is not None else {}
         loss = m.training_loss(frames, frames[:, Ttot - P:], P, lp, **kwargs)
         loss.backward()
         named = dict(m.named_parameters())
-        res[fused] = (float(loss), np.concatenate([named[k].grad.detach().cpu().numpy().reshape(-1) for k in sorted(named)]),
-                      m.sampling_eta, m.training_iteration, float(torch.rand(1, device="cuda")))
-    a, b = res[True], res[False]
-    assert abs(a[0] - b[0]) < 2e-6 * abs(b[0])
-    assert _relmax(a[1], b[1]) < 2e-5
-    assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4]   # schedule state and the RNG stream's position
+        res[(fused, defer)] = (float(loss), np.concatenate([named[k].grad.detach().cpu().numpy().reshape(-1) for k in sorted(named)]),
+                               m.sampling_eta, m.training_iteration, float(torch.rand(1, device="cuda")))
+    b = res[(False, False)]   # the reference's schedule: two passes, every step's weight gradients on their own
+    for key in ((True, True), (True, False), (False, True)):
+        a = res[key]
+        assert abs(a[0] - b[0]) < 2e-6 * abs(b[0]), key
+        assert _relmax(a[1], b[1]) < 2e-5, key
+        assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4], key   # schedule state and the RNG stream's position
 
 
 def test_predrnn_full_size_vs_golden(vpx):

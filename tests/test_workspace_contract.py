@@ -174,6 +174,21 @@ def test_stlstm_step(L, det, prec):
                                                        _fake(21) if wantx else None, _fake(22) if wanth else None, _fake(23), _fake(24),
                                                        *[_fake(i) for i in range(25, 30)], dlnarr, ctypes.c_void_p(WS_BASE_ODD), nb, None)
                             _ok(L, rc, tag + f" bwd dx={wantx} dh={wanth}")
+                        if not ln and layout == 0 and L.vpx_stlstm_defers_wgrad(ctypes.byref(d)):
+                            # deferred weight gradients: the step writes dG8 to the caller's slot; the batch call takes T*B images
+                            sh = _lib.STLSTMShadows((ctypes.c_void_p * 5)(*[0x400000000000 + i * (1 << 34) for i in range(5)]), (ctypes.c_void_p * 3)(),
+                                                    0x500000000000)
+                            rc = L.vpx_stlstm_step_bwd_ex(ctypes.byref(d), *[_fake(i) for i in range(1, 12)], lnarr, _fake(15), rs,
+                                                          *[_fake(i) for i in range(16, 21)], _fake(21), _fake(22), _fake(23), _fake(24),
+                                                          None, None, None, None, None, dlnarr, ctypes.c_void_p(WS_BASE), nb, None, ctypes.byref(sh))
+                            _ok(L, rc, tag + " bwd (deferred weight gradients)", allow_unsupported=False)
+                            for T in (1, 19, 39):
+                                dT = STLSTMDesc(T * B, Cin, Ch, H, W, k, 0, 0, prec, _lib.FLAG_SAVE_FOR_BWD)
+                                nbb = L.vpx_stlstm_wgrad_batch_workspace_bytes(ctypes.byref(dT))
+                                assert nbb > 0
+                                rc = L.vpx_stlstm_wgrad_batch(ctypes.byref(dT), _fake(1), (ctypes.c_void_p * 5)(*[0x400000000000 + i * (1 << 34) for i in range(5)]),
+                                                              *[_fake(i) for i in range(25, 30)], ctypes.c_void_p(WS_BASE_ODD), nbb, None)
+                                _ok(L, rc, tag + f" wgrad_batch T={T}", allow_unsupported=False)
         finally:
             L.vpx_set_option(_lib.OPT_EXPERIMENT, prev)
 

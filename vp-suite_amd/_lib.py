@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "vpx_convlstm_seq_bwd",
     "vpx_stlstm_workspace_bytes", "vpx_stlstm_reserve_bytes", "vpx_stlstm_step_fwd", "vpx_stlstm_step_bwd",
     "vpx_stlstm_uses_split", "vpx_stlstm_step_fwd_ex", "vpx_stlstm_step_bwd_ex",
+    "vpx_stlstm_defers_wgrad", "vpx_stlstm_wgrad_batch_workspace_bytes", "vpx_stlstm_wgrad_batch",
     "vpx_decouple_workspace_bytes", "vpx_decouple_fwd", "vpx_decouple_bwd",
     "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_conv2d_bwd_workspace_bytes", "vpx_conv2d_nhwc_bwd",
     "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd", "vpx_conv2d_ex_fwd_split",
@@ -67,7 +68,7 @@ class TrajGRUDesc(ctypes.Structure):
 
 class STLSTMShadows(ctypes.Structure):
     """vpx_stlstm_shadows: split-format copies of (x, h, m, c_new, m_new) handed in, buffers for (h_new, c_new, m_new) handed out."""
-    _fields_ = [("inp", ctypes.c_void_p * 5), ("out", ctypes.c_void_p * 3)]
+    _fields_ = [("inp", ctypes.c_void_p * 5), ("out", ctypes.c_void_p * 3), ("dg8_out", ctypes.c_void_p)]
 
 
 class VpxError(RuntimeError):
@@ -125,6 +126,12 @@ def lib():
         L.vpx_stlstm_step_fwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 9 + [vp] + [vp] * 5 + [vp, sz, vp, sz, vp]
         L.vpx_stlstm_step_bwd.restype = ctypes.c_int
         L.vpx_stlstm_step_bwd.argtypes = [ctypes.POINTER(STLSTMDesc)] + [vp] * 11 + [vp] + [vp, sz] + [vp] * 5 + [vp] * 9 + [vp] + [vp, sz, vp]
+        L.vpx_stlstm_defers_wgrad.restype = ctypes.c_int
+        L.vpx_stlstm_defers_wgrad.argtypes = [ctypes.POINTER(STLSTMDesc)]
+        L.vpx_stlstm_wgrad_batch_workspace_bytes.restype = sz
+        L.vpx_stlstm_wgrad_batch_workspace_bytes.argtypes = [ctypes.POINTER(STLSTMDesc)]
+        L.vpx_stlstm_wgrad_batch.restype = ctypes.c_int
+        L.vpx_stlstm_wgrad_batch.argtypes = [ctypes.POINTER(STLSTMDesc), vp, vp] + [vp] * 5 + [vp, sz, vp]
         L.vpx_stlstm_step_fwd_ex.restype = ctypes.c_int
         L.vpx_stlstm_step_fwd_ex.argtypes = L.vpx_stlstm_step_fwd.argtypes + [ctypes.POINTER(STLSTMShadows)]
         L.vpx_stlstm_step_bwd_ex.restype = ctypes.c_int

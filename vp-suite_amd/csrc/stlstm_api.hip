@@ -144,6 +144,7 @@ STSplitShadows st_shadows_of(const vpx_stlstm_shadows* p) {
     if (!p) return s;
     for (int i = 0; i < 5; ++i) s.in[i] = reinterpret_cast<const char*>(p->in[i]);
     for (int i = 0; i < 3; ++i) s.out[i] = reinterpret_cast<char*>(p->out[i]);
+    s.dg8 = reinterpret_cast<char*>(p->dg8_out);
     s.set = 1;
     return s;
 }

@@ -224,6 +224,11 @@ extern "C" int vpx_stlstm_step_bwd_ex(const vpx_stlstm_desc* d, const float* x, 
     const bool packed = (d->flags & VPX_FLAG_WEIGHTS_PACKED) != 0;
     Carver ws(workspace, workspace_bytes);
     float* dG7 = ws.take(L.n_g7);
+    // deferred weight gradients (vpx_stlstm_shadows::dg8_out): this step's dG8 goes to the caller's slab slot in the split format and the
+    // five weight gradients are left to ONE vpx_stlstm_wgrad_batch call over all the steps of the cell
+    const bool defer = sh.dg8 != nullptr;
+    if (defer && !L.stw) { set_error("vpx_stlstm_step_bwd_ex: dg8_out given, but this descriptor's weight gradients cannot be deferred (vpx_stlstm_defers_wgrad)"); return VPX_ERR_UNSUPPORTED; }
+    if (defer) dG7 = reinterpret_cast<float*>(sh.dg8);
     float* dlc = ws.take(L.n_state);
     float* dcn_conv = ws.take(L.n_state);
     float* dmn_conv = ws.take(L.n_state);
@@ -302,7 +307,7 @@ extern "C" int vpx_stlstm_step_bwd_ex(const vpx_stlstm_desc* d, const float* x, 
     };
     // The one-launch weight gradient wants dG7 in the split operand format: the two pointwise stages then write that format ONLY
     // (the data-gradient convolutions read it without conversion, ConvSeg.split) — no fp32 dG7, no conversion pass.
-    const bool stw = L.stw && dWx && dWh && dWm && dWo && dWlast;
+    const bool stw = L.stw && (defer || (dWx && dWh && dWm && dWo && dWlast));
     const int g7s = stw ? 1 : 0;
     const int ldG = stw ? 8 * Ch : 7 * Ch;   // stw: dG8 = the seven gate blocks + d conv_last (block 7), all in the split format
     // ---- A: through h_new = o * tanh(conv_last(mem)) ----
@@ -465,7 +470,7 @@ extern "C" int vpx_stlstm_step_bwd_ex(const vpx_stlstm_desc* d, const float* x, 
         VPX_CHECK_HIP(launch_conv_plain_f32(P, ea, L.m.tiles, stream));
     }
     // ---- E: weight gradients ----
-    if (stw) {
+    if (stw && !defer) {
         // all four k x k tensors in one launch (wgrad2.hip, stw): operands once more in the split format
         static thread_local STWArgs sa; static thread_local STWOut so;
         if (stw_build(sa, so, B, H, Wd, Cin, Ch) != L.stw_pairs) { set_error("stlstm bwd: pair table changed"); return VPX_ERR_ARG; }
@@ -498,5 +503,48 @@ extern "C" int vpx_stlstm_step_bwd_ex(const vpx_stlstm_desc* d, const float* x, 
         if (dc) VPX_CHECK_HIP(launch_nhwc_to_nchw(dcn, dc, B, Ch, H, Wd, stream));
         if (dm) VPX_CHECK_HIP(launch_nhwc_to_nchw(dmn, dm, B, Ch, H, Wd, stream));
     }
+    return VPX_OK;
+}
+
+// ---- deferred weight gradients: all the steps of one cell in ONE launch ---------------------------------------------------------
+// The one-launch kernel (stw, wgrad2.hip) walks items = (image, 4 x 16-pixel tile); a step's images are just more images. With every
+// operand of the T steps in a dense slab [T][B][HW][C] (split format) the batch is the same launch over T * B images: one slab write
+// and one slice reduction per cell and training step instead of one per cell STEP (at B = 2..4 per GPU those two were a third of the
+// kernel's time, and the per-step results cost autograd one accumulation launch per weight tensor and step).
+extern "C" int vpx_stlstm_defers_wgrad(const vpx_stlstm_desc* d) {
+    if (!d || d->layout != VPX_LAYOUT_NHWC || d->B < 1 || d->H < 1 || d->W < 1 || d->Cin < 1 || d->Ch < 1) return 0;
+    if (!stw_applicable(d)) return 0;
+    static thread_local STWArgs sa; static thread_local STWOut so;
+    return stw_build(sa, so, d->B, d->H, d->W, d->Cin, d->Ch) >= 1 ? 1 : 0;
+}
+
+extern "C" size_t vpx_stlstm_wgrad_batch_workspace_bytes(const vpx_stlstm_desc* d) {
+    if (!vpx_stlstm_defers_wgrad(d)) return 0;
+    static thread_local STWArgs sa; static thread_local STWOut so;
+    if (stw_build(sa, so, d->B, d->H, d->W, d->Cin, d->Ch) < 1) return 0;
+    const int ns = stw_slices(sa.npairs5, (long long)d->B * ((d->W + 15) / 16) * ((d->H + 3) / 4));
+    return align256(sa.slab_stride * (size_t)ns * 4) + 512;
+}
+
+extern "C" int vpx_stlstm_wgrad_batch(const vpx_stlstm_desc* d, const void* dg8_split, const void* const* src5_split, float* dWx, float* dWh,
+                                      float* dWm, float* dWo, float* dWlast, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!vpx_stlstm_defers_wgrad(d)) { set_error("vpx_stlstm_wgrad_batch: not available for this descriptor (vpx_stlstm_defers_wgrad)"); return VPX_ERR_UNSUPPORTED; }
+    if (!dg8_split || !src5_split || !dWx || !dWh || !dWm || !dWo || !dWlast) { set_error("vpx_stlstm_wgrad_batch: NULL tensor argument"); return VPX_ERR_ARG; }
+    for (int i = 0; i < 5; ++i) if (!src5_split[i]) { set_error("vpx_stlstm_wgrad_batch: source %d is NULL", i); return VPX_ERR_ARG; }
+    if ((long long)d->B * ((d->W + 15) / 16) * ((d->H + 3) / 4) > 0x7fffffffll) { set_error("vpx_stlstm_wgrad_batch: too many items"); return VPX_ERR_UNSUPPORTED; }
+    const size_t need = vpx_stlstm_wgrad_batch_workspace_bytes(d);
+    if (!workspace || workspace_bytes < need) { set_error("vpx_stlstm_wgrad_batch: workspace too small"); return VPX_ERR_WORKSPACE; }
+    static thread_local STWArgs sa; static thread_local STWOut so;
+    if (stw_build(sa, so, d->B, d->H, d->W, d->Cin, d->Ch) < 1) { set_error("vpx_stlstm_wgrad_batch: pair table"); return VPX_ERR_UNSUPPORTED; }
+    const int ns = stw_slices(sa.npairs5, (long long)d->B * ((d->W + 15) / 16) * ((d->H + 3) / 4));
+    Carver ws(workspace, workspace_bytes);
+    float* slabs = ws.take(sa.slab_stride * (size_t)ns);
+    VPX_CHECK_CARVE(ws, "vpx_stlstm_wgrad_batch");
+    sa.g_sp = reinterpret_cast<const char*>(dg8_split);
+    sa.src[0] = STWSrc{reinterpret_cast<const char*>(src5_split[0]), d->Cin};
+    for (int i = 1; i < 5; ++i) sa.src[i] = STWSrc{reinterpret_cast<const char*>(src5_split[i]), d->Ch};
+    sa.n_slices = ns; sa.slabs = slabs;
+    so.dW[0] = dWx; so.dW[1] = dWh; so.dW[2] = dWm; so.dW[3] = dWo; so.dW[4] = dWlast;
+    VPX_CHECK_HIP(launch_stw(sa, so, (hipStream_t)stream_));
     return VPX_OK;
 }

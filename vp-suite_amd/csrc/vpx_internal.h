@@ -490,7 +490,7 @@ struct STGatesKSArgs {
     float *c_new, *m_new, *delta_c, *delta_m, *o_pre, *gates_c, *gates_m;   // gates_*: [B,HW,3Ch] or null
     char *cn_sp, *mn_sp;                     // c_new / m_new once more in the split format, or null
 };
-struct STSplitShadows { const char* in[5]; char* out[3]; int set; };   // vpx_stlstm_shadows of the running call (stlstm_api.hip)
+struct STSplitShadows { const char* in[5]; char* out[3]; char* dg8; int set; };   // vpx_stlstm_shadows of the running call (stlstm_api.hip)
 STSplitShadows st_shadows_of(const vpx_stlstm_shadows* p);
 struct STOutKSArgs {
     char* h_sp; int Ch;                      // h_new once more in the split format, or null

@@ -24,6 +24,40 @@ from ..model_blocks import ActionConditionalSpatioTemporalLSTMCell as ACSTCell
 from ..model_blocks import SpatioTemporalLSTMCell as STCell
 
 
+class _CellBanks:
+    """The operand slabs of one training forward (split operand format, time-major, dense) and one ops.STWeightBank per cell.
+    Slot s of a state slab = that state after step s - 1 (slot 0: the zero initial state), so every operand of step t of every cell is
+    slot t (+ a constant) of ONE slab: h of cell i: H[i] slot t; x of cell i > 0: H[i-1] slot t + 1; m of cell 0: M[L-1] slot t (the
+    zig-zag memory of the previous step's top cell), of cell i > 0: M[i-1] slot t + 1; the step's own c_new / m_new: slot t + 1 of C[i] /
+    M[i]; the frames entering cell 0: X slot t (converted by the step)."""
+
+    def __init__(self, model, geo, T):
+        dev = model.adapter.weight.device
+        self.L = L = len(geo)
+        new = lambda slots, n: torch.empty(slots, n, dtype=torch.float32, device=dev)   # noqa: E731
+        b, cin0, ch, h, w, k = geo[0]
+        n = b * h * w * ch
+        self.H, self.C, self.M = [new(T + 1, n) for _ in range(L)], [new(T + 1, n) for _ in range(L)], [new(T + 1, n) for _ in range(L)]
+        for slab in self.H + self.M:
+            slab[0].zero_()
+        self.X = new(T, b * h * w * cin0)
+        self.banks, self.weights = [], []
+        for i, g in enumerate(geo):
+            cell = model.cell_list[i]
+            bank = ops.STWeightBank((cell.conv_x[0].weight, cell.conv_h[0].weight, cell.conv_m[0].weight, cell.conv_o[0].weight, cell.conv_last.weight),
+                                    *g, T, ops.PRECISIONS[model.cell_precision])
+            bank.set_sources(self.X[0] if i == 0 else self.H[i - 1][1], self.H[i][0], self.M[L - 1][0] if i == 0 else self.M[i - 1][1],
+                             self.C[i][1], self.M[i][1])
+            self.banks.append(bank)
+            self.weights.append(bank.weights())
+
+    def step(self, cell, i, t, x, h, c, m):
+        x_sp = self.X[t] if i == 0 else self.H[i - 1][t + 1]
+        m_sp = self.M[self.L - 1][t] if i == 0 else self.M[i - 1][t + 1]
+        slots = (self.banks[i], t, (x_sp, self.H[i][t], m_sp), (self.H[i][t + 1], self.C[i][t + 1], self.M[i][t + 1]), i == 0)
+        return ops.stlstm_step(x, h, c, m, *self.weights[i], precision=cell.precision, wsholder=cell._ws, slots=slots)
+
+
 class PredRNN_V2(VPModel):
     NAME = "PredRNN++"
     PAPER_REFERENCE = "https://arxiv.org/abs/2103.09504"
@@ -58,6 +92,10 @@ class PredRNN_V2(VPModel):
     #: weights and nothing else, so this is the same arithmetic per sample with every launch on twice the grid and half the launches
     #: (what the 2-sample shards of BASELINE configs[4] need most). False: two forward passes one after the other, as the reference does.
     fuse_reversed_pass: bool = True
+    #: training: the five weight gradients of a cell are computed ONCE per forward pass over all of its steps (ops.STWeightBank) instead of
+    #: once per step with an autograd accumulation per step and tensor. Same sums in another order. Where the library cannot (LayerNorm,
+    #: action-conditional cells, operand modes other than bf16x3, filter sizes other than 5) the steps compute them as before.
+    defer_weight_gradients: bool = True
 
     def __init__(self, device, **model_kwargs):
         super().__init__(device, **model_kwargs)
@@ -139,6 +177,7 @@ class PredRNN_V2(VPModel):
         ops.new_shadow_epoch()
         for cell in self.cell_list:
             cell.use_shadows = True
+        banks = self._weight_banks(b, total_frames - 1) if (train and torch.is_grad_enabled()) else None
 
         def zeros(i):
             return torch.zeros(b, nh[i], self.rnn_h, self.rnn_w, device=dev)
@@ -174,6 +213,8 @@ class PredRNN_V2(VPModel):
                 inp = net if i == 0 else h_t[i - 1]
                 if self.action_conditional:
                     h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory, action)
+                elif banks is not None:
+                    h_t[i], c_t[i], memory, d_c, d_m = banks.step(self.cell_list[i], i, t, inp, h_t[i], c_t[i], memory)
                 else:
                     h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory)
                 decouple.append(self._decouple_term(d_c, d_m))
@@ -187,6 +228,16 @@ class PredRNN_V2(VPModel):
         pred = self._reshape_patch_back(torch.stack(next_frames[-pred_frames:], dim=1))
         loss = torch.mean(torch.stack(decouple, dim=0))
         return pred, {"ST-LSTM decouple loss": self.decoupling_loss_scale * loss}
+
+    def _weight_banks(self, b, T):
+        """ops.STWeightBank per cell for one training forward of T steps (defer_weight_gradients), or None where the library cannot."""
+        if not self.defer_weight_gradients or self.action_conditional or self.layer_norm or len(set(self.num_hidden[:self.num_layers])) != 1:
+            return None
+        cin = [self.patch_c] + list(self.num_hidden[:self.num_layers - 1])
+        geo = [(b, cin[i], self.num_hidden[i], self.rnn_h, self.rnn_w, self.filter_size) for i in range(self.num_layers)]
+        if not all(ops.STWeightBank.available(*g, self.cell_precision) for g in geo):
+            return None
+        return _CellBanks(self, geo, T)
 
     # ---- patch (un)folding: channel order (p_h, p_w, c)  (predrnn_v2.py:232-250) ----
     def _reshape_patch(self, x):

@@ -771,12 +771,81 @@ def _shadow_of(t, tl, channels):
     return buf
 
 
+class STWeightBank:
+    """Deferred weight gradients of ONE ST-LSTM cell over the T steps of one training forward (include/vpx.h: dg8_out,
+    vpx_stlstm_wgrad_batch). The owner (PredRNN_V2.forward) lays the cell's operands out as dense time-major slabs in the split operand
+    format and hands every step its slots explicitly:
+        g       [T][B*HW*8Ch]   dG8 of step t — written by the step's backward
+        sources five tensors, each the slot of step 0 of a slab whose slot t (stride = one slot) is that operand of step t:
+                x, h, m (inputs of the step) and c_new, m_new (its outputs)
+    `weights()` passes the five weight tensors through an identity autograd node; the steps take THOSE. Their backward deposits dG8 and
+    returns no weight gradient; when autograd reaches the identity node — every step of the cell has run its backward by then — `run()`
+    computes the five gradients of all T steps in one launch and returns them as the node's input gradients."""
+
+    def __init__(self, weights5, B, Cin, Ch, H, W, k, T, precision):
+        self.w5 = tuple(weights5)
+        self.geo = (int(B), int(Cin), int(Ch), int(H), int(W), int(k), int(T), int(precision))
+        dev = self.w5[0].device
+        self.g = torch.empty(T, B * H * W * 8 * Ch, dtype=torch.float32, device=dev)
+        self.sources = None
+        self.deposited = set()
+
+    @staticmethod
+    def available(B, Cin, Ch, H, W, k, precision):
+        d = STLSTMDesc(B, Cin, Ch, H, W, k, 0, _lib.LAYOUT_NHWC, PRECISIONS[precision], _lib.FLAG_SAVE_FOR_BWD)
+        L = _lib.lib()
+        return bool(L.vpx_stlstm_defers_wgrad(ctypes.byref(d))) and bool(L.vpx_stlstm_uses_split(ctypes.byref(d)))
+
+    def set_sources(self, x, h, m, c_new, m_new):
+        """Each argument: the slot-0 tensor (1-D, one slot long) of the operand's slab; slots t = 1 .. T-1 follow it in memory."""
+        self.sources = (x, h, m, c_new, m_new)
+
+    def weights(self):
+        return _BankFn.apply(self, *self.w5)
+
+    def run(self):
+        B, Cin, Ch, H, W, k, T, prec = self.geo
+        if self.sources is None:
+            raise _lib.VpxError("STWeightBank: set_sources was never called")
+        for t in range(T):
+            if t not in self.deposited:     # a step whose outputs reached no loss: its dG8 is zero
+                self.g[t].zero_()
+        d = STLSTMDesc(T * B, Cin, Ch, H, W, k, 0, _lib.LAYOUT_NHWC, prec, _lib.FLAG_SAVE_FOR_BWD)
+        L = _lib.lib()
+        nb = L.vpx_stlstm_wgrad_batch_workspace_bytes(ctypes.byref(d))
+        if nb == 0:
+            raise _lib.VpxError("STWeightBank: vpx_stlstm_wgrad_batch is not available for this cell")
+        ws = torch.empty(nb, dtype=torch.uint8, device=self.g.device)
+        dWs = [torch.empty_like(w) for w in self.w5]
+        src = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in self.sources])
+        check(L.vpx_stlstm_wgrad_batch(ctypes.byref(d), ptr(self.g), src, *[ptr(g) for g in dWs], ptr(ws), nb, _stream()), "vpx_stlstm_wgrad_batch")
+        self.deposited.clear()
+        return dWs
+
+
+class _BankFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, bank, *w5):
+        ctx.bank = bank
+        ctx.set_materialize_grads(False)
+        return tuple(w.view_as(w) for w in w5)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        _sync_determinism()
+        dWs = ctx.bank.run()
+        for i, g in enumerate(grads):       # (a consumer that did not defer — none today — adds its gradient the ordinary way)
+            if g is not None:
+                dWs[i] = dWs[i] + g
+        return (None, *dWs)
+
+
 class _STLSTMStepFn(torch.autograd.Function):
     """(h_new, c_new, m_new, delta_c, delta_m) = ST-LSTM cell step (predrnn.py:57-83) in one library call.
     `ln` = () or the 8 LayerNorm tensors (x_gamma, x_beta, h_gamma, h_beta, m_gamma, m_beta, o_gamma, o_beta)."""
 
     @staticmethod
-    def forward(ctx, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision, need_grad, wsholder, use_shadows, *ln):
+    def forward(ctx, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision, need_grad, wsholder, use_shadows, slots, *ln):
         _require_gpu(x, "stlstm_step")
         dev = x.device
         B, Cin, H, Wd = x.shape
@@ -810,11 +879,25 @@ class _STLSTMStepFn(torch.autograd.Function):
         # converted again (h_new is the next step's h and the next layer's x, m_new the next layer's m), and this step's h_new / c_new /
         # m_new come back with shadows of their own
         sp_in, sp_out, shadows = [None] * 5, None, None
-        if use_shadows and not use_ln and L.vpx_stlstm_uses_split(ctypes.byref(d)):
+        bank = None
+        if slots is not None:
+            # explicit operand slots (STWeightBank mode): the owner's slabs hold x, h, m in the split format and receive h_new, c_new, m_new
+            bank, bank_t, slot_in, slot_out, convert_x = slots
+            if use_ln or not need_grad or not L.vpx_stlstm_uses_split(ctypes.byref(d)):
+                raise _lib.VpxError("stlstm_step: operand slots need the split-operand kernels in a call that saves for the backward")
+            sp_in[:3] = list(slot_in)
+            if convert_x:   # an input without a split copy (the first layer's frame): converted into its slot of the owner's x slab
+                check(L.vpx_split_convert(ptr(xs), ptr(sp_in[0]), B * H * Wd, Cin, _stream()), "vpx_split_convert")
+            sp_out = list(slot_out)
+            for buf, n in zip(sp_in[:3] + sp_out, (Cin, Ch, Ch, Ch, Ch, Ch)):
+                if buf.numel() != B * H * Wd * n or not buf.is_contiguous() or buf.dtype != torch.float32:
+                    raise ValueError("stlstm_step: an operand slot does not hold B*H*W*C elements")
+        elif use_shadows and not use_ln and L.vpx_stlstm_uses_split(ctypes.byref(d)):
             sp_in[:3] = [_shadow_of(x, xs, Cin), _shadow_of(h, hs, Ch), _shadow_of(m, ms, Ch)]
             sp_out = [torch.empty(B * H * Wd * Ch, dtype=torch.float32, device=dev) for _ in range(3)]
+        if sp_out is not None:
             shadows = _lib.STLSTMShadows((ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in sp_in]),
-                                         (ctypes.c_void_p * 3)(*[t.data_ptr() for t in sp_out]))
+                                         (ctypes.c_void_p * 3)(*[t.data_ptr() for t in sp_out]), None)
         if PROFILE is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -826,7 +909,7 @@ class _STLSTMStepFn(torch.autograd.Function):
             ev1.record()
             fl, by = stlstm_algorithmic_work(B, Cin, Ch, H, Wd, k)
             PROFILE.records.append((ev0, ev1, fl, by, 4, "stlstm_fwd"))
-        if sp_out is not None:
+        if sp_out is not None and bank is None:
             for t, buf in zip(outs[:3], sp_out):
                 _attach_shadow(t, buf)
         if need_grad:
@@ -838,6 +921,7 @@ class _STLSTMStepFn(torch.autograd.Function):
             ctx.use_ln = use_ln
             ctx.bwd_holder = wsholder.backward_holder() if (wsholder is not None and not use_ln) else None
             ctx.wkey = key
+            ctx.bank = None if bank is None else (bank, bank_t)
         return tuple(outs)
 
     @staticmethod
@@ -855,29 +939,33 @@ class _STLSTMStepFn(torch.autograd.Function):
         dh = new_channels_last(tuple(hs.shape), dev) if needs[1] else None
         dc = new_channels_last(tuple(cs.shape), dev) if needs[2] else None
         dm = new_channels_last(tuple(ms.shape), dev) if needs[3] else None
-        dWs = [torch.empty_like(w) if needs[4 + i] else None for i, w in enumerate((Wx, Wh, Wm, Wo, Wlast))]
-        dln = [torch.empty_like(t) if needs[13 + i] else None for i, t in enumerate(lnc)]
+        bank = getattr(ctx, "bank", None)
+        dWs = [torch.empty_like(w) if (needs[4 + i] and bank is None) else None for i, w in enumerate((Wx, Wh, Wm, Wo, Wlast))]
+        dln = [torch.empty_like(t) if needs[14 + i] else None for i, t in enumerate(lnc)]
         ln_arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in lnc]) if ctx.use_ln else None
         dln_arr = (ctypes.c_void_p * 8)(*[None if t is None else t.data_ptr() for t in dln]) if ctx.use_ln else None
         ws_bytes = L.vpx_stlstm_workspace_bytes(ctypes.byref(d))
         flags0 = d.flags
         if ctx.bwd_holder is not None and BWD_WEIGHT_PACK_REUSE:
             # (which transposed packs a call makes depends on the data gradients it is asked for)
-            ws, packed = ctx.bwd_holder.get(ws_bytes, dev, (ctx.wkey, dx is not None, dh is not None, dm is not None))
+            ws, packed = ctx.bwd_holder.get(ws_bytes, dev, (ctx.wkey, dx is not None, dh is not None, dm is not None, bank is not None))
             if packed:
                 d.flags = flags0 | _lib.FLAG_WEIGHTS_PACKED
         else:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         shadows = None
         if getattr(ctx, "sp", None) is not None:   # the forward's split shadows: the weight-gradient kernel stages them as they are
-            shadows = _lib.STLSTMShadows((ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in ctx.sp]), (ctypes.c_void_p * 3)())
+            shadows = _lib.STLSTMShadows((ctypes.c_void_p * 5)(*[None if t is None else t.data_ptr() for t in ctx.sp]), (ctypes.c_void_p * 3)(),
+                                         None if bank is None else bank[0].g[bank[1]].data_ptr())
         rc = L.vpx_stlstm_step_bwd_ex(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), ptr(c_new), ptr(m_new), ptr(Wx),
                                       ptr(Wh), ptr(Wm), ptr(Wo), ptr(Wlast), ln_arr, ptr(reserve), ctx.rs_bytes,
                                       *[ptr(g) for g in gin], ptr(dx), ptr(dh), ptr(dc), ptr(dm), *[ptr(g) for g in dWs],
                                       dln_arr, ptr(ws), ws_bytes, _stream(), None if shadows is None else ctypes.byref(shadows))
         d.flags = flags0
         check(rc, "vpx_stlstm_step_bwd")
-        return (dx, dh, dc, dm, *dWs, None, None, None, None, *dln)
+        if bank is not None:
+            bank[0].deposited.add(bank[1])
+        return (dx, dh, dc, dm, *dWs, None, None, None, None, None, *dln)
 
 
 def stlstm_algorithmic_work(B, Cin, Ch, H, W, k, dt=4):
@@ -888,16 +976,19 @@ def stlstm_algorithmic_work(B, Cin, Ch, H, W, k, dt=4):
     return flops, nbytes
 
 
-def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=None, ln=(), use_shadows=False):
+def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=None, ln=(), use_shadows=False, slots=None):
     """ln: () or the 8 LayerNorm parameter tensors [C,H,W] (x_gamma, x_beta, h_.., m_.., o_..) of the LayerNorm variant.
     use_shadows: hand h_new / c_new / m_new out with split-format shadows and take the shadows of x / h / m where a previous step of
     the same shadow epoch attached them (no second conversion). Opt-in: the caller vouches that nothing writes those tensors behind
-    the version counter's back between the steps (PredRNN_V2.forward: the tensors never leave its loop)."""
+    the version counter's back between the steps (PredRNN_V2.forward: the tensors never leave its loop).
+    slots: (bank, t, (x_sp, h_sp, m_sp), (h_new_sp, c_new_sp, m_new_sp), convert_x) — STWeightBank mode: the weights must be
+    `bank.weights()`, the operands' split copies live in the owner's slabs (convert_x: x has none yet — converted into x_sp here), the
+    weight gradients of the cell's steps are computed together when autograd reaches the bank."""
     ln = tuple(ln)
     if len(ln) not in (0, 8):
         raise ValueError("stlstm_step: ln must hold 0 or 8 tensors")
     need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (x, h, c, m, Wx, Wh, Wm, Wo, Wlast) + ln)
-    return _STLSTMStepFn.apply(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, PRECISIONS[precision], need_grad, wsholder, bool(use_shadows), *ln)
+    return _STLSTMStepFn.apply(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, PRECISIONS[precision], need_grad, wsholder, bool(use_shadows), slots, *ln)
 
 
 class _LayerNormCHWFn(torch.autograd.Function):
