@@ -132,6 +132,9 @@ class Runner:
         if spec.layers:
             kw["num_layers"] = spec.layers
         self.model = MODEL_CLASSES[spec.model](str(dev), **kw).to(dev)
+        if os.environ.get("VPX_BENCH_EXPERIMENT"):   # A/B runs (tools/): bits of vpx_set_option(VPX_OPT_EXPERIMENT), include/vpx.h
+            from vp_suite_amd import _lib as vlib
+            vlib.lib().vpx_set_option(vlib.OPT_EXPERIMENT, int(os.environ["VPX_BENCH_EXPERIMENT"]))
         if os.environ.get("VPX_BENCH_FUSE_REVERSED") in ("0", "1") and hasattr(self.model, "fuse_reversed_pass"):   # A/B runs (tools/)
             self.model.fuse_reversed_pass = os.environ["VPX_BENCH_FUSE_REVERSED"] == "1"
         if os.environ.get("VPX_BENCH_DEFER_WGRAD") in ("0", "1") and hasattr(self.model, "defer_weight_gradients"):   # A/B runs (tools/)

@@ -158,11 +158,33 @@ def test_conv2d_ex_vs_torch(vpx):
     assert float((y - ref).abs().max()) < 1e-5
 
 
-def _conv2d_ex_cases(vpx, cases, F):
-    for prec, tol in (("f32", 2e-5), ("bf16x3", 5e-5)):
+def test_glue_data_gradient_on_convq_vs_torch_and_first_generation(vpx):
+    """Round 5: the data gradient of a stage-glue layer whose ADJOINT is a layer the schedule-driven kernel takes (bf16x3, >= 64 output
+    channels, a full grid) runs on convq, fed by the LeakyReLU' pass's split-format copy of dy. The EF model's heavy layers
+    (ef_conv_lstm.py:36-65) at 24 frames: against torch autograd and against the first-generation launch (VPX_OPT_EXPERIMENT bit 14)."""
+    import torch.nn.functional as F
+    cases = [  # (transposed, Ci, Co, k, stride, pad, H, W)
+        (False, 64, 64, 3, 2, 1, 64, 64), (False, 96, 96, 3, 2, 1, 32, 32), (True, 96, 96, 4, 2, 1, 16, 16), (True, 96, 96, 4, 2, 1, 32, 32),
+        (True, 64, 16, 3, 1, 1, 64, 64), (False, 64, 96, 3, 2, 1, 33, 47),
+    ]
+    L = vpx._lib.lib()
+    grads = {}
+    for bit in (0, 16384):
+        prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, bit)
+        try:
+            grads[bit] = _conv2d_ex_cases(vpx, cases, F, n=24, precs=(("bf16x3", 5e-5),))
+        finally:
+            L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, prev)
+    for a, b in zip(grads[0], grads[16384]):
+        assert _relmax(a, b) < 2e-5   # same products, same operand split: fp32 summation order only
+
+
+def _conv2d_ex_cases(vpx, cases, F, n=2, precs=(("f32", 2e-5), ("bf16x3", 5e-5))):
+    dxs = []
+    for prec, tol in precs:
         for tr, Ci, Co, k, s, p, H, W in cases:
             tag = f"cex.{tr}.{Ci}.{Co}.{k}.{s}"
-            x = seeded_randn((2, Ci, H, W), name_seed(tag + "x"))
+            x = seeded_randn((n, Ci, H, W), name_seed(tag + "x"))
             wshape = (Ci, Co, k, k) if tr else (Co, Ci, k, k)
             w = seeded_randn(wshape, name_seed(tag + "w"), 1.0 / np.sqrt(Ci * k * k))
             b = seeded_randn((Co,), name_seed(tag + "b"), 0.1)
@@ -180,10 +202,16 @@ def _conv2d_ex_cases(vpx, cases, F):
                 rl = [t.clone().requires_grad_(True) for t in (x, w, b)]
                 rr = F.conv_transpose2d(rl[0], rl[1], rl[2], stride=s, padding=p) if tr else \
                     F.conv2d(rl[0], rl[1], rl[2], stride=s, padding=p)
-                (F.leaky_relu(rr, 0.2) * gy).sum().backward()
+                # LeakyReLU' taken at the sign of OUR forward output, as the library does: where a pre-activation is within rounding of
+                # zero the two forwards may disagree about its sign, and autograd of F.leaky_relu on the reference's own output would
+                # then differ by 0.8 * gy at that element — a property of the activation's kink, not of the gradient kernels
+                slope_map = torch.where(y.detach().cpu() > 0, 1.0, 0.2)
+                (rr * slope_map * gy).sum().backward()
                 (y * gy.cuda()).sum().backward()
                 for a, r in zip(lv, rl):
                     assert _relmax(a.grad, r.grad) < 1e-4, (prec, tag)
+                dxs.append(lv[0].grad.detach().clone())
+    return dxs
 
 
 def test_edge_shapes_vs_oracle(vpx):

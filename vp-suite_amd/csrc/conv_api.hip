@@ -589,14 +589,27 @@ size_t ex_bwd_slab_floats(const vpx_conv_desc* d, const ExGeo& g) {
 
 extern "C" {
 
+// Round 5: the data gradient of a glue layer = its adjoint layer on dy. Where that adjoint is a layer the schedule-driven K = 32 kernel
+// (convq) takes — the same rule as in the forward: bf16x3, >= 64 output channels, a grid that fills the chip — it runs THERE: the pass
+// that scales dy by LeakyReLU' (and sums the bias gradient) writes the scaled gradient once more in the split operand format.
+// VPX_OPT_EXPERIMENT bit 14 keeps the first-generation launch (A/B runs, tests).
+static bool ex_bwd_q(const vpx_conv_desc* d, const vpx_conv_desc* a, ConvQProblem& pr) {
+    if ((g_experiment & 16384) || (d->Co & 7)) return false;
+    const ExGeo ga{d->H, d->W};
+    return exq_preferred(a, ga, pr) && convq_wpk_bytes(pr) != 0;
+}
+
 size_t vpx_conv2d_ex_bwd_workspace_bytes(const vpx_conv_desc* d) {
     ExGeo g;
     vpx_conv_desc a;
     if (ex_check(d, g) != VPX_OK || ex_adjoint(d, g, a) != VPX_OK) return 0;
     // + the LeakyReLU'-scaled copy of dy and the bias-gradient partials
     const size_t n_dy = (size_t)d->N * g.Ho * g.Wo * d->Co;
-    return align256(ex_wpk_floats(&a) * 4) + align256(ex_bwd_slab_floats(d, g) * 4) + align256(n_dy * 4) +
-           align256((size_t)COLSUM_BLOCKS * d->Co * 4) + 1024;
+    size_t b = align256(ex_wpk_floats(&a) * 4) + align256(ex_bwd_slab_floats(d, g) * 4) + align256(n_dy * 4) +
+               align256((size_t)COLSUM_BLOCKS * d->Co * 4) + 1024;
+    static thread_local ConvQProblem pr;
+    if (ex_bwd_q(d, &a, pr)) b += align256(n_dy * 4) + align256(convq_wpk_bytes(pr));   // dy in the split format + the adjoint's convq pack
+    return b;
 }
 
 int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, const float* y, const float* dy, float* dx,
@@ -616,20 +629,30 @@ int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, co
     const size_t n_dy = (size_t)d->N * g.Ho * g.Wo * d->Co;
     float* dys = ws.take(n_dy);
     float* db_part = ws.take((size_t)COLSUM_BLOCKS * d->Co);
+    static thread_local ConvQProblem prq;
+    const bool dq = dx && ex_bwd_q(d, &a, prq);
+    char *dy_sp = nullptr, *wpkq = nullptr;
+    if (dq) { dy_sp = (char*)ws.take(n_dy); wpkq = (char*)ws.take(align256(convq_wpk_bytes(prq)) / 4); }
     VPX_CHECK_CARVE(ws, "vpx_conv2d_ex_bwd");
+    const bool v4 = (d->Co & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y) & 15) == 0;   // (launch_colsum's vector form: the split copy needs it)
+    bool have_sp = false;
     if (d->leaky_slope != 0.0f) {
         // d(pre-activation) = dy * LeakyReLU'(.), the derivative read off the sign of the forward OUTPUT (same sign as the
         // pre-activation for a positive slope) — one pass that also yields the bias gradient
         if (!y) { set_error("vpx_conv2d_ex_bwd: y (forward output) is required when leaky_slope != 0"); return VPX_ERR_ARG; }
         if (d->leaky_slope < 0.0f) { set_error("vpx_conv2d_ex_bwd: negative leaky_slope is not implemented"); return VPX_ERR_UNSUPPORTED; }
-        VPX_CHECK_HIP(launch_colsum(dy, y, d->leaky_slope, dys, db, db_part, (long long)d->N * g.Ho * g.Wo, d->Co, stream));
+        have_sp = dq && v4;
+        VPX_CHECK_HIP(launch_colsum(dy, y, d->leaky_slope, dys, db, db_part, (long long)d->N * g.Ho * g.Wo, d->Co, stream, have_sp ? dy_sp : nullptr));
         dy = dys;
     } else if (db) {
         VPX_CHECK_HIP(launch_colsum(dy, nullptr, 0.f, nullptr, db, db_part, (long long)d->N * g.Ho * g.Wo, d->Co, stream));
     }
     if (dx) {
         ExGeo ga{d->H, d->W};
-        if ((rc = ex_forward(&a, ga, dy, w, nullptr, dx, wpk, stream)) != VPX_OK) return rc;
+        if (dq) {
+            if (!have_sp) VPX_CHECK_HIP(launch_split_convert(dy, dy_sp, (long long)d->N * g.Ho * g.Wo, d->Co, stream));
+            if ((rc = ex_forward_q(&a, ga, dy_sp, (long long)g.Ho * g.Wo * d->Co * 4, 0, 1, w, nullptr, dx, nullptr, wpkq, false, stream)) != VPX_OK) return rc;
+        } else if ((rc = ex_forward(&a, ga, dy, w, nullptr, dx, wpk, stream)) != VPX_OK) return rc;
     }
     if (dw && !d->transposed && wgrad_small_applicable(d->Co, d->Ci, d->kh, d->kw, d->stride, d->pad) &&
         (size_t)WGRAD_SMALL_BLOCKS * d->Co * d->Ci * d->kh * d->kw <= ex_bwd_slab_floats(d, g)) {

@@ -134,10 +134,12 @@ hipError_t launch_peep_reduce(const float* p0, const float* p1, const float* p2,
 // (within a block the threads of one column add their strided rows, then a fixed-order LDS combine), level 2 adds the
 // block rows in order. Optional LeakyReLU': with `y` given, the summed (and, if `scaled` is given, stored) value is
 // m * (y > 0 ? 1 : slope) — the glue's activation derivative from the sign of the forward output.
+// scaled_sp (V = 4, cols % 8 == 0): the scaled matrix once more in the split-bf16 operand format — per row, per group of 8 columns
+// [8 hi bf16 | 8 lo bf16]; a thread's four columns are one 8-byte half of each (the glue's data gradient then runs on convq)
 template <int V>   // V = 4: columns handled as float4 groups (cols % 4 == 0 and 16-byte aligned operands), V = 1: scalar
 __global__ __launch_bounds__(256) void colsum_l1_kernel(const float* __restrict__ m, const float* __restrict__ y, float slope,
                                                         float* __restrict__ scaled, float* __restrict__ partial, long long rows,
-                                                        int cols, long long rows_per_block) {
+                                                        int cols, long long rows_per_block, char* __restrict__ scaled_sp) {
     typedef float vec __attribute__((ext_vector_type(V)));
     __shared__ vec comb[256];
     const long long r0 = blockIdx.x * rows_per_block;
@@ -160,6 +162,21 @@ __global__ __launch_bounds__(256) void colsum_l1_kernel(const float* __restrict_
 #pragma unroll
                         for (int i = 0; i < V; ++i) v[i] *= yv[i] > 0.0f ? 1.0f : slope;
                     if (scaled) reinterpret_cast<vec*>(scaled)[e] = v;
+                }
+                if constexpr (V == 4) {
+                    if (scaled_sp) {
+                        unsigned short h[4], l[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const __bf16 hb = (__bf16)v[i];
+                            h[i] = __builtin_bit_cast(unsigned short, hb);
+                            const __bf16 lb = (__bf16)(v[i] - __builtin_bit_cast(float, (unsigned)h[i] << 16));
+                            l[i] = __builtin_bit_cast(unsigned short, lb);
+                        }
+                        char* grp = scaled_sp + ((size_t)r * vcols + col) / 2 * 32 + (col & 1) * 8;   // vcols is even: (r * vcols + col) / 2 = the row's 8-column group
+                        *reinterpret_cast<uint2*>(grp) = uint2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+                        *reinterpret_cast<uint2*>(grp + 16) = uint2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+                    }
                 }
                 acc += v;
             }
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(256) void colsum_l2_kernel(const float* __restrict_
 }
 
 hipError_t launch_colsum(const float* m, const float* y, float slope, float* scaled, float* out, float* partial_ws,
-                         long long rows, int cols, hipStream_t s) {
+                         long long rows, int cols, hipStream_t s, char* scaled_sp) {
     int blocks = COLSUM_BLOCKS;
     if (rows / 32 < blocks) blocks = (int)(rows / 32 > 0 ? rows / 32 : 1);   // at least 32 rows per level-1 block
     const long long rpb = (rows + blocks - 1) / blocks;
@@ -210,8 +227,10 @@ hipError_t launch_colsum(const float* m, const float* y, float slope, float* sca
     const bool v4 = (cols & 3) == 0 && (((uintptr_t)m | (uintptr_t)y | (uintptr_t)scaled | (uintptr_t)partial_ws) & 15) == 0;
     if (out && !ws_write_ok(partial_ws, (size_t)blocks * cols * sizeof(float), "column-sum partials (colsum_l1_kernel)")) return hipErrorInvalidValue;
     if (scaled && !ws_write_ok(scaled, (size_t)rows * cols * sizeof(float), "scaled gradient (colsum_l1_kernel)")) return hipErrorInvalidValue;
-    if (v4) VPX_LAUNCH(colsum_l1_kernel<4>, dim3(blocks), dim3(256), 0, s, m, y, slope, scaled, out ? partial_ws : nullptr, rows, cols, rpb);
-    else VPX_LAUNCH(colsum_l1_kernel<1>, dim3(blocks), dim3(256), 0, s, m, y, slope, scaled, out ? partial_ws : nullptr, rows, cols, rpb);
+    if (scaled_sp && (!v4 || (cols & 7) || ((uintptr_t)scaled_sp & 15))) return hipErrorInvalidValue;   // the split copy needs whole 8-column groups
+    if (scaled_sp && !ws_write_ok(scaled_sp, (size_t)rows * cols * sizeof(float), "scaled gradient, split format (colsum_l1_kernel)")) return hipErrorInvalidValue;
+    if (v4) VPX_LAUNCH(colsum_l1_kernel<4>, dim3(blocks), dim3(256), 0, s, m, y, slope, scaled, out ? partial_ws : nullptr, rows, cols, rpb, scaled_sp);
+    else VPX_LAUNCH(colsum_l1_kernel<1>, dim3(blocks), dim3(256), 0, s, m, y, slope, scaled, out ? partial_ws : nullptr, rows, cols, rpb, (char*)nullptr);
     if (out) VPX_LAUNCH(colsum_l2_kernel, dim3((cols + 15) / 16), dim3(256), 0, s, partial_ws, out, blocks, cols);
     return vpx_hip_last_error();
 }

@@ -403,7 +403,7 @@ hipError_t launch_peep_reduce(const float* p0, const float* p1, const float* p2,
 // partial_ws: COLSUM_BLOCKS * cols floats of scratch
 constexpr int COLSUM_BLOCKS = 4096;   // level-1 blocks: enough 256-thread blocks in flight to stream a GB-sized dy at HBM speed
 hipError_t launch_colsum(const float* m, const float* y, float slope, float* scaled, float* out, float* partial_ws,
-                         long long rows, int cols, hipStream_t s);
+                         long long rows, int cols, hipStream_t s, char* scaled_sp = nullptr);   // scaled_sp: the scaled matrix again in the split format (cols % 8 == 0)
 
 // A workgroup's 64 activation columns are two 32-channel halves (one per wave column), each its own slice
 // [c0, c0+cn) of segment seg (0 = x, 1 = h); cglobal = column in [x|h]. Halves are paired in order ACROSS the
