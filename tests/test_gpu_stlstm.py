@@ -183,6 +183,36 @@ def test_fused_reversed_pass_equals_two_passes(vpx, mode):
         assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4], key   # schedule state and the RNG stream's position
 
 
+@pytest.mark.parametrize("variant", ["plain", "layer_norm"])
+def test_batched_decoupling_tail_equals_per_step_tails(vpx, variant):
+    """batch_decoupling_tail (the default): every layer-step writes its delta_c / delta_m into one slab and ONE vpx_decouple_fwd/_bwd pair
+    runs over all of them, against one tail per layer-step as the reference's loop does (predrnn_v2.py:197-211, 229). Training loss, the
+    decoupling value itself in eval mode, and every gradient; plain cells (second-generation kernels, deferred weight gradients) and the
+    LayerNorm variant (first-generation path)."""
+    from vp_suite_amd.measure import PredictionLossProvider
+    lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
+    kw = dict(img_shape=(1, 32, 32), action_size=0, tensor_value_range=[0.0, 1.0], num_layers=2, num_hidden=[16, 16], cell_precision="bf16x3",
+              layer_norm=(variant == "layer_norm"))
+    B, Ttot, P = 3, 6, 3
+    frames = seeded_rand((B, Ttot, 1, 32, 32), name_seed("predrnn.btail.frames")).cuda()
+    res = {}
+    for batched in (True, False):
+        m = _predrnn("btail", kw)
+        m.batch_decoupling_tail = batched
+        m.sampling_eta = 0.5
+        torch.manual_seed(99)
+        loss = m.training_loss(frames, frames[:, Ttot - P:], P, lp)
+        loss.backward()
+        named = dict(m.named_parameters())
+        flat = np.concatenate([named[k].grad.detach().cpu().numpy().reshape(-1) for k in sorted(named)])
+        with torch.no_grad():
+            _, ml = m.eval()(frames, pred_frames=P)
+        res[batched] = (float(loss), flat, float(ml["ST-LSTM decouple loss"]))
+    a, b = res[True], res[False]
+    assert abs(a[0] - b[0]) < 2e-6 * abs(b[0]) and abs(a[2] - b[2]) < 2e-6 * abs(b[2])
+    assert _relmax(a[1], b[1]) < 2e-5
+
+
 def test_predrnn_full_size_vs_golden(vpx):
     """BASELINE config C3: default predrnn-pp, 64x64, 10 -> 10."""
     g = load_golden("predrnn_full_c1")

@@ -1306,7 +1306,14 @@ struct C5PackArgs {
     int sps, gc;               // slots per stage (taps: 25 | 9); channels per gate of a gate-interleaved N tile (32; the ConvLSTM forms: NT * 4)
     int S8, Q, Co, n_tiles;    // Co: plain: output channels; gates: channels per gate (Ch)
 };
-__global__ void c5_pack_kernel(const C5PackArgs pk, char* __restrict__ dst) {
+// One launch packs ALL the jobs a library call has prepared since its last c5 launch (round 5: the 128x128x3 shard spent 5 % of its
+// training step in 246 pack launches of ~20 us — one per cell, direction and K chunk; they now share a launch per c5 launch).
+constexpr int C5_MAX_PACKS = 16;
+struct C5PackBatch { int n, _p; C5PackArgs a[C5_MAX_PACKS]; char* dst[C5_MAX_PACKS]; };
+static_assert(sizeof(C5PackBatch) <= 4000, "C5PackBatch travels as a kernel argument");
+__global__ void c5_pack_kernel(const C5PackBatch pb) {
+    const C5PackArgs& pk = pb.a[blockIdx.y];
+    char* const __restrict__ dst = pb.dst[blockIdx.y];
     const int wch2 = pk.NT * 1024;   // bf16 elements of a chunk
     const long long total = (long long)pk.n_tiles * pk.Q * wch2;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -1354,6 +1361,20 @@ size_t c5_wpk_bytes(int K, int Co, int NT, int gates, int ks) {
 
 // fills the job's derived fields (S8, Q, n_tiles, nt_active) and packs its weights into job.wpk unless `packed`.
 // gates = 0: plain column order, Co output channels; gates = 3 | 4: gate-interleaved N tiles of 32 channels (NT = 8), Co = channels per gate
+// packs prepared and not yet launched (this thread's running library call); flushed by the next launch_c5, dropped when a new call
+// carves its workspace (a call that failed between prepare and launch must not leave its pointers behind)
+static thread_local C5PackBatch g_c5_pending = {};
+static thread_local long long g_c5_pending_max = 0;
+void c5_drop_pending_packs() { g_c5_pending.n = 0; g_c5_pending_max = 0; }
+hipError_t c5_flush_packs(hipStream_t s) {
+    if (g_c5_pending.n == 0) return hipSuccess;
+    int blocks = (int)((g_c5_pending_max + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    VPX_LAUNCH(c5_pack_kernel, dim3(blocks, g_c5_pending.n), dim3(256), 0, s, g_c5_pending);
+    c5_drop_pending_packs();
+    return vpx_hip_last_error();
+}
+
 int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s, int gate_major, int ks) {
     const int sps = ks * ks, gc = ks == 3 ? NT * 4 : 32;
     int K = 0;
@@ -1374,10 +1395,11 @@ int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip,
         pk.S8 = j.S8; pk.Q = j.Q; pk.Co = (gates && gate_major) ? j.Co / gates : j.Co; pk.n_tiles = j.n_tiles;
         const long long total = (long long)j.n_tiles * j.Q * NT * 1024;
         if (!ws_write_ok(j.wpk, (size_t)total * 2, "weight pack (c5_pack_kernel)")) { set_error("%s", ws_violation()); return VPX_ERR_WORKSPACE; }
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
-        VPX_LAUNCH(c5_pack_kernel, dim3(blocks), dim3(256), 0, s, pk, const_cast<char*>(j.wpk));
-        VPX_CHECK_HIP(vpx_hip_last_error());
+        if (g_c5_pending.n == C5_MAX_PACKS) VPX_CHECK_HIP(c5_flush_packs(s));
+        g_c5_pending.a[g_c5_pending.n] = pk;
+        g_c5_pending.dst[g_c5_pending.n] = const_cast<char*>(j.wpk);
+        ++g_c5_pending.n;
+        if (total > g_c5_pending_max) g_c5_pending_max = total;
     }
     return VPX_OK;
 }
@@ -1427,6 +1449,7 @@ extern "C" int vpx_dbg_c5_stamps(unsigned long long* dev_buf, int block) { g_c5_
 #endif
 
 hipError_t launch_c5(const C5Plan& P_in, int NT, hipStream_t s) {
+    { const hipError_t ep = c5_flush_packs(s); if (ep != hipSuccess) return ep; }   // the packs this launch (and later ones of the call) read
     C5Plan P = P_in;
     // Block order inside an XCD. The 128-column launches (the forward gate groups: 14 N tiles per pixel tile, 23 MB of packed weights
     // against 4 MB of L2) run the pixel tiles of an N tile next to each other — the XCD's 16 pixel tiles then stream one N tile's weights

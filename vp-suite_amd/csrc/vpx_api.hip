@@ -24,6 +24,7 @@ static thread_local char g_ws_violation[256] = "";
 Carver::Carver(void* workspace, size_t bytes)
     : base((char*)workspace), off((256 - ((uintptr_t)workspace & 255)) & 255), cap(bytes), nslot(0), over(false), prev(g_carver) {
     if (off > cap) over = true;
+    if (!prev) c5_drop_pending_packs();   // (outermost carver of a call: nothing queued by an earlier call survives)
     g_carver = this;
     g_ws_violation[0] = 0;
 }

@@ -547,6 +547,10 @@ static_assert(sizeof(C5Plan) <= 4096, "C5Plan travels as a kernel argument (4 Ki
 struct C5PackRange { const float* w; long long s_oc, s_c; int c0; int gate0[4]; };   // weights of one K range (see c5_pack_kernel)
 size_t c5_wpk_bytes(int K, int Co, int NT, int gates = 0, int ks = 5);
 int c5_prepare_job(C5Job& j, int NT, const C5PackRange* rg, int gates, int flip, bool packed, hipStream_t s, int gate_major = 0, int ks = 5);
+// c5_prepare_job only QUEUES a job's weight pack: launch_c5 packs everything queued in one launch before it starts; a new library call
+// (Carver construction) drops what an earlier, failed call may have left queued
+hipError_t c5_flush_packs(hipStream_t s);
+void c5_drop_pending_packs();
 void c5_chunk_job(const C5Job& full, const C5PackRange* prf, int k, int ks, C5Job& j, C5PackRange* pr);   // K-split: chunk k of ks
 size_t c5_chunk_wpk_bytes(int K, int k, int ks, int cols, int NT);
 hipError_t launch_c5(const C5Plan& P, int NT, hipStream_t s);   // NT = 8: 128-column N tiles, 4: 64-column

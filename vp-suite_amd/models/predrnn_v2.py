@@ -51,11 +51,11 @@ class _CellBanks:
             self.banks.append(bank)
             self.weights.append(bank.weights())
 
-    def step(self, cell, i, t, x, h, c, m):
+    def step(self, cell, i, t, x, h, c, m, delta_out=None):
         x_sp = self.X[t] if i == 0 else self.H[i - 1][t + 1]
         m_sp = self.M[self.L - 1][t] if i == 0 else self.M[i - 1][t + 1]
         slots = (self.banks[i], t, (x_sp, self.H[i][t], m_sp), (self.H[i][t + 1], self.C[i][t + 1], self.M[i][t + 1]), i == 0)
-        return ops.stlstm_step(x, h, c, m, *self.weights[i], precision=cell.precision, wsholder=cell._ws, slots=slots)
+        return ops.stlstm_step(x, h, c, m, *self.weights[i], precision=cell.precision, wsholder=cell._ws, slots=slots, delta_out=delta_out)
 
 
 class PredRNN_V2(VPModel):
@@ -96,6 +96,13 @@ class PredRNN_V2(VPModel):
     #: once per step with an autograd accumulation per step and tensor. Same sums in another order. Where the library cannot (LayerNorm,
     #: action-conditional cells, operand modes other than bf16x3, filter sizes other than 5) the steps compute them as before.
     defer_weight_gradients: bool = True
+    #: the decoupling term of all layer-steps of a pass in ONE library call each way (ops.decouple_term_batched): the steps write their
+    #: delta_c / delta_m into one slab. False: one adapter convolution + statistics + mean per layer-step, as the reference does.
+    #: Used while the slab stays below `DECOUPLE_SLAB_LIMIT` bytes: beyond that the per-step tails win back what they lose in launches
+    #: by finding their operands in the Infinity Cache (measured at 2B = 256, 16x16 maps: 3.8 GB slab, 316 vs 313 ms per training step;
+    #: at B = 32: 88.2 vs 90.5 ms; the 128x128x3 shard at 2B = 4: 89.8 vs 94.7 ms; its inference at B = 4: 28.0 vs 31.0 ms).
+    batch_decoupling_tail: bool = True
+    DECOUPLE_SLAB_LIMIT = 2 << 30
 
     def __init__(self, device, **model_kwargs):
         super().__init__(device, **model_kwargs)
@@ -178,6 +185,12 @@ class PredRNN_V2(VPModel):
         for cell in self.cell_list:
             cell.use_shadows = True
         banks = self._weight_banks(b, total_frames - 1) if (train and torch.is_grad_enabled()) else None
+        n_ls = (total_frames - 1) * self.num_layers
+        slab = None
+        if self.batch_decoupling_tail and not self.action_conditional and len(set(nh[:self.num_layers])) == 1 and \
+                8 * n_ls * b * nh[0] * self.rnn_h * self.rnn_w <= self.DECOUPLE_SLAB_LIMIT:
+            slab = ops.new_channels_last((2, n_ls * b, nh[0], self.rnn_h, self.rnn_w), dev)   # [delta_c | delta_m][layer-step][sample]
+        deltas = []
 
         def zeros(i):
             return torch.zeros(b, nh[i], self.rnn_h, self.rnn_w, device=dev)
@@ -213,11 +226,17 @@ class PredRNN_V2(VPModel):
                 inp = net if i == 0 else h_t[i - 1]
                 if self.action_conditional:
                     h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory, action)
-                elif banks is not None:
-                    h_t[i], c_t[i], memory, d_c, d_m = banks.step(self.cell_list[i], i, t, inp, h_t[i], c_t[i], memory)
                 else:
-                    h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory)
-                decouple.append(self._decouple_term(d_c, d_m))
+                    ls = t * self.num_layers + i
+                    dout = None if slab is None else (slab[0, ls * b:(ls + 1) * b], slab[1, ls * b:(ls + 1) * b])
+                    if banks is not None:
+                        h_t[i], c_t[i], memory, d_c, d_m = banks.step(self.cell_list[i], i, t, inp, h_t[i], c_t[i], memory, dout)
+                    else:
+                        h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory, delta_out=dout)
+                if slab is not None:
+                    deltas += [d_c, d_m]
+                else:
+                    decouple.append(self._decouple_term(d_c, d_m))
             if self.conv_actions_on_input:   # two stride-2 transposed convolutions back to the patch grid (:212-218)
                 res2, res1 = (in2, in1) if self.residual_on_action_conv else (0, 0)
                 x_gen = ops.conv_transpose2d_to_size(h_t[top] + res2, self.deconv_output1.weight, 2, k // 2, shape2, prec)
@@ -226,7 +245,10 @@ class PredRNN_V2(VPModel):
                 x_gen = ops.conv2d_same(h_t[top], self.conv_last.weight, None, prec)
             next_frames.append(x_gen)
         pred = self._reshape_patch_back(torch.stack(next_frames[-pred_frames:], dim=1))
-        loss = torch.mean(torch.stack(decouple, dim=0))
+        if slab is not None:   # mean over the layer-steps of the per-step means = the mean over the slab (equal batch per step)
+            loss = ops.decouple_term_batched(slab, self.adapter.weight, self.cell_precision, n_ls, b, deltas)
+        else:
+            loss = torch.mean(torch.stack(decouple, dim=0))
         return pred, {"ST-LSTM decouple loss": self.decoupling_loss_scale * loss}
 
     def _weight_banks(self, b, T):

@@ -647,6 +647,61 @@ def decouple_term(delta_c, delta_m, adapter_w, precision="f32"):
     return _DecoupleFn.apply(delta_c, delta_m, adapter_w, PRECISIONS[precision])
 
 
+class _DecoupleBatchFn(torch.autograd.Function):
+    """The decoupling term of ALL K layer-steps of a pass in one library call each way. `slab` is [2, K*B, Ch, H, W] (channels-last):
+    slab[0] holds the K steps' delta_c one after the other, slab[1] their delta_m; `deltas` = (dc_0, dm_0, dc_1, dm_1, ...) are the
+    steps' own output tensors — views of those slots — passed so that autograd has an edge to every step; the data is read from the
+    slab. mean over (K*B, channel) of |cos| = the mean over the K steps of the per-step means (equal B): predrnn_v2.py:197-211, 229."""
+
+    @staticmethod
+    def forward(ctx, adapter_w, precision, slab, K, B, *deltas):
+        _require_gpu(slab, "decouple_term_batched")
+        _, KB, Ch, H, Wd = slab.shape
+        if KB != K * B or len(deltas) != 2 * K:
+            raise ValueError("decouple_term_batched: the slab does not hold K steps of B samples / 2K delta tensors")
+        n = B * Ch * H * Wd
+        for k in (0, K - 1):   # the steps wrote where the slab expects them (first and last: the rest follow the same arithmetic)
+            if deltas[2 * k].data_ptr() != slab[0].data_ptr() + 4 * k * n or deltas[2 * k + 1].data_ptr() != slab[1].data_ptr() + 4 * k * n:
+                raise ValueError("decouple_term_batched: a step's delta tensor is not its slot of the slab")
+        dc, dm = slab[0], slab[1]
+        if not (is_channels_last(dc) and dm.data_ptr() == dc.data_ptr() + 4 * K * n):
+            raise ValueError("decouple_term_batched: slab must be one dense channels-last block")
+        A = adapter_w.reshape(Ch, Ch).contiguous()
+        L = _lib.lib()
+        ws_bytes = L.vpx_decouple_workspace_bytes(KB, Ch, H, Wd)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=slab.device)
+        value = torch.empty((), device=slab.device)
+        check(L.vpx_decouple_fwd(ptr(dc), ptr(dm), ptr(A), ptr(value), KB, Ch, H, Wd, precision, ptr(ws), ws_bytes, _stream()), "vpx_decouple_fwd")
+        ctx.save_for_backward(slab, A)
+        ctx.geo = (K, B, precision, tuple(adapter_w.shape))
+        return value
+
+    @staticmethod
+    def backward(ctx, dvalue):
+        _sync_determinism()
+        slab, A = ctx.saved_tensors
+        K, B, precision, wshape = ctx.geo
+        _, KB, Ch, H, Wd = slab.shape
+        gg = new_channels_last((2 * KB, Ch, H, Wd), slab.device)   # adjacent: one adjoint conv for the pair
+        g_dc, g_dm = gg[:KB], gg[KB:]
+        g_A = torch.empty_like(A) if ctx.needs_input_grad[0] else None
+        L = _lib.lib()
+        ws_bytes = L.vpx_decouple_workspace_bytes(KB, Ch, H, Wd)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=slab.device)
+        dv = dvalue.contiguous().reshape(1)
+        check(L.vpx_decouple_bwd(ptr(slab[0]), ptr(slab[1]), ptr(A), ptr(dv), ptr(g_dc), ptr(g_dm), ptr(g_A), KB, Ch, H, Wd, precision,
+                                 ptr(ws), ws_bytes, _stream()), "vpx_decouple_bwd")
+        per_step = []
+        for k in range(K):   # every step's gradients are views of the two slabs: no copies
+            per_step += [g_dc[k * B:(k + 1) * B], g_dm[k * B:(k + 1) * B]]
+        return (None if g_A is None else g_A.reshape(wshape), None, None, None, None, *per_step)
+
+
+def decouple_term_batched(slab, adapter_w, precision, K, B, deltas):
+    """mean over the K layer-steps of decouple_term(delta_c_k, delta_m_k) in ONE call (see _DecoupleBatchFn)."""
+    return _DecoupleBatchFn.apply(adapter_w, PRECISIONS[precision], slab, int(K), int(B), *deltas)
+
+
 def _is_dense(t: torch.Tensor) -> bool:
     """True when the tensor's elements tile one memory block without gaps or overlap (any dimension order)."""
     expect = 1
@@ -845,7 +900,7 @@ class _STLSTMStepFn(torch.autograd.Function):
     `ln` = () or the 8 LayerNorm tensors (x_gamma, x_beta, h_gamma, h_beta, m_gamma, m_beta, o_gamma, o_beta)."""
 
     @staticmethod
-    def forward(ctx, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision, need_grad, wsholder, use_shadows, slots, *ln):
+    def forward(ctx, x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision, need_grad, wsholder, use_shadows, slots, delta_out, *ln):
         _require_gpu(x, "stlstm_step")
         dev = x.device
         B, Cin, H, Wd = x.shape
@@ -872,8 +927,14 @@ class _STLSTMStepFn(torch.autograd.Function):
             d.flags |= _lib.FLAG_WEIGHTS_PACKED
         reserve = torch.empty(max(rs_bytes, 1), dtype=torch.uint8, device=dev)
         outs = [new_channels_last((B, Ch, H, Wd), dev) for _ in range(3)]
-        dd = new_channels_last((2 * B, Ch, H, Wd), dev)  # delta_c | delta_m adjacent: the decoupling tail runs the pair as one conv
-        outs += [dd[:B], dd[B:]]
+        if delta_out is not None:   # the caller's slab slots (decouple_term_batched: one decoupling tail over all the steps of a pass)
+            for t in delta_out:
+                if tuple(t.shape) != (B, Ch, H, Wd) or not is_channels_last(t) or t.dtype != torch.float32 or t.device != dev:
+                    raise ValueError("stlstm_step: delta_out must hold two channels-last float32 [B, Ch, H, W] tensors on the step's device")
+            outs += [delta_out[0], delta_out[1]]
+        else:
+            dd = new_channels_last((2 * B, Ch, H, Wd), dev)  # delta_c | delta_m adjacent: the decoupling tail runs the pair as one conv
+            outs += [dd[:B], dd[B:]]
         ln_arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in lnc]) if use_ln else None
         # split-format shadows (vpx.h): operands a previous step left in the kernels' operand format are handed back instead of being
         # converted again (h_new is the next step's h and the next layer's x, m_new the next layer's m), and this step's h_new / c_new /
@@ -941,7 +1002,7 @@ class _STLSTMStepFn(torch.autograd.Function):
         dm = new_channels_last(tuple(ms.shape), dev) if needs[3] else None
         bank = getattr(ctx, "bank", None)
         dWs = [torch.empty_like(w) if (needs[4 + i] and bank is None) else None for i, w in enumerate((Wx, Wh, Wm, Wo, Wlast))]
-        dln = [torch.empty_like(t) if needs[14 + i] else None for i, t in enumerate(lnc)]
+        dln = [torch.empty_like(t) if needs[15 + i] else None for i, t in enumerate(lnc)]
         ln_arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in lnc]) if ctx.use_ln else None
         dln_arr = (ctypes.c_void_p * 8)(*[None if t is None else t.data_ptr() for t in dln]) if ctx.use_ln else None
         ws_bytes = L.vpx_stlstm_workspace_bytes(ctypes.byref(d))
@@ -965,7 +1026,7 @@ class _STLSTMStepFn(torch.autograd.Function):
         check(rc, "vpx_stlstm_step_bwd")
         if bank is not None:
             bank[0].deposited.add(bank[1])
-        return (dx, dh, dc, dm, *dWs, None, None, None, None, None, *dln)
+        return (dx, dh, dc, dm, *dWs, None, None, None, None, None, None, *dln)
 
 
 def stlstm_algorithmic_work(B, Cin, Ch, H, W, k, dt=4):
@@ -976,19 +1037,21 @@ def stlstm_algorithmic_work(B, Cin, Ch, H, W, k, dt=4):
     return flops, nbytes
 
 
-def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=None, ln=(), use_shadows=False, slots=None):
+def stlstm_step(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, precision="f32", wsholder=None, ln=(), use_shadows=False, slots=None, delta_out=None):
     """ln: () or the 8 LayerNorm parameter tensors [C,H,W] (x_gamma, x_beta, h_.., m_.., o_..) of the LayerNorm variant.
     use_shadows: hand h_new / c_new / m_new out with split-format shadows and take the shadows of x / h / m where a previous step of
     the same shadow epoch attached them (no second conversion). Opt-in: the caller vouches that nothing writes those tensors behind
     the version counter's back between the steps (PredRNN_V2.forward: the tensors never leave its loop).
     slots: (bank, t, (x_sp, h_sp, m_sp), (h_new_sp, c_new_sp, m_new_sp), convert_x) — STWeightBank mode: the weights must be
     `bank.weights()`, the operands' split copies live in the owner's slabs (convert_x: x has none yet — converted into x_sp here), the
-    weight gradients of the cell's steps are computed together when autograd reaches the bank."""
+    weight gradients of the cell's steps are computed together when autograd reaches the bank.
+    delta_out: (delta_c, delta_m) — caller tensors [B, Ch, H, W] (channels-last) the step writes its two deltas into instead of
+    allocating them (slots of the slab `decouple_term_batched` reads)."""
     ln = tuple(ln)
     if len(ln) not in (0, 8):
         raise ValueError("stlstm_step: ln must hold 0 or 8 tensors")
     need_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (x, h, c, m, Wx, Wh, Wm, Wo, Wlast) + ln)
-    return _STLSTMStepFn.apply(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, PRECISIONS[precision], need_grad, wsholder, bool(use_shadows), slots, *ln)
+    return _STLSTMStepFn.apply(x, h, c, m, Wx, Wh, Wm, Wo, Wlast, PRECISIONS[precision], need_grad, wsholder, bool(use_shadows), slots, delta_out, *ln)
 
 
 class _LayerNormCHWFn(torch.autograd.Function):
