@@ -112,6 +112,34 @@ hipError_t launch_st_out_ks(const STOutKSArgs& a, hipStream_t s) {
     VPX_LAUNCH(st_out_ks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     return vpx_hip_last_error();
 }
+// several sums in one launch (blockIdx.y = job): the K-split data gradients of an ST-LSTM step's backward leave up to five of them behind
+struct SumJobs { int n, _p; float* out[5]; const float* part[5]; long long cnt[5]; int ks[5], acc[5]; };
+__global__ __launch_bounds__(256) void sum_partials_multi_kernel(const SumJobs J) {
+    const int j = blockIdx.y;
+    const long long n = J.cnt[j];
+    const float* const part = J.part[j];
+    float* const out = J.out[j];
+    const int ks = J.ks[j];
+    for (long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long long)gridDim.x * 1024) {
+        f32x4 s = J.acc[j] ? *reinterpret_cast<const f32x4*>(out + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < ks; ++k) s += *reinterpret_cast<const f32x4*>(part + (size_t)k * n + e);
+        *reinterpret_cast<f32x4*>(out + e) = s;
+    }
+}
+hipError_t launch_sum_partials_multi(int njobs, float* const* out, const float* const* part, const long long* n, const int* ks, const int* acc, hipStream_t s) {
+    if (njobs < 1) return hipSuccess;
+    if (njobs > 5) return hipErrorInvalidValue;
+    SumJobs J{};
+    J.n = njobs;
+    long long mx = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (n[i] & 3) return hipErrorInvalidValue;
+        J.out[i] = out[i]; J.part[i] = part[i]; J.cnt[i] = n[i]; J.ks[i] = ks[i]; J.acc[i] = acc[i];
+        if (n[i] > mx) mx = n[i];
+    }
+    VPX_LAUNCH(sum_partials_multi_kernel, dim3((unsigned)((mx / 4 + 255) / 256), njobs), dim3(256), 0, s, J);
+    return vpx_hip_last_error();
+}
 hipError_t launch_sum_partials(float* out, const float* part, long long pstride, int ks, long long n, int accumulate, hipStream_t s) {
     VPX_LAUNCH(sum_partials_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, out, part, pstride, ks, n, accumulate);
     return vpx_hip_last_error();

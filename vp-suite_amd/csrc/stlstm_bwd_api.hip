@@ -354,7 +354,13 @@ extern "C" int vpx_stlstm_step_bwd_ex(const vpx_stlstm_desc* d, const float* x, 
     };
     auto c5_flush = [&]() -> int {
         if (cp.njobs) VPX_CHECK_HIP(launch_c5(cp, C5_NT, stream));
-        for (int i = 0; i < npend; ++i) VPX_CHECK_HIP(launch_sum_partials(pend[i].out, pend[i].part, pend[i].n, pend[i].ks, pend[i].n, pend[i].acc, stream));
+        {   // the slots' partial sums in ONE launch (round 5: five 5 us launches per cell step on the small grids)
+            float* po[5]; const float* pp[5]; long long pn[5]; int pk[5], pa[5];
+            bool vec = true;
+            for (int i = 0; i < npend; ++i) { po[i] = pend[i].out; pp[i] = pend[i].part; pn[i] = pend[i].n; pk[i] = pend[i].ks; pa[i] = pend[i].acc; vec = vec && !(pend[i].n & 3); }
+            if (vec) VPX_CHECK_HIP(launch_sum_partials_multi(npend, po, pp, pn, pk, pa, stream));
+            else for (int i = 0; i < npend; ++i) VPX_CHECK_HIP(launch_sum_partials(pend[i].out, pend[i].part, pend[i].n, pend[i].ks, pend[i].n, pend[i].acc, stream));
+        }
         cp.njobs = 0; npend = 0;
         return VPX_OK;
     };

@@ -502,6 +502,8 @@ struct STOutKSArgs {
 hipError_t launch_st_gates_ks(const STGatesKSArgs& a, hipStream_t s);
 hipError_t launch_st_out_ks(const STOutKSArgs& a, hipStream_t s);
 hipError_t launch_sum_partials(float* out, const float* part, long long pstride, int ks, long long n, int accumulate, hipStream_t s);
+// up to five such sums in one launch; job i: out[i][e] (+)= sum_k part[i][k * n[i] + e]  (n[i] % 4 == 0)
+hipError_t launch_sum_partials_multi(int njobs, float* const* out, const float* const* part, const long long* n, const int* ks, const int* acc, hipStream_t s);
 // conv1.hip, c1: 1x1 convolution as a streaming kernel (weights resident in registers), fp32 NHWC in and out, bf16x3 arithmetic
 struct C1Args {
     const float* x[2]; int xld[2], xc[2];   // up to two sources concatenated along K: pixel pitch (floats), channels (multiples of 32; xc[1] = 0: one source)
