@@ -19,7 +19,14 @@ for spec in "cell_64x64x64_b128|--cell 64,64,64,64 --batch 128 --name cell_64x64
             "infer_b32|--batch 32 --name infer_b32" \
             "train_b32|--mode train --batch 32 --name train_b32" \
             "infer_b128_f32|--precision f32 --name infer_b128_f32" \
-            "predrnn_train_b32|--model predrnn-pp --mode train --batch 32 --name predrnn_train_b32"; do
+            "predrnn_train_b32|--model predrnn-pp --mode train --batch 32 --name predrnn_train_b32" \
+            "cell_64x64x64_b32|--cell 64,64,64,64 --batch 32 --name cell_64x64x64_b32" \
+            "cell_64x64x64_b4|--cell 64,64,64,64 --batch 4 --name cell_64x64x64_b4" \
+            "cell_enc1_16x64x64_b128|--cell 16,64,64,64 --batch 128 --name cell_enc1_16x64x64_b128" \
+            "cell_enc2_64x96x32_b128|--cell 64,96,32,32 --batch 128 --name cell_enc2_64x96x32_b128" \
+            "cell_enc3_96x96x16_b128|--cell 96,96,16,16 --batch 128 --name cell_enc3_96x96x16_b128" \
+            "cell_fore2_96x96x32_b128|--cell 96,96,32,32 --batch 128 --name cell_fore2_96x96x32_b128" \
+            "cell_fore1_96x64x64_b128|--cell 96,64,64,64 --batch 128 --name cell_fore1_96x64x64_b128"; do
   tag=${spec%%|*}; args=${spec#*|}
   bash tools/prof_extra.sh $tag $args >> gpurun_out/collect_r05.log 2>&1
   name=$(echo "$args" | sed 's/.*--name //')
