@@ -137,6 +137,8 @@ class Runner:
             vlib.lib().vpx_set_option(vlib.OPT_EXPERIMENT, int(os.environ["VPX_BENCH_EXPERIMENT"]))
         if os.environ.get("VPX_BENCH_FUSE_REVERSED") in ("0", "1") and hasattr(self.model, "fuse_reversed_pass"):   # A/B runs (tools/)
             self.model.fuse_reversed_pass = os.environ["VPX_BENCH_FUSE_REVERSED"] == "1"
+        if os.environ.get("VPX_BENCH_DECOUPLE_SLAB_LIMIT") and hasattr(self.model, "DECOUPLE_SLAB_LIMIT"):   # A/B runs (tools/)
+            self.model.DECOUPLE_SLAB_LIMIT = int(os.environ["VPX_BENCH_DECOUPLE_SLAB_LIMIT"])
         if os.environ.get("VPX_BENCH_DEFER_WGRAD") in ("0", "1") and hasattr(self.model, "defer_weight_gradients"):   # A/B runs (tools/)
             self.model.defer_weight_gradients = os.environ["VPX_BENCH_DEFER_WGRAD"] == "1"
         with torch.no_grad():

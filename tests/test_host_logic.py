@@ -115,6 +115,26 @@ def test_unsupported_glue_fails_when_the_model_is_built_and_cpu_tensors_are_name
         vpx.ops.conv2d_ex(torch.rand(1, 4, 8, 8), torch.rand(4, 4, 1, 1, requires_grad=True), None, 2, 0, False, 0.0, "f32")
 
 
+def test_predrnn_training_slabs_have_byte_limits(vpx, monkeypatch):
+    """The two round-5 slab schemes of PredRNN_V2 fall back to the per-step paths above their byte limits (no unbounded allocation)."""
+    from vp_suite_amd.models import MODEL_CLASSES
+    m = MODEL_CLASSES["predrnn-pp"]("cpu", img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0])
+    monkeypatch.setattr(vpx.ops.STWeightBank, "available", staticmethod(lambda *a: True))
+    built = {}
+    import vp_suite_amd.models.predrnn_v2 as pv
+    monkeypatch.setattr(pv, "_CellBanks", lambda model, geo, T: built.setdefault("geo", (geo, T)) and "banks")
+    assert m._weight_banks(4, 19) == "banks" and built["geo"][1] == 19
+    px = 4 * 16 * 16
+    need = sum(4 * px * (19 * 8 * 128 + 3 * 20 * 128) for _ in range(3)) + 4 * px * 19 * 16
+    m.BANK_BYTES_LIMIT = need
+    assert m._weight_banks(4, 19) == "banks"
+    m.BANK_BYTES_LIMIT = need - 1
+    assert m._weight_banks(4, 19) is None
+    m.defer_weight_gradients = False
+    m.BANK_BYTES_LIMIT = 1 << 60
+    assert m._weight_banks(4, 19) is None
+
+
 def test_workspace_cache_never_keeps_an_entry_larger_than_its_budget(vpx):
     C = vpx.ops._WorkspaceCache(budget_bytes=1000)
     w = torch.zeros(4)

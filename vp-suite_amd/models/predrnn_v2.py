@@ -96,6 +96,9 @@ class PredRNN_V2(VPModel):
     #: once per step with an autograd accumulation per step and tensor. Same sums in another order. Where the library cannot (LayerNorm,
     #: action-conditional cells, operand modes other than bf16x3, filter sizes other than 5) the steps compute them as before.
     defer_weight_gradients: bool = True
+    #: ... while the operand slabs of a pass (dG8 of every step and cell: T*B*H*W*8Ch*4 bytes per cell, plus the state slabs) stay below
+    #: this many bytes; a larger pass computes the weight gradients step by step as before (nothing is kept beyond a step's own context)
+    BANK_BYTES_LIMIT = 64 << 30
     #: the decoupling term of all layer-steps of a pass in ONE library call each way (ops.decouple_term_batched): the steps write their
     #: delta_c / delta_m into one slab. False: one adapter convolution + statistics + mean per layer-step, as the reference does.
     #: Used while the slab stays below `DECOUPLE_SLAB_LIMIT` bytes: beyond that the per-step tails win back what they lose in launches
@@ -258,6 +261,10 @@ class PredRNN_V2(VPModel):
         cin = [self.patch_c] + list(self.num_hidden[:self.num_layers - 1])
         geo = [(b, cin[i], self.num_hidden[i], self.rnn_h, self.rnn_w, self.filter_size) for i in range(self.num_layers)]
         if not all(ops.STWeightBank.available(*g, self.cell_precision) for g in geo):
+            return None
+        px = b * self.rnn_h * self.rnn_w
+        slab_bytes = sum(4 * px * (T * 8 * g[2] + 3 * (T + 1) * g[2]) for g in geo) + 4 * px * T * geo[0][1]
+        if slab_bytes > self.BANK_BYTES_LIMIT:
             return None
         return _CellBanks(self, geo, T)
 
