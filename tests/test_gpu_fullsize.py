@@ -162,6 +162,42 @@ def test_block_backward_at_batch128(vpx, Cin, Ch, HW, precision):
         assert _relmax(grads[0][s:s + 1], lv[0].grad) < 5e-5
 
 
+def test_wide_7x7_block_whose_eight_wave_tiles_do_not_fit_lds(vpx):
+    """Maximum sizes: a 7x7 ConvLSTM block with 288 hidden channels at a batch that selects the 8-wave convolution tiles. Its data
+    gradient contracts 4 * 288 gate channels: no 16- or 32-channel stage table is short enough and 64-channel stages of a 22 x 22 halo
+    tile need 168 KB of LDS in the 8-wave form — found by tools/fuzz_contract.py in round 5 (the launch refused it with 'invalid
+    argument'); the layout now falls back to the 4-wave form. Forward + every gradient of single samples against the oracle, batch-summed
+    gradients against the sum over chunks of the batch."""
+    from oracle import torch_ref as tr
+    B, T, Cin, Ch, H, W, k = 176, 2, 32, 288, 8, 16, 7
+    tag = "wide7"
+    x = seeded_rand((B, T, Cin, H, W), name_seed(tag + ".x")).cuda()
+    Wt = seeded_randn((4 * Ch, Cin + Ch, k, k), name_seed(tag + ".W"), 1.0 / np.sqrt((Cin + Ch) * k * k)).cuda()
+    b = seeded_randn((4 * Ch,), name_seed(tag + ".b"), 0.1).cuda()
+    g_out = seeded_randn((B, T, Ch, H, W), name_seed(tag + ".g")).cuda()
+
+    def run(sl):
+        lv = [t.clone().requires_grad_(True) for t in (x[sl], Wt, b)]
+        out, hT, cT = vpx.ops.convlstm_seq(lv[0], None, None, lv[1], lv[2], seq_len=T, in_channels=Cin, precision="bf16x3")
+        ((out * g_out[sl]).sum() + 0.5 * (cT * cT).sum()).backward()
+        return out.detach(), [t.grad for t in lv]
+
+    out, grads = run(slice(0, B))
+    acc = None
+    for c0 in range(0, B, 44):
+        o, g = run(slice(c0, c0 + 44))
+        assert _relmax(out[c0:c0 + 44], o) < 1e-5 and _relmax(grads[0][c0:c0 + 44], g[0]) < 5e-5
+        acc = g[1:] if acc is None else [a + t for a, t in zip(acc, g[1:])]
+    for name, got, want in zip(("dW", "db"), grads[1:], acc):
+        assert _relmax(got, want) < 5e-5, name
+    s = 137
+    lv = [t.detach().cpu().clone().requires_grad_(True) for t in (x[s:s + 1], Wt, b)]
+    zp = torch.zeros(1, Ch, H, W)   # (no peepholes = zero peepholes: conv_lstm_hzzone.py:30-32 initialises them so)
+    ro, (rh, rc) = tr.convlstm_hzzone_seq(lv[0], None, T, lv[1], lv[2], zp, zp, zp, padding=k // 2)
+    ((ro * g_out[s:s + 1].cpu()).sum() + 0.5 * (rc * rc).sum()).backward()
+    assert _relmax(out[s:s + 1], ro) < 2e-5 and _relmax(grads[0][s:s + 1], lv[0].grad) < 5e-5
+
+
 def test_c1_literal_batch4_full_model_vs_oracle(vpx):
     """BASELINE configs[0]/[1] at their literal batch: convlstm-shi, 1x64x64, 10 -> 10, FOUR samples — every recurrent block on
     the small-grid kernel (cell3), the glue at 40 frames per launch, weight packs re-used on the second call."""

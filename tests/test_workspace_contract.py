@@ -286,3 +286,17 @@ def test_small_workspaces(L):
         _ok(L, L.vpx_layernorm_bwd(_fake(1), _fake(2), _fake(3), _fake(4), _fake(5), _fake(6), _fake(7), B, 256, 128, ctypes.c_void_p(WS_BASE), nb, None), "ln bwd", False)
     nb = L.vpx_mse_loss_workspace_bytes()
     _ok(L, L.vpx_mse_loss(_fake(1), _fake(2), 128 * 10 * 64 * 64, 1280, 1.0, _fake(3), _fake(4), ctypes.c_void_p(WS_BASE), nb, None), "mse", False)
+
+
+def test_random_shapes_fuzz():
+    """tools/fuzz_contract.py: 4 000 random descriptors (odd map sizes, channel counts that are multiples of nothing, every kernel size,
+    layout, operand mode and option bit) through every entry point that takes a workspace, in its own process (it switches the library
+    into a dry run). Round 5: its first run found a 7x7 ConvLSTM data gradient over 4 * 288 gate channels whose 8-wave form needs 168 KB
+    of LDS — refused at the launch with an 'invalid argument'; the layouts now fall back to the 4-wave form (conv_fits_lds)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for seed in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_contract.py"), "2000", str(seed)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -201,7 +201,9 @@ static int ex_mw(const vpx_conv_desc* d, int Ht, int Wt, int sd) {
     if (d->precision == VPX_PREC_F32) return 1;
     if (forced == 1 || forced == 2) return forced;
     if (sd != 1) return 1;
-    return pick_mw(d->N, Ht, Wt, plain_tiles(d->Co), d->precision);
+    const int mw = pick_mw(d->N, Ht, Wt, plain_tiles(d->Co), d->precision);
+    const int segC[1] = {d->Ci};
+    return (mw > 1 && !conv_fits_lds(segC, 1, d->kh, d->kw, plain_groups(d->Co), d->precision, mw, sd)) ? 1 : mw;
 }
 
 // one launch: tile space Ht x Wt, kernel taps th x tw, halo origin (oy, ox), input step `sd`

@@ -913,6 +913,19 @@ int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int p
     return best;
 }
 
+// Does the implicit-GEMM launch with these K segments fit — a stage table of at most MAX_STAGE entries and activation tile + weight
+// ring within the CU's 160 KiB of LDS? (Round 5, found by tools/fuzz_contract.py: a 7x7 data gradient over 4 * 288 gate channels has no
+// 16- or 32-channel stage table short enough, and its 64-channel stages need 168 KB in the 8-wave form: the layout functions now fall
+// back to the 4-wave form, or refuse the descriptor, instead of failing at the launch.)
+bool conv_fits_lds(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw, int stride, int qpc) {
+    ConvStage st[MAX_STAGE];
+    int chunks = 0;
+    const int n = build_stages(st, &chunks, segC, nseg, kh * kw, pick_stage_channels(segC, nseg, kh, kw, ng, prec, mw, stride, qpc), prec, qpc);
+    if (n < 0) return false;
+    const size_t lds = (size_t)conv_a_bytes(st, n, kh, kw, mw, stride) + 2 * (size_t)ng * 32 * (mode_kc(prec, qpc) * 4 + 16);
+    return lds <= 160 * 1024;
+}
+
 int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw, int stride) {
     const int npos = ((TILE_H * mw - 1) * stride + kh) * ((TILE_W - 1) * stride + kw);
     int m = 16;

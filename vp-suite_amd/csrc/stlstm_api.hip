@@ -81,6 +81,7 @@ int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
     const int segG[2] = {d->Cin, d->Ch};
     const int segO[2] = {d->Ch, d->Ch};
     L.mw_g = d->layer_norm ? 1 : pick_mw(d->B, d->H, d->W, 2 * L.tiles32, d->precision);
+    if (L.mw_g > 1 && !conv_fits_lds(segG, 2, d->k, d->k, 4, d->precision, L.mw_g)) L.mw_g = 1;   // (8-wave form too large for LDS)
     L.nstage_g = build_stages(L.stage_g, &L.chunks_g, segG, 2, L.taps, pick_stage_channels(segG, 2, d->k, d->k, 4, d->precision, L.mw_g), d->precision);
     const long long m_tiles = (long long)d->B * ((d->H + TILE_H - 1) / TILE_H) * ((d->W + TILE_W - 1) / TILE_W);
     // conv_o: fused with the output gate (32 channels per workgroup) when that fills the chip; on small maps a 128-wide
@@ -95,6 +96,11 @@ int st_layout(const vpx_stlstm_desc* d, STLayout& L) {
         if (ks > 1) { L.o_split = ks; L.o_ng = ng; L.o_tiles = plain_tiles_ng(d->Ch, ng); }
     }
     L.mw_o = d->layer_norm ? 1 : pick_mw(d->B, d->H, d->W, L.o_tiles, d->precision);
+    if (L.mw_o > 1 && !conv_fits_lds(segO, 2, d->k, d->k, L.o_ng, d->precision, L.mw_o)) L.mw_o = 1;
+    if (!conv_fits_lds(segG, 2, d->k, d->k, 4, d->precision, L.mw_g) || !conv_fits_lds(segO, 2, d->k, d->k, L.o_ng, d->precision, L.mw_o)) {
+        set_error("stlstm: %dx%d kernel over %d+%d channels does not fit the kernel's LDS stages", d->k, d->k, d->Cin, d->Ch);
+        return VPX_ERR_UNSUPPORTED;
+    }
     L.nstage_o = build_stages(L.stage_o, &L.chunks_o, segO, 2, L.taps, pick_stage_channels(segO, 2, d->k, d->k, L.o_ng, d->precision, L.mw_o), d->precision);
     L.nstage_l = build_stages(L.stage_l, &L.chunks_l, segO, 2, 1, pick_stage_channels(segO, 2, 1, 1, L.ng_l, d->precision), d->precision);
     if (L.nstage_g < 0 || L.nstage_o < 0 || L.nstage_l < 0) { set_error("stlstm: too many channel stages"); return VPX_ERR_UNSUPPORTED; }

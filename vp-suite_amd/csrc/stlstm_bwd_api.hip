@@ -38,6 +38,8 @@ int mk_dg(STBwdLayout::DG& g, const int* segC, int nseg, int k, int n_out, int p
     const int taps = k * k;
     g.ng = plain_groups(n_out, m_tiles);
     g.mw = pick_mw_tiles(m_tiles, plain_tiles_ng(n_out, g.ng), prec);  // 8-wave form when the grid stays large
+    if (g.mw > 1 && !conv_fits_lds(segC, nseg, k, k, g.ng, prec, g.mw)) g.mw = 1;   // (... and fits LDS)
+    if (!conv_fits_lds(segC, nseg, k, k, g.ng, prec, g.mw)) return -1;
     g.nstage = build_stages(g.stage, &g.chunks, segC, nseg, taps, pick_stage_channels(segC, nseg, k, k, g.ng, prec, g.mw), prec);
     if (g.nstage < 0) return -1;
     g.tiles = plain_tiles_ng(n_out, g.ng);

@@ -163,6 +163,14 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     const int segC[2] = {d->Cin, d->Ch};
     L.mw = pick_mw(d->B, d->H, d->W, L.n_tiles, d->precision);
     L.qpc = pick_qpc(segC, 2, d->kh, d->kw, 4, d->precision, L.mw);
+    if (L.mw > 1 && !conv_fits_lds(segC, 2, d->kh, d->kw, 4, d->precision, L.mw, 1, L.qpc)) {   // (8-wave form too large for LDS: 4-wave form)
+        L.mw = 1;
+        L.qpc = pick_qpc(segC, 2, d->kh, d->kw, 4, d->precision, 1);
+    }
+    if (!conv_fits_lds(segC, 2, d->kh, d->kw, 4, d->precision, L.mw, 1, L.qpc)) {
+        set_error("convlstm: %dx%d kernel over %d+%d channels does not fit the cell kernel's LDS stages", d->kh, d->kw, d->Cin, d->Ch);
+        return VPX_ERR_UNSUPPORTED;
+    }
     L.nstage = build_stages(L.stage, &L.chunks_total, segC, 2, L.taps, pick_stage_channels(segC, 2, d->kh, d->kw, 4, d->precision, L.mw, 1, L.qpc), d->precision, L.qpc);
     if (L.nstage < 0) { set_error("convlstm: too many channel stages (Cin=%d Ch=%d)", d->Cin, d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.split = 0;
@@ -218,6 +226,14 @@ static inline int convlstm_layout(const vpx_convlstm_desc* d, ConvLSTMLayout& L)
     const int segD[1] = {N4};
     L.d_mw = pick_mw(d->B, d->H, d->W, plain_tiles(Ct), d->precision);
     L.d_qpc = pick_qpc(segD, 1, d->kh, d->kw, 4, d->precision, L.d_mw);
+    if (L.d_mw > 1 && !conv_fits_lds(segD, 1, d->kh, d->kw, 4, d->precision, L.d_mw, 1, L.d_qpc)) {
+        L.d_mw = 1;
+        L.d_qpc = pick_qpc(segD, 1, d->kh, d->kw, 4, d->precision, 1);
+    }
+    if ((d->flags & VPX_FLAG_SAVE_FOR_BWD) && !conv_fits_lds(segD, 1, d->kh, d->kw, 4, d->precision, L.d_mw, 1, L.d_qpc)) {
+        set_error("convlstm: the %dx%d data gradient over %d gate channels does not fit the kernel's LDS stages", d->kh, d->kw, N4);
+        return VPX_ERR_UNSUPPORTED;
+    }
     L.d_nstage = build_stages(L.d_stage, &L.d_chunks, segD, 1, L.taps, pick_stage_channels(segD, 1, d->kh, d->kw, 4, d->precision, L.d_mw, 1, L.d_qpc), d->precision, L.d_qpc);
     if (L.d_nstage < 0) { set_error("convlstm: too many channel stages in the data-gradient conv (Ch=%d)", d->Ch); return VPX_ERR_UNSUPPORTED; }
     L.d_tiles_full = plain_tiles(Ct);

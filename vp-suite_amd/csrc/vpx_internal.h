@@ -153,6 +153,7 @@ const char* ws_violation();   // "" when the running call had none
 int build_stages(ConvStage* st, int* chunks_total, const int* segC, int nseg, int taps, int cs, int prec, int qpc = 2);
 int pick_stage_channels(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw = 1, int stride = 1, int qpc = 2);
 int conv_a_bytes(const ConvStage* st, int nstage, int kh, int kw, int mw = 1, int stride = 1);
+bool conv_fits_lds(const int* segC, int nseg, int kh, int kw, int ng, int prec, int mw = 1, int stride = 1, int qpc = 2);
 // rows per wave: 2 (16x16 workgroup tile) when the operand mode profits (bf16x3 is LDS/issue-bound, not MFMA-bound) and
 // the launch still has >= 2 workgroups per CU; else 1
 int pick_mw(int B, int H, int W, int n_tiles, int prec);
