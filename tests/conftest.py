@@ -24,7 +24,7 @@ def pytest_configure(config):
 #   4  f3     LayerNorm ST-LSTM, action-conditional cell      *layernorm*, *_ln*, *action*
 #   5  f4     TrajGRU, PhyDNet's SingleStepConvLSTM           *trajgru*, *phydnet*
 _FILE_RANK = {"test_gpu_convlstm.py": 0, "test_gpu_stlstm.py": 0, "test_gpu_cell2.py": 0, "test_gpu_models.py": 1, "test_gpu_fullsize.py": 1,
-              "test_gpu_parity_r4.py": 1, "test_gpu_train.py": 1, "test_gpu_dp.py": 2, "test_gpu_convq.py": 3, "test_gpu_more.py": 3}
+              "test_gpu_parity_r4.py": 1, "test_gpu_train.py": 1, "test_gpu_dp.py": 2, "test_gpu_convq.py": 3, "test_gpu_more.py": 3, "test_gpu_fuzz.py": 3}
 
 
 def _gpu_rank(item):

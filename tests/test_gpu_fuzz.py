@@ -1,0 +1,175 @@
+"""Random-shape parity sweep on the GPU (seeded; the CPU counterpart for the workspace contract is tools/fuzz_contract.py): ConvLSTM
+blocks, ST-LSTM steps and stage-glue layers at shapes nobody tuned for — ragged maps, channel counts that are multiples of nothing, every
+kernel size, both gate orders, missing inputs / states / peepholes — forward and every gradient against the oracle (torch fp32 on the
+CPU), in exact-fp32 and bf16x3 operand modes, under the guard bands of tests/canary.py."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import name_seed, seeded_rand, seeded_randn
+
+pytestmark = pytest.mark.gpu
+MORE = int(os.environ.get("VPX_FUZZ_CHUNKS", "0"))   # extra chunks of random cases for a one-off wider sweep (tools/, not the driver's run)
+
+
+def _relmax(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _convlstm_cases(n, seed):
+    rng = random.Random(seed)
+    chs = [1, 2, 3, 5, 8, 12, 16, 20, 24, 32, 40, 48, 64, 72, 96]
+    dims = [3, 5, 8, 9, 12, 16, 17, 20, 24, 31, 32, 33, 40, 48]
+    out = []
+    while len(out) < n:
+        c = dict(B=rng.choice([1, 2, 3, 5, 8]), T=rng.choice([1, 2, 3]), Cin=rng.choice(chs), Ch=rng.choice(chs), H=rng.choice(dims), W=rng.choice(dims),
+                 k=rng.choice([1, 3, 3, 3, 5, 7]), gate=rng.randrange(2), has_x=rng.random() < 0.85, has_h0=rng.random() < 0.6, peep=rng.random() < 0.5,
+                 bias=rng.random() < 0.8, prec=rng.choice(["f32", "bf16x3", "bf16x3"]))
+        if not c["has_x"] and not c["has_h0"]:
+            continue
+        if c["B"] * c["T"] * c["H"] * c["W"] * (c["Cin"] + c["Ch"]) * c["Ch"] * c["k"] ** 2 > 3e9:   # keep the CPU oracle in seconds
+            continue
+        out.append(c)
+    return out
+
+
+@pytest.mark.parametrize("chunk", range(4 + MORE))
+def test_random_convlstm_blocks_vs_oracle(vpx, chunk):
+    from oracle import torch_ref as tr
+    for i, c in enumerate(_convlstm_cases(12, 1000 + chunk)):
+        tag = f"fuzz.clstm.{chunk}.{i}"
+        B, T, Cin, Ch, H, W, k = c["B"], c["T"], c["Cin"], c["Ch"], c["H"], c["W"], c["k"]
+        x = seeded_rand((B, T, Cin, H, W), name_seed(tag + ".x")) if c["has_x"] else None
+        h0 = seeded_randn((B, Ch, H, W), name_seed(tag + ".h"), 0.5) if c["has_h0"] else None
+        c0 = seeded_randn((B, Ch, H, W), name_seed(tag + ".c"), 0.5) if c["has_h0"] else None
+        Wt = seeded_randn((4 * Ch, Cin + Ch, k, k), name_seed(tag + ".W"), 1.0 / np.sqrt((Cin + Ch) * k * k))
+        b = seeded_randn((4 * Ch,), name_seed(tag + ".b"), 0.1) if c["bias"] else None
+        peep = [seeded_randn((1, Ch, H, W), name_seed(tag + f".p{j}"), 0.1) for j in range(3)] if (c["peep"] and c["gate"] == 0) else [None] * 3
+        g_out = seeded_randn((B, T, Ch, H, W), name_seed(tag + ".g"))
+        leaves = {"x": x, "h0": h0, "c0": c0, "W": Wt, "b": b, "p0": peep[0], "p1": peep[1], "p2": peep[2]}
+        dev = {n: (None if t is None else t.cuda().requires_grad_(True)) for n, t in leaves.items()}
+        out, hT, cT = vpx.ops.convlstm_seq(dev["x"], dev["h0"], dev["c0"], dev["W"], dev["b"], dev["p0"], dev["p1"], dev["p2"], seq_len=T, in_channels=Cin,
+                                           gate_order=(vpx._lib.GATE_IFOG if c["gate"] else vpx._lib.GATE_IFGO), precision=c["prec"])
+        ((out * g_out.cuda()).sum() + 0.5 * (cT * cT).sum() + 0.25 * (hT * hT).sum()).backward()
+        ref = {n: (None if t is None else t.clone().requires_grad_(True)) for n, t in leaves.items()}
+        if c["gate"] == 0:   # hzzone block (conv_lstm_hzzone.py:38-70): peepholes, zero tensors where None
+            zp = torch.zeros(1, Ch, H, W)
+            ro, (rh, rc) = tr.convlstm_hzzone_seq(ref["x"], None if h0 is None else (ref["h0"], ref["c0"]), T, ref["W"], ref["b"],
+                                                  *(ref[f"p{j}"] if peep[j] is not None else zp for j in range(3)), padding=k // 2)
+        else:                # ndrplz cell (conv_lstm_ndrplz.py:28-43), gate order (i, f, o, g), no peepholes
+            hr = ref["h0"] if h0 is not None else torch.zeros(B, Ch, H, W)
+            cr = ref["c0"] if h0 is not None else torch.zeros(B, Ch, H, W)
+            outs = []
+            for t in range(T):
+                xt = ref["x"][:, t] if x is not None else torch.zeros(B, Cin, H, W)
+                hr, cr = tr.convlstm_ndrplz_cell(xt, hr, cr, ref["W"], ref["b"])
+                outs.append(hr)
+            ro, rh, rc = torch.stack(outs, 1), hr, cr
+        ((ro * g_out).sum() + 0.5 * (rc * rc).sum() + 0.25 * (rh * rh).sum()).backward()
+        tol = 2e-5 if c["prec"] == "f32" else 5e-5
+        assert _relmax(out, ro) < tol and _relmax(cT, rc) < tol, (c, _relmax(out, ro))
+        for n in leaves:
+            if leaves[n] is None or (n == "x" and x is None):
+                continue
+            if ref[n].grad is None:
+                continue
+            assert _relmax(dev[n].grad, ref[n].grad) < 2e-4, (c, n, _relmax(dev[n].grad, ref[n].grad))
+
+
+def _stlstm_cases(n, seed):
+    rng = random.Random(seed)
+    chs = [4, 8, 12, 16, 24, 32, 40, 64]
+    dims = [4, 7, 8, 12, 16, 17, 24, 32]
+    out = []
+    while len(out) < n:
+        c = dict(B=rng.choice([1, 2, 3, 6]), Cin=rng.choice(chs + [1, 3, 5]), Ch=rng.choice(chs), H=rng.choice(dims), W=rng.choice(dims), k=rng.choice([1, 3, 5, 5, 7]),
+                 ln=rng.random() < 0.3, prec=rng.choice(["f32", "bf16x3", "bf16x3"]))
+        if c["B"] * c["H"] * c["W"] * (c["Cin"] + 2 * c["Ch"]) * c["Ch"] * 16 * c["k"] ** 2 > 3e9:
+            continue
+        out.append(c)
+    return out
+
+
+@pytest.mark.parametrize("chunk", range(3 + MORE))
+def test_random_stlstm_steps_vs_oracle(vpx, chunk):
+    from oracle import torch_ref as tr
+    for i, c in enumerate(_stlstm_cases(10, 2000 + chunk)):
+        tag = f"fuzz.st.{chunk}.{i}"
+        B, Cin, Ch, H, W, k = c["B"], c["Cin"], c["Ch"], c["H"], c["W"], c["k"]
+        shapes = {"Wx": (7 * Ch, Cin, k, k), "Wh": (4 * Ch, Ch, k, k), "Wm": (3 * Ch, Ch, k, k), "Wo": (Ch, 2 * Ch, k, k), "Wlast": (Ch, 2 * Ch, 1, 1)}
+        Ws = {n: seeded_randn(s_, name_seed(f"{tag}.{n}"), 1.0 / np.sqrt(s_[1] * s_[2] * s_[3])) for n, s_ in shapes.items()}
+        st = [seeded_randn((B, Cin if j == 0 else Ch, H, W), name_seed(f"{tag}.s{j}"), 0.5) for j in range(4)]
+        ln = []
+        if c["ln"]:
+            for j, mult in enumerate((7, 4, 3, 1)):
+                ln += [1.0 + seeded_randn((mult * Ch, H, W), name_seed(f"{tag}.lg{j}"), 0.1), seeded_randn((mult * Ch, H, W), name_seed(f"{tag}.lb{j}"), 0.1)]
+        gout = [seeded_randn((B, Ch, H, W), name_seed(f"{tag}.g{j}")) for j in range(5)]
+        dev_s = [t.cuda().requires_grad_(True) for t in st]
+        dev_w = [Ws[n].cuda().requires_grad_(True) for n in shapes]
+        dev_ln = [t.cuda().requires_grad_(True) for t in ln]
+        outs = vpx.ops.stlstm_step(*dev_s, *dev_w, precision=c["prec"], ln=dev_ln)
+        sum((o * g.cuda()).sum() for o, g in zip(outs, gout)).backward()
+        ref_s = [t.clone().requires_grad_(True) for t in st]
+        ref_w = [Ws[n].clone().requires_grad_(True) for n in shapes]
+        ref_ln = [t.clone().requires_grad_(True) for t in ln]
+        pd = {"conv_x.0.weight": ref_w[0], "conv_h.0.weight": ref_w[1], "conv_m.0.weight": ref_w[2], "conv_o.0.weight": ref_w[3], "conv_last.weight": ref_w[4]}
+        for j, name in enumerate(("conv_x", "conv_h", "conv_m", "conv_o")):
+            if ln:
+                pd[f"{name}.1.weight"], pd[f"{name}.1.bias"] = ref_ln[2 * j], ref_ln[2 * j + 1]
+        routs = tr.stlstm_cell(*ref_s, pd, layer_norm=bool(ln))
+        sum((o * g).sum() for o, g in zip(routs, gout)).backward()
+        tol = 2e-5 if c["prec"] == "f32" else 6e-5
+        for o, r in zip(outs, routs):
+            assert _relmax(o, r) < tol, (c, _relmax(o, r))
+        for a, r in zip(dev_s + dev_w + dev_ln, ref_s + ref_w + ref_ln):
+            assert _relmax(a.grad, r.grad) < 2e-4, (c, _relmax(a.grad, r.grad))
+
+
+@pytest.mark.parametrize("chunk", range(1 + MORE))
+def test_random_glue_layers_vs_torch(vpx, chunk):
+    rng = random.Random(3000 + chunk)
+    chs = [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 40, 64, 96]
+    dims = [4, 5, 7, 8, 12, 15, 16, 17, 24, 31, 32, 33]
+    done = 0
+    while done < 40:
+        tr_, Ci, Co, k, s, H, W, n = rng.randrange(2), rng.choice(chs), rng.choice(chs), rng.choice([1, 2, 3, 4, 5, 7]), rng.choice([1, 2]), rng.choice(dims), rng.choice(dims), rng.choice([1, 2, 5, 12])
+        p = rng.choice([0, 1, 2, 3])
+        if k < s or not vpx.ops.glue_supported(k, k, s, p, bool(tr_)) or (not tr_ and (H + 2 * p < k or W + 2 * p < k)):
+            continue
+        prec = rng.choice(["f32", "bf16x3"])
+        tag = f"fuzz.glue.{chunk}.{done}"
+        x = seeded_randn((n, Ci, H, W), name_seed(tag + "x"))
+        w = seeded_randn((Ci, Co, k, k) if tr_ else (Co, Ci, k, k), name_seed(tag + "w"), 1.0 / np.sqrt(Ci * k * k))
+        b = seeded_randn((Co,), name_seed(tag + "b"), 0.1)
+        try:
+            ref = F.conv_transpose2d(x, w, b, stride=s, padding=p) if tr_ else F.conv2d(x, w, b, stride=s, padding=p)
+        except RuntimeError:
+            continue
+        if ref.numel() == 0:
+            continue
+        lv = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+        try:
+            y = vpx.ops.conv2d_ex(lv[0], lv[1], lv[2], s, p, bool(tr_), 0.2, prec)
+        except vpx.VpxError as e:   # a layer without a library backward says so in the FORWARD of a call that needs gradients: inference still runs
+            assert "no backward" in str(e)
+            with torch.no_grad():
+                y = vpx.ops.conv2d_ex(lv[0], lv[1], lv[2], s, p, bool(tr_), 0.2, prec)
+            assert _relmax(y, F.leaky_relu(ref, 0.2)) < (2e-5 if prec == "f32" else 6e-5)
+            continue
+        refy = F.leaky_relu(ref, 0.2)
+        tol = 2e-5 if prec == "f32" else 6e-5
+        assert y.shape == refy.shape and _relmax(y, refy) < tol, ((tr_, Ci, Co, k, s, p, H, W, n, prec), _relmax(y, refy))
+        gy = seeded_randn(tuple(ref.shape), name_seed(tag + "g"))
+        rl = [t.clone().requires_grad_(True) for t in (x, w, b)]
+        rr = F.conv_transpose2d(rl[0], rl[1], rl[2], stride=s, padding=p) if tr_ else F.conv2d(rl[0], rl[1], rl[2], stride=s, padding=p)
+        (rr * torch.where(y.detach().cpu() > 0, 1.0, 0.2) * gy).sum().backward()   # LeakyReLU' at the sign of the library's output (kink: test_gpu_more.py)
+        (y * gy.cuda()).sum().backward()
+        for a, r in zip(lv, rl):
+            assert _relmax(a.grad, r.grad) < 2e-4, ((tr_, Ci, Co, k, s, p, H, W, n, prec), _relmax(a.grad, r.grad))
+        done += 1

@@ -471,10 +471,21 @@ def conv2d_ex(x, w, bias, stride, padding, transposed=False, leaky_slope=0.0, pr
     """Conv2d / ConvTranspose2d (stride 1 or 2; `output_padding` for transposed layers) + bias + LeakyReLU, differentiable."""
     kh, kw = int(w.shape[2]), int(w.shape[3])
     # (decided here: inside Function.forward grad mode is always off and needs_input_grad ignores torch.no_grad())
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, bias)) and (kh < stride or kw < stride or leaky_slope < 0.0):
-        raise _lib.VpxError(f"conv2d_ex: layer (k={kh}x{kw}, stride={stride}, transposed={bool(transposed)}, slope={leaky_slope}) has no backward "
-                            f"in the library (vpx_conv2d_ex_bwd needs kernel >= stride and a non-negative LeakyReLU slope): "
-                            f"unsupported in a call that requires gradients")
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w, bias)):
+        ok = kh >= stride and kw >= stride and leaky_slope >= 0.0
+        if ok and x.dim() == 4:   # ... and the adjoint layer must be one the library runs (the same query the backward makes)
+            N, Ci, H, Wd = x.shape
+            Co = int(w.shape[1] if transposed else w.shape[0])
+            d = ConvDesc(N, H, Wd, Ci, Co, kh, kw, int(stride), int(padding), int(bool(transposed)), float(leaky_slope), PRECISIONS[precision],
+                         int(output_padding[0]), int(output_padding[1]))
+            L = _lib.lib()
+            ho, wo = ctypes.c_int(0), ctypes.c_int(0)
+            if L.vpx_conv2d_ex_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == 0:
+                ok = L.vpx_conv2d_ex_bwd_workspace_bytes(ctypes.byref(d)) != 0
+        if not ok:
+            raise _lib.VpxError(f"conv2d_ex: layer (k={kh}x{kw}, stride={stride}, padding={padding}, transposed={bool(transposed)}, slope={leaky_slope}) has no "
+                                f"backward in the library (vpx_conv2d_ex_bwd needs kernel >= stride, a non-negative LeakyReLU slope and an adjoint layer "
+                                f"it implements: padding <= kernel - 1): unsupported in a call that requires gradients")
     return _ConvExFn.apply(x, w, bias, stride, padding, transposed, leaky_slope, PRECISIONS[precision], tuple(output_padding))
 
 
