@@ -100,7 +100,17 @@ def test_cell2_bit_identical_to_first_generation_and_matches_oracle(vpx, cell2_s
     assert _relmax(o2, ro) < 2e-5 and _relmax(c2, rc) < 2e-5 and _relmax(h2, rh) < 2e-5
 
 
-@pytest.mark.parametrize("tag", ["enc2", "fore1_states", "fore3_noinput"])
+CASES.update({  # plain-bf16 shapes: odd stage counts (a five-step last period), the shortest K loops, a long one, many tiles per CU
+    "plain_s5": (16, 64, 32, 32, 2, 3, True, True, True, 0),
+    "plain_s3": (16, 32, 32, 16, 3, 2, True, False, False, 1),
+    "plain_s2_noinput": (32, 32, 16, 32, 2, 3, False, True, True, 0),
+    "plain_s14": (96, 128, 32, 32, 2, 2, True, True, True, 0),
+    "plain_s7_many_tiles": (48, 64, 64, 64, 24, 2, True, False, True, 0),
+})
+
+
+@pytest.mark.parametrize("tag", ["enc2", "fore1_states", "fore3_noinput", "plain_s5", "plain_s3", "plain_s2_noinput", "plain_s14",
+                                 "plain_s7_many_tiles"])
 def test_plain_bf16_on_the_q_kernel_matches_first_generation_bf16(vpx, cell2_switch, tag):
     """VPX_PREC_BF16 (BASELINE configs[1]'s literal dtype; hi parts only, one MFMA per product, NOT inside the 1e-4 bar) on
     cell2_kernel_q<.., 4, true> (inference, maps in whole 16x16 tiles) against the first-generation kernel's bf16 mode — the same

@@ -15,9 +15,10 @@ Wt = torch.randn(4 * Ch, Cin + Ch, 3, 3, device=dev) * 0.03
 b = torch.zeros(4 * Ch, device=dev)
 pw = [torch.randn(1, Ch, H, W, device=dev) * 0.1 for _ in range(3)]
 h0 = torch.randn(B, Ch, H, W, device=dev) * 0.5
+L.vpx_set_option(v._lib.OPT_EXPERIMENT, int(os.environ.get("EXP", "0"), 0))
 with torch.no_grad():
     for _ in range(20):
-        v.ops.convlstm_seq(x, h0, h0, Wt, b, *pw, seq_len=T, in_channels=Cin, precision="bf16x3")
+        v.ops.convlstm_seq(x, h0, h0, Wt, b, *pw, seq_len=T, in_channels=Cin, precision=os.environ.get("PREC", "bf16x3"))
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 512)()
 L.vpx_dbg_cell2_stamps.argtypes = [ctypes.c_void_p]

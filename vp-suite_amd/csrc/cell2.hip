@@ -131,11 +131,16 @@ size_t cell2_packed_bytes_q(int n_tiles, int S) { return (size_t)n_tiles * cell2
 // developer build only (make ablate): per-wave s_memtime stamps of ONE workgroup (block id = Cell2Plan::_p), read back with
 // vpx_dbg_cell2_stamps(). Never compiled into the product library.
 __device__ unsigned long long c2_stamps[8 * 64];
+// ... and of EVERY workgroup of a half-tile q-form launch: start, loop end, end (s_memtime) and HW_ID | XCC_ID << 32 — which workgroups shared
+// a CU and in what phase relation (tools/trace_cell2q.py); vpx_dbg_cell2_trace() reads it back.
+__device__ unsigned long long c2_trace[8192 * 4];
+#define C2_TRACE(k) do { if (wave == 0 && lane == 0 && L < 8192) c2_trace[L * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define C2_STAMP(slot) do { if (stamp_on && lane == 0) c2_stamps[wave * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define C2_EPI_STAMP(slot) do { if (stamp_on && (lane & 63) == 0) c2_stamps[(prow >> 2) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define C2_STAMP(slot) do { } while (0)
 #define C2_EPI_STAMP(slot) do { } while (0)
+#define C2_TRACE(k) do { } while (0)
 #endif
 
 // The ConvLSTM epilogue (conv_lstm_hzzone.py:62-68), plus the split copy of h_t for the next step / the weight gradient.
@@ -269,7 +274,8 @@ struct Cell2Epi {
         // (LDS operations of one wave execute in order: vec_math's reads see these writes without a barrier)
     }
 
-    __device__ __forceinline__ void vec_math(const VecIn& v, const char* lds, int b, int n_tile, int lane, int H, int W) const {
+    // (ab: timing-only ablations of the developer build — experiment bits 17 = no stores, 26 = no transcendentals; results are garbage)
+    __device__ __forceinline__ void vec_math(const VecIn& v, const char* lds, int b, int n_tile, int lane, int H, int W, int ab = 0) const {
         const unsigned Ch = (unsigned)a.Ch;
         const float* ldsf = reinterpret_cast<const float*>(lds);
         const int cg = lane & 7, p4 = lane >> 3;
@@ -297,6 +303,13 @@ struct Cell2Epi {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float c0 = v.cp[k][e];
+#ifdef VPX_ABLATE
+                if (ab & (1 << 26)) {
+                    i4[e] = ai[e] + bi[e] + v.wi[k][e] * c0; f4[e] = af[e] + bf[e] + v.wf[k][e] * c0; g4[e] = ag[e] + bg[e];
+                    cn[e] = f4[e] * c0 + i4[e] * g4[e]; o4[e] = ao[e] + bo[e] + v.wo[k][e] * cn[e]; hn[e] = o4[e] * cn[e];
+                    continue;
+                }
+#endif
                 i4[e] = sigmoid_f(ai[e] + bi[e] + v.wi[k][e] * c0);
                 f4[e] = sigmoid_f(af[e] + bf[e] + v.wf[k][e] * c0);
                 g4[e] = tanh_f(ag[e] + bg[e]);
@@ -305,6 +318,9 @@ struct Cell2Epi {
                 hn[e] = o4[e] * tanh_f(cn[e]);
             }
             const unsigned eo = v.eo[k];
+#ifdef VPX_ABLATE
+            if (ab & (1 << 17)) { if (cn[0] + hn[1] + i4[2] + f4[3] + g4[0] + o4[1] == 1.2345e-30f) cout_b[eo] = 0.f; continue; }
+#endif
             *reinterpret_cast<f32x4*>(cout_b + eo) = cn;
             if (a.h_out) *reinterpret_cast<f32x4*>(hout_b + eo) = hn;   // (null: the consumer reads the split copy below — VPX_FLAG_OUT_SPLIT)
             if (g0) {
@@ -348,10 +364,18 @@ struct Cell2Epi {
 
     // (the q form is only selected for tiles inside the image and whole 32-channel tiles: cell2_q_applicable)
     __device__ __forceinline__ void finish16(const f32x4 (&acc)[4][8], char* smem, int wave, int lane, int b, int y0, int x0, int n_tile,
-                                             int /*ngr*/, int H, int W, bool stamp_on = false) const {
+                                             int /*ngr*/, int H, int W, bool stamp_on = false, int ab = 0) const {
         const int prow = 4 * wave;
         char* const lds = smem + wave * 16384;
         VecIn v0, v1;
+#ifdef VPX_ABLATE
+        if (ab & (1 << 18)) {   // timing only: no epilogue (one never-taken store keeps the accumulators alive)
+            float t = 0.f;
+            for (int m = 0; m < 4; ++m) for (int nt = 0; nt < 8; ++nt) for (int r = 0; r < 4; ++r) t += acc[m][nt][r];
+            if (t == 1.2345e-30f) a.c_out[0] = t;
+            return;
+        }
+#endif
         C2_EPI_STAMP(43);
         vec_load<false>(v0, b, y0, x0, n_tile, prow, lane, H, W);
         C2_EPI_STAMP(44);
@@ -361,11 +385,11 @@ struct Cell2Epi {
         C2_EPI_STAMP(46);
         vec_load<false>(v1, b, y0, x0, n_tile, prow + 2, lane, H, W);
         C2_EPI_STAMP(47);
-        vec_math(v0, lds, b, n_tile, lane, H, W);
+        vec_math(v0, lds, b, n_tile, lane, H, W, ab);
         C2_EPI_STAMP(48);
         vec_put16(acc, 1, lds, lane);
         C2_EPI_STAMP(49);
-        vec_math(v1, lds, b, n_tile, lane, H, W);
+        vec_math(v1, lds, b, n_tile, lane, H, W, ab);
         C2_EPI_STAMP(50);
         (void)stamp_on;
     }
@@ -766,6 +790,15 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
     int ngr = 4;
     if constexpr (!ALLG) { ngr = P.n_groups - n_tile * P.gpt; if (ngr > P.gpt) ngr = P.gpt; }
 
+#ifdef VPX_ABLATE
+    if (wave == 0 && lane == 0 && L < 8192) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        c2_trace[L * 4 + 3] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+#endif
+    C2_TRACE(0);
     char* const Abuf = smem;
     char* const Wbuf = smem + 2 * G::ABUF;
 
@@ -954,8 +987,9 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
         if constexpr (NW == 4) { const int t = wb0; wb0 = wb1; wb1 = t; }
     }
     C2_STAMP(40);
+    C2_TRACE(1);
 #ifdef VPX_ABLATE
-    if constexpr (std::is_same<Epi, Cell2Epi>::value) epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W, stamp_on);
+    if constexpr (std::is_same<Epi, Cell2Epi>::value) epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W, stamp_on, P._q);
     else
 #endif
     epi.finish16(acc, smem, wave, lane, b, y0, x0, n_tile, ngr, P.H, P.W);
@@ -964,6 +998,7 @@ __global__ __launch_bounds__(64 * NW, 2) void cell2_kernel_q(const Cell2Plan P, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // how long the epilogue's stores take to complete
 #endif
     C2_STAMP(42);
+    C2_TRACE(2);
 }
 
 // Half tile (cell2_kernel_q<.., 4>: 16x16-pixel tiles, two workgroups per CU) or the 32x16 tile? Measured (tools/ab_exp.py,
@@ -1012,6 +1047,14 @@ static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStrea
                 }
             }
             if (plan.plain) return hipErrorInvalidValue;   // (only the fused cell step has the plain form)
+#ifdef VPX_ABLATE
+            if (g_experiment & (1 << 19)) {   // timing only: ONE workgroup per CU (an LDS request above half a CU's)
+                static bool attr_big = false;
+                if (!attr_big) { vpx_func_attr(reinterpret_cast<const void*>(&cell2_kernel_q<Epi, ALLG, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); attr_big = true; }
+                VPX_LAUNCH((cell2_kernel_q<Epi, ALLG, 4>), dim3((unsigned)(per_xcd_h * 8)), dim3(256), 100 * 1024, s, p, epi);
+                return vpx_hip_last_error();
+            }
+#endif
             VPX_LAUNCH((cell2_kernel_q<Epi, ALLG, 4>), dim3((unsigned)(per_xcd_h * 8)), dim3(256), CQGeom<4>::LDS, s, p, epi);
             return vpx_hip_last_error();
         }
@@ -1121,6 +1164,9 @@ hipError_t launch_conv2(const Conv2Args& c, hipStream_t s) {
 }  // namespace vpx
 
 #ifdef VPX_ABLATE
+extern "C" int vpx_dbg_cell2_trace(unsigned long long* out32768) {
+    return (int)hipMemcpyFromSymbol(out32768, HIP_SYMBOL(vpx::c2_trace), sizeof(unsigned long long) * 8192 * 4);
+}
 extern "C" int vpx_dbg_cell2_stamps(unsigned long long* out512) {
     return (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(vpx::c2_stamps), sizeof(unsigned long long) * 512);
 }
