@@ -343,6 +343,40 @@ def test_stlstm_split_shadows_change_nothing(vpx, B):
         assert not any(hasattr(t, "_vpx_sp") for t in o)
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_single_tile_weight_gradients_with_many_k_slices(vpx, prec):
+    """Layers whose whole dW is one output tile (the decoupling adapter, a 1x1 / 3x3 head with <= 64 channels) cut their pixel sum into up to
+    256 K slices (round 5: 32 left most of the chip idle). At sizes where more than 32 slices are launched: the adapter gradient against the
+    oracle's restatement of predrnn_v2.py:197-206 under autograd, conv2d's against torch."""
+    from golden_util import seeded_randn
+    from oracle import torch_ref as tr
+    B, Ch, H, W = 48, 64, 16, 32     # 192 work items -> 192 slices
+    A = seeded_randn((Ch, Ch, 1, 1), name_seed("slices.adapter"), 1.0 / np.sqrt(Ch))
+    dc = seeded_randn((B, Ch, H, W), name_seed("slices.dc"))
+    dm = seeded_randn((B, Ch, H, W), name_seed("slices.dm"))
+    ref = [t.clone().requires_grad_(True) for t in (dc, dm, A)]
+    rv = tr.decouple_term(*ref)
+    rv.backward()
+    mine = [t.cuda().requires_grad_(True) for t in (dc, dm, A)]
+    v = vpx.ops.decouple_term(*mine, prec) if prec != "f32" else vpx.ops.decouple_term(*mine)
+    v.backward()
+    assert abs(float(v) - float(rv)) < 1e-5 * abs(float(rv))
+    tol = 2e-5 if prec == "f32" else 1e-4
+    for a, r, n in zip(mine, ref, ("d_delta_c", "d_delta_m", "d_adapter")):
+        assert _relmax(a.grad, r.grad) < tol, (n, _relmax(a.grad, r.grad))
+    for (Ci, Co, k, N, Hh, Ww) in [(64, 16, 1, 40, 16, 16), (32, 48, 3, 25, 24, 16)]:   # 80 / 75 items
+        x = seeded_randn((N, Ci, Hh, Ww), name_seed(f"slices.x{Ci}{k}"))
+        w = seeded_randn((Co, Ci, k, k), name_seed(f"slices.w{Ci}{k}"), 1.0 / np.sqrt(Ci * k * k))
+        b = seeded_randn((Co,), name_seed(f"slices.b{Ci}{k}"), 0.1)
+        gy = seeded_randn((N, Co, Hh, Ww), name_seed(f"slices.g{Ci}{k}"))
+        ref = [t.clone().requires_grad_(True) for t in (x, w, b)]
+        (torch.nn.functional.conv2d(ref[0], ref[1], ref[2], padding=k // 2) * gy).sum().backward()
+        mine = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+        (vpx.ops.conv2d_same(mine[0], mine[1], mine[2], precision=prec) * gy.cuda()).sum().backward()
+        for a, r in zip(mine, ref):
+            assert _relmax(a.grad, r.grad) < tol, (prec, Ci, k, _relmax(a.grad, r.grad))
+
+
 def test_decouple_and_conv2d_vs_golden_and_autograd(vpx):
     """K4 (vpx_decouple_fwd/_bwd) against the reference-generated pin; K5-style conv2d fwd/bwd against torch autograd."""
     from golden_util import seeded_randn

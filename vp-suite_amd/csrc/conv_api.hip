@@ -12,7 +12,7 @@ extern "C" {
 size_t vpx_conv2d_bwd_workspace_bytes(int N, int H, int W, int Ci, int Co, int kh, int kw) {
     if (N < 1 || H < 1 || W < 1 || Ci < 1 || Co < 1) return 0;
     return align256(plain_conv_wpk_floats(Co, Ci, kh, kw) * 4) +
-           align256((size_t)wgrad_slices(N, H, W) * kh * kw * Co * Ci * 4) + align256((size_t)COLSUM_BLOCKS * Co * 4) + 512;
+           align256((size_t)wgrad_slices_for(N, H, W, Co, Ci, kh, kw) * kh * kw * Co * Ci * 4) + align256((size_t)COLSUM_BLOCKS * Co * 4) + 512;
 }
 
 int vpx_conv2d_nhwc_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int N, int H,
@@ -27,14 +27,15 @@ int vpx_conv2d_nhwc_bwd(const float* x, const float* w, const float* dy, float* 
     hipStream_t stream = (hipStream_t)stream_;
     Carver ws(workspace, workspace_bytes);
     float* wpk = ws.take(plain_conv_wpk_floats(Co, Ci, kh, kw));
-    float* slabs = ws.take((size_t)wgrad_slices(N, H, W) * kh * kw * Co * Ci);
+    const int slice_cap = wgrad_slices_for(N, H, W, Co, Ci, kh, kw);
+    float* slabs = ws.take((size_t)slice_cap * kh * kw * Co * Ci);
     float* db_part = ws.take((size_t)COLSUM_BLOCKS * Co);
     VPX_CHECK_CARVE(ws, "vpx_conv2d_nhwc_bwd");
     const ConvGeo g{N, H, W};
     int rc;
     if (dx && (rc = plain_conv(stream, precision, g, dy, Co, Co, w, (long long)Ci * kh * kw, kh * kw, kh, kw, Ci, true,
                                nullptr, dx, Ci, false, wpk))) return rc;
-    if (dw && (rc = plain_wgrad(stream, precision, g, dy, Co, x, Ci, kh, kw, slabs, dw))) return rc;
+    if (dw && (rc = plain_wgrad(stream, precision, g, dy, Co, x, Ci, kh, kw, slabs, dw, nullptr, slice_cap))) return rc;
     if (db) VPX_CHECK_HIP(launch_colsum(dy, nullptr, 0.f, nullptr, db, db_part, (long long)N * H * W, Co, stream));
     return VPX_OK;
 }
@@ -95,7 +96,7 @@ size_t vpx_decouple_workspace_bytes(int B, int Ch, int H, int W) {
     if (B < 1 || Ch < 1 || H < 1 || W < 1) return 0;
     const size_t n = (size_t)B * H * W * Ch;
     return 4 * align256(n * 4) + align256((size_t)B * Ch * 4 * 4) + align256(plain_conv_wpk_floats(Ch, Ch, 1, 1) * 4) +
-           align256((size_t)wgrad_slices(B, H, W) * Ch * Ch * 4) + align256((size_t)Ch * Ch * 4) + 1024;
+           align256((size_t)wgrad_slices_1x1(B, H, W) * Ch * Ch * 4) + align256((size_t)Ch * Ch * 4) + 1024;
 }
 
 static bool decouple_prec_ok(int prec, const char* who) {
@@ -139,7 +140,8 @@ int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* ad
     float* dym = ws.take(n);
     float* stats = ws.take((size_t)B * Ch * 4);
     float* wpk = ws.take(plain_conv_wpk_floats(Ch, Ch, 1, 1));
-    float* slabs = ws.take((size_t)wgrad_slices(B, H, W) * Ch * Ch);
+    const int slice_cap = wgrad_slices_1x1(B, H, W);
+    float* slabs = ws.take((size_t)slice_cap * Ch * Ch);
     float* dA2 = ws.take((size_t)Ch * Ch);
     VPX_CHECK_CARVE(ws, "vpx_decouple_bwd");
     const ConvGeo g{B, H, W};
@@ -157,10 +159,10 @@ int vpx_decouple_bwd(const float* delta_c, const float* delta_m, const float* ad
     if (d_adapter) {
         if (dym == dyc + n && (((uintptr_t)delta_c ^ (uintptr_t)delta_m) & 15) == 0) {
             // both pairs in ONE launch (the c and m halves are two "time steps"): one weight gradient + reduce instead of two + an add
-            if ((rc = plain_wgrad(stream, prec, g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter, delta_m))) return rc;
+            if ((rc = plain_wgrad(stream, prec, g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter, delta_m, slice_cap))) return rc;
         } else {
-            if ((rc = plain_wgrad(stream, prec, g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter))) return rc;
-            if ((rc = plain_wgrad(stream, prec, g, dym, Ch, delta_m, Ch, 1, 1, slabs, dA2))) return rc;
+            if ((rc = plain_wgrad(stream, prec, g, dyc, Ch, delta_c, Ch, 1, 1, slabs, d_adapter, nullptr, slice_cap))) return rc;
+            if ((rc = plain_wgrad(stream, prec, g, dym, Ch, delta_m, Ch, 1, 1, slabs, dA2, nullptr, slice_cap))) return rc;
             VPX_CHECK_HIP(launch_axpy(d_adapter, dA2, (long long)Ch * Ch, stream));
         }
     }

@@ -363,6 +363,16 @@ static inline int wgrad_slices(int N, int H, int W) {
     const long long items = (long long)N * ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
     return (int)(items < 32 ? items : 32);
 }
+// A layer whose whole dW is ONE output tile (the decoupling adapter: Ch x Ch, 1x1) has as many workgroups as slices: 32 left 7/8 of the chip
+// idle (PredRNN-V2 training, B = 128: 67 launches of 180 us per step for 33 MB of operands each). Up to 256 slices there — a slab is Ch x Ch.
+static inline int wgrad_slices_1x1(int N, int H, int W) {
+    const long long items = (long long)N * ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
+    return (int)(items < 256 ? items : 256);
+}
+// ... and the cap of a general stride-1 layer: 256 where all of dW is one output tile (<= 64 rows x 64 channels, up to 3x3), else 32
+static inline int wgrad_slices_for(int N, int H, int W, int Co, int Ci, int kh, int kw) {
+    return (Co <= 64 && Ci <= 64 && kh * kw <= 9) ? wgrad_slices_1x1(N, H, W) : wgrad_slices(N, H, W);
+}
 // slices actually launched: enough for ~1024 workgroups (each slice costs a slab write + a reduce read of all of dW)
 static inline int wgrad_pick_slices(int cap, int rows, int n_ctiles, int taps) {
     const int out_tiles = ((rows + 63) / 64) * n_ctiles * ((taps + 8) / 9);
@@ -375,7 +385,7 @@ static inline int wgrad_pick_slices(int cap, int rows, int n_ctiles, int taps) {
 // x2: a second operand pair in the same launch — dw = wgrad(dy, x) + wgrad(dy + N*HW*Co, x2) (the two pairs become
 // "time steps" 0 and 1 of one item walk; x2 may live anywhere, its distance from x is just the step stride)
 static inline int plain_wgrad(hipStream_t stream, int prec, ConvGeo g, const float* dy, int Co, const float* x, int C, int kh, int kw,
-                float* slabs, float* dw, const float* x2 = nullptr) {
+                float* slabs, float* dw, const float* x2 = nullptr, int slice_cap = 0) {   // slice_cap: what `slabs` was sized for (0: wgrad_slices)
     WgradArgs wa{};
     wa.T = x2 ? 2 : 1; wa.x_tstride = x2 ? (long long)(x2 - x) : 0;
     wa.B = g.N; wa.H = g.H; wa.W = g.W; wa.HW = g.H * g.W; wa.kh = kh; wa.kw = kw;
@@ -385,7 +395,7 @@ static inline int plain_wgrad(hipStream_t stream, int prec, ConvGeo g, const flo
     wa.n_ctiles = wgrad_make_ctiles(wa.ct, WG_MAX_CTILES, C, 0, 0);
     if (wa.n_ctiles < 0) { set_error("conv wgrad: too many input channels (%d)", C); return VPX_ERR_UNSUPPORTED; }
     wa.slabs = slabs;
-    const int ns = wgrad_pick_slices(wgrad_slices(g.N, g.H, g.W), Co, wa.n_ctiles, kh * kw);
+    const int ns = wgrad_pick_slices(slice_cap > 0 ? slice_cap : wgrad_slices(g.N, g.H, g.W), Co, wa.n_ctiles, kh * kw);
     VPX_CHECK_HIP(launch_wgrad(wa, ns, stream));
     VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dw, ns, kh * kw, Co, C, stream));
     return VPX_OK;
