@@ -183,6 +183,38 @@ def test_fused_reversed_pass_equals_two_passes(vpx, mode):
         assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4], key   # schedule state and the RNG stream's position
 
 
+@pytest.mark.parametrize("B,Ttot,slices", [(24, 12, 8), (48, 12, 16), (128, 17, 32)])
+def test_deferred_weight_gradients_on_whole_slices_per_xcd(vpx, B, Ttot, slices):
+    """The one-launch ST-LSTM weight gradient (stw_kernel) over a whole pass: 8 / 16 / 32 K slices, whole slices per XCD (round 5: its
+    block decode for slice counts in 8s; `stw_slices`) — against the FIRST-GENERATION per-step weight gradients (VPX_OPT_EXPERIMENT bit 6:
+    other kernels, other summation order) on the same model, same frames, same sampling masks. 8x8 maps of two items each: 2B x (Ttot - 1)
+    images -> 1 056 / 2 112 / 8 192 items."""
+    from vp_suite_amd.measure import PredictionLossProvider
+    lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
+    kw = dict(img_shape=(1, 32, 32), action_size=0, tensor_value_range=[0.0, 1.0], num_layers=2, num_hidden=[16, 16], cell_precision="bf16x3")
+    P = 4
+    frames = seeded_rand((B, Ttot, 1, 32, 32), name_seed(f"predrnn.slices{slices}.frames")).cuda()
+    L = vpx._lib.lib()
+    res = {}
+    for first_generation in (False, True):
+        prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, 64 if first_generation else 0)
+        try:
+            m = _predrnn("slices", kw)
+            m.sampling_eta = 0.5
+            torch.manual_seed(4321)
+            loss = m.training_loss(frames, frames[:, Ttot - P:], P, lp)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, prev)
+        named = dict(m.named_parameters())
+        res[first_generation] = (float(loss), {k: named[k].grad.detach().cpu().numpy() for k in sorted(named)})
+    a, b = res[False], res[True]
+    assert abs(a[0] - b[0]) < 2e-6 * abs(b[0])
+    worst = max((_relmax(a[1][k], b[1][k]), k) for k in a[1])
+    assert worst[0] < 5e-5, worst
+
+
 @pytest.mark.parametrize("variant", ["plain", "layer_norm"])
 def test_batched_decoupling_tail_equals_per_step_tails(vpx, variant):
     """batch_decoupling_tail (the default): every layer-step writes its delta_c / delta_m into one slab and ONE vpx_decouple_fwd/_bwd pair

@@ -498,6 +498,20 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
         const long long total = (long long)per_slice * a.n_slices;
         const long long per_xcd = (total + 7) / 8;
         const unsigned L = blockIdx.x;
+        if ((a.n_slices & 7) == 0) {
+            // Whole slices per XCD (round 5): XCD x takes slices x, x + 8, ... — every XCD gets the same mix of long (tap rows {0,1}, {2,3}),
+            // short (tap row 4: half the work) and centre-tap workgroups, and all its workgroups walk the same pixels (one L2). In dispatch
+            // order: the long ones of all its slices, then the short ones, then the 1x1 tensor's. The contiguous-range rule below handed
+            // XCD 0 long workgroups only and its neighbour mostly short ones: the launch took two long rounds at 70 % of the CUs' time.
+            const int i = (int)(L >> 3), spx = a.n_slices >> 3;
+            const int nl = 2 * a.npairs5, nsh = a.npairs5, nc = a.npairs - a.npairs5;
+            if (i >= spx * per_slice) return;
+            int sl;
+            if (i < spx * nl) { sl = i / nl; const int r = i - sl * nl; pair_i = r >> 1; pass = r & 1; }
+            else if (i < spx * (nl + nsh)) { const int j = i - spx * nl; sl = j / nsh; pair_i = j - sl * nsh; pass = 2; }
+            else { const int j = i - spx * (nl + nsh); sl = j / nc; pair_i = a.npairs5 + (j - sl * nc); pass = 3; }
+            slice = (int)(L & 7) + 8 * sl;
+        } else {
         const long long v = (long long)(L & 7) * per_xcd + (L >> 3);
         if ((long long)(L >> 3) >= per_xcd || v >= total) return;
         slice = (int)(v / per_slice);
@@ -507,6 +521,7 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
         if (rem < 2 * a.npairs5) { pair_i = rem >> 1; pass = rem & 1; }
         else if (rem < 3 * a.npairs5) { pair_i = rem - 2 * a.npairs5; pass = 2; }
         else { pair_i = rem - 2 * a.npairs5; pass = 3; }
+        }
         slice = __builtin_amdgcn_readfirstlane(slice); pair_i = __builtin_amdgcn_readfirstlane(pair_i); pass = __builtin_amdgcn_readfirstlane(pass);
     }
     const STWPair pr = a.pair[pair_i];
@@ -830,6 +845,19 @@ int stw_build(STWArgs& a, STWOut& o, int B, int H, int W, int Cin, int Ch) {
 // K slices: about two rounds of one-per-CU workgroups (npairs x 3 workgroups per slice), every slice at least 8 items
 int stw_slices(int npairs, long long items) {   // npairs: the k x k tensors' pairs (three workgroups each; the 1 x 1 pairs add one short one)
     int ns = (480 + npairs * 3 / 2) / (npairs * 3);
+    // round 5: whole slices per XCD (stw_kernel's block decode) wherever a slice keeps >= 32 items — 8, 16 or 32 of them as the item list grows
+    // (the deferred weight gradients of a whole pass: 19 456 items at B = 128): finer workgroups fill the last dispatch round of every XCD, a
+    // slab costs 0.8 MB per pair. Measured, PredRNN-V2 training step (A/B builds -DVPX_STW_NS_FIXED=n, one box): B = 128 round-4 rule (4 slices,
+    // contiguous ranges) 307.8 / 308.8 ms, 8 slices 297.8, 16 291.0, 32 288.1 / 287.8, 48 286.5; configs[4]'s shard (2 496 items) 82.5 -> 80.1 / 79.6 / 80.1.
+    if (items >= 32 * 256) ns = 32;
+    else if (items >= 16 * 128) ns = 16;
+    else if (items >= 8 * 32) ns = 8;
+#ifdef VPX_DEV_SWITCHES
+    ns = dev_switch("VPX_STW_NS", ns);
+#endif
+#ifdef VPX_STW_NS_FIXED
+    ns = VPX_STW_NS_FIXED ? VPX_STW_NS_FIXED : (480 + npairs * 3 / 2) / (npairs * 3);   // A/B builds (0: the round-4 rule)
+#endif
     if (ns > items / 8) ns = (int)(items / 8);
     return ns < 1 ? 1 : ns;
 }
