@@ -208,7 +208,40 @@ def test_deferred_weight_gradients_on_whole_slices_per_xcd(vpx, B, Ttot, slices)
         finally:
             L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, prev)
         named = dict(m.named_parameters())
-        res[first_generation] = (float(loss), {k: named[k].grad.detach().cpu().numpy() for k in sorted(named)})
+        res[first_generation] = (float(loss.detach()), {k: named[k].grad.detach().cpu().numpy() for k in sorted(named)})
+    a, b = res[False], res[True]
+    assert abs(a[0] - b[0]) < 2e-6 * abs(b[0])
+    worst = max((_relmax(a[1][k], b[1][k]), k) for k in a[1])
+    assert worst[0] < 5e-5, worst
+
+
+@pytest.mark.parametrize("B,slices", [(32, 16), (96, 32)])
+def test_deferred_weight_gradients_at_model_width_on_whole_slices(vpx, B, slices):
+    """The same comparison at the reference's default width (128 hidden channels: the pair table of the bench's launches — eight 128-row
+    tiles of dG8, 36 k x k pairs + the 1x1 tensor's), 64x64 frames -> 16x16 maps of four items: 2B x 11 images = 2 816 / 8 448 items ->
+    16 / 32 K slices, two / four whole slices per XCD. One training pass each way; every parameter gradient."""
+    from vp_suite_amd.measure import PredictionLossProvider
+    lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
+    kw = dict(img_shape=(1, 64, 64), action_size=0, tensor_value_range=[0.0, 1.0], num_layers=2, num_hidden=[128, 128], cell_precision="bf16x3")
+    Ttot, P = 12, 4
+    frames = seeded_rand((B, Ttot, 1, 64, 64), name_seed(f"predrnn.wide{slices}.frames")).cuda()
+    L = vpx._lib.lib()
+    res = {}
+    for first_generation in (False, True):
+        prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, 64 if first_generation else 0)
+        try:
+            m = _predrnn("wide", kw)
+            m.sampling_eta = 0.5
+            torch.manual_seed(777)
+            loss = m.training_loss(frames, frames[:, Ttot - P:], P, lp)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, prev)
+        named = dict(m.named_parameters())
+        res[first_generation] = (float(loss.detach()), {k: named[k].grad.detach().cpu().numpy() for k in sorted(named)})
+        del m, loss
+        torch.cuda.empty_cache()
     a, b = res[False], res[True]
     assert abs(a[0] - b[0]) < 2e-6 * abs(b[0])
     worst = max((_relmax(a[1][k], b[1][k]), k) for k in a[1])
