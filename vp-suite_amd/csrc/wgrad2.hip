@@ -487,6 +487,12 @@ constexpr int W5_LDS = 2 * W5_BUF;                // 147456 B
 constexpr int W5_APIECES = 2 * W5_NPOS * 8;       // 2560 pieces = 5 per thread exactly
 constexpr int W5_BLOCK = 25 * 128 * 64;           // floats of a pair's slab block
 
+#ifdef VPX_DEV_SWITCHES
+// developer build: per WORKGROUP start / end of the item loop (s_memtime), HW_ID | XCC_ID << 32, pass | slice << 8 | pair << 24 — how the launch's
+// workgroups were dealt to XCDs and CUs and when each finished (tools/trace_stw.py; vpx_dbg_stw_trace reads it back)
+__device__ unsigned long long stw_trace[8192 * 4];
+#endif
+
 __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
     constexpr int TA = 5;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -524,6 +530,16 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
         }
         slice = __builtin_amdgcn_readfirstlane(slice); pair_i = __builtin_amdgcn_readfirstlane(pair_i); pass = __builtin_amdgcn_readfirstlane(pass);
     }
+#ifdef VPX_DEV_SWITCHES
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stw_trace[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        stw_trace[blockIdx.x * 4 + 2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        stw_trace[blockIdx.x * 4 + 3] = (unsigned long long)pass | ((unsigned long long)slice << 8) | ((unsigned long long)pair_i << 24);
+    }
+#endif
     const STWPair pr = a.pair[pair_i];
     const STWHalf ch0 = pr.h[0], ch1 = pr.h[1];
     const int n0 = pr.n0;
@@ -701,6 +717,7 @@ __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
         cur = nxt; advance(nxt); bsel ^= 1;
     }
 #ifdef VPX_DEV_SWITCHES
+    if (threadIdx.x == 0 && blockIdx.x < 8192) stw_trace[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
     if (stamp && lane == 0) {
         a.stamps[wave * 8 + 0] = t_dma; a.stamps[wave * 8 + 1] = t_mul; a.stamps[wave * 8 + 2] = t_sync; a.stamps[wave * 8 + 3] = n_it;
         a.stamps[wave * 8 + 4] = (unsigned long long)pass; a.stamps[wave * 8 + 5] = (unsigned long long)pair_i;
@@ -866,6 +883,9 @@ int stw_slices(int npairs, long long items) {   // npairs: the k x k tensors' pa
 static unsigned long long* g_stw_stamps = nullptr;
 static int g_stw_stamp_block = 0;
 extern "C" int vpx_dbg_stw_stamps(unsigned long long* dev_buf, int block) { g_stw_stamps = dev_buf; g_stw_stamp_block = block; return 0; }
+extern "C" int vpx_dbg_stw_trace(unsigned long long* out32768) {
+    return (int)hipMemcpyFromSymbol(out32768, HIP_SYMBOL(vpx::stw_trace), sizeof(unsigned long long) * 8192 * 4);
+}
 #endif
 
 hipError_t launch_stw(const STWArgs& a_in, const STWOut& o, hipStream_t s) {
