@@ -58,6 +58,13 @@ __device__ __forceinline__ void w2_dma16(const char* g, char* lds_wave_base) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef VPX_DEV_SWITCHES
+// developer build: per WORKGROUP start / end of the item loop (s_memtime), HW_ID | XCC_ID << 32, and what it worked on (stw_kernel: pass | slice << 8 |
+// pair << 24; wgrad2_kernel: 4 | half-tail << 3 | slice << 8 | tile << 24) — how a launch's workgroups were dealt to XCDs and CUs and how long each
+// ran (tools/trace_stw.py; vpx_dbg_stw_trace reads it back). Only times of ONE CU may be compared: the counter's base differs between shader engines.
+__device__ unsigned long long stw_trace[8192 * 4];
+#endif
+
 // QF: the same kernel on v_mfma_f32_16x16x32_bf16 (vpx_set_option(VPX_OPT_MFMA_SHAPE, 1)): a K = 32 step is two tile rows of the
 // item, a wave's 64 gate rows x 32 channels x tap group are 4 x 2 accumulator tiles of 16x16 per tap (the same 160 registers),
 // the same fragment bytes per MFMA cycle.
@@ -89,6 +96,16 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
         bx = fi >= 0 ? (fi / n_ctf) * a.n_ctiles + fi % n_ctf : (-1 - fi) * a.n_ctiles + (a.n_ctiles - 1);
         slice = __builtin_amdgcn_readfirstlane(slice); bx = __builtin_amdgcn_readfirstlane(bx); ns = __builtin_amdgcn_readfirstlane(ns);
     }
+#ifdef VPX_DEV_SWITCHES
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stw_trace[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime();
+        stw_trace[blockIdx.x * 4 + 2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        stw_trace[blockIdx.x * 4 + 3] = 4ull | (ns != a.grid_slices ? 8ull : 0ull) | ((unsigned long long)slice << 8) | ((unsigned long long)bx << 24);
+    }
+#endif
     const int n_ct = a.n_ctiles;
     const int ct_id = __builtin_amdgcn_readfirstlane(bx % n_ct);
     const WgradCHalf ch0 = a.ct[ct_id].h[0], ch1 = a.ct[ct_id].h[1];
@@ -324,6 +341,9 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         cur = nxt; advance(nxt); bsel ^= 1;
     }
+#ifdef VPX_DEV_SWITCHES
+    if (threadIdx.x == 0 && blockIdx.x < 8192) stw_trace[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+#endif
 
     if (ksplit) {
         // pair reduction (once per workgroup): the wc = 1 wave of each (tap group, row half) pair parks its accumulators in LDS,
@@ -486,12 +506,6 @@ constexpr int W5_BUF = W2_A0 + 2 * W5_APL;        // 73728 B per item
 constexpr int W5_LDS = 2 * W5_BUF;                // 147456 B
 constexpr int W5_APIECES = 2 * W5_NPOS * 8;       // 2560 pieces = 5 per thread exactly
 constexpr int W5_BLOCK = 25 * 128 * 64;           // floats of a pair's slab block
-
-#ifdef VPX_DEV_SWITCHES
-// developer build: per WORKGROUP start / end of the item loop (s_memtime), HW_ID | XCC_ID << 32, pass | slice << 8 | pair << 24 — how the launch's
-// workgroups were dealt to XCDs and CUs and when each finished (tools/trace_stw.py; vpx_dbg_stw_trace reads it back)
-__device__ unsigned long long stw_trace[8192 * 4];
-#endif
 
 __global__ __launch_bounds__(512, 2) void stw_kernel(const STWArgs a) {
     constexpr int TA = 5;
