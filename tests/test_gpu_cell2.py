@@ -358,3 +358,53 @@ def test_hoisted_projection_on_convq_matches_first_generation_launch(vpx, cell3_
     assert not torch.equal(o2, o1)
     ro, rh, rc, _ = _oracle(tag)
     assert _relmax(o2, ro) < 2e-5 and _relmax(c2, rc) < 2e-5
+
+
+# ---- the eight-wave half tile (csrc/cell2x.hip, round 6): 64-register wave tiles, four waves per SIMD; VPX_OPT_EXPERIMENT bit 15 selects
+#      it, bit 16 swaps its wave split (columns <-> rows) ----
+X_FORM, X_SWAP = 32768, 65536
+
+
+@pytest.mark.parametrize("tag", list(CASESQ) + ["plain_s14", "plain_s7_many_tiles"])
+def test_x_form_bit_identical_to_half_tile(vpx, cell2_switch, shape_switch, experiment_switch, tag):
+    """cell2_kernel_x (both wave splits) multiplies the same operand pieces in the same order per output element as the four-wave half
+    tile: bit-identical h, c and output sequence; and the oracle's bound on top."""
+    cell2_switch(2)
+    shape_switch(1)
+    with torch.no_grad():
+        experiment_switch(0)
+        o1, h1, c1, _ = _run(vpx, tag, grads=False)
+        for bits in (X_FORM, X_FORM | X_SWAP):
+            experiment_switch(bits)
+            o2, h2, c2, _ = _run(vpx, tag, grads=False)
+            assert torch.equal(o2, o1) and torch.equal(c2, c1) and torch.equal(h2, h1), (bits, _relmax(o2, o1), _relmax(c2, c1))
+    ro, rh, rc, _ = _oracle(tag)
+    assert _relmax(o2, ro) < 2e-5 and _relmax(c2, rc) < 2e-5 and _relmax(h2, rh) < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["enc2", "fore1_states", "fore3_noinput", "plain_s5", "plain_s3", "plain_s2_noinput", "plain_s14",
+                                 "plain_s7_many_tiles"])
+def test_x_form_plain_bf16_bit_identical_to_half_tile(vpx, cell2_switch, experiment_switch, tag):
+    """VPX_PREC_BF16 on cell2_kernel_x<true, *> (copies split between the two wave groups) against cell2_kernel_q<.., 4, true>."""
+    cell2_switch(2)
+    with torch.no_grad():
+        experiment_switch(0)
+        o1, h1, c1, _ = _run(vpx, tag, grads=False, precision="bf16")
+        for bits in (X_FORM, X_FORM | X_SWAP):
+            experiment_switch(bits)
+            o2, h2, c2, _ = _run(vpx, tag, grads=False, precision="bf16")
+            assert torch.equal(o2, o1) and torch.equal(c2, c1) and torch.equal(h2, h1), (bits, _relmax(o2, o1), _relmax(c2, c1))
+
+
+@pytest.mark.parametrize("tag", ["q_enc1_oddx", "q_odd_total_states", "q_ifog_nopeep", "fore1_states"])
+def test_x_form_training_path_vs_oracle(vpx, cell2_switch, shape_switch, experiment_switch, tag):
+    """The x form fills the saved-for-backward reserve (gates, c, split h): every gradient against autograd, both wave splits."""
+    cell2_switch(2)
+    shape_switch(1)
+    ro, rh, rc, rg = _oracle(tag)
+    for bits in (X_FORM, X_FORM | X_SWAP):
+        experiment_switch(bits)
+        out, hT, cT, g = _run(vpx, tag, grads=True)
+        assert _relmax(out, ro) < 2e-5
+        for k in rg:
+            assert _relmax(g[k], rg[k]) < 5e-5, (bits, k)

@@ -11,6 +11,7 @@ shapes = [(64, 64, 64, 64), (16, 64, 64, 64), (64, 96, 32, 32), (96, 96, 32, 32)
 B, T = int(os.environ.get("BB", 128)), 6
 train = os.environ.get("MODE", "infer") == "train"
 MODES = [int(x) for x in os.environ.get("MODES", "0,1,2,3").split(",")]
+PREC = os.environ.get("PREC", "bf16x3")   # bf16: inference only (the plain form of the fused cell)
 res, data = {}, {}
 for s in shapes:
     Cin, Ch, H, W = s
@@ -22,11 +23,11 @@ for s in shapes:
 def once(s):
     x, Wt, b, pw = data[s]
     if train:
-        out, hT, cT = v.ops.convlstm_seq(x, None, None, Wt, b, *pw, seq_len=T, in_channels=s[0], precision="bf16x3")
+        out, hT, cT = v.ops.convlstm_seq(x, None, None, Wt, b, *pw, seq_len=T, in_channels=s[0], precision=PREC)
         out.backward(out.detach())
     else:
         with torch.no_grad():
-            v.ops.convlstm_seq(x, None, None, Wt, b, *pw, seq_len=T, in_channels=s[0], precision="bf16x3")
+            v.ops.convlstm_seq(x, None, None, Wt, b, *pw, seq_len=T, in_channels=s[0], precision=PREC)
 
 
 for rnd in range(5):
@@ -43,7 +44,7 @@ for rnd in range(5):
 for s in shapes:
     Cin, Ch, H, W = s
     fl = 2.0 * 4 * Ch * (Cin + Ch * (T - 1) / T) * 9 * H * W * B * T * (3 if train else 1)
-    line = f"B={B} {'train' if train else 'infer'} {s}:"
+    line = f"B={B} {PREC} {'train' if train else 'infer'} {s}:"
     base = sorted(res[(s, MODES[0])])
     for mode in MODES:
         r = sorted(res[(s, mode)])

@@ -55,8 +55,7 @@ hipError_t launch_split_convert(const float* src, void* dst, long long npix, int
 // ---------------------------------------------------------------------------------------------------------------
 // weight repack: reference OIHW [4Ch, Cin+Ch, 3, 3] -> [n_tile][chunk = stage*3 + dy][q = dx][part][khalf][n][8 bf16]
 // step p (0..8) of a two-stage period, lane half tsel (k groups 0,1 | 2,3): which stage of the period (0 even, 1 odd) and tap
-__host__ __device__ constexpr int cq_stage_of(int p, int tsel) { return p < 4 ? 0 : (p == 4 ? tsel : 1); }
-__host__ __device__ constexpr int cq_tap_of(int p, int tsel) { return p < 4 ? 2 * p + tsel : (p == 4 ? (tsel ? 0 : 8) : 2 * (p - 5) + 1 + tsel); }
+// (cq_stage_of / cq_tap_of — the step schedule of a two-stage period — live in cell2_dev.h: cell2x.hip shares them)
 
 // q form: [n_tile][step q][half = n >> 6][part][k group][n & 63][8 bf16] over the present stage sequence pk.stage_col[0 .. S-1]
 // (a chunk is two 8 KiB halves, one per four column tiles: the half-tile kernel's weight ring turns over in halves)
@@ -738,9 +737,7 @@ __global__ __launch_bounds__(512, 2) void cell2_kernel(const Cell2Plan P, const 
 //   two weight sets (column tile nt + 1 is read before the MFMAs of nt).
 struct CQFrags { bf16x8 ah[4], al[4], bh[2], bl[2]; };
 
-__host__ __device__ constexpr int cq_slot(int tap) { return (tap / 3) * C2_HALO_W + tap % 3; }
-__host__ __device__ constexpr int cq_kind(int p) { return p == 4 ? 2 : ((p == 1 || p == 7) ? 1 : 0); }   // slot distance tB - tA: 1 | 16 | other buffer
-__host__ __device__ constexpr int cq_aoff(int p, int abuf) { return (p >= 5 ? abuf : 0) + cq_slot(cq_tap_of(p, 0)) * 16; }
+// (cq_slot / cq_kind / cq_aoff: cell2_dev.h)
 
 // NW = 8: the 32x16 tile, one workgroup per CU. NW = 4: the half tile (16x16 pixels), two workgroups per CU — the epilogue of
 // one (transcendental-bound: ~18 k of a 158 k-cycle tile at NW = 8) and its prologue run under the other's MFMAs. Its weight
@@ -1071,6 +1068,12 @@ static hipError_t launch_cell2_t(const Cell2Plan& plan, const Epi& epi, hipStrea
 }
 
 hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s) {
+    if (plan.qform && cell2x_selected()) {   // the eight-wave half tile (cell2x.hip): four waves per SIMD
+        Cell2Plan p = plan;
+        p.tiles_y = (p.H + 15) / 16;
+        p.grid_m = p.B * p.tiles_x * p.tiles_y;
+        return launch_cell2x(p, ea, h_sp, h_sp_bstride, s);
+    }
     Cell2Epi epi{ea, reinterpret_cast<char*>(h_sp), h_sp_bstride};
     return launch_cell2_t<Cell2Epi, true>(plan, epi, s);
 }

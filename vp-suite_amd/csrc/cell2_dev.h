@@ -39,6 +39,14 @@ struct CQGeom {
     static constexpr int LDS = 2 * ABUF + WSLOTS * CQ_WCHUNK;   // 131072 | 81920 B (the epilogue needs NW x 16 KiB)
 };
 
+// q form, step schedule of a two-stage period (nine K = 32 steps): step p (0..8), lane half tsel (k groups 0,1 | 2,3) -> which stage of the
+// period (0 even, 1 odd) and which tap; fragment addressing of the step (slot of a tap in the 18-wide halo image, base kind, offset)
+__host__ __device__ constexpr int cq_stage_of(int p, int tsel) { return p < 4 ? 0 : (p == 4 ? tsel : 1); }
+__host__ __device__ constexpr int cq_tap_of(int p, int tsel) { return p < 4 ? 2 * p + tsel : (p == 4 ? (tsel ? 0 : 8) : 2 * (p - 5) + 1 + tsel); }
+__host__ __device__ constexpr int cq_slot(int tap) { return (tap / 3) * C2_HALO_W + tap % 3; }
+__host__ __device__ constexpr int cq_kind(int p) { return p == 4 ? 2 : ((p == 1 || p == 7) ? 1 : 0); }   // slot distance tB - tA: 1 | 16 | other buffer
+__host__ __device__ constexpr int cq_aoff(int p, int abuf) { return (p >= 5 ? abuf : 0) + cq_slot(cq_tap_of(p, 0)) * 16; }
+
 __device__ const float c2_zero16[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};  // source of out-of-image pieces
 
 __device__ __forceinline__ unsigned short c2_bf16_bits(float v) {

@@ -223,6 +223,11 @@ extern int g_experiment;   // vpx_api.hip: bits of kernel experiments in flight 
 extern int g_mfma_shape;   // vpx_api.hip: -1 = not yet read from the environment (VPX_MFMA_SHAPE), else 0 / 1 (vpx_set_option)
 int mfma_shape();
 hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s);
+// the same step on the eight-wave half tile (cell2x.hip, round 6: 64-register wave tiles, four waves per SIMD); plan.qform launches only
+// (maps in whole 16x16 tiles, whole 32-channel N tiles), tiles_y / grid_m set for 16-row tiles. VPX_OPT_EXPERIMENT bit 15 selects it
+// (development state: the four-wave half tile stays the default until the A/B says otherwise)
+hipError_t launch_cell2x(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s);
+static inline bool cell2x_selected() { return (g_experiment & 32768) != 0; }
 // conv2: the same kernel with a plain epilogue — 3x3 'same' convolution of one split-format source with C channels (C % 16 == 0)
 // into Co fp32 NHWC output channels, [0, split) -> out0, [split, Co) -> out1. N tiling: 128-column tiles, balanced.
 static inline int conv2_tiles(int Co) { return ((Co + 31) / 32 + 3) / 4; }
