@@ -117,7 +117,7 @@ int vpx_set_deterministic(int on);
  *                        and the bounds checks of everything it would write into the workspace) but issues no HIP call: needs no GPU
  *                        and touches none of the pointers (they only have to be non-NULL where the call requires a tensor). A sizing
  *                        rule of a `*_workspace_bytes` query that disagrees with the launch code returns VPX_ERR_WORKSPACE. For the
- *                        CPU test-suite (tests/test_workspace_contract.py); a process that ran dry must not launch afterwards. */
+ *                        CPU test-suite (tests/test_workspace_contract.py). Leaves no state behind: switch it off again and launch. */
 #define VPX_OPT_DRY_RUN 5
 int vpx_set_option(int option, int value);
 /* A counter that advances with every vpx_set_option / vpx_set_deterministic call: callers that cache anything kernel-selection
@@ -169,7 +169,10 @@ size_t vpx_stlstm_reserve_bytes(const vpx_stlstm_desc* d);
  *            sources x, h, m, c_new, m_new (split format) in dense slabs [T][B][H*W][C] and calls vpx_stlstm_wgrad_batch ONCE with a
  *            descriptor whose B is T*B: the same kernel over all the steps' images — one launch, one slab reduction and no per-step
  *            accumulation of the results. Available where vpx_stlstm_defers_wgrad(d) says 1 (5x5, bf16x3, channels in 8s, no LayerNorm).
- *   NHWC layout only (ignored otherwise). `shadows` may be NULL: vpx_stlstm_step_fwd / _bwd are exactly that. */
+ *   NHWC layout only: on reference-layout (NCHW) descriptors in[] / out[] are ignored and a non-NULL dg8_out is refused with
+ *   VPX_ERR_UNSUPPORTED (never silently dropped). Without dg8_out a NULL dW pointer means "this weight is frozen": that gradient is
+ *   not computed.
+ *   `shadows` may be NULL: vpx_stlstm_step_fwd / _bwd are exactly that. */
 typedef struct vpx_stlstm_shadows { const void* in[5]; void* out[3]; void* dg8_out; } vpx_stlstm_shadows;
 int vpx_stlstm_uses_split(const vpx_stlstm_desc* d);
 int vpx_stlstm_defers_wgrad(const vpx_stlstm_desc* d);

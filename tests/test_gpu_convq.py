@@ -11,8 +11,7 @@ from golden_util import name_seed, seeded_rand, seeded_randn
 pytestmark = pytest.mark.gpu
 
 
-def _relmax(a, b):
-    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+from parity import relmax as _relmax   # max|a - b| / max|b|, recorded (tests/parity.py)
 
 
 CASES = {  # tag: (N, Ci, Co, H, W, k, stride, pad, transposed, slope)

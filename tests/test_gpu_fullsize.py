@@ -16,10 +16,7 @@ from golden_util import fill_state_dict_, name_seed, seeded_rand, seeded_randn
 pytestmark = pytest.mark.gpu
 
 
-def _relmax(a, b):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+from parity import relmax as _relmax   # max|a - b| / max|b|, recorded (tests/parity.py)
 
 
 def _model(name, seed_tag, **kw):

@@ -16,10 +16,7 @@ pytestmark = pytest.mark.gpu
 MORE = int(os.environ.get("VPX_FUZZ_CHUNKS", "0"))   # extra chunks of random cases for a one-off wider sweep (tools/, not the driver's run)
 
 
-def _relmax(a, b):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+from parity import relmax as _relmax   # max|a - b| / max|b|, recorded (tests/parity.py)
 
 
 def _convlstm_cases(n, seed):

@@ -12,10 +12,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4  # north_star: within 1e-4 relative (fp32)
 
 
-def _relmax(a, b):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+from parity import relmax as _relmax   # max|a - b| / max|b|, recorded (tests/parity.py)
 
 
 def _ef(vpx, tag, kw):

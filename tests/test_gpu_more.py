@@ -12,10 +12,7 @@ from golden_util import fill_state_dict_, load_golden, name_seed, seeded_rand, s
 pytestmark = pytest.mark.gpu
 
 
-def _relmax(a, b):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+from parity import relmax as _relmax   # max|a - b| / max|b|, recorded (tests/parity.py)
 
 
 @pytest.mark.parametrize("tag", list(gc.NDRPLZ_SEQ_CASES))
@@ -495,3 +492,38 @@ def test_bias_gradients_are_bit_reproducible(vpx):
     assert torch.equal(res[0], res[1])
     want = (gy.double() * torch.where(y > 0, 1.0, 0.2).double()).sum(dim=(0, 2, 3))
     assert _relmax(res[0], want.float()) < 1e-5
+
+
+def test_real_launch_after_dry_run():
+    """a dry run (VPX_OPT_DRY_RUN) must leave no state behind that a later real launch depends on — in a FRESH process (no function
+    attribute set yet) the same calls run dry first, then for real, on a shape of each fused-cell kernel family (the small-grid kernel
+    used to record its LDS attribute as set during the dry run), and the real results match a process that never ran dry."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import vp_suite_amd as v
+L = v._lib.lib()
+dry_first = sys.argv[1] == "1"
+outs = []
+for (Cin, Ch, H, W, B) in ((96, 96, 16, 16, 3), (64, 64, 64, 64, 8), (16, 64, 32, 32, 2)):
+    g = torch.Generator().manual_seed(Cin + Ch + H)
+    x = v.ops.to_channels_last(torch.rand(B, 3, Cin, H, W, generator=g).cuda())
+    Wt = (torch.randn(4 * Ch, Cin + Ch, 3, 3, generator=g) * 0.03).cuda()
+    b = torch.zeros(4 * Ch).cuda()
+    pw = [(torch.randn(1, Ch, H, W, generator=g) * 0.1).cuda() for _ in range(3)]
+    for dry in ((1, 0) if dry_first else (0,)):
+        L.vpx_set_option(v._lib.OPT_DRY_RUN, dry)
+        with torch.no_grad():
+            out, hT, cT = v.ops.convlstm_seq(x, None, None, Wt, b, *pw, seq_len=3, in_channels=Cin, precision="bf16x3")
+    torch.cuda.synchronize()
+    outs.append(float(out.double().abs().sum()) + float(cT.double().abs().sum()))
+print("RESULT", " ".join(repr(o) for o in outs))
+''' % root
+    res = []
+    for dry_first in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", script, dry_first], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res.append([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1])
+    assert res[0] == res[1], res

@@ -14,10 +14,7 @@ RTOL = 1e-5
 GRTOL = 5e-5
 
 
-def _relmax(a, b):
-    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+from parity import relmax as _relmax   # max|a - b| / max|b|, recorded (tests/parity.py)
 
 
 @pytest.mark.parametrize("tag", ["plain", "k3", "ln"])
@@ -181,6 +178,44 @@ def test_fused_reversed_pass_equals_two_passes(vpx, mode):
         assert abs(a[0] - b[0]) < 2e-6 * abs(b[0]), key
         assert _relmax(a[1], b[1]) < 2e-5, key
         assert a[2] == b[2] and a[3] == b[3] and a[4] == b[4], key   # schedule state and the RNG stream's position
+
+
+@pytest.mark.parametrize("frozen", ["cell0", "all"])
+def test_training_forward_with_frozen_cells(vpx, frozen):
+    """with cell 0's weights frozen its step at t = 0 has nothing that requires a gradient (frames and zero states) and saves
+    nothing for the backward — the deferred-weight-gradient banks must not be built then (the reference and the per-step path run this
+    case). Loss equal to the unfrozen model's; the trainable cells' gradients equal to the per-step path's; a frozen cell has none; and a
+    cell driven directly afterwards still runs with its own defaults (the model no longer flips use_shadows on the modules)."""
+    from vp_suite_amd.measure import PredictionLossProvider
+    lp = PredictionLossProvider({"device": "cuda", "losses_and_scales": {"mse": 1.0}})
+    kw = dict(img_shape=(1, 32, 32), action_size=0, tensor_value_range=[0.0, 1.0], num_layers=2, num_hidden=[16, 16], cell_precision="bf16x3")
+    B, Ttot, P = 3, 6, 3
+    frames = seeded_rand((B, Ttot, 1, 32, 32), name_seed("predrnn.frozen.frames")).cuda()
+    res = {}
+    for defer in (True, False):
+        m = _predrnn("fuse", kw)
+        m.defer_weight_gradients = defer
+        if frozen == "cell0":
+            m.cell_list[0].requires_grad_(False)
+        else:
+            m.requires_grad_(False)
+        m.sampling_eta = 0.5
+        torch.manual_seed(99)
+        loss = m.training_loss(frames, frames[:, Ttot - P:], P, lp)
+        if frozen == "cell0":
+            loss.backward()
+        named = dict(m.named_parameters())
+        assert all(p.grad is None for k, p in named.items() if k.startswith("cell_list.0.") or frozen == "all")
+        res[defer] = (float(loss.detach()), {k: p.grad.detach().cpu().numpy() for k, p in named.items() if p.grad is not None})
+        assert all(c.use_shadows is False for c in m.cell_list)
+    assert abs(res[True][0] - res[False][0]) < 2e-6 * abs(res[False][0])
+    for k, g in res[False][1].items():
+        assert _relmax(res[True][1][k], g) < 2e-5, k
+    m = _predrnn("fuse", kw)
+    m.sampling_eta = 0.5
+    torch.manual_seed(99)
+    ref = float(m.training_loss(frames, frames[:, Ttot - P:], P, lp).detach())
+    assert abs(res[False][0] - ref) < 2e-6 * abs(ref)
 
 
 @pytest.mark.parametrize("B,Ttot,slices", [(24, 12, 8), (48, 12, 16), (128, 17, 32)])

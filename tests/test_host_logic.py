@@ -366,11 +366,13 @@ def test_bench_final_line_fits_the_driver_capture(vpx):
         assert k in rf, k
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3)
     # traffic is a citation of a committed PMC pass, never presented as live: its source file is named next to it
-    assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
-    if rf["traffic_source"]:
-        assert os.path.exists(os.path.join(ROOT, rf["traffic_source"]))
+    # (round 6: ... and only while the loaded library is the one that was measured — else null + "stale: <file> ...")
+    src = rf["traffic_source"]
+    assert (rf["traffic"] is None) == (src is None or src.startswith("stale:"))
+    if src and not src.startswith("stale:"):
+        assert os.path.exists(os.path.join(ROOT, src))
     cb = got["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 16 and len(cb["sample"]) <= 200
+    assert cb["kind"] == "port" and cb["cores"] == 16 and len(cb["sample"]) <= 360
     names = [e["name"] for e in got["extras"]]
     assert names == [e["name"] for e in full["extras"]] and got["extras_file"] == "bench_extras.json"
     e0 = got["extras"][0]
@@ -410,3 +412,26 @@ def test_tools_compile_and_referenced_tools_exist():
         text = open(os.path.join(root, doc)).read()
         for t in set(re.findall(r"tools/[A-Za-z0-9_]+\.(?:py|sh)", text)):
             assert os.path.exists(os.path.join(root, t)), (doc, t)
+
+
+def test_bench_drops_traffic_measured_on_another_library(vpx, tmp_path, monkeypatch):
+    """`roofline.traffic` cites a committed PMC summary only while the loaded library IS the one that was measured
+    (the file's `lib_sha16` = sha256(libvpx_hip.so)[:16]); another build — or a pre-round-6 file without the field — gives null and says why."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sha = bench.loaded_lib_sha16()
+    assert sha is not None and len(sha) == 16
+    good, stale, old = tmp_path / "r06_pmc_x.json", tmp_path / "r06_pmc_y.json", tmp_path / "r05_pmc_z.json"
+    good.write_text(json.dumps({"lib_sha16": sha, "hbm_traffic_bytes_per_launch": {"total": 123.4}}))
+    stale.write_text(json.dumps({"lib_sha16": "0" * 16, "hbm_traffic_bytes_per_launch": {"total": 123.4}}))
+    old.write_text(json.dumps({"hbm_traffic_bytes_per_launch": {"total": 123.4}}))
+    assert bench.traffic_from_file(str(good), sha) == (123, "profiles/r06_pmc_x.json")
+    for f in (stale, old):
+        t, why = bench.traffic_from_file(str(f), sha)
+        assert t is None and why.startswith("stale:")
+    # the committed round-5 files predate the field: the headline's traffic must read null until this round's passes are committed
+    t, why = bench.measured_traffic(bench.Spec("headline"))
+    assert t is None or why.startswith("profiles/r06")

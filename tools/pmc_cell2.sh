@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 TAG=${1:-gen2}
 OUT=gpurun_out/pmc_cell2_$TAG
 rm -rf $OUT; mkdir -p $OUT
-export PREC=bf16x3
+export PREC=${PREC:-bf16x3}
 i=0
 while read -r line; do
   [ -z "$line" ] && continue

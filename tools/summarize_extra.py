@@ -6,6 +6,15 @@ counts per step (what `roofline.traffic` of the `extras` entry <name> reports).
 usage: tools/summarize_extra.py <round> <tag> <name>"""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def lib_sha16():
+    """sha256(vp-suite_amd/libvpx_hip.so)[:16] — the library these counters were collected on; bench.py reports `roofline.traffic` from a
+    committed PMC file only while the library it loaded has this hash (a kernel change without a fresh PMC pass then shows null, not old bytes)"""
+    import hashlib
+    with open(os.path.join(ROOT, "vp-suite_amd", "libvpx_hip.so"), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
 ROUND, TAG, NAME = sys.argv[1], sys.argv[2], sys.argv[3]
 SRC = os.path.join(ROOT, "gpurun_out", "prof_extra", TAG)
 DST = os.environ.get("VPX_PROFILES_DST") or os.path.join(ROOT, "profiles")   # (the GPU box writes under gpurun_out/: only that comes back)
@@ -44,7 +53,7 @@ for d, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc
         k = r["Kernel_Name"].split("(")[0][:100]
         e = tab[k].setdefault(cname, [0.0, 0])
         e[0] += float(r["Counter_Value"]); e[1] += 1
-out = {"configuration": NAME, "command": f"tools/prof_extra.sh {TAG} ... (separate --pmc passes over bench.py --steps 3 --warmup 1)", "per_kernel": {}}
+out = {"configuration": NAME, "lib_sha16": lib_sha16(), "command": f"tools/prof_extra.sh {TAG} ... (separate --pmc passes over bench.py --steps 3 --warmup 1)", "per_kernel": {}}
 cell_bytes = 0.0
 for k, cs in tab.items():
     e = {}

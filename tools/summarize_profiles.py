@@ -12,6 +12,15 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def lib_sha16():
+    """sha256(vp-suite_amd/libvpx_hip.so)[:16] — the library these counters were collected on; bench.py reports `roofline.traffic` from a
+    committed PMC file only while the library it loaded has this hash (a kernel change without a fresh PMC pass then shows null, not old bytes)"""
+    import hashlib
+    with open(os.path.join(ROOT, "vp-suite_amd", "libvpx_hip.so"), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
 SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
 DST = os.environ.get("VPX_PROFILES_DST") or os.path.join(ROOT, "profiles")   # (the GPU box writes under gpurun_out/: only that comes back)
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
@@ -96,6 +105,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
 summary = {"kernel": "fused ConvLSTM cell step (cell2_kernel_q<Cell2Epi, true, 4>: every block shape of convlstm-shi at this batch) "
                      f"averaged over the launches of `bench.py --steps 3` (convlstm-shi, {BT}, 6 block shapes)",
            "command": "tools/collect_profiles.sh (rocprofv3 --pmc <counter> --kernel-trace, one pass per counter group)",
+           "lib_sha16": lib_sha16(),
            "counters": counters}
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     # per CELL STEP (fused launches and K-split trios alike): the unit bench.py's algorithmic_bytes_per_launch uses
@@ -133,7 +143,7 @@ if "FETCH_SIZE" in tcount and "WRITE_SIZE" in tcount:
     wr = tcount["WRITE_SIZE"]["mean_per_cell_step"] * 1024
     tsum = {"kernel": "forward fused ConvLSTM cell steps inside the TRAINING step (gates and cell states saved for BPTT), "
                       f"`bench.py --mode train --steps 2` (convlstm-shi, {BT})",
-            "command": "tools/collect_profiles.sh (pmc_train_* passes)",
+            "command": "tools/collect_profiles.sh (pmc_train_* passes)", "lib_sha16": lib_sha16(),
             "counters": tcount,
             "hbm_traffic_bytes_per_launch": {"read": rd, "write": wr, "total": rd + wr,
                                              "note": "per forward cell step; read = 2 * FETCH_SIZE KiB, write = WRITE_SIZE KiB"}}

@@ -30,16 +30,34 @@ struct CellXEpi {
 };
 
 // LDS-DMA with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit vector address arithmetic, one
-// VGPR per request (c2_dma16's notes on the inline asm and M0 apply)
-__device__ __forceinline__ void cx_dma16(const char* sbase, unsigned voff, char* lds_wave_base) {
-    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base;
-    // (the base IS wave-uniform; readfirstlane makes the compiler's divergence analysis agree, else it hands the asm a VGPR pair)
-    const unsigned long long sb = reinterpret_cast<unsigned long long>(sbase);
-    const unsigned long long su = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sb >> 32)) << 32) |
-                                  (unsigned)__builtin_amdgcn_readfirstlane((int)sb);
-    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :: "v"(voff), "s"(su), "{m0}"(__builtin_amdgcn_readfirstlane(lds)) : "memory");
+// VGPR per request (c2_dma16's notes on the inline asm and M0 apply). `lds` = LDS byte address of the wave's 1 KiB (an integer: casting a
+// generic pointer to the LDS address space per request costs a null test of three scalar instructions each time).
+__device__ __forceinline__ unsigned long long cx_uniform(const char* p) {
+    // (the pointer IS wave-uniform; readfirstlane makes the compiler's divergence analysis agree, else it hands the asm a VGPR pair)
+    const unsigned long long sb = reinterpret_cast<unsigned long long>(p);
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sb >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)sb);
 }
+__device__ __forceinline__ void cx_dma16(const char* sbase, unsigned voff, unsigned lds) {
+    asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(cx_uniform(sbase)), "{m0}"(__builtin_amdgcn_readfirstlane(lds)) : "memory");
+}
+// ... with a lane mask applied INSIDE the asm: the instruction is always issued (an all-zero mask included), so the wave's vmcnt
+// sequence never depends on the data — behind a compiler-made `if (lane valid)` a wave whose 64 lanes are all outside the image skips
+// the request (s_cbranch_execz), and every counted wait after it then allows one OLDER request to be in flight (round 6: the first form
+// of this kernel did exactly that on tiles at the image's lower edge — intermittently wrong results at many tiles per CU)
+__device__ __forceinline__ void cx_dma16_masked(const char* sbase, unsigned voff, unsigned lds, unsigned long long lanes) {
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(cx_uniform(sbase)), "{m0}"(__builtin_amdgcn_readfirstlane(lds)), "s"(lanes) : "memory", "scc");
+}
+#ifdef VPX_ABLATE
+// developer build only (make ablate): per-workgroup s_memtime stamps of wave 0 — start, first MFMA, loop end, end — and HW_ID | XCC_ID << 32
+// (tools/trace_cell2x.py); vpx_dbg_cell2x_trace() reads them back. Never compiled into the product library.
+__device__ unsigned long long cx_trace[8192 * 8];
+#define CX_TRACE(k) do { if (wave == 0 && lane == 0 && L < 8192) cx_trace[L * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CX_TRACE(k) do { } while (0)
+#endif
 template <int N> __device__ __forceinline__ void cx_wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N) : "memory"); }
 
 // PLAIN: VPX_PREC_BF16 — hi parts only (one MFMA per product); the lo planes of a stage and the lo half of every weight piece are
@@ -79,20 +97,48 @@ __global__ __launch_bounds__(512, 4) void cell2_kernel_x(const Cell2Plan P, cons
 
     char* const Abuf = smem;
     char* const Wbuf = smem + 2 * G::ABUF;
+#ifdef VPX_ABLATE
+    // TIMING-ONLY ablations of the developer build (garbage results): experiment bits 20 no waits for copies at the sync points, 21 no
+    // barrier at the sync points, 22 no weight copies, 23 no stage copies, 24 no epilogue, 25 no fragment reads
+    const int ab = P._q;
+#else
+    constexpr int ab = 0;
+#endif
+#ifdef VPX_ABLATE
+    if (wave == 0 && lane == 0 && L < 8192) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        cx_trace[L * 8 + 4] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+#endif
+    CX_TRACE(0);
 
     // this thread's pieces of a stage copy: piece = tid + 512 u -> (plane = part * 2 + channel half, halo position). The plane of a piece
     // is wave-uniform (a plane is 384 = 6 x 64 pieces): its byte offset inside a split pixel row stays in a scalar register. Positions
-    // outside the image are zeroed ONCE here, in both stage buffers, and their lanes sit out every copy (the DMA writes LDS per lane).
-    int pixoff[NPC];
+    // outside the image are zeroed ONCE here, in both stage buffers, and their lanes sit out every copy (the DMA writes LDS per lane;
+    // inimg[u] = the lanes inside the image, a scalar pair). The pixel offset of a piece is RECOMPUTED at each of its two uses per period
+    // (a dozen vector instructions per 432 MFMAs) instead of living in a register through the loop: at 128 registers per wave the
+    // compiler spilled exactly these values, and a reload from scratch memory waits on vmcnt(0) in the middle of the copy requests.
+    const unsigned smem0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the dynamic segment
+    unsigned long long inimg[NPC];
     int choff[NPC];
-#pragma unroll
-    for (int u = 0; u < NPC; ++u) {
-        const int plane = (wave * 64 + 512 * u) / G::PLANE_POS;                  // wave-uniform
-        const int pos = tid + 512 * u - plane * G::PLANE_POS;
+    auto piece_pix = [&](int u, bool& ok) {
+        int t = tid;
+        asm volatile("" : "+v"(t));   // (opaque: keeps the loop-invariant arithmetic below from being hoisted back into registers)
+        const int plane = (wave * 64 + 512 * u) / G::PLANE_POS;   // wave-uniform
+        const int pos = t + 512 * u - plane * G::PLANE_POS;
         const int hy = pos / C2_HALO_W, hx = pos - hy * C2_HALO_W;
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = pos < G::NPOS && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
-        pixoff[u] = ok ? gy * P.W + gx : -1;
+        ok = pos < G::NPOS && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+        return ok ? gy * P.W + gx : 0;
+    };
+#pragma unroll
+    for (int u = 0; u < NPC; ++u) {
+        const int plane = (wave * 64 + 512 * u) / G::PLANE_POS;
+        bool ok;
+        (void)piece_pix(u, ok);
+        inimg[u] = __builtin_amdgcn_ballot_w64(ok);
         choff[u] = __builtin_amdgcn_readfirstlane((plane & 1) * 32 + (plane >> 1) * 16);   // pixel row: [8-channel group][hi 16 B | lo 16 B]
         if (!ok && (!PLAIN || u == 0 || grpA)) {
             const uint4 z = {0u, 0u, 0u, 0u};
@@ -100,11 +146,11 @@ __global__ __launch_bounds__(512, 4) void cell2_kernel_x(const Cell2Plan P, cons
             *reinterpret_cast<uint4*>(Abuf + G::ABUF + (tid + 512 * u) * 16) = z;
         }
     }
-    const int dma_off = wave * 1024;   // wave-uniform LDS offset of this wave's 64 pieces inside a 512-piece pass
+    const unsigned dma_lds = smem0 + wave * 1024;   // LDS address of this wave's 64 pieces inside a 512-piece pass (buffer 0, pass 0)
     // weight pieces: a half chunk is [part][k group][64 columns][16 B] = 512 pieces (PLAIN: its hi part = the first 256, copied by one group)
     const char* const wtile = P.wpk + (size_t)n_tile * P.chunks_total * CQ_WCHUNK;   // wave-uniform
     const unsigned wvoff = (unsigned)((PLAIN ? (tid & 255) : tid) * 16);
-    const int wdma_off = PLAIN ? (wave & 3) * 1024 : dma_off;
+    const unsigned wdma_lds = smem0 + 2 * G::ABUF + (PLAIN ? (wave & 3) : wave) * 1024;
 
     const int nx = P.nx, S = P.nx + P.nh, Q = (9 * S + 1) / 2;
     const char* const xb = P.seg[0].sp + (size_t)b * P.seg[0].bstride;
@@ -114,7 +160,9 @@ __global__ __launch_bounds__(512, 4) void cell2_kernel_x(const Cell2Plan P, cons
         const bool isx = s < nx;
         const char* base = isx ? xb + s * 64 : hb + (s - nx) * 64;   // 16 channels = 64 bytes of a split pixel row (wave-uniform)
         const unsigned prow = isx ? xrow : hrow;
-        if (pixoff[u] >= 0) cx_dma16(base + (unsigned)choff[u], (unsigned)pixoff[u] * prow, Abuf + buf * G::ABUF + dma_off + u * 8192);
+        bool ok;
+        const unsigned pix = (unsigned)piece_pix(u, ok);
+        cx_dma16_masked(base + (unsigned)choff[u], pix * prow, dma_lds + buf * G::ABUF + u * 8192, inimg[u]);
     };
     auto issue_A = [&](int s, int buf) {   // this wave's share of a stage copy
         issue_A1(s, buf, 0);
@@ -123,7 +171,7 @@ __global__ __launch_bounds__(512, 4) void cell2_kernel_x(const Cell2Plan P, cons
     };
     auto issue_Wh = [&](int chunk, int slot, int half) {   // one 8 KiB half of a weight chunk (PLAIN: its 4 KiB hi part, by the half's group)
         if constexpr (PLAIN) { if (grpA != (half == 0)) return; }
-        cx_dma16(wtile + (size_t)chunk * CQ_WCHUNK + half * 8192, wvoff, Wbuf + slot * CQ_WCHUNK + half * 8192 + wdma_off);
+        cx_dma16(wtile + (size_t)chunk * CQ_WCHUNK + half * 8192, wvoff, wdma_lds + slot * CQ_WCHUNK + half * 8192);
     };
 
     f32x4 acc[RW][NTW];   // [tile row m][local column tile]: global tile 2 lt + nh (column split: lt = gate) | lt (row split: gate lt >> 1)
@@ -166,6 +214,7 @@ __global__ __launch_bounds__(512, 4) void cell2_kernel_x(const Cell2Plan P, cons
         for (int m = 0; m < RW; ++m) load_A1(0, m, a_lane);
         load_B(0, 0);
     }
+    CX_TRACE(1);
     for (int s0 = 0; s0 < S; s0 += 2) {
         const bool odd = s0 + 1 < S;         // the period's odd stage exists
         const bool more = s0 + 2 < S;        // another period follows
@@ -182,11 +231,12 @@ __global__ __launch_bounds__(512, 4) void cell2_kernel_x(const Cell2Plan P, cons
                         // ---- sync point X_q, before this wave's first read of half 1 of chunk q: the fragments of its half-0 tiles are in
                         //      registers (lgkmcnt) before that half is given away; the stage copy issued one step ago may still fly ----
                         const bool stage_flies = (p == 1 && odd) || (p == 6 && more);
-                        if (stage_flies) {
+                        if (ab & (1 << 20)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        else if (stage_flies) {
                             if constexpr (PLAIN) { if (grpA) cx_wait_vm_lgkm<2>(); else cx_wait_vm_lgkm<1>(); }
                             else cx_wait_vm_lgkm<3>();
                         } else cx_wait_vm_lgkm<0>();
-                        c2_barrier();
+                        if (!(ab & (1 << 21))) c2_barrier();
                     }
                     // ---- weight fragments of the next column tile (after the last step: bytes nobody uses, cheaper than a branch) ----
                     if (lt < NTW - 1) load_B(p, lt + 1);
@@ -208,12 +258,16 @@ __global__ __launch_bounds__(512, 4) void cell2_kernel_x(const Cell2Plan P, cons
                     // ---- this sync point's copies, behind the MFMAs of the following column tiles: the weights first, then the stage ----
                     if (lt == SYNC_LT) {
                         const int sl = (p & 1) ^ par;   // ring slot of chunk q (and q + 2)
-                        if (q + 1 < Q) issue_Wh(q + 1, sl ^ 1, 1);
-                        if (q + 2 < Q) issue_Wh(q + 2, sl, 0);
+                        if (!(ab & (1 << 22))) {
+                            if (q + 1 < Q) issue_Wh(q + 1, sl ^ 1, 1);
+                            if (q + 2 < Q) issue_Wh(q + 2, sl, 0);
+                        }
                     }
                     if (lt == SYNC_LT + 1) {
-                        if (p == 0 && odd) issue_A(s0 + 1, 1);
-                        if (p == 5 && more) issue_A(s0 + 2, 0);
+                        if (!(ab & (1 << 23))) {
+                            if (p == 0 && odd) issue_A(s0 + 1, 1);
+                            if (p == 5 && more) issue_A(s0 + 2, 0);
+                        }
                     }
                 }
             }
@@ -225,10 +279,24 @@ __global__ __launch_bounds__(512, 4) void cell2_kernel_x(const Cell2Plan P, cons
     //      two passes of two tile rows, image [gate][pixel 32][16 channels]; a lane then owns FOUR channels of a pixel for all four
     //      gates: 16-byte global accesses, four lanes = one pixel's 64-byte channel run ----
     const ConvLSTMStepArgs& a = E.a;
-    c2_barrier();   // every wave has read its last fragments: the staging buffers become the transposition space
+    CX_TRACE(2);
+#ifdef VPX_ABLATE
+    if (ab & (1 << 24)) {   // timing only: no epilogue (one never-taken store keeps the accumulators alive)
+        float t = 0.f;
+        for (int m = 0; m < RW; ++m) for (int nt = 0; nt < NTW; ++nt) for (int r = 0; r < 4; ++r) t += acc[m][nt][r];
+        if (t == 1.2345e-30f) a.c_out[0] = t;
+        CX_TRACE(3);
+        return;
+    }
+#endif
     float* const lx = reinterpret_cast<float*>(smem + wave * 8192);
-    const int cg = lane & 3, pp = lane >> 2;
+    // lane -> (four channels cg, pixel pp) of a pass: row split — a pass is ONE tile row x 32 channels (8 lanes = a pixel's whole 128-byte
+    // channel run: every global access a full line); column split — two tile rows x the wave's 16 channels (4 lanes = 64 bytes)
+    const int cg = MSPLIT ? (lane & 7) : (lane & 3), pp = MSPLIT ? (lane >> 3) : (lane >> 2);
+    constexpr int PCH = MSPLIT ? 32 : 16;          // channels of a pass
+    constexpr int PPI = MSPLIT ? 8 : 16;           // pixels per iteration of a pass (64 lanes / lanes per pixel)
     const unsigned Ch = (unsigned)a.Ch;
+    const unsigned ch = (unsigned)(n_tile * 32 + (MSPLIT ? 0 : nh * 16) + cg * 4);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const size_t img = (size_t)b * P.H * P.W;
     const float* const cin_b = a.c_in ? a.c_in + img * Ch : nullptr;
@@ -236,83 +304,115 @@ __global__ __launch_bounds__(512, 4) void cell2_kernel_x(const Cell2Plan P, cons
     float* const hout_b = a.h_out ? a.h_out + (size_t)b * a.h_bstride : nullptr;
     float* const g0 = a.gates ? a.gates + img * 4 * Ch : nullptr;
     char* const hsp_b = E.h_sp ? E.h_sp + (size_t)b * E.h_sp_bstride : nullptr;
+    // Four iterations k = 2 * pass + it of 16 (row split: 8) pixels x 4 channels per lane. The global operands of iteration k + 1 (cell state,
+    // three peepholes: 64 bytes per lane) are requested BEFORE the arithmetic of iteration k, those of iteration 0 before the barrier and the
+    // first LDS round trip: issued right before their use (the first form of this epilogue) every iteration exposed a whole HBM / L2 round
+    // trip — 21-22 k cycles per tile of which the arithmetic is 7 k (developer build stamps, profiles/r06_cell2x_trace.txt).
+    struct EIn { unsigned eo; f32x4 cp, wi, wf, wo; };
+    auto eload = [&](int k, EIn& v) {
+        const int ps = k >> 1, it = k & 1;
+        const int pix = MSPLIT ? (y0 + mrow0 + ps) * P.W + x0 + it * 8 + pp : (y0 + mrow0 + 2 * ps + it) * P.W + x0 + pp;
+        v.eo = __umul24((unsigned)pix, Ch) + ch;
+        v.cp = cin_b ? *reinterpret_cast<const f32x4*>(cin_b + v.eo) : zero;
+        v.wi = a.wci ? *reinterpret_cast<const f32x4*>(a.wci + v.eo) : zero;
+        v.wf = a.wci ? *reinterpret_cast<const f32x4*>(a.wcf + v.eo) : zero;
+        v.wo = a.wco ? *reinterpret_cast<const f32x4*>(a.wco + v.eo) : zero;
+    };
+    // pass ps: column split — tile rows 2 ps, 2 ps + 1 of the wave's four, channel half nh; row split — tile row ps of the wave's two, all 32
+    // channels. LDS image [gate][pixel][PCH channels] = 8 KiB either way. Bias: a lane's accumulator column is ONE channel of every gate —
+    // added on the way into LDS.
+    auto put = [&](int ps) {
+        if constexpr (MSPLIT) {
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        // pass ps: column split — tile rows 2 ps, 2 ps + 1 of the wave's four, channel half nh; row split — the wave's two rows, channel half ps
-        const int chh = MSPLIT ? ps : nh;
-        const unsigned ch = (unsigned)(n_tile * 32 + chh * 16 + cg * 4);
-        // bias: a lane's accumulator column is channel 16 chh + r16 of every gate — one value per gate, added on the way into LDS
-        float bq[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
+            for (int nt = 0; nt < 8; ++nt) {
+                const float bq = a.bias ? a.bias[a.gate_pos[nt >> 1] * Ch + (unsigned)(n_tile * 32 + (nt & 1) * 16 + r16)] : 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bq[g] = a.bias[a.gate_pos[g] * Ch + (unsigned)(n_tile * 32 + chh * 16 + r16)];
+                for (int r = 0; r < 4; ++r) lx[(nt >> 1) * 512 + (4 * kg + r) * 32 + (nt & 1) * 16 + r16] = acc[ps][nt][r] + bq;
+            }
+        } else {
+            float bq[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[g] = a.bias[a.gate_pos[g] * Ch + (unsigned)(n_tile * 32 + nh * 16 + r16)];
+            }
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lx[g * 512 + (mm * 16 + 4 * kg + r) * 16 + r16] = acc[2 * ps + mm][g][r] + bq[g];
         }
+    };
+    auto emath = [&](int k, const EIn& v) {
+        const int it = k & 1;
+        const unsigned eo = v.eo;
+        const float* row = lx + (it * PPI + pp) * PCH + cg * 4;
+        const f32x4 ai = *reinterpret_cast<const f32x4*>(row);
+        const f32x4 af = *reinterpret_cast<const f32x4*>(row + 512);
+        const f32x4 ag = *reinterpret_cast<const f32x4*>(row + 1024);
+        const f32x4 ao = *reinterpret_cast<const f32x4*>(row + 1536);
+        f32x4 i4, f4, g4, o4, cn, hn;
 #pragma unroll
-        for (int mm = 0; mm < 2; ++mm)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    lx[g * 512 + (mm * 16 + 4 * kg + r) * 16 + r16] = (MSPLIT ? acc[mm][2 * g + ps][r] : acc[2 * ps + mm][g][r]) + bq[g];
-        // (LDS operations of one wave execute in order: the reads below see these writes without a barrier)
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int pix = (y0 + mrow0 + (MSPLIT ? 0 : 2 * ps) + it) * P.W + x0 + pp;
-            const unsigned eo = __umul24((unsigned)pix, Ch) + ch;
-            const f32x4 cp = cin_b ? *reinterpret_cast<const f32x4*>(cin_b + eo) : zero;
-            const f32x4 wi = a.wci ? *reinterpret_cast<const f32x4*>(a.wci + eo) : zero;
-            const f32x4 wf = a.wci ? *reinterpret_cast<const f32x4*>(a.wcf + eo) : zero;
-            const f32x4 wo = a.wco ? *reinterpret_cast<const f32x4*>(a.wco + eo) : zero;
-            const float* row = lx + (it * 16 + pp) * 16 + cg * 4;
-            const f32x4 ai = *reinterpret_cast<const f32x4*>(row);
-            const f32x4 af = *reinterpret_cast<const f32x4*>(row + 512);
-            const f32x4 ag = *reinterpret_cast<const f32x4*>(row + 1024);
-            const f32x4 ao = *reinterpret_cast<const f32x4*>(row + 1536);
-            f32x4 i4, f4, g4, o4, cn, hn;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float c0 = cp[e];
-                i4[e] = sigmoid_f(ai[e] + wi[e] * c0);   // (ai .. ao carry their bias)
-                f4[e] = sigmoid_f(af[e] + wf[e] * c0);
-                g4[e] = tanh_f(ag[e]);
-                cn[e] = f4[e] * c0 + i4[e] * g4[e];
-                o4[e] = sigmoid_f(ao[e] + wo[e] * cn[e]);
-                hn[e] = o4[e] * tanh_f(cn[e]);
-            }
-            *reinterpret_cast<f32x4*>(cout_b + eo) = cn;
-            if (hout_b) *reinterpret_cast<f32x4*>(hout_b + eo) = hn;   // (null: the consumer reads the split copy below — VPX_FLAG_OUT_SPLIT)
-            if (g0) {
-                const unsigned go = 4u * (eo - ch) + ch;
-                *reinterpret_cast<f32x4*>(g0 + go) = i4;
-                *reinterpret_cast<f32x4*>(g0 + go + Ch) = f4;
-                *reinterpret_cast<f32x4*>(g0 + go + 2 * Ch) = g4;
-                *reinterpret_cast<f32x4*>(g0 + go + 3 * Ch) = o4;
-            }
-            if (hsp_b) {
-                // the lane pair (cg even, cg odd) holds one 8-channel group = 32 bytes [8 hi | 8 lo]: the even lane stores the 16 hi bytes,
-                // the odd lane the 16 lo bytes (Cell2Epi::vec_math's exchange: quad_perm [1,0,3,2])
-                unsigned h[4], l[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) c2_split(hn[e], h[e], l[e]);
-                const bool oddl = (cg & 1) != 0;
-                const unsigned h0 = h[0] | (h[1] << 16), h1 = h[2] | (h[3] << 16), l0 = l[0] | (l[1] << 16), l1 = l[2] | (l[3] << 16);
-                const unsigned s0 = oddl ? h0 : l0, s1 = oddl ? h1 : l1;   // what the partner stores of mine
-                const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, true);
-                const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, true);
-                char* dst = hsp_b + 4u * (eo - ch) + (ch >> 3) * 32 + (oddl ? 16 : 0);
-                *reinterpret_cast<uint4*>(dst) = oddl ? uint4{r0, r1, l0, l1} : uint4{h0, h1, r0, r1};
-            }
+        for (int e = 0; e < 4; ++e) {
+            const float c0 = v.cp[e];
+            i4[e] = sigmoid_f(ai[e] + v.wi[e] * c0);   // (ai .. ao carry their bias)
+            f4[e] = sigmoid_f(af[e] + v.wf[e] * c0);
+            g4[e] = tanh_f(ag[e]);
+            cn[e] = f4[e] * c0 + i4[e] * g4[e];
+            o4[e] = sigmoid_f(ao[e] + v.wo[e] * cn[e]);
+            hn[e] = o4[e] * tanh_f(cn[e]);
         }
-    }
+        *reinterpret_cast<f32x4*>(cout_b + eo) = cn;
+        if (hout_b) *reinterpret_cast<f32x4*>(hout_b + eo) = hn;   // (null: the consumer reads the split copy below — VPX_FLAG_OUT_SPLIT)
+        if (g0) {
+            const unsigned go = 4u * (eo - ch) + ch;
+            *reinterpret_cast<f32x4*>(g0 + go) = i4;
+            *reinterpret_cast<f32x4*>(g0 + go + Ch) = f4;
+            *reinterpret_cast<f32x4*>(g0 + go + 2 * Ch) = g4;
+            *reinterpret_cast<f32x4*>(g0 + go + 3 * Ch) = o4;
+        }
+        if (hsp_b) {
+            // the lane pair (cg even, cg odd) holds one 8-channel group = 32 bytes [8 hi | 8 lo]: the even lane stores the 16 hi bytes,
+            // the odd lane the 16 lo bytes (Cell2Epi::vec_math's exchange: quad_perm [1,0,3,2])
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c2_split(hn[e], h[e], l[e]);
+            const bool oddl = (cg & 1) != 0;
+            const unsigned h0 = h[0] | (h[1] << 16), h1 = h[2] | (h[3] << 16), l0 = l[0] | (l[1] << 16), l1 = l[2] | (l[3] << 16);
+            const unsigned s0 = oddl ? h0 : l0, s1 = oddl ? h1 : l1;   // what the partner stores of mine
+            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, true);
+            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, true);
+            char* dst = hsp_b + 4u * (eo - ch) + (ch >> 3) * 32 + (oddl ? 16 : 0);
+            *reinterpret_cast<uint4*>(dst) = oddl ? uint4{r0, r1, l0, l1} : uint4{h0, h1, r0, r1};
+        }
+    };
+    EIn va, vb;
+    eload(0, va);
+    c2_barrier();   // every wave has read its last fragments: the staging buffers become the transposition space
+    put(0);
+    // (LDS operations of one wave execute in order: the reads of emath see put's writes without a barrier, and the next put's writes come
+    //  after the reads of the pass before it)
+    eload(1, vb);
+    emath(0, va);
+    eload(2, va);
+    emath(1, vb);
+    put(1);
+    eload(3, vb);
+    emath(2, va);
+    emath(3, vb);
+#ifdef VPX_ABLATE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (how long the epilogue's stores take to complete)
+#endif
+    CX_TRACE(3);
 }
 
 // the fused cell step on the eight-wave half tile; the caller (launch_cell2, cell2.hip) has checked that the q form applies (maps in
 // whole 16x16 tiles, whole 32-channel N tiles) and set tiles_y / grid_m for 16-row tiles
-hipError_t launch_cell2x(const Cell2Plan& p, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s) {
+hipError_t launch_cell2x(const Cell2Plan& p_in, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s) {
     // split: 0 = columns (wave tile 4 rows x 4 column tiles), 1 = rows (2 rows x 8 column tiles). Default: rows for bf16x3 (the column split
     // spills fragment registers inside the loop at 128 registers), columns for plain bf16 (fewer fragment reads per MFMA; it fits).
     // VPX_OPT_EXPERIMENT bit 16 swaps the two (tests, A/B runs).
-    const bool msplit = (p.plain == 0) != ((g_experiment & 65536) != 0);
+    const bool msplit = (p_in.plain == 0) != ((g_experiment & 65536) != 0);
     static bool attr_set = false;
     if (!attr_set) {
         const void* fn[4] = {reinterpret_cast<const void*>(&cell2_kernel_x<false, false>), reinterpret_cast<const void*>(&cell2_kernel_x<false, true>),
@@ -324,6 +424,8 @@ hipError_t launch_cell2x(const Cell2Plan& p, const ConvLSTMStepArgs& ea, void* h
         attr_set = !g_dry_run;
     }
     const CellXEpi epi{ea, reinterpret_cast<char*>(h_sp), h_sp_bstride};
+    Cell2Plan p = p_in;
+    p._q = g_experiment;   // (read by the developer build's timing ablations only)
     const long long per_xcd = ((long long)p.grid_m * p.n_tiles + 7) / 8;
     const dim3 grid((unsigned)(per_xcd * 8)), block(512);
     if (p.plain) {
@@ -337,3 +439,9 @@ hipError_t launch_cell2x(const Cell2Plan& p, const ConvLSTMStepArgs& ea, void* h
 }
 
 }  // namespace vpx
+
+#ifdef VPX_ABLATE
+extern "C" int vpx_dbg_cell2x_trace(unsigned long long* out65536) {
+    return (int)hipMemcpyFromSymbol(out65536, HIP_SYMBOL(vpx::cx_trace), sizeof(unsigned long long) * 8192 * 8);
+}
+#endif

@@ -274,7 +274,7 @@ hipError_t launch_cell3(const Cell3Args& args, hipStream_t s) {
     if (lds > attr_lds) {
         hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&cell3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C3_ABUF + (9 * C3_MAX_CH / 16) * C3_KSTEP);
         if (e != hipSuccess) return e;
-        attr_lds = 2 * C3_ABUF + (9 * C3_MAX_CH / 16) * C3_KSTEP;
+        if (!g_dry_run) attr_lds = 2 * C3_ABUF + (9 * C3_MAX_CH / 16) * C3_KSTEP;   // (a dry run sets nothing: a real launch may follow it)
     }
     const long long total = (long long)P.B * P.tiles_x * P.tiles_y * P.n_slices;
     const long long per_xcd = (total + 7) / 8;

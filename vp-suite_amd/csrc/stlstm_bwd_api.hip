@@ -172,7 +172,13 @@ extern "C" int vpx_stlstm_step_bwd_ex(const vpx_stlstm_desc* d, const float* x, 
                                       size_t workspace_bytes, void* stream_, const vpx_stlstm_shadows* shadows) {
     STSplitShadows sh = st_shadows_of(shadows);   // an argument of THIS call
     if (!d) { set_error("stlstm desc is NULL"); return VPX_ERR_ARG; }
-    if (d->layout != VPX_LAYOUT_NHWC) sh = STSplitShadows{};
+    if (d->layout != VPX_LAYOUT_NHWC) {
+        // the split-format shadows (and the deferred weight gradient's dG8 slot with them) exist for NHWC callers only: a request for a
+        // deferred weight gradient on reference-layout buffers is refused, not dropped (a caller who passed NULL dW pointers for it would
+        // get VPX_OK and no weight gradient at all)
+        if (shadows && shadows->dg8_out) { set_error("vpx_stlstm_step_bwd_ex: dg8_out (deferred weight gradients) needs VPX_LAYOUT_NHWC"); return VPX_ERR_UNSUPPORTED; }
+        sh = STSplitShadows{};
+    }
     if ((d->precision < VPX_PREC_F32 || d->precision > VPX_PREC_BF16)) { set_error("stlstm: precision %d not implemented", d->precision); return VPX_ERR_UNSUPPORTED; }
     if (!(d->flags & VPX_FLAG_SAVE_FOR_BWD)) { set_error("vpx_stlstm_step_bwd: desc lacks VPX_FLAG_SAVE_FOR_BWD"); return VPX_ERR_ARG; }
     if (!x || !h || !c || !m || !c_new || !m_new || !Wx || !Wh || !Wm || !Wo || !Wlast || !reserve) {

@@ -31,6 +31,7 @@ Carver::Carver(void* workspace, size_t bytes)
 Carver::~Carver() { g_carver = prev; }
 
 const char* ws_violation() { return g_ws_violation; }
+void ws_violation_clear() { g_ws_violation[0] = 0; }
 
 bool ws_write_ok(const void* dst_, size_t bytes, const char* what) {
     const char* dst = (const char*)dst_;

@@ -16,6 +16,7 @@ namespace vpx {
         if (e__ != hipSuccess) {                                                              \
             if (ws_violation()[0]) {   /* a launcher refused to write past its workspace slot */ \
                 set_error("%s (%s:%d)", ws_violation(), __FILE__, __LINE__);                   \
+                ws_violation_clear();   /* consumed: a later, unrelated HIP error must not report it again */ \
                 return VPX_ERR_WORKSPACE;                                                     \
             }                                                                                 \
             set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \

@@ -94,7 +94,9 @@ void set_error(const char* fmt, ...);
 // the launchers — and skips the HIP runtime calls themselves. Needs no GPU: the CPU test-suite sweeps the models' layer
 // shapes through every entry point this way (tests/test_workspace_contract.py), so a sizing rule that drifts from a launch
 // fails in the container, not as memory corruption on the GPU box. Every HIP runtime call of the library goes through the
-// wrappers below. A process that has run dry must not launch for real afterwards (function attributes were not set).
+// wrappers below. A dry run leaves no state behind that a later real launch depends on: the launchers record a function attribute as set
+// only when it really was (`attr_set = !g_dry_run`), so a process may switch the option off again and launch
+// (tests/test_gpu_more.py::test_real_launch_after_dry_run).
 extern int g_dry_run;
 #define VPX_LAUNCH(...) do { if (!::vpx::g_dry_run) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 static inline hipError_t vpx_hip_last_error() { return g_dry_run ? hipSuccess : hipGetLastError(); }
@@ -141,6 +143,7 @@ struct Carver {  // bump allocator over the caller's workspace
 // true when [dst, dst + bytes) is a legal write for the running call (see above); false + ws_violation() text otherwise
 bool ws_write_ok(const void* dst, size_t bytes, const char* what);
 const char* ws_violation();   // "" when the running call had none
+void ws_violation_clear();
 // after carving: the layout must fit what the caller handed over
 #define VPX_CHECK_CARVE(ws, who)                                                                                      \
     do {                                                                                                              \

@@ -57,13 +57,16 @@ class SpatioTemporalLSTMCell(VPModelBlock):
         state["_ws"] = ops.STWorkspace()
         return state
 
-    def forward(self, x_t, h_t, c_t, m_t, delta_out=None):
+    def forward(self, x_t, h_t, c_t, m_t, delta_out=None, use_shadows=None, precision=None):
+        # use_shadows / precision: per-call overrides for a model whose time loop owns the states (PredRNN_V2.forward) — the module's own
+        # attributes stay what user code that drives the cell directly set them to
         ln = ()
         if self.layer_norm:  # LayerNorm([C,H,W]) after conv_x / conv_h / conv_m / conv_o (predrnn.py:24-40)
             ln = tuple(p for seq in (self.conv_x, self.conv_h, self.conv_m, self.conv_o) for p in (seq[1].weight, seq[1].bias))
         return ops.stlstm_step(x_t, h_t, c_t, m_t, self.conv_x[0].weight, self.conv_h[0].weight, self.conv_m[0].weight,
-                               self.conv_o[0].weight, self.conv_last.weight, precision=self.precision, wsholder=self._ws,
-                               ln=ln, use_shadows=self.use_shadows, delta_out=delta_out)
+                               self.conv_o[0].weight, self.conv_last.weight, precision=self.precision if precision is None else precision,
+                               wsholder=self._ws, ln=ln, use_shadows=self.use_shadows if use_shadows is None else use_shadows,
+                               delta_out=delta_out)
 
 
 class ActionConditionalSpatioTemporalLSTMCell(VPModelBlock):

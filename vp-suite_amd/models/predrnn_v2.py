@@ -42,6 +42,7 @@ class _CellBanks:
             slab[0].zero_()
         self.X = new(T, b * h * w * cin0)
         self.banks, self.weights = [], []
+        self.precision = model.cell_precision   # ONE source for the banks and for every step they serve
         for i, g in enumerate(geo):
             cell = model.cell_list[i]
             bank = ops.STWeightBank((cell.conv_x[0].weight, cell.conv_h[0].weight, cell.conv_m[0].weight, cell.conv_o[0].weight, cell.conv_last.weight),
@@ -55,7 +56,7 @@ class _CellBanks:
         x_sp = self.X[t] if i == 0 else self.H[i - 1][t + 1]
         m_sp = self.M[self.L - 1][t] if i == 0 else self.M[i - 1][t + 1]
         slots = (self.banks[i], t, (x_sp, self.H[i][t], m_sp), (self.H[i][t + 1], self.C[i][t + 1], self.M[i][t + 1]), i == 0)
-        return ops.stlstm_step(x, h, c, m, *self.weights[i], precision=cell.precision, wsholder=cell._ws, slots=slots, delta_out=delta_out)
+        return ops.stlstm_step(x, h, c, m, *self.weights[i], precision=self.precision, wsholder=cell._ws, slots=slots, delta_out=delta_out)
 
 
 class PredRNN_V2(VPModel):
@@ -91,6 +92,9 @@ class PredRNN_V2(VPModel):
     #: training_loss runs the sequence and its time-reversal (predrnn_v2.py:326-352) as ONE batch of 2B samples: the two passes share the
     #: weights and nothing else, so this is the same arithmetic per sample with every launch on twice the grid and half the launches
     #: (what the 2-sample shards of BASELINE configs[4] need most). False: two forward passes one after the other, as the reference does.
+    #: REQUIRES every term of `loss_provider` to be a mean over the batch of per-sample values (MSE and the decoupling term are; a
+    #: batch-coupled or sum-normalised measure is not: set this to False for those). Costs the activation memory of a 2B batch; falls back
+    #: to two passes by itself when `actions` is not a [B, T, a] tensor or when a 2B pass would not fit the free device memory.
     fuse_reversed_pass: bool = True
     #: training: the five weight gradients of a cell are computed ONCE per forward pass over all of its steps (ops.STWeightBank) instead of
     #: once per step with an autograd accumulation per step and tensor. Same sums in another order. Where the library cannot (LayerNorm,
@@ -98,6 +102,7 @@ class PredRNN_V2(VPModel):
     defer_weight_gradients: bool = True
     #: ... while the operand slabs of a pass (dG8 of every step and cell: T*B*H*W*8Ch*4 bytes per cell, plus the state slabs) stay below
     #: this many bytes; a larger pass computes the weight gradients step by step as before (nothing is kept beyond a step's own context)
+    #: (and below half of the device memory that is free when the forward starts)
     BANK_BYTES_LIMIT = 64 << 30
     #: the decoupling term of all layer-steps of a pass in ONE library call each way (ops.decouple_term_batched): the steps write their
     #: delta_c / delta_m into one slab. False: one adapter convolution + statistics + mean per layer-step, as the reference does.
@@ -185,8 +190,6 @@ class PredRNN_V2(VPModel):
         nh, top = self.num_hidden, self.num_layers - 1
         # split-format shadows of the states live from one step of THIS loop to the next and no longer (ops.new_shadow_epoch)
         ops.new_shadow_epoch()
-        for cell in self.cell_list:
-            cell.use_shadows = True
         banks = self._weight_banks(b, total_frames - 1) if (train and torch.is_grad_enabled()) else None
         n_ls = (total_frames - 1) * self.num_layers
         slab = None
@@ -235,7 +238,8 @@ class PredRNN_V2(VPModel):
                     if banks is not None:
                         h_t[i], c_t[i], memory, d_c, d_m = banks.step(self.cell_list[i], i, t, inp, h_t[i], c_t[i], memory, dout)
                     else:
-                        h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory, delta_out=dout)
+                        h_t[i], c_t[i], memory, d_c, d_m = self.cell_list[i](inp, h_t[i], c_t[i], memory, delta_out=dout, use_shadows=True,
+                                                                             precision=prec)
                 if slab is not None:
                     deltas += [d_c, d_m]
                 else:
@@ -258,13 +262,23 @@ class PredRNN_V2(VPModel):
         """ops.STWeightBank per cell for one training forward of T steps (defer_weight_gradients), or None where the library cannot."""
         if not self.defer_weight_gradients or self.action_conditional or self.layer_norm or len(set(self.num_hidden[:self.num_layers])) != 1:
             return None
+        # a bank collects the weight gradients of a cell whose every step saves for the backward: with a frozen cell (or a frozen model) the
+        # first steps have nothing that requires a gradient and save nothing — the plain per-step path handles that (as the reference does)
+        for cell in self.cell_list:
+            ws = (cell.conv_x[0].weight, cell.conv_h[0].weight, cell.conv_m[0].weight, cell.conv_o[0].weight, cell.conv_last.weight)
+            if not all(w.requires_grad for w in ws):
+                return None
         cin = [self.patch_c] + list(self.num_hidden[:self.num_layers - 1])
         geo = [(b, cin[i], self.num_hidden[i], self.rnn_h, self.rnn_w, self.filter_size) for i in range(self.num_layers)]
         if not all(ops.STWeightBank.available(*g, self.cell_precision) for g in geo):
             return None
         px = b * self.rnn_h * self.rnn_w
         slab_bytes = sum(4 * px * (T * 8 * g[2] + 3 * (T + 1) * g[2]) for g in geo) + 4 * px * T * geo[0][1]
-        if slab_bytes > self.BANK_BYTES_LIMIT:
+        limit = self.BANK_BYTES_LIMIT
+        dev = self.adapter.weight.device
+        if dev.type == "cuda":
+            limit = min(limit, torch.cuda.mem_get_info(dev)[0] // 2 + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev))
+        if slab_bytes > limit:
             return None
         return _CellBanks(self, geo, T)
 
@@ -347,7 +361,10 @@ class PredRNN_V2(VPModel):
         if self.reverse_input and reversed_pair is None:
             inp_r = torch.flip(inp, dims=[1])
             reversed_pair = (inp_r, inp_r[:, inp.shape[1] - pred_frames:])
-        if self.reverse_input and self.fuse_reversed_pass and reversed_pair[0].shape == inp.shape and reversed_pair[1].shape == targets.shape:
+        acts = fwd_kwargs.get("actions")
+        acts_ok = acts is None or (torch.is_tensor(acts) and (acts.dim() == 3 or acts.numel() == 0))   # (a layout this cannot duplicate: two passes)
+        if self.reverse_input and self.fuse_reversed_pass and acts_ok and reversed_pair[0].shape == inp.shape and \
+                reversed_pair[1].shape == targets.shape:
             # One batch of 2B: rows [0, B) the sequence, rows [B, 2B) its reversal. Exact: the samples of a batch only meet in the two
             # batch MEANS of the loss — MSE (mean over b, t of the per-frame sum, base_measure.py:57) and the decoupling term (mean over
             # b, channel, predrnn_v2.py:197-211, then over steps x layers) — and a mean over two halves of equal size is the average of
