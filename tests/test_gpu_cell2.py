@@ -382,7 +382,8 @@ def test_x_form_bit_identical_to_half_tile(vpx, cell2_switch, shape_switch, expe
 @pytest.mark.parametrize("tag", ["enc2", "fore1_states", "fore3_noinput", "plain_s5", "plain_s3", "plain_s2_noinput", "plain_s14",
                                  "plain_s7_many_tiles"])
 def test_x_form_plain_bf16_bit_identical_to_half_tile(vpx, cell2_switch, experiment_switch, tag):
-    """VPX_PREC_BF16 on cell2_kernel_x<true, *> (copies split between the two wave groups) against cell2_kernel_q<.., 4, true>."""
+    """VPX_PREC_BF16 on cell2_kernel_x<true, *> (both wave splits; the copies are divided between the two wave groups) against
+    cell2_kernel_q<.., 4, true>."""
     cell2_switch(2)
     with torch.no_grad():
         experiment_switch(0)

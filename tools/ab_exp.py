@@ -12,12 +12,14 @@ B, T = int(os.environ.get("BB", 128)), 6
 train = os.environ.get("MODE", "infer") == "train"
 MODES = [int(x) for x in os.environ.get("MODES", "0,1,2,3").split(",")]
 PREC = os.environ.get("PREC", "bf16x3")   # bf16: inference only (the plain form of the fused cell)
+ZERO = os.environ.get("ZERO", "0") == "1"  # all-zero operands: the clock the chip holds without data toggling (MI355X_MICROARCH.md, DVFS give-back 1)
 res, data = {}, {}
 for s in shapes:
     Cin, Ch, H, W = s
-    data[s] = (v.ops.to_channels_last(torch.rand(B, T, Cin, H, W, device=dev)).requires_grad_(train),
-               (torch.randn(4 * Ch, Cin + Ch, 3, 3, device=dev) * 0.03).requires_grad_(train), torch.zeros(4 * Ch, device=dev).requires_grad_(train),
-               [(torch.randn(1, Ch, H, W, device=dev) * 0.1).requires_grad_(train) for _ in range(3)])
+    z = 0.0 if ZERO else 1.0
+    data[s] = (v.ops.to_channels_last(torch.rand(B, T, Cin, H, W, device=dev) * z).requires_grad_(train),
+               (torch.randn(4 * Ch, Cin + Ch, 3, 3, device=dev) * 0.03 * z).requires_grad_(train), torch.zeros(4 * Ch, device=dev).requires_grad_(train),
+               [(torch.randn(1, Ch, H, W, device=dev) * 0.1 * z).requires_grad_(train) for _ in range(3)])
 
 
 def once(s):
@@ -44,7 +46,7 @@ for rnd in range(5):
 for s in shapes:
     Cin, Ch, H, W = s
     fl = 2.0 * 4 * Ch * (Cin + Ch * (T - 1) / T) * 9 * H * W * B * T * (3 if train else 1)
-    line = f"B={B} {PREC} {'train' if train else 'infer'} {s}:"
+    line = f"B={B} {PREC}{' ZERO-DATA' if ZERO else ''} {'train' if train else 'infer'} {s}:"
     base = sorted(res[(s, MODES[0])])
     for mode in MODES:
         r = sorted(res[(s, mode)])

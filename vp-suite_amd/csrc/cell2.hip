@@ -205,7 +205,7 @@ struct Cell2Epi {
                 const float ai = acc[0][r] + bi + wi[u] * cp, af = acc[1][r] + bf + wf[u] * cp;
                 const float ag = acc[2][r] + bg;
                 const float i_ = sigmoid_f(ai), f_ = sigmoid_f(af), g_ = tanh_f(ag);
-                const float cn = f_ * cp + i_ * g_;
+                const float cn = lstm_c(f_, cp, i_, g_);
                 const float ao = acc[3][r] + bo + wo[u] * cn;
                 const float o_ = sigmoid_f(ao);
                 const float hn = o_ * tanh_f(cn);
@@ -305,14 +305,14 @@ struct Cell2Epi {
 #ifdef VPX_ABLATE
                 if (ab & (1 << 26)) {
                     i4[e] = ai[e] + bi[e] + v.wi[k][e] * c0; f4[e] = af[e] + bf[e] + v.wf[k][e] * c0; g4[e] = ag[e] + bg[e];
-                    cn[e] = f4[e] * c0 + i4[e] * g4[e]; o4[e] = ao[e] + bo[e] + v.wo[k][e] * cn[e]; hn[e] = o4[e] * cn[e];
+                    cn[e] = lstm_c(f4[e], c0, i4[e], g4[e]); o4[e] = ao[e] + bo[e] + v.wo[k][e] * cn[e]; hn[e] = o4[e] * cn[e];
                     continue;
                 }
 #endif
                 i4[e] = sigmoid_f(ai[e] + bi[e] + v.wi[k][e] * c0);
                 f4[e] = sigmoid_f(af[e] + bf[e] + v.wf[k][e] * c0);
                 g4[e] = tanh_f(ag[e] + bg[e]);
-                cn[e] = f4[e] * c0 + i4[e] * g4[e];
+                cn[e] = lstm_c(f4[e], c0, i4[e], g4[e]);
                 o4[e] = sigmoid_f(ao[e] + bo[e] + v.wo[k][e] * cn[e]);
                 hn[e] = o4[e] * tanh_f(cn[e]);
             }

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void cell3_kernel(const Cell3Args P) {
         i4[q] = sigmoid_f(z[0][q]);
         f4[q] = sigmoid_f(z[1][q]);
         g4[q] = tanh_f(z[2][q]);
-        cn[q] = f4[q] * cp[q] + i4[q] * g4[q];
+        cn[q] = lstm_c(f4[q], cp[q], i4[q], g4[q]);
         o4[q] = sigmoid_f(z[3][q] + wo[q] * cn[q]);
         hn[q] = o4[q] * tanh_f(cn[q]);
     }

@@ -162,7 +162,7 @@ struct EpiConvLSTM {
                 const float ai = acc[0][r] + bi + wi[u] * cp, af = acc[1][r] + bf + wf[u] * cp;
                 const float ag = acc[2][r] + bg;
                 const float i_ = sigmoid_f(ai), f_ = sigmoid_f(af), g_ = tanh_f(ag);
-                const float cn = f_ * cp + i_ * g_;
+                const float cn = lstm_c(f_, cp, i_, g_);
                 const float ao = acc[3][r] + bo + wo[u] * cn;  // peephole on the NEW cell state (:67)
                 const float o_ = sigmoid_f(ao);
                 const float hn = o_ * tanh_f(cn);

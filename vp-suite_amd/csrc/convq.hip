@@ -993,7 +993,7 @@ __device__ __forceinline__ void c5_finish_clstm(const f32x4 (&acc)[4][NT], const
         for (int q = 0; q < 4; ++q) {
             const float i_ = sigmoid_f(vi[q] + bi[q] + wi[q] * cp[q]), f_ = sigmoid_f(vf[q] + bf[q] + wf[q] * cp[q]);
             const float g_ = tanh_f(vg[q] + bg[q]);
-            cn[q] = f_ * cp[q] + i_ * g_;
+            cn[q] = lstm_c(f_, cp[q], i_, g_);
             const float o_ = sigmoid_f(vo[q] + bo[q] + wo[q] * cn[q]);
             hn[q] = o_ * tanh_f(cn[q]);
         }

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void convlstm_pointwise_kernel(const ConvLSTMS
     const float cp = a.c_in ? a.c_in[e] : 0.0f;
     if (a.wci) { ai += a.wci[pix * Ch + ch] * cp; af += a.wcf[pix * Ch + ch] * cp; }
     const float i_ = sigmoid_f(ai), f_ = sigmoid_f(af), g_ = tanh_f(ag);
-    const float cn = f_ * cp + i_ * g_;
+    const float cn = lstm_c(f_, cp, i_, g_);
     if (a.wco) ao += a.wco[pix * Ch + ch] * cn;
     const float o_ = sigmoid_f(ao);
     a.c_out[e] = cn;

@@ -657,6 +657,11 @@ __device__ __forceinline__ float tanh_f(float v) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * v));
 }
 #endif
+// c_t = f * c_{t-1} + i * g (conv_lstm_hzzone.py:66) with ITS contraction spelled out: one rounded product i * g, then ONE fused multiply-add.
+// Left to the compiler, `f * c + i * g` becomes fma(f, c, i * g) in one kernel and fma(i, g, f * c) in another (its SLP / contraction choice
+// depends on the surrounding code): kernel forms that sum the same products in the same order then still differed in the last bit of c_t
+// (round 6: cell2_kernel_x against cell2_kernel_q, 13 % of the elements of one shape by one ulp). Every fused ConvLSTM epilogue calls this.
+__device__ __forceinline__ float lstm_c(float f, float c_prev, float i, float g) { return __builtin_fmaf(f, c_prev, i * g); }
 
 #endif
 
