@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--extras-seconds", type=float, default=3.0, help="minimum timed region of each `extras` entry")
+    ap.add_argument("--stub", action="store_true",
+                    help="(tests/test_host_logic.py) a CPU stand-in for the model on the gloo backend: the launcher, the rank plumbing, the "
+                         "barrier + MAX-over-ranks timing brackets and the one JSON line of rank 0 run without a GPU; measures nothing")
     return ap.parse_args()
 
 
@@ -177,7 +180,8 @@ class Runner:
         import torch.distributed as dist
         if self.use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
 
     def timed(self, steps, warmup):
         """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize brackets; MAX over ranks."""
@@ -260,6 +264,27 @@ def traffic_from_file(path, lib_sha):
     if doc.get("lib_sha16") is None or doc.get("lib_sha16") != lib_sha:
         return None, f"stale: {rel} was collected on library {doc.get('lib_sha16')}, this run loaded {lib_sha}"
     return round(t["total"]), rel
+
+
+class StubRunner(Runner):
+    """--stub: what a rank does around the model, without the model (CPU tensors, gloo). A step sleeps VPX_BENCH_STUB_MS[rank] milliseconds
+    (comma-separated per rank; default 2) and, in train mode, all-reduces a small bucket — so a test can see that the slowest rank sets
+    the reported time."""
+
+    def __init__(self, spec, dev, rank, world, use_dist):
+        import torch
+        self.spec, self.dev, self.rank, self.world, self.use_dist = spec, dev, rank, world, use_dist
+        self.model = None
+        ms = [float(v) for v in os.environ.get("VPX_BENCH_STUB_MS", "2").split(",")]
+        self.sleep_s = ms[min(rank, len(ms) - 1)] * 1e-3
+        self.bucket = torch.ones(1024)
+        self.semantics = "stub (no model): sleep + gloo all-reduce in train mode"
+
+    def step(self):
+        import torch.distributed as dist
+        time.sleep(self.sleep_s)
+        if self.spec.mode == "train" and self.use_dist:
+            dist.all_reduce(self.bucket)
 
 
 def measured_traffic(spec):
@@ -553,19 +578,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "RANK" in os.environ and world != args.gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus={world}", file=sys.stderr)
-    ndev = torch.cuda.device_count()
-    if local_rank >= ndev:
-        print(f"[bench] rank {rank}: local rank {local_rank} has no GPU ({ndev} visible); one process per GPU is required",
-              file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.stub:
+        dev = torch.device("cpu")
+        args.no_extras = args.no_cpu_baseline = True
+        args.prewarm = 0.0
+    else:
+        ndev = torch.cuda.device_count()
+        if local_rank >= ndev:
+            print(f"[bench] rank {rank}: local rank {local_rank} has no GPU ({ndev} visible); one process per GPU is required",
+                  file=sys.stderr)
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     use_dist = "RANK" in os.environ  # under torch.distributed.run always go through RCCL (also at N=1)
     os.environ.setdefault("NCCL_DEBUG", "WARN")  # keep RCCL's version banner off stdout: rank 0 prints exactly one JSON line
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         world = dist.get_world_size()  # the size RCCL reports
 
     import vp_suite_amd  # noqa: F401
@@ -573,7 +606,7 @@ def main():
     spec = Spec(args.name or "headline", model=args.model, mode=args.mode, batch=args.batch, precision=args.precision, img=args.img,
                 channels=args.channels, context=args.context, pred=args.pred, layers=args.layers,
                 cell=tuple(int(v) for v in args.cell.split(",")) if args.cell else None)
-    runner = Runner(spec, dev, rank, world, use_dist)
+    runner = (StubRunner if args.stub else Runner)(spec, dev, rank, world, use_dist)
     prewarm_steps = runner.prewarm(args.prewarm)
     elapsed, ps = runner.timed(args.steps, args.warmup)
 
@@ -595,7 +628,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": spec.workload(), "mode": spec.mode, "semantics": runner.semantics,
                        "per_gpu_batch": spec.batch, "global_batch": spec.batch * world, "parallelism": f"dp{world}",
-                       "ranks": world, "backend": ("nccl (RCCL)" if use_dist else "single process"),
+                       "ranks": world, "backend": (("gloo (stub)" if args.stub else "nccl (RCCL)") if use_dist else "single process"),
                        "prewarm": {"seconds": args.prewarm, "steps": prewarm_steps,
                                    "what": "untimed steps before the W warmup steps: clock ramp out of the idle power state"}},
             "roofline": roofline(spec, ps),
@@ -603,7 +636,8 @@ def main():
     cpu_model = runner.model if (world == 1 and not args.no_cpu_baseline and spec.model == "convlstm-shi") else None
     if cpu_model is None:
         del runner
-        torch.cuda.empty_cache()
+        if not args.stub:
+            torch.cuda.empty_cache()
 
     extras = []
     if not args.no_extras:

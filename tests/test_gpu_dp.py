@@ -181,3 +181,70 @@ def test_flat_adam_survives_set_to_none_and_keeps_state(vpx):
     assert fresh.steps == 2 and torch.equal(fresh.exp_avg, opt.exp_avg)
     with pytest.raises(ValueError):
         FlatAdam([{"params": list(m.parameters())}], opt.flat_param, opt.flat_grad)
+
+
+@pytest.mark.timeout(600)
+def test_predrnn_deferred_weight_gradients_drive_the_bucket_hooks_under_rccl_world1():
+    """a full predrnn-pp training step with DEFERRED weight gradients (ops.STWeightBank: a cell's five weight
+    gradients reach autograd once per pass, from the bank's identity node, after every step's backward) under the bucketed
+    post-accumulate hooks and real RCCL collectives (world 1, own process). The hooks of a cell's bucket then fire late and together —
+    the launch order must still be strictly descending, every bucket must go out exactly once per step, and the reduced gradient must
+    equal the gradient of the same step without collectives."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    script = r'''
+import json, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch, torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import vp_suite_amd
+from vp_suite_amd.models import MODEL_CLASSES
+from vp_suite_amd.train import DataParallelTrainer
+from golden_util import fill_state_dict_, name_seed, seeded_rand
+kw = dict(img_shape=(1, 32, 32), action_size=0, tensor_value_range=[0.0, 1.0], num_layers=2, num_hidden=[16, 16], cell_precision="bf16x3")
+def build():
+    m = MODEL_CLASSES["predrnn-pp"]("cuda", **kw)
+    fill_state_dict_(m, name_seed("dp.predrnn.banks"))
+    m = m.to("cuda"); m.sampling_eta = 0.5
+    return m
+frames = seeded_rand((4, 7, 1, 32, 32), name_seed("dp.predrnn.banks.frames")).cuda()
+a, b = build(), build()
+tr = DataParallelTrainer(a, lr=1e-3, world_size=1, force_collectives=True)      # RCCL at world 1, bucketed hooks
+ref = DataParallelTrainer(b, lr=1e-3, world_size=1)                               # no collectives
+assert tr.collectives and tr.bucketed and not ref.collectives
+banks = a._weight_banks(8, 6) is not None
+launched, fired = [], []
+orig_launch, orig_ready = tr._launch_bucket, tr._grad_ready
+def launch(i): launched[-1].append(i); return orig_launch(i)
+def ready(p): fired[-1].append(tr._bucket_of[id(p)]); return orig_ready(p)
+tr._launch_bucket = launch
+for h in tr._hooks: h.remove()
+tr._hooks = [p.register_post_accumulate_grad_hook(ready) for p in tr.params]
+diffs = []
+for step in range(2):
+    launched.append([]); fired.append([])
+    torch.manual_seed(100 + step); tr.backward_shard(frames, frames[:, 4:], 3); tr.reduce_gradients()
+    torch.manual_seed(100 + step); ref.backward_shard(frames, frames[:, 4:], 3); ref.reduce_gradients()
+    torch.cuda.synchronize()
+    diffs.append(float((tr.flat_grad - ref.flat_grad).abs().max() / ref.flat_grad.abs().max()))
+    tr.optimizer.step(); ref.optimizer.step()
+print("RESULT " + json.dumps({"banks": banks, "names": [x[3] for x in tr.buckets], "launched": launched, "fired": fired, "diffs": diffs}))
+dist.destroy_process_group()
+''' % (root, root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(bench.free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=500, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert res["banks"], "the deferred-weight-gradient banks were not built for this model"
+    nb = len(res["names"])
+    assert any(n.startswith("cell_list.") for n in res["names"])
+    for step in range(2):
+        assert res["launched"][step] == list(range(nb - 1, -1, -1)), res["launched"][step]   # every bucket once, strictly descending
+        assert sorted(set(res["fired"][step])) == list(range(nb))                            # every bucket's hooks fired (banks included)
+        assert res["diffs"][step] < 1e-6, res["diffs"]                                        # all-reduce over one rank = identity

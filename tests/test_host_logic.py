@@ -435,3 +435,26 @@ def test_bench_drops_traffic_measured_on_another_library(vpx, tmp_path, monkeypa
     # the committed round-5 files predate the field: the headline's traffic must read null until this round's passes are committed
     t, why = bench.measured_traffic(bench.Spec("headline"))
     assert t is None or why.startswith("profiles/r06")
+
+
+def test_bench_two_ranks_end_to_end_on_gloo():
+    """`python bench.py --gpus 2` end to end without a GPU (--stub: CPU stand-in for the model, gloo): the launcher
+    child, RANK / WORLD_SIZE plumbing, EXACTLY one JSON line (rank 0 only), n_gpus / ranks / backend fields, whole-job value, and the
+    MAX-over-ranks timing — rank 1 sleeps 30 ms per step, rank 0 5 ms: the line must report the slow rank's time."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, VPX_BENCH_STUB_MS="5,30", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub", "--steps", "4", "--warmup", "1",
+                        "--mode", "train", "--batch", "8"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["global_batch"] == 16
+    assert out["config"]["backend"] == "gloo (stub)" and out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak"
+    assert out["steps"] == 4 and out["warmup"] == 1
+    assert 30.0 <= out["ms_per_step"] < 80.0, out["ms_per_step"]            # the slowest rank's step, not rank 0's 5 ms
+    assert out["value"] == pytest.approx(2 * 8 * 10 * 4 / (out["ms_per_step"] * 4e-3), rel=1e-3)   # whole-job frames / the bracketed time

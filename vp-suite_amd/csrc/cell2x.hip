@@ -253,6 +253,8 @@ __global__ __launch_bounds__(512, 4) void cell2_kernel_x(const Cell2Plan P, cons
                     else load_B(p + 1, 0);
                     // ---- the MFMAs of column tile lt: three (plain: one) per tile row ----
                     __builtin_amdgcn_s_setprio(1);
+                    // (the order of a product's three MFMAs — which operand two consecutive ones share — measured as nothing on the
+                    //  power-bound loop: profiles/r06_cell2x_ab.txt, "order")
 #pragma unroll
                     for (int m = 0; m < RW; ++m) {
                         f32x4 c = acc[m][lt];
