@@ -321,6 +321,7 @@ def roofline(spec, ps):
         "bound": "mfma", "achieved": round(ach_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(ach_tflops / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
         "algorithmic_bytes_per_launch": round(ps["bytes"] / launches),
+        "wide_read_bytes_per_launch": round(ps.get("wide_read_bytes", 0.0) / launches),
         "kernel": ((f"cell2_kernel_q<Cell2Epi, true, 4> (second-generation fused ConvLSTM cell step: pre-split bf16x3 operands, "
                     f"LDS-DMA staging, v_mfma_f32_16x16x32_bf16, 16x16-pixel tiles at two workgroups per CU; cell3_kernel — 8-channel "
                     f"slices, hoisted input projection — on grids below 256 workgroups), forward" if spec.precision == "bf16x3" else
@@ -469,7 +470,7 @@ def cpu_baseline(model, spec, seconds):
 # (BENCH_r03.json: "parsed": null). The final stdout line is therefore the compact form below (< LINE_BUDGET bytes); the full
 # record (long kernel / workload / semantics / note strings of every entry) goes to bench_extras.json.
 LINE_BUDGET = 6144
-ROOFLINE_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch",
+ROOFLINE_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "wide_read_bytes_per_launch",
                  "launches", "avg_launch_us", "frac_of_bf16_dense_peak")
 
 

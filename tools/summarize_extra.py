@@ -54,7 +54,7 @@ for d, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc
         e = tab[k].setdefault(cname, [0.0, 0])
         e[0] += float(r["Counter_Value"]); e[1] += 1
 out = {"configuration": NAME, "lib_sha16": lib_sha16(), "command": f"tools/prof_extra.sh {TAG} ... (separate --pmc passes over bench.py --steps 3 --warmup 1)", "per_kernel": {}}
-cell_bytes = 0.0
+cell_bytes = cell_fetch_raw = cell_write = 0.0
 for k, cs in tab.items():
     e = {}
     if "FETCH_SIZE" in cs:
@@ -66,12 +66,22 @@ for k, cs in tab.items():
         e["mfma_pipe_busy_frac"] = round(cs["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (cs["GRBM_GUI_ACTIVE"][0] / 8 * 1024), 4)
     if is_cell(k):
         cell_bytes += 2.0 * cs.get("FETCH_SIZE", [0, 1])[0] * 1024 + cs.get("WRITE_SIZE", [0, 1])[0] * 1024
+        cell_fetch_raw += cs.get("FETCH_SIZE", [0, 1])[0] * 1024
+        cell_write += cs.get("WRITE_SIZE", [0, 1])[0] * 1024
     out["per_kernel"][k] = e
 out["per_kernel"] = dict(sorted(out["per_kernel"].items(), key=lambda kv: -(kv[1].get("read_MB_per_launch", 0) + kv[1].get("write_MB_per_launch", 0)) * kv[1].get("launches", 0))[:20])
 if line is not None and cell_bytes > 0:
     per_step_launches = line["roofline"]["launches"] / line["steps"]
-    out["hbm_traffic_bytes_per_launch"] = {"total": cell_bytes / steps_in_pmc / per_step_launches,
-                                           "note": "HBM bytes of the fused-cell kernels per step / cell launches per step as bench.py counts them"}
+    # Two readings of FETCH_SIZE (profiles/r06_fetch_calibration.md): the guide's x2 holds for WIDE reads (16 B per lane, whole 128-byte lines:
+    # tallied at half their size); the fused cell's operand stages arrive by LDS-DMA as 64-byte segments at the pixel pitch and are tallied in
+    # full (calibrated on three shapes of this very kernel). calibrated = raw FETCH + half of the wide reads (the epilogue's c_{t-1}) + WRITE;
+    # x2 = the upper bound the earlier rounds reported.
+    n_l = steps_in_pmc * per_step_launches
+    wide = line["roofline"].get("wide_read_bytes_per_launch")
+    out["hbm_traffic_bytes_per_launch"] = {"x2_upper_bound": cell_bytes / n_l, "raw_lower_bound": (cell_fetch_raw + cell_write) / n_l,
+                                           "note": "HBM bytes of the fused-cell kernels per step / cell launches per step as bench.py counts them; "
+                                                   "total = calibrated (FETCH x1 + wide reads / 2 + WRITE) where bench.py states the wide reads, else the x2 bound"}
+    out["hbm_traffic_bytes_per_launch"]["total"] = ((cell_fetch_raw + cell_write) / n_l + 0.5 * wide) if wide is not None else cell_bytes / n_l
     out["algorithmic_bytes_per_launch"] = line["roofline"].get("algorithmic_bytes_per_launch")
 json.dump(out, open(os.path.join(DST, f"{ROUND}_pmc_{NAME}.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}, indent=1))

@@ -107,12 +107,35 @@ summary = {"kernel": "fused ConvLSTM cell step (cell2_kernel_q<Cell2Epi, true, 4
            "command": "tools/collect_profiles.sh (rocprofv3 --pmc <counter> --kernel-trace, one pass per counter group)",
            "lib_sha16": lib_sha16(),
            "counters": counters}
+def wide_reads(log_name):
+    """roofline.wide_read_bytes_per_launch of the bench line recorded next to the counters (bench.py states it since round 6), or None"""
+    log = os.path.join(SRC, log_name)
+    if os.path.exists(log):
+        for l in open(log):
+            if l.startswith("{"):
+                return json.loads(l).get("roofline", {}).get("wide_read_bytes_per_launch")
+    return None
+
+
+def traffic(cnt, wide):
+    # per CELL STEP (fused launches and K-split trios alike): the unit bench.py's algorithmic_bytes_per_launch uses.
+    # FETCH_SIZE read two ways (profiles/r06_fetch_calibration.md): x2 = the guide's correction for WIDE reads (whole 128-byte lines, 16 B per
+    # lane: tallied at half their size) applied to everything — an upper bound here; the fused cell's operand stages arrive by LDS-DMA as
+    # 64-byte segments at the pixel pitch and are tallied in FULL (calibrated on three shapes of this kernel), only its cell-state reads are
+    # wide: calibrated = raw FETCH + half of the wide reads + WRITE.
+    raw = cnt["FETCH_SIZE"]["mean_per_cell_step"] * 1024
+    wr = cnt["WRITE_SIZE"]["mean_per_cell_step"] * 1024
+    t = {"read_raw": raw, "read_x2": 2.0 * raw, "write": wr, "x2_upper_bound": 2.0 * raw + wr, "raw_lower_bound": raw + wr,
+         "note": "per cell step; write = WRITE_SIZE KiB; total = calibrated read (FETCH x1 + wide reads / 2) + write where the bench line states the "
+                 "wide reads, else the x2 bound"}
+    t["read"] = raw + 0.5 * wide if wide is not None else 2.0 * raw
+    t["total"] = t["read"] + wr
+    return t
+
+
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
-    # per CELL STEP (fused launches and K-split trios alike): the unit bench.py's algorithmic_bytes_per_launch uses
-    rd = 2.0 * counters["FETCH_SIZE"]["mean_per_cell_step"] * 1024
-    wr = counters["WRITE_SIZE"]["mean_per_cell_step"] * 1024
-    summary["hbm_traffic_bytes_per_launch"] = {"read": rd, "write": wr, "total": rd + wr,
-                                               "note": "per cell step; read = 2 * FETCH_SIZE KiB (gfx950 wide-read correction), write = WRITE_SIZE KiB"}
+    summary["hbm_traffic_bytes_per_launch"] = traffic(counters, wide_reads("bench_infer.log"))
+    rd, wr = summary["hbm_traffic_bytes_per_launch"]["read"], summary["hbm_traffic_bytes_per_launch"]["write"]
     rd1 = 2.0 * counters["FETCH_SIZE"]["mean_per_launch"] * 1024
     wr1 = counters["WRITE_SIZE"]["mean_per_launch"] * 1024
     summary["hbm_traffic_bytes_per_fused_launch"] = {"read": rd1, "write": wr1, "total": rd1 + wr1}
@@ -139,14 +162,13 @@ tcount = {}
 for d in ("pmc_train_fetch", "pmc_train_write", "pmc_train_sq"):
     tcount.update(pmc_means(d))
 if "FETCH_SIZE" in tcount and "WRITE_SIZE" in tcount:
-    rd = 2.0 * tcount["FETCH_SIZE"]["mean_per_cell_step"] * 1024
-    wr = tcount["WRITE_SIZE"]["mean_per_cell_step"] * 1024
+    ttr = traffic(tcount, wide_reads("bench_train.log"))
+    rd, wr = ttr["read"], ttr["write"]
     tsum = {"kernel": "forward fused ConvLSTM cell steps inside the TRAINING step (gates and cell states saved for BPTT), "
                       f"`bench.py --mode train --steps 2` (convlstm-shi, {BT})",
             "command": "tools/collect_profiles.sh (pmc_train_* passes)", "lib_sha16": lib_sha16(),
             "counters": tcount,
-            "hbm_traffic_bytes_per_launch": {"read": rd, "write": wr, "total": rd + wr,
-                                             "note": "per forward cell step; read = 2 * FETCH_SIZE KiB, write = WRITE_SIZE KiB"}}
+            "hbm_traffic_bytes_per_launch": ttr}
     table = {}
     for d, cname in (("pmc_train_fetch", "FETCH_SIZE"), ("pmc_train_write", "WRITE_SIZE")):
         for k, cs in per_kernel(d).items():

@@ -18,12 +18,15 @@ class KernelProfile:
     Events are recorded on the stream the kernels are launched on (torch's current stream)."""
 
     def __init__(self):
-        self.records = []  # (start_event, end_event, algorithmic_flops, algorithmic_bytes, cell_launches, tag)
+        self.records = []  # (start_event, end_event, algorithmic_flops, algorithmic_bytes, cell_launches, tag, wide_read_bytes)
 
     def summary(self):
-        ms = sum(s.elapsed_time(e) for s, e, *_ in self.records)
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        # wide_read_bytes: the part of the algorithmic reads that reaches HBM as wide (128-byte, 16 B per lane) coalesced requests — the
+        # epilogue's cell-state reads; the operand stages arrive as 64-byte segments by LDS-DMA. The two are tallied differently by
+        # FETCH_SIZE on gfx950 (profiles/r06_fetch_calibration.md): the PMC summaries need the split to turn the counter into bytes.
         return dict(ms=ms, flops=sum(r[2] for r in self.records), bytes=sum(r[3] for r in self.records),
-                    launches=sum(r[4] for r in self.records))
+                    launches=sum(r[4] for r in self.records), wide_read_bytes=sum(r[6] for r in self.records if len(r) > 6))
 
 
 PROFILE = None  # set to a KernelProfile() to collect
@@ -266,7 +269,8 @@ class _ConvLSTMSeqFn(torch.autograd.Function):
             ev1.record()
             fl, by = convlstm_algorithmic_work(B, T, Cin if x is not None else 0, Ch, H, Wd, kh, kw,
                                                h0 is not None, peep)
-            PROFILE.records.append((ev0, ev1, fl, by, T, "convlstm_fwd"))
+            wide = 4.0 * H * Wd * Ch * B * (T if h0 is not None else T - 1)   # c_{t-1}, read by the fused step's epilogue in full lines
+            PROFILE.records.append((ev0, ev1, fl, by, T, "convlstm_fwd", wide))
         if need_grad:
             ctx.save_for_backward(x, h0c, c0c, Wc, wci, wcf, wco, out, reserve)
             ctx.desc = d
@@ -980,7 +984,7 @@ class _STLSTMStepFn(torch.autograd.Function):
         if PROFILE is not None:
             ev1.record()
             fl, by = stlstm_algorithmic_work(B, Cin, Ch, H, Wd, k)
-            PROFILE.records.append((ev0, ev1, fl, by, 4, "stlstm_fwd"))
+            PROFILE.records.append((ev0, ev1, fl, by, 4, "stlstm_fwd", 0.0))
         if sp_out is not None and bank is None:
             for t, buf in zip(outs[:3], sp_out):
                 _attach_shadow(t, buf)
