@@ -113,7 +113,8 @@ int vpx_set_deterministic(int on);
  *                        8192 c3 with 32-column tiles (c5_kernel<2, 3>) instead of 64-column ones; 16384 the stage glue's data
  *                        gradients on the first-generation kernel where the schedule-driven one (convq) would take them; 32768 the fused
  *                        ConvLSTM step on the eight-wave half tile (cell2_kernel_x: 64-register wave tiles, four waves per SIMD) instead of the
- *                        four-wave one, 65536 its column split instead of the row split */
+ *                        four-wave one, 65536 its column split instead of the row split; 1 << 27 the ST-LSTM step's conv_last (1x1) on the fp32 c_new / m_new (converted in the
+ *                        kernel) instead of on the split copies its gate stage leaves */
 #define VPX_OPT_EXPERIMENT 4
 /*   VPX_OPT_DRY_RUN      1 = every entry point does all of its host-side work (argument checks, kernel selection, workspace carving
  *                        and the bounds checks of everything it would write into the workspace) but issues no HIP call: needs no GPU

@@ -366,7 +366,8 @@ def test_stlstm_second_generation_backward_matches_first_generation(vpx, B, Cin,
         res = {}
         # 0 = the product's choice on these small grids: the K-split job forms of c5 (partial sums + pointwise stages); 2048 = the
         # first generation there
-        for bits in (FORCE | 64, FORCE | 128, FORCE | 256, FORCE | 64 | 256, FORCE | 512, 0, 2048, 2048 | 64):
+        # (round 6) 1 << 27: conv_last reads the fp32 c_new / m_new and converts in the kernel, instead of the split copies the gate stage leaves
+        for bits in (FORCE | 64, FORCE | 128, FORCE | 256, FORCE | 64 | 256, FORCE | 512, FORCE | (1 << 27), 0, 1 << 27, 2048, 2048 | 64):
             prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, bits)
             try:
                 res[bits] = run()
@@ -381,6 +382,8 @@ def test_stlstm_second_generation_backward_matches_first_generation(vpx, B, Cin,
             assert _relmax(a, b) < 5e-6, (bits, n, _relmax(a, b))
     for a, b in zip(new, again):
         assert torch.equal(a, b)   # no atomics in either kernel or in the slice reduction: bit-reproducible
+    # the 1x1 layer on split sources multiplies the very same (hi, lo) pairs the in-kernel conversion makes: bit-identical h_new
+    assert torch.equal(new[0], res[FORCE | (1 << 27)][0]) and torch.equal(res[0][0], res[1 << 27][0])
 
 
 @pytest.mark.parametrize("B", [3, 100])

@@ -16,7 +16,12 @@
 
 namespace vpx {
 
-template <int NTW, int KS>   // column tiles (of 16) per wave, K = 32 steps
+// XSPLIT (round 6): the sources are already in the split operand format (the ST-LSTM gate stage writes c_new / m_new that way next to
+// the fp32 tensors). The 32 bytes a lane loads per step — eight channels of a pixel — sit at the SAME address in both layouts (8 fp32 |
+// 8 hi bf16 + 8 lo bf16), so the requests are unchanged and the two halves ARE the step's hi / lo fragments: the 16 fp32 -> (hi, lo)
+// conversions per lane and step (~100 vector instructions against 6 MFMAs per column tile: the kernel was VALU-bound, 44-48 us for
+// 50 MB) disappear.
+template <int NTW, int KS, bool XSPLIT = false>   // column tiles (of 16) per wave, K = 32 steps
 __global__ __launch_bounds__(256, 2) void c1_kernel(const C1Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,11 +75,17 @@ __global__ __launch_bounds__(256, 2) void c1_kernel(const C1Args a) {
         for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            unsigned h[8], l[8];
+            bf16x8 ah, al;
+            if constexpr (XSPLIT) {
+                ah = __builtin_bit_cast(bf16x8, raw[ks][0]);
+                al = __builtin_bit_cast(bf16x8, raw[ks][1]);
+            } else {
+                unsigned h[8], l[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) c2_split(i < 4 ? raw[ks][0][i] : raw[ks][1][i - 4], h[i], l[i]);
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, uint4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)});
-            const bf16x8 al = __builtin_bit_cast(bf16x8, uint4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)});
+                for (int i = 0; i < 8; ++i) c2_split(i < 4 ? raw[ks][0][i] : raw[ks][1][i - 4], h[i], l[i]);
+                ah = __builtin_bit_cast(bf16x8, uint4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)});
+                al = __builtin_bit_cast(bf16x8, uint4{l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)});
+            }
             request(tile + gridDim.x, ks);
             // the WEIGHTS are the MFMA's row operand: D[row = column 4 * kg + r of the tile][column = pixel r16] — a lane ends up with
             // four consecutive output channels of one pixel (one 16-byte store instead of four 4-byte ones)
@@ -121,6 +132,12 @@ hipError_t launch_c1(const C1Args& a, hipStream_t s) {
     const long long ntile = (a.npix + 15) / 16;
     const long long gmax = dev_switch("VPX_C1_GRID", 512);
     const unsigned grid = (unsigned)(ntile < gmax ? ntile : gmax);   // two workgroups per CU, one round: every workgroup reads the weights once
+    if (a.x_split) {
+        if (a.Co == 128 && K == 256) VPX_LAUNCH((c1_kernel<2, 8, true>), dim3(grid), dim3(256), 0, s, a);
+        else if (a.Co == 256 && K == 128) VPX_LAUNCH((c1_kernel<4, 4, true>), dim3(grid), dim3(256), 0, s, a);
+        else VPX_LAUNCH((c1_kernel<2, 4, true>), dim3(grid), dim3(256), 0, s, a);
+        return vpx_hip_last_error();
+    }
     if (a.Co == 128 && K == 256) VPX_LAUNCH((c1_kernel<2, 8>), dim3(grid), dim3(256), 0, s, a);
     else if (a.Co == 256 && K == 128) VPX_LAUNCH((c1_kernel<4, 4>), dim3(grid), dim3(256), 0, s, a);
     else VPX_LAUNCH((c1_kernel<2, 4>), dim3(grid), dim3(256), 0, s, a);

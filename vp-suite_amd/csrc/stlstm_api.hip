@@ -447,6 +447,11 @@ int vpx_stlstm_step_fwd_ex(const vpx_stlstm_desc* d, const float* x, const float
     c1.npix = (long long)B * (long long)HW;
     c1.w = Wlast; c1.w_sn = 2 * Ch; c1.w_sc = 1;
     c1.y[0] = lc; c1.yld[0] = Ch; c1.ysplit = Ch; c1.Co = Ch;
+    if ((L.c5 || L.c5k) && cn_sp && mn_sp && !(g_experiment & (1 << 27))) {
+        // the gate stage left c_new / m_new in the operand format as well: read THOSE (no fp32 -> (hi, lo) conversion in the kernel; round 6).
+        // VPX_OPT_EXPERIMENT bit 27 keeps the fp32 sources (tests, A/B)
+        c1.x[0] = reinterpret_cast<const float*>(cn_sp); c1.x[1] = reinterpret_cast<const float*>(mn_sp); c1.x_split = 1;
+    }
     if (c1_applicable(c1, d->precision)) {
         VPX_CHECK_HIP(launch_c1(c1, stream));   // streaming form (conv1.hip): no weight pack, no LDS
     } else {

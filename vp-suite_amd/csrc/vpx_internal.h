@@ -520,6 +520,7 @@ struct C1Args {
     const float* w; long long w_sn, w_sc;   // weight element (column n, channel c) at w[n * w_sn + c * w_sc]
     float* y[2]; int yld[2], ysplit;        // columns [0, ysplit) go to y[0], the rest to y[1] (pixel pitches yld)
     int Co, accumulate;
+    int x_split, _pad;                      // 1: the sources are in the split-bf16 operand format (same pixel pitch in bytes: xld * 4) — read as MFMA fragments, no conversion
 };
 bool c1_applicable(const C1Args& a, int prec);   // (Co, K) in {(128, 256), (256, 128), (128, 128)}, aligned operands, bf16x3
 hipError_t launch_c1(const C1Args& a, hipStream_t s);
