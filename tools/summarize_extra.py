@@ -54,7 +54,7 @@ for d, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc
         e = tab[k].setdefault(cname, [0.0, 0])
         e[0] += float(r["Counter_Value"]); e[1] += 1
 out = {"configuration": NAME, "lib_sha16": lib_sha16(), "command": f"tools/prof_extra.sh {TAG} ... (separate --pmc passes over bench.py --steps 3 --warmup 1)", "per_kernel": {}}
-cell_bytes = cell_fetch_raw = cell_write = 0.0
+cell_bytes = cell_fetch_raw = cell2_fetch_raw = cell_write = 0.0
 for k, cs in tab.items():
     e = {}
     if "FETCH_SIZE" in cs:
@@ -67,6 +67,8 @@ for k, cs in tab.items():
     if is_cell(k):
         cell_bytes += 2.0 * cs.get("FETCH_SIZE", [0, 1])[0] * 1024 + cs.get("WRITE_SIZE", [0, 1])[0] * 1024
         cell_fetch_raw += cs.get("FETCH_SIZE", [0, 1])[0] * 1024
+        if "cell2_kernel_q<vpx::Cell2Epi" in k or "cell2_kernel_x" in k:
+            cell2_fetch_raw += cs.get("FETCH_SIZE", [0, 1])[0] * 1024
         cell_write += cs.get("WRITE_SIZE", [0, 1])[0] * 1024
     out["per_kernel"][k] = e
 out["per_kernel"] = dict(sorted(out["per_kernel"].items(), key=lambda kv: -(kv[1].get("read_MB_per_launch", 0) + kv[1].get("write_MB_per_launch", 0)) * kv[1].get("launches", 0))[:20])
@@ -80,8 +82,14 @@ if line is not None and cell_bytes > 0:
     wide = line["roofline"].get("wide_read_bytes_per_launch")
     out["hbm_traffic_bytes_per_launch"] = {"x2_upper_bound": cell_bytes / n_l, "raw_lower_bound": (cell_fetch_raw + cell_write) / n_l,
                                            "note": "HBM bytes of the fused-cell kernels per step / cell launches per step as bench.py counts them; "
-                                                   "total = calibrated (FETCH x1 + wide reads / 2 + WRITE) where bench.py states the wide reads, else the x2 bound"}
-    out["hbm_traffic_bytes_per_launch"]["total"] = ((cell_fetch_raw + cell_write) / n_l + 0.5 * wide) if wide is not None else cell_bytes / n_l
+                                                   "total = calibrated (FETCH x1 + wide reads / 2 + WRITE) for the ConvLSTM entries (bench.py states their wide reads), else the x2 bound"}
+    # (calibrated for the fused ConvLSTM cell only — the entries whose bench line states wide reads > 0; the ST-LSTM kernels' 32-byte stage
+    #  pieces are NOT calibrated: those entries keep the x2 bound as their total)
+    share = cell2_fetch_raw / cell_fetch_raw if cell_fetch_raw > 0 else 0.0
+    cal = bool(wide) and share >= 0.9   # ... and only where cell2_kernel_q / _x — the kernel the calibration was done on — makes >= 90 % of the cell reads
+    out["hbm_traffic_bytes_per_launch"]["total"] = ((cell_fetch_raw + cell_write) / n_l + 0.5 * wide) if cal else cell_bytes / n_l
+    out["hbm_traffic_bytes_per_launch"]["rule"] = "calibrated" if cal else "x2"
+    out["hbm_traffic_bytes_per_launch"]["cell2_share_of_cell_reads"] = round(share, 3)
     out["algorithmic_bytes_per_launch"] = line["roofline"].get("algorithmic_bytes_per_launch")
 json.dump(out, open(os.path.join(DST, f"{ROUND}_pmc_{NAME}.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}, indent=1))

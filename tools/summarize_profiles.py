@@ -128,7 +128,8 @@ def traffic(cnt, wide):
     t = {"read_raw": raw, "read_x2": 2.0 * raw, "write": wr, "x2_upper_bound": 2.0 * raw + wr, "raw_lower_bound": raw + wr,
          "note": "per cell step; write = WRITE_SIZE KiB; total = calibrated read (FETCH x1 + wide reads / 2) + write where the bench line states the "
                  "wide reads, else the x2 bound"}
-    t["read"] = raw + 0.5 * wide if wide is not None else 2.0 * raw
+    t["read"] = raw + 0.5 * wide if wide else 2.0 * raw
+    t["rule"] = "calibrated" if wide else "x2"
     t["total"] = t["read"] + wr
     return t
 
