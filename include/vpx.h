@@ -114,7 +114,8 @@ int vpx_set_deterministic(int on);
  *                        gradients on the first-generation kernel where the schedule-driven one (convq) would take them; 32768 the fused
  *                        ConvLSTM step on the eight-wave half tile (cell2_kernel_x: 64-register wave tiles, four waves per SIMD) instead of the
  *                        four-wave one, 65536 its column split instead of the row split; 1 << 27 the ST-LSTM step's conv_last (1x1) on the fp32 c_new / m_new (converted in the
- *                        kernel) instead of on the split copies its gate stage leaves */
+ *                        kernel) instead of on the split copies its gate stage leaves; 1 << 28 3x3 layers with 16 output channels on the
+ *                        first-generation kernel instead of the resident-weights one (csrc/conv16.hip) */
 #define VPX_OPT_EXPERIMENT 4
 /*   VPX_OPT_DRY_RUN      1 = every entry point does all of its host-side work (argument checks, kernel selection, workspace carving
  *                        and the bounds checks of everything it would write into the workspace) but issues no HIP call: needs no GPU
@@ -278,7 +279,8 @@ int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float*
  * x_tstride bytes, x_bstride = 0: dense, x_nT <= 1: plain batch), on the schedule-driven K = 32 kernel (csrc/convq.hip): bf16x3,
  * Ci % 16 == 0, stride 1 or 2, taps within one pixel of the (sub-)image grid (3x3 pad 1, 4x4 stride 2 pad 1, plain or transposed)
  * — vpx_conv2d_ex_takes_split says whether a descriptor qualifies (0 no; 1 yes; 2 yes, and on the schedule-driven K = 32 kernel,
- *   which is worth a vpx_split_convert of an fp32 input for stride-2 transposed layers). y (fp32) and y_split may each be NULL, not both.
+ *   which is worth a vpx_split_convert of an fp32 input for stride-2 transposed layers — or, for 3x3 stride-1 pad-1 layers with 16
+ *   output channels and 16..64 input channels, on the resident-weights kernel of csrc/conv16.hip). y (fp32) and y_split may each be NULL, not both.
  * weights_packed: the workspace still holds this layer's packed weights (same values, same descriptor) — the pack launch is skipped
  *   (both kernels; on the first-generation kernel for the single-launch forms: a stride-2 transposed layer's four phase launches
  *   share the space and pack every time). */

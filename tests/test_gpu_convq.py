@@ -26,6 +26,11 @@ CASES = {  # tag: (N, Ci, Co, H, W, k, stride, pad, transposed, slope)
     "ragged_s2k3": (2, 32, 48, 37, 21, 3, 2, 1, False, 0.2),
     "ragged_t2k4": (1, 16, 40, 19, 9, 4, 2, 1, True, 0.0),
     "one_stage_k3": (1, 16, 32, 32, 16, 3, 1, 1, False, 0.0),
+    # 16 output channels: conv16.hip (weights resident in registers, whole K of a tile in LDS); > 256 tiles = several per workgroup
+    "c16_plain_ci32_ragged": (2, 32, 16, 37, 21, 3, 1, 1, False, 0.2),
+    "c16_t_ci16": (1, 16, 16, 20, 40, 3, 1, 1, True, 0.0),
+    "c16_plain_ci48_many_tiles": (70, 48, 16, 24, 24, 3, 1, 1, False, 0.2),
+    "c16_t_ci64_many_tiles": (40, 64, 16, 30, 34, 3, 1, 1, True, 0.2),
 }
 
 
@@ -79,6 +84,27 @@ def test_half_tile_and_full_tile_agree_bit_for_bit(vpx, tag):
     finally:
         L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, prev)
     assert torch.equal(y4, y8)
+
+
+@pytest.mark.parametrize("tag", ["deconv3_t1k3_co16", "c16_plain_ci32_ragged", "c16_plain_ci48_many_tiles", "c16_t_ci64_many_tiles"])
+def test_sixteen_column_kernel_vs_first_generation(vpx, tag):
+    """conv16.hip against the first-generation kernel on the same split input (VPX_OPT_EXPERIMENT bit 28): the same bf16x3 products,
+    summed in a different order — equal to fp32 rounding of the sums."""
+    N, Ci, Co, H, W, k, s, p, tr, slope = CASES[tag]
+    x = seeded_rand((N, Ci, H, W), name_seed(f"convq.{tag}.x")).cuda() - 0.3
+    wshape = (Ci, Co, k, k) if tr else (Co, Ci, k, k)
+    w = (seeded_randn(wshape, name_seed(f"convq.{tag}.w"), 1.0 / np.sqrt(Ci * k * k))).cuda()
+    b = seeded_randn((Co,), name_seed(f"convq.{tag}.b"), 0.1).cuda()
+    xbuf, _ = vpx.ops.split_convert(x)
+    L = vpx._lib.lib()
+    prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, 0)
+    try:
+        y16, _, _ = vpx.ops.conv2d_ex_from_split(xbuf, (N, Ci, H, W), w, b, s, p, tr, slope, "bf16x3")
+        L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, 1 << 28)
+        y1, _, _ = vpx.ops.conv2d_ex_from_split(xbuf, (N, Ci, H, W), w, b, s, p, tr, slope, "bf16x3")
+    finally:
+        L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, prev)
+    assert _relmax(y16, y1) < 2e-6, tag
 
 
 def test_split_convert_entry_point_matches_the_torch_restatement(vpx):

@@ -322,7 +322,8 @@ int vpx_conv2d_ex_fwd_split(const vpx_conv_desc* d, const float* x, const float*
 // convq on half tiles): layers with >= 64 output channels — stride-2 convolutions 64 -> 64 at 64x64 0.72 -> 0.60 and 96 -> 96 at
 // 32x32 0.32 -> 0.25, stride-2 transposed 4x4 96 -> 96 at 16x16 0.48 -> 0.38 and at 32x32 1.79 -> 1.47 (at 40 frames 0.12 -> 0.04 /
 // 0.15 -> 0.06: the phase form is one launch) — but plain convolutions only on grids of >= 256 workgroups (40 frames: 0.045 -> 0.049).
-// 64 -> 16 3x3 stays on the first-generation kernel (0.92 vs 1.22). VPX_CONVQ=0 / 2: never / wherever it applies.
+// 3x3 stride-1 layers with 16 output channels (64 -> 16: 0.83 first generation, 1.22 convq) have their own kernel (conv16.hip: 0.41).
+// VPX_CONVQ=0 / 2: convq never / wherever it applies.
 static bool exq_preferred(const vpx_conv_desc* d, const ExGeo& g, ConvQProblem& pr) {
     static int mode = -1;
     if (mode < 0) mode = dev_switch("VPX_CONVQ", 1);
@@ -341,7 +342,7 @@ int vpx_conv2d_ex_takes_split(const vpx_conv_desc* d) {
     ExGeo g;
     static thread_local ConvQProblem pr;
     if (ex_check(d, g) != VPX_OK) return 0;
-    if (exq_preferred(d, g, pr)) return 2;
+    if (exq_preferred(d, g, pr) || c16_applicable(d)) return 2;
     return ex_split_gen1_ok(d) ? 1 : 0;
 }
 
@@ -352,6 +353,7 @@ size_t vpx_conv2d_ex_split_workspace_bytes(const vpx_conv_desc* d) {
     size_t b = 0;
     if (exq_preferred(d, g, pr)) b = align256(convq_wpk_bytes(pr)) + 512;
     if (ex_split_gen1_ok(d)) { const size_t b1 = align256(ex_wpk_floats(d) * 4) + 512; if (b1 > b) b = b1; }
+    if (c16_applicable(d)) { const size_t b1 = align256(c16_wpk_bytes(d)) + 512; if (b1 > b) b = b1; }
     return b;
 }
 
@@ -372,6 +374,9 @@ int vpx_conv2d_ex_fwd_from_split(const vpx_conv_desc* d, const void* x_split, lo
     const long long dense = (long long)d->H * d->W * d->Ci * 4;
     if (x_bstride == 0) x_bstride = dense;
     static thread_local ConvQProblem pr;
+    if (c16_applicable(d))   // 16 output channels: the whole K of a tile resident (conv16.hip)
+        return c16_forward(d, reinterpret_cast<const char*>(x_split), x_bstride, x_tstride, x_nT, w, bias, y, reinterpret_cast<char*>(y_split),
+                           wpk, weights_packed != 0, (hipStream_t)stream_);
     if (exq_preferred(d, g, pr))
         return ex_forward_q(d, g, reinterpret_cast<const char*>(x_split), x_bstride, x_tstride, x_nT, w, bias, y, reinterpret_cast<char*>(y_split),
                             wpk, weights_packed != 0, (hipStream_t)stream_);

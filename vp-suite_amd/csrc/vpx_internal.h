@@ -231,6 +231,11 @@ hipError_t launch_cell2(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void*
 // (development state: the four-wave half tile stays the default until the A/B says otherwise)
 hipError_t launch_cell2x(const Cell2Plan& plan, const ConvLSTMStepArgs& ea, void* h_sp, long long h_sp_bstride, hipStream_t s);
 static inline bool cell2x_selected() { return (g_experiment & 32768) != 0; }
+// c16 (conv16.hip): 3x3 stride-1 'same' (transposed or not) layers with 16 output channels on split input, weights resident in registers
+bool c16_applicable(const ::vpx_conv_desc* d);
+size_t c16_wpk_bytes(const ::vpx_conv_desc* d);
+int c16_forward(const ::vpx_conv_desc* d, const char* x_split, long long x_bstride, long long x_tstride, int x_nT, const float* w,
+                const float* bias, float* y, char* y_split, char* wpk, bool packed, hipStream_t s);
 // conv2: the same kernel with a plain epilogue — 3x3 'same' convolution of one split-format source with C channels (C % 16 == 0)
 // into Co fp32 NHWC output channels, [0, split) -> out0, [split, Co) -> out1. N tiling: 128-column tiles, balanced.
 static inline int conv2_tiles(int Co) { return ((Co + 31) / 32 + 3) / 4; }
