@@ -339,21 +339,36 @@ int vpx_trajgru_seq_bwd(const vpx_trajgru_desc* d, const float* x, const float* 
                         const void* reserve, size_t reserve_bytes, const float* dout, const float* dhT, float* dx, float* dh0,
                         float* const* dparams, void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- action-conditional ST-LSTM cell, pointwise half (vp_suite/model_blocks/predrnn.py:139-169), NHWC ---------------- *
- * gates: from the conv outputs xc [npix,7Ch] (i,f,g,i',f',g',o), hc [npix,4Ch], ac [npix,4Ch] (multiplies hc; NULL = plain
- *        ST-LSTM arithmetic), mc [npix,3Ch] and the states c, m: c_new, m_new, delta_c, delta_m, o_pre = o_x + o_h*o_a,
- *        mem = (c_new | m_new) [npix,2Ch]; save [npix,6Ch] (post-activation gates) feeds the backward, which takes the
- *        gradients of c_new / m_new / delta_c / delta_m / o_pre / mem (each may be NULL = zero).
- * out:   h_new = sigmoid(o_pre + oc) * tanh(lc); backward: d_o (gradient of the sigmoid argument) and d_lc. */
-int vpx_acst_gates_fwd(const float* xc, const float* hc, const float* ac, const float* mc, const float* c, const float* m,
-                       float* c_new, float* m_new, float* delta_c, float* delta_m, float* o_pre, float* mem, float* save,
-                       long long npix, int Ch, float forget_bias, void* stream);
-int vpx_acst_gates_bwd(const float* hc, const float* ac, const float* c, const float* m, const float* save, const float* d_cn,
-                       const float* d_mn, const float* d_dc, const float* d_dm, const float* d_opre, const float* d_mem, float* dxc,
-                       float* dhc, float* dac, float* dmc, float* dc, float* dm, long long npix, int Ch, void* stream);
-int vpx_st_out_fwd(const float* o_pre, const float* oc, const float* lc, float* h_new, float* o_save, float* tl_save, long long n,
-                   void* stream);
-int vpx_st_out_bwd(const float* dh, const float* o, const float* tl, float* d_o, float* d_lc, long long n, void* stream);
+/* ---- action-conditional ST-LSTM cell, one step (vp_suite/model_blocks/predrnn.py:86-169), NHWC ------------------------------ *
+ * replaces ActionConditionalSpatioTemporalLSTMCell.forward (:139-169) and its autograd: x_concat = conv_x(x), h_concat = conv_h(h),
+ * a_concat = conv_a(a), m_concat = conv_m(m) — Conv2d WITH bias, each followed by LayerNorm([C,H,W]) when layer_norm (:102-136) —
+ * h_concat * a_concat (:144), both gate groups and the state updates (:146-164), conv_o / conv_last on mem = (c_new | m_new), the
+ * output gate (:165-167). Tensors are [B][H*W][C] (x: Cin channels; h, c, m, a and all outputs: Ch).
+ *   params / dparams: 12 pointers, (conv_x, conv_h, conv_a, conv_m, conv_o, conv_last) x (weight OIHW, bias); conv_x [7Ch,Cin,k,k],
+ *        conv_h / conv_a [4Ch,Ch,k,k], conv_m [3Ch,Ch,k,k], conv_o [Ch,2Ch,k,k], conv_last [Ch,2Ch,1,1]. A NULL dparams entry is skipped
+ *        (frozen parameter); gradients are OVERWRITTEN.
+ *   ln / dln: 10 pointers, (x, h, a, m, o) x (weight, bias) in the reference's [C,H,W] layout; NULL unless layer_norm (eps = 1e-5).
+ *   backward: dh_new is required; dc_new / dm_new / ddc / ddm (gradients of c_new, m_new, delta_c, delta_m) may be NULL = zero;
+ *        dx / dh / dc / dm / da may be NULL (not wanted).
+ *   reserve: vpx_acstlstm_reserve_bytes (0 without VPX_FLAG_SAVE_FOR_BWD), written by the forward, read by the backward.
+ * First-generation convolution kernels in every precision; k odd, stride 1. */
+typedef struct vpx_acstlstm_desc {
+    int32_t B, Cin, Ch, H, W;
+    int32_t k;             /* kernel size of conv_x / conv_h / conv_a / conv_m / conv_o ('same', stride 1) */
+    int32_t layer_norm;    /* LayerNorm after those five convolutions */
+    int32_t precision;     /* VPX_PREC_* of the six convolutions */
+    int32_t flags;         /* VPX_FLAG_SAVE_FOR_BWD */
+    float forget_bias;     /* added to both forget gates' pre-activations (the reference: 1.0) */
+} vpx_acstlstm_desc;
+size_t vpx_acstlstm_workspace_bytes(const vpx_acstlstm_desc* d);
+size_t vpx_acstlstm_reserve_bytes(const vpx_acstlstm_desc* d);
+int vpx_acstlstm_step_fwd(const vpx_acstlstm_desc* d, const float* x, const float* h, const float* c, const float* m, const float* a,
+                          const float* const* params, const float* const* ln, float* h_new, float* c_new, float* m_new, float* delta_c,
+                          float* delta_m, void* reserve, size_t reserve_bytes, void* workspace, size_t workspace_bytes, void* stream);
+int vpx_acstlstm_step_bwd(const vpx_acstlstm_desc* d, const float* x, const float* h, const float* c, const float* m, const float* a,
+                          const float* const* params, const float* const* ln, const void* reserve, size_t reserve_bytes, const float* dh_new,
+                          const float* dc_new, const float* dm_new, const float* ddc, const float* ddm, float* dx, float* dh, float* dc, float* dm,
+                          float* da, float* const* dparams, float* const* dln, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- LayerNorm([C,H,W]) per sample on NHWC tensors (predrnn.py:27-40, 105-135; eps = 1e-5) ---------------------------------- *
  * x, y, xhat: [B][n = H*W*C]; gamma, beta (and dgamma, dbeta): [H*W][C], i.e. the reference's [C,H,W] parameters channels-last;

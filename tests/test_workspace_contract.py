@@ -278,6 +278,39 @@ def test_trajgru_sequence(L):
     assert L.vpx_trajgru_workspace_bytes(ctypes.byref(d)) == 0
 
 
+def test_acstlstm_step(L):
+    """vpx_acstlstm_step_fwd / _bwd (action-conditional ST-LSTM cell, predrnn.py:86-169): with / without LayerNorm, every operand mode, odd
+    map sizes, frozen parameters and unwanted data gradients."""
+    from vp_suite_amd._lib import ACSTLSTMDesc
+    shapes = [(4, 8, 16, 16, 3), (16, 32, 32, 32, 5), (3, 6, 9, 11, 3), (64, 64, 16, 16, 5), (1, 4, 7, 5, 1), (12, 20, 33, 17, 7)]
+    for det in (0, 1):
+        L.vpx_set_deterministic(det)
+        for (Cin, Ch, H, W, k), B, ln, prec, save in itertools.product(shapes, (1, 2, 8), (0, 1), (0, 1, 2), (0, 1)):
+            d = ACSTLSTMDesc(B, Cin, Ch, H, W, k, ln, prec, _lib.FLAG_SAVE_FOR_BWD if save else 0, 1.0)
+            nb, rs = L.vpx_acstlstm_workspace_bytes(ctypes.byref(d)), L.vpx_acstlstm_reserve_bytes(ctypes.byref(d))
+            assert nb > 0 and (rs > 0) == bool(save)
+            params = (ctypes.c_void_p * 12)(*[0x200000000000 + i * (1 << 32) for i in range(12)])
+            lnp = (ctypes.c_void_p * 10)(*[0x280000000000 + i * (1 << 32) for i in range(10)]) if ln else None
+            tag = f"acstlstm {(Cin, Ch, H, W, k)} B={B} ln={ln} prec={prec} save={save} det={det}"
+            for base in (WS_BASE, WS_BASE_ODD):
+                rc = L.vpx_acstlstm_step_fwd(ctypes.byref(d), *[_fake(i) for i in range(1, 6)], params, lnp, *[_fake(i) for i in range(6, 11)], _fake(11), rs,
+                                             ctypes.c_void_p(base), nb, None)
+                _ok(L, rc, tag + " fwd", allow_unsupported=False)
+            if save:
+                for frozen in (False, True):
+                    dparams = (ctypes.c_void_p * 12)(*[None if (frozen and i % 3 == 0) else 0x300000000000 + i * (1 << 32) for i in range(12)])
+                    dln = (ctypes.c_void_p * 10)(*[None if (frozen and i % 4 == 1) else 0x380000000000 + i * (1 << 32) for i in range(10)]) if ln else None
+                    douts = [_fake(12)] + [None if frozen else _fake(13 + i) for i in range(4)]
+                    dins = [None if (frozen and i in (0, 3)) else _fake(20 + i) for i in range(5)]
+                    rc = L.vpx_acstlstm_step_bwd(ctypes.byref(d), *[_fake(i) for i in range(1, 6)], params, lnp, _fake(11), rs, *douts, *dins, dparams, dln,
+                                                 ctypes.c_void_p(WS_BASE_ODD), nb, None)
+                    _ok(L, rc, tag + f" bwd frozen={frozen}", allow_unsupported=False)
+                assert L.vpx_acstlstm_step_bwd(ctypes.byref(d), *[_fake(i) for i in range(1, 6)], params, lnp, _fake(11), rs, *douts, *dins, dparams, dln,
+                                               ctypes.c_void_p(WS_BASE), nb - 4096, None) == E_WS
+    d = ACSTLSTMDesc(2, 4, 8, 8, 8, 4, 0, 0, 0, 1.0)   # even kernel size
+    assert L.vpx_acstlstm_workspace_bytes(ctypes.byref(d)) == 0
+
+
 def test_small_workspaces(L):
     """LayerNorm, MSE."""
     for B in (1, 2, 8, 128):

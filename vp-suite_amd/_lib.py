@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "vpx_conv2d_ex_takes_split", "vpx_split_convert", "vpx_conv2d_ex_split_workspace_bytes", "vpx_conv2d_ex_fwd_from_split",
     "vpx_conv2d_ex_bwd_workspace_bytes", "vpx_conv2d_ex_bwd",
     "vpx_conv2d_nhwc_fwd_ex",
-    "vpx_acst_gates_fwd", "vpx_acst_gates_bwd", "vpx_st_out_fwd", "vpx_st_out_bwd",
+    "vpx_acstlstm_workspace_bytes", "vpx_acstlstm_reserve_bytes", "vpx_acstlstm_step_fwd", "vpx_acstlstm_step_bwd",
     "vpx_trajgru_workspace_bytes", "vpx_trajgru_reserve_bytes", "vpx_trajgru_seq_fwd", "vpx_trajgru_seq_bwd",
     "vpx_nchw_to_nhwc", "vpx_nhwc_to_nchw",
     "vpx_layernorm_workspace_bytes", "vpx_layernorm_fwd", "vpx_layernorm_bwd",
@@ -60,6 +60,10 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "W", "Ci", "Co", "kh", "kw", "stride", "pad", "transposed")] + \
                [("leaky_slope", ctypes.c_float), ("precision", ctypes.c_int32), ("out_pad_h", ctypes.c_int32),
                 ("out_pad_w", ctypes.c_int32)]
+
+
+class ACSTLSTMDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("B", "Cin", "Ch", "H", "W", "k", "layer_norm", "precision", "flags")] + [("forget_bias", ctypes.c_float)]
 
 
 class TrajGRUDesc(ctypes.Structure):
@@ -163,14 +167,13 @@ def lib():
         ll, fl, ci = ctypes.c_longlong, ctypes.c_float, ctypes.c_int
         L.vpx_conv2d_nhwc_fwd_ex.restype = ci
         L.vpx_conv2d_nhwc_fwd_ex.argtypes = [vp] * 4 + [ci] * 9 + [fl, vp, sz, vp]
-        L.vpx_acst_gates_fwd.restype = ci
-        L.vpx_acst_gates_fwd.argtypes = [vp] * 13 + [ll, ci, fl, vp]
-        L.vpx_acst_gates_bwd.restype = ci
-        L.vpx_acst_gates_bwd.argtypes = [vp] * 17 + [ll, ci, vp]
-        L.vpx_st_out_fwd.restype = ci
-        L.vpx_st_out_fwd.argtypes = [vp] * 6 + [ll, vp]
-        L.vpx_st_out_bwd.restype = ci
-        L.vpx_st_out_bwd.argtypes = [vp] * 5 + [ll, vp]
+        for name in ("vpx_acstlstm_workspace_bytes", "vpx_acstlstm_reserve_bytes"):
+            getattr(L, name).restype = sz
+            getattr(L, name).argtypes = [ctypes.POINTER(ACSTLSTMDesc)]
+        L.vpx_acstlstm_step_fwd.restype = ci
+        L.vpx_acstlstm_step_fwd.argtypes = [ctypes.POINTER(ACSTLSTMDesc)] + [vp] * 12 + [vp, sz, vp, sz, vp]
+        L.vpx_acstlstm_step_bwd.restype = ci
+        L.vpx_acstlstm_step_bwd.argtypes = [ctypes.POINTER(ACSTLSTMDesc)] + [vp] * 7 + [vp, sz] + [vp] * 12 + [vp, sz, vp]
         for name in ("vpx_trajgru_workspace_bytes", "vpx_trajgru_reserve_bytes"):
             getattr(L, name).restype = sz
             getattr(L, name).argtypes = [ctypes.POINTER(TrajGRUDesc)]

@@ -6,11 +6,10 @@ same return tuple `(h_new, c_new, m_new, delta_c, delta_m)`. The five convolutio
 fused implicit-GEMM launches (csrc/stlstm_api.hip); with layer_norm=True the convolutions are normalised one by one
 (csrc/stlstm_ln_api.hip, csrc/layernorm.hip).
 
-`ActionConditionalSpatioTemporalLSTMCell` (:86-169): its six biased convolutions run on the library's implicit-GEMM kernel
-(`ops.conv2d_same`, forward and backward); the `conv_h(h) * conv_a(a)` product (:144), both gate groups, the state updates
-and the output gate are two HIP kernels with explicit backward (`ops.acst_gates`, `ops.st_out`, csrc/acst.hip) — the
-product of two contractions cannot be folded into one GEMM epilogue, so the convolutions stay separate launches. Only the
-optional LayerNorms (layer_norm=True) still go through `F.layer_norm`."""
+`ActionConditionalSpatioTemporalLSTMCell` (:86-169): the whole step is one library call each way (`ops.acstlstm_step` ->
+`vpx_acstlstm_step_fwd / _bwd`, csrc/acst.hip): its six biased convolutions on the implicit-GEMM kernel, the optional LayerNorms,
+the `conv_h(h) * conv_a(a)` product (:144), both gate groups, the state updates and the output gate (the product of two
+contractions cannot be folded into one GEMM epilogue, so the convolutions stay separate launches inside the call)."""
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -99,19 +98,15 @@ class ActionConditionalSpatioTemporalLSTMCell(VPModelBlock):
         self.conv_o = conv(num_hidden * 2, num_hidden)
         self.conv_last = nn.Conv2d(num_hidden * 2, num_hidden, kernel_size=1, stride=1, padding=0)
 
-    def _conv(self, seq, t):
-        y = ops.conv2d_same(t, seq[0].weight, seq[0].bias, precision=self.precision)
-        if self.layer_norm:
-            y = ops.layer_norm_chw(y, seq[1].weight, seq[1].bias, seq[1].eps)   # library LayerNorm kernels (csrc/layernorm.hip)
-        return y
-
     def forward(self, x_t, h_t, c_t, m_t, a_t):
-        # four biased convolutions (+ LayerNorm), then ONE gate kernel: conv_h(h) * conv_a(a) (predrnn.py:144), both gate
-        # groups, c / m updates, o_pre and mem = (c_new | m_new); conv_o / conv_last on mem; one output-gate kernel
-        x_concat, h_concat = self._conv(self.conv_x, x_t), self._conv(self.conv_h, h_t)
-        a_concat, m_concat = self._conv(self.conv_a, a_t), self._conv(self.conv_m, m_t)
-        c_new, m_new, delta_c, delta_m, o_pre, mem = ops.acst_gates(x_concat, h_concat, a_concat, m_concat, c_t, m_t,
-                                                                    self._forget_bias)
-        lc = ops.conv2d_same(mem, self.conv_last.weight, self.conv_last.bias, precision=self.precision)
-        h_new = ops.st_out(o_pre, self._conv(self.conv_o, mem), lc)
-        return h_new, c_new, m_new, delta_c, delta_m
+        # the whole step — six biased convolutions (+ LayerNorms), conv_h(h) * conv_a(a) (predrnn.py:144), both gate groups, the c / m
+        # updates, conv_o / conv_last on mem = (c_new | m_new), the output gate — is one library call each way (vpx_acstlstm_step_fwd / _bwd)
+        seqs = (self.conv_x, self.conv_h, self.conv_a, self.conv_m, self.conv_o)
+        params = [p for seq in seqs for p in (seq[0].weight, seq[0].bias)] + [self.conv_last.weight, self.conv_last.bias]
+        ln = ()
+        if self.layer_norm:
+            for seq in seqs:
+                if abs(float(seq[1].eps) - 1e-5) > 1e-12:
+                    raise ValueError("the library's LayerNorm kernels use eps = 1e-5 (nn.LayerNorm's default)")
+            ln = [p for seq in seqs for p in (seq[1].weight, seq[1].bias)]
+        return ops.acstlstm_step(x_t, h_t, c_t, m_t, a_t, params, ln, precision=self.precision, forget_bias=self._forget_bias)

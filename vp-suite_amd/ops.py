@@ -1120,72 +1120,69 @@ def layer_norm_chw(x, weight, bias, eps=1e-5):
     return _LayerNormCHWFn.apply(x, weight, bias)
 
 
-class _ACSTGatesFn(torch.autograd.Function):
-    """(c_new, m_new, delta_c, delta_m, o_pre, mem) from the conv outputs of the (action-conditional) ST-LSTM cell
-    (predrnn.py:143-164): conv_h(h) * conv_a(a) product, both gate groups and the state updates in ONE HIP pass,
-    explicit backward (csrc/acst.hip). `ac` may be None (plain ST-LSTM arithmetic on conv outputs)."""
+class _ACSTStepFn(torch.autograd.Function):
+    """(h_new, c_new, m_new, delta_c, delta_m) = action-conditional ST-LSTM cell step (predrnn.py:139-169) in ONE library call each
+    way (vpx_acstlstm_step_fwd / _bwd): six biased convolutions, optional LayerNorms, the conv_h(h) * conv_a(a) product, both gate
+    groups, the state updates and the output gate. `tensors` = the 12 parameters (conv_x, conv_h, conv_a, conv_m, conv_o, conv_last)
+    x (weight, bias), then — with layer_norm — the 10 LayerNorm tensors (x, h, a, m, o) x (weight, bias)."""
 
     @staticmethod
-    def forward(ctx, xc, hc, ac, mc, c, m, forget_bias):
-        _require_gpu(xc, "acst_gates")
-        xs, hs, ms, cs, mm = (to_channels_last(t) for t in (xc, hc, mc, c, m))
-        as_ = None if ac is None else to_channels_last(ac)
-        B, Ch, H, Wd = cs.shape
-        dev = xc.device
+    def forward(ctx, x, h, c, m, a, precision, forget_bias, *tensors):
+        _require_gpu(x, "acstlstm_step")
+        dev = x.device
+        B, Cin, H, Wd = x.shape
+        Ch = h.shape[1]
+        prm = [t.contiguous() for t in tensors[:12]]
+        lnc = [t.contiguous() for t in tensors[12:]]
+        if len(prm) != 12 or len(lnc) not in (0, 10):
+            raise ValueError("acstlstm_step: 12 parameters, then either no or ten LayerNorm tensors")
+        k = int(prm[0].shape[-1])
+        need = any(ctx.needs_input_grad)
+        d = _lib.ACSTLSTMDesc(B, Cin, Ch, H, Wd, k, int(bool(lnc)), precision, _lib.FLAG_SAVE_FOR_BWD if need else 0, float(forget_bias))
+        L = _lib.lib()
+        ws_bytes = L.vpx_acstlstm_workspace_bytes(ctypes.byref(d))
+        if ws_bytes == 0:
+            check(-1, "vpx_acstlstm_workspace_bytes")
+        rs_bytes = L.vpx_acstlstm_reserve_bytes(ctypes.byref(d))
+        xs, hs, cs, ms, as_ = (to_channels_last(t) for t in (x, h, c, m, a))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        reserve = torch.empty(max(rs_bytes, 1), dtype=torch.uint8, device=dev)
         outs = [new_channels_last((B, Ch, H, Wd), dev) for _ in range(5)]
-        mem = new_channels_last((B, 2 * Ch, H, Wd), dev)
-        need = any(ctx.needs_input_grad)
-        save = torch.empty(B * H * Wd * 6 * Ch, device=dev) if need else None
-        check(_lib.lib().vpx_acst_gates_fwd(ptr(xs), ptr(hs), ptr(as_), ptr(ms), ptr(cs), ptr(mm), *[ptr(o) for o in outs], ptr(mem),
-                                            ptr(save), B * H * Wd, Ch, float(forget_bias), _stream()), "vpx_acst_gates_fwd")
+        p_arr = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in prm])
+        ln_arr = (ctypes.c_void_p * 10)(*[t.data_ptr() for t in lnc]) if lnc else None
+        check(L.vpx_acstlstm_step_fwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), ptr(as_), p_arr, ln_arr, *[ptr(o) for o in outs],
+                                      ptr(reserve), rs_bytes, ptr(ws), ws_bytes, _stream()), "vpx_acstlstm_step_fwd")
         if need:
-            ctx.save_for_backward(hs, as_, cs, mm, save)
-        return (*outs, mem)
+            ctx.save_for_backward(xs, hs, cs, ms, as_, reserve, *prm, *lnc)
+            ctx.desc, ctx.rs_bytes = d, rs_bytes
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, d_cn, d_mn, d_dc, d_dm, d_opre, d_mem):
-        hs, as_, cs, mm, save = ctx.saved_tensors
-        B, Ch, H, Wd = cs.shape
-        dev = cs.device
-        g = [None if t is None else to_channels_last(t) for t in (d_cn, d_mn, d_dc, d_dm, d_opre, d_mem)]
-        dxc = new_channels_last((B, 7 * Ch, H, Wd), dev)
-        dhc = new_channels_last((B, 4 * Ch, H, Wd), dev)
-        dac = new_channels_last((B, 4 * Ch, H, Wd), dev) if as_ is not None else None
-        dmc = new_channels_last((B, 3 * Ch, H, Wd), dev)
-        dc, dm = new_channels_last((B, Ch, H, Wd), dev), new_channels_last((B, Ch, H, Wd), dev)
-        check(_lib.lib().vpx_acst_gates_bwd(ptr(hs), ptr(as_), ptr(cs), ptr(mm), ptr(save), *[ptr(t) for t in g], ptr(dxc), ptr(dhc),
-                                            ptr(dac), ptr(dmc), ptr(dc), ptr(dm), B * H * Wd, Ch, _stream()), "vpx_acst_gates_bwd")
-        return dxc, dhc, dac, dmc, dc, dm, None
+    def backward(ctx, dh_new, dc_new, dm_new, ddc, ddm):
+        _sync_determinism()
+        saved = ctx.saved_tensors
+        xs, hs, cs, ms, as_, reserve = saved[:6]
+        prm, lnc = list(saved[6:18]), list(saved[18:])
+        d, dev, L = ctx.desc, xs.device, _lib.lib()
+        gin = [None if g is None else to_channels_last(g) for g in (dh_new, dc_new, dm_new, ddc, ddm)]
+        if gin[0] is None:
+            gin[0] = torch.zeros_like(hs)
+        needs = ctx.needs_input_grad
+        dins = [new_channels_last(tuple(t.shape), dev) if needs[i] else None for i, t in enumerate((xs, hs, cs, ms, as_))]
+        dprm = [torch.empty_like(t) if needs[7 + i] else None for i, t in enumerate(prm)]
+        dln = [torch.empty_like(t) if needs[19 + i] else None for i, t in enumerate(lnc)]
+        p_arr = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in prm])
+        dp_arr = (ctypes.c_void_p * 12)(*[None if t is None else t.data_ptr() for t in dprm])
+        ln_arr = (ctypes.c_void_p * 10)(*[t.data_ptr() for t in lnc]) if lnc else None
+        dln_arr = (ctypes.c_void_p * 10)(*[None if t is None else t.data_ptr() for t in dln]) if lnc else None
+        ws_bytes = L.vpx_acstlstm_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(L.vpx_acstlstm_step_bwd(ctypes.byref(d), ptr(xs), ptr(hs), ptr(cs), ptr(ms), ptr(as_), p_arr, ln_arr, ptr(reserve), ctx.rs_bytes,
+                                      *[ptr(g) for g in gin], *[ptr(t) for t in dins], dp_arr, dln_arr, ptr(ws), ws_bytes, _stream()),
+              "vpx_acstlstm_step_bwd")
+        return (*dins, None, None, *dprm, *dln)
 
 
-def acst_gates(xc, hc, ac, mc, c, m, forget_bias=1.0):
-    return _ACSTGatesFn.apply(xc, hc, ac, mc, c, m, float(forget_bias))
-
-
-class _STOutFn(torch.autograd.Function):
-    """h_new = sigmoid(o_pre + oc) * tanh(lc)  (predrnn.py:166-167), one HIP pass each way."""
-
-    @staticmethod
-    def forward(ctx, o_pre, oc, lc):
-        _require_gpu(o_pre, "st_out")
-        a, b, c = to_channels_last(o_pre), to_channels_last(oc), to_channels_last(lc)
-        h = new_channels_last(tuple(a.shape), a.device)
-        need = any(ctx.needs_input_grad)
-        o_s = torch.empty_like(h) if need else None
-        t_s = torch.empty_like(h) if need else None
-        check(_lib.lib().vpx_st_out_fwd(ptr(a), ptr(b), ptr(c), ptr(h), ptr(o_s), ptr(t_s), a.numel(), _stream()), "vpx_st_out_fwd")
-        if need:
-            ctx.save_for_backward(o_s, t_s)
-        return h
-
-    @staticmethod
-    def backward(ctx, dh):
-        o_s, t_s = ctx.saved_tensors
-        g = torch.empty_like(o_s).copy_(dh) if dh.stride() != o_s.stride() else dh
-        d_o, d_lc = torch.empty_like(o_s), torch.empty_like(o_s)
-        check(_lib.lib().vpx_st_out_bwd(ptr(g), ptr(o_s), ptr(t_s), ptr(d_o), ptr(d_lc), o_s.numel(), _stream()), "vpx_st_out_bwd")
-        return d_o, d_o, d_lc
-
-
-def st_out(o_pre, oc, lc):
-    return _STOutFn.apply(o_pre, oc, lc)
+def acstlstm_step(x, h, c, m, a, params, ln=(), precision="f32", forget_bias=1.0):
+    """One step of the action-conditional ST-LSTM cell; `params`: the 12 convolution tensors, `ln`: () or the 10 LayerNorm tensors."""
+    return _ACSTStepFn.apply(x, h, c, m, a, PRECISIONS[precision], float(forget_bias), *params, *ln)
