@@ -14,6 +14,8 @@
  *                                  ConvLSTMCell.forward (T=1, IFOG)         vp_suite/model_blocks/conv_lstm_ndrplz.py:28-43
  *                                  ConvLSTM(ndrplz) per-layer time loop     vp_suite/model_blocks/conv_lstm_ndrplz.py:112-121
  * vpx_stlstm_step_fwd / _bwd       SpatioTemporalLSTMCell.forward           vp_suite/model_blocks/predrnn.py:57-83
+ * vpx_acstlstm_step_fwd / _bwd     ActionConditionalSpatioTemporalLSTMCell.forward  vp_suite/model_blocks/predrnn.py:139-169
+ * vpx_trajgru_seq_fwd / _bwd       TrajGRU.forward (time loop, warps, gates)        vp_suite/model_blocks/traj_gru.py:164-214
  * vpx_decouple_fwd / _bwd          adapter + normalize + |cos| + mean       vp_suite/models/predrnn_v2.py:197-198,209-211
  * vpx_conv2d_nhwc_fwd / _bwd       F.conv2d 1x1 / kxk "same", stride 1      vp_suite/models/predrnn_v2.py:223 (conv_last)
  * vpx_conv2d_ex_fwd / _bwd         Conv2d / ConvTranspose2d + LeakyReLU     vp_suite/models/precipitation_nowcasting/ef_blocks.py:15-49

@@ -107,6 +107,38 @@ def test_sixteen_column_kernel_vs_first_generation(vpx, tag):
     assert _relmax(y16, y1) < 2e-6, tag
 
 
+@pytest.mark.parametrize("tag", ["deconv3_t1k3_co16", "c16_plain_ci32_ragged", "deconv1_t2k4_small", "deconv2_t2k4"])
+def test_strided_sequence_source_through_the_c_abi(vpx, tag):
+    """vpx_conv2d_ex_fwd_from_split on a source that is a [B][T] sequence with a gap between the samples (x_bstride, x_tstride, x_nT:
+    image n at (n / x_nT) * x_bstride + (n % x_nT) * x_tstride) — what a recurrent block's output slab looks like to the glue. Called
+    through the C ABI (the Python wrapper only hands over dense batches); equal to the dense call bit for bit, on both split-input
+    kernels (conv16.hip, convq.hip)."""
+    import ctypes
+    from vp_suite_amd._lib import ConvDesc
+    N, Ci, Co, H, W, k, s, p, tr, slope = CASES[tag]
+    B, T = 2, 3
+    N = B * T
+    x = seeded_rand((N, Ci, H, W), name_seed(f"convq.seq.{tag}.x")).cuda() - 0.3
+    wshape = (Ci, Co, k, k) if tr else (Co, Ci, k, k)
+    w = (seeded_randn(wshape, name_seed(f"convq.{tag}.w"), 1.0 / np.sqrt(Ci * k * k))).cuda()
+    b = seeded_randn((Co,), name_seed(f"convq.{tag}.b"), 0.1).cuda()
+    xbuf, _ = vpx.ops.split_convert(x)
+    dense, _, shp = vpx.ops.conv2d_ex_from_split(xbuf, (N, Ci, H, W), w, b, s, p, tr, slope, "bf16x3")
+    img = H * W * Ci                                     # floats per image in the split format (same byte count as fp32)
+    slab = torch.full((B, T + 1, img), float("nan"), device="cuda")   # one unused image slot per sample: the gap
+    slab[:, :T] = xbuf.view(B, T, img)
+    L = vpx._lib.lib()
+    d = ConvDesc(N, H, W, Ci, Co, k, k, s, p, int(tr), float(slope), vpx._lib.PREC_BF16X3, 0, 0)
+    ws_bytes = L.vpx_conv2d_ex_split_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    y = torch.empty_like(dense)
+    pv = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = L.vpx_conv2d_ex_fwd_from_split(ctypes.byref(d), pv(slab), (T + 1) * img * 4, img * 4, T, pv(w), pv(b), pv(y), None, 0, pv(ws), ws_bytes,
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, L.vpx_last_error().decode()
+    assert torch.equal(y, dense)
+
+
 def test_split_convert_entry_point_matches_the_torch_restatement(vpx):
     """vpx_split_convert (fp32 channels-last -> operand format) against the same two roundings written with torch ops."""
     x = seeded_randn((3, 40, 19, 23), name_seed("split_convert.x"), 2.0).cuda()
