@@ -176,7 +176,31 @@ def test_glue_data_gradient_on_convq_vs_torch_and_first_generation(vpx):
         assert _relmax(a, b) < 2e-5   # same products, same operand split: fp32 summation order only
 
 
-def _conv2d_ex_cases(vpx, cases, F, n=2, precs=(("f32", 2e-5), ("bf16x3", 5e-5))):
+def test_glue_weight_gradient_on_split_operands_vs_torch_and_tap_group_kernel(vpx):
+    """Round 6: the weight gradient of a stage-glue layer (bf16x3, channel counts in groups of 8) runs per stride residue on wgrad2_kernel's
+    glue form — both operands (x and the LeakyReLU'-scaled dy) once more in the split format, staged by LDS-DMA, sub-image addressing in the
+    copy's source address. The EF model's layers (ef_conv_lstm.py:36-65) and ragged / narrow ones at 24 frames: against torch autograd and
+    against the tap-group kernel on fp32 operands (VPX_OPT_EXPERIMENT bit 29)."""
+    import torch.nn.functional as F
+    cases = [  # (transposed, Ci, Co, k, stride, pad, H, W)
+        (False, 64, 64, 3, 2, 1, 64, 64), (False, 96, 96, 3, 2, 1, 32, 32), (True, 96, 96, 4, 2, 1, 16, 16), (True, 96, 96, 4, 2, 1, 32, 32),
+        (True, 64, 16, 3, 1, 1, 64, 64), (False, 64, 96, 3, 2, 1, 33, 47), (False, 24, 40, 3, 1, 1, 19, 21), (True, 8, 136, 4, 2, 1, 9, 7),
+        (False, 16, 8, 2, 2, 0, 12, 20),
+    ]
+    L = vpx._lib.lib()
+    grads = {}
+    for bit in (0, 1 << 29):
+        prev = L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, bit)
+        try:
+            grads[bit] = []
+            _conv2d_ex_cases(vpx, cases, F, n=24, precs=(("bf16x3", 5e-5),), dws=grads[bit])
+        finally:
+            L.vpx_set_option(vpx._lib.OPT_EXPERIMENT, prev)
+    for a, b in zip(grads[0], grads[1 << 29]):
+        assert _relmax(a, b) < 2e-5   # same products, same operand split: fp32 summation order only
+
+
+def _conv2d_ex_cases(vpx, cases, F, n=2, precs=(("f32", 2e-5), ("bf16x3", 5e-5)), dws=None):
     dxs = []
     for prec, tol in precs:
         for tr, Ci, Co, k, s, p, H, W in cases:
@@ -208,6 +232,8 @@ def _conv2d_ex_cases(vpx, cases, F, n=2, precs=(("f32", 2e-5), ("bf16x3", 5e-5))
                 for a, r in zip(lv, rl):
                     assert _relmax(a.grad, r.grad) < 1e-4, (prec, tag)
                 dxs.append(lv[0].grad.detach().clone())
+                if dws is not None:
+                    dws.append(lv[1].grad.detach().clone())
     return dxs
 
 

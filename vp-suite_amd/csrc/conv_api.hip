@@ -526,8 +526,11 @@ constexpr long long GLUE_SLAB_FLOATS = 4ll << 20;  // K-slice slab budget of the
 // dW[r][c][ky][kx] = sum_{b,y,x} G[b,y,x,r] * A[b, s*y + ky - p, s*x + kx - p, c]   (G: [N,Hg,Wg,Rg], A: [N,Ha,Wa,Ca], NHWC).
 // ky - p = s*a + ry: the taps of one residue (ry, rx) slide over the sub-image A[s*i + ry, s*j + rx] with offsets a —
 // one stride-1 weight-gradient launch per residue on the MFMA kernel, its taps scattered into dW by the reduce.
+// G_sp / A_sp (round 6): both operands once more in the split format — residues with >= 2 taps then run on wgrad2_kernel's glue form
+// (LDS-DMA staging, no conversion work in the loop; wgrad2.hip), `slab_floats` = what `slabs` holds.
 int strided_wgrad(hipStream_t stream, int prec, int N, int Hg, int Wg, const float* G, int Rg, int Ha, int Wa, const float* A,
-                  int Ca, int kh, int kw, int s, int p, float* slabs, float* dW) {
+                  int Ca, int kh, int kw, int s, int p, float* slabs, float* dW, const char* G_sp = nullptr, const char* A_sp = nullptr,
+                  size_t slab_floats = 0) {
     auto fdiv = [](int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); };
     for (int ry = 0; ry < s; ++ry)
         for (int rx = 0; rx < s; ++rx) {
@@ -556,6 +559,12 @@ int strided_wgrad(hipStream_t stream, int prec, int N, int Hg, int Wg, const flo
             long long cap = GLUE_SLAB_FLOATS / per_slice;
             if (cap < 32) cap = 32;
             int ns = wgrad_pick_slices((int)(cap < items ? cap : items), Rg, wa.n_ctiles, taps);
+            WgradArgs wq = wa;
+            wq.g_sp = G_sp; wq.x_sp = A_sp; wq.x_sp_bstride = (long long)Ha * Wa * Ca * 4; wq.a_split = 1;
+            if (G_sp && A_sp && wgrad2g_applicable(wq)) {
+                const long long room = (long long)(slab_floats / (size_t)per_slice);
+                VPX_CHECK_HIP(launch_wgrad2g(wq, (int)(room < 1 ? 1 : (room > 4096 ? 4096 : room)), &ns, stream));
+            } else
             VPX_CHECK_HIP(launch_wgrad(wa, ns, stream));
             if (s == 1) {
                 VPX_CHECK_HIP(launch_wgrad_reduce(slabs, dW, ns, taps, Rg, Ca, stream));
@@ -587,11 +596,27 @@ int ex_adjoint(const vpx_conv_desc* d, const ExGeo& g, vpx_conv_desc& a) {
     return VPX_OK;
 }
 
+// weight gradient on split copies of x and dy (wgrad2_kernel's glue form): bf16x3 on the 16x16x32 shape, channel counts in whole groups of 8
+static bool ex_wgrad_split(const vpx_conv_desc* d) {
+    return !(g_experiment & (1 << 29)) && d->precision == VPX_PREC_BF16X3 && mfma_shape() == 1 && (d->Ci & 7) == 0 && (d->Co & 7) == 0 &&
+           d->kh <= 2 * d->stride + 1 && d->kw <= 2 * d->stride + 1 && d->kh * d->kw > 1 &&
+           !(!d->transposed && wgrad_small_applicable(d->Co, d->Ci, d->kh, d->kw, d->stride, d->pad));
+}
+
 size_t ex_bwd_slab_floats(const vpx_conv_desc* d, const ExGeo& g) {
     // a residue launch uses <= max(32 slices, GLUE_SLAB_FLOATS / slice) slices of <= kh*kw*Ci*Co floats
     (void)g;
     const size_t full = (size_t)32 * d->kh * d->kw * d->Ci * d->Co;
-    return full > (size_t)GLUE_SLAB_FLOATS ? full : (size_t)GLUE_SLAB_FLOATS;
+    size_t b = full > (size_t)GLUE_SLAB_FLOATS ? full : (size_t)GLUE_SLAB_FLOATS;
+    // the glue form of wgrad2_kernel: up to wgrad2_target_wgs() workgroups = that many slices of ONE row x column tile pair
+    // (a residue's slab is at most kh * kw * Ci * Co / stride^2 floats)
+    if (ex_wgrad_split(d)) {
+        const int rows = ((d->transposed ? d->Ci : d->Co) + 127) / 128, cols = ((d->transposed ? d->Co : d->Ci) + 63) / 64;
+        const size_t per = (size_t)((d->kh + d->stride - 1) / d->stride) * ((d->kw + d->stride - 1) / d->stride) * d->Ci * d->Co;
+        const size_t need = (size_t)(wgrad2_target_wgs() / (rows * cols) + 1) * per;
+        if (need > b) b = need;
+    }
+    return b;
 }
 
 }  // namespace
@@ -618,6 +643,7 @@ size_t vpx_conv2d_ex_bwd_workspace_bytes(const vpx_conv_desc* d) {
                align256((size_t)COLSUM_BLOCKS * d->Co * 4) + 1024;
     static thread_local ConvQProblem pr;
     if (ex_bwd_q(d, &a, pr)) b += align256(n_dy * 4) + align256(convq_wpk_bytes(pr));   // dy in the split format + the adjoint's convq pack
+    if (ex_wgrad_split(d)) b += align256(n_dy * 4) + align256((size_t)d->N * d->H * d->W * d->Ci * 4);   // dy and x in the split format
     return b;
 }
 
@@ -642,6 +668,9 @@ int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, co
     const bool dq = dx && ex_bwd_q(d, &a, prq);
     char *dy_sp = nullptr, *wpkq = nullptr;
     if (dq) { dy_sp = (char*)ws.take(n_dy); wpkq = (char*)ws.take(align256(convq_wpk_bytes(prq)) / 4); }
+    const bool wsp = dw && ex_wgrad_split(d);
+    char* x_sp = nullptr;
+    if (wsp) { if (!dy_sp) dy_sp = (char*)ws.take(n_dy); x_sp = (char*)ws.take((size_t)d->N * d->H * d->W * d->Ci); }
     VPX_CHECK_CARVE(ws, "vpx_conv2d_ex_bwd");
     const bool v4 = (d->Co & 3) == 0 && (((uintptr_t)dy | (uintptr_t)y) & 15) == 0;   // (launch_colsum's vector form: the split copy needs it)
     bool have_sp = false;
@@ -650,7 +679,7 @@ int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, co
         // pre-activation for a positive slope) — one pass that also yields the bias gradient
         if (!y) { set_error("vpx_conv2d_ex_bwd: y (forward output) is required when leaky_slope != 0"); return VPX_ERR_ARG; }
         if (d->leaky_slope < 0.0f) { set_error("vpx_conv2d_ex_bwd: negative leaky_slope is not implemented"); return VPX_ERR_UNSUPPORTED; }
-        have_sp = dq && v4;
+        have_sp = (dq || wsp) && v4;
         VPX_CHECK_HIP(launch_colsum(dy, y, d->leaky_slope, dys, db, db_part, (long long)d->N * g.Ho * g.Wo, d->Co, stream, have_sp ? dy_sp : nullptr));
         dy = dys;
     } else if (db) {
@@ -659,7 +688,7 @@ int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, co
     if (dx) {
         ExGeo ga{d->H, d->W};
         if (dq) {
-            if (!have_sp) VPX_CHECK_HIP(launch_split_convert(dy, dy_sp, (long long)d->N * g.Ho * g.Wo, d->Co, stream));
+            if (!have_sp) { VPX_CHECK_HIP(launch_split_convert(dy, dy_sp, (long long)d->N * g.Ho * g.Wo, d->Co, stream)); have_sp = true; }
             if ((rc = ex_forward_q(&a, ga, dy_sp, (long long)g.Ho * g.Wo * d->Co * 4, 0, 1, w, nullptr, dx, nullptr, wpkq, false, stream)) != VPX_OK) return rc;
         } else if ((rc = ex_forward(&a, ga, dy, w, nullptr, dx, wpk, stream)) != VPX_OK) return rc;
     }
@@ -667,10 +696,17 @@ int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, co
         (size_t)WGRAD_SMALL_BLOCKS * d->Co * d->Ci * d->kh * d->kw <= ex_bwd_slab_floats(d, g)) {
         VPX_CHECK_HIP(launch_wgrad_small(dy, x, d->N, d->H, d->W, d->Co, d->Ci, d->kh, d->pad, slabs, dw, stream));
     } else if (dw) {
+        if (wsp) {   // both operands once more in the split format (dy: unless the LeakyReLU' pass or the data gradient already wrote it)
+            if (!have_sp) { VPX_CHECK_HIP(launch_split_convert(dy, dy_sp, (long long)d->N * g.Ho * g.Wo, d->Co, stream)); have_sp = true; }
+            VPX_CHECK_HIP(launch_split_convert(x, x_sp, (long long)d->N * d->H * d->W, d->Ci, stream));
+        }
+        const size_t slab_floats = ex_bwd_slab_floats(d, g);
         if (!d->transposed)  // dW[co][ci][ky][kx] = sum dy[b,oy,ox,co] x[b, s*oy + ky - p, s*ox + kx - p, ci]
-            rc = strided_wgrad(stream, d->precision, d->N, g.Ho, g.Wo, dy, d->Co, d->H, d->W, x, d->Ci, d->kh, d->kw, d->stride, d->pad, slabs, dw);
+            rc = strided_wgrad(stream, d->precision, d->N, g.Ho, g.Wo, dy, d->Co, d->H, d->W, x, d->Ci, d->kh, d->kw, d->stride, d->pad, slabs, dw,
+                               wsp ? dy_sp : nullptr, x_sp, slab_floats);
         else                 // dW[ci][co][ky][kx] = sum x[b,i,j,ci] dy[b, s*i + ky - p, s*j + kx - p, co]
-            rc = strided_wgrad(stream, d->precision, d->N, d->H, d->W, x, d->Ci, g.Ho, g.Wo, dy, d->Co, d->kh, d->kw, d->stride, d->pad, slabs, dw);
+            rc = strided_wgrad(stream, d->precision, d->N, d->H, d->W, x, d->Ci, g.Ho, g.Wo, dy, d->Co, d->kh, d->kw, d->stride, d->pad, slabs, dw,
+                               x_sp, wsp ? dy_sp : nullptr, slab_floats);
         if (rc != VPX_OK) return rc;
     }
     return VPX_OK;

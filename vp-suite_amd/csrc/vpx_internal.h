@@ -496,6 +496,10 @@ static inline int wgrad2_slices(int target, int rows128, int n_ctiles, bool half
 hipError_t launch_wgrad2(const WgradArgs& a, int max_slices, int* used_slices, int* tail_col0, int* tail_slices, hipStream_t s);
 hipError_t launch_wgrad_reduce_tail(const float* slabs, float* dW, int n_slices, int taps, int N4, int Ct, int tail_col0, int tail_slices,
                                     hipStream_t s);
+// wgrad2.hip, glue form: one stride residue of a stage-glue layer's weight gradient with BOTH operands in the split format (g_sp: the
+// contraction-side rows, x_sp: the activation image, a_sub / use_org addressing); slabs [*used_slices][kh * kw][N4][Ct]
+bool wgrad2g_applicable(const WgradArgs& a);
+hipError_t launch_wgrad2g(const WgradArgs& a, int max_slices, int* used_slices, hipStream_t s);
 // st_pointwise.hip: the pointwise stages behind K-split c5 launches (small grids)
 struct STGatesKSArgs {
     long long npix; int Ch, ks; long long pstride; float fbias;

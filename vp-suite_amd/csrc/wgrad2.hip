@@ -68,9 +68,15 @@ __device__ unsigned long long stw_trace[8192 * 4];
 // QF: the same kernel on v_mfma_f32_16x16x32_bf16 (vpx_set_option(VPX_OPT_MFMA_SHAPE, 1)): a K = 32 step is two tile rows of the
 // item, a wave's 64 gate rows x 32 channels x tap group are 4 x 2 accumulator tiles of 16x16 per tap (the same 160 registers),
 // the same fragment bytes per MFMA cycle.
-template <bool QF>
+// GLUE (round 6, QF only): the weight gradient of a stage-glue layer's stride residue (conv_api.hip, strided_wgrad) on the same machinery —
+// kh x kw <= 3 x 3 taps (a 4x4 stride-2 layer's residues have 2 x 2, a 3x3 stride-2 layer's 2 x 2 / 2 x 1 / 1 x 2), the tap (0,0) at
+// (org_y, org_x) instead of (-1,-1), and the activation operand a SUB-IMAGE of a larger one: position (y, x) of the walk reads pixel
+// (a_sy * y + a_oy, a_sx * x + a_ox) of an image a_Wfull pixels wide. All of it is linear in the position, so a copy is still a per-item
+// scalar base + a per-thread offset fixed for the launch. T = 1, x segment only. Row tiles past N4 are skipped (96 rows: 6 of 8 tiles).
+template <bool QF, bool GLUE = false>
 __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
-    constexpr int TA = 5, TB = 4;   // taps of group 0 / group 1
+    static_assert(QF || !GLUE, "the glue form exists on the 16x16x32 shape only");
+    constexpr int TA = 5, TB = 4;   // taps of group 0 / group 1 (GLUE: ceil(ntaps / 2) and the rest, at run time)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, hh = lane >> 5;
@@ -110,7 +116,9 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
     const int ct_id = __builtin_amdgcn_readfirstlane(bx % n_ct);
     const WgradCHalf ch0 = a.ct[ct_id].h[0], ch1 = a.ct[ct_id].h[1];
     const int n0 = __builtin_amdgcn_readfirstlane((bx / n_ct) * 128);
-    const int tap0 = tg ? TA : 0;
+    const int g_kw = GLUE ? a.kw : 3, g_ntaps = GLUE ? a.kh * a.kw : 9, g_ta = GLUE ? (g_ntaps + 1) / 2 : TA;
+    const int tap0 = tg ? g_ta : 0;
+    const int my_nt = tg ? g_ntaps - g_ta : g_ta;   // taps of this wave's group
 
     f32x16 acc[QF ? 1 : 2][QF ? 1 : TA];     // 32x32x16 form: [row block of 32][tap]
     f32x4 accq[QF ? 4 : 1][2][QF ? TA : 1];  // 16x16x32 form: [row tile of 16][channel tile of 16][tap]
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
         const int tp = tap0 + t;
-        const int dy = tp / 3, dx = tp - dy * 3;
+        const int dy = tp / g_kw, dx = tp - dy * g_kw;
         tapoff[t] = (dy * W2_HALO_W + dx) * 128;
     }
 
@@ -201,10 +209,11 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
         const int sl = (w2_swz<QF>(pos * 128 + (qq & 7) * 16) & 127) >> 4;     // logical slot = 8 channels of the 64-channel row
         const int hy = pos / W2_HALO_W, hx = pos - hy * W2_HALO_W;
         const WgradCHalf hf = (sl >> 2) ? ch1 : ch0;
-        const bool ok = piece < W2_APIECES && (sl & 3) * 8 < hf.cn;
+        const bool ok = piece < W2_APIECES && (sl & 3) * 8 < hf.cn && (!GLUE || (hy < W2_TH + a.kh - 1 && hx < 16 + a.kw - 1));
         const unsigned prow_h = (unsigned)(hf.seg == 0 ? a.Cin : a.Ch) * 4u;
         pc_hyx[u] = ok ? ((hy << 16) | hx) : -1;
-        pc_toff[u] = (unsigned)(hy * a.W + hx) * prow_h + (unsigned)(((hf.c0 + (sl & 3) * 8) >> 3) * 32 + plane * 16);
+        pc_toff[u] = (GLUE ? (unsigned)(hy * a.a_sy * a.a_Wfull + hx * a.a_sx) : (unsigned)(hy * a.W + hx)) * prow_h +
+                     (unsigned)(((hf.c0 + (sl & 3) * 8) >> 3) * 32 + plane * 16);
         pc_h1[u] = (sl >> 2) != 0;
     }
     const unsigned prow0 = (unsigned)(ch0.seg == 0 ? a.Cin : a.Ch) * 4u, prow1 = (unsigned)(ch1.seg == 0 ? a.Cin : a.Ch) * 4u;
@@ -233,14 +242,17 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
             else if (it.t > 0) base[h] = a.h_sp + (size_t)(it.t - 1) * a.h_sp_tstride + (size_t)it.b * a.h_sp_bstride;
             else if (a.h0_sp) base[h] = a.h0_sp + (size_t)it.b * a.HW * a.Ch * 4;
         }
-        const long long org = (long long)(y0 - 1) * a.W + (x0 - 1);
+        // halo origin in the operand's own grid (GLUE: the sub-image's), and its pixel index in memory
+        const int oy = GLUE ? y0 + a.org_y : y0 - 1, ox = GLUE ? x0 + a.org_x : x0 - 1;
+        const int lim_y = GLUE ? a.a_Hs : a.H, lim_x = GLUE ? a.a_Ws : a.W;
+        const long long org = GLUE ? (long long)(oy * a.a_sy + a.a_oy) * a.a_Wfull + (ox * a.a_sx + a.a_ox) : (long long)oy * a.W + ox;
         const bool ok0 = base[0] != nullptr, ok1 = base[1] != nullptr;
         const char* const ab0 = ok0 ? base[0] + org * (long long)prow0 : nullptr;
         const char* const ab1 = ok1 ? base[1] + org * (long long)prow1 : nullptr;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int gy = y0 - 1 + (pc_hyx[u] >> 16), gx = x0 - 1 + (pc_hyx[u] & 0xffff);
-            const bool ok = (pc_hyx[u] >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (pc_h1[u] ? ok1 : ok0);
+            const int gy = oy + (pc_hyx[u] >> 16), gx = ox + (pc_hyx[u] & 0xffff);
+            const bool ok = (pc_hyx[u] >= 0) & ((unsigned)gy < (unsigned)lim_y) & ((unsigned)gx < (unsigned)lim_x) & (pc_h1[u] ? ok1 : ok0);
             const char* src = ok ? (pc_h1[u] ? ab1 : ab0) + pc_toff[u] : reinterpret_cast<const char*>(w2_zero16);
             if (512 * u + wave * 64 < W2_APIECES)   // (wave-uniform: 1728 = 27 waves' worth of pieces)
                 w2_dma16(src, buf + W2_A0 + (512 * u + wave * 64) * 16);
@@ -271,6 +283,8 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) acc[nb][T0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[nb], ah[j], acc[nb][T0 + j], 0, 0, 0);
     };
+    // GLUE: 16-row tiles of this wave's 64 rows that lie inside the layer's rows
+    const int rt_lim = GLUE ? (a.N4 - n0 - wn * 64 + 15) / 16 : 4;
     auto multiply = [&](const char* buf) {
         const char* gb = buf + wn * 2 * W2_GPL;
         if constexpr (QF) {
@@ -286,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
                 const int arow = a_lane + s2 * 2 * W2_HALO_W * 128;
 #pragma unroll
                 for (int t = 0; t < TA; ++t) {
-                    if (t == TA - 1 && tg != 0) break;
+                    if (GLUE ? t >= my_nt : (t == TA - 1 && tg != 0)) break;
                     bf16x8 ah[2], al[2];
                     const int aoff = w2_swz<true>(arow + tapoff[t]);
 #pragma unroll
@@ -295,17 +309,23 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
                         al[ct] = w2_frag<1024>(buf + W2_A0 + W2_APL + (aoff ^ (ct * 32)));
                     }
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt)
+                    for (int rt = 0; rt < 4; ++rt) {
+                        if (GLUE && rt >= rt_lim) break;   // (wave-uniform: row tiles past the layer's rows hold zeros)
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) accq[rt][ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gl[rt], ah[ct], accq[rt][ct][t], 0, 0, 0);
+                    }
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt)
+                    for (int rt = 0; rt < 4; ++rt) {
+                        if (GLUE && rt >= rt_lim) break;
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) accq[rt][ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[rt], al[ct], accq[rt][ct][t], 0, 0, 0);
+                    }
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt)
+                    for (int rt = 0; rt < 4; ++rt) {
+                        if (GLUE && rt >= rt_lim) break;
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) accq[rt][ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gh[rt], ah[ct], accq[rt][ct][t], 0, 0, 0);
+                    }
                 }
             }
         } else {
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
         }
     }
     const WgradCHalf oh = wc ? ch1 : ch0;
-    float* slab = a.slabs + (size_t)slice * 9 * a.N4 * a.Ct;
+    float* slab = a.slabs + (size_t)slice * g_ntaps * a.N4 * a.Ct;
     if constexpr (QF) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
@@ -401,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void wgrad2_kernel(const WgradArgs a) {
                 const bool col_ok = cw < oh.cn;
 #pragma unroll
                 for (int t = 0; t < TA; ++t) {
-                    if (tg == 1 && t >= TB) break;
+                    if (GLUE ? t >= my_nt : (tg == 1 && t >= TB)) break;
                     float* st = slab + (size_t)(tap0 + t) * a.N4 * a.Ct;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -479,6 +499,53 @@ hipError_t launch_wgrad2(const WgradArgs& a_in, int max_slices, int* used_slices
     if (!ws_write_ok(a.slabs, (size_t)ns * 9 * a.N4 * a.Ct * sizeof(float), "weight-gradient slabs (wgrad2_kernel)")) return hipErrorInvalidValue;
     if (mfma_shape() == 1) VPX_LAUNCH(wgrad2_kernel<true>, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
     else VPX_LAUNCH(wgrad2_kernel<false>, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
+    return vpx_hip_last_error();
+}
+
+// ---- glue form (wgrad2_kernel<true, true>): one stride residue of a stage-glue layer's weight gradient, both operands pre-split ----
+bool wgrad2g_applicable(const WgradArgs& a) {
+    if (g_experiment & (1 << 29)) return false;   // VPX_OPT_EXPERIMENT bit 29: the tap-group kernel on fp32 operands (A/B runs, tests)
+    if (mfma_shape() != 1 || a.prec != VPX_PREC_BF16X3 || !a.g_sp || !a.x_sp || a.T != 1) return false;
+    const int taps = a.kh * a.kw;
+    if (taps < 2 || a.kh > 3 || a.kw > 3) return false;
+    if (a.blk || (a.n_out && a.n_out != a.N4) || (a.N4 & 7) || (a.Cin & 7) || a.Ct != a.Cin) return false;
+    for (int c = 0; c < a.n_ctiles; ++c)
+        for (int h = 0; h < 2; ++h) if (a.ct[c].h[h].cn && a.ct[c].h[h].seg != 0) return false;
+    // 32-bit per-thread offsets: a halo position's byte offset inside the operand image
+    const long long span = ((long long)(W2_TH + 2) * (a.a_sub ? a.a_sy : 1) * (a.a_sub ? a.a_Wfull : a.W) + 18ll * (a.a_sub ? a.a_sx : 1)) * a.Cin * 4;
+    if (span >= (1ll << 31) || (long long)a.HW * a.N4 * 4 >= (1ll << 31)) return false;
+    const long long items = (long long)a.B * ((a.W + 15) / 16) * ((a.H + W2_TH - 1) / W2_TH);
+    return items + 4096 < (1ll << 31);
+}
+
+// slabs [used_slices][kh * kw][N4][Ct]; every column tile on the same slices (the caller's reduce maps taps, it has no tail form)
+hipError_t launch_wgrad2g(const WgradArgs& a_in, int max_slices, int* used_slices, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = vpx_func_attr(reinterpret_cast<const void*>(&wgrad2_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS);
+        if (e != hipSuccess) return e;
+        attr_set = !g_dry_run;
+    }
+    WgradArgs a = a_in;
+    if (!a.a_sub) {   // plain stride-1 layer: the "sub-image" is the image
+        a.a_sy = a.a_sx = 1; a.a_oy = a.a_ox = 0; a.a_Hs = a.H; a.a_Ws = a.W; a.a_Wfull = a.W;
+        if (!a.use_org) { a.org_y = -(a.kh / 2); a.org_x = -(a.kw / 2); }
+    }
+    const int rows = (a.N4 + 127) / 128;
+    a.grid_x = rows * a.n_ctiles;
+    const bool half_tail = a.ct[a.n_ctiles - 1].h[1].cn == 0;
+    a.w2_nh = half_tail ? rows : 0;
+    int ns = wgrad2_target_wgs() / a.grid_x;
+    if (ns > max_slices) ns = max_slices;
+    const long long items = (long long)a.B * ((a.W + 15) / 16) * ((a.H + W2_TH - 1) / W2_TH);
+    if (ns > items) ns = (int)items;
+    if (ns < 1) ns = 1;
+    a.grid_slices = ns;
+    a.w2_ns_half = half_tail ? ns : 0;
+    *used_slices = ns;
+    const long long total = (long long)a.grid_x * ns;
+    if (!ws_write_ok(a.slabs, (size_t)ns * a.kh * a.kw * a.N4 * a.Ct * sizeof(float), "weight-gradient slabs (wgrad2_kernel, glue form)")) return hipErrorInvalidValue;
+    VPX_LAUNCH((wgrad2_kernel<true, true>), dim3((unsigned)(8 * ((total + 7) / 8))), dim3(512), W2_LDS, s, a);
     return vpx_hip_last_error();
 }
 
