@@ -117,7 +117,8 @@ int vpx_set_deterministic(int on);
  *                        ConvLSTM step on the eight-wave half tile (cell2_kernel_x: 64-register wave tiles, four waves per SIMD) instead of the
  *                        four-wave one, 65536 its column split instead of the row split; 1 << 27 the ST-LSTM step's conv_last (1x1) on the fp32 c_new / m_new (converted in the
  *                        kernel) instead of on the split copies its gate stage leaves; 1 << 28 3x3 layers with 16 output channels on the
- *                        first-generation kernel instead of the resident-weights one (csrc/conv16.hip) */
+ *                        first-generation kernel instead of the resident-weights one (csrc/conv16.hip); 1 << 29 the stage glue's weight
+ *                        gradients on the tap-group kernel (fp32 operands) instead of wgrad2_kernel's glue form on split copies */
 #define VPX_OPT_EXPERIMENT 4
 /*   VPX_OPT_DRY_RUN      1 = every entry point does all of its host-side work (argument checks, kernel selection, workspace carving
  *                        and the bounds checks of everything it would write into the workspace) but issues no HIP call: needs no GPU
@@ -304,6 +305,13 @@ int vpx_conv2d_ex_fwd_from_split(const vpx_conv_desc* d, const void* x_split, lo
 size_t vpx_conv2d_ex_bwd_workspace_bytes(const vpx_conv_desc* d);
 int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, const float* y, const float* dy, float* dx,
                       float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+/* Round 6: with bf16x3 operands and channel counts in groups of 8 (vpx_conv2d_ex_bwd_uses_split(d) != 0) the weight gradient runs
+ * per stride residue on split copies of x and dy (csrc/wgrad2.hip, glue form). _bwd converts x itself; a caller that ran the forward
+ * through vpx_conv2d_ex_fwd_from_split hands that x_split [N,H,W,Ci] back to _bwd_ex and saves the pass (x stays required: residues of a
+ * single tap and the other operand modes read it). x_split == NULL: exactly vpx_conv2d_ex_bwd. */
+int vpx_conv2d_ex_bwd_uses_split(const vpx_conv_desc* d);
+int vpx_conv2d_ex_bwd_ex(const vpx_conv_desc* d, const float* x, const void* x_split, const float* w, const float* y, const float* dy,
+                         float* dx, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
 /* y = act(conv(x, w) + bias [+ y]): the stride-1 "same" convolution of vpx_conv2d_nhwc_fwd with an optional accumulate
  * into the destination (two convolutions summed into one output) and LeakyReLU (slope >= 0, 0 = none) applied to the sum.

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "vpx_conv2d_workspace_bytes", "vpx_conv2d_nhwc_fwd", "vpx_conv2d_bwd_workspace_bytes", "vpx_conv2d_nhwc_bwd",
     "vpx_conv2d_ex_out_shape", "vpx_conv2d_ex_workspace_bytes", "vpx_conv2d_ex_fwd", "vpx_conv2d_ex_fwd_split",
     "vpx_conv2d_ex_takes_split", "vpx_split_convert", "vpx_conv2d_ex_split_workspace_bytes", "vpx_conv2d_ex_fwd_from_split",
-    "vpx_conv2d_ex_bwd_workspace_bytes", "vpx_conv2d_ex_bwd",
+    "vpx_conv2d_ex_bwd_workspace_bytes", "vpx_conv2d_ex_bwd", "vpx_conv2d_ex_bwd_uses_split", "vpx_conv2d_ex_bwd_ex",
     "vpx_conv2d_nhwc_fwd_ex",
     "vpx_acstlstm_workspace_bytes", "vpx_acstlstm_reserve_bytes", "vpx_acstlstm_step_fwd", "vpx_acstlstm_step_bwd",
     "vpx_trajgru_workspace_bytes", "vpx_trajgru_reserve_bytes", "vpx_trajgru_seq_fwd", "vpx_trajgru_seq_bwd",
@@ -164,6 +164,10 @@ def lib():
         L.vpx_conv2d_ex_bwd_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
         L.vpx_conv2d_ex_bwd.restype = ctypes.c_int
         L.vpx_conv2d_ex_bwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7 + [vp, sz, vp]
+        L.vpx_conv2d_ex_bwd_uses_split.restype = ctypes.c_int
+        L.vpx_conv2d_ex_bwd_uses_split.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.vpx_conv2d_ex_bwd_ex.restype = ctypes.c_int
+        L.vpx_conv2d_ex_bwd_ex.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 8 + [vp, sz, vp]
         ll, fl, ci = ctypes.c_longlong, ctypes.c_float, ctypes.c_int
         L.vpx_conv2d_nhwc_fwd_ex.restype = ci
         L.vpx_conv2d_nhwc_fwd_ex.argtypes = [vp] * 4 + [ci] * 9 + [fl, vp, sz, vp]

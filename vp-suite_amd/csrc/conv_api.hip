@@ -647,8 +647,19 @@ size_t vpx_conv2d_ex_bwd_workspace_bytes(const vpx_conv_desc* d) {
     return b;
 }
 
+int vpx_conv2d_ex_bwd_uses_split(const vpx_conv_desc* d) {
+    ExGeo g;
+    if (!d || ex_check(d, g) != VPX_OK) return 0;
+    return ex_wgrad_split(d) ? 1 : 0;
+}
+
 int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, const float* y, const float* dy, float* dx,
                       float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream_) {
+    return vpx_conv2d_ex_bwd_ex(d, x, nullptr, w, y, dy, dx, dw, db, workspace, workspace_bytes, stream_);
+}
+
+int vpx_conv2d_ex_bwd_ex(const vpx_conv_desc* d, const float* x, const void* x_split, const float* w, const float* y, const float* dy, float* dx,
+                         float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream_) {
     ExGeo g;
     int rc = ex_check(d, g);
     if (rc != VPX_OK) return rc;
@@ -698,7 +709,8 @@ int vpx_conv2d_ex_bwd(const vpx_conv_desc* d, const float* x, const float* w, co
     } else if (dw) {
         if (wsp) {   // both operands once more in the split format (dy: unless the LeakyReLU' pass or the data gradient already wrote it)
             if (!have_sp) { VPX_CHECK_HIP(launch_split_convert(dy, dy_sp, (long long)d->N * g.Ho * g.Wo, d->Co, stream)); have_sp = true; }
-            VPX_CHECK_HIP(launch_split_convert(x, x_sp, (long long)d->N * d->H * d->W, d->Ci, stream));
+            if (x_split) x_sp = reinterpret_cast<char*>(const_cast<void*>(x_split));   // the caller kept the forward's copy
+            else VPX_CHECK_HIP(launch_split_convert(x, x_sp, (long long)d->N * d->H * d->W, d->Ci, stream));
         }
         const size_t slab_floats = ex_bwd_slab_floats(d, g);
         if (!d->transposed)  // dW[co][ci][ky][kx] = sum dy[b,oy,ox,co] x[b, s*oy + ky - p, s*ox + kx - p, ci]

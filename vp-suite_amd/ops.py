@@ -434,11 +434,24 @@ class _ConvExFn(torch.autograd.Function):
         L = _lib.lib()
         ho, wo = ctypes.c_int(0), ctypes.c_int(0)
         check(L.vpx_conv2d_ex_out_shape(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "vpx_conv2d_ex_out_shape")
-        ws_bytes = L.vpx_conv2d_ex_workspace_bytes(ctypes.byref(d))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         y = new_channels_last((N, Co, ho.value, wo.value), x.device)
-        check(L.vpx_conv2d_ex_fwd(ctypes.byref(d), ptr(xs), ptr(wc), ptr(bc), ptr(y), ptr(ws), ws_bytes, _stream()),
-              "vpx_conv2d_ex_fwd")
+        x_sp = None
+        if (ctx.needs_input_grad[1] and tuple(out_pad) == (0, 0) and L.vpx_conv2d_ex_bwd_uses_split(ctypes.byref(d))
+                and L.vpx_conv2d_ex_takes_split(ctypes.byref(d))):
+            # a training call whose weight gradient will want x in the split operand format anyway (wgrad2.hip, glue form): convert once,
+            # run the forward on the split-input kernels (convq / c16 / first generation without its in-kernel conversion) and keep the copy
+            x_sp = torch.empty(xs.numel(), dtype=torch.float32, device=x.device)
+            check(L.vpx_split_convert(ptr(xs), ptr(x_sp), N * H * Wd, Ci, _stream()), "vpx_split_convert")
+            ws_bytes = L.vpx_conv2d_ex_split_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            check(L.vpx_conv2d_ex_fwd_from_split(ctypes.byref(d), ptr(x_sp), 0, 0, 1, ptr(wc), ptr(bc), ptr(y), None, 0, ptr(ws), ws_bytes,
+                                                 _stream()), "vpx_conv2d_ex_fwd_from_split")
+        else:
+            ws_bytes = L.vpx_conv2d_ex_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            check(L.vpx_conv2d_ex_fwd(ctypes.byref(d), ptr(xs), ptr(wc), ptr(bc), ptr(y), ptr(ws), ws_bytes, _stream()),
+                  "vpx_conv2d_ex_fwd")
+        ctx.x_sp = x_sp
         ctx.save_for_backward(xs, wc, y)
         ctx.cfg = (int(stride), int(padding), bool(transposed), float(slope), bias is not None)
         ctx.desc = d
@@ -463,8 +476,9 @@ class _ConvExFn(torch.autograd.Function):
             dx = new_channels_last(tuple(xs.shape), dy.device) if mask[0] else None
             dw = torch.empty_like(wc) if mask[1] else None
             db = torch.empty(d.Co, device=dy.device) if mask[2] else None
-            check(L.vpx_conv2d_ex_bwd(ctypes.byref(d), ptr(xs), ptr(wc), ptr(y), ptr(dyc), ptr(dx), ptr(dw), ptr(db), ptr(ws),
-                                      ws_bytes, _stream()), "vpx_conv2d_ex_bwd")
+            check(L.vpx_conv2d_ex_bwd_ex(ctypes.byref(d), ptr(xs), ptr(ctx.x_sp), ptr(wc), ptr(y), ptr(dyc), ptr(dx), ptr(dw), ptr(db), ptr(ws),
+                                         ws_bytes, _stream()), "vpx_conv2d_ex_bwd")
+            ctx.x_sp = None
             return dx, dw, db, None, None, None, None, None, None
         # No second backend in the product path: a layer the library's glue backward does not implement fails loudly.
         raise _lib.VpxError(f"conv2d_ex backward: layer (k={d.kh}x{d.kw}, stride={stride}, transposed={bool(transposed)}, slope={slope}) "
