@@ -224,7 +224,7 @@ GLUE = [  # (Ci, Co, k, stride, pad, transposed)
 @pytest.mark.parametrize("det", [0, 1])
 def test_stage_glue(L, det):
     L.vpx_set_deterministic(det)
-    for (Ci, Co, k, s, p, tr), (N, H, W), prec, slope, exp in itertools.product(GLUE, GEOS + [(1280, 16, 16), (40, 64, 64)], (0, 1, 2), (0.0, 0.2), (0, 16)):
+    for (Ci, Co, k, s, p, tr), (N, H, W), prec, slope, exp in itertools.product(GLUE, GEOS + [(1280, 16, 16), (40, 64, 64)], (0, 1, 2), (0.0, 0.2), (0, 16, 1 << 29)):
         if N * H * W * max(Ci, Co) > 1 << 31 or (exp and prec != 1):
             continue
         prev = L.vpx_set_option(_lib.OPT_EXPERIMENT, exp)
@@ -250,6 +250,13 @@ def test_stage_glue(L, det):
             if nbb:
                 rc = L.vpx_conv2d_ex_bwd(ctypes.byref(d), _fake(1), _fake(2), _fake(4), _fake(6), _fake(7), _fake(8), _fake(9), ctypes.c_void_p(WS_BASE_ODD), nbb, None)
                 _ok(L, rc, tag + " bwd")
+                if L.vpx_conv2d_ex_bwd_uses_split(ctypes.byref(d)):   # the weight gradient on split operands, the forward's copy of x handed back
+                    rc = L.vpx_conv2d_ex_bwd_ex(ctypes.byref(d), _fake(1), _fake(10), _fake(2), _fake(4), _fake(6), _fake(7), _fake(8), _fake(9),
+                                                ctypes.c_void_p(WS_BASE), nbb, None)
+                    _ok(L, rc, tag + " bwd_ex")
+                    rc = L.vpx_conv2d_ex_bwd_ex(ctypes.byref(d), _fake(1), _fake(10), _fake(2), _fake(4), _fake(6), None, _fake(8), None,
+                                                ctypes.c_void_p(WS_BASE_ODD), nbb, None)
+                    _ok(L, rc, tag + " bwd_ex (dw only)")
         finally:
             L.vpx_set_option(_lib.OPT_EXPERIMENT, prev)
 
