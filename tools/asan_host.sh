@@ -2,7 +2,7 @@
 # Host-side AddressSanitizer + UBSan build of libvpx_hip (device code un-instrumented: GPU ASan is not available on this pool) and a run of
 # every CPU test that drives the library's host code — tests/test_workspace_contract.py (the dry-run sweep over every entry point: all
 # kernel selection, planning, carving and bounds-check paths) and tests/test_host_logic.py. CPU only; objects and the .so go to /tmp/asan.
-# Round 5: 43 passed, no sanitizer report.
+# Round 5: 43 passed, no sanitizer report. Round 6 (final tree, with the acstlstm / bwd_ex / c16 entry points in the sweep): 48 passed, none.
 set -e
 OUT=${VPX_ASAN_DIR:-/tmp/asan}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
